@@ -1,0 +1,128 @@
+/*
+ * include/lpd_hip.h -- C-ABI of liblpd_hip.so, the MI355X (gfx950) kernels of the LPD-Net
+ * global-descriptor hot path.
+ *
+ * The reference (qiaozhijian/LPD-Net-Pytorch) is pure Python and has no FFI layer of its own; the
+ * drop-in boundary is its Python module API (util.PointNetVlad / util.lpdnet_model /
+ * loss.pointnetvlad_loss), mirrored by lpd-net-pytorch_amd/.  This header is the boundary UNDER
+ * that mirror: each entry point names the reference lines it replaces.  A maintainer binds it with
+ * ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C: device pointers, ints, floats; no torch types, no exceptions.
+ *   - the caller owns every buffer (inputs, outputs, workspaces); nothing here allocates.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream); nothing synchronises.
+ *   - return 0 on success, <0 on error (LPD_ERR_*); lpd_last_error() gives the text
+ *     (thread-local).  No global mutable state => callable concurrently from several host
+ *     threads (nn.DataParallel-style callers) on different streams/devices.
+ *   - all tensors fp32 unless noted; "point-major" = [rows = B*N points][channels], row-major;
+ *     "channel-major" = the reference's [B][C][N].
+ *   - activation codes: 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 sigmoid.
+ */
+#ifndef LPD_HIP_H
+#define LPD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPD_OK 0
+#define LPD_ERR_ARG (-1)
+#define LPD_ERR_LAUNCH (-2)
+#define LPD_ERR_UNSUPPORTED (-3)
+
+#define LPD_ACT_NONE 0
+#define LPD_ACT_RELU 1
+#define LPD_ACT_LEAKY 2
+#define LPD_ACT_SIGMOID 3
+
+int lpd_version(void);
+const char* lpd_last_error(void);
+
+/*
+ * kNN graph construction.  Replaces util/lpdnet_model.py:317-326 `knn(x, k)`.
+ *   x      [B][C][N] channel-major (exactly the reference's argument layout)
+ *   idx    [B][N][k] int32, the k largest pd = -|x_i - x_j|^2 (reference arithmetic order, see
+ *          csrc/lpd_knn.hip), descending; self is included; ties -> lower index first.
+ *   xx_ws  workspace [B][N] floats (per-point sum of squares)
+ *   impl   0 = f32-MFMA distance tiles (product path); 1 = VALU fmaf cross-check (k <= 20)
+ * Supported: C <= 256, k <= 64, k <= N.  Bit-exact vs the reference CPU path on tie-free rows.
+ */
+int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* xx_ws, int impl, void* stream);
+
+/*
+ * Dense fp32 GEMM with fused epilogue:  C = act((A.B + bias) * scale + shift), per output column.
+ * Replaces the 1x1 Conv1d/Conv2d + eval BatchNorm + activation stacks
+ * (util/lpdnet_model.py:231-232,262,297-305; util/PointNetVlad.py:152-175,213-230), the NetVLAD
+ * matmuls (PointNetVlad.py:48,66,76) and the gating matmul (PointNetVlad.py:104).
+ *   A logical [M][K]: a_kmajor = 0 -> stored [M][lda]; 1 -> stored [K][lda] (i.e. A^T in memory)
+ *   B logical [K][N]: b_kmajor = 1 -> stored [K][ldb]; 0 -> stored [N][ldb] (torch conv weight)
+ *   batch > 1: strides sA/sB/sC in elements between problems
+ *   splits > 1: split-K; splitk_ws must hold batch*splits*M*N floats; epilogue applied after the sum
+ *   bias/scale/shift: [N] or NULL (scale and shift together)
+ * Requires K % (32*splits) == 0, lda/ldb/sA/sB % 4 == 0, A and B 16-byte aligned.
+ */
+int lpd_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+             int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC, int splits,
+             float* splitk_ws, const float* bias, const float* scale, const float* shift, int act, float slope,
+             void* stream);
+
+/*
+ * kNN-graph aggregation (K-agg).  Replaces the gather/repeat/cat of util/lpdnet_model.py:331-363
+ * fused with a split edge convolution + BatchNorm + activation + max over k
+ * (lpdnet_model.py:249-250 convDG1/x1, :257-258 convSN1/x3):
+ *   out[m][c] = act(scale[c] * (sel_t P[cloud(m)*N + idx[m][t]][c] + Q[m][c]) + shift[c])
+ *   sel = max over the k neighbours where scale[c] >= 0, min where scale[c] < 0.
+ *   P [M][ldp], Q [M][ldq] or NULL, idx [M][k] (indices local to the cloud), out [M][ldo].
+ * C in {64,128,256}; M = B*N; leading dims % 4 == 0; pointers 16-byte aligned.
+ */
+int lpd_edge_gather_max(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, float* out, int ldo,
+                        const float* scale, const float* shift, int M, int N, int C, int k, int act, float slope,
+                        void* stream);
+
+/*
+ * Fused per-edge MLP: stage-1 BatchNorm+activation on the fly, stage-2 1x1 conv on the f32 MFMA,
+ * BatchNorm + activation + max over k.  Replaces util/lpdnet_model.py:251-252 (convDG2 applied to
+ * the un-maxed convDG1 output, then max) and the LPDNetOrign chains lpdnet_model.py:97-100,105-107:
+ *   y1[m][t][:] = act(s1 * (P[nbr(m,t)] + Q[m]) + b1)            (never materialised)
+ *   out[m][o]   = act(s2[o] * sel_t (W2 y1[m][t])[o] + b2[o])
+ *   W2 [CO][CM] torch [out,in] layout.  (CM,CO) in {(128,128),(64,64)}; k <= 128.
+ */
+int lpd_edge_mlp(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
+                 const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo, int M,
+                 int N, int CM, int CO, int k, int act, float slope, void* stream);
+
+/* Per-point linear layer with K <= 8 inputs (+bias, affine, activation): the 3 -> 64 first layers
+ * (util/lpdnet_model.py:185,231; util/PointNetVlad.py:190,213; T-Net conv1 lpdnet_model.py:276). W [N][K]. */
+int lpd_linear_smallk(const float* X, int ldx, const float* W, float* Y, int ldy, int M, int N, int K,
+                      const float* bias, const float* scale, const float* shift, int act, float slope, void* stream);
+
+/* Batched transpose in [batch][R][C] -> out [batch][C][R] (point-major <-> channel-major). */
+int lpd_transpose(const float* in, float* out, int batch, int R, int C, int ldi, int ldo, long long si,
+                  long long so, void* stream);
+
+/* NetVLAD soft-assignment: out[r][:] = softmax(scale * in[r][:] + shift), ncols <= 64
+ * (util/PointNetVlad.py:51-58, eval-mode bn1 folded into scale/shift). In-place allowed. */
+int lpd_softmax_affine(const float* in, float* out, int rows, int ncols, const float* scale, const float* shift,
+                       void* stream);
+
+/* NetVLAD residual + normalisations (util/PointNetVlad.py:61-74).
+ *   vraw [B][F][KC] = act^T x per cloud, act [B][N][KC], cw2 [F][KC] (cluster_weights2[0]),
+ *   out [B][F*KC]: (vraw - a_sum*cw2), L2-normalised over F per cluster, flattened f*KC+c, L2-normalised. KC = 64. */
+int lpd_vlad_finalize(const float* vraw, const float* act, const float* cw2, float* out, int B, int N, int F, int KC,
+                      void* stream);
+
+/* Per-cloud max over the N points: in [B][N][ldi] -> out [B][C]
+ * (util/PointNetVlad.py:137,162 mp1; util/lpdnet_model.py:300). */
+int lpd_colmax(const float* in, int ldi, float* out, int B, int N, int C, void* stream);
+
+/* out = a * b elementwise (context gating product, util/PointNetVlad.py:113). */
+int lpd_mul(const float* a, const float* b, float* out, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPD_HIP_H */

@@ -1,0 +1,244 @@
+// lpd_misc.hip -- the small bandwidth-bound pieces around the MFMA kernels.
+//
+//   lpd_linear_smallk   per-point linear layer with K <= 8 inputs (the 3 -> 64 first layers:
+//                       util/lpdnet_model.py:185,231 conv1_lpd; util/PointNetVlad.py:190,213 conv1
+//                       Conv2d(1,64,(1,3)); T-Net conv1 lpdnet_model.py:276) + affine + activation
+//   lpd_transpose       batched [R][C] -> [C][R] (point-major <-> the reference's channel-major
+//                       [B,C,N] layout that `knn` consumes, lpdnet_model.py:212,317)
+//   lpd_softmax_affine  NetVLAD soft-assignment: softmax_c(scale_c * a_c + shift_c)
+//                       (util/PointNetVlad.py:51-58: bn1 over B*N rows, then softmax over clusters)
+//   lpd_vlad_finalize   a = a_sum * cluster_weights2; vlad - a; intra-normalise per cluster over the
+//                       feature axis; flatten f*K+c; L2 normalise  (PointNetVlad.py:61-74)
+//   lpd_colmax          per-cloud column max over the N points (MaxPool2d((num_points,1)) of STN3d
+//                       PointNetVlad.py:137,162 and torch.max(x, 2) of TranformNet lpdnet_model.py:300)
+//   lpd_mul             context gating product x * gates (PointNetVlad.py:113)
+#include "lpd_common.h"
+#include <math.h>
+
+namespace {
+
+__global__ void linear_smallk_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W,  // [N][K]
+                                     float* __restrict__ Y, int ldy, int M, int N, int K, const float* bias,
+                                     const float* scale, const float* shift, int act, float slope)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)M * N) return;
+    const int m = (int)(e / N), n = (int)(e - (long long)m * N);
+    const float* x = X + (size_t)m * ldx;
+    const float* w = W + (size_t)n * K;
+    float v = 0.0f;
+    for (int c = 0; c < K; ++c) v = fmaf(x[c], w[c], v);
+    if (bias) v += bias[n];
+    if (scale) v = v * scale[n] + shift[n];
+    Y[(size_t)m * ldy + n] = lpd_act(v, act, slope);
+}
+
+// in [batch][R][C] (row stride ldi) -> out [batch][C][R] (row stride ldo)
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C, int ldi, int ldo,
+                                 long long si, long long so)
+{
+    __shared__ float tile[32][33];
+    const float* src = in + (long long)blockIdx.z * si;
+    float* dst = out + (long long)blockIdx.z * so;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[(size_t)r * ldi + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) dst[(size_t)c * ldo + r] = tile[tx][i];
+    }
+}
+
+// one wavefront per row; ncols <= 64
+__global__ void softmax_affine_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int ncols,
+                                      const float* scale, const float* shift)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v = -INFINITY;
+    if (lane < ncols) {
+        v = in[(size_t)row * ncols + lane];
+        if (scale) v = v * scale[lane] + shift[lane];
+    }
+    float mx = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float e = lane < ncols ? expf(v - mx) : 0.0f;
+    float s = e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane < ncols) out[(size_t)row * ncols + lane] = e / s;
+}
+
+// block reduce helper (sum) over 256 threads
+__device__ __forceinline__ float block_sum_256(float v, float* red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// one block (256 threads) per cloud.  vraw [B][F][KC] (index f*KC + c), act [B][N][KC].
+template <int KC>
+__global__ __launch_bounds__(256) void vlad_finalize_kernel(const float* __restrict__ vraw, const float* __restrict__ act,
+                                                            const float* __restrict__ cw2,  // [F][KC]
+                                                            float* __restrict__ out,        // [B][F*KC]
+                                                            int N, int F)
+{
+    __shared__ float s_part[256];
+    __shared__ float s_asum[KC];
+    __shared__ float s_inv[KC];
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    constexpr int RPB = 256 / KC;  // row groups
+    const int c = tid % KC, rg = tid / KC;
+    // a_sum[c] = sum_n act[n][c]
+    {
+        const float* a = act + (size_t)b * N * KC;
+        float s = 0.0f;
+        for (int n = rg; n < N; n += RPB) s += a[(size_t)n * KC + c];
+        s_part[tid] = s;
+        __syncthreads();
+        if (tid < KC) {
+            float t = 0.0f;
+            for (int r = 0; r < RPB; ++r) t += s_part[r * KC + tid];
+            s_asum[tid] = t;
+        }
+        __syncthreads();
+    }
+    // residual + per-cluster squared norm over f
+    const float* v = vraw + (size_t)b * F * KC;
+    float* o = out + (size_t)b * F * KC;
+    const float as = s_asum[c];
+    float ss = 0.0f;
+    for (int f = rg; f < F; f += RPB) {
+        float r = v[(size_t)f * KC + c] - as * cw2[(size_t)f * KC + c];
+        o[(size_t)f * KC + c] = r;
+        ss += r * r;
+    }
+    __syncthreads();
+    s_part[tid] = ss;
+    __syncthreads();
+    if (tid < KC) {
+        float t = 0.0f;
+        for (int r = 0; r < RPB; ++r) t += s_part[r * KC + tid];
+        s_inv[tid] = 1.0f / fmaxf(sqrtf(t), 1e-12f);  // F.normalize eps
+    }
+    __syncthreads();
+    const float inv = s_inv[c];
+    float tot = 0.0f;
+    for (int f = rg; f < F; f += RPB) {
+        float r = o[(size_t)f * KC + c] * inv;
+        o[(size_t)f * KC + c] = r;
+        tot += r * r;
+    }
+    float total = block_sum_256(tot, red);
+    const float ginv = 1.0f / fmaxf(sqrtf(total), 1e-12f);
+    for (int f = rg; f < F; f += RPB) o[(size_t)f * KC + c] *= ginv;
+}
+
+// per-cloud column max: in [B][N][C] -> out [B][C].  grid (ceil(C/64), B), 256 threads = 4 row groups x 64 cols
+__global__ __launch_bounds__(256) void colmax_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int N, int C)
+{
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rg = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    float m = -INFINITY;
+    if (c < C) {
+        const float* p = in + (size_t)b * N * ldi + c;
+        for (int n = rg; n < N; n += 4) m = fmaxf(m, p[(size_t)n * ldi]);
+    }
+    part[rg][threadIdx.x & 63] = m;
+    __syncthreads();
+    if (rg == 0 && c < C) out[(size_t)b * C + c] = fmaxf(fmaxf(part[0][threadIdx.x], part[1][threadIdx.x]),
+                                                         fmaxf(part[2][threadIdx.x], part[3][threadIdx.x]));
+}
+
+__global__ void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, long long n)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] * b[i];
+}
+
+}  // namespace
+
+extern "C" int lpd_linear_smallk(const float* X, int ldx, const float* W, float* Y, int ldy, int M, int N, int K,
+                                 const float* bias, const float* scale, const float* shift, int act, float slope,
+                                 void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(X && W && Y, "lpd_linear_smallk: null pointer");
+    LPD_CHECK_ARG(M > 0 && N > 0 && K > 0 && K <= 8, "lpd_linear_smallk: bad dims M=%d N=%d K=%d (K <= 8)", M, N, K);
+    LPD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "lpd_linear_smallk: scale and shift must be given together");
+    long long total = (long long)M * N;
+    hipLaunchKernelGGL(linear_smallk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, X, ldx, W, Y, ldy,
+                       M, N, K, bias, scale, shift, act, slope);
+    LPD_CHECK_LAUNCH("lpd_linear_smallk");
+    return LPD_OK;
+}
+
+extern "C" int lpd_transpose(const float* in, float* out, int batch, int R, int C, int ldi, int ldo, long long si,
+                             long long so, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(in && out, "lpd_transpose: null pointer");
+    LPD_CHECK_ARG(batch > 0 && batch <= 65535 && R > 0 && C > 0, "lpd_transpose: bad dims batch=%d R=%d C=%d", batch, R, C);
+    dim3 grid((C + 31) / 32, (R + 31) / 32, batch);
+    LPD_CHECK_ARG(grid.y <= 65535, "lpd_transpose: R=%d too large", R);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, out, R, C, ldi, ldo, si, so);
+    LPD_CHECK_LAUNCH("lpd_transpose");
+    return LPD_OK;
+}
+
+extern "C" int lpd_softmax_affine(const float* in, float* out, int rows, int ncols, const float* scale,
+                                  const float* shift, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(in && out, "lpd_softmax_affine: null pointer");
+    LPD_CHECK_ARG(rows > 0 && ncols > 0 && ncols <= 64, "lpd_softmax_affine: bad dims rows=%d ncols=%d (<= 64)", rows, ncols);
+    LPD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "lpd_softmax_affine: scale and shift must be given together");
+    hipLaunchKernelGGL(softmax_affine_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, out, rows, ncols, scale, shift);
+    LPD_CHECK_LAUNCH("lpd_softmax_affine");
+    return LPD_OK;
+}
+
+extern "C" int lpd_vlad_finalize(const float* vraw, const float* act, const float* cw2, float* out, int B, int N,
+                                 int F, int KC, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(vraw && act && cw2 && out, "lpd_vlad_finalize: null pointer");
+    LPD_CHECK_ARG(B > 0 && N > 0 && F > 0, "lpd_vlad_finalize: bad dims");
+    LPD_CHECK_ARG(KC == 64, "lpd_vlad_finalize: cluster_size=%d unsupported (64)", KC);
+    hipLaunchKernelGGL(vlad_finalize_kernel<64>, dim3(B), dim3(256), 0, stream, vraw, act, cw2, out, N, F);
+    LPD_CHECK_LAUNCH("lpd_vlad_finalize");
+    return LPD_OK;
+}
+
+extern "C" int lpd_colmax(const float* in, int ldi, float* out, int B, int N, int C, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(in && out, "lpd_colmax: null pointer");
+    LPD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && C > 0, "lpd_colmax: bad dims");
+    hipLaunchKernelGGL(colmax_kernel, dim3((C + 63) / 64, B), dim3(256), 0, stream, in, ldi, out, N, C);
+    LPD_CHECK_LAUNCH("lpd_colmax");
+    return LPD_OK;
+}
+
+extern "C" int lpd_mul(const float* a, const float* b, float* out, long long n, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(a && b && out && n > 0, "lpd_mul: bad arguments");
+    hipLaunchKernelGGL(mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, b, out, n);
+    LPD_CHECK_LAUNCH("lpd_mul");
+    return LPD_OK;
+}

@@ -1,0 +1,79 @@
+"""Build liblpd_hip.so (gfx950) in-tree with hipcc.  No torch dependency: pure HIP runtime.
+
+Used by __graft_entry__.build(); the resulting .so travels to the GPU box with the repo snapshot.
+"""
+import concurrent.futures
+import hashlib
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "csrc")
+LIB_PATH = os.path.join(HERE, "liblpd_hip.so")
+OBJ_DIR = os.path.join(CSRC, "build")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wno-unused-value"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; cannot build liblpd_hip.so")
+    return exe
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest(path, headers):
+    h = hashlib.sha256()
+    for p in [path] + headers:
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    """Compile every csrc/*.hip for gfx950 and link liblpd_hip.so. Incremental by content hash."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    jobs, objs = [], []
+    for src in _sources():
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        stamp = obj + ".sha"
+        dig = _digest(src, headers)
+        objs.append(obj)
+        if (not force and os.path.exists(obj) and os.path.exists(stamp)
+                and open(stamp).read() == dig):
+            continue
+        jobs.append((src, obj, stamp, dig))
+
+    def compile_one(job):
+        src, obj, stamp, dig = job
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        with open(stamp, "w") as fh:
+            fh.write(dig)
+        return src
+
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for done in ex.map(compile_one, jobs):
+                if verbose:
+                    print("compiled", os.path.basename(done))
+    if jobs or not os.path.exists(LIB_PATH):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

@@ -1,0 +1,72 @@
+"""ctypes binding of liblpd_hip.so (C-ABI declared in include/lpd_hip.h).
+
+torch is imported first on purpose: liblpd_hip.so needs libamdhip64.so.7, and the dynamic loader
+then reuses the HIP runtime torch already loaded (same SONAME), so device pointers and stream
+handles are shared between torch and these kernels.
+
+There is NO fallback: if the library is missing this raises, and every op in ops.py raises on
+non-CUDA tensors.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblpd_hip.so")
+
+_c_int = ctypes.c_int
+_c_ll = ctypes.c_longlong
+_c_f = ctypes.c_float
+_c_p = ctypes.c_void_p
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "lpd_version": [],
+    "lpd_last_error": [],
+    "lpd_knn": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_int, _c_p],
+    "lpd_gemm": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                 _c_ll, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p],
+    "lpd_edge_gather_max": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int,
+                            _c_int, _c_int, _c_f, _c_p],
+    "lpd_edge_mlp": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int,
+                     _c_int, _c_int, _c_int, _c_int, _c_f, _c_p],
+    "lpd_linear_smallk": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f,
+                          _c_p],
+    "lpd_transpose": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_p],
+    "lpd_softmax_affine": [_c_p, _c_p, _c_int, _c_int, _c_p, _c_p, _c_p],
+    "lpd_vlad_finalize": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "lpd_colmax": [_c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_p],
+    "lpd_mul": [_c_p, _c_p, _c_p, _c_ll, _c_p],
+}
+_RESTYPES = {"lpd_last_error": ctypes.c_char_p}
+
+_lib = None
+
+
+class LpdHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load liblpd_hip.so; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LpdHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` at the repo root (needs hipcc). There is no CPU/PyTorch fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, ctypes.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().lpd_last_error()
+        raise LpdHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,231 @@
+"""Tensor-level wrappers over the C-ABI (include/lpd_hip.h).  Forward-only building blocks;
+autograd lives in autograd.py.  Every op requires CUDA fp32 tensors and raises otherwise --
+there is deliberately no CPU or eager-PyTorch fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, name, dtype=torch.float32):
+    if t is None:
+        return
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise _lib.LpdHipError(
+            f"{name}: tensor is on {t.device}; the LPD-Net HIP path runs on MI355X only (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _rows(t, name):
+    """2-D view with unit column stride -> (tensor, leading dim)."""
+    _req(t, name)
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected a 2-D tensor with contiguous rows, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(0)
+
+
+def _vec(t, name, n):
+    if t is None:
+        return None
+    _req(t, name)
+    if t.numel() != n:
+        raise ValueError(f"{name}: expected {n} elements, got {t.numel()}")
+    return t.contiguous()
+
+
+def knn(x_cm, k, impl=0):
+    """x_cm [B,C,N] channel-major fp32 -> idx [B,N,k] int32 (reference util/lpdnet_model.py:317-326)."""
+    _req(x_cm, "x")
+    if x_cm.dim() != 3:
+        raise ValueError("knn: expected [B,C,N]")
+    x_cm = x_cm.contiguous()
+    B, C, N = x_cm.shape
+    idx = torch.empty((B, N, k), dtype=torch.int32, device=x_cm.device)
+    ws = torch.empty((B, N), dtype=torch.float32, device=x_cm.device)
+    lib = _lib.load()
+    _lib.check(lib.lpd_knn(_ptr(x_cm), B, C, N, k, _ptr(idx), _ptr(ws), impl, _stream()), "lpd_knn")
+    return idx
+
+
+def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=None, act=ACT_NONE, slope=0.01,
+         out=None, splits=1):
+    """Single (2-D) or batched (3-D) GEMM with fused epilogue.
+
+    A: [M,K] (a_kmajor False) or [K,M] (True); B: [K,N] (b_kmajor True) or [N,K] (False).
+    3-D inputs add a leading batch dim (must be contiguous in that dim ordering).
+    """
+    _req(A, "A")
+    _req(B, "B")
+    batched = A.dim() == 3
+    if batched:
+        if B.dim() != 3 or A.shape[0] != B.shape[0]:
+            raise ValueError("gemm: batched A needs batched B with the same batch")
+        nb = A.shape[0]
+        A2, B2 = A[0], B[0]
+        sA, sB = A.stride(0), B.stride(0)
+    else:
+        nb, A2, B2, sA, sB = 1, A, B, 0, 0
+    lda, ldb = _rows(A2, "A"), _rows(B2, "B")
+    M, K = (A2.shape[1], A2.shape[0]) if a_kmajor else (A2.shape[0], A2.shape[1])
+    Kb, N = (B2.shape[0], B2.shape[1]) if b_kmajor else (B2.shape[1], B2.shape[0])
+    if K != Kb:
+        raise ValueError(f"gemm: inner dims differ ({K} vs {Kb})")
+    if out is None:
+        out = torch.empty((nb, M, N) if batched else (M, N), dtype=torch.float32, device=A.device)
+    _req(out, "out")
+    O2 = out[0] if batched else out
+    ldc = _rows(O2, "out")
+    if O2.shape[0] != M or O2.shape[1] != N:
+        raise ValueError("gemm: out has the wrong shape")
+    sC = out.stride(0) if batched else 0
+    ws = None
+    if splits > 1:
+        ws = torch.empty((nb * splits * M * N,), dtype=torch.float32, device=A.device)
+    bias, scale, shift = _vec(bias, "bias", N), _vec(scale, "scale", N), _vec(shift, "shift", N)
+    lib = _lib.load()
+    _lib.check(lib.lpd_gemm(_ptr(A), _ptr(B), _ptr(out), M, N, K, lda, ldb, ldc, int(a_kmajor), int(b_kmajor), nb,
+                            sA, sB, sC, splits, _ptr(ws), _ptr(bias), _ptr(scale), _ptr(shift), act, float(slope),
+                            _stream()), "lpd_gemm")
+    return out
+
+
+def linear(x, w, *, bias=None, scale=None, shift=None, act=ACT_NONE, slope=0.01, out=None):
+    """y = act((x @ w.T + bias) * scale + shift); x [M,K] rows, w [N,K] (torch Linear/Conv1x1 layout)."""
+    ldx = _rows(x, "x")
+    _req(w, "w")
+    w = w.reshape(w.shape[0], -1).contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"linear: weight has {w.shape[1]} inputs, x has {K}")
+    if K <= 8:
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        ldy = _rows(out, "out")
+        bias, scale, shift = _vec(bias, "bias", N), _vec(scale, "scale", N), _vec(shift, "shift", N)
+        lib = _lib.load()
+        _lib.check(lib.lpd_linear_smallk(_ptr(x), ldx, _ptr(w), _ptr(out), ldy, M, N, K, _ptr(bias), _ptr(scale),
+                                         _ptr(shift), act, float(slope), _stream()), "lpd_linear_smallk")
+        return out
+    return gemm(x, w, a_kmajor=False, b_kmajor=False, bias=bias, scale=scale, shift=shift, act=act, slope=slope,
+                out=out)
+
+
+def edge_gather_max(P, Q, idx, N, *, scale=None, shift=None, act=ACT_NONE, slope=0.01, out=None):
+    """K-agg: out[m] = act(scale * (sel_t P[nbr(m,t)] + Q[m]) + shift); idx [M,k] int32 local indices."""
+    ldp = _rows(P, "P")
+    ldq = _rows(Q, "Q") if Q is not None else 0
+    _req(idx, "idx", torch.int32)
+    idx = idx.reshape(-1, idx.shape[-1]).contiguous()
+    M, C = P.shape
+    k = idx.shape[1]
+    if idx.shape[0] != M:
+        raise ValueError("edge_gather_max: idx rows != P rows")
+    if out is None:
+        out = torch.empty((M, C), dtype=torch.float32, device=P.device)
+    ldo = _rows(out, "out")
+    scale, shift = _vec(scale, "scale", C), _vec(shift, "shift", C)
+    lib = _lib.load()
+    _lib.check(lib.lpd_edge_gather_max(_ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(out), ldo, _ptr(scale),
+                                       _ptr(shift), M, N, C, k, act, float(slope), _stream()), "lpd_edge_gather_max")
+    return out
+
+
+def edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, *, act=ACT_LEAKY, slope=0.01, out=None):
+    """Fused DG1-activation -> DG2 conv -> BN -> act -> max over k (include/lpd_hip.h lpd_edge_mlp)."""
+    ldp = _rows(P, "P")
+    ldq = _rows(Q, "Q") if Q is not None else 0
+    _req(idx, "idx", torch.int32)
+    idx = idx.reshape(-1, idx.shape[-1]).contiguous()
+    M, CM = P.shape
+    k = idx.shape[1]
+    _req(W2, "W2")
+    W2 = W2.reshape(W2.shape[0], -1).contiguous()
+    CO = W2.shape[0]
+    if W2.shape[1] != CM:
+        raise ValueError("edge_mlp: W2 input width != P width")
+    if out is None:
+        out = torch.empty((M, CO), dtype=torch.float32, device=P.device)
+    ldo = _rows(out, "out")
+    s1, b1 = _vec(s1, "s1", CM), _vec(b1, "b1", CM)
+    s2, b2 = _vec(s2, "s2", CO), _vec(b2, "b2", CO)
+    lib = _lib.load()
+    _lib.check(lib.lpd_edge_mlp(_ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(s1), _ptr(b1), _ptr(W2), _ptr(s2),
+                                _ptr(b2), _ptr(out), ldo, M, N, CM, CO, k, act, float(slope), _stream()),
+               "lpd_edge_mlp")
+    return out
+
+
+def transpose(x):
+    """[batch,R,C] -> [batch,C,R] (contiguous)."""
+    _req(x, "x")
+    if x.dim() != 3:
+        raise ValueError("transpose: expected a 3-D tensor")
+    x = x.contiguous()
+    nb, R, C = x.shape
+    out = torch.empty((nb, C, R), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.lpd_transpose(_ptr(x), _ptr(out), nb, R, C, C, R, R * C, R * C, _stream()), "lpd_transpose")
+    return out
+
+
+def softmax_affine(x, scale=None, shift=None, out=None):
+    _rows(x, "x")
+    x = x.contiguous()
+    rows, n = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    scale, shift = _vec(scale, "scale", n), _vec(shift, "shift", n)
+    lib = _lib.load()
+    _lib.check(lib.lpd_softmax_affine(_ptr(x), _ptr(out), rows, n, _ptr(scale), _ptr(shift), _stream()),
+               "lpd_softmax_affine")
+    return out
+
+
+def vlad_finalize(vraw, act, cw2):
+    """vraw [B,F,KC], act [B,N,KC], cw2 [F,KC] -> [B,F*KC] normalised VLAD."""
+    _req(vraw, "vraw"), _req(act, "act"), _req(cw2, "cw2")
+    vraw, act, cw2 = vraw.contiguous(), act.contiguous(), cw2.contiguous()
+    B, F, KC = vraw.shape
+    N = act.shape[1]
+    out = torch.empty((B, F * KC), dtype=torch.float32, device=vraw.device)
+    lib = _lib.load()
+    _lib.check(lib.lpd_vlad_finalize(_ptr(vraw), _ptr(act), _ptr(cw2), _ptr(out), B, N, F, KC, _stream()),
+               "lpd_vlad_finalize")
+    return out
+
+
+def colmax(x, B, N):
+    """x [B*N, C] rows -> per-cloud max [B, C]."""
+    ldi = _rows(x, "x")
+    C = x.shape[1]
+    if x.shape[0] != B * N:
+        raise ValueError("colmax: rows != B*N")
+    out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.lpd_colmax(_ptr(x), ldi, _ptr(out), B, N, C, _stream()), "lpd_colmax")
+    return out
+
+
+def mul(a, b):
+    _req(a, "a"), _req(b, "b")
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    lib = _lib.load()
+    _lib.check(lib.lpd_mul(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "lpd_mul")
+    return out
