@@ -96,9 +96,13 @@ int lpd_edge_mlp(const float* P, int ldp, const float* Q, int ldq, const int32_t
                  int N, int CM, int CO, int k, int act, float slope, void* stream);
 
 /* Per-point linear layer with K <= 8 inputs (+bias, affine, activation): the 3 -> 64 first layers
- * (util/lpdnet_model.py:185,231; util/PointNetVlad.py:190,213; T-Net conv1 lpdnet_model.py:276). W [N][K]. */
-int lpd_linear_smallk(const float* X, int ldx, const float* W, float* Y, int ldy, int M, int N, int K,
-                      const float* bias, const float* scale, const float* shift, int act, float slope, void* stream);
+ * (util/lpdnet_model.py:185,231; util/PointNetVlad.py:190,213; T-Net conv1 lpdnet_model.py:276) and the
+ * per-cloud 3x3 alignment products x @ trans (lpdnet_model.py:229; PointNetVlad.py:209).
+ * Weight element (n, c) of weight set b is W[b*w_sb + n*w_sn + c*w_sk]; row m uses set m / rows_per_w
+ * (rows_per_w = 0: one shared weight). */
+int lpd_linear_smallk(const float* X, int ldx, const float* W, int w_sn, int w_sk, long long w_sb, int rows_per_w,
+                      float* Y, int ldy, int M, int N, int K, const float* bias, const float* scale,
+                      const float* shift, int act, float slope, void* stream);
 
 /* Batched transpose in [batch][R][C] -> out [batch][C][R] (point-major <-> channel-major). */
 int lpd_transpose(const float* in, float* out, int batch, int R, int C, int ldi, int ldo, long long si,
@@ -121,6 +125,21 @@ int lpd_colmax(const float* in, int ldi, float* out, int B, int N, int C, void* 
 
 /* out = a * b elementwise (context gating product, util/PointNetVlad.py:113). */
 int lpd_mul(const float* a, const float* b, float* out, long long n, void* stream);
+
+/*
+ * Lazy triplet / quadruplet loss, forward + gradient in one launch.  Replaces
+ * loss/pointnetvlad_loss.py:6-97 (best_pos_distance, triplet_loss, quadruplet_loss).
+ *   q (b,0,d) at q[b*q_sb + d]; pos (b,p,d) at pos[b*pos_sb + p*pos_st + d]; neg likewise; other like q
+ *   (strides in elements, unit stride over d) -- the four inputs are normally views of one
+ *   [bq, 1+P+Ng+1, D] descriptor tensor (train_pointnetvlad.py:214-217).
+ *   quad = 0: triplet form (other/m2/gother ignored).  use_min / lazy / ignore_zero: the reference flags.
+ *   loss [1]; minmax [2][bq] (min_pos, max_pos); gradients of the loss: gq [bq][D], gpos [bq][P][D],
+ *   gneg [bq][Ng][D], gother [bq][D].
+ */
+int lpd_metric_loss(const float* q, long long q_sb, const float* pos, long long pos_sb, long long pos_st,
+                    const float* neg, long long neg_sb, long long neg_st, const float* other, long long other_sb,
+                    int bq, int P, int Ng, int D, float m1, float m2, int use_min, int lazy, int ignore_zero, int quad,
+                    float* loss, float* minmax, float* gq, float* gpos, float* gneg, float* gother, void* stream);
 
 #ifdef __cplusplus
 }

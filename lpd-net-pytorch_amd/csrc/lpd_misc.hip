@@ -17,7 +17,9 @@
 
 namespace {
 
-__global__ void linear_smallk_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W,  // [N][K]
+// W element (n, c) of weight set b lives at W[b * w_sb + n * w_sn + c * w_sk]; rows m use set m / rows_per_w
+__global__ void linear_smallk_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W,
+                                     int w_sn, int w_sk, long long w_sb, int rows_per_w,
                                      float* __restrict__ Y, int ldy, int M, int N, int K, const float* bias,
                                      const float* scale, const float* shift, int act, float slope)
 {
@@ -25,9 +27,9 @@ __global__ void linear_smallk_kernel(const float* __restrict__ X, int ldx, const
     if (e >= (long long)M * N) return;
     const int m = (int)(e / N), n = (int)(e - (long long)m * N);
     const float* x = X + (size_t)m * ldx;
-    const float* w = W + (size_t)n * K;
+    const float* w = W + (rows_per_w > 0 ? (long long)(m / rows_per_w) * w_sb : 0) + (size_t)n * w_sn;
     float v = 0.0f;
-    for (int c = 0; c < K; ++c) v = fmaf(x[c], w[c], v);
+    for (int c = 0; c < K; ++c) v = fmaf(x[c], w[(size_t)c * w_sk], v);
     if (bias) v += bias[n];
     if (scale) v = v * scale[n] + shift[n];
     Y[(size_t)m * ldy + n] = lpd_act(v, act, slope);
@@ -172,17 +174,17 @@ __global__ void mul_kernel(const float* __restrict__ a, const float* __restrict_
 
 }  // namespace
 
-extern "C" int lpd_linear_smallk(const float* X, int ldx, const float* W, float* Y, int ldy, int M, int N, int K,
-                                 const float* bias, const float* scale, const float* shift, int act, float slope,
-                                 void* stream_)
+extern "C" int lpd_linear_smallk(const float* X, int ldx, const float* W, int w_sn, int w_sk, long long w_sb,
+                                 int rows_per_w, float* Y, int ldy, int M, int N, int K, const float* bias,
+                                 const float* scale, const float* shift, int act, float slope, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(X && W && Y, "lpd_linear_smallk: null pointer");
     LPD_CHECK_ARG(M > 0 && N > 0 && K > 0 && K <= 8, "lpd_linear_smallk: bad dims M=%d N=%d K=%d (K <= 8)", M, N, K);
     LPD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "lpd_linear_smallk: scale and shift must be given together");
     long long total = (long long)M * N;
-    hipLaunchKernelGGL(linear_smallk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, X, ldx, W, Y, ldy,
-                       M, N, K, bias, scale, shift, act, slope);
+    hipLaunchKernelGGL(linear_smallk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, X, ldx, W, w_sn,
+                       w_sk, w_sb, rows_per_w, Y, ldy, M, N, K, bias, scale, shift, act, slope);
     LPD_CHECK_LAUNCH("lpd_linear_smallk");
     return LPD_OK;
 }

@@ -13,7 +13,10 @@ CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 LIB_PATH = os.path.join(HERE, "liblpd_hip.so")
 OBJ_DIR = os.path.join(CSRC, "build")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wno-unused-value"]
+# -ffp-contract=off: the kNN arithmetic contract distinguishes fused from non-fused operations
+# (HIP's __fmul_rn/__fadd_rn are plain operators and DO get contracted otherwise); explicit fmaf /
+# MFMA are unaffected.
+FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wno-unused-value"]
 
 
 def _hipcc():

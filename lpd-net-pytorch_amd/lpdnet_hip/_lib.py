@@ -31,13 +31,15 @@ SIGNATURES = {
                             _c_int, _c_int, _c_f, _c_p],
     "lpd_edge_mlp": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int,
                      _c_int, _c_int, _c_int, _c_int, _c_f, _c_p],
-    "lpd_linear_smallk": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f,
-                          _c_p],
+    "lpd_linear_smallk": [_c_p, _c_int, _c_p, _c_int, _c_int, _c_ll, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int,
+                          _c_p, _c_p, _c_p, _c_int, _c_f, _c_p],
     "lpd_transpose": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_p],
     "lpd_softmax_affine": [_c_p, _c_p, _c_int, _c_int, _c_p, _c_p, _c_p],
     "lpd_vlad_finalize": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "lpd_colmax": [_c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_p],
     "lpd_mul": [_c_p, _c_p, _c_p, _c_ll, _c_p],
+    "lpd_metric_loss": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_int, _c_int, _c_int,
+                        _c_int, _c_f, _c_f, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
 }
 _RESTYPES = {"lpd_last_error": ctypes.c_char_p}
 

@@ -1,0 +1,283 @@
+"""Inference (eval-mode) engine: runs the reference modules' math on the HIP kernels.
+
+The nn.Modules in util/ are parameter containers with the reference's names/shapes; this file is
+where their forward passes are expressed as sequences of C-ABI calls.  Activations are kept
+point-major ([B*N, C] rows) end to end; the reference's channel-major [B,C,N(,1)] layout only
+appears at the public module boundaries.
+
+Eval-mode BatchNorm is a per-channel affine (scale = w / sqrt(var + eps), shift = b - mean * scale)
+that rides in the producing kernel's epilogue; the folded vectors are cached per module and
+re-derived when any of the four BN tensors changes (tensor._version) or moves device.
+"""
+import torch
+
+from . import ops
+
+LEAKY_SLOPE = 0.01
+
+# test hook: when set to a dict, the trunks drop intermediate tensors into it (idx_feat, idx_xyz, F0, cat)
+DEBUG_AUX = None
+
+
+# ------------------------------------------------------------------------------------------------
+# cached derived parameters
+# ------------------------------------------------------------------------------------------------
+def _cache_of(module):
+    c = module.__dict__.get("_lpd_cache")
+    if c is None:
+        c = {}
+        module.__dict__["_lpd_cache"] = c  # not a parameter/buffer: never enters state_dict
+    return c
+
+
+def _cached(module, key, tensors, build):
+    """Derived tensors keyed on the (data_ptr, version, device) of their sources."""
+    sig = tuple((t.data_ptr(), t._version, t.device) for t in tensors)
+    c = _cache_of(module)
+    hit = c.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    with torch.no_grad():
+        val = build()
+    c[key] = (sig, val)
+    return val
+
+
+def bn_affine(bn):
+    """(scale, shift) of an eval-mode BatchNorm layer."""
+    def build():
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale
+        return scale.contiguous(), shift.contiguous()
+    return _cached(bn, "affine", (bn.weight, bn.bias, bn.running_mean, bn.running_var), build)
+
+
+def _w2d(conv):
+    w = conv.weight
+    return w.reshape(w.shape[0], -1)
+
+
+def split_edge_weight(seq, mode):
+    """Stacked [neighbour ; centre] projection weight of a split edge convolution.
+
+    mode 'cat_nc'  : input cat(neighbour, centre)              (util/lpdnet_model.py:357)
+         'cat_cd'  : input cat(centre, neighbour - centre)     (util/lpdnet_model.py:142)
+         'nbr'     : neighbours only                           (util/lpdnet_model.py:144)
+    Returns W [2*Co or Co, C]: rows [0,Co) give P (gathered), rows [Co,2Co) give Q (centre).
+    """
+    conv = seq[0]
+
+    def build():
+        w = _w2d(conv)
+        if mode == "nbr":
+            return w.contiguous()
+        c = w.shape[1] // 2
+        if mode == "cat_nc":
+            wn, wc = w[:, :c], w[:, c:]
+        else:  # W [x_i ; f_j - x_i] = Wb f_j + (Wa - Wb) x_i
+            wn, wc = w[:, c:], w[:, :c] - w[:, c:]
+        return torch.cat((wn, wc), dim=0).contiguous()
+    return _cached(seq, "split_" + mode, (conv.weight,), build)
+
+
+def _need_eval(module, what):
+    if module.training:
+        raise NotImplementedError(
+            f"{what}: training-mode forward goes through lpdnet_hip.autograd; call .eval() for inference")
+
+
+def _check_input(x):
+    if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 1 or x.shape[3] != 3:
+        raise ValueError(f"expected input [B,1,N,3], got {tuple(x.shape) if isinstance(x, torch.Tensor) else type(x)}")
+    if not x.is_cuda:
+        raise ops._lib.LpdHipError(
+            f"input is on {x.device}: the LPD-Net HIP path runs on MI355X only (no CPU fallback)")
+    return x.float().contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# T-Nets
+# ------------------------------------------------------------------------------------------------
+def _tnet_common(net, h, B, N, kdim, bns):
+    """conv k->64->128->1024 (+bias)(+BN) + ReLU, max over N, fc 512, 256, k*k (+I).  h [B*N, k] rows."""
+    def layer(x, lin, bn):
+        sc, sh = bn_affine(bn) if bn is not None else (None, None)
+        return ops.linear(x, _w2d(lin), bias=lin.bias, scale=sc, shift=sh, act=ops.ACT_RELU)
+    h = layer(h, net.conv1, bns[0])
+    h = layer(h, net.conv2, bns[1])
+    h = layer(h, net.conv3, bns[2])
+    g = ops.colmax(h, B, N)                                            # [B,1024]
+    g = layer(g, net.fc1, bns[3])
+    g = layer(g, net.fc2, bns[4])
+    eye_bias = _cached(net, "fc3_bias_eye", (net.fc3.bias,),
+                       lambda: (net.fc3.bias + torch.eye(kdim, device=net.fc3.bias.device).flatten()).contiguous())
+    t = ops.linear(g, net.fc3.weight, bias=eye_bias)
+    return t.view(B, kdim, kdim)
+
+
+def transform_net_eval(net, h, B, N):
+    """util/lpdnet_model.py:295-313 (TranformNet, always with BatchNorm)."""
+    return _tnet_common(net, h, B, N, net.k, (net.bn1, net.bn2, net.bn3, net.bn4, net.bn5))
+
+
+def stn3d_eval(net, h, B, N):
+    """util/PointNetVlad.py:150-179 (STN3d; BatchNorm only when use_bn)."""
+    bns = (net.bn1, net.bn2, net.bn3, net.bn4, net.bn5) if net.use_bn else (None,) * 5
+    return _tnet_common(net, h, B, N, net.k, bns)
+
+
+# ------------------------------------------------------------------------------------------------
+# trunks (return point-major features [B*N, E])
+# ------------------------------------------------------------------------------------------------
+def lpdnet_features_eval(net, x):
+    """util/lpdnet_model.py:211-268 (LPDNet.forward), eval mode."""
+    x = _check_input(x)
+    B, N = x.shape[0], x.shape[2]
+    M = B * N
+    k = net.k
+    act, slope = (ops.ACT_RELU, 0.0) if net.use_relu else (ops.ACT_LEAKY, LEAKY_SLOPE)
+    xyz = x.view(M, 3)
+    p = xyz
+    if net.t3d:
+        trans = transform_net_eval(net.t_net3d, xyz, B, N)
+        p = ops.apply_transform(xyz, trans, N)
+    s, b = bn_affine(net.bn1_lpd)
+    f = ops.linear(p, _w2d(net.conv1_lpd), scale=s, shift=b, act=act, slope=slope)
+    s, b = bn_affine(net.bn2_lpd)
+    f = ops.linear(f, _w2d(net.conv2_lpd), scale=s, shift=b, act=act, slope=slope)      # F0 [M,64]
+    if net.tfea:
+        tf = transform_net_eval(net.t_net_fea, f, B, N)
+        f = ops.apply_transform(f, tf, N)
+    # dynamic graph in feature space
+    idx_f = ops.knn(ops.transpose(f.view(B, N, 64)), k)
+    cat = torch.empty((M, 512), dtype=torch.float32, device=x.device)                   # [x1 | x2 | x3]
+    pq = ops.linear(f, split_edge_weight(net.convDG1, "cat_nc"))                        # [M,256] = [P | Q]
+    s1, b1 = bn_affine(net.convDG1[1])
+    s2, b2 = bn_affine(net.convDG2[1])
+    ops.edge_gather_max(pq[:, :128], pq[:, 128:], idx_f, N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:128])
+    ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope,
+                 out=cat[:, 128:256])
+    # static graph in Cartesian space (raw xyz even when t3d, lpdnet_model.py:226,255)
+    idx_x = ops.knn(ops.transpose(x.view(B, N, 3)), k)
+    pq = ops.linear(cat[:, 128:256], split_edge_weight(net.convSN1, "cat_nc"))          # [M,512]
+    s3, b3 = bn_affine(net.convSN1[1])
+    ops.edge_gather_max(pq[:, :256], pq[:, 256:], idx_x, N, scale=s3, shift=b3, act=act, slope=slope, out=cat[:, 256:512])
+    if DEBUG_AUX is not None:
+        DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=cat)
+    s, b = bn_affine(net.bn3_lpd)
+    return ops.linear(cat, _w2d(net.conv3_lpd), scale=s, shift=b, act=act, slope=slope), B, N
+
+
+def lpdnet_origin_features_eval(net, x):
+    """util/lpdnet_model.py:68-114 (LPDNetOrign.forward), eval mode."""
+    x = _check_input(x)
+    B, N = x.shape[0], x.shape[2]
+    M = B * N
+    k = net.k
+    act, slope = (ops.ACT_RELU, 0.0) if net.use_relu else (ops.ACT_LEAKY, LEAKY_SLOPE)
+
+    def seq(h, block):
+        s, b = bn_affine(block[1])
+        return ops.linear(h, _w2d(block[0]), scale=s, shift=b, act=act, slope=slope)
+    xyz = x.view(M, 3)
+    p = xyz
+    if net.t3d:
+        trans = transform_net_eval(net.t_net3d, xyz, B, N)
+        p = ops.apply_transform(xyz, trans, N)
+    f = seq(seq(p, net.conv1_lpd), net.conv2_lpd)
+    if net.tfea:
+        tf = transform_net_eval(net.t_net_fea, f, B, N)
+        f = ops.apply_transform(f, tf, N)
+    idx_f = ops.knn(ops.transpose(f.view(B, N, 64)), k)
+    pq = ops.linear(f, split_edge_weight(net.convDG1, "cat_cd"))                        # [M,128] = [P | Q]
+    s1, b1 = bn_affine(net.convDG1[1])
+    s2, b2 = bn_affine(net.convDG2[1])
+    g = ops.edge_mlp(pq[:, :64], pq[:, 64:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope)
+    idx_x = ops.knn(ops.transpose(x.view(B, N, 3)), k)
+    pn = ops.linear(g, split_edge_weight(net.convSN1, "nbr"))                           # [M,64] neighbours only
+    s1, b1 = bn_affine(net.convSN1[1])
+    s2, b2 = bn_affine(net.convSN2[1])
+    h = ops.edge_mlp(pn, None, idx_x, N, s1, b1, _w2d(net.convSN2[0]), s2, b2, act=act, slope=slope)
+    if DEBUG_AUX is not None:
+        DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x)
+    h = seq(seq(seq(h, net.conv3_lpd), net.conv4_lpd), net.conv5_lpd)
+    return h, B, N
+
+
+def pointnet_features_eval(net, x):
+    """util/PointNetVlad.py:204-233 (PointNetfeat.forward with max_pool=False), eval mode."""
+    x = _check_input(x)
+    B, N = x.shape[0], x.shape[2]
+    if N != net.num_points:
+        raise ValueError(f"PointNetfeat was built for num_points={net.num_points}, got N={N} (MaxPool2d((num_points,1)))")
+    M = B * N
+    xyz = x.view(M, 3)
+    trans = stn3d_eval(net.stn, xyz, B, N)
+    p = ops.apply_transform(xyz, trans, N)
+
+    def layer(h, conv, bn, act):
+        s, b = bn_affine(bn)
+        return ops.linear(h, _w2d(conv), bias=conv.bias, scale=s, shift=b, act=act)
+    h = layer(p, net.conv1, net.bn1, ops.ACT_RELU)
+    h = layer(h, net.conv2, net.bn2, ops.ACT_RELU)
+    if net.apply_feature_trans:
+        ft = stn3d_eval(net.feature_trans, h, B, N)
+        h = ops.apply_transform(h, ft, N)
+    h = layer(h, net.conv3, net.bn3, ops.ACT_RELU)
+    h = layer(h, net.conv4, net.bn4, ops.ACT_RELU)
+    h = layer(h, net.conv5, net.bn5, ops.ACT_NONE)     # no ReLU after bn5 (PointNetVlad.py:230)
+    return h, B, N, trans
+
+
+# ------------------------------------------------------------------------------------------------
+# NetVLAD head
+# ------------------------------------------------------------------------------------------------
+def _head_splits(K):
+    """split-K factor for the [B, K] x [K, out] hidden projection: ~256 blocks, >= 8 k-tiles each."""
+    s = 1
+    while s < 128 and K % (32 * s * 2) == 0 and K // (s * 2) >= 256:
+        s *= 2
+    return s
+
+
+def netvlad_eval(vlad, feat, B, N):
+    """util/PointNetVlad.py:45-83 + GatingContext :103-115, eval mode.  feat [B*N, E] point-major."""
+    if N != vlad.max_samples:
+        raise ValueError(f"NetVLADLoupe was built for max_samples={vlad.max_samples}, got N={N}")
+    E, K = vlad.feature_size, vlad.cluster_size
+    if vlad.add_batch_norm:
+        a = ops.gemm(feat, vlad.cluster_weights, b_kmajor=True)
+        s, b = bn_affine(vlad.bn1)
+        a = ops.softmax_affine(a, s, b, out=a)
+    else:
+        ones = _cached(vlad, "ones", (vlad.cluster_biases,), lambda: torch.ones_like(vlad.cluster_biases))
+        a = ops.gemm(feat, vlad.cluster_weights, b_kmajor=True)
+        a = ops.softmax_affine(a, ones, vlad.cluster_biases, out=a)
+    vraw = ops.gemm(feat.view(B, N, E), a.view(B, N, K), a_kmajor=True, b_kmajor=True)     # [B,E,K]
+    v = ops.vlad_finalize(vraw, a.view(B, N, K), vlad.cluster_weights2.view(E, K))         # [B,E*K]
+    s, b = bn_affine(vlad.bn2)
+    h = ops.gemm(v, vlad.hidden1_weights, b_kmajor=True, scale=s, shift=b, splits=_head_splits(E * K))
+    if not vlad.gating:
+        return h
+    return gating_eval(vlad.context_gating, h)
+
+
+def gating_eval(gc, h):
+    """util/PointNetVlad.py:103-115."""
+    if gc.add_batch_norm:
+        s, b = bn_affine(gc.bn1)
+        gates = ops.gemm(h, gc.gating_weights, b_kmajor=True, scale=s, shift=b, act=ops.ACT_SIGMOID)
+    else:
+        gates = ops.gemm(h, gc.gating_weights, b_kmajor=True, bias=gc.gating_biases, act=ops.ACT_SIGMOID)
+    return ops.mul(h, gates)
+
+
+def to_channel_major(feat, B, N):
+    """[B*N, E] rows -> the reference's [B, E, N, 1]."""
+    return ops.transpose(feat.view(B, N, feat.shape[1])).unsqueeze(-1)
+
+
+def to_point_major(x4):
+    """[B, E, N, 1] -> ([B*N, E] rows, B, N)."""
+    B, E, N = x4.shape[0], x4.shape[1], x4.shape[2]
+    return ops.transpose(x4.reshape(B, E, N).float().contiguous()).view(B * N, E), B, N

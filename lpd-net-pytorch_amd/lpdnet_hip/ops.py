@@ -10,6 +10,24 @@ from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 
+# When set to a dict, every C-ABI call is bracketed by HIP events recorded on the launch stream
+# (torch's current stream): {label: [(start_event, end_event), ...]}.  Used by bench.py.
+PROFILE = None
+
+
+def _call(label, fn, *args):
+    prof = PROFILE
+    if prof is None:
+        _lib.check(fn(*args), fn.__name__)
+        return
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    rc = fn(*args)
+    b.record()
+    _lib.check(rc, fn.__name__)
+    prof.setdefault(label, []).append((a, b))
+
 
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
@@ -58,7 +76,7 @@ def knn(x_cm, k, impl=0):
     idx = torch.empty((B, N, k), dtype=torch.int32, device=x_cm.device)
     ws = torch.empty((B, N), dtype=torch.float32, device=x_cm.device)
     lib = _lib.load()
-    _lib.check(lib.lpd_knn(_ptr(x_cm), B, C, N, k, _ptr(idx), _ptr(ws), impl, _stream()), "lpd_knn")
+    _call(f"knn[C={C},k={k}]", lib.lpd_knn, _ptr(x_cm), B, C, N, k, _ptr(idx), _ptr(ws), impl, _stream())
     return idx
 
 
@@ -98,9 +116,9 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
         ws = torch.empty((nb * splits * M * N,), dtype=torch.float32, device=A.device)
     bias, scale, shift = _vec(bias, "bias", N), _vec(scale, "scale", N), _vec(shift, "shift", N)
     lib = _lib.load()
-    _lib.check(lib.lpd_gemm(_ptr(A), _ptr(B), _ptr(out), M, N, K, lda, ldb, ldc, int(a_kmajor), int(b_kmajor), nb,
+    _call(f"gemm[{M}x{N}x{K}]", lib.lpd_gemm, _ptr(A), _ptr(B), _ptr(out), M, N, K, lda, ldb, ldc, int(a_kmajor), int(b_kmajor), nb,
                             sA, sB, sC, splits, _ptr(ws), _ptr(bias), _ptr(scale), _ptr(shift), act, float(slope),
-                            _stream()), "lpd_gemm")
+                            _stream())
     return out
 
 
@@ -119,11 +137,38 @@ def linear(x, w, *, bias=None, scale=None, shift=None, act=ACT_NONE, slope=0.01,
         ldy = _rows(out, "out")
         bias, scale, shift = _vec(bias, "bias", N), _vec(scale, "scale", N), _vec(shift, "shift", N)
         lib = _lib.load()
-        _lib.check(lib.lpd_linear_smallk(_ptr(x), ldx, _ptr(w), _ptr(out), ldy, M, N, K, _ptr(bias), _ptr(scale),
-                                         _ptr(shift), act, float(slope), _stream()), "lpd_linear_smallk")
+        _call("linear_smallk", lib.lpd_linear_smallk, _ptr(x), ldx, _ptr(w), K, 1, 0, 0, _ptr(out), ldy, M, N, K, _ptr(bias),
+                                         _ptr(scale), _ptr(shift), act, float(slope), _stream())
         return out
     return gemm(x, w, a_kmajor=False, b_kmajor=False, bias=bias, scale=scale, shift=shift, act=act, slope=slope,
                 out=out)
+
+
+def apply_transform(x, trans, rows_per_cloud, out=None):
+    """Per-cloud alignment product y[m] = x[m] @ trans[m // rows_per_cloud]; x [M,K], trans [B,K,K].
+
+    K <= 8 -> small-K kernel; otherwise the batched MFMA GEMM (K % 32 == 0).
+    (util/lpdnet_model.py:229,240; util/PointNetVlad.py:209,223)
+    """
+    _rows(x, "x")
+    _req(trans, "trans")
+    trans = trans.contiguous()
+    M, K = x.shape
+    Bn = trans.shape[0]
+    if trans.shape[1] != K or trans.shape[2] != K or Bn * rows_per_cloud != M:
+        raise ValueError("apply_transform: shape mismatch")
+    if K <= 8:
+        if out is None:
+            out = torch.empty((M, K), dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        # y[m][n] = sum_c x[m][c] * trans[b][c][n]  => W(n,c) at b*K*K + n*1 + c*K
+        _call("linear_smallk", lib.lpd_linear_smallk, _ptr(x), x.stride(0), _ptr(trans), 1, K, K * K, rows_per_cloud, _ptr(out),
+                                         out.stride(0), M, K, K, None, None, None, ACT_NONE, 0.0, _stream())
+        return out
+    if not x.is_contiguous():
+        raise ValueError("apply_transform: x must be contiguous for the batched GEMM")
+    y = gemm(x.view(Bn, rows_per_cloud, K), trans, a_kmajor=False, b_kmajor=True)
+    return y.view(M, K)
 
 
 def edge_gather_max(P, Q, idx, N, *, scale=None, shift=None, act=ACT_NONE, slope=0.01, out=None):
@@ -141,8 +186,8 @@ def edge_gather_max(P, Q, idx, N, *, scale=None, shift=None, act=ACT_NONE, slope
     ldo = _rows(out, "out")
     scale, shift = _vec(scale, "scale", C), _vec(shift, "shift", C)
     lib = _lib.load()
-    _lib.check(lib.lpd_edge_gather_max(_ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(out), ldo, _ptr(scale),
-                                       _ptr(shift), M, N, C, k, act, float(slope), _stream()), "lpd_edge_gather_max")
+    _call(f"edge_gather_max[C={C}]", lib.lpd_edge_gather_max, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(out), ldo, _ptr(scale),
+                                       _ptr(shift), M, N, C, k, act, float(slope), _stream())
     return out
 
 
@@ -165,9 +210,8 @@ def edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, *, act=ACT_LEAKY, slope=0.01, out
     s1, b1 = _vec(s1, "s1", CM), _vec(b1, "b1", CM)
     s2, b2 = _vec(s2, "s2", CO), _vec(b2, "b2", CO)
     lib = _lib.load()
-    _lib.check(lib.lpd_edge_mlp(_ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(s1), _ptr(b1), _ptr(W2), _ptr(s2),
-                                _ptr(b2), _ptr(out), ldo, M, N, CM, CO, k, act, float(slope), _stream()),
-               "lpd_edge_mlp")
+    _call(f"edge_mlp[{CM}->{CO}]", lib.lpd_edge_mlp, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(s1), _ptr(b1), _ptr(W2), _ptr(s2),
+                                _ptr(b2), _ptr(out), ldo, M, N, CM, CO, k, act, float(slope), _stream())
     return out
 
 
@@ -180,7 +224,7 @@ def transpose(x):
     nb, R, C = x.shape
     out = torch.empty((nb, C, R), dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.lpd_transpose(_ptr(x), _ptr(out), nb, R, C, C, R, R * C, R * C, _stream()), "lpd_transpose")
+    _call("transpose", lib.lpd_transpose, _ptr(x), _ptr(out), nb, R, C, C, R, R * C, R * C, _stream())
     return out
 
 
@@ -192,8 +236,7 @@ def softmax_affine(x, scale=None, shift=None, out=None):
         out = torch.empty_like(x)
     scale, shift = _vec(scale, "scale", n), _vec(shift, "shift", n)
     lib = _lib.load()
-    _lib.check(lib.lpd_softmax_affine(_ptr(x), _ptr(out), rows, n, _ptr(scale), _ptr(shift), _stream()),
-               "lpd_softmax_affine")
+    _call("softmax_affine", lib.lpd_softmax_affine, _ptr(x), _ptr(out), rows, n, _ptr(scale), _ptr(shift), _stream())
     return out
 
 
@@ -205,8 +248,7 @@ def vlad_finalize(vraw, act, cw2):
     N = act.shape[1]
     out = torch.empty((B, F * KC), dtype=torch.float32, device=vraw.device)
     lib = _lib.load()
-    _lib.check(lib.lpd_vlad_finalize(_ptr(vraw), _ptr(act), _ptr(cw2), _ptr(out), B, N, F, KC, _stream()),
-               "lpd_vlad_finalize")
+    _call("vlad_finalize", lib.lpd_vlad_finalize, _ptr(vraw), _ptr(act), _ptr(cw2), _ptr(out), B, N, F, KC, _stream())
     return out
 
 
@@ -218,7 +260,7 @@ def colmax(x, B, N):
         raise ValueError("colmax: rows != B*N")
     out = torch.empty((B, C), dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.lpd_colmax(_ptr(x), ldi, _ptr(out), B, N, C, _stream()), "lpd_colmax")
+    _call("colmax", lib.lpd_colmax, _ptr(x), ldi, _ptr(out), B, N, C, _stream())
     return out
 
 
@@ -227,5 +269,5 @@ def mul(a, b):
     a, b = a.contiguous(), b.contiguous()
     out = torch.empty_like(a)
     lib = _lib.load()
-    _lib.check(lib.lpd_mul(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "lpd_mul")
+    _call("mul", lib.lpd_mul, _ptr(a), _ptr(b), _ptr(out), a.numel(), _stream())
     return out

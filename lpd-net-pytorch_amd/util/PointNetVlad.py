@@ -1,0 +1,186 @@
+"""MI355X-native PointNetVLAD head + PointNet trunk behind the reference's module API.
+
+Mirror of util/PointNetVlad.py of qiaozhijian/LPD-Net-Pytorch (NetVLADLoupe :12-83, GatingContext
+:86-115, Flatten :118-123, STN3d :126-179, PointNetfeat :181-241, PointNetVlad :244-270): same names,
+constructor signatures, shapes and state_dict keys; the math runs on liblpd_hip.so.  The nn.* children
+are parameter containers only.  Inputs must be on the GPU (no CPU fallback).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from lpdnet_hip import engine
+from util.lpdnet_model import LPDNet, LPDNetOrign
+
+
+class GatingContext(nn.Module):
+    """Reference PointNetVlad.py:86-115."""
+
+    def __init__(self, dim, add_batch_norm=True):
+        super().__init__()
+        self.dim = dim
+        self.add_batch_norm = add_batch_norm
+        self.gating_weights = nn.Parameter(torch.randn(dim, dim) * 1 / math.sqrt(dim))
+        self.sigmoid = nn.Sigmoid()
+        if add_batch_norm:
+            self.gating_biases = None
+            self.bn1 = nn.BatchNorm1d(dim)
+        else:
+            self.gating_biases = nn.Parameter(torch.randn(dim) * 1 / math.sqrt(dim))
+            self.bn1 = None
+
+    def forward(self, x):
+        engine._need_eval(self, "GatingContext")
+        return engine.gating_eval(self, x.float().contiguous())
+
+
+class NetVLADLoupe(nn.Module):
+    """Reference PointNetVlad.py:12-83.  forward: [B,feature_size,max_samples,1] -> [B,output_dim]."""
+
+    def __init__(self, feature_size, max_samples, cluster_size, output_dim, gating=True, add_batch_norm=True,
+                 is_training=True):
+        super().__init__()
+        self.feature_size = feature_size
+        self.max_samples = max_samples
+        self.output_dim = output_dim
+        self.is_training = is_training
+        self.gating = gating
+        self.add_batch_norm = add_batch_norm
+        self.cluster_size = cluster_size
+        self.softmax = nn.Softmax(dim=-1)
+        self.cluster_weights = nn.Parameter(torch.randn(feature_size, cluster_size) * 1 / math.sqrt(feature_size))
+        self.cluster_weights2 = nn.Parameter(torch.randn(1, feature_size, cluster_size) * 1 / math.sqrt(feature_size))
+        self.hidden1_weights = nn.Parameter(torch.randn(cluster_size * feature_size, output_dim) * 1 / math.sqrt(feature_size))
+        if add_batch_norm:
+            self.cluster_biases = None
+            self.bn1 = nn.BatchNorm1d(cluster_size)
+        else:
+            self.cluster_biases = nn.Parameter(torch.randn(cluster_size) * 1 / math.sqrt(feature_size))
+            self.bn1 = None
+        self.bn2 = nn.BatchNorm1d(output_dim)
+        if gating:
+            self.context_gating = GatingContext(output_dim, add_batch_norm=add_batch_norm)
+
+    def _pool(self, feat, B, N):
+        """feat: point-major [B*N, feature_size] rows."""
+        if self.training:
+            from lpdnet_hip import autograd
+            return autograd.netvlad_train(self, feat, B, N)
+        return engine.netvlad_eval(self, feat, B, N)
+
+    def forward(self, x):
+        feat, B, N = engine.to_point_major(x)
+        return self._pool(feat, B, N)
+
+
+class Flatten(nn.Module):
+    """Reference PointNetVlad.py:118-123."""
+
+    def forward(self, input):
+        return input.view(input.size(0), -1)
+
+
+class STN3d(nn.Module):
+    """Reference PointNetVlad.py:126-179: [B,1,N,3] (k=3) or [B,k,N,1] -> [B,k,k]."""
+
+    def __init__(self, num_points=2500, k=3, use_bn=True):
+        super().__init__()
+        self.k = k
+        self.kernel_size = 3 if k == 3 else 1
+        self.channels = 1 if k == 3 else k
+        self.num_points = num_points
+        self.use_bn = use_bn
+        self.conv1 = nn.Conv2d(self.channels, 64, (1, self.kernel_size))
+        self.conv2 = nn.Conv2d(64, 128, (1, 1))
+        self.conv3 = nn.Conv2d(128, 1024, (1, 1))
+        self.mp1 = nn.MaxPool2d((num_points, 1), 1)
+        self.fc1 = nn.Linear(1024, 512)
+        self.fc2 = nn.Linear(512, 256)
+        self.fc3 = nn.Linear(256, k * k)
+        self.fc3.weight.data.zero_()
+        self.fc3.bias.data.zero_()
+        self.relu = nn.ReLU()
+        if use_bn:
+            self.bn1 = nn.BatchNorm2d(64)
+            self.bn2 = nn.BatchNorm2d(128)
+            self.bn3 = nn.BatchNorm2d(1024)
+            self.bn4 = nn.BatchNorm1d(512)
+            self.bn5 = nn.BatchNorm1d(256)
+
+    def forward(self, x):
+        engine._need_eval(self, "STN3d")
+        B = x.shape[0]
+        if self.k == 3:
+            N = x.shape[2]
+            rows = x.float().contiguous().view(B * N, 3)
+        else:
+            rows, B, N = engine.to_point_major(x)
+        if N != self.num_points:
+            raise ValueError(f"STN3d was built for num_points={self.num_points}, got N={N}")
+        return engine.stn3d_eval(self, rows, B, N)
+
+
+class PointNetfeat(nn.Module):
+    """Reference PointNetVlad.py:181-241."""
+
+    def __init__(self, num_points=2500, global_feat=True, feature_transform=False, max_pool=True, emb_dims=1024):
+        super().__init__()
+        self.stn = STN3d(num_points=num_points, k=3, use_bn=False)
+        self.feature_trans = STN3d(num_points=num_points, k=64, use_bn=False)  # always constructed (:185)
+        self.apply_feature_trans = feature_transform
+        self.conv1 = nn.Conv2d(1, 64, (1, 3))
+        self.conv2 = nn.Conv2d(64, 64, (1, 1))
+        self.conv3 = nn.Conv2d(64, 64, (1, 1))
+        self.conv4 = nn.Conv2d(64, 128, (1, 1))
+        self.conv5 = nn.Conv2d(128, emb_dims, (1, 1))
+        self.bn1 = nn.BatchNorm2d(64)
+        self.bn2 = nn.BatchNorm2d(64)
+        self.bn3 = nn.BatchNorm2d(64)
+        self.bn4 = nn.BatchNorm2d(128)
+        self.bn5 = nn.BatchNorm2d(emb_dims)
+        self.mp1 = nn.MaxPool2d((num_points, 1), 1)
+        self.num_points = num_points
+        self.global_feat = global_feat
+        self.max_pool = max_pool
+        self.emb_dims = emb_dims
+
+    def _features(self, x):
+        if self.training:
+            from lpdnet_hip import autograd
+            return autograd.pointnet_features_train(self, x)
+        feat, B, N, _ = engine.pointnet_features_eval(self, x)
+        return feat, B, N
+
+    def forward(self, x):
+        if self.max_pool:
+            raise NotImplementedError("PointNetfeat(max_pool=True) (the classification-style global feature, reference "
+                                      "PointNetVlad.py:234-241) is not on the PointNetVLAD path and is not built")
+        feat, B, N = self._features(x)
+        return engine.to_channel_major(feat, B, N)
+
+
+class PointNetVlad(nn.Module):
+    """Reference PointNetVlad.py:244-270.  forward: [B,1,num_points,3] fp32 -> [B,output_dim]."""
+
+    def __init__(self, num_points=4096, global_feat=True, feature_transform=False, max_pool=False, output_dim=256,
+                 emb_dims=1024, featnet="lpdnet", xyz_trans=False):
+        super().__init__()
+        if featnet == "lpdnet":
+            self.emb_nn = LPDNet(emb_dims=emb_dims, tfea=feature_transform, t3d=xyz_trans)
+        elif featnet == "pointnet":
+            self.emb_nn = None
+            self.point_net = PointNetfeat(num_points=num_points, global_feat=global_feat,
+                                          feature_transform=feature_transform, max_pool=max_pool, emb_dims=emb_dims)
+        elif featnet == "lpdnetorigin":
+            self.emb_nn = LPDNetOrign(emb_dims=emb_dims, tfea=feature_transform, t3d=xyz_trans)
+        else:
+            # the reference prints "featnet error" and crashes later (PointNetVlad.py:256); fail here instead
+            raise ValueError(f"featnet error: {featnet!r} (expected 'lpdnet', 'pointnet' or 'lpdnetorigin')")
+        self.net_vlad = NetVLADLoupe(feature_size=emb_dims, max_samples=num_points, cluster_size=64,
+                                     output_dim=output_dim, gating=True, add_batch_norm=True, is_training=True)
+
+    def forward(self, x):
+        trunk = self.emb_nn if self.emb_nn is not None else self.point_net
+        feat, B, N = trunk._features(x)          # point-major: no [B,E,N,1] round trip between trunk and head
+        return self.net_vlad._pool(feat, B, N)

@@ -1,0 +1,191 @@
+"""End-to-end parity of the HIP-backed modules (reference API mirror) against the golden vectors
+captured from the reference and against the oracle.  -m gpu only.
+
+Gates (BASELINE.json north_star): kNN indices bit-exact on tie-free rows at the op boundary;
+fp32 descriptors within 1e-4, norm-relative per descriptor (max|a-b| / max|a|).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lpd_oracle as orc
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+DESC_TOL = 1e-4
+
+
+def _model(featnet, N, cuda, **kw):
+    from util.PointNetVlad import PointNetVlad
+    m = PointNetVlad(num_points=N, featnet=featnet, **kw)
+    sd = orc.synthetic_state(featnet, num_points=N, **kw)
+    m.load_state_dict(sd, strict=True)
+    return m.to(cuda).eval(), sd
+
+
+def _norm_rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().amax(dim=1) / b.abs().amax(dim=1)).max().item()
+
+
+CASES = [("eval_lpdnet_b2_n4096", "lpdnet", {}),
+         ("eval_lpdnet_tnets_b2_n1024", "lpdnet", dict(feature_transform=True, xyz_trans=True)),
+         ("eval_lpdnetorigin_b2_n1024", "lpdnetorigin", {}),
+         ("eval_pointnet_b2_n4096", "pointnet", {}),
+         ("eval_pointnet_ft_b2_n1024", "pointnet", dict(feature_transform=True))]
+
+
+@pytest.mark.parametrize("tag,featnet,kw", CASES)
+def test_eval_descriptors_vs_reference_golden(cuda, golden_dir, tag, featnet, kw):
+    from lpdnet_hip import engine
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    B, N = int(g["B"]), int(g["N"])
+    m, _ = _model(featnet, N, cuda, **kw)
+    x = torch.from_numpy(synth.cloud(int(g["seed"]), B, N)).unsqueeze(1).to(cuda)
+    engine.DEBUG_AUX = {}
+    try:
+        with torch.no_grad():
+            desc = m(x)
+        aux = engine.DEBUG_AUX
+    finally:
+        engine.DEBUG_AUX = None
+    assert desc.shape == (B, 256)
+    rel = _norm_rel(desc, torch.from_numpy(g["desc"]))
+    assert rel < DESC_TOL, f"descriptor norm-rel error {rel:.3e}"
+    if featnet != "pointnet":
+        # xyz-space kNN sees exactly the reference's input: bit-exact on tie-free rows
+        idx_x = aux["idx_xyz"].cpu().numpy()
+        ok = (idx_x == g["idx_xyz"].astype(np.int32)).all(-1)
+        assert (~ok & ~g["tie_xyz"]).sum() == 0
+        # feature-space kNN inherits upstream conv rounding: report agreement
+        idx_f = aux["idx_feat"].cpu().numpy()
+        agree = (idx_f == g["idx_feat"].astype(np.int32)).all(-1).mean()
+        assert agree > 0.98, f"feature-space kNN rows equal to the reference: {agree:.4f}"
+
+
+@pytest.mark.parametrize("featnet,kw,B,N", [("lpdnet", {}, 3, 512), ("lpdnet", dict(xyz_trans=True), 2, 256),
+                                            ("lpdnetorigin", dict(feature_transform=True), 2, 256),
+                                            ("pointnet", {}, 5, 256)])
+def test_eval_descriptors_vs_oracle(cuda, featnet, kw, B, N):
+    m, sd = _model(featnet, N, cuda, **kw)
+    x = torch.from_numpy(synth.cloud(77, B, N)).unsqueeze(1)
+    with torch.no_grad():
+        ref = orc.pointnetvlad_forward(sd, x, featnet=featnet, train=False, **kw)
+        desc = m(x.to(cuda))
+    assert _norm_rel(desc, ref) < DESC_TOL
+
+
+def test_module_api_surface(cuda):
+    """What the reference's callers do with the modules."""
+    from util import lpdnet_model as lm
+    from util.PointNetVlad import NetVLADLoupe, PointNetVlad
+    N = 256
+    m, sd = _model("lpdnet", N, cuda)
+    x = torch.from_numpy(synth.cloud(5, 2, N)).unsqueeze(1).to(cuda)
+    # trunk and head usable on their own with the reference's layouts
+    with torch.no_grad():
+        feat = m.emb_nn(x)
+        assert feat.shape == (2, 1024, N, 1)
+        d1 = m.net_vlad(feat)
+        d2 = m(x)
+    assert torch.equal(d1, d2)
+    # knn(): int64 [B,N,k], matches the oracle on tie-free rows
+    pts = x.squeeze(1).transpose(1, 2).contiguous()
+    idx = lm.knn(pts, 20)
+    assert idx.dtype == torch.int64 and idx.shape == (2, N, 20)
+    oidx, _ = orc.knn_np(synth.cloud(5, 2, N), 20)
+    tie = orc.knn_tie_rows(synth.cloud(5, 2, N), 20)
+    assert ((idx.cpu().numpy() == oidx).all(-1) | tie).all()
+    # get_graph_feature(): [B,2C,N,k] = cat(neighbour, centre)
+    gf = lm.get_graph_feature(pts, k=20)
+    ogf = orc.graph_feature(pts.cpu(), 20, torch.from_numpy(oidx.astype(np.int64)))
+    assert gf.shape == (2, 6, N, 20)
+    keep = torch.from_numpy(~tie)
+    assert torch.equal(gf.cpu().permute(0, 2, 1, 3)[keep], ogf.permute(0, 2, 1, 3)[keep])
+    gfo = lm.get_graph_feature_Origin(pts, k=20, cat=False)
+    assert gfo.shape == (2, 3, N, 20)
+    # state_dict round trip, DataParallel wrapper attribute access, train()/eval() toggles
+    m2 = PointNetVlad(num_points=N, featnet="lpdnet")
+    m2.load_state_dict(m.state_dict(), strict=True)
+    m2 = m2.to(cuda).eval()
+    with torch.no_grad():
+        assert torch.equal(m2(x), d2)
+    assert m._get_name() == "PointNetVlad"
+    # CPU tensors are refused loudly (no fallback)
+    from lpdnet_hip import LpdHipError
+    with pytest.raises(LpdHipError):
+        m(x.cpu())
+    with pytest.raises(ValueError):
+        PointNetVlad(featnet="nope")
+
+
+def test_eval_batch_invariance_and_bn_cache(cuda):
+    """Eval-mode descriptors do not depend on batch composition; folded BN is refreshed after updates."""
+    m, _ = _model("lpdnet", 256, cuda)
+    x = torch.from_numpy(synth.cloud(9, 4, 256)).unsqueeze(1).to(cuda)
+    with torch.no_grad():
+        full = m(x)
+        parts = torch.cat([m(x[:1]), m(x[1:])])
+    assert _norm_rel(parts, full) < 1e-5
+    with torch.no_grad():
+        m.emb_nn.bn3_lpd.weight.mul_(1.5)
+        changed = m(x)
+    assert _norm_rel(changed, full) > 1e-3
+
+
+# ------------------------------------------------------------------ losses
+def _loss_inputs(device):
+    bq, P, Ng, D = 3, 2, 5, 16
+    q = 0.5 * torch.from_numpy(synth.uniform("loss/q", bq * D).astype(np.float32).reshape(bq, 1, D))
+    pos = 0.5 * torch.from_numpy(synth.uniform("loss/pos", bq * P * D).astype(np.float32).reshape(bq, P, D))
+    neg = 0.5 * torch.from_numpy(synth.uniform("loss/neg", bq * Ng * D).astype(np.float32).reshape(bq, Ng, D))
+    oth = 0.5 * torch.from_numpy(synth.uniform("loss/oth", bq * D).astype(np.float32).reshape(bq, 1, D))
+    return [t.to(device) for t in (q, pos, neg, oth)]
+
+
+def test_losses_vs_reference_golden_and_oracle_grads(cuda, golden_dir):
+    import loss.pointnetvlad_loss as L
+    g = np.load(os.path.join(golden_dir, "loss_kat.npz"))
+    for row in g["table"]:
+        use_min, lazy, ign, rq, rt, rw = bool(row[0]), bool(row[1]), bool(row[2]), row[3], row[4], row[5]
+        ins = [t.requires_grad_(True) for t in _loss_inputs(cuda)]
+        lq = L.quadruplet_loss(*ins, 0.5, 0.2, use_min, lazy, ign)
+        lt = L.triplet_loss(ins[0], ins[1], ins[2], 0.5, use_min, lazy, ign)
+        lw = L.triplet_loss_wrapper(*ins, 0.5, 0.2, use_min, lazy, ign)
+        assert abs(lq.item() - rq) < 1e-5 * max(1, abs(rq)), (use_min, lazy, ign)
+        assert abs(lt.item() - rt) < 1e-5 * max(1, abs(rt))
+        assert abs(lw.item() - rw) < 1e-5 * max(1, abs(rw))
+        # gradients vs the oracle's autograd
+        lq.backward()
+        cins = [t.detach().cpu().requires_grad_(True) for t in ins]
+        orc.quadruplet_loss(*cins, 0.5, 0.2, use_min, lazy, ign).backward()
+        for a, b in zip(ins, cins):
+            assert torch.allclose(a.grad.cpu(), b.grad, atol=1e-6, rtol=1e-5), (use_min, lazy, ign)
+    q, pos, neg, oth = _loss_inputs(cuda)
+    mn, mx = L.best_pos_distance(q, pos)
+    assert np.allclose(mn.cpu().numpy(), g["min_pos"], rtol=1e-6) and np.allclose(mx.cpu().numpy(), g["max_pos"], rtol=1e-6)
+    # hand KAT
+    kq = torch.tensor([[[0., 0.]]], device=cuda); kp = torch.tensor([[[1., 0.], [0., 2.]]], device=cuda)
+    kn = torch.tensor([[[1., 1.], [3., 0.]]], device=cuda); ko = torch.tensor([[[2., 2.]]], device=cuda)
+    assert abs(L.quadruplet_loss(kq, kp, kn, ko, 0.5, 0.2, False, False, False).item() - 4.7) < 1e-6
+    assert abs(L.triplet_loss(kq, kp, kn, 0.5, False, False, False).item() - 2.5) < 1e-6
+    assert L.quadruplet_loss(kq, kp, kn, ko, 0.5, 0.2, True, True, False).item() == 0.0
+
+
+def test_loss_on_split_views(cuda):
+    """The callers pass non-contiguous views of one [bq, 1+P+Ng+1, D] tensor (train_pointnetvlad.py:214-217)."""
+    import loss.pointnetvlad_loss as L
+    bq, P, Ng, D = 2, 2, 18, 256
+    out = torch.from_numpy(synth.uniform("loss/views", bq * (P + Ng + 2) * D).astype(np.float32)).view(bq, -1, D) * 0.3
+    dev = out.to(cuda).requires_grad_(True)
+    parts = torch.split(dev, [1, P, Ng, 1], dim=1)
+    l = L.quadruplet_loss(*parts, 0.5, 0.2, use_min=True, lazy=True, ignore_zero_loss=False)
+    l.backward()
+    cpu = out.clone().requires_grad_(True)
+    lo = orc.quadruplet_loss(*torch.split(cpu, [1, P, Ng, 1], dim=1), 0.5, 0.2, True, True, False)
+    lo.backward()
+    assert abs(l.item() - lo.item()) < 1e-5 * max(1.0, abs(lo.item()))
+    assert torch.allclose(dev.grad.cpu(), cpu.grad, atol=1e-6, rtol=1e-5)
