@@ -63,12 +63,13 @@ int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* xx_
  *   batch > 1: strides sA/sB/sC in elements between problems
  *   splits > 1: split-K; splitk_ws must hold batch*splits*M*N floats; epilogue applied after the sum
  *   bias/scale/shift: [N] or NULL (scale and shift together)
+ *   accumulate != 0: C += result (after the epilogue) -- gradient accumulation in the backward pass
  * Requires K % (32*splits) == 0, lda/ldb/sA/sB % 4 == 0, A and B 16-byte aligned.
  */
 int lpd_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
              int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC, int splits,
              float* splitk_ws, const float* bias, const float* scale, const float* shift, int act, float slope,
-             void* stream);
+             int accumulate, void* stream);
 
 /*
  * kNN-graph aggregation (K-agg).  Replaces the gather/repeat/cat of util/lpdnet_model.py:331-363
@@ -115,9 +116,11 @@ int lpd_softmax_affine(const float* in, float* out, int rows, int ncols, const f
 
 /* NetVLAD residual + normalisations (util/PointNetVlad.py:61-74).
  *   vraw [B][F][KC] = act^T x per cloud, act [B][N][KC], cw2 [F][KC] (cluster_weights2[0]),
- *   out [B][F*KC]: (vraw - a_sum*cw2), L2-normalised over F per cluster, flattened f*KC+c, L2-normalised. KC = 64. */
-int lpd_vlad_finalize(const float* vraw, const float* act, const float* cw2, float* out, int B, int N, int F, int KC,
-                      void* stream);
+ *   out [B][F*KC]: (vraw - a_sum*cw2), L2-normalised over F per cluster, flattened f*KC+c, L2-normalised. KC = 64.
+ *   aux_asum [B][KC], aux_inv_c [B][KC], aux_inv_g [B]: optional (NULL in inference) -- a_sum and the two
+ *   reciprocal norms, saved for lpd_vlad_finalize_bwd. */
+int lpd_vlad_finalize(const float* vraw, const float* act, const float* cw2, float* out, float* aux_asum,
+                      float* aux_inv_c, float* aux_inv_g, int B, int N, int F, int KC, void* stream);
 
 /* Per-cloud max over the N points: in [B][N][ldi] -> out [B][C]
  * (util/PointNetVlad.py:137,162 mp1; util/lpdnet_model.py:300). */
@@ -140,6 +143,68 @@ int lpd_metric_loss(const float* q, long long q_sb, const float* pos, long long 
                     const float* neg, long long neg_sb, long long neg_st, const float* other, long long other_sb,
                     int bq, int P, int Ng, int D, float m1, float m2, int use_min, int lazy, int ignore_zero, int quad,
                     float* loss, float* minmax, float* gq, float* gpos, float* gneg, float* gother, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training path (forward in train mode + backward).  What `loss.backward()` does implicitly in the
+ * reference (train_pointnetvlad.py:129,158) through BatchNorm batch statistics, LeakyReLU, the max
+ * over k, the neighbour gather, softmax and the NetVLAD normalisations; dense products reuse lpd_gemm.
+ * fp64 buffers hold the statistics / reduction results ([C] doubles, caller-owned).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Column sums and sums of squares over R rows of X [R][ld] (BatchNorm batch statistics,
+ * nn.BatchNorm1d/2d in train mode).  C = 4*2^n <= 1024. */
+int lpd_colstats(const float* X, long long ld, long long R, int C, double* sum, double* sumsq, void* stream);
+
+/* From the sums: mean, biased variance -> scale = gamma/sqrt(var+eps), shift = beta - mean*scale, mean, invstd;
+ * updates running_mean / running_var in place (momentum, unbiased variance) when given. */
+int lpd_bn_finalize(const double* sum, const double* sumsq, double count, int C, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                    float* mean, float* invstd, void* stream);
+
+/* Y = act(scale * X + shift) elementwise per column (scale/shift NULL = identity affine).  In-place allowed. */
+int lpd_affine_act(const float* X, long long ldx, float* Y, long long ldy, long long R, int C, const float* scale,
+                   const float* shift, int act, float slope, void* stream);
+
+/* Backward of Y = act(BN(X)) given dY: dbeta = sum dpre, dgamma = sum dpre*xhat (fp64 [C]) and
+ * dX = scale*(dpre - dbeta/R - xhat*dgamma/R); has_bn = 0: plain activation backward (dbeta = bias gradient).
+ * X is the raw pre-BatchNorm tensor.  In-place (dX == dY) allowed. */
+int lpd_bn_act_bwd(const float* dY, long long lddy, const float* X, long long ldx, float* dX, long long lddx, long long R,
+                   int C, const float* scale, const float* shift, const float* mean, const float* invstd, int act,
+                   float slope, int has_bn, double* dbeta, double* dgamma, void* stream);
+
+/* Materialised edge tensor (training only): U[(i,t)] = P[nbr(i,t)] + Q[i], rows i*k+t, [M*k][C]
+ * (the split form of util/lpdnet_model.py:350-357 + the 1x1 conv).  C in {64,128,256}. */
+int lpd_edge_build(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, float* U, long long M,
+                   int N, int C, int k, void* stream);
+
+/* out[i][c] = act(scale[c] * sel_t X[(i,t)][c] + shift[c]) over k consecutive rows (x.max(dim=-1) after
+ * BatchNorm + activation, lpdnet_model.py:250,252,258); arg[i][c] = selected t (uint8). */
+int lpd_group_max(const float* X, long long ldx, int k, const float* scale, const float* shift, int act, float slope,
+                  float* out, long long ldo, uint8_t* arg, long long M, int C, void* stream);
+
+/* Backward of lpd_group_max w.r.t. the post-activation edge values: dX[(i,arg[i][c])][c] (+)= dOut[i][c];
+ * accumulate = 0 writes all k rows (zeros elsewhere). */
+int lpd_group_max_bwd(const float* dOut, long long ldo, const uint8_t* arg, int k, float* dX, long long M, int C,
+                      int accumulate, void* stream);
+
+/* dQ[i] = sum_t dU[(i,t)]  (gradient of the centre term). */
+int lpd_group_sum(const float* dU, int k, float* dQ, long long ldq, long long M, int C, void* stream);
+
+/* dP[nbr(i,t)] += dU[(i,t)]  (transpose of the neighbour gather; float atomics; dP zeroed by the caller). */
+int lpd_scatter_add_rows(const float* dU, const int32_t* idx, float* dP, long long ldp, long long M, int N, int k, int C,
+                         void* stream);
+
+/* dW[o][c] = sum_m dY[m][o] * X[m][c] for Kin <= 8 input channels (first layer weight gradient). */
+int lpd_dw_smallk(const float* dY, long long lddy, const float* X, long long ldx, long long M, int Co, int Kin, float* dW,
+                  void* stream);
+
+/* Softmax backward with the a_sum path folded in: dS = A*(g - sum_c A*g), g = dA + dasum[cloud]. */
+int lpd_softmax_bwd(const float* A, const float* dA, const float* dasum, float* dS, long long rows, int ncols,
+                    int rows_per_cloud, void* stream);
+
+/* Backward of lpd_vlad_finalize: dVraw [B][F][KC], dasum [B][KC], dcw2 [F][KC] (summed over clouds). */
+int lpd_vlad_finalize_bwd(const float* dOut, const float* v, const float* inv_c, const float* inv_g, const float* asum,
+                          const float* cw2, float* dVraw, float* dasum, float* dcw2, int B, int F, int KC, void* stream);
 
 #ifdef __cplusplus
 }

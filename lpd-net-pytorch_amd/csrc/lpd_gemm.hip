@@ -41,6 +41,7 @@ struct GemmArgs {
     const float* shift;   // [N] or null
     int act;
     float slope;
+    int accumulate;       // C += result (applied after the epilogue)
 };
 
 __device__ __forceinline__ float4 ld4_guard(const float* row, int i, int limit)
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
                     v += bi;
                     v = v * sc + sh;
                     v = lpd_act(v, g.act, g.slope);
+                    if (g.accumulate) v += C[(long long)m * g.ldc + n];
                 }
                 C[(long long)m * g.ldc + n] = v;
             }
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
 __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
                                           int ldc, int splits, long long slab_stride, long long sWs_batch,
                                           long long sC_batch, const float* bias, const float* scale,
-                                          const float* shift, int act, float slope)
+                                          const float* shift, int act, float slope, int accumulate)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int m = blockIdx.y;
@@ -233,7 +235,9 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slabs, float
     if (bias) v += bias[n];
     if (scale) v = v * scale[n] + shift[n];
     v = lpd_act(v, act, slope);
-    C[(long long)batch * sC_batch + (long long)m * ldc + n] = v;
+    float* dst = C + (long long)batch * sC_batch + (long long)m * ldc + n;
+    if (accumulate) v += *dst;
+    *dst = v;
 }
 
 template <bool AK, bool BK_, int TN>
@@ -257,7 +261,7 @@ int gemm_launch(const GemmArgs& g, int batch, hipStream_t stream)
 extern "C" int lpd_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                         int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC,
                         int splits, float* splitk_ws, const float* bias, const float* scale, const float* shift,
-                        int act, float slope, void* stream_)
+                        int act, float slope, int accumulate, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(A && B && C, "lpd_gemm: null pointer");
@@ -277,6 +281,7 @@ extern "C" int lpd_gemm(const float* A, const float* B, float* C, int M, int N, 
     g.sA = sA; g.sB = sB;
     g.splits = splits;
     g.bias = bias; g.scale = scale; g.shift = shift; g.act = act; g.slope = slope;
+    g.accumulate = accumulate;
     if (splits > 1) {
         g.C = splitk_ws; g.ldc = N; g.sC = (long long)splits * M * N; g.sCsplit = (long long)M * N;
     } else {
@@ -295,7 +300,7 @@ extern "C" int lpd_gemm(const float* A, const float* B, float* C, int M, int N, 
     if (splits > 1) {
         dim3 grid((N + 255) / 256, M, batch);
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, grid, dim3(256), 0, stream, (const float*)splitk_ws, C, M, N,
-                           ldc, splits, (long long)M * N, (long long)splits * M * N, sC, bias, scale, shift, act, slope);
+                           ldc, splits, (long long)M * N, (long long)splits * M * N, sC, bias, scale, shift, act, slope, accumulate);
         LPD_CHECK_LAUNCH("lpd_gemm(splitk reduce)");
     }
     return LPD_OK;

@@ -93,6 +93,7 @@ template <int KC>
 __global__ __launch_bounds__(256) void vlad_finalize_kernel(const float* __restrict__ vraw, const float* __restrict__ act,
                                                             const float* __restrict__ cw2,  // [F][KC]
                                                             float* __restrict__ out,        // [B][F*KC]
+                                                            float* aux_asum, float* aux_inv_c, float* aux_inv_g,  // optional (training)
                                                             int N, int F)
 {
     __shared__ float s_part[256];
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256) void vlad_finalize_kernel(const float* __restr
             float t = 0.0f;
             for (int r = 0; r < RPB; ++r) t += s_part[r * KC + tid];
             s_asum[tid] = t;
+            if (aux_asum) aux_asum[b * KC + tid] = t;
         }
         __syncthreads();
     }
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(256) void vlad_finalize_kernel(const float* __restr
         float t = 0.0f;
         for (int r = 0; r < RPB; ++r) t += s_part[r * KC + tid];
         s_inv[tid] = 1.0f / fmaxf(sqrtf(t), 1e-12f);  // F.normalize eps
+        if (aux_inv_c) aux_inv_c[b * KC + tid] = s_inv[tid];
     }
     __syncthreads();
     const float inv = s_inv[c];
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(256) void vlad_finalize_kernel(const float* __restr
     }
     float total = block_sum_256(tot, red);
     const float ginv = 1.0f / fmaxf(sqrtf(total), 1e-12f);
+    if (aux_inv_g && tid == 0) aux_inv_g[b] = ginv;
     for (int f = rg; f < F; f += RPB) o[(size_t)f * KC + c] *= ginv;
 }
 
@@ -214,14 +218,15 @@ extern "C" int lpd_softmax_affine(const float* in, float* out, int rows, int nco
     return LPD_OK;
 }
 
-extern "C" int lpd_vlad_finalize(const float* vraw, const float* act, const float* cw2, float* out, int B, int N,
-                                 int F, int KC, void* stream_)
+extern "C" int lpd_vlad_finalize(const float* vraw, const float* act, const float* cw2, float* out, float* aux_asum,
+                                 float* aux_inv_c, float* aux_inv_g, int B, int N, int F, int KC, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(vraw && act && cw2 && out, "lpd_vlad_finalize: null pointer");
     LPD_CHECK_ARG(B > 0 && N > 0 && F > 0, "lpd_vlad_finalize: bad dims");
     LPD_CHECK_ARG(KC == 64, "lpd_vlad_finalize: cluster_size=%d unsupported (64)", KC);
-    hipLaunchKernelGGL(vlad_finalize_kernel<64>, dim3(B), dim3(256), 0, stream, vraw, act, cw2, out, N, F);
+    hipLaunchKernelGGL(vlad_finalize_kernel<64>, dim3(B), dim3(256), 0, stream, vraw, act, cw2, out, aux_asum,
+                       aux_inv_c, aux_inv_g, N, F);
     LPD_CHECK_LAUNCH("lpd_vlad_finalize");
     return LPD_OK;
 }

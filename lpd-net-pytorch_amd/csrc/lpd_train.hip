@@ -1,0 +1,590 @@
+// lpd_train.hip -- bandwidth-bound kernels of the training path (forward in train mode + backward).
+//
+// What autograd does implicitly for the reference's `loss.backward()` (train_pointnetvlad.py:129,158)
+// through BatchNorm (batch statistics over all B*N points or all B*N*k edges), LeakyReLU, max over k,
+// the gather of get_graph_feature (lpdnet_model.py:350-357), softmax and the NetVLAD normalisations
+// (PointNetVlad.py:51-74) is written out here as explicit kernels; the dense products of the backward
+// pass (dX = dY W, dW = dY^T X) reuse lpd_gemm.hip.
+//
+// BatchNorm statistics and the backward reductions accumulate in fp64 (per-thread fp64 partials,
+// fp64 global atomics): the sums run over up to B*N*k = 3.6 M rows.
+#include "lpd_common.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float act_grad(float pre, int act, float slope)
+{
+    switch (act) {
+        case 1: return pre > 0.0f ? 1.0f : 0.0f;
+        case 2: return pre > 0.0f ? 1.0f : slope;
+        case 3: { float s = 1.0f / (1.0f + __expf(-pre)); return s * (1.0f - s); }
+        default: return 1.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// column statistics: sum and sum of squares over R rows.  C/4 <= 256 and 256 % (C/4) == 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ X, long long ld, long long R, int C,
+                                                       double* __restrict__ sum, double* __restrict__ sumsq)
+{
+    __shared__ double red[256][8];
+    const int Q = C >> 2;
+    const int RG = 256 / Q;
+    const int q = threadIdx.x % Q, rg = threadIdx.x / Q;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (long long r = (long long)blockIdx.x * RG + rg; r < R; r += (long long)gridDim.x * RG) {
+        const float4 v = *reinterpret_cast<const float4*>(X + r * ld + q * 4);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y; ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s[e]; red[threadIdx.x][4 + e] = ss[e]; }
+    __syncthreads();
+    if (rg == 0) {
+        for (int g = 1; g < RG; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[q][e] += red[g * Q + q][e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&sum[q * 4 + e], red[q][e]);
+            atomicAdd(&sumsq[q * 4 + e], red[q][4 + e]);
+        }
+    }
+}
+
+// mean / biased var -> scale, shift, mean, invstd; running-stat update (momentum, unbiased var)
+__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, double count, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                   float* running_var, float momentum, float eps, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ mean, float* __restrict__ invstd)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sum[c] / count;
+    double var = sumsq[c] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)gamma[c] * is);
+    scale[c] = sc;
+    shift[c] = (float)((double)beta[c] - m * (double)gamma[c] * is);
+    mean[c] = (float)m;
+    invstd[c] = (float)is;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
+// Y = act(scale * X + shift), float4 per thread.  In-place allowed.
+__global__ void affine_act_kernel(const float* __restrict__ X, long long ldx, float* __restrict__ Y, long long ldy,
+                                  long long R, int C, const float* __restrict__ scale, const float* __restrict__ shift,
+                                  int act, float slope)
+{
+    const int Q = C >> 2;
+    const long long total = R * Q;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / Q;
+        const int q = (int)(e - r * Q);
+        const float4 x = *reinterpret_cast<const float4*>(X + r * ldx + q * 4);
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale) { sc = *reinterpret_cast<const float4*>(scale + q * 4); sh = *reinterpret_cast<const float4*>(shift + q * 4); }
+        float4 y;
+        y.x = lpd_act(sc.x * x.x + sh.x, act, slope);
+        y.y = lpd_act(sc.y * x.y + sh.y, act, slope);
+        y.z = lpd_act(sc.z * x.z + sh.z, act, slope);
+        y.w = lpd_act(sc.w * x.w + sh.w, act, slope);
+        *reinterpret_cast<float4*>(Y + r * ldy + q * 4) = y;
+    }
+}
+
+// backward reductions of  Y = act(scale * X + shift):  dbeta = sum dpre, dgamma = sum dpre * xhat
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ dY, long long lddy,
+                                                                const float* __restrict__ X, long long ldx, long long R,
+                                                                int C, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int act, float slope,
+                                                                double* __restrict__ dbeta, double* __restrict__ dgamma)
+{
+    __shared__ double red[256][8];
+    const int Q = C >> 2;
+    const int RG = 256 / Q;
+    const int q = threadIdx.x % Q, rg = threadIdx.x / Q;
+    float sc[4] = {1, 1, 1, 1}, sh[4] = {0, 0, 0, 0}, mu[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (scale) { sc[e] = scale[q * 4 + e]; sh[e] = shift[q * 4 + e]; }
+        if (mean) { mu[e] = mean[q * 4 + e]; is[e] = invstd[q * 4 + e]; }
+    }
+    double sb[4] = {0, 0, 0, 0}, sg[4] = {0, 0, 0, 0};
+    for (long long r = (long long)blockIdx.x * RG + rg; r < R; r += (long long)gridDim.x * RG) {
+        const float4 xv = *reinterpret_cast<const float4*>(X + r * ldx + q * 4);
+        const float4 gv = *reinterpret_cast<const float4*>(dY + r * lddy + q * 4);
+        const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+        const float g[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dpre = g[e] * act_grad(sc[e] * x[e] + sh[e], act, slope);
+            sb[e] += dpre;
+            sg[e] += (double)dpre * ((x[e] - mu[e]) * is[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = sb[e]; red[threadIdx.x][4 + e] = sg[e]; }
+    __syncthreads();
+    if (rg == 0) {
+        for (int g = 1; g < RG; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[q][e] += red[g * Q + q][e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&dbeta[q * 4 + e], red[q][e]);
+            atomicAdd(&dgamma[q * 4 + e], red[q][4 + e]);
+        }
+    }
+}
+
+// dX = scale * (dpre - dbeta/R - xhat * dgamma/R)   (has_bn)   or   dX = dpre   (no BN).  In-place on dY allowed.
+__global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dY, long long lddy, const float* __restrict__ X,
+                                        long long ldx, float* __restrict__ dX, long long lddx, long long R, int C,
+                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                        const double* __restrict__ dbeta, const double* __restrict__ dgamma,
+                                        double count, int act, float slope, int has_bn)
+{
+    const int Q = C >> 2;
+    const long long total = R * Q;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / Q;
+        const int q = (int)(e - r * Q);
+        const float4 xv = *reinterpret_cast<const float4*>(X + r * ldx + q * 4);
+        const float4 gv = *reinterpret_cast<const float4*>(dY + r * lddy + q * 4);
+        const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+        const float g[4] = {gv.x, gv.y, gv.z, gv.w};
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ch = q * 4 + c;
+            const float sc = scale ? scale[ch] : 1.0f, sh = scale ? shift[ch] : 0.0f;
+            const float dpre = g[c] * act_grad(sc * x[c] + sh, act, slope);
+            if (has_bn) {
+                const float xhat = (x[c] - mean[ch]) * invstd[ch];
+                const float mb = (float)(dbeta[ch] / count), mg = (float)(dgamma[ch] / count);
+                o[c] = sc * (dpre - mb - xhat * mg);
+            } else {
+                o[c] = dpre;
+            }
+        }
+        *reinterpret_cast<float4*>(dX + r * lddx + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// edge tensors: rows (i, t) = i*k + t
+// ---------------------------------------------------------------------------------------------
+// U[(i,t)] = P[cloud(i)*N + idx[i][t]] + Q[i]      (lpdnet_model.py:350-357 gather + cat, in split form)
+template <int LPP>
+__global__ __launch_bounds__(256) void edge_build_kernel(const float* __restrict__ P, long long ldp,
+                                                         const float* __restrict__ Q, long long ldq,
+                                                         const int32_t* __restrict__ idx, float* __restrict__ U,
+                                                         long long M, int N, int k)
+{
+    constexpr int PPW = 64 / LPP;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPP, cl = lane % LPP;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+    const int C = LPP * 4;
+    for (long long w = wave; w * PPW < M; w += nw) {
+        const long long m = w * PPW + sub;
+        const bool ok = m < M;
+        const long long mm = ok ? m : M - 1;
+        const long long base = (mm / N) * N;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (Q) q = *reinterpret_cast<const float4*>(Q + mm * ldq + cl * 4);
+        for (int t = 0; t < k; ++t) {
+            const int j = idx[mm * k + t];
+            float4 p = *reinterpret_cast<const float4*>(P + (base + j) * ldp + cl * 4);
+            p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w;
+            if (ok) *reinterpret_cast<float4*>(U + (mm * k + t) * C + cl * 4) = p;
+        }
+    }
+}
+
+// out[i][c] = act(scale[c] * sel_t X[(i,t)][c] + shift[c]), arg[i][c] = the selected t
+__global__ void group_max_kernel(const float* __restrict__ X, long long ldx, int k, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, int act, float slope, float* __restrict__ out,
+                                 long long ldo, uint8_t* __restrict__ arg, long long M, int C)
+{
+    const int Q = C >> 2;
+    const long long total = M * Q;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long i = e / Q;
+        const int q = (int)(e - i * Q);
+        float mx[4], mn[4];
+        int amx[4] = {0, 0, 0, 0}, amn[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { mx[c] = -INFINITY; mn[c] = INFINITY; }
+        for (int t = 0; t < k; ++t) {
+            const float4 v4 = *reinterpret_cast<const float4*>(X + (i * k + t) * ldx + q * 4);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (v[c] > mx[c]) { mx[c] = v[c]; amx[c] = t; }   // first arg-max, like torch.max
+                if (v[c] < mn[c]) { mn[c] = v[c]; amn[c] = t; }
+            }
+        }
+        float o[4];
+        uint8_t a[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ch = q * 4 + c;
+            const float sc = scale[ch], sh = shift[ch];
+            const bool usemax = sc >= 0.0f;
+            o[c] = lpd_act(sc * (usemax ? mx[c] : mn[c]) + sh, act, slope);
+            a[c] = (uint8_t)(usemax ? amx[c] : amn[c]);
+        }
+        *reinterpret_cast<float4*>(out + i * ldo + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uchar4*>(arg + i * C + q * 4) = make_uchar4(a[0], a[1], a[2], a[3]);
+    }
+}
+
+// dX[(i,t)][c] (+)= (arg[i][c] == t) ? dOut[i][c] : 0      accumulate = 0 writes every row (zero fill included)
+__global__ void group_max_bwd_kernel(const float* __restrict__ dOut, long long ldo, const uint8_t* __restrict__ arg, int k,
+                                     float* __restrict__ dX, long long M, int C, int accumulate)
+{
+    const int Q = C >> 2;
+    const long long total = M * Q;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long i = e / Q;
+        const int q = (int)(e - i * Q);
+        const float4 g4 = *reinterpret_cast<const float4*>(dOut + i * ldo + q * 4);
+        const uchar4 a4 = *reinterpret_cast<const uchar4*>(arg + i * C + q * 4);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        const int a[4] = {a4.x, a4.y, a4.z, a4.w};
+        if (accumulate) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dX[(i * k + a[c]) * C + q * 4 + c] += g[c];
+        } else {
+            for (int t = 0; t < k; ++t) {
+                float4 v;
+                v.x = a[0] == t ? g[0] : 0.f; v.y = a[1] == t ? g[1] : 0.f;
+                v.z = a[2] == t ? g[2] : 0.f; v.w = a[3] == t ? g[3] : 0.f;
+                *reinterpret_cast<float4*>(dX + (i * k + t) * C + q * 4) = v;
+            }
+        }
+    }
+}
+
+// dQ[i] = sum_t dU[(i,t)]
+__global__ void group_sum_kernel(const float* __restrict__ dU, int k, float* __restrict__ dQ, long long ldq, long long M, int C)
+{
+    const int Q = C >> 2;
+    const long long total = M * Q;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long i = e / Q;
+        const int q = (int)(e - i * Q);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < k; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(dU + (i * k + t) * C + q * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dQ + i * ldq + q * 4) = s;
+    }
+}
+
+// dP[cloud(i)*N + idx[i][t]] += dU[(i,t)]   (transpose of the gather; float atomics, 256 contiguous bytes per wave op)
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ dU, const int32_t* __restrict__ idx,
+                                                               float* __restrict__ dP, long long ldp, long long M, int N,
+                                                               int k, int C)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long i = wave; i < M; i += nw) {
+        const long long base = (i / N) * N;
+        for (int t = 0; t < k; ++t) {
+            const int j = idx[i * k + t];
+            const float* src = dU + (i * k + t) * C;
+            float* dst = dP + (base + j) * ldp;
+            for (int c = lane; c < C; c += 64) atomicAdd(dst + c, src[c]);
+        }
+    }
+}
+
+// dW[o][c] = sum_m dY[m][o] * X[m][c], Kin <= 8 (first layer, lpdnet_model.py:185).  dW zeroed by the caller.
+__global__ __launch_bounds__(256) void dw_smallk_kernel(const float* __restrict__ dY, long long lddy,
+                                                        const float* __restrict__ X, long long ldx, long long M, int Co,
+                                                        int Kin, float* __restrict__ dW)
+{
+    // thread = (o, row group); Co <= 256 and 256 % Co == 0
+    __shared__ float red[256][8];
+    const int RG = 256 / Co;
+    const int o = threadIdx.x % Co, rg = threadIdx.x / Co;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long m = (long long)blockIdx.x * RG + rg; m < M; m += (long long)gridDim.x * RG) {
+        const float g = dY[m * lddy + o];
+        for (int c = 0; c < Kin; ++c) acc[c] += g * X[m * ldx + c];
+    }
+    for (int c = 0; c < 8; ++c) red[threadIdx.x][c] = acc[c];
+    __syncthreads();
+    if (rg == 0) {
+        for (int g = 1; g < RG; ++g)
+            for (int c = 0; c < Kin; ++c) red[o][c] += red[g * Co + o][c];
+        for (int c = 0; c < Kin; ++c) atomicAdd(&dW[o * Kin + c], red[o][c]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NetVLAD backward pieces
+// ---------------------------------------------------------------------------------------------
+// dS = A * (g - sum_c A*g),  g = dA + dasum[cloud]    (softmax backward, PointNetVlad.py:58; a_sum path :61)
+__global__ void softmax_bwd_kernel(const float* __restrict__ A, const float* __restrict__ dA, const float* __restrict__ dasum,
+                                   float* __restrict__ dS, long long rows, int ncols, int rows_per_cloud)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float a = 0.f, g = 0.f;
+    if (lane < ncols) {
+        a = A[row * ncols + lane];
+        g = dA[row * ncols + lane];
+        if (dasum) g += dasum[(row / rows_per_cloud) * ncols + lane];
+    }
+    float dot = a * g;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if (lane < ncols) dS[row * ncols + lane] = a * (g - dot);
+}
+
+__device__ __forceinline__ float block_sum_256t(float v, float* red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// backward of lpd_vlad_finalize.  v = final normalised vlad [B][F*KC]; inv_c [B][KC], inv_g [B], asum [B][KC] saved
+// by the forward.  Outputs dVraw [B][F][KC], dasum [B][KC], dcw2 [F][KC] (atomic accumulation over clouds; zeroed by caller).
+template <int KC>
+__global__ __launch_bounds__(256) void vlad_finalize_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ v,
+                                                                const float* __restrict__ inv_c, const float* __restrict__ inv_g,
+                                                                const float* __restrict__ asum, const float* __restrict__ cw2,
+                                                                float* __restrict__ dVraw, float* __restrict__ dasum,
+                                                                float* __restrict__ dcw2, int F)
+{
+    __shared__ float s_part[256];
+    __shared__ float s_col[KC];
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    constexpr int RPB = 256 / KC;
+    const int c = tid % KC, rg = tid / KC;
+    const float* dv = dOut + (size_t)b * F * KC;
+    const float* vv = v + (size_t)b * F * KC;
+    float* dr = dVraw + (size_t)b * F * KC;
+    const float ig = inv_g[b], ic = inv_c[b * KC + c], as = asum[b * KC + c];
+    // <dv, v> over the whole descriptor
+    float p = 0.f;
+    for (int f = rg; f < F; f += RPB) p += dv[(size_t)f * KC + c] * vv[(size_t)f * KC + c];
+    const float dvv = block_sum_256t(p, red);
+    // du = ig * (dv - v * <dv,v>);  u = v / ig;  per-column <du, u>
+    float pc = 0.f;
+    for (int f = rg; f < F; f += RPB) {
+        const float vf = vv[(size_t)f * KC + c];
+        const float du = ig * (dv[(size_t)f * KC + c] - vf * dvv);
+        pc += du * (vf / ig);
+    }
+    s_part[tid] = pc;
+    __syncthreads();
+    if (tid < KC) {
+        float t = 0.f;
+        for (int r = 0; r < RPB; ++r) t += s_part[r * KC + tid];
+        s_col[tid] = t;
+    }
+    __syncthreads();
+    const float duu = s_col[c];
+    float pa = 0.f;
+    for (int f = rg; f < F; f += RPB) {
+        const float vf = vv[(size_t)f * KC + c];
+        const float u = vf / ig;
+        const float du = ig * (dv[(size_t)f * KC + c] - vf * dvv);
+        const float d = ic * (du - u * duu);           // d r[f][c]
+        dr[(size_t)f * KC + c] = d;
+        const float w = cw2[(size_t)f * KC + c];
+        pa += d * w;
+        atomicAdd(&dcw2[(size_t)f * KC + c], -as * d);
+    }
+    __syncthreads();
+    s_part[tid] = pa;
+    __syncthreads();
+    if (tid < KC) {
+        float t = 0.f;
+        for (int r = 0; r < RPB; ++r) t += s_part[r * KC + tid];
+        dasum[b * KC + tid] = -t;
+    }
+}
+
+inline int grid_for(long long work_items, int per_block)
+{
+    long long b = (work_items + per_block - 1) / per_block;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+inline bool cols_ok(int C) { return C >= 4 && C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0; }
+
+}  // namespace
+
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int lpd_colstats(const float* X, long long ld, long long R, int C, double* sum, double* sumsq, void* stream)
+{
+    LPD_CHECK_ARG(X && sum && sumsq && R > 0, "lpd_colstats: bad arguments");
+    LPD_CHECK_ARG(cols_ok(C) && ld % 4 == 0, "lpd_colstats: C=%d must be 4*2^n <= 1024 and ld %% 4 == 0", C);
+    (void)hipMemsetAsync(sum, 0, sizeof(double) * C, ST(stream));
+    (void)hipMemsetAsync(sumsq, 0, sizeof(double) * C, ST(stream));
+    const int RG = 256 / (C / 4);
+    hipLaunchKernelGGL(colstats_kernel, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream), X, ld, R, C, sum, sumsq);
+    LPD_CHECK_LAUNCH("lpd_colstats");
+    return LPD_OK;
+}
+
+extern "C" int lpd_bn_finalize(const double* sum, const double* sumsq, double count, int C, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               float* scale, float* shift, float* mean, float* invstd, void* stream)
+{
+    LPD_CHECK_ARG(sum && sumsq && gamma && beta && scale && shift && mean && invstd && C > 0 && count > 0,
+                  "lpd_bn_finalize: bad arguments");
+    LPD_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "lpd_bn_finalize: running stats come in pairs");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), sum, sumsq, count, C, gamma,
+                       beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
+    LPD_CHECK_LAUNCH("lpd_bn_finalize");
+    return LPD_OK;
+}
+
+extern "C" int lpd_affine_act(const float* X, long long ldx, float* Y, long long ldy, long long R, int C,
+                              const float* scale, const float* shift, int act, float slope, void* stream)
+{
+    LPD_CHECK_ARG(X && Y && R > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "lpd_affine_act: bad arguments");
+    LPD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "lpd_affine_act: scale and shift come in pairs");
+    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(R * (C / 4), 256 * 4)), dim3(256), 0, ST(stream), X, ldx, Y, ldy, R,
+                       C, scale, shift, act, slope);
+    LPD_CHECK_LAUNCH("lpd_affine_act");
+    return LPD_OK;
+}
+
+extern "C" int lpd_bn_act_bwd(const float* dY, long long lddy, const float* X, long long ldx, float* dX, long long lddx,
+                              long long R, int C, const float* scale, const float* shift, const float* mean,
+                              const float* invstd, int act, float slope, int has_bn, double* dbeta, double* dgamma,
+                              void* stream)
+{
+    LPD_CHECK_ARG(dY && X && dX && dbeta && dgamma && R > 0, "lpd_bn_act_bwd: bad arguments");
+    LPD_CHECK_ARG(cols_ok(C) && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0, "lpd_bn_act_bwd: C=%d / leading dims unsupported", C);
+    LPD_CHECK_ARG(!has_bn || (scale && shift && mean && invstd), "lpd_bn_act_bwd: BatchNorm form needs scale/shift/mean/invstd");
+    (void)hipMemsetAsync(dbeta, 0, sizeof(double) * C, ST(stream));
+    (void)hipMemsetAsync(dgamma, 0, sizeof(double) * C, ST(stream));
+    const int RG = 256 / (C / 4);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream), dY, lddy, X, ldx, R, C,
+                       scale, shift, has_bn ? mean : nullptr, has_bn ? invstd : nullptr, act, slope, dbeta, dgamma);
+    LPD_CHECK_LAUNCH("lpd_bn_act_bwd(reduce)");
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(R * (C / 4), 256 * 4)), dim3(256), 0, ST(stream), dY, lddy, X,
+                       ldx, dX, lddx, R, C, scale, shift, mean, invstd, dbeta, dgamma, (double)R, act, slope, has_bn);
+    LPD_CHECK_LAUNCH("lpd_bn_act_bwd(apply)");
+    return LPD_OK;
+}
+
+extern "C" int lpd_edge_build(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, float* U,
+                              long long M, int N, int C, int k, void* stream)
+{
+    LPD_CHECK_ARG(P && idx && U && M > 0 && N > 0 && k > 0 && M % N == 0, "lpd_edge_build: bad arguments");
+    LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_build: C=%d unsupported (64/128/256)", C);
+    LPD_CHECK_ARG(ldp % 4 == 0 && (!Q || ldq % 4 == 0), "lpd_edge_build: leading dims must be multiples of 4");
+    const int lpp = C / 4;
+    const int g = grid_for((M + 64 / lpp - 1) / (64 / lpp), 4);
+    if (lpp == 64) hipLaunchKernelGGL(edge_build_kernel<64>, dim3(g), dim3(256), 0, ST(stream), P, ldp, Q, ldq, idx, U, M, N, k);
+    else if (lpp == 32) hipLaunchKernelGGL(edge_build_kernel<32>, dim3(g), dim3(256), 0, ST(stream), P, ldp, Q, ldq, idx, U, M, N, k);
+    else hipLaunchKernelGGL(edge_build_kernel<16>, dim3(g), dim3(256), 0, ST(stream), P, ldp, Q, ldq, idx, U, M, N, k);
+    LPD_CHECK_LAUNCH("lpd_edge_build");
+    return LPD_OK;
+}
+
+extern "C" int lpd_group_max(const float* X, long long ldx, int k, const float* scale, const float* shift, int act,
+                             float slope, float* out, long long ldo, uint8_t* arg, long long M, int C, void* stream)
+{
+    LPD_CHECK_ARG(X && scale && shift && out && arg && M > 0 && k > 0 && k <= 255, "lpd_group_max: bad arguments");
+    LPD_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "lpd_group_max: C and leading dims must be multiples of 4");
+    hipLaunchKernelGGL(group_max_kernel, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, ST(stream), X, ldx, k, scale, shift,
+                       act, slope, out, ldo, arg, M, C);
+    LPD_CHECK_LAUNCH("lpd_group_max");
+    return LPD_OK;
+}
+
+extern "C" int lpd_group_max_bwd(const float* dOut, long long ldo, const uint8_t* arg, int k, float* dX, long long M, int C,
+                                 int accumulate, void* stream)
+{
+    LPD_CHECK_ARG(dOut && arg && dX && M > 0 && k > 0 && C % 4 == 0 && ldo % 4 == 0, "lpd_group_max_bwd: bad arguments");
+    hipLaunchKernelGGL(group_max_bwd_kernel, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, ST(stream), dOut, ldo, arg, k, dX,
+                       M, C, accumulate);
+    LPD_CHECK_LAUNCH("lpd_group_max_bwd");
+    return LPD_OK;
+}
+
+extern "C" int lpd_group_sum(const float* dU, int k, float* dQ, long long ldq, long long M, int C, void* stream)
+{
+    LPD_CHECK_ARG(dU && dQ && M > 0 && k > 0 && C % 4 == 0 && ldq % 4 == 0, "lpd_group_sum: bad arguments");
+    hipLaunchKernelGGL(group_sum_kernel, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, ST(stream), dU, k, dQ, ldq, M, C);
+    LPD_CHECK_LAUNCH("lpd_group_sum");
+    return LPD_OK;
+}
+
+extern "C" int lpd_scatter_add_rows(const float* dU, const int32_t* idx, float* dP, long long ldp, long long M, int N, int k,
+                                    int C, void* stream)
+{
+    LPD_CHECK_ARG(dU && idx && dP && M > 0 && N > 0 && k > 0 && M % N == 0 && C > 0, "lpd_scatter_add_rows: bad arguments");
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for(M, 4)), dim3(256), 0, ST(stream), dU, idx, dP, ldp, M, N, k, C);
+    LPD_CHECK_LAUNCH("lpd_scatter_add_rows");
+    return LPD_OK;
+}
+
+extern "C" int lpd_dw_smallk(const float* dY, long long lddy, const float* X, long long ldx, long long M, int Co, int Kin,
+                             float* dW, void* stream)
+{
+    LPD_CHECK_ARG(dY && X && dW && M > 0, "lpd_dw_smallk: bad arguments");
+    LPD_CHECK_ARG(Co > 0 && Co <= 256 && 256 % Co == 0 && Kin > 0 && Kin <= 8, "lpd_dw_smallk: Co=%d Kin=%d unsupported", Co, Kin);
+    (void)hipMemsetAsync(dW, 0, sizeof(float) * Co * Kin, ST(stream));
+    hipLaunchKernelGGL(dw_smallk_kernel, dim3(grid_for(M, (256 / Co) * 64)), dim3(256), 0, ST(stream), dY, lddy, X, ldx, M, Co,
+                       Kin, dW);
+    LPD_CHECK_LAUNCH("lpd_dw_smallk");
+    return LPD_OK;
+}
+
+extern "C" int lpd_softmax_bwd(const float* A, const float* dA, const float* dasum, float* dS, long long rows, int ncols,
+                               int rows_per_cloud, void* stream)
+{
+    LPD_CHECK_ARG(A && dA && dS && rows > 0 && ncols > 0 && ncols <= 64 && rows_per_cloud > 0, "lpd_softmax_bwd: bad arguments");
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), A, dA, dasum, dS, rows,
+                       ncols, rows_per_cloud);
+    LPD_CHECK_LAUNCH("lpd_softmax_bwd");
+    return LPD_OK;
+}
+
+extern "C" int lpd_vlad_finalize_bwd(const float* dOut, const float* v, const float* inv_c, const float* inv_g,
+                                     const float* asum, const float* cw2, float* dVraw, float* dasum, float* dcw2, int B,
+                                     int F, int KC, void* stream)
+{
+    LPD_CHECK_ARG(dOut && v && inv_c && inv_g && asum && cw2 && dVraw && dasum && dcw2 && B > 0 && F > 0,
+                  "lpd_vlad_finalize_bwd: bad arguments");
+    LPD_CHECK_ARG(KC == 64, "lpd_vlad_finalize_bwd: cluster_size=%d unsupported (64)", KC);
+    (void)hipMemsetAsync(dcw2, 0, sizeof(float) * (size_t)F * KC, ST(stream));
+    hipLaunchKernelGGL(vlad_finalize_bwd_kernel<64>, dim3(B), dim3(256), 0, ST(stream), dOut, v, inv_c, inv_g, asum, cw2, dVraw,
+                       dasum, dcw2, F);
+    LPD_CHECK_LAUNCH("lpd_vlad_finalize_bwd");
+    return LPD_OK;
+}

@@ -78,15 +78,265 @@ def best_pos_distance(query, pos_vecs):
 
 
 # ------------------------------------------------------------------------------------------------
-# model training forward/backward (filled in below)
+# model training forward / backward
+#
+# Train-mode BatchNorm needs batch statistics over ALL B*N points (or all B*N*k edges) before any
+# normalised value exists, so the fused inference kernels do not apply.  The training formulation is:
+#   * per-point layers: raw GEMM -> column statistics -> affine+activation (3 passes over [M,C]);
+#   * edge stages: the edge tensor U[(i,t)] = P[nbr] + Q[i] IS materialised ([B*N*k, C] fp32 -- 1.85 GB at
+#     B=44, C=128; sized for 288 GB of HBM) so BatchNorm statistics, the DG2 convolution (a plain
+#     [E,128]x[128,128] GEMM) and every backward step are row-parallel kernels + lpd_gemm;
+#   * backward of the neighbour gather = group-sum (centre term) + atomic row scatter (neighbour term).
+# Gradients do not flow through the kNN indices (same as the reference: topk indices are not
+# differentiable) nor into the input cloud.
 # ------------------------------------------------------------------------------------------------
+LEAKY = 0.01
+
+
+def _pick_splits(R, tiles):
+    """split-K factor for a reduction over R rows: ~512 blocks, >= 8 k-tiles per block, R % (32*s) == 0."""
+    s = 1
+    while s * 2 * tiles <= 512 and R % (32 * s * 2) == 0 and R // (s * 2) >= 256:
+        s *= 2
+    return s
+
+
+def _dweight(dY, X, rows=None):
+    """dW [Co, Kin] = dY^T X over the first `rows` rows (reduction on the MFMA GEMM, split-K)."""
+    R = dY.shape[0] if rows is None else rows
+    Co, Kin = dY.shape[1], X.shape[1]
+    if Kin <= 8:
+        return ops.dw_smallk(dY[:R], X[:R])
+    if R % 32 != 0:
+        raise ValueError(f"weight-gradient GEMM needs the row count ({R}) to be a multiple of 32")
+    tiles = ((Co + 127) // 128) * ((Kin + 127) // 128)
+    return ops.gemm(dY[:R], X[:R], a_kmajor=True, b_kmajor=True, splits=_pick_splits(R, tiles))
+
+
+class _PointLayer:
+    """y = x W^T (raw) ; z = act(BN_train(y)).  Helper used inside the autograd Functions."""
+
+    @staticmethod
+    def fwd(x, w2d, bn, act, slope):
+        y = ops.linear(x, w2d)
+        st = ops.bn_train_stats(y, bn)
+        z = ops.affine_act(y, st.scale, st.shift, act, slope)
+        return y, st, z
+
+    @staticmethod
+    def bwd(dz, x, w2d, y, st, act, slope, need_dx=True, inplace=True):
+        dy, dgamma, dbeta = ops.bn_act_bwd(dz, y, st, act, slope, out=dz if inplace else None)
+        dw = _dweight(dy, x)
+        dx = ops.gemm(dy, w2d, b_kmajor=True) if need_dx else None               # dY [R,Co] x W [Co,Kin]
+        return dx, dw, dgamma, dbeta
+
+
+def _unsplit_cat_nc(dwcat, conv_weight):
+    """gradient of the stacked [W_n ; W_c] projection -> gradient of the conv weight [Co, 2Ci, 1, 1]."""
+    co = conv_weight.shape[0]
+    return torch.cat((dwcat[:co], dwcat[co:]), dim=1).reshape(conv_weight.shape)
+
+
+class _LPDNetTrainFn(torch.autograd.Function):
+    """LPDNet.forward in train mode (util/lpdnet_model.py:211-268, t3d = tfea = False)."""
+
+    PARAMS = ("conv1_lpd.weight", "bn1_lpd.weight", "bn1_lpd.bias", "conv2_lpd.weight", "bn2_lpd.weight", "bn2_lpd.bias",
+              "convDG1.0.weight", "convDG1.1.weight", "convDG1.1.bias", "convDG2.0.weight", "convDG2.1.weight",
+              "convDG2.1.bias", "convSN1.0.weight", "convSN1.1.weight", "convSN1.1.bias", "conv3_lpd.weight",
+              "bn3_lpd.weight", "bn3_lpd.bias")
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        from . import engine
+        B, N = x.shape[0], x.shape[2]
+        M, k = B * N, net.k
+        act, slope = (ops.ACT_RELU, 0.0) if net.use_relu else (ops.ACT_LEAKY, LEAKY)
+        w2d = engine._w2d
+        xyz = x.view(M, 3)
+        y1, st1, f1 = _PointLayer.fwd(xyz, w2d(net.conv1_lpd), net.bn1_lpd, act, slope)
+        y2, st2, f0 = _PointLayer.fwd(f1, w2d(net.conv2_lpd), net.bn2_lpd, act, slope)
+        idx_f = ops.knn(ops.transpose(f0.view(B, N, 64)), k)
+        cat = torch.empty((M, 512), dtype=torch.float32, device=x.device)
+        # DG1 (split projection, materialised edges)
+        wcat1 = engine.split_edge_weight(net.convDG1, "cat_nc")
+        pq1 = ops.linear(f0, wcat1)                                             # [M,256] = [P | Q]
+        u1 = ops.edge_build(pq1[:, :128], pq1[:, 128:], idx_f, N)               # [E,128] raw
+        stg1 = ops.bn_train_stats(u1, net.convDG1[1])
+        arg1 = ops.group_max(u1, k, stg1.scale, stg1.shift, act, slope, cat[:, 0:128])            # x1
+        y1e = ops.affine_act(u1, stg1.scale, stg1.shift, act, slope)            # [E,128] post-activation edges
+        # DG2 on every edge
+        z = ops.linear(y1e, w2d(net.convDG2[0]))                                # [E,128] raw
+        stg2 = ops.bn_train_stats(z, net.convDG2[1])
+        arg2 = ops.group_max(z, k, stg2.scale, stg2.shift, act, slope, cat[:, 128:256])           # x2
+        # SN1 on the xyz graph
+        idx_x = ops.knn(ops.transpose(x.view(B, N, 3)), k)
+        wcat3 = engine.split_edge_weight(net.convSN1, "cat_nc")
+        pq3 = ops.linear(cat[:, 128:256], wcat3)                                # [M,512]
+        u3 = ops.edge_build(pq3[:, :256], pq3[:, 256:], idx_x, N)               # [E,256] raw
+        stg3 = ops.bn_train_stats(u3, net.convSN1[1])
+        arg3 = ops.group_max(u3, k, stg3.scale, stg3.shift, act, slope, cat[:, 256:512])          # x3
+        y3, st3, feat = _PointLayer.fwd(cat, w2d(net.conv3_lpd), net.bn3_lpd, act, slope)
+        ctx.net, ctx.dims, ctx.actslope = net, (B, N, M, k), (act, slope)
+        ctx.saved = dict(xyz=xyz, y1=y1, st1=st1, f1=f1, y2=y2, st2=st2, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1,
+                         u1=u1, stg1=stg1, arg1=arg1, y1e=y1e, z=z, stg2=stg2, arg2=arg2, wcat3=wcat3, u3=u3, stg3=stg3,
+                         arg3=arg3, cat=cat, y3=y3, st3=st3)
+        if engine.DEBUG_AUX is not None:
+            engine.DEBUG_AUX.update(F0=f0, idx_feat=idx_f, idx_xyz=idx_x, cat=cat)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        from . import engine
+        net, S = ctx.net, ctx.saved
+        B, N, M, k = ctx.dims
+        act, slope = ctx.actslope
+        w2d = engine._w2d
+        dfeat = dfeat.contiguous()
+        # conv3 + bn3 (the incoming gradient buffer belongs to autograd: not modified in place)
+        dcat, dw3, dg3, db3 = _PointLayer.bwd(dfeat, S["cat"], w2d(net.conv3_lpd), S["y3"], S["st3"], act, slope,
+                                              inplace=False)
+        # SN1: x3 = groupmax(act(BN(U3)))
+        du3 = ops.group_max_bwd(dcat[:, 256:512], S["arg3"], k)                 # sparse rows, [E,256]
+        du3, dgs3, dbs3 = ops.bn_act_bwd(du3, S["u3"], S["stg3"], act, slope, out=du3)
+        dpq3 = torch.zeros((M, 512), dtype=torch.float32, device=dfeat.device)
+        ops.group_sum(du3, k, dpq3[:, 256:])
+        ops.scatter_add_rows(du3, S["idx_x"], dpq3[:, :256], N)
+        del du3
+        x2 = S["cat"][:, 128:256]
+        dwcat3 = _dweight(dpq3, x2)
+        ops.gemm(dpq3, S["wcat3"], b_kmajor=True, out=dcat[:, 128:256], accumulate=True)   # dx2 += dPQ3 Wcat3
+        # DG2: x2 = groupmax(act(BN(Z))), Z = Y1e W2^T
+        dz = ops.group_max_bwd(dcat[:, 128:256], S["arg2"], k)
+        dz, dgs2, dbs2 = ops.bn_act_bwd(dz, S["z"], S["stg2"], act, slope, out=dz)
+        dw2 = _dweight(dz, S["y1e"])
+        dy1e = ops.gemm(dz, w2d(net.convDG2[0]), b_kmajor=True)                 # [E,128]
+        del dz
+        # DG1: y1e = act(BN(U1)); consumers: DG2 (dense) and x1 = groupmax (sparse)
+        ops.group_max_bwd(dcat[:, 0:128], S["arg1"], k, dX=dy1e, accumulate=True)
+        du1, dgs1, dbs1 = ops.bn_act_bwd(dy1e, S["u1"], S["stg1"], act, slope, out=dy1e)
+        dpq1 = torch.zeros((M, 256), dtype=torch.float32, device=dfeat.device)
+        ops.group_sum(du1, k, dpq1[:, 128:])
+        ops.scatter_add_rows(du1, S["idx_f"], dpq1[:, :128], N)
+        del du1, dy1e
+        dwcat1 = _dweight(dpq1, S["f0"])
+        df0 = ops.gemm(dpq1, S["wcat1"], b_kmajor=True)                         # [M,64]
+        if engine.DEBUG_AUX is not None:
+            engine.DEBUG_AUX.update(dcat=dcat.clone(), dpq3=dpq3.clone(), dpq1=dpq1.clone(), df0=df0.clone())
+        # conv2 + bn2, conv1 + bn1
+        df1, dwc2, dg2, db2 = _PointLayer.bwd(df0, S["f1"], w2d(net.conv2_lpd), S["y2"], S["st2"], act, slope)
+        _, dwc1, dg1, db1 = _PointLayer.bwd(df1, S["xyz"], w2d(net.conv1_lpd), S["y1"], S["st1"], act, slope, need_dx=False)
+        grads = (dwc1.reshape(net.conv1_lpd.weight.shape), dg1, db1, dwc2.reshape(net.conv2_lpd.weight.shape), dg2, db2,
+                 _unsplit_cat_nc(dwcat1, net.convDG1[0].weight), dgs1, dbs1, dw2.reshape(net.convDG2[0].weight.shape), dgs2,
+                 dbs2, _unsplit_cat_nc(dwcat3, net.convSN1[0].weight), dgs3, dbs3, dw3.reshape(net.conv3_lpd.weight.shape),
+                 dg3, db3)
+        ctx.saved = None
+        return (None, None) + grads
+
+
+def _named(module, names):
+    out = []
+    for n in names:
+        obj = module
+        for part in n.split("."):
+            obj = obj[int(part)] if part.isdigit() else getattr(obj, part)
+        out.append(obj)
+    return out
+
+
 def lpdnet_features_train(net, x):
-    raise NotImplementedError("LPDNet training-mode forward is not built yet; call .eval() for inference")
+    """LPDNet training-mode forward: ([B*N, E] features with autograd, B, N)."""
+    from . import engine
+    if net.t3d or net.tfea:
+        raise NotImplementedError("training with the T-Nets (xyz_trans / feature_transform) is not built on the HIP path yet; "
+                                  "inference (.eval()) supports them")
+    x = engine._check_input(x)
+    params = _named(net, _LPDNetTrainFn.PARAMS)
+    feat = _LPDNetTrainFn.apply(net, x, *params)
+    return feat, x.shape[0], x.shape[2]
 
 
 def pointnet_features_train(net, x):
-    raise NotImplementedError("PointNetfeat training-mode forward is not built yet; call .eval() for inference")
+    raise NotImplementedError("PointNetfeat training-mode forward is not built on the HIP path yet (BASELINE configs[0] is the "
+                              "reference's CPU plumbing case); inference (.eval()) is supported")
+
+
+class _NetVLADTrainFn(torch.autograd.Function):
+    """NetVLADLoupe.forward + GatingContext in train mode (util/PointNetVlad.py:45-83,103-115)."""
+
+    PARAMS = ("cluster_weights", "cluster_weights2", "hidden1_weights", "bn1.weight", "bn1.bias", "bn2.weight", "bn2.bias",
+              "context_gating.gating_weights", "context_gating.bn1.weight", "context_gating.bn1.bias")
+
+    @staticmethod
+    def forward(ctx, vlad, B, N, feat, *params):
+        E, K, O = vlad.feature_size, vlad.cluster_size, vlad.output_dim
+        M = B * N
+        dev = feat.device
+        Bp = (B + 31) // 32 * 32                                    # rows padded so K = Bp weight-gradient GEMMs are legal
+        a0 = ops.gemm(feat, vlad.cluster_weights, b_kmajor=True)    # [M,K] raw
+        sta = ops.bn_train_stats(a0, vlad.bn1)
+        a = ops.softmax_affine(a0, sta.scale, sta.shift)
+        vraw = ops.gemm(feat.view(B, N, E), a.view(B, N, K), a_kmajor=True, b_kmajor=True)
+        aux = {}
+        v = torch.zeros((Bp, E * K), dtype=torch.float32, device=dev)
+        ops.vlad_finalize(vraw, a.view(B, N, K), vlad.cluster_weights2.view(E, K), out=v, aux=aux)
+        from . import engine
+        h0 = ops.gemm(v, vlad.hidden1_weights, b_kmajor=True, splits=engine._head_splits(E * K))     # [Bp,O] raw
+        sth = ops.bn_train_stats(h0, vlad.bn2, rows=B)
+        h = torch.zeros((Bp, O), dtype=torch.float32, device=dev)
+        ops.affine_act(h0, sth.scale, sth.shift, out=h, rows=B)
+        gc = vlad.context_gating
+        g0 = ops.gemm(h, gc.gating_weights, b_kmajor=True)           # [Bp,O] raw
+        stg = ops.bn_train_stats(g0, gc.bn1, rows=B)
+        gates = ops.affine_act(g0, stg.scale, stg.shift, ops.ACT_SIGMOID, rows=B)
+        out = ops.mul(h[:B], gates[:B])
+        ctx.vlad, ctx.dims = vlad, (B, N, M, E, K, O, Bp)
+        ctx.saved = dict(feat=feat, a0=a0, sta=sta, a=a, aux=aux, v=v, h0=h0, sth=sth, h=h, g0=g0, stg=stg, gates=gates)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        vlad, S = ctx.vlad, ctx.saved
+        B, N, M, E, K, O, Bp = ctx.dims
+        gc = vlad.context_gating
+        dev = dout.device
+        dout = dout.contiguous()
+        h, gates = S["h"], S["gates"]
+        # out = h * gates
+        dgates = torch.zeros((Bp, O), dtype=torch.float32, device=dev)
+        dgates[:B] = ops.mul(dout, h[:B])
+        dh = torch.zeros((Bp, O), dtype=torch.float32, device=dev)
+        dh[:B] = ops.mul(dout, gates[:B])
+        # gates = sigmoid(BN(g0)), g0 = h Wg
+        dg0, dgam_g, dbet_g = ops.bn_act_bwd(dgates, S["g0"], S["stg"], ops.ACT_SIGMOID, out=dgates, rows=B)
+        dwg = ops.gemm(h, dg0, a_kmajor=True, b_kmajor=True)                       # h^T dG0  [O,O]  (K = Bp, zero rows pad)
+        ops.gemm(dg0, gc.gating_weights, b_kmajor=False, out=dh, accumulate=True)  # dh += dG0 Wg^T
+        # h = BN(h0), h0 = v Wh
+        dh0, dgam_h, dbet_h = ops.bn_act_bwd(dh, S["h0"], S["sth"], ops.ACT_NONE, out=dh, rows=B)
+        if Bp > B:
+            dh0[B:].zero_()
+        dwh = ops.gemm(S["v"], dh0, a_kmajor=True, b_kmajor=True)                  # v^T dH0  [E*K, O]
+        dv = ops.gemm(dh0, vlad.hidden1_weights, b_kmajor=False)                   # dH0 Wh^T [Bp, E*K]
+        cw2 = vlad.cluster_weights2.view(E, K)
+        dvraw, dasum, dcw2 = ops.vlad_finalize_bwd(dv, S["v"], S["aux"], cw2, B, E, K)
+        del dv
+        feat, a = S["feat"], S["a"]
+        # vraw[b] = feat[b]^T a[b]
+        da = ops.gemm(feat.view(B, N, E), dvraw, a_kmajor=False, b_kmajor=True)    # [B,N,K]
+        dfeat = ops.gemm(a.view(B, N, K), dvraw, a_kmajor=False, b_kmajor=False)   # [B,N,E] = a dVraw^T
+        ds = ops.softmax_bwd(a, da.view(M, K), dasum, N)
+        da0, dgam_a, dbet_a = ops.bn_act_bwd(ds, S["a0"], S["sta"], ops.ACT_NONE, out=ds)
+        dwc = _dweight(feat, da0)                                                  # feat^T dA0 [E,K]
+        dfeat = dfeat.view(M, E)
+        ops.gemm(da0, vlad.cluster_weights, b_kmajor=False, out=dfeat, accumulate=True)   # += dA0 Wc^T
+        ctx.saved = None
+        return (None, None, None, dfeat, dwc, dcw2.view(1, E, K), dwh, dgam_a, dbet_a, dgam_h, dbet_h, dwg, dgam_g, dbet_g)
 
 
 def netvlad_train(vlad, feat, B, N):
-    raise NotImplementedError("NetVLADLoupe training-mode forward is not built yet; call .eval() for inference")
+    if not (vlad.add_batch_norm and vlad.gating):
+        raise NotImplementedError("NetVLADLoupe training on the HIP path is built for add_batch_norm=True, gating=True "
+                                  "(what PointNetVlad constructs, reference PointNetVlad.py:257-259)")
+    if N != vlad.max_samples:
+        raise ValueError(f"NetVLADLoupe was built for max_samples={vlad.max_samples}, got N={N}")
+    params = _named(vlad, _NetVLADTrainFn.PARAMS)
+    return _NetVLADTrainFn.apply(vlad, B, N, feat, *params)

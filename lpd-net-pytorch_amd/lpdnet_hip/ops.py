@@ -81,7 +81,7 @@ def knn(x_cm, k, impl=0):
 
 
 def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=None, act=ACT_NONE, slope=0.01,
-         out=None, splits=1):
+         out=None, splits=1, accumulate=False):
     """Single (2-D) or batched (3-D) GEMM with fused epilogue.
 
     A: [M,K] (a_kmajor False) or [K,M] (True); B: [K,N] (b_kmajor True) or [N,K] (False).
@@ -118,7 +118,7 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
     lib = _lib.load()
     _call(f"gemm[{M}x{N}x{K}]", lib.lpd_gemm, _ptr(A), _ptr(B), _ptr(out), M, N, K, lda, ldb, ldc, int(a_kmajor), int(b_kmajor), nb,
                             sA, sB, sC, splits, _ptr(ws), _ptr(bias), _ptr(scale), _ptr(shift), act, float(slope),
-                            _stream())
+                            int(bool(accumulate)), _stream())
     return out
 
 
@@ -240,15 +240,26 @@ def softmax_affine(x, scale=None, shift=None, out=None):
     return out
 
 
-def vlad_finalize(vraw, act, cw2):
-    """vraw [B,F,KC], act [B,N,KC], cw2 [F,KC] -> [B,F*KC] normalised VLAD."""
+def vlad_finalize(vraw, act, cw2, out=None, aux=None):
+    """vraw [B,F,KC], act [B,N,KC], cw2 [F,KC] -> [B,F*KC] normalised VLAD.
+
+    out: optional preallocated [>=B, F*KC] buffer (rows beyond B untouched); aux: optional dict that
+    receives asum [B,KC], inv_c [B,KC], inv_g [B] for the backward pass."""
     _req(vraw, "vraw"), _req(act, "act"), _req(cw2, "cw2")
     vraw, act, cw2 = vraw.contiguous(), act.contiguous(), cw2.contiguous()
     B, F, KC = vraw.shape
     N = act.shape[1]
-    out = torch.empty((B, F * KC), dtype=torch.float32, device=vraw.device)
+    if out is None:
+        out = torch.empty((B, F * KC), dtype=torch.float32, device=vraw.device)
+    a1 = a2 = a3 = None
+    if aux is not None:
+        a1 = torch.empty((B, KC), dtype=torch.float32, device=vraw.device)
+        a2 = torch.empty((B, KC), dtype=torch.float32, device=vraw.device)
+        a3 = torch.empty((B,), dtype=torch.float32, device=vraw.device)
+        aux.update(asum=a1, inv_c=a2, inv_g=a3)
     lib = _lib.load()
-    _call("vlad_finalize", lib.lpd_vlad_finalize, _ptr(vraw), _ptr(act), _ptr(cw2), _ptr(out), B, N, F, KC, _stream())
+    _call("vlad_finalize", lib.lpd_vlad_finalize, _ptr(vraw), _ptr(act), _ptr(cw2), _ptr(out), _ptr(a1), _ptr(a2), _ptr(a3), B, N, F,
+          KC, _stream())
     return out
 
 
@@ -271,3 +282,151 @@ def mul(a, b):
     lib = _lib.load()
     _call("mul", lib.lpd_mul, _ptr(a), _ptr(b), _ptr(out), a.numel(), _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# training-path wrappers (csrc/lpd_train.hip)
+# ------------------------------------------------------------------------------------------------
+class BNStats:
+    """Per-channel batch statistics of one BatchNorm application (all fp32 [C] device tensors)."""
+    __slots__ = ("scale", "shift", "mean", "invstd", "count")
+
+    def __init__(self, scale, shift, mean, invstd, count):
+        self.scale, self.shift, self.mean, self.invstd, self.count = scale, shift, mean, invstd, count
+
+
+def bn_train_stats(X, bn, rows=None):
+    """Batch statistics of X [R, C] rows (first `rows` rows) for nn.BatchNorm `bn` in train mode; updates
+    bn.running_mean / running_var / num_batches_tracked like torch does."""
+    ld = _rows(X, "X")
+    R = X.shape[0] if rows is None else rows
+    C = X.shape[1]
+    dev = X.device
+    sums = torch.empty((2, C), dtype=torch.float64, device=dev)
+    out = torch.empty((4, C), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _call("colstats", lib.lpd_colstats, _ptr(X), ld, R, C, _ptr(sums[0]), _ptr(sums[1]), _stream())
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    track = bn.track_running_stats and bn.running_mean is not None
+    _call("bn_finalize", lib.lpd_bn_finalize, _ptr(sums[0]), _ptr(sums[1]), float(R), C, _ptr(bn.weight), _ptr(bn.bias),
+          _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None, float(momentum),
+          float(bn.eps), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _stream())
+    if track:
+        bn.num_batches_tracked += 1
+    return BNStats(out[0], out[1], out[2], out[3], R)
+
+
+def affine_act(X, scale, shift, act=ACT_NONE, slope=0.01, out=None, rows=None):
+    ldx = _rows(X, "X")
+    R = X.shape[0] if rows is None else rows
+    C = X.shape[1]
+    if out is None:
+        out = torch.empty((X.shape[0], C), dtype=torch.float32, device=X.device)
+    ldy = _rows(out, "out")
+    lib = _lib.load()
+    _call("affine_act", lib.lpd_affine_act, _ptr(X), ldx, _ptr(out), ldy, R, C, _ptr(scale), _ptr(shift), act, float(slope),
+          _stream())
+    return out
+
+
+def bn_act_bwd(dY, X, st, act=ACT_NONE, slope=0.01, out=None, rows=None):
+    """Backward of Y = act(BN_train(X)) (st: BNStats) or of Y = act(X) (st None).
+    Returns (dX, dgamma fp32 [C], dbeta fp32 [C]).  out may alias dY (in-place)."""
+    lddy, ldx = _rows(dY, "dY"), _rows(X, "X")
+    R = X.shape[0] if rows is None else rows
+    C = X.shape[1]
+    if out is None:
+        out = torch.empty((dY.shape[0], C), dtype=torch.float32, device=X.device)
+    lddx = _rows(out, "out")
+    red = torch.empty((2, C), dtype=torch.float64, device=X.device)
+    lib = _lib.load()
+    has_bn = st is not None
+    _call("bn_act_bwd", lib.lpd_bn_act_bwd, _ptr(dY), lddy, _ptr(X), ldx, _ptr(out), lddx, R, C,
+          _ptr(st.scale) if has_bn else None, _ptr(st.shift) if has_bn else None, _ptr(st.mean) if has_bn else None,
+          _ptr(st.invstd) if has_bn else None, act, float(slope), int(has_bn), _ptr(red[0]), _ptr(red[1]), _stream())
+    redf = red.float()
+    return out, redf[1], redf[0]
+
+
+def edge_build(P, Q, idx, N):
+    ldp = _rows(P, "P")
+    ldq = _rows(Q, "Q") if Q is not None else 0
+    idx = idx.reshape(-1, idx.shape[-1])
+    M, C = P.shape
+    k = idx.shape[1]
+    U = torch.empty((M * k, C), dtype=torch.float32, device=P.device)
+    lib = _lib.load()
+    _call(f"edge_build[C={C}]", lib.lpd_edge_build, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(U), M, N, C, k, _stream())
+    return U
+
+
+def group_max(X, k, scale, shift, act, slope, out):
+    ldx, ldo = _rows(X, "X"), _rows(out, "out")
+    M, C = out.shape
+    if X.shape[0] != M * k or X.shape[1] != C:
+        raise ValueError("group_max: shape mismatch")
+    arg = torch.empty((M, C), dtype=torch.uint8, device=X.device)
+    lib = _lib.load()
+    _call(f"group_max[C={C}]", lib.lpd_group_max, _ptr(X), ldx, k, _ptr(scale), _ptr(shift), act, float(slope), _ptr(out), ldo,
+          _ptr(arg), M, C, _stream())
+    return arg
+
+
+def group_max_bwd(dOut, arg, k, dX=None, accumulate=False):
+    ldo = _rows(dOut, "dOut")
+    M, C = arg.shape
+    if dX is None:
+        dX = torch.empty((M * k, C), dtype=torch.float32, device=dOut.device)
+        accumulate = False
+    lib = _lib.load()
+    _call(f"group_max_bwd[C={C}]", lib.lpd_group_max_bwd, _ptr(dOut), ldo, _ptr(arg), k, _ptr(dX), M, C, int(accumulate),
+          _stream())
+    return dX
+
+
+def group_sum(dU, k, out):
+    ldq = _rows(out, "out")
+    M, C = out.shape
+    lib = _lib.load()
+    _call(f"group_sum[C={C}]", lib.lpd_group_sum, _ptr(dU), k, _ptr(out), ldq, M, C, _stream())
+    return out
+
+
+def scatter_add_rows(dU, idx, dP, N):
+    """dP[nbr(i,t)] += dU[(i,t)]; dP must be zero-initialised (or hold a partial sum)."""
+    ldp = _rows(dP, "dP")
+    idx = idx.reshape(-1, idx.shape[-1])
+    M, C = dP.shape
+    k = idx.shape[1]
+    lib = _lib.load()
+    _call(f"scatter_add_rows[C={C}]", lib.lpd_scatter_add_rows, _ptr(dU), _ptr(idx), _ptr(dP), ldp, M, N, k, C, _stream())
+    return dP
+
+
+def dw_smallk(dY, X):
+    lddy, ldx = _rows(dY, "dY"), _rows(X, "X")
+    M, Co = dY.shape
+    Kin = X.shape[1]
+    dW = torch.empty((Co, Kin), dtype=torch.float32, device=dY.device)
+    lib = _lib.load()
+    _call("dw_smallk", lib.lpd_dw_smallk, _ptr(dY), lddy, _ptr(X), ldx, M, Co, Kin, _ptr(dW), _stream())
+    return dW
+
+
+def softmax_bwd(A, dA, dasum, rows_per_cloud):
+    rows, n = A.shape
+    dS = torch.empty_like(A)
+    lib = _lib.load()
+    _call("softmax_bwd", lib.lpd_softmax_bwd, _ptr(A), _ptr(dA), _ptr(dasum), _ptr(dS), rows, n, rows_per_cloud, _stream())
+    return dS
+
+
+def vlad_finalize_bwd(dOut, v, aux, cw2, B, F, KC):
+    dev = dOut.device
+    dVraw = torch.empty((B, F, KC), dtype=torch.float32, device=dev)
+    dasum = torch.empty((B, KC), dtype=torch.float32, device=dev)
+    dcw2 = torch.empty((F, KC), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _call("vlad_finalize_bwd", lib.lpd_vlad_finalize_bwd, _ptr(dOut), _ptr(v), _ptr(aux["inv_c"]), _ptr(aux["inv_g"]),
+          _ptr(aux["asum"]), _ptr(cw2), _ptr(dVraw), _ptr(dasum), _ptr(dcw2), B, F, KC, _stream())
+    return dVraw, dasum, dcw2

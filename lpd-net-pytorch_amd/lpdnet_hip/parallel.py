@@ -1,0 +1,80 @@
+"""Data-parallel training: one process per GPU, weights resident per rank, gradients averaged with
+bucketed all-reduce over RCCL/xGMI (torch.distributed backend "nccl" IS RCCL on ROCm).
+
+Replaces the reference's `nn.DataParallel(para.model)` (train_pointnetvlad.py:79-81): a single process
+that re-broadcasts all 17.6 M parameters (70 MB) to every GPU each step, scatters clouds, gathers outputs
+on GPU 0 and reduce-adds gradients there.  Here each rank owns whole tuples (BatchNorm statistics stay
+per rank, as under DataParallel) and the only exchange per step is the gradient all-reduce:
+
+  * `net_vlad.hidden1_weights` (65536x256 fp32 = 67 MB, 95 % of all gradient bytes) becomes ready FIRST in
+    backward (the NetVLAD head is differentiated before the trunk), so its all-reduce is launched
+    immediately from a post-accumulate hook and overlaps with the trunk's backward kernels;
+  * every other gradient (3.3 MB in total) is flattened into one bucket and reduced at the end of
+    backward -- xGMI is point-to-point (7 links x ~153 GB/s per GPU), ring collectives are per-link bound,
+    so few large messages beat many small ones.
+
+The wrapper is backend-agnostic (tested with gloo on CPU, world_size 2).
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class GradAllReduce(nn.Module):
+    def __init__(self, module, process_group=None, big_bytes=8 << 20, broadcast_from=0):
+        super().__init__()
+        if not dist.is_initialized():
+            raise RuntimeError("GradAllReduce needs torch.distributed to be initialised (one process per GPU)")
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.big_bytes = big_bytes
+        self._handles = []
+        self._small = []
+        self._finalize_queued = False
+        # identical replicas to start from
+        with torch.no_grad():
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=broadcast_from, group=process_group)
+        for p in module.parameters():
+            if p.requires_grad:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    # -- hooks ------------------------------------------------------------------------------------
+    def _on_grad(self, p):
+        if self.world == 1:
+            return
+        if not self._finalize_queued:
+            self._finalize_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+        if p.grad.numel() * p.grad.element_size() >= self.big_bytes:
+            self._handles.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+        else:
+            self._small.append(p)
+
+    def _finalize(self):
+        """End of backward: reduce the bucket of small gradients, wait for everything, divide by world."""
+        try:
+            if self._small:
+                flat = torch.cat([p.grad.reshape(-1) for p in self._small])
+                h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._handles.append((h, flat, list(self._small)))
+            inv = 1.0 / self.world
+            big = []
+            for h, flat, plist in self._handles:
+                h.wait()
+                if flat is not None:
+                    off = 0
+                    for p in plist:
+                        n = p.grad.numel()
+                        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                        p.grad.mul_(inv)
+                        off += n
+            for p in self.module.parameters():
+                if p.grad is not None and p.grad.numel() * p.grad.element_size() >= self.big_bytes:
+                    p.grad.mul_(inv)
+        finally:
+            self._handles, self._small, self._finalize_queued = [], [], False
