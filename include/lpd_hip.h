@@ -48,7 +48,8 @@ const char* lpd_last_error(void);
  *   idx    [B][N][k] int32, the k largest pd = -|x_i - x_j|^2 (reference arithmetic order, see
  *          csrc/lpd_knn.hip), descending; self is included; ties -> lower index first.
  *   xx_ws  workspace [B][N] floats (per-point sum of squares)
- *   impl   0 = f32-MFMA distance tiles (product path); 1 = VALU fmaf cross-check (k <= 20)
+ *   impl   0 = f32-MFMA distance tiles + queued selection (product path); 1 = VALU fmaf cross-check (k <= 20);
+ *          2 = first-generation MFMA kernel with in-scan insertion (kept for A/B timing)
  * Supported: C <= 256, k <= 64, k <= N.  Bit-exact vs the reference CPU path on tie-free rows.
  */
 int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* xx_ws, int impl, void* stream);
@@ -117,9 +118,10 @@ int lpd_softmax_affine(const float* in, float* out, int rows, int ncols, const f
 /* NetVLAD residual + normalisations (util/PointNetVlad.py:61-74).
  *   vraw [B][F][KC] = act^T x per cloud, act [B][N][KC], cw2 [F][KC] (cluster_weights2[0]),
  *   out [B][F*KC]: (vraw - a_sum*cw2), L2-normalised over F per cluster, flattened f*KC+c, L2-normalised. KC = 64.
+ *   ws: workspace of B*2*KC floats (a_sum and per-cluster sums of squares, zeroed here).
  *   aux_asum [B][KC], aux_inv_c [B][KC], aux_inv_g [B]: optional (NULL in inference) -- a_sum and the two
  *   reciprocal norms, saved for lpd_vlad_finalize_bwd. */
-int lpd_vlad_finalize(const float* vraw, const float* act, const float* cw2, float* out, float* aux_asum,
+int lpd_vlad_finalize(const float* vraw, const float* act, const float* cw2, float* out, float* ws, float* aux_asum,
                       float* aux_inv_c, float* aux_inv_g, int B, int N, int F, int KC, void* stream);
 
 /* Per-cloud max over the N points: in [B][N][ldi] -> out [B][C]
@@ -143,6 +145,11 @@ int lpd_metric_loss(const float* q, long long q_sb, const float* pos, long long 
                     const float* neg, long long neg_sb, long long neg_st, const float* other, long long other_sb,
                     int bq, int P, int Ng, int D, float m1, float m2, int use_min, int lazy, int ignore_zero, int quad,
                     float* loss, float* minmax, float* gq, float* gpos, float* gneg, float* gother, void* stream);
+
+/* Per-cloud Morton (Z-order) reordering of the input points: out[b][r] = xyz[b][perm[b][r]].  The descriptor is
+ * invariant to point order; sorting makes the neighbour gathers of the aggregation kernels cache-local.
+ * xyz/out [B][N][3] (out != xyz), perm [B][N] int32 or NULL.  N <= 16384. */
+int lpd_morton_sort(const float* xyz, float* out, int32_t* perm, int B, int N, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training path (forward in train mode + backward).  What `loss.backward()` does implicitly in the

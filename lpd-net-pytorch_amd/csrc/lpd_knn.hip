@@ -251,6 +251,241 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Product path (impl 0): wave-independent streaming kNN.
+//
+// Lessons from the first two generations (profiles/r01a, r01b): (1) inserting into the sorted register list
+// inside the scan executes the ~100-instruction insertion on almost every candidate step, because the
+// probability that ANY of the 64 lanes accepts is ~1 even when each lane accepts 5 %; (2) sharing staged
+// candidate chunks through LDS couples the waves of a block at a barrier every chunk, so one wave's list
+// maintenance stalls all others.  This kernel therefore
+//   * gives every wave its own 32 queries and lets it stream the candidates straight from L2 into MFMA operand
+//     registers (channel-major input => each operand fetch is two coalesced 128-B segments); no block barrier
+//     in the scan; blocks are remapped so that one XCD walks whole clouds and their features stay in its L2;
+//   * phase A: exact top-k of the ~96 candidates around the query's own tile (clouds are Z-ordered by
+//     lpd_morton.hip, so these are spatial neighbours) gives a per-query admission threshold T0 that at least
+//     k candidates are known to reach;
+//   * phase B: one ascending scan of all candidates; the fast path per candidate is 3 VALU for pd, a compare
+//     against max(T0, current k-th best) and an exec-masked 8-byte append to the lane's LDS queue; queues are
+//     drained into the register lists only when a lane could overflow on the next tile (wave vote).
+// Results are identical to the reference arithmetic (bit-exact pd, ties -> lower index first).
+// ---------------------------------------------------------------------------------------------
+constexpr int KNN3_WAVES = 4;
+constexpr int KNN3_THREADS = KNN3_WAVES * 64;
+constexpr int KNN3_QCAP = 24;   // queue slots per lane; a tile can add 16
+
+// per-lane operand fetch of candidate tile j0: a[s] = x[2s+h][j0+col] (zero beyond C or N)
+template <int CP>
+__device__ __forceinline__ float knn3_ld_a(const float* __restrict__ xb, int C, int N, int j0, int col, int h, int s)
+{
+    const int j = j0 + col;
+    const int c = 2 * s + h;
+    return (j < N && c < C) ? xb[(size_t)c * N + j] : 0.0f;
+}
+
+// squared norms of the 16 candidate rows this lane receives from the MFMA (rows 8g+4h+{0..3}); NaN for padding
+__device__ __forceinline__ void knn3_ld_xx(const float* __restrict__ xxb, int N, int j0, int h, bool vec_ok, float4 (&x4)[4])
+{
+    const float nanv = __builtin_nanf("");   // padded candidates: pd = NaN, never admitted
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int r0 = j0 + 8 * g + 4 * h;
+        if (vec_ok && r0 + 3 < N) {
+            x4[g] = *reinterpret_cast<const float4*>(xxb + r0);
+        } else {
+            x4[g].x = r0 + 0 < N ? xxb[r0 + 0] : nanv;
+            x4[g].y = r0 + 1 < N ? xxb[r0 + 1] : nanv;
+            x4[g].z = r0 + 2 < N ? xxb[r0 + 2] : nanv;
+            x4[g].w = r0 + 3 < N ? xxb[r0 + 3] : nanv;
+        }
+    }
+}
+
+// One tile: pd of 32 candidates x 32 queries on the MFMA.  Each operand register is refilled with the NEXT tile's
+// value right after the MFMA that consumed it has issued, so the loads for tile t+1 fly under tile t's MFMAs and
+// selection without a second register set.
+template <int CP>
+__device__ __forceinline__ void knn3_tile(float (&a)[CP], float4 (&x4)[4], const float (&qreg)[CP], float xq,
+                                          const float* __restrict__ xb, const float* __restrict__ xxb, int C, int N,
+                                          int j_next, bool have_next, int col, int h, bool vec_ok, float (&pd)[16])
+{
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < CP; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], qreg[s], acc, 0, 0, 0);
+        if (have_next) a[s] = knn3_ld_a<CP>(xb, C, N, j_next, col, h, s);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float4 xv = x4[r >> 2];
+        const float xxj = (r & 3) == 0 ? xv.x : (r & 3) == 1 ? xv.y : (r & 3) == 2 ? xv.z : xv.w;
+        const float inner = __fmul_rn(-2.0f, acc[r]);
+        const float tt = __fsub_rn(-xxj, inner);
+        pd[r] = __fsub_rn(tt, xq);
+    }
+    if (have_next) knn3_ld_xx(xxb, N, j_next, h, vec_ok, x4);
+}
+
+template <int CP, int KMAX>
+__global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __restrict__ x, const float* __restrict__ xx,
+                                                             int32_t* __restrict__ idx, int C, int N, int k, int blocks_per_cloud)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int h = lane >> 5;
+    const int col = lane & 31;
+    // XCD-aware: each XCD takes a contiguous range of (cloud, query-block) items => whole clouds per L2
+    const int vb = lpd_xcd_remap(blockIdx.x, gridDim.x);
+    const int b = vb / blocks_per_cloud;
+    const int qb = vb - b * blocks_per_cloud;
+    const int q0 = qb * (KNN3_WAVES * 32) + wave * 32;   // first query of this wave
+    const int q = q0 + col;
+    const bool q_ok = q < N;
+    const float* xb = x + (size_t)b * C * N;
+    const float* xxb = xx + (size_t)b * N;
+    const bool vec_ok = (N & 3) == 0;
+    float2* myq = reinterpret_cast<float2*>(smem) + (size_t)wave * KNN3_QCAP * 64 + lane;   // slot s at myq[s*64]
+
+    float qreg[CP];
+#pragma unroll
+    for (int s = 0; s < CP; ++s) {
+        const int c = 2 * s + h;
+        qreg[s] = (q_ok && c < C) ? xb[(size_t)c * N + q] : 0.0f;
+    }
+    const float xq = q_ok ? xxb[q] : 0.0f;
+
+    float lv[KMAX];
+    int li[KMAX];
+    auto reset_lists = [&]() {
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) {
+            lv[s] = -INFINITY;
+            li[s] = 0x7fffffff;
+        }
+    };
+    reset_lists();
+
+    const int ntiles = (N + 31) / 32;
+    float a[CP];
+    float4 x4[4];
+    float pd[16];
+
+    // ---- phase A: admission threshold from the tiles around the wave's own tile ----
+    {
+        const int t_own = q0 / 32;
+        int t_lo = t_own - 1, t_hi = t_own + 2;                 // 3 tiles = 96 candidates
+        while ((t_hi - t_lo) * 16 < KMAX) { --t_lo; ++t_hi; }   // each half-wave must see >= KMAX candidates
+        if (t_lo < 0) { t_hi -= t_lo; t_lo = 0; }
+        if (t_hi > ntiles) { t_lo -= t_hi - ntiles; t_hi = ntiles; }
+        if (t_lo < 0) t_lo = 0;
+#pragma unroll
+        for (int s = 0; s < CP; ++s) a[s] = knn3_ld_a<CP>(xb, C, N, t_lo * 32, col, h, s);
+        knn3_ld_xx(xxb, N, t_lo * 32, h, vec_ok, x4);
+        for (int t = t_lo; t < t_hi; ++t) {
+            knn3_tile<CP>(a, x4, qreg, xq, xb, xxb, C, N, (t + 1) * 32, t + 1 < t_hi, col, h, vec_ok, pd);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (pd[r] > lv[KMAX - 1]) knn_insert<KMAX>(lv, li, pd[r], 0);
+        }
+    }
+    // k-th best of my half; the larger of the two halves' values is reached by >= k candidates overall
+    float t0 = k <= KMAX ? lv[KMAX - 1] : -INFINITY;
+    {
+        // lists hold KMAX >= k entries: use the k-th (index k-1) when k < KMAX would be tighter, but k is a runtime
+        // value and the list is in registers; the KMAX-th is a valid (slightly looser) bound
+        const float other = __shfl_xor(t0, 32, 64);
+        t0 = fmaxf(t0, other);
+        if (!(t0 > -INFINITY)) t0 = -INFINITY;   // fewer than KMAX local candidates (tiny N): admit everything
+    }
+    reset_lists();
+
+    // ---- phase B: ascending scan with queued selection ----
+    int cnt = 0;
+    auto drain = [&]() {
+        for (int e = 0; __any(e < cnt); ++e) {
+            if (e < cnt) {
+                const float2 ent = myq[e * 64];
+                if (ent.x > lv[KMAX - 1]) knn_insert<KMAX>(lv, li, ent.x, __float_as_int(ent.y));   // FIFO => j ascending
+            }
+        }
+        cnt = 0;
+    };
+#pragma unroll
+    for (int s = 0; s < CP; ++s) a[s] = knn3_ld_a<CP>(xb, C, N, 0, col, h, s);
+    knn3_ld_xx(xxb, N, 0, h, vec_ok, x4);
+    for (int t = 0; t < ntiles; ++t) {
+        knn3_tile<CP>(a, x4, qreg, xq, xb, xxb, C, N, (t + 1) * 32, t + 1 < ntiles, col, h, vec_ok, pd);
+        const float thr = fmaxf(t0, lv[KMAX - 1]);
+        const bool list_full = lv[KMAX - 1] > -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // before the list is full every candidate reaching T0 is admitted; afterwards it must beat the k-th best
+            const bool admit = list_full ? (pd[r] > thr) : (pd[r] >= thr);
+            if (admit) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                myq[cnt * 64] = make_float2(pd[r], __int_as_float(t * 32 + row));
+                ++cnt;
+            }
+        }
+        if (__any(cnt > KNN3_QCAP - 16)) drain();
+    }
+    drain();
+
+    // ---- merge the two half-lists (queue region of this wave is free now; DS ops of a wave execute in order) ----
+    float* mv = smem + (size_t)wave * KNN3_QCAP * 128;   // wave region: QCAP*64 float2 = QCAP*128 floats >= 2*32*KMAX
+    int* mi = reinterpret_cast<int*>(mv + 32 * KMAX);
+    if (h == 1) {
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) {
+            mv[col * KMAX + s] = lv[s];
+            mi[col * KMAX + s] = li[s];
+        }
+    }
+    __syncthreads();
+    if (h == 0) {
+        for (int e = 0; e < KMAX; ++e) {
+            const float pv = mv[col * KMAX + e];
+            const int pj = mi[col * KMAX + e];
+            const bool enters = (pv > lv[KMAX - 1]) || (pv == lv[KMAX - 1] && pj < li[KMAX - 1]);
+            if (!enters) break;
+            knn_insert_any<KMAX>(lv, li, pv, pj);
+        }
+        if (q_ok) {
+            int32_t* out = idx + ((size_t)b * N + q) * k;
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s)
+                if (s < k) out[s] = li[s];
+        }
+    }
+}
+
+template <int CP, int KMAX>
+int knn3_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream)
+{
+    static_assert(KNN3_QCAP * 128 >= 2 * 32 * KMAX, "merge region must fit the wave's queue region");
+    size_t lds = (size_t)KNN3_WAVES * KNN3_QCAP * 64 * sizeof(float2);
+    const int bpc = (N + KNN3_WAVES * 32 - 1) / (KNN3_WAVES * 32);
+    auto kern = knn3_kernel<CP, KMAX>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(KNN3_THREADS), lds, stream, x, xx, idx, C, N, k, bpc);
+    LPD_CHECK_LAUNCH("lpd_knn");
+    return LPD_OK;
+}
+
+template <int CP>
+int knn_dispatch_k(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, int impl, hipStream_t stream);
+
+template <int CP>
+int knn3_dispatch_k(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream)
+{
+    if (k <= 20) return knn3_launch<CP, 20>(x, xx, idx, B, C, N, k, stream);
+    if (k <= 32) return knn3_launch<CP, 32>(x, xx, idx, B, C, N, k, stream);
+    // k > 32: a 64-entry register list; the first-generation kernel (one wave per SIMD, 512 VGPRs) takes those
+    return knn_dispatch_k<CP>(x, xx, idx, B, C, N, k, 0, stream);
+}
+
 template <int CP, int KMAX>
 int knn_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, int impl,
                hipStream_t stream)
@@ -302,9 +537,16 @@ extern "C" int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
     LPD_CHECK_ARG(B <= 65535, "lpd_knn: B=%d exceeds grid.y", B);
     hipLaunchKernelGGL(knn_sumsq_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xx_ws, C, N);
     LPD_CHECK_LAUNCH("lpd_knn(sumsq)");
-    if (C <= 4) return knn_dispatch_k<2>(x, xx_ws, idx, B, C, N, k, impl, stream);
-    if (C <= 64) return knn_dispatch_k<32>(x, xx_ws, idx, B, C, N, k, impl, stream);
-    if (C <= 256) return knn_dispatch_k<128>(x, xx_ws, idx, B, C, N, k, impl, stream);
+    if (impl == 0) {
+        if (C <= 4) return knn3_dispatch_k<2>(x, xx_ws, idx, B, C, N, k, stream);
+        if (C <= 64) return knn3_dispatch_k<32>(x, xx_ws, idx, B, C, N, k, stream);
+        if (C <= 256) return knn_dispatch_k<128>(x, xx_ws, idx, B, C, N, k, 0, stream);   // wide features: v1
+    } else {
+        const int v1impl = impl == 1 ? 1 : 0;   // 1: VALU cross-check, 2: v1 MFMA + in-scan insertion
+        if (C <= 4) return knn_dispatch_k<2>(x, xx_ws, idx, B, C, N, k, v1impl, stream);
+        if (C <= 64) return knn_dispatch_k<32>(x, xx_ws, idx, B, C, N, k, v1impl, stream);
+        if (C <= 256) return knn_dispatch_k<128>(x, xx_ws, idx, B, C, N, k, v1impl, stream);
+    }
     lpd_set_error("lpd_knn: C=%d > 256 unsupported", C);
     return LPD_ERR_UNSUPPORTED;
 }

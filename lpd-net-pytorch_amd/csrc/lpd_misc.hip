@@ -88,68 +88,89 @@ __device__ __forceinline__ float block_sum_256(float v, float* red)
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// one block (256 threads) per cloud.  vraw [B][F][KC] (index f*KC + c), act [B][N][KC].
+// NetVLAD finalize in three multi-block passes (grid y = cloud), vraw [B][F][KC] (index f*KC + c), act [B][N][KC]:
+//   1. a_sum[b][c] = sum_n act[b][n][c]                         (atomics into ws[b][0..KC))
+//   2. r = vraw - a_sum * cw2 -> out ; column sums of squares    (atomics into ws[b][KC..2KC))
+//   3. out *= inv_c[c] * inv_g, inv_c = 1/max(|r[:,c]|, eps), inv_g = 1/max(sqrt(sum_c |r[:,c]|^2 inv_c^2), eps)
+// (after the intra-normalisation every non-degenerate column has unit norm, so the global norm follows from the
+//  column norms alone -- no third reduction over the 65536 values).
 template <int KC>
-__global__ __launch_bounds__(256) void vlad_finalize_kernel(const float* __restrict__ vraw, const float* __restrict__ act,
-                                                            const float* __restrict__ cw2,  // [F][KC]
-                                                            float* __restrict__ out,        // [B][F*KC]
-                                                            float* aux_asum, float* aux_inv_c, float* aux_inv_g,  // optional (training)
-                                                            int N, int F)
+__global__ __launch_bounds__(256) void vlad_asum_kernel(const float* __restrict__ act, float* __restrict__ ws, int N)
 {
-    __shared__ float s_part[256];
-    __shared__ float s_asum[KC];
-    __shared__ float s_inv[KC];
-    __shared__ float red[4];
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x;
-    constexpr int RPB = 256 / KC;  // row groups
+    __shared__ float part[256];
+    constexpr int RPB = 256 / KC;
+    const int b = blockIdx.y, tid = threadIdx.x;
     const int c = tid % KC, rg = tid / KC;
-    // a_sum[c] = sum_n act[n][c]
-    {
-        const float* a = act + (size_t)b * N * KC;
-        float s = 0.0f;
-        for (int n = rg; n < N; n += RPB) s += a[(size_t)n * KC + c];
-        s_part[tid] = s;
-        __syncthreads();
-        if (tid < KC) {
-            float t = 0.0f;
-            for (int r = 0; r < RPB; ++r) t += s_part[r * KC + tid];
-            s_asum[tid] = t;
-            if (aux_asum) aux_asum[b * KC + tid] = t;
-        }
-        __syncthreads();
+    const int chunk = (N + gridDim.x - 1) / gridDim.x;
+    const int n0 = blockIdx.x * chunk, n1 = min(n0 + chunk, N);
+    const float* a = act + (size_t)b * N * KC;
+    float s = 0.0f;
+    for (int n = n0 + rg; n < n1; n += RPB) s += a[(size_t)n * KC + c];
+    part[tid] = s;
+    __syncthreads();
+    if (tid < KC) {
+        float t = 0.0f;
+        for (int r = 0; r < RPB; ++r) t += part[r * KC + tid];
+        atomicAdd(&ws[(size_t)b * 2 * KC + tid], t);
     }
-    // residual + per-cluster squared norm over f
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void vlad_resid_kernel(const float* __restrict__ vraw, const float* __restrict__ cw2,
+                                                         float* __restrict__ out, float* __restrict__ ws, int F, int FCH)
+{
+    __shared__ float part[256];
+    constexpr int RPB = 256 / KC;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int c = tid % KC, rg = tid / KC;
+    const int f0 = blockIdx.x * FCH, f1 = min(f0 + FCH, F);
     const float* v = vraw + (size_t)b * F * KC;
     float* o = out + (size_t)b * F * KC;
-    const float as = s_asum[c];
+    const float as = ws[(size_t)b * 2 * KC + c];
     float ss = 0.0f;
-    for (int f = rg; f < F; f += RPB) {
+    for (int f = f0 + rg; f < f1; f += RPB) {
         float r = v[(size_t)f * KC + c] - as * cw2[(size_t)f * KC + c];
         o[(size_t)f * KC + c] = r;
         ss += r * r;
     }
-    __syncthreads();
-    s_part[tid] = ss;
+    part[tid] = ss;
     __syncthreads();
     if (tid < KC) {
         float t = 0.0f;
-        for (int r = 0; r < RPB; ++r) t += s_part[r * KC + tid];
-        s_inv[tid] = 1.0f / fmaxf(sqrtf(t), 1e-12f);  // F.normalize eps
-        if (aux_inv_c) aux_inv_c[b * KC + tid] = s_inv[tid];
+        for (int r = 0; r < RPB; ++r) t += part[r * KC + tid];
+        atomicAdd(&ws[(size_t)b * 2 * KC + KC + tid], t);
+    }
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void vlad_scale_kernel(float* __restrict__ out, const float* __restrict__ ws,
+                                                         float* aux_asum, float* aux_inv_c, float* aux_inv_g, int F, int FCH)
+{
+    __shared__ float s_inv[KC];
+    __shared__ float s_g;
+    constexpr int RPB = 256 / KC;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int c = tid % KC, rg = tid / KC;
+    if (tid < KC) {
+        const float inv = 1.0f / fmaxf(sqrtf(ws[(size_t)b * 2 * KC + KC + tid]), 1e-12f);   // F.normalize eps
+        s_inv[tid] = inv;
+        if (blockIdx.x == 0) {
+            if (aux_inv_c) aux_inv_c[b * KC + tid] = inv;
+            if (aux_asum) aux_asum[b * KC + tid] = ws[(size_t)b * 2 * KC + tid];
+        }
     }
     __syncthreads();
-    const float inv = s_inv[c];
-    float tot = 0.0f;
-    for (int f = rg; f < F; f += RPB) {
-        float r = o[(size_t)f * KC + c] * inv;
-        o[(size_t)f * KC + c] = r;
-        tot += r * r;
+    if (tid == 0) {
+        float tot = 0.0f;
+        for (int k = 0; k < KC; ++k) tot += ws[(size_t)b * 2 * KC + KC + k] * s_inv[k] * s_inv[k];
+        s_g = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+        if (aux_inv_g && blockIdx.x == 0) aux_inv_g[b] = s_g;
     }
-    float total = block_sum_256(tot, red);
-    const float ginv = 1.0f / fmaxf(sqrtf(total), 1e-12f);
-    if (aux_inv_g && tid == 0) aux_inv_g[b] = ginv;
-    for (int f = rg; f < F; f += RPB) o[(size_t)f * KC + c] *= ginv;
+    __syncthreads();
+    const float sc = s_inv[c] * s_g;
+    const int f0 = blockIdx.x * FCH, f1 = min(f0 + FCH, F);
+    float* o = out + (size_t)b * F * KC;
+    for (int f = f0 + rg; f < f1; f += RPB) o[(size_t)f * KC + c] *= sc;
 }
 
 // per-cloud column max: in [B][N][C] -> out [B][C].  grid (ceil(C/64), B), 256 threads = 4 row groups x 64 cols
@@ -218,16 +239,25 @@ extern "C" int lpd_softmax_affine(const float* in, float* out, int rows, int nco
     return LPD_OK;
 }
 
-extern "C" int lpd_vlad_finalize(const float* vraw, const float* act, const float* cw2, float* out, float* aux_asum,
-                                 float* aux_inv_c, float* aux_inv_g, int B, int N, int F, int KC, void* stream_)
+extern "C" int lpd_vlad_finalize(const float* vraw, const float* act, const float* cw2, float* out, float* ws,
+                                 float* aux_asum, float* aux_inv_c, float* aux_inv_g, int B, int N, int F, int KC,
+                                 void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    LPD_CHECK_ARG(vraw && act && cw2 && out, "lpd_vlad_finalize: null pointer");
-    LPD_CHECK_ARG(B > 0 && N > 0 && F > 0, "lpd_vlad_finalize: bad dims");
+    LPD_CHECK_ARG(vraw && act && cw2 && out && ws, "lpd_vlad_finalize: null pointer");
+    LPD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && F > 0, "lpd_vlad_finalize: bad dims");
     LPD_CHECK_ARG(KC == 64, "lpd_vlad_finalize: cluster_size=%d unsupported (64)", KC);
-    hipLaunchKernelGGL(vlad_finalize_kernel<64>, dim3(B), dim3(256), 0, stream, vraw, act, cw2, out, aux_asum,
-                       aux_inv_c, aux_inv_g, N, F);
-    LPD_CHECK_LAUNCH("lpd_vlad_finalize");
+    (void)hipMemsetAsync(ws, 0, sizeof(float) * (size_t)B * 2 * KC, stream);
+    const int nchunks = N >= 1024 ? 16 : (N + 63) / 64;
+    hipLaunchKernelGGL(vlad_asum_kernel<64>, dim3(nchunks, B), dim3(256), 0, stream, act, ws, N);
+    LPD_CHECK_LAUNCH("lpd_vlad_finalize(asum)");
+    const int FCH = 64;
+    const int fblocks = (F + FCH - 1) / FCH;
+    hipLaunchKernelGGL(vlad_resid_kernel<64>, dim3(fblocks, B), dim3(256), 0, stream, vraw, cw2, out, ws, F, FCH);
+    LPD_CHECK_LAUNCH("lpd_vlad_finalize(resid)");
+    hipLaunchKernelGGL(vlad_scale_kernel<64>, dim3(fblocks, B), dim3(256), 0, stream, out, (const float*)ws, aux_asum,
+                       aux_inv_c, aux_inv_g, F, FCH);
+    LPD_CHECK_LAUNCH("lpd_vlad_finalize(scale)");
     return LPD_OK;
 }
 

@@ -249,7 +249,7 @@ def lpdnet_features_train(net, x):
     if net.t3d or net.tfea:
         raise NotImplementedError("training with the T-Nets (xyz_trans / feature_transform) is not built on the HIP path yet; "
                                   "inference (.eval()) supports them")
-    x = engine._check_input(x)
+    x = engine.reorder_points(engine._check_input(x))
     params = _named(net, _LPDNetTrainFn.PARAMS)
     feat = _LPDNetTrainFn.apply(net, x, *params)
     return feat, x.shape[0], x.shape[2]

@@ -18,6 +18,18 @@ LEAKY_SLOPE = 0.01
 # test hook: when set to a dict, the trunks drop intermediate tensors into it (idx_feat, idx_xyz, F0, cat)
 DEBUG_AUX = None
 
+# Z-order the points of each cloud once per forward (descriptor is order-invariant; makes the neighbour
+# gathers cache-local).  Tests switch it off to compare intermediate index tensors in the caller's order.
+MORTON_ORDER = True
+MORTON_MAX_POINTS = 16384
+
+
+def reorder_points(x):
+    """x [B,1,N,3] -> Z-ordered copy (or x itself when disabled / too large)."""
+    if MORTON_ORDER and 64 <= x.shape[2] <= MORTON_MAX_POINTS:
+        return ops.morton_sort(x)
+    return x
+
 
 # ------------------------------------------------------------------------------------------------
 # cached derived parameters
@@ -131,7 +143,7 @@ def stn3d_eval(net, h, B, N):
 # ------------------------------------------------------------------------------------------------
 def lpdnet_features_eval(net, x):
     """util/lpdnet_model.py:211-268 (LPDNet.forward), eval mode."""
-    x = _check_input(x)
+    x = reorder_points(_check_input(x))
     B, N = x.shape[0], x.shape[2]
     M = B * N
     k = net.k
@@ -170,7 +182,7 @@ def lpdnet_features_eval(net, x):
 
 def lpdnet_origin_features_eval(net, x):
     """util/lpdnet_model.py:68-114 (LPDNetOrign.forward), eval mode."""
-    x = _check_input(x)
+    x = reorder_points(_check_input(x))
     B, N = x.shape[0], x.shape[2]
     M = B * N
     k = net.k

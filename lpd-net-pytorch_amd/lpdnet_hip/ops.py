@@ -66,8 +66,13 @@ def _vec(t, name, n):
     return t.contiguous()
 
 
-def knn(x_cm, k, impl=0):
+KNN_IMPL = int(__import__("os").environ.get("LPD_KNN_IMPL", "0"))   # A/B switch for benchmarking (0 = product kernel)
+
+
+def knn(x_cm, k, impl=None):
     """x_cm [B,C,N] channel-major fp32 -> idx [B,N,k] int32 (reference util/lpdnet_model.py:317-326)."""
+    if impl is None:
+        impl = KNN_IMPL
     _req(x_cm, "x")
     if x_cm.dim() != 3:
         raise ValueError("knn: expected [B,C,N]")
@@ -257,9 +262,10 @@ def vlad_finalize(vraw, act, cw2, out=None, aux=None):
         a2 = torch.empty((B, KC), dtype=torch.float32, device=vraw.device)
         a3 = torch.empty((B,), dtype=torch.float32, device=vraw.device)
         aux.update(asum=a1, inv_c=a2, inv_g=a3)
+    ws = torch.empty((B, 2 * KC), dtype=torch.float32, device=vraw.device)
     lib = _lib.load()
-    _call("vlad_finalize", lib.lpd_vlad_finalize, _ptr(vraw), _ptr(act), _ptr(cw2), _ptr(out), _ptr(a1), _ptr(a2), _ptr(a3), B, N, F,
-          KC, _stream())
+    _call("vlad_finalize", lib.lpd_vlad_finalize, _ptr(vraw), _ptr(act), _ptr(cw2), _ptr(out), _ptr(ws), _ptr(a1), _ptr(a2),
+          _ptr(a3), B, N, F, KC, _stream())
     return out
 
 
@@ -282,6 +288,20 @@ def mul(a, b):
     lib = _lib.load()
     _call("mul", lib.lpd_mul, _ptr(a), _ptr(b), _ptr(out), a.numel(), _stream())
     return out
+
+
+def morton_sort(x, want_perm=False):
+    """x [B,1,N,3] or [B,N,3] -> points reordered along a Z-order curve per cloud (same shape); N <= 16384."""
+    _req(x, "x")
+    shape = x.shape
+    x3 = x.reshape(-1, shape[-2], 3).contiguous()
+    B, N = x3.shape[0], x3.shape[1]
+    out = torch.empty_like(x3)
+    perm = torch.empty((B, N), dtype=torch.int32, device=x.device) if want_perm else None
+    lib = _lib.load()
+    _call("morton_sort", lib.lpd_morton_sort, _ptr(x3), _ptr(out), _ptr(perm), B, N, _stream())
+    out = out.view(shape)
+    return (out, perm) if want_perm else out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -29,8 +29,9 @@ def _rel(a, b):
 # ------------------------------------------------------------------ kNN
 @pytest.mark.parametrize("C,N,k,B", [(3, 4096, 20, 2), (64, 4096, 20, 2), (3, 100, 7, 3), (5, 333, 20, 2),
                                       (64, 1000, 20, 1), (3, 16384, 64, 1), (130, 512, 32, 1), (3, 64, 64, 1)])
-@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("impl", [0, 1, 2])
 def test_knn_bit_exact_vs_oracle(cuda, C, N, k, B, impl):
+    """impl 0: product kernel (MFMA tiles + queued selection); 1: VALU fmaf cross-check; 2: first-generation MFMA kernel."""
     if impl == 1 and (k > 20 or N > 4096):
         pytest.skip("VALU cross-check path is built for k <= 20 and is slow")
     ops = _ops()
@@ -57,6 +58,26 @@ def test_knn_vs_reference_golden(cuda, golden_dir, tag):
     ok = (idx == g["idx"].astype(np.int32)).all(-1)
     bad = ~ok & ~g["tie"]
     assert bad.sum() == 0, f"{bad.sum()} tie-free rows differ from the reference"
+
+
+def test_morton_sort_is_a_permutation_and_improves_locality(cuda):
+    ops = _ops()
+    pts = torch.from_numpy(synth.cloud(12, 3, 4096)).to(cuda)
+    out, perm = ops.morton_sort(pts, want_perm=True)
+    p = perm.cpu().long()
+    assert (torch.sort(p, dim=1)[0] == torch.arange(4096)).all()                 # a permutation per cloud
+    assert torch.equal(out.cpu(), torch.gather(pts.cpu(), 1, p.unsqueeze(-1).expand(-1, -1, 3)))
+    # consecutive points are close after sorting, far before
+    d_sorted = (out[:, 1:] - out[:, :-1]).norm(dim=-1).mean().item()
+    d_raw = (pts[:, 1:] - pts[:, :-1]).norm(dim=-1).mean().item()
+    assert d_sorted < 0.25 * d_raw
+    # kNN on the sorted cloud = relabelled kNN of the original cloud (tie-free rows)
+    idx_s = ops.knn(out.transpose(1, 2).contiguous(), 20).cpu().long()
+    idx_o = ops.knn(pts.transpose(1, 2).contiguous(), 20).cpu().long()
+    relabelled = torch.gather(p, 1, idx_s.reshape(3, -1)).reshape(3, 4096, 20)      # sorted-row r, neighbours in original ids
+    expect = torch.gather(idx_o, 1, p.unsqueeze(-1).expand(-1, -1, 20))             # original kNN rows in sorted order
+    same = (torch.sort(relabelled, dim=-1)[0] == torch.sort(expect, dim=-1)[0]).all(-1).float().mean().item()
+    assert same > 0.995   # equal up to rows with (near-)ties: pd depends on summation order only through ties
 
 
 # ------------------------------------------------------------------ GEMM

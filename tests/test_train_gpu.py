@@ -85,11 +85,13 @@ def test_train_grads_vs_oracle(cuda, bq, P, Ng, N):
     m, sd0 = _train_model(N, cuda)
     xc = torch.from_numpy(synth.cloud(21, B, N)).unsqueeze(1)
     engine.DEBUG_AUX = {}
+    engine.MORTON_ORDER = False   # compare index tensors in the caller's point order
     try:
         out, loss = _step(m, xc.to(cuda), bq, P, Ng)
         aux = engine.DEBUG_AUX
     finally:
         engine.DEBUG_AUX = None
+        engine.MORTON_ORDER = True
     graphs = iter([aux["idx_feat"].cpu().long(), aux["idx_xyz"].cpu().long()])
     dt = torch.float64
     sd = {k: (v.to(dt).requires_grad_(True) if v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var"))
