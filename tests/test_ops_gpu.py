@@ -29,11 +29,14 @@ def _rel(a, b):
 # ------------------------------------------------------------------ kNN
 @pytest.mark.parametrize("C,N,k,B", [(3, 4096, 20, 2), (64, 4096, 20, 2), (3, 100, 7, 3), (5, 333, 20, 2),
                                       (64, 1000, 20, 1), (3, 16384, 64, 1), (130, 512, 32, 1), (3, 64, 64, 1)])
-@pytest.mark.parametrize("impl", [0, 1, 2])
+@pytest.mark.parametrize("impl", [0, 1, 2, 3])
 def test_knn_bit_exact_vs_oracle(cuda, C, N, k, B, impl):
-    """impl 0: product kernel (MFMA tiles + queued selection); 1: VALU fmaf cross-check; 2: first-generation MFMA kernel."""
+    """impl 0: streaming kernel (MFMA tiles + queued selection); 1: VALU fmaf cross-check; 2: first-generation MFMA kernel;
+    3: LDS-staged stream + admission threshold + queued selection."""
     if impl == 1 and (k > 20 or N > 4096):
         pytest.skip("VALU cross-check path is built for k <= 20 and is slow")
+    if impl == 3 and (k > 20 or C > 64):
+        pytest.skip("impl 3 is built for k <= 20, C <= 64")
     ops = _ops()
     x_pm = synth.cloud(1000 + C + N, B, N, C)
     oidx, _ = orc.knn_np(x_pm, k)
