@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-KAGG_BYTES_PER_POINT = 3152  # C=256, k=20, fp32, split form: P row + Q row + out row + idx
+KAGG_ROW_BYTES = 3 * 256 * 4   # C=256 fp32, split form: P row + Q row + out row; + 4*k for the indices
 
 
 def parse():
@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="clouds per step per GPU (eval_batch_size)")
     ap.add_argument("--points", type=int, default=4096)
+    ap.add_argument("--k", type=int, default=20, help="neighbours per point (reference hard-codes 20; configs[4] uses 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary quadruplet train-step measurement")
     ap.add_argument("--train-steps", type=int, default=5)
@@ -162,6 +163,7 @@ def main():
             m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
             m.weight.data.copy_(0.5 + torch.rand(m.weight.shape, generator=g))
             m.bias.data.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+    model.emb_nn.k = args.k
     model = model.to(dev).eval()
 
     gen = torch.Generator().manual_seed(1234 + rank)
@@ -206,16 +208,16 @@ def main():
     key = "edge_gather_max[C=256]"
     if key in kern:
         t_s = kern[key]["avg_us"] * 1e-6
-        alg = KAGG_BYTES_PER_POINT * args.batch * args.points
+        alg = (KAGG_ROW_BYTES + 4 * args.k) * args.batch * args.points
         ach = alg / t_s / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "kagg_pmc.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and (args.batch, args.points, args.k) == (32, 4096, 20):   # PMC run is for the default workload
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof = {"kernel": "edge_gather_max_kernel<64> (SN1 stage, C=256, k=20)", "bound": "hbm", "achieved": round(ach, 1),
+        roof = {"kernel": f"edge_gather_max_kernel<64> (SN1 stage, C=256, k={args.k})", "bound": "hbm", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_us": kern[key]["avg_us"]}
 
@@ -231,8 +233,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (U[-1,1)^3 clouds resident in HBM, seed 1234+rank; random-init weights, randomised BN statistics)",
-            "config": {"workload": "BASELINE configs[1]: LPD-Net (featnet=lpdnet, emb_dims=1024, k=20, no T-Nets) eval forward, "
-                                   f"N={args.points}, eval_batch_size={args.batch} clouds/step/GPU",
+            "config": {"workload": ("BASELINE configs[1]" if (args.points, args.k) == (4096, 20) else "BASELINE configs[4] (stress)") +
+                                   ": LPD-Net (featnet=lpdnet, emb_dims=1024, no T-Nets) eval forward, "
+                                   f"N={args.points}, k={args.k}, eval_batch_size={args.batch} clouds/step/GPU",
                        "clouds_per_step_per_gpu": args.batch, "num_points": args.points, "parallelism": f"shard-by-cloud x{world}"},
             "roofline": roof, "kernels": kern, "train": train,
         }

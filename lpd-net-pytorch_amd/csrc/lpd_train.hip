@@ -79,18 +79,27 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sum, const double*
 }
 
 // Y = act(scale * X + shift), float4 per thread.  In-place allowed.
+// The grid stride (gridDim * 256 threads) is a multiple of the C/4 column quads whenever C/4 divides 256 (all layer
+// widths here), so a thread keeps ONE column quad for its whole loop and the per-column constants are loaded once.
 __global__ void affine_act_kernel(const float* __restrict__ X, long long ldx, float* __restrict__ Y, long long ldy,
                                   long long R, int C, const float* __restrict__ scale, const float* __restrict__ shift,
                                   int act, float slope)
 {
     const int Q = C >> 2;
     const long long total = R * Q;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const bool fixed_q = (stride % Q) == 0;
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int q = (int)(e % Q);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) { sc = *reinterpret_cast<const float4*>(scale + q * 4); sh = *reinterpret_cast<const float4*>(shift + q * 4); }
+    for (; e < total; e += stride) {
         const long long r = e / Q;
-        const int q = (int)(e - r * Q);
+        if (!fixed_q) {
+            q = (int)(e - r * Q);
+            if (scale) { sc = *reinterpret_cast<const float4*>(scale + q * 4); sh = *reinterpret_cast<const float4*>(shift + q * 4); }
+        }
         const float4 x = *reinterpret_cast<const float4*>(X + r * ldx + q * 4);
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (scale) { sc = *reinterpret_cast<const float4*>(scale + q * 4); sh = *reinterpret_cast<const float4*>(shift + q * 4); }
         float4 y;
         y.x = lpd_act(sc.x * x.x + sh.x, act, slope);
         y.y = lpd_act(sc.y * x.y + sh.y, act, slope);
@@ -148,6 +157,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
 }
 
 // dX = scale * (dpre - dbeta/R - xhat * dgamma/R)   (has_bn)   or   dX = dpre   (no BN).  In-place on dY allowed.
+// Per-column constants (incl. the two fp64 means) are formed once per thread: see affine_act_kernel.
 __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dY, long long lddy, const float* __restrict__ X,
                                         long long ldx, float* __restrict__ dX, long long lddx, long long R, int C,
                                         const float* __restrict__ scale, const float* __restrict__ shift,
@@ -157,9 +167,27 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dY, long long 
 {
     const int Q = C >> 2;
     const long long total = R * Q;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const bool fixed_q = (stride % Q) == 0;
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int q = (int)(e % Q);
+    float sc[4], sh[4], mu[4], is[4], mb[4], mg[4];
+    auto load_consts = [&]() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ch = q * 4 + c;
+            sc[c] = scale ? scale[ch] : 1.0f;
+            sh[c] = scale ? shift[ch] : 0.0f;
+            mu[c] = has_bn ? mean[ch] : 0.0f;
+            is[c] = has_bn ? invstd[ch] : 1.0f;
+            mb[c] = has_bn ? (float)(dbeta[ch] / count) : 0.0f;
+            mg[c] = has_bn ? (float)(dgamma[ch] / count) : 0.0f;
+        }
+    };
+    load_consts();
+    for (; e < total; e += stride) {
         const long long r = e / Q;
-        const int q = (int)(e - r * Q);
+        if (!fixed_q) { q = (int)(e - r * Q); load_consts(); }
         const float4 xv = *reinterpret_cast<const float4*>(X + r * ldx + q * 4);
         const float4 gv = *reinterpret_cast<const float4*>(dY + r * lddy + q * 4);
         const float x[4] = {xv.x, xv.y, xv.z, xv.w};
@@ -167,16 +195,8 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dY, long long 
         float o[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int ch = q * 4 + c;
-            const float sc = scale ? scale[ch] : 1.0f, sh = scale ? shift[ch] : 0.0f;
-            const float dpre = g[c] * act_grad(sc * x[c] + sh, act, slope);
-            if (has_bn) {
-                const float xhat = (x[c] - mean[ch]) * invstd[ch];
-                const float mb = (float)(dbeta[ch] / count), mg = (float)(dgamma[ch] / count);
-                o[c] = sc * (dpre - mb - xhat * mg);
-            } else {
-                o[c] = dpre;
-            }
+            const float dpre = g[c] * act_grad(sc[c] * x[c] + sh[c], act, slope);
+            o[c] = has_bn ? sc[c] * (dpre - mb[c] - (x[c] - mu[c]) * is[c] * mg[c]) : dpre;
         }
         *reinterpret_cast<float4*>(dX + r * lddx + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
     }
