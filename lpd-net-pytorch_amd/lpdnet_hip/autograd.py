@@ -233,6 +233,127 @@ class _LPDNetTrainFn(torch.autograd.Function):
         return (None, None) + grads
 
 
+def _unsplit_cat_cd(dwcat, conv_weight):
+    """DGCNN-style input cat(centre, neighbour - centre): W = [Wa | Wb], P = Wb f_j, Q = (Wa - Wb) f_i
+    => dWb = dP-weight - dQ-weight ... in terms of the stacked gradient [dWn ; dWc]: dWa = dWc, dWb = dWn - dWc."""
+    co = conv_weight.shape[0]
+    dwn, dwc = dwcat[:co], dwcat[co:]
+    return torch.cat((dwc, dwn - dwc), dim=1).reshape(conv_weight.shape)
+
+
+class _EdgeChain:
+    """Two chained edge convolutions followed by max over k (LPDNetOrign: convDG1->convDG2->max, lpdnet_model.py:97-100,
+    and convSN1->convSN2->max, :105-107), train mode, on materialised edge tensors."""
+
+    @staticmethod
+    def fwd(pq, c, has_q, idx, N, k, bn_a, w_b, bn_b, act, slope, out):
+        u = ops.edge_build(pq[:, :c], pq[:, c:] if has_q else None, idx, N)       # [E,c] raw
+        st_a = ops.bn_train_stats(u, bn_a)
+        ya = ops.affine_act(u, st_a.scale, st_a.shift, act, slope)               # [E,c]
+        z = ops.linear(ya, w_b)                                                   # [E,co] raw
+        st_b = ops.bn_train_stats(z, bn_b)
+        arg = ops.group_max(z, k, st_b.scale, st_b.shift, act, slope, out)
+        return dict(u=u, st_a=st_a, ya=ya, z=z, st_b=st_b, arg=arg)
+
+    @staticmethod
+    def bwd(dout, S, w_b, idx, N, k, c, has_q, act, slope):
+        """returns (dPQ [M, c or 2c], dW_b, dgamma_b, dbeta_b, dgamma_a, dbeta_a)"""
+        M = dout.shape[0]
+        dz = ops.group_max_bwd(dout, S["arg"], k)
+        dz, dg_b, db_b = ops.bn_act_bwd(dz, S["z"], S["st_b"], act, slope, out=dz)
+        dw_b = _dweight(dz, S["ya"])
+        dya = ops.gemm(dz, w_b, b_kmajor=True)
+        del dz
+        du, dg_a, db_a = ops.bn_act_bwd(dya, S["u"], S["st_a"], act, slope, out=dya)
+        dpq = torch.zeros((M, 2 * c if has_q else c), dtype=torch.float32, device=dout.device)
+        if has_q:
+            ops.group_sum(du, k, dpq[:, c:])
+        ops.scatter_add_rows(du, idx, dpq[:, :c], N)
+        return dpq, dw_b, dg_b, db_b, dg_a, db_a
+
+
+class _LPDNetOrignTrainFn(torch.autograd.Function):
+    """LPDNetOrign.forward in train mode (util/lpdnet_model.py:68-114, t3d = tfea = False)."""
+
+    PARAMS = tuple(f"{blk}.{leaf}" for blk in ("conv1_lpd", "conv2_lpd", "convDG1", "convDG2", "convSN1", "convSN2",
+                                               "conv3_lpd", "conv4_lpd", "conv5_lpd")
+                   for leaf in ("0.weight", "1.weight", "1.bias"))
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        from . import engine
+        B, N = x.shape[0], x.shape[2]
+        M, k = B * N, net.k
+        act, slope = (ops.ACT_RELU, 0.0) if net.use_relu else (ops.ACT_LEAKY, LEAKY)
+        w2d = engine._w2d
+        xyz = x.view(M, 3)
+        S = dict(xyz=xyz)
+        S["y1"], S["st1"], f1 = _PointLayer.fwd(xyz, w2d(net.conv1_lpd[0]), net.conv1_lpd[1], act, slope)
+        S["y2"], S["st2"], f0 = _PointLayer.fwd(f1, w2d(net.conv2_lpd[0]), net.conv2_lpd[1], act, slope)
+        S["f1"], S["f0"] = f1, f0
+        idx_f = ops.knn(ops.transpose(f0.view(B, N, 64)), k)
+        wcat1 = engine.split_edge_weight(net.convDG1, "cat_cd")
+        pq1 = ops.linear(f0, wcat1)                                               # [M,128] = [P | Q]
+        g = torch.empty((M, 64), dtype=torch.float32, device=x.device)
+        S["dg"] = _EdgeChain.fwd(pq1, 64, True, idx_f, N, k, net.convDG1[1], w2d(net.convDG2[0]), net.convDG2[1], act, slope, g)
+        idx_x = ops.knn(ops.transpose(x.view(B, N, 3)), k)
+        wsn1 = engine.split_edge_weight(net.convSN1, "nbr")
+        pn = ops.linear(g, wsn1)                                                  # [M,64] neighbours only
+        h = torch.empty((M, 64), dtype=torch.float32, device=x.device)
+        S["sn"] = _EdgeChain.fwd(pn, 64, False, idx_x, N, k, net.convSN1[1], w2d(net.convSN2[0]), net.convSN2[1], act, slope, h)
+        S["y3"], S["st3"], h3 = _PointLayer.fwd(h, w2d(net.conv3_lpd[0]), net.conv3_lpd[1], act, slope)
+        S["y4"], S["st4"], h4 = _PointLayer.fwd(h3, w2d(net.conv4_lpd[0]), net.conv4_lpd[1], act, slope)
+        S["y5"], S["st5"], feat = _PointLayer.fwd(h4, w2d(net.conv5_lpd[0]), net.conv5_lpd[1], act, slope)
+        S.update(g=g, h=h, h3=h3, h4=h4, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1, wsn1=wsn1)
+        ctx.net, ctx.dims, ctx.actslope, ctx.saved = net, (B, N, M, k), (act, slope), S
+        if engine.DEBUG_AUX is not None:
+            engine.DEBUG_AUX.update(F0=f0, idx_feat=idx_f, idx_xyz=idx_x)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        from . import engine
+        net, S = ctx.net, ctx.saved
+        B, N, M, k = ctx.dims
+        act, slope = ctx.actslope
+        w2d = engine._w2d
+        dfeat = dfeat.contiguous()
+        dh4, dw5, dg5, db5 = _PointLayer.bwd(dfeat, S["h4"], w2d(net.conv5_lpd[0]), S["y5"], S["st5"], act, slope, inplace=False)
+        dh3, dw4, dg4, db4 = _PointLayer.bwd(dh4, S["h3"], w2d(net.conv4_lpd[0]), S["y4"], S["st4"], act, slope)
+        dh, dw3, dg3, db3 = _PointLayer.bwd(dh3, S["h"], w2d(net.conv3_lpd[0]), S["y3"], S["st3"], act, slope)
+        # SN1 -> SN2 -> max on the xyz graph (neighbours only)
+        dpn, dwsn2, dgsn2, dbsn2, dgsn1, dbsn1 = _EdgeChain.bwd(dh, S["sn"], w2d(net.convSN2[0]), S["idx_x"], N, k, 64, False, act, slope)
+        dwsn1 = _dweight(dpn, S["g"])
+        dg_ = ops.gemm(dpn, S["wsn1"], b_kmajor=True)                             # [M,64]
+        # DG1 -> DG2 -> max on the feature graph
+        dpq1, dwdg2, dgdg2, dbdg2, dgdg1, dbdg1 = _EdgeChain.bwd(dg_, S["dg"], w2d(net.convDG2[0]), S["idx_f"], N, k, 64, True, act, slope)
+        dwcat1 = _dweight(dpq1, S["f0"])
+        df0 = ops.gemm(dpq1, S["wcat1"], b_kmajor=True)
+        df1, dwc2, dg2, db2 = _PointLayer.bwd(df0, S["f1"], w2d(net.conv2_lpd[0]), S["y2"], S["st2"], act, slope)
+        _, dwc1, dg1, db1 = _PointLayer.bwd(df1, S["xyz"], w2d(net.conv1_lpd[0]), S["y1"], S["st1"], act, slope, need_dx=False)
+
+        def shp(dw, seq):
+            return dw.reshape(seq[0].weight.shape)
+        grads = (shp(dwc1, net.conv1_lpd), dg1, db1, shp(dwc2, net.conv2_lpd), dg2, db2,
+                 _unsplit_cat_cd(dwcat1, net.convDG1[0].weight), dgdg1, dbdg1, shp(dwdg2, net.convDG2), dgdg2, dbdg2,
+                 shp(dwsn1, net.convSN1), dgsn1, dbsn1, shp(dwsn2, net.convSN2), dgsn2, dbsn2,
+                 shp(dw3, net.conv3_lpd), dg3, db3, shp(dw4, net.conv4_lpd), dg4, db4, shp(dw5, net.conv5_lpd), dg5, db5)
+        ctx.saved = None
+        return (None, None) + grads
+
+
+def lpdnet_origin_features_train(net, x):
+    """LPDNetOrign training-mode forward: ([B*N, E] features with autograd, B, N)."""
+    from . import engine
+    if net.t3d or net.tfea:
+        raise NotImplementedError("training with the T-Nets (xyz_trans / feature_transform) is not built on the HIP path yet; "
+                                  "inference (.eval()) supports them")
+    x = engine.reorder_points(engine._check_input(x))
+    params = _named(net, _LPDNetOrignTrainFn.PARAMS)
+    feat = _LPDNetOrignTrainFn.apply(net, x, *params)
+    return feat, x.shape[0], x.shape[2]
+
+
 def _named(module, names):
     out = []
     for n in names:

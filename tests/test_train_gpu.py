@@ -23,10 +23,10 @@ GRAD_TOL = 1e-2
 GRAD_MEDIAN_TOL = 2.5e-3
 
 
-def _train_model(N, cuda):
+def _train_model(N, cuda, featnet="lpdnet"):
     from util.PointNetVlad import PointNetVlad
-    m = PointNetVlad(num_points=N, featnet="lpdnet")
-    sd = orc.synthetic_state("lpdnet", num_points=N)
+    m = PointNetVlad(num_points=N, featnet=featnet)
+    sd = orc.synthetic_state(featnet, num_points=N)
     m.load_state_dict(sd, strict=True)
     return m.to(cuda).train(), sd
 
@@ -78,11 +78,11 @@ def test_train_step0_vs_reference_golden(cuda, golden_dir):
             assert int(b) == 1
 
 
-@pytest.mark.parametrize("bq,P,Ng,N", [(1, 2, 2, 256), (2, 1, 3, 512)])
-def test_train_grads_vs_oracle(cuda, bq, P, Ng, N):
+@pytest.mark.parametrize("featnet,bq,P,Ng,N", [("lpdnet", 1, 2, 2, 256), ("lpdnet", 2, 1, 3, 512), ("lpdnetorigin", 1, 2, 2, 256)])
+def test_train_grads_vs_oracle(cuda, featnet, bq, P, Ng, N):
     from lpdnet_hip import engine
     B = bq * (1 + P + Ng + 1)
-    m, sd0 = _train_model(N, cuda)
+    m, sd0 = _train_model(N, cuda, featnet)
     xc = torch.from_numpy(synth.cloud(21, B, N)).unsqueeze(1)
     engine.DEBUG_AUX = {}
     engine.MORTON_ORDER = False   # compare index tensors in the caller's point order
@@ -100,13 +100,14 @@ def test_train_grads_vs_oracle(cuda, bq, P, Ng, N):
     orig = orc.knn
     orc.knn = lambda xx, k: next(graphs)          # the GPU's graphs (kNN parity is tested bit-exactly elsewhere)
     try:
-        od = orc.pointnetvlad_forward(sd, xc.to(dt), featnet="lpdnet", train=True, new_stats=new_stats)
+        od = orc.pointnetvlad_forward(sd, xc.to(dt), featnet=featnet, train=True, new_stats=new_stats)
     finally:
         orc.knn = orig
     q, p, n, o = torch.split(od.view(bq, -1, 256), [1, P, Ng, 1], dim=1)
     ol = orc.quadruplet_loss(q, p, n, o, 0.5, 0.2, use_min=True, lazy=True, ignore_zero_loss=False)
     assert ol.item() > 0, "vacuous fixture: hinge inactive"
     ol.backward()
+    assert all(p.grad is not None for p in m.parameters())
     rel = ((out.detach().cpu().double() - od.detach()).abs().amax(dim=1) / od.detach().abs().amax(dim=1)).max().item()
     assert rel < 1e-4, rel
     assert abs(loss.item() - ol.item()) < 5e-4 * abs(ol.item())
@@ -141,3 +142,13 @@ def test_train_then_eval_roundtrip_and_adam_step(cuda):
     with torch.no_grad():
         d = m(x)
     assert torch.isfinite(d).all() and d.shape == (bq * (P + Ng + 2), 256)
+
+
+def test_unbuilt_training_variants_fail_loudly(cuda):
+    """Training with T-Nets / the PointNet trunk is not built on the HIP path: a clear error, never a silent fallback."""
+    from util.PointNetVlad import PointNetVlad
+    x = torch.from_numpy(synth.cloud(1, 2, 256)).unsqueeze(1).to(cuda)
+    for kw in (dict(featnet="lpdnet", xyz_trans=True), dict(featnet="pointnet")):
+        m = PointNetVlad(num_points=256, **kw).to(cuda).train()
+        with pytest.raises(NotImplementedError):
+            m(x)
