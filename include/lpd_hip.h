@@ -65,7 +65,7 @@ int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* xx_
  *   splits > 1: split-K; splitk_ws must hold batch*splits*M*N floats; epilogue applied after the sum
  *   bias/scale/shift: [N] or NULL (scale and shift together)
  *   accumulate != 0: C += result (after the epilogue) -- gradient accumulation in the backward pass
- * Requires K % (32*splits) == 0, lda/ldb/sA/sB % 4 == 0, A and B 16-byte aligned.
+ * Any M, N, K (tails are zero-filled / masked).  Requires lda/ldb/sA/sB % 4 == 0, A and B 16-byte aligned.
  */
 int lpd_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
              int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC, int splits,

@@ -30,7 +30,8 @@ struct GemmArgs {
     const float* A;
     const float* B;
     float* C;
-    int M, N, K;          // logical sizes; K is the per-split depth handled by one block
+    int M, N, K;          // logical sizes; K is the per-split depth handled by one block (multiple of 32)
+    int Ktot;             // true reduction length: k >= Ktot reads as zero (ragged K, e.g. N points not % 32)
     int lda, ldb, ldc;
     long long sA, sB, sC;  // batch strides (elements)
     int splits;            // grid.z = batch * splits
@@ -99,12 +100,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
             int f = e * GEMM_THREADS + tid;
             if constexpr (A_KMAJOR) {  // memory [k][m]: 32 float4 per k-row
                 int kk = f / (BM / 4), mq = f % (BM / 4);
-                ra[e] = ld4_guard(A + (long long)(k0 + kk) * g.lda, m0 + mq * 4, g.M);
+                ra[e] = (k0 + kk < g.Ktot) ? ld4_guard(A + (long long)(k0 + kk) * g.lda, m0 + mq * 4, g.M)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {                   // memory [m][k]: 8 float4 per m-row
                 int mm = f / (BK / 4), kq = f % (BK / 4);
                 int m = m0 + mm;
                 m = m < g.M ? m : g.M - 1;  // clamp: rows >= M are never stored
-                ra[e] = *reinterpret_cast<const float4*>(A + (long long)m * g.lda + k0 + kq * 4);
+                ra[e] = ld4_guard(A + (long long)m * g.lda, k0 + kq * 4, g.Ktot);
             }
         }
 #pragma unroll
@@ -112,12 +114,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
             int f = e * GEMM_THREADS + tid;
             if constexpr (B_KMAJOR) {  // memory [k][n]
                 int kk = f / (BN / 4), nq = f % (BN / 4);
-                rb[e] = ld4_guard(B + (long long)(k0 + kk) * g.ldb, n0 + nq * 4, g.N);
+                rb[e] = (k0 + kk < g.Ktot) ? ld4_guard(B + (long long)(k0 + kk) * g.ldb, n0 + nq * 4, g.N)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {                   // memory [n][k]
                 int nn = f / (BK / 4), kq = f % (BK / 4);
                 int n = n0 + nn;
                 n = n < g.N ? n : g.N - 1;
-                rb[e] = *reinterpret_cast<const float4*>(B + (long long)n * g.ldb + k0 + kq * 4);
+                rb[e] = ld4_guard(B + (long long)n * g.ldb, k0 + kq * 4, g.Ktot);
             }
         }
     };
@@ -266,7 +269,7 @@ extern "C" int lpd_gemm(const float* A, const float* B, float* C, int M, int N, 
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(A && B && C, "lpd_gemm: null pointer");
     LPD_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "lpd_gemm: bad dims M=%d N=%d K=%d batch=%d", M, N, K, batch);
-    LPD_CHECK_ARG(splits >= 1 && K % (GEMM_BK * splits) == 0, "lpd_gemm: K=%d must be a multiple of 32*splits (splits=%d)", K, splits);
+    LPD_CHECK_ARG(splits >= 1, "lpd_gemm: splits=%d", splits);
     LPD_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0, "lpd_gemm: lda/ldb must be multiples of 4 (lda=%d ldb=%d)", lda, ldb);
     LPD_CHECK_ARG(sA % 4 == 0 && sB % 4 == 0, "lpd_gemm: batch strides of A/B must be multiples of 4");
     LPD_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "lpd_gemm: A/B must be 16-byte aligned");
@@ -276,7 +279,9 @@ extern "C" int lpd_gemm(const float* A, const float* B, float* C, int M, int N, 
 
     GemmArgs g;
     g.A = A; g.B = B;
-    g.M = M; g.N = N; g.K = K / splits;
+    g.M = M; g.N = N;
+    g.K = ((K + splits - 1) / splits + GEMM_BK - 1) / GEMM_BK * GEMM_BK;   // per-split depth, rounded up to the k-tile
+    g.Ktot = K;
     g.lda = lda; g.ldb = ldb;
     g.sA = sA; g.sB = sB;
     g.splits = splits;

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 constexpr int KNN3_WAVES = 4;
 constexpr int KNN3_THREADS = KNN3_WAVES * 64;
-constexpr int KNN3_QCAP = 24;   // queue slots per lane; a tile can add 16
+constexpr int KNN3_QCAP = 40;   // queue slots per lane; a tile can add 16
 
 // per-lane operand fetch of candidate tile j0: a[s] = x[2s+h][j0+col] (zero beyond C or N)
 template <int CP>
@@ -328,7 +328,7 @@ __device__ __forceinline__ void knn3_tile(float (&a)[CP], float4 (&x4)[4], const
 
 template <int CP, int KMAX>
 __global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __restrict__ x, const float* __restrict__ xx,
-                                                             int32_t* __restrict__ idx, int C, int N, int k, int blocks_per_cloud)
+                                                             int32_t* __restrict__ idx, int C, int N, int k, int blocks_per_cloud, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -383,6 +383,7 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __re
 #pragma unroll
         for (int s = 0; s < CP; ++s) a[s] = knn3_ld_a<CP>(xb, C, N, t_lo * 32, col, h, s);
         knn3_ld_xx(xxb, N, t_lo * 32, h, vec_ok, x4);
+        if (dbg & 2) t_hi = t_lo;   // timing ablation: no admission threshold
         for (int t = t_lo; t < t_hi; ++t) {
             knn3_tile<CP>(a, x4, qreg, xq, xb, xxb, C, N, (t + 1) * 32, t + 1 < t_hi, col, h, vec_ok, pd);
 #pragma unroll
@@ -416,13 +417,13 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __re
     for (int s = 0; s < CP; ++s) a[s] = knn3_ld_a<CP>(xb, C, N, 0, col, h, s);
     knn3_ld_xx(xxb, N, 0, h, vec_ok, x4);
     for (int t = 0; t < ntiles; ++t) {
-        knn3_tile<CP>(a, x4, qreg, xq, xb, xxb, C, N, (t + 1) * 32, t + 1 < ntiles, col, h, vec_ok, pd);
+        knn3_tile<CP>(a, x4, qreg, xq, xb, xxb, C, N, (t + 1) * 32, (t + 1 < ntiles) && !(dbg & 4), col, h, vec_ok, pd);   // dbg&4: timing ablation, no operand refill
         const float thr = fmaxf(t0, lv[KMAX - 1]);
         const bool list_full = lv[KMAX - 1] > -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             // before the list is full every candidate reaching T0 is admitted; afterwards it must beat the k-th best
-            const bool admit = list_full ? (pd[r] > thr) : (pd[r] >= thr);
+            const bool admit = (list_full ? (pd[r] > thr) : (pd[r] >= thr)) && !(dbg & 1);   // dbg&1: timing ablation
             if (admit) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
                 myq[cnt * 64] = make_float2(pd[r], __int_as_float(t * 32 + row));
@@ -433,30 +434,33 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __re
     }
     drain();
 
-    // ---- merge the two half-lists (queue region of this wave is free now; DS ops of a wave execute in order) ----
-    float* mv = smem + (size_t)wave * KNN3_QCAP * 128;   // wave region: QCAP*64 float2 = QCAP*128 floats >= 2*32*KMAX
-    int* mi = reinterpret_cast<int*>(mv + 32 * KMAX);
-    if (h == 1) {
+    // ---- merge the two half-lists: both halves publish their sorted lists in this wave's (now free) queue region and
+    // the lower half-wave walks the two lists with a 2-pointer merge (k steps of two LDS reads and a compare) ----
+    float* mv = smem + (size_t)wave * KNN3_QCAP * 128;   // wave region: QCAP*64 float2 = QCAP*128 floats >= 2*64*KMAX
+    int* mi = reinterpret_cast<int*>(mv + 64 * KMAX);
 #pragma unroll
-        for (int s = 0; s < KMAX; ++s) {
-            mv[col * KMAX + s] = lv[s];
-            mi[col * KMAX + s] = li[s];
-        }
+    for (int s = 0; s < KMAX; ++s) {
+        mv[lane * KMAX + s] = lv[s];
+        mi[lane * KMAX + s] = li[s];
     }
     __syncthreads();
-    if (h == 0) {
-        for (int e = 0; e < KMAX; ++e) {
-            const float pv = mv[col * KMAX + e];
-            const int pj = mi[col * KMAX + e];
-            const bool enters = (pv > lv[KMAX - 1]) || (pv == lv[KMAX - 1] && pj < li[KMAX - 1]);
-            if (!enters) break;
-            knn_insert_any<KMAX>(lv, li, pv, pj);
-        }
-        if (q_ok) {
-            int32_t* out = idx + ((size_t)b * N + q) * k;
-#pragma unroll
-            for (int s = 0; s < KMAX; ++s)
-                if (s < k) out[s] = li[s];
+    if (h == 0 && q_ok) {
+        const float* av = mv + lane * KMAX;
+        const int* ai = mi + lane * KMAX;
+        const float* bv = mv + (lane + 32) * KMAX;
+        const int* bi = mi + (lane + 32) * KMAX;
+        int pa = 0, pb = 0;
+        int32_t* out = idx + ((size_t)b * N + q) * k;
+        for (int s = 0; s < k; ++s) {
+            bool take_a;
+            if (pa >= KMAX) take_a = false;
+            else if (pb >= KMAX) take_a = true;
+            else {
+                const float va = av[pa], vb2 = bv[pb];
+                take_a = (va > vb2) || (va == vb2 && ai[pa] < bi[pb]);
+            }
+            if (take_a) out[s] = ai[pa++];
+            else out[s] = bi[pb++];
         }
     }
 }
@@ -682,14 +686,14 @@ int knn6_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
 }
 
 template <int CP, int KMAX>
-int knn3_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream)
+int knn3_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg = 0)
 {
-    static_assert(KNN3_QCAP * 128 >= 2 * 32 * KMAX, "merge region must fit the wave's queue region");
+    static_assert(KNN3_QCAP * 128 >= 2 * 64 * KMAX, "merge region must fit the wave's queue region");
     size_t lds = (size_t)KNN3_WAVES * KNN3_QCAP * 64 * sizeof(float2);
     const int bpc = (N + KNN3_WAVES * 32 - 1) / (KNN3_WAVES * 32);
     auto kern = knn3_kernel<CP, KMAX>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(KNN3_THREADS), lds, stream, x, xx, idx, C, N, k, bpc);
+    hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(KNN3_THREADS), lds, stream, x, xx, idx, C, N, k, bpc, dbg);
     LPD_CHECK_LAUNCH("lpd_knn");
     return LPD_OK;
 }
@@ -761,6 +765,9 @@ extern "C" int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
         if (C <= 4) return knn3_dispatch_k<2>(x, xx_ws, idx, B, C, N, k, stream);
         if (C <= 64) return knn3_dispatch_k<32>(x, xx_ws, idx, B, C, N, k, stream);
         if (C <= 256) return knn_dispatch_k<128>(x, xx_ws, idx, B, C, N, k, 0, stream);   // wide features: v1
+    } else if (impl >= 10 && impl < 18 && k <= 20 && C <= 64) {   // timing ablations of the product kernel (wrong results)
+        if (C <= 4) return knn3_launch<2, 20>(x, xx_ws, idx, B, C, N, k, stream, impl - 10);
+        return knn3_launch<32, 20>(x, xx_ws, idx, B, C, N, k, stream, impl - 10);
     } else if (impl == 3 && k <= 20 && C <= 64) {
         if (C <= 4) return knn6_launch<2, 20>(x, xx_ws, idx, B, C, N, k, stream);
         return knn6_launch<32, 20>(x, xx_ws, idx, B, C, N, k, stream);

@@ -96,7 +96,7 @@ LEAKY = 0.01
 def _pick_splits(R, tiles):
     """split-K factor for a reduction over R rows: ~512 blocks, >= 8 k-tiles per block, R % (32*s) == 0."""
     s = 1
-    while s * 2 * tiles <= 512 and R % (32 * s * 2) == 0 and R // (s * 2) >= 256:
+    while s * 2 * tiles <= 512 and R // (s * 2) >= 256:
         s *= 2
     return s
 
@@ -107,8 +107,6 @@ def _dweight(dY, X, rows=None):
     Co, Kin = dY.shape[1], X.shape[1]
     if Kin <= 8:
         return ops.dw_smallk(dY[:R], X[:R])
-    if R % 32 != 0:
-        raise ValueError(f"weight-gradient GEMM needs the row count ({R}) to be a multiple of 32")
     tiles = ((Co + 127) // 128) * ((Kin + 127) // 128)
     return ops.gemm(dY[:R], X[:R], a_kmajor=True, b_kmajor=True, splits=_pick_splits(R, tiles))
 

@@ -247,7 +247,7 @@ def pointnet_features_eval(net, x):
 def _head_splits(K):
     """split-K factor for the [B, K] x [K, out] hidden projection: ~256 blocks, >= 8 k-tiles each."""
     s = 1
-    while s < 128 and K % (32 * s * 2) == 0 and K // (s * 2) >= 256:
+    while s < 128 and K // (s * 2) >= 256:
         s *= 2
     return s
 

@@ -206,3 +206,52 @@ def test_loss_on_split_views(cuda):
     lo.backward()
     assert abs(l.item() - lo.item()) < 1e-5 * max(1.0, abs(lo.item()))
     assert torch.allclose(dev.grad.cpu(), cpu.grad, atol=1e-6, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ callers (H1, H2) and ragged shapes
+@pytest.mark.parametrize("featnet,B,N", [("lpdnet", 3, 200), ("lpdnet", 1, 96), ("lpdnetorigin", 2, 333), ("pointnet", 1, 130)])
+def test_ragged_sizes_vs_oracle(cuda, featnet, B, N):
+    """N not a multiple of the 32/64/128-row tiles, B = 1: every kernel's tail handling against the oracle."""
+    m, sd = _model(featnet, N, cuda)
+    x = torch.from_numpy(synth.cloud(55, B, N)).unsqueeze(1)
+    with torch.no_grad():
+        ref = orc.pointnetvlad_forward(sd, x, featnet=featnet, train=False)
+        got = m(x.to(cuda))
+    assert _norm_rel(got, ref) < DESC_TOL
+
+
+def test_get_latent_vectors_and_run_model(cuda):
+    from lpdnet_hip import harness
+    import loss.pointnetvlad_loss as L
+    N = 256
+    m, sd = _model("lpdnet", N, cuda)
+    m.train()                                                     # the helper must switch to eval and back
+    clouds = synth.cloud(8, 7, N).astype(np.float64)               # float64 like the benchmark's .bin submaps
+    vec = harness.get_latent_vectors(m, clouds, batch_size=3)      # 3 + 3 + ragged 1
+    assert m.training and vec.shape == (7, 256) and vec.dtype == np.float32
+    with torch.no_grad():
+        ref = orc.pointnetvlad_forward(sd, torch.from_numpy(clouds).float().unsqueeze(1), featnet="lpdnet", train=False)
+    assert _norm_rel(torch.from_numpy(vec), ref) < DESC_TOL
+    assert harness.get_latent_vectors(m, clouds[:0], 3).shape[0] == 0
+    # run_model: tuple layout q | pos | neg | other (train_pointnetvlad.py:204-217)
+    m.eval()
+    tup = torch.from_numpy(synth.cloud(9, 6, N)).view(1, 6, N, 3)
+    q, p, n, o = harness.run_model(m, tup[:, :1], tup[:, 1:3], tup[:, 3:5], tup[:, 5:6], require_grad=False)
+    assert q.shape == (1, 1, 256) and p.shape == (1, 2, 256) and n.shape == (1, 2, 256) and o.shape == (1, 1, 256)
+    with torch.no_grad():
+        flat = m(tup.view(6, 1, N, 3).to(cuda))
+    assert torch.allclose(torch.cat((q, p, n, o), 1).view(6, 256), flat, atol=1e-6)
+    loss = L.quadruplet_loss(q, p, n, o, 0.5, 0.2, use_min=True, lazy=True, ignore_zero_loss=False)
+    assert torch.isfinite(loss)
+
+
+def test_train_step_helper(cuda):
+    from lpdnet_hip import harness
+    N = 256
+    m, _ = _model("lpdnet", N, cuda)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    tup = torch.from_numpy(synth.cloud(10, 12, N)).view(2, 6, N, 3)
+    before = m.net_vlad.hidden1_weights.detach().clone()
+    loss = harness.train_step(m, opt, tup[:, :1], tup[:, 1:3], tup[:, 3:5], tup[:, 5:6])
+    assert torch.isfinite(loss) and loss.item() > 0
+    assert not torch.equal(before, m.net_vlad.hidden1_weights.detach())

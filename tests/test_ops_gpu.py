@@ -86,7 +86,8 @@ def test_morton_sort_is_a_permutation_and_improves_locality(cuda):
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K,ak,bk", [(256, 128, 64, False, False), (1000, 200, 96, False, True), (128, 64, 32, False, False),
                                           (77, 513, 128, False, False), (512, 64, 1024, False, True), (300, 1024, 512, False, False),
-                                          (132, 72, 64, True, True), (1024, 64, 4096, True, True)])
+                                          (132, 72, 64, True, True), (1024, 64, 4096, True, True),
+                                          (200, 64, 100, True, True), (96, 40, 52, False, False), (64, 64, 600, False, True)])
 def test_gemm_modes(cuda, M, N, K, ak, bk):
     ops = _ops()
     g = torch.Generator().manual_seed(M + N + K)
@@ -231,4 +232,4 @@ def test_errors_are_loud(cuda):
     with pytest.raises(LpdHipError):
         ops.knn(torch.zeros(1, 3, 8, device=cuda), 9)        # k > N
     with pytest.raises(LpdHipError):
-        ops.gemm(torch.zeros(4, 48, device=cuda), torch.zeros(48, 8, device=cuda))  # K % 32 != 0
+        ops.gemm(torch.zeros(4, 50, device=cuda), torch.zeros(50, 8, device=cuda))  # leading dim not a multiple of 4
