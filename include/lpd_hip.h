@@ -194,6 +194,15 @@ int lpd_group_max(const float* X, long long ldx, int k, const float* scale, cons
 int lpd_group_max_bwd(const float* dOut, long long ldo, const uint8_t* arg, int k, float* dX, long long M, int C,
                       int accumulate, void* stream);
 
+/* Fused backward of out[i] = max_t act(BN(X[(i,t)])) on a materialised edge tensor X [M*k][C]: the arg-max gradient
+ * comes from (dOut [M][ldo], arg [M][C]); dDense [M*k][C] (optional) is an additional dense gradient on the
+ * post-activation edge values (DG1: the DG2 convolution consumes every edge).  Writes dX [M*k][C] (may alias dDense),
+ * dQ[i] = sum_t dX[(i,t)] (optional, the centre-term gradient) and the fp64 reductions dbeta/dgamma [C]. */
+int lpd_edge_bn_bwd(const float* dOut, long long ldo, const uint8_t* arg, const float* dDense, const float* X, float* dX,
+                    float* dQ, long long ldq, int k, long long M, int C, const float* scale, const float* shift,
+                    const float* mean, const float* invstd, int act, float slope, double* dbeta, double* dgamma,
+                    void* stream);
+
 /* dQ[i] = sum_t dU[(i,t)]  (gradient of the centre term). */
 int lpd_group_sum(const float* dU, int k, float* dQ, long long ldq, long long M, int C, void* stream);
 

@@ -299,6 +299,126 @@ __global__ void group_max_bwd_kernel(const float* __restrict__ dOut, long long l
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused backward of  out[i] = max_t act(BN(X[(i,t)]))  (+ an optional dense gradient on the post-activation
+// edge values): replaces group_max_bwd -> bn_act_bwd(reduce, apply) -> group_sum on the materialised edge
+// tensors.  The arg-max gradient is generated on the fly from (dOut, arg), so the zero-filled [E,C] gradient is
+// never written or re-read; the centre-term gradient dQ[i] = sum_t dX[(i,t)] falls out of the apply pass.
+// One thread per (point, float4 of channels); column quad fixed per thread (C/4 divides 256).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_bn_bwd_reduce_kernel(const float* __restrict__ dOut, long long ldo,
+                                                                 const uint8_t* __restrict__ arg,
+                                                                 const float* __restrict__ dDense,   // [E][C] or null
+                                                                 const float* __restrict__ X, int k, long long M, int C,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 int act, float slope, double* __restrict__ dbeta,
+                                                                 double* __restrict__ dgamma)
+{
+    __shared__ double red[256][8];
+    const int Q = C >> 2;
+    const int RG = 256 / Q;
+    const int q = threadIdx.x % Q, rg = threadIdx.x / Q;
+    float sc[4], sh[4], mu[4], is[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        sc[c] = scale[q * 4 + c]; sh[c] = shift[q * 4 + c]; mu[c] = mean[q * 4 + c]; is[c] = invstd[q * 4 + c];
+    }
+    double sb[4] = {0, 0, 0, 0}, sg[4] = {0, 0, 0, 0};
+    for (long long i = (long long)blockIdx.x * RG + rg; i < M; i += (long long)gridDim.x * RG) {
+        const float4 g4 = *reinterpret_cast<const float4*>(dOut + i * ldo + q * 4);
+        const uchar4 a4 = *reinterpret_cast<const uchar4*>(arg + i * C + q * 4);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        const int a[4] = {a4.x, a4.y, a4.z, a4.w};
+        if (dDense) {
+            for (int t = 0; t < k; ++t) {
+                const float4 xv = *reinterpret_cast<const float4*>(X + (i * k + t) * C + q * 4);
+                const float4 dv = *reinterpret_cast<const float4*>(dDense + (i * k + t) * C + q * 4);
+                const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+                const float d[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float gy = d[c] + (a[c] == t ? g[c] : 0.0f);
+                    const float dpre = gy * act_grad(sc[c] * x[c] + sh[c], act, slope);
+                    sb[c] += dpre;
+                    sg[c] += (double)dpre * ((x[c] - mu[c]) * is[c]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {   // only the arg-max edge carries gradient
+                const float x = X[(i * k + a[c]) * C + q * 4 + c];
+                const float dpre = g[c] * act_grad(sc[c] * x + sh[c], act, slope);
+                sb[c] += dpre;
+                sg[c] += (double)dpre * ((x - mu[c]) * is[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = sb[e]; red[threadIdx.x][4 + e] = sg[e]; }
+    __syncthreads();
+    if (rg == 0) {
+        for (int g2 = 1; g2 < RG; ++g2)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[q][e] += red[g2 * Q + q][e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&dbeta[q * 4 + e], red[q][e]);
+            atomicAdd(&dgamma[q * 4 + e], red[q][4 + e]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void edge_bn_bwd_apply_kernel(const float* __restrict__ dOut, long long ldo,
+                                                                const uint8_t* __restrict__ arg,
+                                                                const float* __restrict__ dDense, const float* __restrict__ X,
+                                                                float* __restrict__ dX, float* __restrict__ dQ, long long ldq,
+                                                                int k, long long M, int C, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const double* __restrict__ dbeta,
+                                                                const double* __restrict__ dgamma, double count, int act,
+                                                                float slope)
+{
+    const int Q = C >> 2;
+    const int RG = 256 / Q;
+    const int q = threadIdx.x % Q, rg = threadIdx.x / Q;
+    float sc[4], sh[4], mu[4], is[4], mb[4], mg[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = q * 4 + c;
+        sc[c] = scale[ch]; sh[c] = shift[ch]; mu[c] = mean[ch]; is[c] = invstd[ch];
+        mb[c] = (float)(dbeta[ch] / count);
+        mg[c] = (float)(dgamma[ch] / count);
+    }
+    for (long long i = (long long)blockIdx.x * RG + rg; i < M; i += (long long)gridDim.x * RG) {
+        const float4 g4 = *reinterpret_cast<const float4*>(dOut + i * ldo + q * 4);
+        const uchar4 a4 = *reinterpret_cast<const uchar4*>(arg + i * C + q * 4);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        const int a[4] = {a4.x, a4.y, a4.z, a4.w};
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < k; ++t) {
+            const long long off = (i * k + t) * C + q * 4;
+            const float4 xv = *reinterpret_cast<const float4*>(X + off);
+            float d[4] = {0.f, 0.f, 0.f, 0.f};
+            if (dDense) {
+                const float4 dv = *reinterpret_cast<const float4*>(dDense + off);
+                d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
+            }
+            const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float gy = d[c] + (a[c] == t ? g[c] : 0.0f);
+                const float dpre = gy * act_grad(sc[c] * x[c] + sh[c], act, slope);
+                o[c] = sc[c] * (dpre - mb[c] - (x[c] - mu[c]) * is[c] * mg[c]);
+                sum[c] += o[c];
+            }
+            *reinterpret_cast<float4*>(dX + off) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        if (dQ) *reinterpret_cast<float4*>(dQ + i * ldq + q * 4) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+    }
+}
+
 // dQ[i] = sum_t dU[(i,t)]
 __global__ void group_sum_kernel(const float* __restrict__ dU, int k, float* __restrict__ dQ, long long ldq, long long M, int C)
 {
@@ -553,6 +673,26 @@ extern "C" int lpd_group_max_bwd(const float* dOut, long long ldo, const uint8_t
     hipLaunchKernelGGL(group_max_bwd_kernel, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, ST(stream), dOut, ldo, arg, k, dX,
                        M, C, accumulate);
     LPD_CHECK_LAUNCH("lpd_group_max_bwd");
+    return LPD_OK;
+}
+
+extern "C" int lpd_edge_bn_bwd(const float* dOut, long long ldo, const uint8_t* arg, const float* dDense, const float* X,
+                               float* dX, float* dQ, long long ldq, int k, long long M, int C, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, int act, float slope,
+                               double* dbeta, double* dgamma, void* stream)
+{
+    LPD_CHECK_ARG(dOut && arg && X && dX && scale && shift && mean && invstd && dbeta && dgamma && M > 0 && k > 0 && k <= 255,
+                  "lpd_edge_bn_bwd: bad arguments");
+    LPD_CHECK_ARG(cols_ok(C) && ldo % 4 == 0 && (!dQ || ldq % 4 == 0), "lpd_edge_bn_bwd: C=%d / leading dims unsupported", C);
+    (void)hipMemsetAsync(dbeta, 0, sizeof(double) * C, ST(stream));
+    (void)hipMemsetAsync(dgamma, 0, sizeof(double) * C, ST(stream));
+    const int RG = 256 / (C / 4);
+    hipLaunchKernelGGL(edge_bn_bwd_reduce_kernel, dim3(grid_for(M, RG * 2)), dim3(256), 0, ST(stream), dOut, ldo, arg, dDense, X, k,
+                       M, C, scale, shift, mean, invstd, act, slope, dbeta, dgamma);
+    LPD_CHECK_LAUNCH("lpd_edge_bn_bwd(reduce)");
+    hipLaunchKernelGGL(edge_bn_bwd_apply_kernel, dim3(grid_for(M, RG)), dim3(256), 0, ST(stream), dOut, ldo, arg, dDense, X, dX, dQ,
+                       ldq, k, M, C, scale, shift, mean, invstd, dbeta, dgamma, (double)M * k, act, slope);
+    LPD_CHECK_LAUNCH("lpd_edge_bn_bwd(apply)");
     return LPD_OK;
 }
 

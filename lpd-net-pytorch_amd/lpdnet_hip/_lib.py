@@ -47,6 +47,8 @@ SIGNATURES = {
     "lpd_edge_build": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p],
     "lpd_group_max": [_c_p, _c_ll, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p],
     "lpd_group_max_bwd": [_c_p, _c_ll, _c_p, _c_int, _c_p, _c_ll, _c_int, _c_int, _c_p],
+    "lpd_edge_bn_bwd": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int,
+                        _c_f, _c_p, _c_p, _c_p],
     "lpd_group_sum": [_c_p, _c_int, _c_p, _c_ll, _c_ll, _c_int, _c_p],
     "lpd_scatter_add_rows": [_c_p, _c_p, _c_p, _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_p],
     "lpd_dw_smallk": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_int, _c_p, _c_p],

@@ -194,26 +194,22 @@ class _LPDNetTrainFn(torch.autograd.Function):
         dcat, dw3, dg3, db3 = _PointLayer.bwd(dfeat, S["cat"], w2d(net.conv3_lpd), S["y3"], S["st3"], act, slope,
                                               inplace=False)
         # SN1: x3 = groupmax(act(BN(U3)))
-        du3 = ops.group_max_bwd(dcat[:, 256:512], S["arg3"], k)                 # sparse rows, [E,256]
-        du3, dgs3, dbs3 = ops.bn_act_bwd(du3, S["u3"], S["stg3"], act, slope, out=du3)
         dpq3 = torch.zeros((M, 512), dtype=torch.float32, device=dfeat.device)
-        ops.group_sum(du3, k, dpq3[:, 256:])
+        du3, dgs3, dbs3 = ops.edge_bn_bwd(dcat[:, 256:512], S["arg3"], k, S["u3"], S["stg3"], act, slope, dQ=dpq3[:, 256:])
         ops.scatter_add_rows(du3, S["idx_x"], dpq3[:, :256], N)
         del du3
         x2 = S["cat"][:, 128:256]
         dwcat3 = _dweight(dpq3, x2)
         ops.gemm(dpq3, S["wcat3"], b_kmajor=True, out=dcat[:, 128:256], accumulate=True)   # dx2 += dPQ3 Wcat3
         # DG2: x2 = groupmax(act(BN(Z))), Z = Y1e W2^T
-        dz = ops.group_max_bwd(dcat[:, 128:256], S["arg2"], k)
-        dz, dgs2, dbs2 = ops.bn_act_bwd(dz, S["z"], S["stg2"], act, slope, out=dz)
+        dz, dgs2, dbs2 = ops.edge_bn_bwd(dcat[:, 128:256], S["arg2"], k, S["z"], S["stg2"], act, slope)
         dw2 = _dweight(dz, S["y1e"])
         dy1e = ops.gemm(dz, w2d(net.convDG2[0]), b_kmajor=True)                 # [E,128]
         del dz
         # DG1: y1e = act(BN(U1)); consumers: DG2 (dense) and x1 = groupmax (sparse)
-        ops.group_max_bwd(dcat[:, 0:128], S["arg1"], k, dX=dy1e, accumulate=True)
-        du1, dgs1, dbs1 = ops.bn_act_bwd(dy1e, S["u1"], S["stg1"], act, slope, out=dy1e)
         dpq1 = torch.zeros((M, 256), dtype=torch.float32, device=dfeat.device)
-        ops.group_sum(du1, k, dpq1[:, 128:])
+        du1, dgs1, dbs1 = ops.edge_bn_bwd(dcat[:, 0:128], S["arg1"], k, S["u1"], S["stg1"], act, slope, dense=dy1e,
+                                          dQ=dpq1[:, 128:])
         ops.scatter_add_rows(du1, S["idx_f"], dpq1[:, :128], N)
         del du1, dy1e
         dwcat1 = _dweight(dpq1, S["f0"])
@@ -257,8 +253,7 @@ class _EdgeChain:
     def bwd(dout, S, w_b, idx, N, k, c, has_q, act, slope):
         """returns (dPQ [M, c or 2c], dW_b, dgamma_b, dbeta_b, dgamma_a, dbeta_a)"""
         M = dout.shape[0]
-        dz = ops.group_max_bwd(dout, S["arg"], k)
-        dz, dg_b, db_b = ops.bn_act_bwd(dz, S["z"], S["st_b"], act, slope, out=dz)
+        dz, dg_b, db_b = ops.edge_bn_bwd(dout, S["arg"], k, S["z"], S["st_b"], act, slope)
         dw_b = _dweight(dz, S["ya"])
         dya = ops.gemm(dz, w_b, b_kmajor=True)
         del dz

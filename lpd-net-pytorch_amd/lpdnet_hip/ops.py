@@ -404,6 +404,23 @@ def group_max_bwd(dOut, arg, k, dX=None, accumulate=False):
     return dX
 
 
+def edge_bn_bwd(dOut, arg, k, X, st, act, slope, dense=None, dQ=None):
+    """Fused backward through max-over-k + activation + train-mode BatchNorm on a materialised edge tensor X [M*k, C].
+    dOut [M, C] (view allowed): gradient of the group-max output; dense [M*k, C]: optional dense gradient on the
+    post-activation edges (overwritten with the result).  Returns (dX [M*k, C], dgamma, dbeta); fills dQ if given."""
+    ldo = _rows(dOut, "dOut")
+    M, C = arg.shape
+    dX = dense if dense is not None else torch.empty((M * k, C), dtype=torch.float32, device=X.device)
+    ldq = _rows(dQ, "dQ") if dQ is not None else 0
+    red = torch.empty((2, C), dtype=torch.float64, device=X.device)
+    lib = _lib.load()
+    _call(f"edge_bn_bwd[C={C}]", lib.lpd_edge_bn_bwd, _ptr(dOut), ldo, _ptr(arg), _ptr(dense), _ptr(X), _ptr(dX), _ptr(dQ), ldq, k,
+          M, C, _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(red[0]), _ptr(red[1]),
+          _stream())
+    redf = red.float()
+    return dX, redf[1], redf[0]
+
+
 def group_sum(dU, k, out):
     ldq = _rows(out, "out")
     M, C = out.shape
