@@ -145,10 +145,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run: one process per GPU over RCCL
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from lpdnet_hip import ops
     from util.PointNetVlad import PointNetVlad
