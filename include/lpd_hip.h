@@ -47,12 +47,13 @@ const char* lpd_last_error(void);
  *   x      [B][C][N] channel-major (exactly the reference's argument layout)
  *   idx    [B][N][k] int32, the k largest pd = -|x_i - x_j|^2 (reference arithmetic order, see
  *          csrc/lpd_knn.hip), descending; self is included; ties -> lower index first.
- *   xx_ws  workspace [B][N] floats (per-point sum of squares)
+ *   ws     workspace of B*N*(1 + 2*CP) floats, CP = 2 for C <= 4, 32 for C <= 64, 0 beyond: per-point sums of squares
+ *          followed by the packed MFMA operand image xp[b][n][h][s] = x[b][2s+h][n]
  *   impl   0 = f32-MFMA distance tiles + queued selection (product path); 1 = VALU fmaf cross-check (k <= 20);
  *          2 = first-generation MFMA kernel with in-scan insertion (kept for A/B timing)
  * Supported: C <= 256, k <= 64, k <= N.  Bit-exact vs the reference CPU path on tie-free rows.
  */
-int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* xx_ws, int impl, void* stream);
+int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* ws, int impl, void* stream);
 
 /*
  * Dense fp32 GEMM with fused epilogue:  C = act((A.B + bias) * scale + shift), per output column.

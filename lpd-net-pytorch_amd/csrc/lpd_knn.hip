@@ -274,61 +274,106 @@ constexpr int KNN3_WAVES = 4;
 constexpr int KNN3_THREADS = KNN3_WAVES * 64;
 constexpr int KNN3_QCAP = 40;   // queue slots per lane; a tile can add 16
 
-// per-lane operand fetch of candidate tile j0: a[s] = x[2s+h][j0+col] (zero beyond C or N)
+// ---- packed operand layout -------------------------------------------------------------------------------
+// Ablations on MI355X (tools/knn_bench.py, impl 10..41) showed the scan is INSTRUCTION-ISSUE bound, not MFMA- or
+// memory-bound: with channel-major operands every MFMA needed its own dword load plus ~6 scalar address
+// instructions (each channel row is N floats away), and the per-candidate exec-masked appends cost ~100 executed
+// instructions per tile even when nothing is admitted -- ~650 instructions per 32x32 tile against 32 MFMAs.
+// A pre-pass therefore repacks the cloud as xp[b][n][h][s] = x[b][2s+h][n] (h = k-half of the MFMA operand
+// layout): a lane's whole operand column is CP contiguous floats = CP/4 dwordx4 loads with immediate offsets.
 template <int CP>
-__device__ __forceinline__ float knn3_ld_a(const float* __restrict__ xb, int C, int N, int j0, int col, int h, int s)
+__global__ void knn_pack_kernel(const float* __restrict__ x, float* __restrict__ xp, int C, int N)
 {
-    const int j = j0 + col;
-    const int c = 2 * s + h;
-    return (j < N && c < C) ? xb[(size_t)c * N + j] : 0.0f;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= N) return;
+    const float* src = x + (size_t)b * C * N + n;
+    float* dst = xp + ((size_t)b * N + n) * (2 * CP);
+#pragma unroll 4
+    for (int h = 0; h < 2; ++h)
+        for (int s = 0; s < CP; ++s) {
+            const int c = 2 * s + h;
+            dst[h * CP + s] = c < C ? src[(size_t)c * N] : 0.0f;
+        }
+}
+
+// operand column of point j (clamped to N-1: padded candidates are neutralised through xx = NaN)
+template <int CP>
+__device__ __forceinline__ void knn3_ld_ops(const float* __restrict__ xpb, int N, int j, int h, float (&a)[CP])
+{
+    const float* row = xpb + ((size_t)min(j, N - 1) * 2 + h) * CP;
+    if constexpr (CP % 4 == 0) {
+#pragma unroll
+        for (int g = 0; g < CP / 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(row + 4 * g);
+            a[4 * g + 0] = v.x; a[4 * g + 1] = v.y; a[4 * g + 2] = v.z; a[4 * g + 3] = v.w;
+        }
+    } else {
+        const float2 v = *reinterpret_cast<const float2*>(row);
+        a[0] = v.x; a[1] = v.y;
+    }
 }
 
 // squared norms of the 16 candidate rows this lane receives from the MFMA (rows 8g+4h+{0..3}); NaN for padding
 __device__ __forceinline__ void knn3_ld_xx(const float* __restrict__ xxb, int N, int j0, int h, bool vec_ok, float4 (&x4)[4])
 {
+    if (vec_ok && j0 + 32 <= N) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) x4[g] = *reinterpret_cast<const float4*>(xxb + j0 + 8 * g + 4 * h);
+        return;
+    }
     const float nanv = __builtin_nanf("");   // padded candidates: pd = NaN, never admitted
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int r0 = j0 + 8 * g + 4 * h;
-        if (vec_ok && r0 + 3 < N) {
-            x4[g] = *reinterpret_cast<const float4*>(xxb + r0);
-        } else {
-            x4[g].x = r0 + 0 < N ? xxb[r0 + 0] : nanv;
-            x4[g].y = r0 + 1 < N ? xxb[r0 + 1] : nanv;
-            x4[g].z = r0 + 2 < N ? xxb[r0 + 2] : nanv;
-            x4[g].w = r0 + 3 < N ? xxb[r0 + 3] : nanv;
-        }
+        x4[g].x = r0 + 0 < N ? xxb[r0 + 0] : nanv;
+        x4[g].y = r0 + 1 < N ? xxb[r0 + 1] : nanv;
+        x4[g].z = r0 + 2 < N ? xxb[r0 + 2] : nanv;
+        x4[g].w = r0 + 3 < N ? xxb[r0 + 3] : nanv;
     }
 }
 
-// One tile: pd of 32 candidates x 32 queries on the MFMA.  Each operand register is refilled with the NEXT tile's
-// value right after the MFMA that consumed it has issued, so the loads for tile t+1 fly under tile t's MFMAs and
-// selection without a second register set.
+// One tile: pd of 32 candidates x 32 queries on the MFMA; operand registers are refilled with the NEXT tile's
+// values four at a time right after the MFMAs that consumed them have issued.
+//   pd = ((-xx_j) - (-2 dot)) - xx_i ;  (-xx_j) - (-2 dot) == fma(2, dot, -xx_j) bit for bit (2*dot is exact).
 template <int CP>
 __device__ __forceinline__ void knn3_tile(float (&a)[CP], float4 (&x4)[4], const float (&qreg)[CP], float xq,
-                                          const float* __restrict__ xb, const float* __restrict__ xxb, int C, int N,
-                                          int j_next, bool have_next, int col, int h, bool vec_ok, float (&pd)[16])
+                                          const float* __restrict__ xpb, const float* __restrict__ xxb, int N, int j_next,
+                                          bool have_next, int col, int h, bool vec_ok, float (&pd)[16])
 {
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float* row = xpb + ((size_t)min(j_next + col, N - 1) * 2 + h) * CP;
+    if constexpr (CP % 4 == 0) {
 #pragma unroll
-    for (int s = 0; s < CP; ++s) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], qreg[s], acc, 0, 0, 0);
-        if (have_next) a[s] = knn3_ld_a<CP>(xb, C, N, j_next, col, h, s);
+        for (int g = 0; g < CP / 4; ++g) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * g + e], qreg[4 * g + e], acc, 0, 0, 0);
+            if (have_next) {
+                const float4 v = *reinterpret_cast<const float4*>(row + 4 * g);
+                a[4 * g + 0] = v.x; a[4 * g + 1] = v.y; a[4 * g + 2] = v.z; a[4 * g + 3] = v.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < CP; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], qreg[s], acc, 0, 0, 0);
+        if (have_next) {
+            const float2 v = *reinterpret_cast<const float2*>(row);
+            a[0] = v.x; a[1] = v.y;
+        }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float4 xv = x4[r >> 2];
         const float xxj = (r & 3) == 0 ? xv.x : (r & 3) == 1 ? xv.y : (r & 3) == 2 ? xv.z : xv.w;
-        const float inner = __fmul_rn(-2.0f, acc[r]);
-        const float tt = __fsub_rn(-xxj, inner);
-        pd[r] = __fsub_rn(tt, xq);
+        pd[r] = __fsub_rn(__fmaf_rn(2.0f, acc[r], -xxj), xq);
     }
     if (have_next) knn3_ld_xx(xxb, N, j_next, h, vec_ok, x4);
 }
 
 template <int CP, int KMAX>
-__global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __restrict__ x, const float* __restrict__ xx,
-                                                             int32_t* __restrict__ idx, int C, int N, int k, int blocks_per_cloud, int dbg)
+__global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
+                                                             int32_t* __restrict__ idx, int N, int k, int blocks_per_cloud, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -343,18 +388,14 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __re
     const int q0 = qb * (KNN3_WAVES * 32) + wave * 32;   // first query of this wave
     const int q = q0 + col;
     const bool q_ok = q < N;
-    const float* xb = x + (size_t)b * C * N;
+    const float* xpb = xp + (size_t)b * N * (2 * CP);
     const float* xxb = xx + (size_t)b * N;
     const bool vec_ok = (N & 3) == 0;
     float2* myq = reinterpret_cast<float2*>(smem) + (size_t)wave * KNN3_QCAP * 64 + lane;   // slot s at myq[s*64]
 
     float qreg[CP];
-#pragma unroll
-    for (int s = 0; s < CP; ++s) {
-        const int c = 2 * s + h;
-        qreg[s] = (q_ok && c < C) ? xb[(size_t)c * N + q] : 0.0f;
-    }
-    const float xq = q_ok ? xxb[q] : 0.0f;
+    knn3_ld_ops<CP>(xpb, N, q, h, qreg);
+    const float xq = xxb[min(q, N - 1)];
 
     float lv[KMAX];
     int li[KMAX];
@@ -367,7 +408,7 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __re
     };
     reset_lists();
 
-    const int ntiles = (N + 31) / 32;
+    const int ntiles = (dbg & 16) ? 0 : (N + 31) / 32;   // dbg&16: timing ablation, empty scan
     float a[CP];
     float4 x4[4];
     float pd[16];
@@ -380,15 +421,16 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __re
         if (t_lo < 0) { t_hi -= t_lo; t_lo = 0; }
         if (t_hi > ntiles) { t_lo -= t_hi - ntiles; t_hi = ntiles; }
         if (t_lo < 0) t_lo = 0;
-#pragma unroll
-        for (int s = 0; s < CP; ++s) a[s] = knn3_ld_a<CP>(xb, C, N, t_lo * 32, col, h, s);
+        knn3_ld_ops<CP>(xpb, N, t_lo * 32 + col, h, a);
         knn3_ld_xx(xxb, N, t_lo * 32, h, vec_ok, x4);
         if (dbg & 2) t_hi = t_lo;   // timing ablation: no admission threshold
         for (int t = t_lo; t < t_hi; ++t) {
-            knn3_tile<CP>(a, x4, qreg, xq, xb, xxb, C, N, (t + 1) * 32, t + 1 < t_hi, col, h, vec_ok, pd);
+            knn3_tile<CP>(a, x4, qreg, xq, xpb, xxb, N, (t + 1) * 32, t + 1 < t_hi, col, h, vec_ok, pd);
+            // unconditional, branch-free insertion: a value that does not beat the K-th best (or NaN padding) is replaced
+            // by -inf, which leaves the list unchanged.  No divergent region => the compiler keeps the lists in place
+            // (inserting under `if` cost ~4x the useful instructions in v_mov copies at the control-flow join).
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (pd[r] > lv[KMAX - 1]) knn_insert<KMAX>(lv, li, pd[r], 0);
+            for (int r = 0; r < 16; ++r) knn_insert<KMAX>(lv, li, pd[r] > lv[KMAX - 1] ? pd[r] : -INFINITY, 0);
         }
     }
     // k-th best of my half; the larger of the two halves' values is reached by >= k candidates overall
@@ -404,35 +446,42 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __re
 
     // ---- phase B: ascending scan with queued selection ----
     int cnt = 0;
+    int stat_adm = 0, stat_it = 0, stat_pass = 0;   // diagnostics (dbg&64): admissions of this lane, drain iterations / passing tiles of the wave
     auto drain = [&]() {
-        for (int e = 0; __any(e < cnt); ++e) {
-            if (e < cnt) {
-                const float2 ent = myq[e * 64];
-                if (ent.x > lv[KMAX - 1]) knn_insert<KMAX>(lv, li, ent.x, __float_as_int(ent.y));   // FIFO => j ascending
-            }
+        stat_adm += cnt;
+        for (int e = 0; __any(e < cnt); ++e) {   // uniform trip count = the fullest queue of the wave
+            ++stat_it;
+            const float2 ent = myq[(e < cnt ? e : 0) * 64];
+            const float pv = (e < cnt && ent.x > lv[KMAX - 1]) ? ent.x : -INFINITY;   // -inf: no-op insert (branch-free)
+            knn_insert<KMAX>(lv, li, pv, __float_as_int(ent.y));                       // FIFO => j ascending
         }
         cnt = 0;
     };
-#pragma unroll
-    for (int s = 0; s < CP; ++s) a[s] = knn3_ld_a<CP>(xb, C, N, 0, col, h, s);
+    knn3_ld_ops<CP>(xpb, N, col, h, a);
     knn3_ld_xx(xxb, N, 0, h, vec_ok, x4);
     for (int t = 0; t < ntiles; ++t) {
-        knn3_tile<CP>(a, x4, qreg, xq, xb, xxb, C, N, (t + 1) * 32, (t + 1 < ntiles) && !(dbg & 4), col, h, vec_ok, pd);   // dbg&4: timing ablation, no operand refill
+        knn3_tile<CP>(a, x4, qreg, xq, xpb, xxb, N, (t + 1) * 32, (t + 1 < ntiles) && !(dbg & 4), col, h, vec_ok, pd);   // dbg&4: timing ablation, no operand refill
         const float thr = fmaxf(t0, lv[KMAX - 1]);
         const bool list_full = lv[KMAX - 1] > -INFINITY;
+        // tile-level reject: most tiles are far from all 32 (Z-ordered, hence clustered) queries of the wave; one max
+        // over the 16 values and a wave vote replace 16 exec-masked append sequences (~100 executed instructions)
+        float mx = fmaxf(fmaxf(fmaxf(pd[0], pd[1]), fmaxf(pd[2], pd[3])), fmaxf(fmaxf(pd[4], pd[5]), fmaxf(pd[6], pd[7])));
+        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(pd[8], pd[9]), fmaxf(pd[10], pd[11])), fmaxf(fmaxf(pd[12], pd[13]), fmaxf(pd[14], pd[15]))));
+        if (!__any(list_full ? (mx > thr) : (mx >= thr)) || (dbg & 1)) continue;   // dbg&1: timing ablation
+        ++stat_pass;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             // before the list is full every candidate reaching T0 is admitted; afterwards it must beat the k-th best
-            const bool admit = (list_full ? (pd[r] > thr) : (pd[r] >= thr)) && !(dbg & 1);   // dbg&1: timing ablation
+            const bool admit = list_full ? (pd[r] > thr) : (pd[r] >= thr);
             if (admit) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
                 myq[cnt * 64] = make_float2(pd[r], __int_as_float(t * 32 + row));
                 ++cnt;
             }
         }
-        if (__any(cnt > KNN3_QCAP - 16)) drain();
+        if (__any(cnt > KNN3_QCAP - 16)) { if (dbg & 32) cnt = 0; else drain(); }   // dbg&32: timing ablation, drop instead of drain
     }
-    drain();
+    if (!(dbg & 32)) drain();
 
     // ---- merge the two half-lists: both halves publish their sorted lists in this wave's (now free) queue region and
     // the lower half-wave walks the two lists with a 2-pointer merge (k steps of two LDS reads and a compare) ----
@@ -444,7 +493,11 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __re
         mi[lane * KMAX + s] = li[s];
     }
     __syncthreads();
-    if (h == 0 && q_ok) {
+    if ((dbg & 64) && q_ok) {   // diagnostics instead of indices: [admitted by this half, drain iterations, passing tiles, T0 bits]
+        if (h == 0) { int32_t* o = idx + ((size_t)b * N + q) * k; o[0] = stat_adm; o[1] = stat_it; o[2] = stat_pass; o[3] = __float_as_int(t0); }
+        else { int32_t* o = idx + ((size_t)b * N + q) * k; o[4] = stat_adm; }
+    } else
+    if (h == 0 && q_ok && !(dbg & 8)) {   // dbg&8: timing ablation, no merge / no output
         const float* av = mv + lane * KMAX;
         const int* ai = mi + lane * KMAX;
         const float* bv = mv + (lane + 32) * KMAX;
@@ -689,11 +742,15 @@ template <int CP, int KMAX>
 int knn3_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg = 0)
 {
     static_assert(KNN3_QCAP * 128 >= 2 * 64 * KMAX, "merge region must fit the wave's queue region");
+    // packed operands live behind the squared norms in the caller's workspace: [xx: B*N][xp: B*N*2*CP]
+    float* xp = const_cast<float*>(xx) + (size_t)B * N;
+    hipLaunchKernelGGL(knn_pack_kernel<CP>, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xp, C, N);
+    LPD_CHECK_LAUNCH("lpd_knn(pack)");
     size_t lds = (size_t)KNN3_WAVES * KNN3_QCAP * 64 * sizeof(float2);
     const int bpc = (N + KNN3_WAVES * 32 - 1) / (KNN3_WAVES * 32);
     auto kern = knn3_kernel<CP, KMAX>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(KNN3_THREADS), lds, stream, x, xx, idx, C, N, k, bpc, dbg);
+    hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(KNN3_THREADS), lds, stream, (const float*)xp, xx, idx, N, k, bpc, dbg);
     LPD_CHECK_LAUNCH("lpd_knn");
     return LPD_OK;
 }
@@ -765,7 +822,7 @@ extern "C" int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
         if (C <= 4) return knn3_dispatch_k<2>(x, xx_ws, idx, B, C, N, k, stream);
         if (C <= 64) return knn3_dispatch_k<32>(x, xx_ws, idx, B, C, N, k, stream);
         if (C <= 256) return knn_dispatch_k<128>(x, xx_ws, idx, B, C, N, k, 0, stream);   // wide features: v1
-    } else if (impl >= 10 && impl < 18 && k <= 20 && C <= 64) {   // timing ablations of the product kernel (wrong results)
+    } else if (impl >= 10 && impl < 138 && k <= 20 && C <= 64) {   // timing ablations of the product kernel (wrong results)
         if (C <= 4) return knn3_launch<2, 20>(x, xx_ws, idx, B, C, N, k, stream, impl - 10);
         return knn3_launch<32, 20>(x, xx_ws, idx, B, C, N, k, stream, impl - 10);
     } else if (impl == 3 && k <= 20 && C <= 64) {

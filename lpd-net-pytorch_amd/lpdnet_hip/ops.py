@@ -69,6 +69,13 @@ def _vec(t, name, n):
 KNN_IMPL = int(__import__("os").environ.get("LPD_KNN_IMPL", "0"))   # A/B switch for benchmarking (0 = product kernel)
 
 
+def knn_workspace_floats(B, C, N):
+    """Workspace of lpd_knn: squared norms [B*N] + the packed MFMA operand image [B*N*2*CP] (CP = 2 for C <= 4,
+    32 for C <= 64; wider features use the first-generation kernel, which needs the norms only)."""
+    cp = 2 if C <= 4 else (32 if C <= 64 else 0)
+    return B * N * (1 + 2 * cp)
+
+
 def knn(x_cm, k, impl=None):
     """x_cm [B,C,N] channel-major fp32 -> idx [B,N,k] int32 (reference util/lpdnet_model.py:317-326)."""
     if impl is None:
@@ -79,7 +86,7 @@ def knn(x_cm, k, impl=None):
     x_cm = x_cm.contiguous()
     B, C, N = x_cm.shape
     idx = torch.empty((B, N, k), dtype=torch.int32, device=x_cm.device)
-    ws = torch.empty((B, N), dtype=torch.float32, device=x_cm.device)
+    ws = torch.empty((knn_workspace_floats(B, C, N),), dtype=torch.float32, device=x_cm.device)
     lib = _lib.load()
     _call(f"knn[C={C},k={k}]", lib.lpd_knn, _ptr(x_cm), B, C, N, k, _ptr(idx), _ptr(ws), impl, _stream())
     return idx
