@@ -57,7 +57,9 @@ __device__ __forceinline__ float4 ld4_guard(const float* row, int i, int limit)
 }
 
 // TN: 32-wide n-tiles per wave (1 => BN = 64, 2 => BN = 128).  TM fixed at 2 (BM = 128).
-template <bool A_KMAJOR, bool B_KMAJOR, int TN>
+// KTAIL: the reduction length is not a multiple of 32 (ragged point counts); only then are the operand loads k-guarded
+// (the guards cost ~25 % on the big GEMMs when compiled in unconditionally).
+template <bool A_KMAJOR, bool B_KMAJOR, int TN, bool KTAIL>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
 {
     constexpr int BM = 128;
@@ -100,13 +102,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
             int f = e * GEMM_THREADS + tid;
             if constexpr (A_KMAJOR) {  // memory [k][m]: 32 float4 per k-row
                 int kk = f / (BM / 4), mq = f % (BM / 4);
-                ra[e] = (k0 + kk < g.Ktot) ? ld4_guard(A + (long long)(k0 + kk) * g.lda, m0 + mq * 4, g.M)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[e] = (!KTAIL || k0 + kk < g.Ktot) ? ld4_guard(A + (long long)(k0 + kk) * g.lda, m0 + mq * 4, g.M)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {                   // memory [m][k]: 8 float4 per m-row
                 int mm = f / (BK / 4), kq = f % (BK / 4);
                 int m = m0 + mm;
                 m = m < g.M ? m : g.M - 1;  // clamp: rows >= M are never stored
-                ra[e] = ld4_guard(A + (long long)m * g.lda, k0 + kq * 4, g.Ktot);
+                if constexpr (KTAIL) ra[e] = ld4_guard(A + (long long)m * g.lda, k0 + kq * 4, g.Ktot);
+                else ra[e] = *reinterpret_cast<const float4*>(A + (long long)m * g.lda + k0 + kq * 4);
             }
         }
 #pragma unroll
@@ -114,13 +117,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
             int f = e * GEMM_THREADS + tid;
             if constexpr (B_KMAJOR) {  // memory [k][n]
                 int kk = f / (BN / 4), nq = f % (BN / 4);
-                rb[e] = (k0 + kk < g.Ktot) ? ld4_guard(B + (long long)(k0 + kk) * g.ldb, n0 + nq * 4, g.N)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[e] = (!KTAIL || k0 + kk < g.Ktot) ? ld4_guard(B + (long long)(k0 + kk) * g.ldb, n0 + nq * 4, g.N)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {                   // memory [n][k]
                 int nn = f / (BK / 4), kq = f % (BK / 4);
                 int n = n0 + nn;
                 n = n < g.N ? n : g.N - 1;
-                rb[e] = ld4_guard(B + (long long)n * g.ldb, k0 + kq * 4, g.Ktot);
+                if constexpr (KTAIL) rb[e] = ld4_guard(B + (long long)n * g.ldb, k0 + kq * 4, g.Ktot);
+                else rb[e] = *reinterpret_cast<const float4*>(B + (long long)n * g.ldb + k0 + kq * 4);
             }
         }
     };
@@ -243,15 +247,26 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slabs, float
     *dst = v;
 }
 
+template <bool AK, bool BK_, int TN, bool KTAIL>
+int gemm_launch_t(const GemmArgs& g, int batch, hipStream_t stream);
+
 template <bool AK, bool BK_, int TN>
 int gemm_launch(const GemmArgs& g, int batch, hipStream_t stream)
+{
+    // every split covers whole 32-deep k-tiles of real data <=> Ktot is a multiple of 32 and splits divide it evenly
+    const bool ktail = (g.Ktot % GEMM_BK) != 0 || (long long)g.K * g.splits != g.Ktot;
+    return ktail ? gemm_launch_t<AK, BK_, TN, true>(g, batch, stream) : gemm_launch_t<AK, BK_, TN, false>(g, batch, stream);
+}
+
+template <bool AK, bool BK_, int TN, bool KTAIL>
+int gemm_launch_t(const GemmArgs& g, int batch, hipStream_t stream)
 {
     constexpr int BM = 128, BN = 64 * TN;
     constexpr int LDA = AK ? BM + 4 : BM + 1;
     constexpr int LDB = BK_ ? BN + 4 : BN + 1;
     size_t lds = (size_t)2 * GEMM_BK * (LDA + LDB) * sizeof(float);
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch * g.splits);
-    auto kern = gemm_f32_kernel<AK, BK_, TN>;
+    auto kern = gemm_f32_kernel<AK, BK_, TN, KTAIL>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, stream, g);
     LPD_CHECK_LAUNCH("lpd_gemm");
