@@ -160,7 +160,7 @@ int lpd_morton_sort(const float* xyz, float* out, int32_t* perm, int B, int N, v
  * ------------------------------------------------------------------------------------------------ */
 
 /* Column sums and sums of squares over R rows of X [R][ld] (BatchNorm batch statistics,
- * nn.BatchNorm1d/2d in train mode).  C = 4*2^n <= 1024. */
+ * nn.BatchNorm1d/2d in train mode).  C and ld multiples of 4. */
 int lpd_colstats(const float* X, long long ld, long long R, int C, double* sum, double* sumsq, void* stream);
 
 /* From the sums: mean, biased variance -> scale = gamma/sqrt(var+eps), shift = beta - mean*scale, mean, invstd;
@@ -214,6 +214,17 @@ int lpd_scatter_add_rows(const float* dU, const int32_t* idx, float* dP, long lo
 /* dW[o][c] = sum_m dY[m][o] * X[m][c] for Kin <= 8 input channels (first layer weight gradient). */
 int lpd_dw_smallk(const float* dY, long long lddy, const float* X, long long ldx, long long M, int Co, int Kin, float* dW,
                   void* stream);
+
+/* Per-cloud max over the N points with the arg-max row (first maximum): in [B][N][ld] -> out [B][C], arg [B][C]
+ * (train-mode MaxPool2d((num_points,1)) / torch.max(x, 2): util/PointNetVlad.py:162, util/lpdnet_model.py:300). */
+int lpd_colmax_arg(const float* in, long long ld, float* out, int32_t* arg, int B, int N, int C, void* stream);
+
+/* Backward of lpd_colmax_arg: dIn[b*N + arg[b][c]][c] = dOut[b][c]; dIn [B*N][ld] zero-filled by the caller. */
+int lpd_colmax_bwd(const float* dOut, const int32_t* arg, float* dIn, long long ld, int B, int N, int C, void* stream);
+
+/* Gradient of a per-cloud KD x KD alignment matrix (KD <= 8): dT[b] = sum over the cloud's points of X[m]^T dY[m]
+ * (backward of x @ trans, util/lpdnet_model.py:229, util/PointNetVlad.py:209). */
+int lpd_cloud_outer(const float* X, long long ldx, const float* dY, long long ldy, float* dT, int B, int N, int KD, void* stream);
 
 /* Softmax backward with the a_sum path folded in: dS = A*(g - sum_c A*g), g = dA + dasum[cloud]. */
 int lpd_softmax_bwd(const float* A, const float* dA, const float* dasum, float* dS, long long rows, int ncols,

@@ -570,6 +570,81 @@ __global__ __launch_bounds__(256) void vlad_finalize_bwd_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// T-Net / STN pieces: per-cloud max over the points with arg-max, its backward, and the gradient of the
+// per-cloud k x k alignment matrix for k <= 8 (lpdnet_model.py:229,300; PointNetVlad.py:162,209).
+// ---------------------------------------------------------------------------------------------
+// in [B][N][ld] -> out [B][C], arg [B][C] (row index inside the cloud, first maximum)
+__global__ __launch_bounds__(256) void colmax_arg_kernel(const float* __restrict__ in, long long ld, float* __restrict__ out,
+                                                         int32_t* __restrict__ arg, int N, int C)
+{
+    __shared__ float pv[4][64];
+    __shared__ int pi[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rg = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    float m = -INFINITY;
+    int am = 0;
+    if (c < C) {
+        const float* p = in + (size_t)b * N * ld + c;
+        for (int n = rg; n < N; n += 4) {
+            const float v = p[(size_t)n * ld];
+            if (v > m) { m = v; am = n; }
+        }
+    }
+    pv[rg][threadIdx.x & 63] = m;
+    pi[rg][threadIdx.x & 63] = am;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        for (int g = 1; g < 4; ++g) {
+            const float v = pv[g][threadIdx.x];
+            const int i = pi[g][threadIdx.x];
+            if (v > m || (v == m && i < am)) { m = v; am = i; }
+        }
+        out[(size_t)b * C + c] = m;
+        arg[(size_t)b * C + c] = am;
+    }
+}
+
+// dIn[b*N + arg[b][c]][c] = dOut[b][c]   (dIn zero-filled by the caller)
+__global__ void colmax_bwd_kernel(const float* __restrict__ dOut, const int32_t* __restrict__ arg, float* __restrict__ dIn,
+                                  long long ld, int B, int N, int C)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * C) return;
+    const int b = e / C, c = e - b * C;
+    dIn[((size_t)b * N + arg[e]) * ld + c] = dOut[e];
+}
+
+// dT[b][i][j] = sum_{m in cloud b} X[m][i] * dY[m][j],  i, j < KD <= 8.  One block per cloud.
+__global__ __launch_bounds__(256) void cloud_outer_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ dY,
+                                                          long long ldy, float* __restrict__ dT, int N, int KD)
+{
+    __shared__ float red[4][64];
+    const int b = blockIdx.x;
+    float acc[64];
+#pragma unroll
+    for (int e = 0; e < 64; ++e) acc[e] = 0.0f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float* x = X + ((size_t)b * N + n) * ldx;
+        const float* y = dY + ((size_t)b * N + n) * ldy;
+        for (int i = 0; i < KD; ++i)
+            for (int j = 0; j < KD; ++j) acc[i * 8 + j] += x[i] * y[j];
+    }
+    for (int i = 0; i < KD; ++i)
+        for (int j = 0; j < KD; ++j) {
+            float v = acc[i * 8 + j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i * 8 + j] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < KD * KD) {
+        const int i = threadIdx.x / KD, j = threadIdx.x % KD;
+        dT[(size_t)b * KD * KD + threadIdx.x] = red[0][i * 8 + j] + red[1][i * 8 + j] + red[2][i * 8 + j] + red[3][i * 8 + j];
+    }
+}
+
 inline int grid_for(long long work_items, int per_block)
 {
     long long b = (work_items + per_block - 1) / per_block;
@@ -587,11 +662,18 @@ inline bool cols_ok(int C) { return C >= 4 && C % 4 == 0 && (C / 4) <= 256 && 25
 extern "C" int lpd_colstats(const float* X, long long ld, long long R, int C, double* sum, double* sumsq, void* stream)
 {
     LPD_CHECK_ARG(X && sum && sumsq && R > 0, "lpd_colstats: bad arguments");
-    LPD_CHECK_ARG(cols_ok(C) && ld % 4 == 0, "lpd_colstats: C=%d must be 4*2^n <= 1024 and ld %% 4 == 0", C);
+    LPD_CHECK_ARG(C >= 4 && C % 4 == 0 && ld % 4 == 0, "lpd_colstats: C=%d and ld must be multiples of 4", C);
     (void)hipMemsetAsync(sum, 0, sizeof(double) * C, ST(stream));
     (void)hipMemsetAsync(sumsq, 0, sizeof(double) * C, ST(stream));
-    const int RG = 256 / (C / 4);
-    hipLaunchKernelGGL(colstats_kernel, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream), X, ld, R, C, sum, sumsq);
+    // the kernel takes a column panel of 4*2^n <= 1024 columns; other widths (k*k = 12, 4096 of the T-Nets) go panel by panel
+    for (int c0 = 0; c0 < C;) {
+        int w = 1024;
+        while (w > C - c0) w >>= 1;
+        const int RG = 256 / (w / 4);
+        hipLaunchKernelGGL(colstats_kernel, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream), X + c0, ld, R, w, sum + c0,
+                           sumsq + c0);
+        c0 += w;
+    }
     LPD_CHECK_LAUNCH("lpd_colstats");
     return LPD_OK;
 }
@@ -746,5 +828,30 @@ extern "C" int lpd_vlad_finalize_bwd(const float* dOut, const float* v, const fl
     hipLaunchKernelGGL(vlad_finalize_bwd_kernel<64>, dim3(B), dim3(256), 0, ST(stream), dOut, v, inv_c, inv_g, asum, cw2, dVraw,
                        dasum, dcw2, F);
     LPD_CHECK_LAUNCH("lpd_vlad_finalize_bwd");
+    return LPD_OK;
+}
+
+extern "C" int lpd_colmax_arg(const float* in, long long ld, float* out, int32_t* arg, int B, int N, int C, void* stream)
+{
+    LPD_CHECK_ARG(in && out && arg && B > 0 && B <= 65535 && N > 0 && C > 0, "lpd_colmax_arg: bad arguments");
+    hipLaunchKernelGGL(colmax_arg_kernel, dim3((C + 63) / 64, B), dim3(256), 0, ST(stream), in, ld, out, arg, N, C);
+    LPD_CHECK_LAUNCH("lpd_colmax_arg");
+    return LPD_OK;
+}
+
+extern "C" int lpd_colmax_bwd(const float* dOut, const int32_t* arg, float* dIn, long long ld, int B, int N, int C, void* stream)
+{
+    LPD_CHECK_ARG(dOut && arg && dIn && B > 0 && N > 0 && C > 0, "lpd_colmax_bwd: bad arguments");
+    hipLaunchKernelGGL(colmax_bwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, ST(stream), dOut, arg, dIn, ld, B, N, C);
+    LPD_CHECK_LAUNCH("lpd_colmax_bwd");
+    return LPD_OK;
+}
+
+extern "C" int lpd_cloud_outer(const float* X, long long ldx, const float* dY, long long ldy, float* dT, int B, int N, int KD,
+                               void* stream)
+{
+    LPD_CHECK_ARG(X && dY && dT && B > 0 && N > 0 && KD > 0 && KD <= 8, "lpd_cloud_outer: bad arguments (KD <= 8)");
+    hipLaunchKernelGGL(cloud_outer_kernel, dim3(B), dim3(256), 0, ST(stream), X, ldx, dY, ldy, dT, N, KD);
+    LPD_CHECK_LAUNCH("lpd_cloud_outer");
     return LPD_OK;
 }

@@ -52,6 +52,9 @@ SIGNATURES = {
     "lpd_group_sum": [_c_p, _c_int, _c_p, _c_ll, _c_ll, _c_int, _c_p],
     "lpd_scatter_add_rows": [_c_p, _c_p, _c_p, _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_p],
     "lpd_dw_smallk": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_int, _c_p, _c_p],
+    "lpd_colmax_arg": [_c_p, _c_ll, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
+    "lpd_colmax_bwd": [_c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p],
+    "lpd_cloud_outer": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_int, _c_int, _c_int, _c_p],
     "lpd_softmax_bwd": [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_p],
     "lpd_vlad_finalize_bwd": [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "lpd_metric_loss": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_int, _c_int, _c_int,

@@ -129,6 +129,179 @@ class _PointLayer:
         return dx, dw, dgamma, dbeta
 
 
+class _Dense:
+    """y = act(BN_train(x W^T + bias)) or act(x W^T + bias) -- the general per-row layer (bias and BatchNorm optional;
+    T-Net / STN / PointNet stacks: util/lpdnet_model.py:297-305, util/PointNetVlad.py:152-175,213-230)."""
+
+    @staticmethod
+    def fwd(x, lin, bn, act, slope=0.0, rows=None):
+        from . import engine
+        w = engine._w2d(lin)
+        raw = ops.linear(x, w, bias=lin.bias)
+        if bn is not None:
+            st = ops.bn_train_stats(raw, bn, rows=rows)
+            out = ops.affine_act(raw, st.scale, st.shift, act, slope, rows=rows)
+        else:
+            st = None
+            out = ops.affine_act(raw, None, None, act, slope, rows=rows) if act != ops.ACT_NONE else raw
+        return raw, st, out
+
+    @staticmethod
+    def bwd(dout, x, lin, raw, st, act, slope=0.0, need_dx=True, inplace=True, rows=None, dx_accum=None):
+        """-> (dx or None, dW, dbias or None, dgamma or None, dbeta or None); dx_accum: add dx into this buffer instead"""
+        from . import engine
+        w = engine._w2d(lin)
+        R = raw.shape[0] if rows is None else rows
+        if st is None and act == ops.ACT_NONE:
+            draw = dout
+            dbias = ops.colsum(draw, rows=R) if lin.bias is not None else None
+            dgamma = dbeta = None
+        else:
+            draw, dgamma, dbeta = ops.bn_act_bwd(dout, raw, st, act, slope, out=dout if inplace else None, rows=R)
+            if st is None:
+                dbias, dgamma, dbeta = (dbeta if lin.bias is not None else None), None, None   # sum of dpre = bias gradient
+            else:
+                dbias = ops.colsum(draw, rows=R) if lin.bias is not None else None               # analytically 0 before a BN
+        dw = _dweight(draw, x, rows=R)
+        dx = None
+        if need_dx:
+            if w.shape[1] % 4 != 0:   # 3-channel input: the B operand needs a leading dim that is a multiple of 4
+                wp = torch.zeros((w.shape[0], (w.shape[1] + 3) // 4 * 4), dtype=w.dtype, device=w.device)
+                wp[:, :w.shape[1]] = w
+                dx = ops.gemm(draw[:R], wp, b_kmajor=True)[:, :w.shape[1]]
+            elif dx_accum is not None:
+                dx = ops.gemm(draw[:R], w, b_kmajor=True, out=dx_accum, accumulate=True)
+            else:
+                dx = ops.gemm(draw[:R], w, b_kmajor=True)
+        return dx, dw.reshape(lin.weight.shape), dbias, dgamma, dbeta
+
+
+class _TNet:
+    """TranformNet (lpdnet_model.py:273-313) / STN3d (PointNetVlad.py:126-179) in train mode: rows [B*N, kd] -> [B,kd,kd]."""
+
+    NAMES = ("conv1", "conv2", "conv3", "fc1", "fc2", "fc3")
+
+    @staticmethod
+    def param_names(net, use_bn):
+        names = []
+        for i, lname in enumerate(_TNet.NAMES):
+            names += [f"{lname}.weight", f"{lname}.bias"]
+            if use_bn and i < 5:
+                names += [f"bn{i + 1}.weight", f"bn{i + 1}.bias"]
+        return names
+
+    @staticmethod
+    def fwd(net, h, B, N, use_bn):
+        kd = net.k
+        bns = [getattr(net, f"bn{i}") if use_bn else None for i in range(1, 6)]
+        S = dict(h=h)
+        S["r1"], S["s1"], a1 = _Dense.fwd(h, net.conv1, bns[0], ops.ACT_RELU)
+        S["r2"], S["s2"], a2 = _Dense.fwd(a1, net.conv2, bns[1], ops.ACT_RELU)
+        S["r3"], S["s3"], a3 = _Dense.fwd(a2, net.conv3, bns[2], ops.ACT_RELU)
+        g, S["arg"] = ops.colmax_arg(a3, B, N)
+        del a3
+        S["r4"], S["s4"], a4 = _Dense.fwd(g, net.fc1, bns[3], ops.ACT_RELU)
+        S["r5"], S["s5"], a5 = _Dense.fwd(a4, net.fc2, bns[4], ops.ACT_RELU)
+        w3 = net.fc3.weight
+        kk = kd * kd
+        ld = (kk + 3) // 4 * 4
+        t = torch.zeros((B, ld), dtype=torch.float32, device=h.device)        # padded leading dim (k*k = 9 -> 12)
+        eye = torch.eye(kd, device=h.device).flatten()
+        ops.linear(a5, w3, bias=(net.fc3.bias + eye), out=t[:, :kk])
+        S.update(a1=a1, a2=a2, g=g, a4=a4, a5=a5, ld=ld)
+        return t[:, :kk].reshape(B, kd, kd).contiguous(), S
+
+    @staticmethod
+    def bwd(net, dtrans, S, B, N, use_bn, need_dh, dh_accum=None):
+        """dtrans [B,kd,kd] -> (dh [B*N,kd] or None, grads in param_names order); dh_accum: buffer dh is added into"""
+        kd = net.k
+        kk, ld = kd * kd, S["ld"]
+        dt = torch.zeros((B, ld), dtype=torch.float32, device=dtrans.device)
+        dt[:, :kk] = dtrans.reshape(B, kk)
+        # fc3 (no BN, no activation)
+        dw3 = ops.gemm(dt, S["a5"], a_kmajor=True, b_kmajor=True)[:kk]          # [ld,256] -> [kk,256]
+        db3 = ops.colsum(dt)[:kk]
+        w3p = torch.zeros((ld, net.fc3.weight.shape[1]), dtype=torch.float32, device=dt.device)   # rows padded like dt's columns
+        w3p[:kk] = net.fc3.weight
+        da5 = ops.gemm(dt, w3p, b_kmajor=True)                                  # [B,256]
+        da4, dw2f, db2f, dg5, dbt5 = _Dense.bwd(da5, S["a4"], net.fc2, S["r5"], S["s5"], ops.ACT_RELU)
+        dg, dw1f, db1f, dg4, dbt4 = _Dense.bwd(da4, S["g"], net.fc1, S["r4"], S["s4"], ops.ACT_RELU)
+        da3 = ops.colmax_bwd(dg, S["arg"], N)
+        da2, dwc3, dbc3, dg3, dbt3 = _Dense.bwd(da3, S["a2"], net.conv3, S["r3"], S["s3"], ops.ACT_RELU)
+        da1, dwc2, dbc2, dg2, dbt2 = _Dense.bwd(da2, S["a1"], net.conv2, S["r2"], S["s2"], ops.ACT_RELU)
+        dh, dwc1, dbc1, dg1, dbt1 = _Dense.bwd(da1, S["h"], net.conv1, S["r1"], S["s1"], ops.ACT_RELU, need_dx=need_dh,
+                                                  dx_accum=dh_accum)
+        per_layer = [(dwc1, dbc1, dg1, dbt1), (dwc2, dbc2, dg2, dbt2), (dwc3, dbc3, dg3, dbt3), (dw1f, db1f, dg4, dbt4),
+                     (dw2f, db2f, dg5, dbt5), (dw3.reshape(net.fc3.weight.shape), db3, None, None)]
+        grads = []
+        for i, (dw, db, dgm, dbt) in enumerate(per_layer):
+            grads += [dw, db]
+            if use_bn and i < 5:
+                grads += [dgm, dbt]
+        return dh, grads
+
+
+def _transform_bwd(x, trans, dy, B, N):
+    """backward of y[m] = x[m] @ trans[cloud(m)]: (dx [M,kd], dtrans [B,kd,kd])."""
+    kd = x.shape[1]
+    if kd <= 8:
+        dx = ops.apply_transform(dy.contiguous(), trans.transpose(1, 2).contiguous(), N)
+        dtr = ops.cloud_outer(x, dy, B, N)
+    else:
+        dyc = dy.contiguous()
+        dx = ops.gemm(dyc.view(B, N, kd), trans, b_kmajor=False).view(B * N, kd)            # dy @ trans^T
+        dtr = ops.gemm(x.contiguous().view(B, N, kd), dyc.view(B, N, kd), a_kmajor=True, b_kmajor=True)   # x^T dy per cloud
+    return dx, dtr
+
+
+class _Front:
+    """The shared front of both LPD-Net trunks: [T-Net3d ->] conv1+bn1 -> conv2+bn2 [-> feature T-Net]
+    (util/lpdnet_model.py:85-99 and :226-241).  Bias-free convs; T-Nets optional."""
+
+    @staticmethod
+    def tnet_param_names(net):
+        names = []
+        if net.t3d:      # gradient order of bwd(): t_net3d, then t_net_fea
+            names += ["t_net3d." + n for n in _TNet.param_names(net.t_net3d, True)]
+        if net.tfea:
+            names += ["t_net_fea." + n for n in _TNet.param_names(net.t_net_fea, True)]
+        return names
+
+    @staticmethod
+    def fwd(net, xyz, w1, bn1, w2, bn2, B, N, act, slope):
+        S = dict(xyz=xyz, p_in=xyz)
+        if net.t3d:
+            S["trans3"], S["S3"] = _TNet.fwd(net.t_net3d, xyz, B, N, True)
+            S["p_in"] = ops.apply_transform(xyz, S["trans3"], N)
+        S["y1"], S["st1"], S["f1"] = _PointLayer.fwd(S["p_in"], w1, bn1, act, slope)
+        S["y2"], S["st2"], f0 = _PointLayer.fwd(S["f1"], w2, bn2, act, slope)
+        if net.tfea:
+            S["f_pre"] = f0
+            S["transf"], S["Sf"] = _TNet.fwd(net.t_net_fea, f0, B, N, True)
+            f0 = ops.apply_transform(f0, S["transf"], N)
+        return f0, S
+
+    @staticmethod
+    def bwd(net, df0, S, w1, w2, B, N, act, slope):
+        """-> ((dW1, dgamma1, dbeta1, dW2, dgamma2, dbeta2), [T-Net grads in tnet_param_names order])"""
+        g_f, g_3 = [], []
+        if net.tfea:   # f = f_pre @ transf: gradient to f_pre directly and through the feature T-Net
+            dfp, dtf = _transform_bwd(S["f_pre"], S["transf"], df0, B, N)
+            df0, g_f = _TNet.bwd(net.t_net_fea, dtf, S["Sf"], B, N, True, need_dh=True, dh_accum=dfp)
+        df1, dwc2, dg2, db2 = _PointLayer.bwd(df0, S["f1"], w2, S["y2"], S["st2"], act, slope)
+        if net.t3d:    # p = xyz @ trans3 feeds conv1: gradient to trans3 only (the cloud itself needs none)
+            dy1, dg1, db1 = ops.bn_act_bwd(df1, S["y1"], S["st1"], act, slope, out=df1)
+            dwc1 = _dweight(dy1, S["p_in"])
+            w1p = torch.zeros((w1.shape[0], 4), dtype=torch.float32, device=w1.device)
+            w1p[:, :3] = w1
+            dp = ops.gemm(dy1, w1p, b_kmajor=True)[:, :3]
+            dt3 = ops.cloud_outer(S["xyz"], dp, B, N)
+            _, g_3 = _TNet.bwd(net.t_net3d, dt3, S["S3"], B, N, True, need_dh=False)
+        else:
+            _, dwc1, dg1, db1 = _PointLayer.bwd(df1, S["p_in"], w1, S["y1"], S["st1"], act, slope, need_dx=False)
+        return (dwc1, dg1, db1, dwc2, dg2, db2), list(g_3) + list(g_f)
+
+
 def _unsplit_cat_nc(dwcat, conv_weight):
     """gradient of the stacked [W_n ; W_c] projection -> gradient of the conv weight [Co, 2Ci, 1, 1]."""
     co = conv_weight.shape[0]
@@ -151,8 +324,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         act, slope = (ops.ACT_RELU, 0.0) if net.use_relu else (ops.ACT_LEAKY, LEAKY)
         w2d = engine._w2d
         xyz = x.view(M, 3)
-        y1, st1, f1 = _PointLayer.fwd(xyz, w2d(net.conv1_lpd), net.bn1_lpd, act, slope)
-        y2, st2, f0 = _PointLayer.fwd(f1, w2d(net.conv2_lpd), net.bn2_lpd, act, slope)
+        f0, front = _Front.fwd(net, xyz, w2d(net.conv1_lpd), net.bn1_lpd, w2d(net.conv2_lpd), net.bn2_lpd, B, N, act, slope)
         idx_f = ops.knn(ops.transpose(f0.view(B, N, 64)), k)
         cat = torch.empty((M, 512), dtype=torch.float32, device=x.device)
         # DG1 (split projection, materialised edges)
@@ -175,7 +347,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         arg3 = ops.group_max(u3, k, stg3.scale, stg3.shift, act, slope, cat[:, 256:512])          # x3
         y3, st3, feat = _PointLayer.fwd(cat, w2d(net.conv3_lpd), net.bn3_lpd, act, slope)
         ctx.net, ctx.dims, ctx.actslope = net, (B, N, M, k), (act, slope)
-        ctx.saved = dict(xyz=xyz, y1=y1, st1=st1, f1=f1, y2=y2, st2=st2, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1,
+        ctx.saved = dict(front=front, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1,
                          u1=u1, stg1=stg1, arg1=arg1, y1e=y1e, z=z, stg2=stg2, arg2=arg2, wcat3=wcat3, u3=u3, stg3=stg3,
                          arg3=arg3, cat=cat, y3=y3, st3=st3)
         if engine.DEBUG_AUX is not None:
@@ -216,15 +388,14 @@ class _LPDNetTrainFn(torch.autograd.Function):
         df0 = ops.gemm(dpq1, S["wcat1"], b_kmajor=True)                         # [M,64]
         if engine.DEBUG_AUX is not None:
             engine.DEBUG_AUX.update(dcat=dcat.clone(), dpq3=dpq3.clone(), dpq1=dpq1.clone(), df0=df0.clone())
-        # conv2 + bn2, conv1 + bn1
-        df1, dwc2, dg2, db2 = _PointLayer.bwd(df0, S["f1"], w2d(net.conv2_lpd), S["y2"], S["st2"], act, slope)
-        _, dwc1, dg1, db1 = _PointLayer.bwd(df1, S["xyz"], w2d(net.conv1_lpd), S["y1"], S["st1"], act, slope, need_dx=False)
+        (dwc1, dg1, db1, dwc2, dg2, db2), extra = _Front.bwd(net, df0, S["front"], w2d(net.conv1_lpd), w2d(net.conv2_lpd), B, N,
+                                                             act, slope)
         grads = (dwc1.reshape(net.conv1_lpd.weight.shape), dg1, db1, dwc2.reshape(net.conv2_lpd.weight.shape), dg2, db2,
                  _unsplit_cat_nc(dwcat1, net.convDG1[0].weight), dgs1, dbs1, dw2.reshape(net.convDG2[0].weight.shape), dgs2,
                  dbs2, _unsplit_cat_nc(dwcat3, net.convSN1[0].weight), dgs3, dbs3, dw3.reshape(net.conv3_lpd.weight.shape),
                  dg3, db3)
         ctx.saved = None
-        return (None, None) + grads
+        return (None, None) + grads + tuple(extra)
 
 
 def _unsplit_cat_cd(dwcat, conv_weight):
@@ -280,10 +451,10 @@ class _LPDNetOrignTrainFn(torch.autograd.Function):
         act, slope = (ops.ACT_RELU, 0.0) if net.use_relu else (ops.ACT_LEAKY, LEAKY)
         w2d = engine._w2d
         xyz = x.view(M, 3)
-        S = dict(xyz=xyz)
-        S["y1"], S["st1"], f1 = _PointLayer.fwd(xyz, w2d(net.conv1_lpd[0]), net.conv1_lpd[1], act, slope)
-        S["y2"], S["st2"], f0 = _PointLayer.fwd(f1, w2d(net.conv2_lpd[0]), net.conv2_lpd[1], act, slope)
-        S["f1"], S["f0"] = f1, f0
+        S = {}
+        f0, S["front"] = _Front.fwd(net, xyz, w2d(net.conv1_lpd[0]), net.conv1_lpd[1], w2d(net.conv2_lpd[0]), net.conv2_lpd[1],
+                                    B, N, act, slope)
+        S["f0"] = f0
         idx_f = ops.knn(ops.transpose(f0.view(B, N, 64)), k)
         wcat1 = engine.split_edge_weight(net.convDG1, "cat_cd")
         pq1 = ops.linear(f0, wcat1)                                               # [M,128] = [P | Q]
@@ -322,8 +493,8 @@ class _LPDNetOrignTrainFn(torch.autograd.Function):
         dpq1, dwdg2, dgdg2, dbdg2, dgdg1, dbdg1 = _EdgeChain.bwd(dg_, S["dg"], w2d(net.convDG2[0]), S["idx_f"], N, k, 64, True, act, slope)
         dwcat1 = _dweight(dpq1, S["f0"])
         df0 = ops.gemm(dpq1, S["wcat1"], b_kmajor=True)
-        df1, dwc2, dg2, db2 = _PointLayer.bwd(df0, S["f1"], w2d(net.conv2_lpd[0]), S["y2"], S["st2"], act, slope)
-        _, dwc1, dg1, db1 = _PointLayer.bwd(df1, S["xyz"], w2d(net.conv1_lpd[0]), S["y1"], S["st1"], act, slope, need_dx=False)
+        (dwc1, dg1, db1, dwc2, dg2, db2), extra = _Front.bwd(net, df0, S["front"], w2d(net.conv1_lpd[0]), w2d(net.conv2_lpd[0]),
+                                                             B, N, act, slope)
 
         def shp(dw, seq):
             return dw.reshape(seq[0].weight.shape)
@@ -332,17 +503,14 @@ class _LPDNetOrignTrainFn(torch.autograd.Function):
                  shp(dwsn1, net.convSN1), dgsn1, dbsn1, shp(dwsn2, net.convSN2), dgsn2, dbsn2,
                  shp(dw3, net.conv3_lpd), dg3, db3, shp(dw4, net.conv4_lpd), dg4, db4, shp(dw5, net.conv5_lpd), dg5, db5)
         ctx.saved = None
-        return (None, None) + grads
+        return (None, None) + grads + tuple(extra)
 
 
 def lpdnet_origin_features_train(net, x):
     """LPDNetOrign training-mode forward: ([B*N, E] features with autograd, B, N)."""
     from . import engine
-    if net.t3d or net.tfea:
-        raise NotImplementedError("training with the T-Nets (xyz_trans / feature_transform) is not built on the HIP path yet; "
-                                  "inference (.eval()) supports them")
     x = engine.reorder_points(engine._check_input(x))
-    params = _named(net, _LPDNetOrignTrainFn.PARAMS)
+    params = _named(net, list(_LPDNetOrignTrainFn.PARAMS) + _Front.tnet_param_names(net))
     feat = _LPDNetOrignTrainFn.apply(net, x, *params)
     return feat, x.shape[0], x.shape[2]
 
@@ -360,18 +528,80 @@ def _named(module, names):
 def lpdnet_features_train(net, x):
     """LPDNet training-mode forward: ([B*N, E] features with autograd, B, N)."""
     from . import engine
-    if net.t3d or net.tfea:
-        raise NotImplementedError("training with the T-Nets (xyz_trans / feature_transform) is not built on the HIP path yet; "
-                                  "inference (.eval()) supports them")
     x = engine.reorder_points(engine._check_input(x))
-    params = _named(net, _LPDNetTrainFn.PARAMS)
-    feat = _LPDNetTrainFn.apply(net, x, *params)
+    names = list(_LPDNetTrainFn.PARAMS) + _Front.tnet_param_names(net)
+    feat = _LPDNetTrainFn.apply(net, x, *_named(net, names))
     return feat, x.shape[0], x.shape[2]
 
 
+class _PointNetTrainFn(torch.autograd.Function):
+    """PointNetfeat.forward in train mode, max_pool=False (util/PointNetVlad.py:204-233): STN3d(k=3, no BN) alignment,
+    conv1..conv5 with bias + BatchNorm2d (ReLU after bn1..bn4, none after bn5), optional 64x64 feature transform."""
+
+    LAYERS = (("conv1", "bn1"), ("conv2", "bn2"), ("conv3", "bn3"), ("conv4", "bn4"), ("conv5", "bn5"))
+
+    @staticmethod
+    def param_names(net):
+        names = ["stn." + n for n in _TNet.param_names(net.stn, net.stn.use_bn)]
+        for c, b in _PointNetTrainFn.LAYERS:
+            names += [f"{c}.weight", f"{c}.bias", f"{b}.weight", f"{b}.bias"]
+        if net.apply_feature_trans:
+            names += ["feature_trans." + n for n in _TNet.param_names(net.feature_trans, net.feature_trans.use_bn)]
+        return names
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        B, N = x.shape[0], x.shape[2]
+        xyz = x.view(B * N, 3)
+        S = dict(xyz=xyz)
+        S["trans"], S["S3"] = _TNet.fwd(net.stn, xyz, B, N, net.stn.use_bn)
+        S["p"] = ops.apply_transform(xyz, S["trans"], N)
+        S["r1"], S["s1"], S["a1"] = _Dense.fwd(S["p"], net.conv1, net.bn1, ops.ACT_RELU)
+        S["r2"], S["s2"], S["a2"] = _Dense.fwd(S["a1"], net.conv2, net.bn2, ops.ACT_RELU)
+        S["h"] = S["a2"]
+        if net.apply_feature_trans:
+            S["transf"], S["Sf"] = _TNet.fwd(net.feature_trans, S["a2"], B, N, net.feature_trans.use_bn)
+            S["h"] = ops.apply_transform(S["a2"], S["transf"], N)
+        S["r3"], S["s3"], S["a3"] = _Dense.fwd(S["h"], net.conv3, net.bn3, ops.ACT_RELU)
+        S["r4"], S["s4"], S["a4"] = _Dense.fwd(S["a3"], net.conv4, net.bn4, ops.ACT_RELU)
+        S["r5"], S["s5"], out = _Dense.fwd(S["a4"], net.conv5, net.bn5, ops.ACT_NONE)
+        ctx.net, ctx.saved, ctx.dims = net, S, (B, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        net, S = ctx.net, ctx.saved
+        B, N = ctx.dims
+        R = ops.ACT_RELU
+        dfeat = dfeat.contiguous()
+        da4, dw5, dc5, dg5, db5 = _Dense.bwd(dfeat, S["a4"], net.conv5, S["r5"], S["s5"], ops.ACT_NONE, inplace=False)
+        da3, dw4, dc4, dg4, db4 = _Dense.bwd(da4, S["a3"], net.conv4, S["r4"], S["s4"], R)
+        dh, dw3, dc3, dg3, db3 = _Dense.bwd(da3, S["h"], net.conv3, S["r3"], S["s3"], R)
+        g_f = []
+        if net.apply_feature_trans:
+            da2, dtf = _transform_bwd(S["a2"], S["transf"], dh, B, N)
+            da2, g_f = _TNet.bwd(net.feature_trans, dtf, S["Sf"], B, N, net.feature_trans.use_bn, need_dh=True, dh_accum=da2)
+        else:
+            da2 = dh
+        da1, dw2, dc2, dg2, db2 = _Dense.bwd(da2, S["a1"], net.conv2, S["r2"], S["s2"], R)
+        dp, dw1, dc1, dg1, db1 = _Dense.bwd(da1, S["p"], net.conv1, S["r1"], S["s1"], R)
+        dt3 = ops.cloud_outer(S["xyz"], dp, B, N)
+        _, g_3 = _TNet.bwd(net.stn, dt3, S["S3"], B, N, net.stn.use_bn, need_dh=False)
+        grads = list(g_3) + [dw1, dc1, dg1, db1, dw2, dc2, dg2, db2, dw3, dc3, dg3, db3, dw4, dc4, dg4, db4,
+                             dw5, dc5, dg5, db5] + list(g_f)
+        ctx.saved = None
+        return (None, None) + tuple(grads)
+
+
 def pointnet_features_train(net, x):
-    raise NotImplementedError("PointNetfeat training-mode forward is not built on the HIP path yet (BASELINE configs[0] is the "
-                              "reference's CPU plumbing case); inference (.eval()) is supported")
+    """PointNetfeat (max_pool=False) train-mode trunk: -> (features [B*N, emb_dims] point-major, B, N)."""
+    from . import engine
+    x = engine._check_input(x)
+    B, N = x.shape[0], x.shape[2]
+    if N != net.num_points:
+        raise ValueError(f"PointNetfeat was built for num_points={net.num_points}, got N={N} (MaxPool2d((num_points,1)))")
+    feat = _PointNetTrainFn.apply(net, x, *_named(net, _PointNetTrainFn.param_names(net)))
+    return feat, B, N
 
 
 class _NetVLADTrainFn(torch.autograd.Function):

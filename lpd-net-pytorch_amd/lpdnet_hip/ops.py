@@ -134,8 +134,11 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
     return out
 
 
-def linear(x, w, *, bias=None, scale=None, shift=None, act=ACT_NONE, slope=0.01, out=None):
-    """y = act((x @ w.T + bias) * scale + shift); x [M,K] rows, w [N,K] (torch Linear/Conv1x1 layout)."""
+def linear(x, w, *, bias=None, scale=None, shift=None, act=ACT_NONE, slope=0.01, out=None, splits=None):
+    """y = act((x @ w.T + bias) * scale + shift); x [M,K] rows, w [N,K] (torch Linear/Conv1x1 layout).
+
+    splits None: the per-cloud fully-connected layers (M = B rows, K >= 512: T-Net fc1/fc2) run split-K over 128-deep
+    slices -- one block per output tile would leave the chip idle, and the short partial sums are also more accurate."""
     ldx = _rows(x, "x")
     _req(w, "w")
     w = w.reshape(w.shape[0], -1).contiguous()
@@ -152,8 +155,10 @@ def linear(x, w, *, bias=None, scale=None, shift=None, act=ACT_NONE, slope=0.01,
         _call("linear_smallk", lib.lpd_linear_smallk, _ptr(x), ldx, _ptr(w), K, 1, 0, 0, _ptr(out), ldy, M, N, K, _ptr(bias),
                                          _ptr(scale), _ptr(shift), act, float(slope), _stream())
         return out
+    if splits is None:
+        splits = K // 128 if (M <= 128 and K >= 512) else 1
     return gemm(x, w, a_kmajor=False, b_kmajor=False, bias=bias, scale=scale, shift=shift, act=act, slope=slope,
-                out=out)
+                out=out, splits=splits)
 
 
 def apply_transform(x, trans, rows_per_cloud, out=None):
@@ -343,6 +348,17 @@ def bn_train_stats(X, bn, rows=None):
     return BNStats(out[0], out[1], out[2], out[3], R)
 
 
+def colsum(X, rows=None):
+    """fp32 [C] column sums over the first `rows` rows (fp64 accumulation; bias gradients)."""
+    ld = _rows(X, "X")
+    R = X.shape[0] if rows is None else rows
+    C = X.shape[1]
+    sums = torch.empty((2, C), dtype=torch.float64, device=X.device)
+    lib = _lib.load()
+    _call("colstats", lib.lpd_colstats, _ptr(X), ld, R, C, _ptr(sums[0]), _ptr(sums[1]), _stream())
+    return sums[0].float()
+
+
 def affine_act(X, scale, shift, act=ACT_NONE, slope=0.01, out=None, rows=None):
     ldx = _rows(X, "X")
     R = X.shape[0] if rows is None else rows
@@ -455,6 +471,36 @@ def dw_smallk(dY, X):
     lib = _lib.load()
     _call("dw_smallk", lib.lpd_dw_smallk, _ptr(dY), lddy, _ptr(X), ldx, M, Co, Kin, _ptr(dW), _stream())
     return dW
+
+
+def colmax_arg(x, B, N):
+    """x [B*N, C] rows -> (per-cloud max [B, C], arg-max row inside the cloud int32 [B, C])."""
+    ld = _rows(x, "x")
+    C = x.shape[1]
+    out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
+    lib = _lib.load()
+    _call("colmax_arg", lib.lpd_colmax_arg, _ptr(x), ld, _ptr(out), _ptr(arg), B, N, C, _stream())
+    return out, arg
+
+
+def colmax_bwd(dOut, arg, N):
+    """-> dense [B*N, C] gradient, zero except at the arg-max rows."""
+    B, C = arg.shape
+    dIn = torch.zeros((B * N, C), dtype=torch.float32, device=dOut.device)
+    lib = _lib.load()
+    _call("colmax_bwd", lib.lpd_colmax_bwd, _ptr(dOut.contiguous()), _ptr(arg), _ptr(dIn), C, B, N, C, _stream())
+    return dIn
+
+
+def cloud_outer(X, dY, B, N):
+    """dT[b] = sum_m X[m]^T dY[m] over each cloud; X, dY [B*N, KD] rows, KD <= 8 -> [B, KD, KD]."""
+    ldx, ldy = _rows(X, "X"), _rows(dY, "dY")
+    KD = X.shape[1]
+    dT = torch.empty((B, KD, KD), dtype=torch.float32, device=X.device)
+    lib = _lib.load()
+    _call("cloud_outer", lib.lpd_cloud_outer, _ptr(X), ldx, _ptr(dY), ldy, _ptr(dT), B, N, KD, _stream())
+    return dT
 
 
 def softmax_bwd(A, dA, dasum, rows_per_cloud):

@@ -23,10 +23,10 @@ GRAD_TOL = 1e-2
 GRAD_MEDIAN_TOL = 2.5e-3
 
 
-def _train_model(N, cuda, featnet="lpdnet"):
+def _train_model(N, cuda, featnet="lpdnet", **variant):
     from util.PointNetVlad import PointNetVlad
-    m = PointNetVlad(num_points=N, featnet=featnet)
-    sd = orc.synthetic_state(featnet, num_points=N)
+    m = PointNetVlad(num_points=N, featnet=featnet, **variant)
+    sd = orc.synthetic_state(featnet, num_points=N, **variant)
     m.load_state_dict(sd, strict=True)
     return m.to(cuda).train(), sd
 
@@ -40,11 +40,15 @@ def _step(m, x, bq, P, Ng):
     return out, loss
 
 
-def test_train_step0_vs_reference_golden(cuda, golden_dir):
-    g = np.load(os.path.join(golden_dir, "train_lpdnet_bq1_p2_n2_n1024.npz"))
+@pytest.mark.parametrize("tag,featnet", [("train_lpdnet_bq1_p2_n2_n1024", "lpdnet"), ("train_pointnet_bq1_p2_n2_n4096", "pointnet")])
+def test_train_step0_vs_reference_golden(cuda, golden_dir, tag, featnet):
+    """Step 0 of the reference's training loop.  For the PointNet trunk the fixture's point_net.* gradients are the
+    oracle's (validated by fp64 finite differences; the reference's torch-CPU BatchNorm2d backward is inconsistent
+    there, see tests/golden/make_golden.py), everything else is the reference's own autograd."""
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
     bq, P, Ng, N = [int(v) for v in g["dims"]]
     B = bq * (1 + P + Ng + 1)
-    m, _ = _train_model(N, cuda)
+    m, _ = _train_model(N, cuda, featnet)
     x = torch.from_numpy(synth.cloud(int(g["seed"]), B, N)).unsqueeze(1).to(cuda)
     out, loss = _step(m, x, bq, P, Ng)
     ref = torch.from_numpy(g["desc"])
@@ -73,16 +77,26 @@ def test_train_step0_vs_reference_golden(cuda, golden_dir):
             name = key[4:]
             buf = dict(m.named_buffers())[name].cpu().numpy()
             assert np.allclose(buf, g[key], rtol=2e-4, atol=2e-5), name
+        elif key.startswith("nograd/"):       # parameters the forward never touches (unused feature_trans)
+            assert params[key[7:]].grad is None, key
+        elif key.startswith("zerograd/"):     # bias in front of a BatchNorm: analytically zero, rounding noise only
+            assert params[key[9:]].grad.norm().item() < 1e-3, key
     for name, b in m.named_buffers():
         if name.endswith("num_batches_tracked"):
             assert int(b) == 1
 
 
-@pytest.mark.parametrize("featnet,bq,P,Ng,N", [("lpdnet", 1, 2, 2, 256), ("lpdnet", 2, 1, 3, 512), ("lpdnetorigin", 1, 2, 2, 256)])
-def test_train_grads_vs_oracle(cuda, featnet, bq, P, Ng, N):
+VARIANTS = [("lpdnet", 1, 2, 2, 256, {}), ("lpdnet", 2, 1, 3, 512, {}), ("lpdnetorigin", 1, 2, 2, 256, {}),
+            ("lpdnet", 1, 2, 2, 256, dict(xyz_trans=True)), ("lpdnet", 1, 2, 2, 256, dict(xyz_trans=True, feature_transform=True)),
+            ("lpdnetorigin", 1, 2, 2, 256, dict(xyz_trans=True, feature_transform=True)),
+            ("pointnet", 1, 2, 2, 256, {}), ("pointnet", 2, 1, 3, 512, dict(feature_transform=True))]
+
+
+@pytest.mark.parametrize("featnet,bq,P,Ng,N,variant", VARIANTS, ids=lambda v: "+".join(v) if isinstance(v, dict) else str(v))
+def test_train_grads_vs_oracle(cuda, featnet, bq, P, Ng, N, variant):
     from lpdnet_hip import engine
     B = bq * (1 + P + Ng + 1)
-    m, sd0 = _train_model(N, cuda, featnet)
+    m, sd0 = _train_model(N, cuda, featnet, **variant)
     xc = torch.from_numpy(synth.cloud(21, B, N)).unsqueeze(1)
     engine.DEBUG_AUX = {}
     engine.MORTON_ORDER = False   # compare index tensors in the caller's point order
@@ -92,7 +106,7 @@ def test_train_grads_vs_oracle(cuda, featnet, bq, P, Ng, N):
     finally:
         engine.DEBUG_AUX = None
         engine.MORTON_ORDER = True
-    graphs = iter([aux["idx_feat"].cpu().long(), aux["idx_xyz"].cpu().long()])
+    graphs = iter([aux["idx_feat"].cpu().long(), aux["idx_xyz"].cpu().long()] if featnet != "pointnet" else [])
     dt = torch.float64
     sd = {k: (v.to(dt).requires_grad_(True) if v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var"))
               else (v.to(dt) if v.dtype == torch.float32 else v.clone())) for k, v in sd0.items()}
@@ -100,23 +114,34 @@ def test_train_grads_vs_oracle(cuda, featnet, bq, P, Ng, N):
     orig = orc.knn
     orc.knn = lambda xx, k: next(graphs)          # the GPU's graphs (kNN parity is tested bit-exactly elsewhere)
     try:
-        od = orc.pointnetvlad_forward(sd, xc.to(dt), featnet=featnet, train=True, new_stats=new_stats)
+        od = orc.pointnetvlad_forward(sd, xc.to(dt), featnet=featnet, train=True, new_stats=new_stats, **variant)
     finally:
         orc.knn = orig
     q, p, n, o = torch.split(od.view(bq, -1, 256), [1, P, Ng, 1], dim=1)
     ol = orc.quadruplet_loss(q, p, n, o, 0.5, 0.2, use_min=True, lazy=True, ignore_zero_loss=False)
     assert ol.item() > 0, "vacuous fixture: hinge inactive"
     ol.backward()
-    assert all(p.grad is not None for p in m.parameters())
+    unused = {n for n, v in sd.items() if v.is_floating_point() and v.requires_grad and v.grad is None}
+    assert {n for n, p in m.named_parameters() if p.grad is None} == unused, "a parameter the oracle reaches has no HIP gradient"
     rel = ((out.detach().cpu().double() - od.detach()).abs().amax(dim=1) / od.detach().abs().amax(dim=1)).max().item()
-    assert rel < 1e-4, rel
-    assert abs(loss.item() - ol.item()) < 5e-4 * abs(ol.item())
+    # Both T-Nets chained in train mode (BatchNorm over B = 6 rows inside each) is ill-conditioned: the fp32 oracle itself
+    # sits 0.4e-4..1.2e-4 from the fp64 oracle there, the MI355X path 0.4e-4..1.2e-4 (tools/diag_tnet.py), so the
+    # comparison against fp64 gets 3e-4 for that variant; every other variant keeps the 1e-4 bar.
+    desc_tol = 3e-4 if len(variant) == 2 else 1e-4
+    assert rel < desc_tol, rel
+    assert abs(loss.item() - ol.item()) < (5e-4 if len(variant) < 2 else 2e-3) * abs(ol.item())
     errs = {}
     for name, prm in m.named_parameters():
         want = sd[name].grad
+        if want is None:
+            continue
+        if want.norm().item() < 1e-6 * max(1.0, sd[name].detach().norm().item()):   # bias in front of a BatchNorm: analytically 0
+            wgrad = sd[name.replace(".bias", ".weight")].grad.norm().item()      # rounding noise scales with the layer's gradient
+            assert prm.grad.norm().item() < 1e-3 * max(1.0, wgrad), name
+            continue
         errs[name] = ((prm.grad.cpu().double() - want).norm() / want.norm()).item()
         assert errs[name] < GRAD_TOL, (name, errs[name])
-    assert float(np.median(list(errs.values()))) < GRAD_MEDIAN_TOL, errs
+    assert float(np.median(list(errs.values()))) < (GRAD_MEDIAN_TOL if len(variant) < 2 else 2 * GRAD_MEDIAN_TOL), errs
     # everything before the first max-over-k (head) is tight
     for name, e in errs.items():
         if name.startswith("net_vlad."):
@@ -145,10 +170,11 @@ def test_train_then_eval_roundtrip_and_adam_step(cuda):
 
 
 def test_unbuilt_training_variants_fail_loudly(cuda):
-    """Training with T-Nets / the PointNet trunk is not built on the HIP path: a clear error, never a silent fallback."""
-    from util.PointNetVlad import PointNetVlad
+    """What the HIP training path does not build raises a clear error, never a silent fallback."""
+    from util.PointNetVlad import NetVLADLoupe, PointNetfeat
     x = torch.from_numpy(synth.cloud(1, 2, 256)).unsqueeze(1).to(cuda)
-    for kw in (dict(featnet="lpdnet", xyz_trans=True), dict(featnet="pointnet")):
-        m = PointNetVlad(num_points=256, **kw).to(cuda).train()
-        with pytest.raises(NotImplementedError):
-            m(x)
+    with pytest.raises(NotImplementedError):
+        PointNetfeat(num_points=256, max_pool=True).to(cuda).train()(x)
+    head = NetVLADLoupe(feature_size=64, max_samples=256, cluster_size=8, output_dim=16, gating=False).to(cuda).train()
+    with pytest.raises(NotImplementedError):
+        head(torch.zeros(2, 64, 256, 1, device=cuda))
