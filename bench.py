@@ -207,7 +207,9 @@ def main():
         ms = [a.elapsed_time(b) for a, b in evs]
         kern[name] = {"launches": len(ms), "avg_us": round(1e3 * sum(ms) / len(ms), 2)}
     roof = None
-    key = "edge_gather_max[C=256]"
+    key, kname = "edge_gather_max16[C=256]", "edge_gather_max_cloud16_kernel (LDS-resident cloud slice)"
+    if key not in kern:     # k != 20 or N > 5120: the direct gather form
+        key, kname = "edge_gather_max[C=256]", "edge_gather_max_kernel<64> (direct gather)"
     if key in kern:
         t_s = kern[key]["avg_us"] * 1e-6
         alg = (KAGG_ROW_BYTES + 4 * args.k) * args.batch * args.points
@@ -216,10 +218,11 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "kagg_pmc.json")
         if os.path.exists(pmc) and (args.batch, args.points, args.k) == (32, 4096, 20):   # PMC run is for the default workload
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                traffic = rec.get("hbm_bytes_per_launch") if rec.get("bench_key") == key else None
             except Exception:
                 traffic = None
-        roof = {"kernel": f"edge_gather_max_kernel<64> (SN1 stage, C=256, k={args.k})", "bound": "hbm", "achieved": round(ach, 1),
+        roof = {"kernel": f"{kname}, SN1 stage, C=256, k={args.k}", "bound": "hbm", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_us": kern[key]["avg_us"]}
 

@@ -87,6 +87,21 @@ int lpd_edge_gather_max(const float* P, int ldp, const float* Q, int ldq, const 
                         void* stream);
 
 /*
+ * K-agg, cloud-resident form on row-major operands with 16-bit indices: as lpd_edge_gather_max, but one
+ * workgroup keeps an 8-channel slice of ALL N rows of one cloud's P in LDS (N*32 bytes), so the k gathers per
+ * point are LDS reads and P, Q, out cross the memory system once.  idx16: the blocked uint16 copy made by lpd_pack_idx16.
+ * Built for k = 20, N <= 5120; bit-identical to lpd_edge_gather_max.
+ */
+int lpd_edge_gather_max16(const float* P, int ldp, const float* Q, int ldq, const uint16_t* idx16, float* out, int ldo,
+                          const float* scale, const float* shift, int M, int N, int C, int k, int act, float slope,
+                          void* stream);
+
+/* int32 kNN indices [M][k] (local to the cloud, < 65536) -> the uint16 copy lpd_edge_gather_max16 reads:
+ * blocked by 32 points, index quad i of point m at ((m/32)*5 + i)*32 + m%32 (uint2 units); idx16 holds
+ * ceil(M/32)*32*k uint16.  k = 20. */
+int lpd_pack_idx16(const int32_t* idx, uint16_t* idx16, long long M, int k, void* stream);
+
+/*
  * Fused per-edge MLP: stage-1 BatchNorm+activation on the fly, stage-2 1x1 conv on the f32 MFMA,
  * BatchNorm + activation + max over k.  Replaces util/lpdnet_model.py:251-252 (convDG2 applied to
  * the un-maxed convDG1 output, then max) and the LPDNetOrign chains lpdnet_model.py:97-100,105-107:

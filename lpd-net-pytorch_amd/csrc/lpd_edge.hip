@@ -111,6 +111,125 @@ __global__ __launch_bounds__(256) void edge_gather_max_kernel(GatherArgs g)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// K-agg, cloud-resident form (the product path for N*32 B <= 160 KiB, k = 20).
+//
+// One workgroup owns (cloud, slice of 8 channels) and keeps that slice of ALL N rows of P in LDS (N * 32 bytes: 128 KiB
+// at N = 4096), so each of the k gathers per point is an LDS read and P, Q and out cross the memory system once; the
+// direct form above sends k = 20 row reads per point through L2 (2.7 GB per launch at B = 32) and tops out at the L2
+// gather rate.  The rows are stored sign-adjusted (sgn(scale) * P) so that one running max serves both selections:
+// sel_j P_j = sgn * max_j (sgn * P_j), exact.  2 lanes per point (16 B each), 512 points per block pass.
+// The kernel is bound by bytes through L2 per CU: with C/8 slices per cloud every slice re-reads the index rows, so
+// they come as uint16 (lpd_pack_idx16; 40 B instead of 80 B per point and slice) and the per-pass operands (indices,
+// centre term) rotate through three register sets, two passes of lookahead, no copies.  Straight-line body: the
+// activation is the branch-free  max(v,0) + ns * min(v,0)  with ns = 1 / 0 / slope for none / ReLU / LeakyReLU.
+// (Tried and dropped, profiles/r01d_kagg_variants.txt: Z-order windows of 256..1024 rows in LDS with the misses from
+// L2 -- 13 % misses cost more instructions than the hits save; panel-major P/Q -- no gain, the 32-B row pieces are
+// not over-fetched.)
+// ------------------------------------------------------------------------------------------
+struct CloudOps {
+    uint2 ix[5];    // 20 16-bit neighbour indices
+    float4 q;
+    unsigned m;     // global row of the point (32-bit element offsets: the host checks M * ld * 4 < 2^32)
+};
+
+template <bool HAS_Q>
+__global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArgs g, const uint16_t* __restrict__ idx16,
+                                                                       int nslices, float ns)
+{
+    extern __shared__ float4 win[];   // [N][2]
+    constexpr int LPP = 2, GROUPS = 512, KQ = 5;
+    const int tid = threadIdx.x;
+    const int cl = tid & 1;
+    const int grp = tid >> 1;
+    const int w = lpd_xcd_remap(blockIdx.x, gridDim.x);   // the slices of one cloud run next to each other on one XCD
+    const int sl = w % nslices;
+    const int b = w / nslices;
+    const int col = sl * 8 + cl * 4;
+    const unsigned row0 = (unsigned)b * g.N;
+    const int N = g.N;
+    const int passes = (N + GROUPS - 1) / GROUPS;
+    const uint2* idx2 = reinterpret_cast<const uint2*>(idx16);
+    const float* Qc = g.Q + col;
+    float* outc = g.out + col;
+    const unsigned ldq = g.ldq, ldo = g.ldo;
+
+    // A pass past the end of the cloud re-reads (and later re-stores, with identical values) the last point:
+    // no divergent tail, so the row reads below are consumed as they arrive instead of being sunk into a branch.
+    auto load = [&](CloudOps& o, int ps) {
+        o.m = row0 + min(ps * GROUPS + grp, N - 1);
+        // blocked index layout [M/32][5][32] uint2 (lpd_pack_idx16): a wave's load touches 4 lines instead of 20
+        const unsigned ib = (o.m >> 5) * (KQ * 32) + (o.m & 31);
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) o.ix[i] = idx2[ib + i * 32];
+        if (HAS_Q) o.q = *reinterpret_cast<const float4*>(Qc + o.m * ldq);
+    };
+    CloudOps A, Bo, Co;
+    load(A, 0);
+    load(Bo, 1);
+
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.scale) sc = *reinterpret_cast<const float4*>(g.scale + col);
+    if (g.shift) sh = *reinterpret_cast<const float4*>(g.shift + col);
+    const float4 sg = make_float4(sc.x >= 0.f ? 1.f : -1.f, sc.y >= 0.f ? 1.f : -1.f, sc.z >= 0.f ? 1.f : -1.f,
+                                  sc.w >= 0.f ? 1.f : -1.f);
+    const float* Pc = g.P + (size_t)row0 * g.ldp + col;
+    for (int r = grp; r < N; r += GROUPS) {
+        float4 p = *reinterpret_cast<const float4*>(Pc + (size_t)r * g.ldp);
+        p.x *= sg.x; p.y *= sg.y; p.z *= sg.z; p.w *= sg.w;
+        win[r * LPP + cl] = p;
+    }
+    __syncthreads();
+
+    auto process = [&](const CloudOps& o) {
+        float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) {
+            const float4 a = win[(o.ix[i].x & 0xffffu) * LPP + cl], bq = win[(o.ix[i].x >> 16) * LPP + cl];
+            const float4 c = win[(o.ix[i].y & 0xffffu) * LPP + cl], d = win[(o.ix[i].y >> 16) * LPP + cl];
+            v.x = fmaxf(fmaxf(v.x, a.x), bq.x); v.y = fmaxf(fmaxf(v.y, a.y), bq.y);
+            v.z = fmaxf(fmaxf(v.z, a.z), bq.z); v.w = fmaxf(fmaxf(v.w, a.w), bq.w);
+            v.x = fmaxf(fmaxf(v.x, c.x), d.x); v.y = fmaxf(fmaxf(v.y, c.y), d.y);
+            v.z = fmaxf(fmaxf(v.z, c.z), d.z); v.w = fmaxf(fmaxf(v.w, c.w), d.w);
+            __builtin_amdgcn_sched_barrier(0);   // 4 row reads in flight per wave (measured at C=256: 2 -> 137 us, 4 -> 131, 8 -> 178)
+        }
+        float4 r;
+        r.x = sc.x * (sg.x * v.x + (HAS_Q ? o.q.x : 0.f)) + sh.x;
+        r.y = sc.y * (sg.y * v.y + (HAS_Q ? o.q.y : 0.f)) + sh.y;
+        r.z = sc.z * (sg.z * v.z + (HAS_Q ? o.q.z : 0.f)) + sh.z;
+        r.w = sc.w * (sg.w * v.w + (HAS_Q ? o.q.w : 0.f)) + sh.w;
+        r.x = fmaxf(r.x, 0.f) + ns * fminf(r.x, 0.f);
+        r.y = fmaxf(r.y, 0.f) + ns * fminf(r.y, 0.f);
+        r.z = fmaxf(r.z, 0.f) + ns * fminf(r.z, 0.f);
+        r.w = fmaxf(r.w, 0.f) + ns * fminf(r.w, 0.f);
+        *reinterpret_cast<float4*>(outc + o.m * ldo) = r;
+    };
+    for (int ps = 0; ps < passes; ps += 3) {
+        load(Co, ps + 2);
+        process(A);
+        load(A, ps + 3);
+        if (ps + 1 < passes) process(Bo);
+        load(Bo, ps + 4);
+        if (ps + 2 < passes) process(Co);
+    }
+}
+
+// int32 [M][20] -> uint16, blocked for the kernel above: point m, index quad i (4 x u16 = uint2) at
+// ((m / 32) * 5 + i) * 32 + m % 32.  One thread per (point, quad).
+__global__ void pack_idx16_kernel(const int32_t* __restrict__ in, uint2* __restrict__ out, long long M)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long m = t / 5;
+    const int i = (int)(t - m * 5);
+    if (m >= M) return;
+    const int4 v = *reinterpret_cast<const int4*>(in + m * 20 + i * 4);
+    uint2 o;
+    o.x = (uint32_t)(v.x & 0xffff) | ((uint32_t)v.y << 16);
+    o.y = (uint32_t)(v.z & 0xffff) | ((uint32_t)v.w << 16);
+    out[((m >> 5) * 5 + i) * 32 + (m & 31)] = o;
+}
+
 // ------------------------------------------------------------------------------------------
 // fused edge MLP (DG1 activation -> DG2 conv -> max over k)
 // ------------------------------------------------------------------------------------------
@@ -334,4 +453,49 @@ extern "C" int lpd_edge_mlp(const float* P, int ldp, const float* Q, int ldq, co
     if (CM == 64 && CO == 64) return edge_mlp_launch<64, 64>(g, stream);
     lpd_set_error("lpd_edge_mlp: (CM=%d, CO=%d) unsupported; built for (128,128) and (64,64)", CM, CO);
     return LPD_ERR_UNSUPPORTED;
+}
+
+extern "C" int lpd_pack_idx16(const int32_t* idx, uint16_t* idx16, long long M, int k, void* stream_)
+{
+    LPD_CHECK_ARG(idx && idx16 && M > 0, "lpd_pack_idx16: bad arguments");
+    LPD_CHECK_ARG(k == 20, "lpd_pack_idx16: built for k = 20 (got %d)", k);
+    LPD_CHECK_ARG((((uintptr_t)idx | (uintptr_t)idx16) & 15) == 0, "lpd_pack_idx16: pointers must be 16-byte aligned");
+    const long long threads = M * 5;
+    hipLaunchKernelGGL(pack_idx16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, idx,
+                       reinterpret_cast<uint2*>(idx16), M);
+    LPD_CHECK_LAUNCH("lpd_pack_idx16");
+    return LPD_OK;
+}
+
+extern "C" int lpd_edge_gather_max16(const float* P, int ldp, const float* Q, int ldq, const uint16_t* idx16, float* out,
+                                     int ldo, const float* scale, const float* shift, int M, int N, int C, int k, int act,
+                                     float slope, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(P && idx16 && out, "lpd_edge_gather_max16: null pointer");
+    LPD_CHECK_ARG(M > 0 && N > 0 && k > 0 && M % N == 0, "lpd_edge_gather_max16: bad dims M=%d N=%d k=%d", M, N, k);
+    LPD_CHECK_ARG(C > 0 && C % 8 == 0, "lpd_edge_gather_max16: C=%d must be a multiple of 8", C);
+    LPD_CHECK_ARG(ldp % 4 == 0 && ldo % 4 == 0 && (!Q || ldq % 4 == 0), "lpd_edge_gather_max16: leading dims must be multiples of 4");
+    LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)out | (uintptr_t)Q | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0 &&
+                  ((uintptr_t)idx16 & 7) == 0, "lpd_edge_gather_max16: pointers must be 16-byte aligned (idx16: 8)");
+    LPD_CHECK_ARG(k == 20 && (size_t)N * 8 * sizeof(float) <= 160 * 1024,
+                  "lpd_edge_gather_max16: built for k = 20 and N <= 5120 (an 8-channel slice of one cloud in LDS); got k=%d N=%d", k, N);
+    LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_gather_max16: act=%d unsupported (none/ReLU/LeakyReLU)", act);
+    LPD_CHECK_ARG((unsigned long long)M * (unsigned long long)(ldo > ldq ? ldo : ldq) * 4ull < (1ull << 32) &&
+                  (unsigned long long)M * 40ull < (1ull << 32), "lpd_edge_gather_max16: M=%d too large for 32-bit row offsets", M);
+    GatherArgs g{P, Q, nullptr, out, scale, shift, M, N, C, k, ldp, ldq, ldo, act, slope};
+    const int nslices = C / 8;
+    const size_t lds = (size_t)N * 8 * sizeof(float);
+    const float ns = act == 0 ? 1.0f : (act == 1 ? 0.0f : slope);
+    if (Q) {
+        auto kern = edge_gather_max_cloud16_kernel<true>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((M / N) * nslices), dim3(1024), lds, stream, g, idx16, nslices, ns);
+    } else {
+        auto kern = edge_gather_max_cloud16_kernel<false>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((M / N) * nslices), dim3(1024), lds, stream, g, idx16, nslices, ns);
+    }
+    LPD_CHECK_LAUNCH("lpd_edge_gather_max16");
+    return LPD_OK;
 }

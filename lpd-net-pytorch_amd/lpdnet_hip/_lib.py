@@ -29,6 +29,9 @@ SIGNATURES = {
                  _c_ll, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_p],
     "lpd_edge_gather_max": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int,
                             _c_int, _c_int, _c_f, _c_p],
+    "lpd_edge_gather_max16": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int,
+                              _c_int, _c_int, _c_f, _c_p],
+    "lpd_pack_idx16": [_c_p, _c_p, ctypes.c_longlong, _c_int, _c_p],
     "lpd_edge_mlp": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int,
                      _c_int, _c_int, _c_int, _c_int, _c_f, _c_p],
     "lpd_linear_smallk": [_c_p, _c_int, _c_p, _c_int, _c_int, _c_ll, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int,

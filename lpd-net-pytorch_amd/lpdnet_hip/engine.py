@@ -141,6 +141,15 @@ def stn3d_eval(net, h, B, N):
 # ------------------------------------------------------------------------------------------------
 # trunks (return point-major features [B*N, E])
 # ------------------------------------------------------------------------------------------------
+def kagg(P, Q, idx, N, *, scale, shift, act, slope, out):
+    """K-agg dispatch: the cloud-resident kernel when an 8-channel slice of one cloud fits LDS (N <= 5120) and k = 20,
+    the direct gather otherwise (cfg5: N = 16384, k = 64).  Same bits either way."""
+    k = idx.shape[-1]
+    if k == 20 and N * 32 <= 160 * 1024 and act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY) and P.shape[0] * 512 * 4 < 2 ** 32:
+        return ops.edge_gather_max16(P, Q, ops.pack_idx16(idx), N, scale=scale, shift=shift, act=act, slope=slope, out=out)
+    return ops.edge_gather_max(P, Q, idx, N, scale=scale, shift=shift, act=act, slope=slope, out=out)
+
+
 def lpdnet_features_eval(net, x):
     """util/lpdnet_model.py:211-268 (LPDNet.forward), eval mode."""
     x = reorder_points(_check_input(x))
@@ -166,14 +175,14 @@ def lpdnet_features_eval(net, x):
     pq = ops.linear(f, split_edge_weight(net.convDG1, "cat_nc"))                        # [M,256] = [P | Q]
     s1, b1 = bn_affine(net.convDG1[1])
     s2, b2 = bn_affine(net.convDG2[1])
-    ops.edge_gather_max(pq[:, :128], pq[:, 128:], idx_f, N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:128])
+    kagg(pq[:, :128], pq[:, 128:], idx_f, N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:128])
     ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope,
                  out=cat[:, 128:256])
     # static graph in Cartesian space (raw xyz even when t3d, lpdnet_model.py:226,255)
     idx_x = ops.knn(ops.transpose(x.view(B, N, 3)), k)
     pq = ops.linear(cat[:, 128:256], split_edge_weight(net.convSN1, "cat_nc"))          # [M,512]
     s3, b3 = bn_affine(net.convSN1[1])
-    ops.edge_gather_max(pq[:, :256], pq[:, 256:], idx_x, N, scale=s3, shift=b3, act=act, slope=slope, out=cat[:, 256:512])
+    kagg(pq[:, :256], pq[:, 256:], idx_x, N, scale=s3, shift=b3, act=act, slope=slope, out=cat[:, 256:512])
     if DEBUG_AUX is not None:
         DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=cat)
     s, b = bn_affine(net.bn3_lpd)

@@ -208,6 +208,37 @@ def edge_gather_max(P, Q, idx, N, *, scale=None, shift=None, act=ACT_NONE, slope
     return out
 
 
+def pack_idx16(idx):
+    """int32 kNN indices [..., k=20] -> the blocked uint16 copy the cloud-resident K-agg reads (opaque int16 tensor)."""
+    _req(idx, "idx", torch.int32)
+    k = idx.shape[-1]
+    idx = idx.reshape(-1, k).contiguous()
+    M = idx.shape[0]
+    out = torch.empty(((M + 31) // 32 * 32, k), dtype=torch.int16, device=idx.device)
+    lib = _lib.load()
+    _call("pack_idx16", lib.lpd_pack_idx16, _ptr(idx), _ptr(out), M, k, _stream())
+    return out
+
+
+def edge_gather_max16(P, Q, idx16, N, *, scale=None, shift=None, act=ACT_NONE, slope=0.01, out=None):
+    """Cloud-resident K-agg (k = 20, N <= 5120): same result as edge_gather_max; idx16 from pack_idx16."""
+    ldp = _rows(P, "P")
+    ldq = _rows(Q, "Q") if Q is not None else 0
+    _req(idx16, "idx16", torch.int16)
+    M, C = P.shape
+    k = idx16.shape[1]
+    if idx16.dim() != 2 or idx16.shape[0] != (M + 31) // 32 * 32 or not idx16.is_contiguous():
+        raise ValueError("edge_gather_max16: idx16 must come from pack_idx16 of this graph")
+    if out is None:
+        out = torch.empty((M, C), dtype=torch.float32, device=P.device)
+    ldo = _rows(out, "out")
+    scale, shift = _vec(scale, "scale", C), _vec(shift, "shift", C)
+    lib = _lib.load()
+    _call(f"edge_gather_max16[C={C}]", lib.lpd_edge_gather_max16, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx16), _ptr(out), ldo,
+          _ptr(scale), _ptr(shift), M, N, C, k, act, float(slope), _stream())
+    return out
+
+
 def edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, *, act=ACT_LEAKY, slope=0.01, out=None):
     """Fused DG1-activation -> DG2 conv -> BN -> act -> max over k (include/lpd_hip.h lpd_edge_mlp)."""
     ldp = _rows(P, "P")

@@ -171,6 +171,28 @@ def test_edge_gather_max(cuda, C, N, k, B):
     assert _rel(out2, _gather(P, idx, B, N).max(dim=1)[0]) == 0.0
 
 
+@pytest.mark.parametrize("C,N,B,act", [(256, 512, 2, 2), (128, 1000, 3, 1), (64, 37, 2, 0), (256, 4096, 2, 2), (64, 5120, 1, 2)])
+def test_edge_gather_max_cloud_resident_is_bit_identical(cuda, C, N, B, act):
+    """lpd_edge_gather_max16 (LDS-resident cloud slice, uint16 indices) == lpd_edge_gather_max, bit for bit; ragged N,
+    point counts that are not multiples of 32 or 512, output into a column slice, and the no-centre-term form."""
+    ops = _ops()
+    k = 20
+    P, Q, idx, scale, shift = _edge_inputs(B, N, C, k, C + N)
+    PQ = torch.cat([P, Q], dim=1).to(cuda)
+    idx = idx.to(cuda)
+    idx16 = ops.pack_idx16(idx)
+    for q in (PQ[:, C:], None):
+        want = ops.edge_gather_max(PQ[:, :C], q, idx, N, scale=scale.to(cuda), shift=shift.to(cuda), act=act, slope=0.01)
+        buf = torch.full((B * N, C + 8), -7.0, device=cuda)
+        ops.edge_gather_max16(PQ[:, :C], q, idx16, N, scale=scale.to(cuda), shift=shift.to(cuda), act=act, slope=0.01, out=buf[:, 4:4 + C])
+        assert torch.equal(buf[:, 4:4 + C], want)
+        assert (buf[:, :4] == -7.0).all() and (buf[:, 4 + C:] == -7.0).all()
+    plain = ops.edge_gather_max16(PQ[:, :C], None, idx16, N)
+    assert torch.equal(plain, _gather(P, idx.cpu(), B, N).max(dim=1)[0].to(cuda))
+    with pytest.raises(ops._lib.LpdHipError):
+        ops.edge_gather_max16(PQ[:, :C], None, idx16, N, act=ops.ACT_SIGMOID)
+
+
 @pytest.mark.parametrize("CM,CO,N,k,B,useQ", [(128, 128, 256, 20, 2, True), (64, 64, 200, 20, 2, True), (64, 64, 128, 20, 1, False),
                                                (128, 128, 100, 7, 1, True)])
 def test_edge_mlp(cuda, CM, CO, N, k, B, useQ):
