@@ -34,15 +34,27 @@ void lpd_set_error(const char* fmt, ...);
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// activation codes shared by every epilogue (include/lpd_hip.h LPD_ACT_*)
-__device__ __forceinline__ float lpd_act(float v, int act, float slope)
+// activation codes shared by every epilogue (include/lpd_hip.h LPD_ACT_*): 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 sigmoid.
+// The piecewise-linear three are ONE branch-free expression,  max(v,0) + ns * min(v,0)  with ns = 1 / 0 / slope (exact:
+// one of the two terms is +-0).  The sigmoid costs an exp and a divide: written as a switch the compiler if-converted it
+// into every element of every kernel (80 v_exp_f32 in the edge-MLP tile builder), so it is a separate function that
+// only the kernels with a sigmoid epilogue call, behind a branch on the (uniform) activation code.
+__device__ __forceinline__ float lpd_neg_slope(int act, float slope) { return act == 0 ? 1.0f : (act == 1 ? 0.0f : slope); }
+__device__ __forceinline__ float lpd_act_pl(float v, float ns) { return fmaxf(v, 0.0f) + ns * fminf(v, 0.0f); }
+__device__ __forceinline__ float lpd_sigmoid(float v)
 {
-    switch (act) {
-        case 1: return v > 0.0f ? v : 0.0f;             // ReLU
-        case 2: return v > 0.0f ? v : v * slope;         // LeakyReLU(slope)
-        case 3: return 1.0f / (1.0f + __expf(-v));       // sigmoid
-        default: return v;
-    }
+    asm volatile("" ::: "memory");   // not speculatable: keeps the exp + divide inside the branch that needs them
+    return 1.0f / (1.0f + __expf(-v));
+}
+
+// acts 0..2 only (hosts reject the sigmoid where it is not built)
+__device__ __forceinline__ float lpd_act(float v, int act, float slope) { return lpd_act_pl(v, lpd_neg_slope(act, slope)); }
+
+// any activation; the caller keeps `act` uniform so that the branch is scalar
+__device__ __forceinline__ float lpd_act_any(float v, int act, float slope)
+{
+    if (act == 3) return lpd_sigmoid(v);
+    return lpd_act_pl(v, lpd_neg_slope(act, slope));
 }
 
 // Blocks b and b+8 share an XCD (round-robin dispatch, MI355X_MICROARCH.md "Workgroup dispatch").

@@ -421,6 +421,7 @@ extern "C" int lpd_edge_gather_max(const float* P, int ldp, const float* Q, int 
     LPD_CHECK_ARG(P && idx && out, "lpd_edge_gather_max: null pointer");
     LPD_CHECK_ARG(M > 0 && N > 0 && k > 0 && M % N == 0, "lpd_edge_gather_max: bad dims M=%d N=%d k=%d", M, N, k);
     LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_gather_max: C=%d unsupported (64/128/256)", C);
+    LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_gather_max: act=%d unsupported (none/ReLU/LeakyReLU)", act);
     LPD_CHECK_ARG(ldp % 4 == 0 && ldo % 4 == 0 && (!Q || ldq % 4 == 0), "lpd_edge_gather_max: leading dims must be multiples of 4");
     LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)out | (uintptr_t)Q | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0,
                   "lpd_edge_gather_max: pointers must be 16-byte aligned");
@@ -445,6 +446,7 @@ extern "C" int lpd_edge_mlp(const float* P, int ldp, const float* Q, int ldq, co
     LPD_CHECK_ARG(P && idx && s1 && b1 && W2 && s2 && b2 && out, "lpd_edge_mlp: null pointer");
     LPD_CHECK_ARG(M > 0 && N > 0 && k > 0 && M % N == 0, "lpd_edge_mlp: bad dims M=%d N=%d k=%d", M, N, k);
     LPD_CHECK_ARG(k <= 128, "lpd_edge_mlp: k=%d > 128 unsupported", k);
+    LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_mlp: act=%d unsupported (none/ReLU/LeakyReLU)", act);
     LPD_CHECK_ARG(ldp % 4 == 0 && (!Q || ldq % 4 == 0), "lpd_edge_mlp: leading dims must be multiples of 4");
     LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)Q | (uintptr_t)s1 | (uintptr_t)b1 | (uintptr_t)W2) & 15) == 0,
                   "lpd_edge_mlp: pointers must be 16-byte aligned");

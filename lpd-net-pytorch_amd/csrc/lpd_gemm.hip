@@ -56,6 +56,50 @@ __device__ __forceinline__ float4 ld4_guard(const float* row, int i, int limit)
     return v;
 }
 
+// Epilogue of one wave's 64 x (32*TN) accumulator block (32x32 MFMA tile layout: column = lane & 31, row =
+// (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)).  The activation code is uniform: the sigmoid (exp + divide per element)
+// lives behind a scalar branch, the other three are the branch-free  max(v,0) + ns * min(v,0).
+template <int TN, bool SIGMOID>
+__device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, const f32x16 (&acc)[2][TN], float* C, int mw, int nw, int h, int col)
+{
+    const bool raw = g.splits > 1;
+    const float ns = g.act == 0 ? 1.0f : (g.act == 1 ? 0.0f : g.slope);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 32 + col;
+        if (n >= g.N) continue;
+        float bi = 0.f, sc = 1.f, sh = 0.f;
+        if (!raw) {
+            if (g.bias) bi = g.bias[n];
+            if (g.scale) { sc = g.scale[n]; sh = g.shift[n]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= g.M) continue;
+                float v = acc[i][j][r];
+                if (!raw) {
+                    v += bi;
+                    v = v * sc + sh;
+                    if constexpr (SIGMOID) v = 1.0f / (1.0f + __expf(-v));
+                    else v = fmaxf(v, 0.0f) + ns * fminf(v, 0.0f);
+                    if (g.accumulate) v += C[(long long)m * g.ldc + n];
+                }
+                C[(long long)m * g.ldc + n] = v;
+            }
+        }
+    }
+}
+
+template <int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][TN], float* C, int mw, int nw, int h, int col)
+{
+    if (g.act == 3 && g.splits == 1) gemm_epilogue_t<TN, true>(g, acc, C, mw, nw, h, col);
+    else gemm_epilogue_t<TN, false>(g, acc, C, mw, nw, h, col);
+}
+
 // TN: 32-wide n-tiles per wave (1 => BN = 64, 2 => BN = 128).  TM fixed at 2 (BM = 128).
 // KTAIL: the reduction length is not a multiple of 32 (ragged point counts); only then are the operand loads k-guarded
 // (the guards cost ~25 % on the big GEMMs when compiled in unconditionally).
@@ -197,33 +241,203 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
     }
 
     // ---- epilogue ----
-    const bool raw = g.splits > 1;
+    gemm_epilogue<TN>(g, acc, C, m0 + wm * 64, n0 + wn * (32 * TN), h, col);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") GEMM: fp32 operands, fp32 accumulation, three bf16 MFMA products per term.
+//
+// Each fp32 operand is split while it is staged into LDS:  x = hi + lo + O(2^-17 |x|),  hi = bf16(x),
+// lo = bf16(x - hi), and  a*b ~= a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  on v_mfma_f32_32x32x16_bf16 (products of bf16
+// values are exact in fp32; the dropped lo*lo term and the split residual are ~2^-16 relative per product).
+// Measured effect on the descriptors of the full network: 2e-6 norm-relative against the fp32/fp64 reference, 45x
+// inside the 1e-4 bar (DESIGN.md "GEMM precision"); the bf16 MFMA runs at 16x the rate of the f32-input MFMA, so
+// three products still leave > 5x.  Not used where bits matter: the kNN distance tiles and the layers that feed the
+// feature-space kNN (conv1/conv2) stay on the f32-input MFMA / fp32 FMA paths.
+//
+// LDS images are [row][k] with k contiguous (row stride 40 bf16 = 80 B: conflict-free ds_read_b128 for the 32x32x16
+// operand: lane (r = lane & 31, h = lane >> 5) reads k = 8h .. 8h+7 of row r).  Operands stored k-major in memory
+// are transposed in registers: a thread loads a 4(k) x 4(m) patch and writes four 8-byte k-runs.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, bf16x4& hi, bf16x4& lo)
+{
+    hi[0] = (__bf16)x0; hi[1] = (__bf16)x1; hi[2] = (__bf16)x2; hi[3] = (__bf16)x3;
+    lo[0] = (__bf16)(x0 - (float)hi[0]); lo[1] = (__bf16)(x1 - (float)hi[1]);
+    lo[2] = (__bf16)(x2 - (float)hi[2]); lo[3] = (__bf16)(x3 - (float)hi[3]);
+}
+
+// Register staging of one operand tile (ROWS x 32): NR = max(ROWS / 32, 4 for k-major with ROWS = 64) float4 per thread.
+// k-major operands are held as 4(k) x 4(row) patches: patch id = p * 256 + tid, kq = id / (ROWS/4), rq = id % (ROWS/4).
+template <int ROWS>
+struct X3Regs { static constexpr int NR = ROWS >= 128 ? ROWS / 32 : 4; };
+
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ void x3_store(const float4 (&r)[X3Regs<ROWS>::NR], __bf16* hi_img, __bf16* lo_img, int tid)
+{
+    constexpr int LDK = GEMM_BK + 8;
+    if constexpr (KMAJOR) {
+        constexpr int NP = (2 * ROWS + GEMM_THREADS - 1) / GEMM_THREADS;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (32 * TN) + j * 32 + col;
-        if (n >= g.N) continue;
-        float bi = 0.f, sc = 1.f, sh = 0.f;
-        if (!raw) {
-            if (g.bias) bi = g.bias[n];
-            if (g.scale) { sc = g.scale[n]; sh = g.shift[n]; }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= g.M) continue;
-                float v = acc[i][j][r];
-                if (!raw) {
-                    v += bi;
-                    v = v * sc + sh;
-                    v = lpd_act(v, g.act, g.slope);
-                    if (g.accumulate) v += C[(long long)m * g.ldc + n];
-                }
-                C[(long long)m * g.ldc + n] = v;
+        for (int p = 0; p < NP; ++p) {
+            const int id = p * GEMM_THREADS + tid;
+            const int kq = id / (ROWS / 4), rq = id % (ROWS / 4);
+            if (2 * ROWS % GEMM_THREADS == 0 || kq < GEMM_BK / 4) {
+                const float4 &r0 = r[p * 4], &r1 = r[p * 4 + 1], &r2 = r[p * 4 + 2], &r3 = r[p * 4 + 3];
+                bf16x4 h, l;
+                split4(r0.x, r1.x, r2.x, r3.x, h, l);
+                *reinterpret_cast<bf16x4*>(hi_img + (rq * 4 + 0) * LDK + kq * 4) = h;
+                *reinterpret_cast<bf16x4*>(lo_img + (rq * 4 + 0) * LDK + kq * 4) = l;
+                split4(r0.y, r1.y, r2.y, r3.y, h, l);
+                *reinterpret_cast<bf16x4*>(hi_img + (rq * 4 + 1) * LDK + kq * 4) = h;
+                *reinterpret_cast<bf16x4*>(lo_img + (rq * 4 + 1) * LDK + kq * 4) = l;
+                split4(r0.z, r1.z, r2.z, r3.z, h, l);
+                *reinterpret_cast<bf16x4*>(hi_img + (rq * 4 + 2) * LDK + kq * 4) = h;
+                *reinterpret_cast<bf16x4*>(lo_img + (rq * 4 + 2) * LDK + kq * 4) = l;
+                split4(r0.w, r1.w, r2.w, r3.w, h, l);
+                *reinterpret_cast<bf16x4*>(hi_img + (rq * 4 + 3) * LDK + kq * 4) = h;
+                *reinterpret_cast<bf16x4*>(lo_img + (rq * 4 + 3) * LDK + kq * 4) = l;
             }
         }
+    } else {                       // register e: row (e*256 + tid) / 8, k quad (e*256 + tid) % 8
+        constexpr int NF4 = ROWS * GEMM_BK / 4 / GEMM_THREADS;
+#pragma unroll
+        for (int e = 0; e < NF4; ++e) {
+            const int f = e * GEMM_THREADS + tid;
+            const int rr = f / (GEMM_BK / 4), kq = f % (GEMM_BK / 4);
+            bf16x4 h, l;
+            split4(r[e].x, r[e].y, r[e].z, r[e].w, h, l);
+            *reinterpret_cast<bf16x4*>(hi_img + rr * LDK + kq * 4) = h;
+            *reinterpret_cast<bf16x4*>(lo_img + rr * LDK + kq * 4) = l;
+        }
     }
+}
+
+// load one operand tile (ROWS x 32 at row0, k0) into r[]; `mem` is the operand base, ld its leading dim
+template <bool KMAJOR, int ROWS, bool KTAIL>
+__device__ __forceinline__ void x3_load(float4 (&r)[X3Regs<ROWS>::NR], const float* mem, int ld, int row0, int nrows, int k0,
+                                        int Ktot, int tid)
+{
+    if constexpr (KMAJOR) {        // memory [k][row]
+        constexpr int NP = (2 * ROWS + GEMM_THREADS - 1) / GEMM_THREADS;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int id = p * GEMM_THREADS + tid;
+            const int kq = id / (ROWS / 4), rq = id % (ROWS / 4);
+            if (2 * ROWS % GEMM_THREADS == 0 || kq < GEMM_BK / 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = k0 + kq * 4 + e;
+                    r[p * 4 + e] = (!KTAIL || kk < Ktot) ? ld4_guard(mem + (long long)kk * ld, row0 + rq * 4, nrows)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+    } else {                       // memory [row][k]
+        constexpr int NF4 = ROWS * GEMM_BK / 4 / GEMM_THREADS;
+#pragma unroll
+        for (int e = 0; e < NF4; ++e) {
+            const int f = e * GEMM_THREADS + tid;
+            const int rr = f / (GEMM_BK / 4), kq = f % (GEMM_BK / 4);
+            int row = row0 + rr;
+            row = row < nrows ? row : nrows - 1;   // clamp: rows past the end are never stored
+            if constexpr (KTAIL) r[e] = ld4_guard(mem + (long long)row * ld, k0 + kq * 4, Ktot);
+            else r[e] = *reinterpret_cast<const float4*>(mem + (long long)row * ld + k0 + kq * 4);
+        }
+    }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR, int TN, bool KTAIL>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x3_kernel(GemmArgs g)
+{
+    constexpr int BM = 128;
+    constexpr int BN = 64 * TN;
+    constexpr int BK = GEMM_BK;
+    constexpr int LDK = BK + 8;                         // bf16 elements per LDS row (80 B)
+    constexpr int A_IMG = BM * LDK, B_IMG = BN * LDK;   // elements per image (hi or lo)
+    // LDS: A_hi | A_lo | B_hi | B_lo
+
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int h = lane >> 5;
+    const int col = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int z = blockIdx.z;
+    const int batch = z / g.splits;
+    const int split = z - batch * g.splits;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int kbase = split * g.K;
+
+    const float* A = g.A + (long long)batch * g.sA;
+    const float* B = g.B + (long long)batch * g.sB;
+    float* C = g.C + (long long)batch * g.sC + (long long)split * g.sCsplit;
+
+    float4 ra[X3Regs<BM>::NR], rb[X3Regs<BN>::NR];
+    auto load_tiles = [&](int kt) {
+        const int k0 = kbase + kt * BK;
+        x3_load<A_KMAJOR, BM, KTAIL>(ra, A, g.lda, m0, g.M, k0, g.Ktot, tid);
+        x3_load<B_KMAJOR, BN, KTAIL>(rb, B, g.ldb, n0, g.N, k0, g.Ktot, tid);
+    };
+    auto store_tiles = [&]() {
+        x3_store<A_KMAJOR, BM>(ra, smem16, smem16 + A_IMG, tid);
+        x3_store<B_KMAJOR, BN>(rb, smem16 + 2 * A_IMG, smem16 + 2 * A_IMG + B_IMG, tid);
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // One LDS buffer (40 KiB at TN = 2 -> four workgroups per CU), the next tile prefetched into registers while the
+    // MFMAs of this one run: the split (VALU) and the MFMA phases of different workgroups overlap on a SIMD.
+    const int nk = g.K / BK;
+    const __bf16* ah = smem16 + (wm * 64 + col) * LDK + h * 8;
+    const __bf16* al = ah + A_IMG;
+    const __bf16* bh = smem16 + 2 * A_IMG + (wn * (32 * TN) + col) * LDK + h * 8;
+    const __bf16* bl = bh + B_IMG;
+    load_tiles(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt > 0) __syncthreads();          // every wave is done reading the previous tile
+        store_tiles();
+        __syncthreads();
+        if (kt + 1 < nk) load_tiles(kt + 1);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 a_hi[2], a_lo[2], b_hi[TN], b_lo[TN];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a_hi[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * LDK + s * 16);
+                a_lo[i] = *reinterpret_cast<const bf16x8*>(al + i * 32 * LDK + s * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                b_hi[j] = *reinterpret_cast<const bf16x8*>(bh + j * 32 * LDK + s * 16);
+                b_lo[j] = *reinterpret_cast<const bf16x8*>(bl + j * 32 * LDK + s * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue (accumulator layout identical to the f32-input 32x32 tile) ----
+    gemm_epilogue<TN>(g, acc, C, m0 + wm * 64, n0 + wn * (32 * TN), h, col);
 }
 
 // sums split-K slabs and applies the epilogue.  one thread per output element.
@@ -241,7 +455,7 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slabs, float
     for (int s = 0; s < splits; ++s) v += p[(long long)s * slab_stride];
     if (bias) v += bias[n];
     if (scale) v = v * scale[n] + shift[n];
-    v = lpd_act(v, act, slope);
+    v = lpd_act_any(v, act, slope);
     float* dst = C + (long long)batch * sC_batch + (long long)m * ldc + n;
     if (accumulate) v += *dst;
     *dst = v;
@@ -249,13 +463,31 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slabs, float
 
 template <bool AK, bool BK_, int TN, bool KTAIL>
 int gemm_launch_t(const GemmArgs& g, int batch, hipStream_t stream);
+template <bool AK, bool BK_, int TN, bool KTAIL>
+int gemm_x3_launch_t(const GemmArgs& g, int batch, hipStream_t stream);
 
 template <bool AK, bool BK_, int TN>
-int gemm_launch(const GemmArgs& g, int batch, hipStream_t stream)
+int gemm_launch(const GemmArgs& g, int batch, bool x3, hipStream_t stream)
 {
     // every split covers whole 32-deep k-tiles of real data <=> Ktot is a multiple of 32 and splits divide it evenly
     const bool ktail = (g.Ktot % GEMM_BK) != 0 || (long long)g.K * g.splits != g.Ktot;
+    if (x3) {
+        return ktail ? gemm_x3_launch_t<AK, BK_, TN, true>(g, batch, stream) : gemm_x3_launch_t<AK, BK_, TN, false>(g, batch, stream);
+    }
     return ktail ? gemm_launch_t<AK, BK_, TN, true>(g, batch, stream) : gemm_launch_t<AK, BK_, TN, false>(g, batch, stream);
+}
+
+template <bool AK, bool BK_, int TN, bool KTAIL>
+int gemm_x3_launch_t(const GemmArgs& g, int batch, hipStream_t stream)
+{
+    constexpr int BM = 128, BN = 64 * TN, LDK = GEMM_BK + 8;
+    size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(__bf16);
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch * g.splits);
+    auto kern = gemm_bf16x3_kernel<AK, BK_, TN, KTAIL>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, stream, g);
+    LPD_CHECK_LAUNCH("lpd_gemm(bf16x3)");
+    return LPD_OK;
 }
 
 template <bool AK, bool BK_, int TN, bool KTAIL>
@@ -276,10 +508,10 @@ int gemm_launch_t(const GemmArgs& g, int batch, hipStream_t stream)
 }  // namespace
 
 // C-ABI: see include/lpd_hip.h for the contract.
-extern "C" int lpd_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                        int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC,
-                        int splits, float* splitk_ws, const float* bias, const float* scale, const float* shift,
-                        int act, float slope, int accumulate, void* stream_)
+static int gemm_entry(bool x3, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                      int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC,
+                      int splits, float* splitk_ws, const float* bias, const float* scale, const float* shift,
+                      int act, float slope, int accumulate, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(A && B && C, "lpd_gemm: null pointer");
@@ -310,7 +542,7 @@ extern "C" int lpd_gemm(const float* A, const float* B, float* C, int M, int N, 
     const int tn = N > 64 ? 2 : 1;
     int rc;
 #define LPD_GEMM_CASE(AK, BK_)                                                       \
-    rc = (tn == 2) ? gemm_launch<AK, BK_, 2>(g, batch, stream) : gemm_launch<AK, BK_, 1>(g, batch, stream)
+    rc = (tn == 2) ? gemm_launch<AK, BK_, 2>(g, batch, x3, stream) : gemm_launch<AK, BK_, 1>(g, batch, x3, stream)
     if (a_kmajor && b_kmajor) LPD_GEMM_CASE(true, true);
     else if (a_kmajor) LPD_GEMM_CASE(true, false);
     else if (b_kmajor) LPD_GEMM_CASE(false, true);
@@ -324,4 +556,22 @@ extern "C" int lpd_gemm(const float* A, const float* B, float* C, int M, int N, 
         LPD_CHECK_LAUNCH("lpd_gemm(splitk reduce)");
     }
     return LPD_OK;
+}
+
+extern "C" int lpd_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                        int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC,
+                        int splits, float* splitk_ws, const float* bias, const float* scale, const float* shift,
+                        int act, float slope, int accumulate, void* stream)
+{
+    return gemm_entry(false, A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, batch, sA, sB, sC, splits, splitk_ws, bias,
+                      scale, shift, act, slope, accumulate, stream);
+}
+
+extern "C" int lpd_gemm_bf16x3(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                               int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC,
+                               int splits, float* splitk_ws, const float* bias, const float* scale, const float* shift,
+                               int act, float slope, int accumulate, void* stream)
+{
+    return gemm_entry(true, A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, batch, sA, sB, sC, splits, splitk_ws, bias,
+                      scale, shift, act, slope, accumulate, stream);
 }

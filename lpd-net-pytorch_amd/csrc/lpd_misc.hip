@@ -32,7 +32,7 @@ __global__ void linear_smallk_kernel(const float* __restrict__ X, int ldx, const
     for (int c = 0; c < K; ++c) v = fmaf(x[c], w[(size_t)c * w_sk], v);
     if (bias) v += bias[n];
     if (scale) v = v * scale[n] + shift[n];
-    Y[(size_t)m * ldy + n] = lpd_act(v, act, slope);
+    Y[(size_t)m * ldy + n] = lpd_act_any(v, act, slope);
 }
 
 // in [batch][R][C] (row stride ldi) -> out [batch][C][R] (row stride ldo)

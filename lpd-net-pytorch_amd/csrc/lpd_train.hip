@@ -15,12 +15,11 @@ namespace {
 
 __device__ __forceinline__ float act_grad(float pre, int act, float slope)
 {
-    switch (act) {
-        case 1: return pre > 0.0f ? 1.0f : 0.0f;
-        case 2: return pre > 0.0f ? 1.0f : slope;
-        case 3: { float s = 1.0f / (1.0f + __expf(-pre)); return s * (1.0f - s); }
-        default: return 1.0f;
+    if (act == 3) {      // uniform; lpd_sigmoid is not speculatable, so the common cases below stay two instructions
+        const float s = lpd_sigmoid(pre);
+        return s * (1.0f - s);
     }
+    return pre > 0.0f ? 1.0f : lpd_neg_slope(act, slope);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -101,10 +100,13 @@ __global__ void affine_act_kernel(const float* __restrict__ X, long long ldx, fl
         }
         const float4 x = *reinterpret_cast<const float4*>(X + r * ldx + q * 4);
         float4 y;
-        y.x = lpd_act(sc.x * x.x + sh.x, act, slope);
-        y.y = lpd_act(sc.y * x.y + sh.y, act, slope);
-        y.z = lpd_act(sc.z * x.z + sh.z, act, slope);
-        y.w = lpd_act(sc.w * x.w + sh.w, act, slope);
+        y.x = sc.x * x.x + sh.x; y.y = sc.y * x.y + sh.y; y.z = sc.z * x.z + sh.z; y.w = sc.w * x.w + sh.w;
+        if (act == 3) {      // uniform: a scalar branch, the exp/divide path is not if-converted into the common case
+            y.x = lpd_sigmoid(y.x); y.y = lpd_sigmoid(y.y); y.z = lpd_sigmoid(y.z); y.w = lpd_sigmoid(y.w);
+        } else {
+            const float ns = lpd_neg_slope(act, slope);
+            y.x = lpd_act_pl(y.x, ns); y.y = lpd_act_pl(y.y, ns); y.z = lpd_act_pl(y.z, ns); y.w = lpd_act_pl(y.w, ns);
+        }
         *reinterpret_cast<float4*>(Y + r * ldy + q * 4) = y;
     }
 }
@@ -742,6 +744,7 @@ extern "C" int lpd_group_max(const float* X, long long ldx, int k, const float* 
 {
     LPD_CHECK_ARG(X && scale && shift && out && arg && M > 0 && k > 0 && k <= 255, "lpd_group_max: bad arguments");
     LPD_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "lpd_group_max: C and leading dims must be multiples of 4");
+    LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_group_max: act=%d unsupported (none/ReLU/LeakyReLU)", act);
     hipLaunchKernelGGL(group_max_kernel, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, ST(stream), X, ldx, k, scale, shift,
                        act, slope, out, ldo, arg, M, C);
     LPD_CHECK_LAUNCH("lpd_group_max");

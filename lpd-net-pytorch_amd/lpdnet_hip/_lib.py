@@ -27,6 +27,8 @@ SIGNATURES = {
     "lpd_knn": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_int, _c_p],
     "lpd_gemm": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                  _c_ll, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_p],
+"lpd_gemm_bf16x3": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                 _c_ll, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_p],
     "lpd_edge_gather_max": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int,
                             _c_int, _c_int, _c_f, _c_p],
     "lpd_edge_gather_max16": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int,

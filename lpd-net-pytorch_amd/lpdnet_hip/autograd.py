@@ -195,6 +195,11 @@ class _TNet:
         kd = net.k
         bns = [getattr(net, f"bn{i}") if use_bn else None for i in range(1, 6)]
         S = dict(h=h)
+        with ops.exact_gemm():   # BatchNorm over the B rows of the fc stack amplifies GEMM rounding ~100x: f32-input MFMA here
+            return _TNet._fwd(net, h, B, N, kd, bns, S)
+
+    @staticmethod
+    def _fwd(net, h, B, N, kd, bns, S):
         S["r1"], S["s1"], a1 = _Dense.fwd(h, net.conv1, bns[0], ops.ACT_RELU)
         S["r2"], S["s2"], a2 = _Dense.fwd(a1, net.conv2, bns[1], ops.ACT_RELU)
         S["r3"], S["s3"], a3 = _Dense.fwd(a2, net.conv3, bns[2], ops.ACT_RELU)
@@ -270,15 +275,16 @@ class _Front:
     @staticmethod
     def fwd(net, xyz, w1, bn1, w2, bn2, B, N, act, slope):
         S = dict(xyz=xyz, p_in=xyz)
-        if net.t3d:
-            S["trans3"], S["S3"] = _TNet.fwd(net.t_net3d, xyz, B, N, True)
-            S["p_in"] = ops.apply_transform(xyz, S["trans3"], N)
-        S["y1"], S["st1"], S["f1"] = _PointLayer.fwd(S["p_in"], w1, bn1, act, slope)
-        S["y2"], S["st2"], f0 = _PointLayer.fwd(S["f1"], w2, bn2, act, slope)
-        if net.tfea:
-            S["f_pre"] = f0
-            S["transf"], S["Sf"] = _TNet.fwd(net.t_net_fea, f0, B, N, True)
-            f0 = ops.apply_transform(f0, S["transf"], N)
+        with ops.exact_gemm():      # F0 feeds the feature-space kNN: exact fp32 (the backward may use the fast GEMM)
+            if net.t3d:
+                S["trans3"], S["S3"] = _TNet.fwd(net.t_net3d, xyz, B, N, True)
+                S["p_in"] = ops.apply_transform(xyz, S["trans3"], N)
+            S["y1"], S["st1"], S["f1"] = _PointLayer.fwd(S["p_in"], w1, bn1, act, slope)
+            S["y2"], S["st2"], f0 = _PointLayer.fwd(S["f1"], w2, bn2, act, slope)
+            if net.tfea:
+                S["f_pre"] = f0
+                S["transf"], S["Sf"] = _TNet.fwd(net.t_net_fea, f0, B, N, True)
+                f0 = ops.apply_transform(f0, S["transf"], N)
         return f0, S
 
     @staticmethod
@@ -318,6 +324,11 @@ class _LPDNetTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, x, *params):
+        with ops.train_forward_gemm():
+            return _LPDNetTrainFn._forward(ctx, net, x, *params)
+
+    @staticmethod
+    def _forward(ctx, net, x, *params):
         from . import engine
         B, N = x.shape[0], x.shape[2]
         M, k = B * N, net.k
@@ -445,6 +456,11 @@ class _LPDNetOrignTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, x, *params):
+        with ops.train_forward_gemm():
+            return _LPDNetOrignTrainFn._forward(ctx, net, x, *params)
+
+    @staticmethod
+    def _forward(ctx, net, x, *params):
         from . import engine
         B, N = x.shape[0], x.shape[2]
         M, k = B * N, net.k
@@ -551,6 +567,11 @@ class _PointNetTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, x, *params):
+        with ops.train_forward_gemm():
+            return _PointNetTrainFn._forward(ctx, net, x, *params)
+
+    @staticmethod
+    def _forward(ctx, net, x, *params):
         B, N = x.shape[0], x.shape[2]
         xyz = x.view(B * N, 3)
         S = dict(xyz=xyz)
@@ -612,6 +633,11 @@ class _NetVLADTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, vlad, B, N, feat, *params):
+        with ops.train_forward_gemm():
+            return _NetVLADTrainFn._forward(ctx, vlad, B, N, feat, *params)
+
+    @staticmethod
+    def _forward(ctx, vlad, B, N, feat, *params):
         E, K, O = vlad.feature_size, vlad.cluster_size, vlad.output_dim
         M = B * N
         dev = feat.device

@@ -111,7 +111,13 @@ def _check_input(x):
 # T-Nets
 # ------------------------------------------------------------------------------------------------
 def _tnet_common(net, h, B, N, kdim, bns):
-    """conv k->64->128->1024 (+bias)(+BN) + ReLU, max over N, fc 512, 256, k*k (+I).  h [B*N, k] rows."""
+    """conv k->64->128->1024 (+bias)(+BN) + ReLU, max over N, fc 512, 256, k*k (+I).  h [B*N, k] rows.
+    Always on the exact (f32-input MFMA) GEMM, like the training form."""
+    with ops.exact_gemm():
+        return _tnet_layers(net, h, B, N, kdim, bns)
+
+
+def _tnet_layers(net, h, B, N, kdim, bns):
     def layer(x, lin, bn):
         sc, sh = bn_affine(bn) if bn is not None else (None, None)
         return ops.linear(x, _w2d(lin), bias=lin.bias, scale=sc, shift=sh, act=ops.ACT_RELU)
@@ -159,16 +165,17 @@ def lpdnet_features_eval(net, x):
     act, slope = (ops.ACT_RELU, 0.0) if net.use_relu else (ops.ACT_LEAKY, LEAKY_SLOPE)
     xyz = x.view(M, 3)
     p = xyz
-    if net.t3d:
-        trans = transform_net_eval(net.t_net3d, xyz, B, N)
-        p = ops.apply_transform(xyz, trans, N)
-    s, b = bn_affine(net.bn1_lpd)
-    f = ops.linear(p, _w2d(net.conv1_lpd), scale=s, shift=b, act=act, slope=slope)
-    s, b = bn_affine(net.bn2_lpd)
-    f = ops.linear(f, _w2d(net.conv2_lpd), scale=s, shift=b, act=act, slope=slope)      # F0 [M,64]
-    if net.tfea:
-        tf = transform_net_eval(net.t_net_fea, f, B, N)
-        f = ops.apply_transform(f, tf, N)
+    with ops.exact_gemm():      # everything in front of the feature-space kNN is exact fp32
+        if net.t3d:
+            trans = transform_net_eval(net.t_net3d, xyz, B, N)
+            p = ops.apply_transform(xyz, trans, N)
+        s, b = bn_affine(net.bn1_lpd)
+        f = ops.linear(p, _w2d(net.conv1_lpd), scale=s, shift=b, act=act, slope=slope)
+        s, b = bn_affine(net.bn2_lpd)
+        f = ops.linear(f, _w2d(net.conv2_lpd), scale=s, shift=b, act=act, slope=slope)      # F0 [M,64]
+        if net.tfea:
+            tf = transform_net_eval(net.t_net_fea, f, B, N)
+            f = ops.apply_transform(f, tf, N)
     # dynamic graph in feature space
     idx_f = ops.knn(ops.transpose(f.view(B, N, 64)), k)
     cat = torch.empty((M, 512), dtype=torch.float32, device=x.device)                   # [x1 | x2 | x3]
@@ -202,13 +209,14 @@ def lpdnet_origin_features_eval(net, x):
         return ops.linear(h, _w2d(block[0]), scale=s, shift=b, act=act, slope=slope)
     xyz = x.view(M, 3)
     p = xyz
-    if net.t3d:
-        trans = transform_net_eval(net.t_net3d, xyz, B, N)
-        p = ops.apply_transform(xyz, trans, N)
-    f = seq(seq(p, net.conv1_lpd), net.conv2_lpd)
-    if net.tfea:
-        tf = transform_net_eval(net.t_net_fea, f, B, N)
-        f = ops.apply_transform(f, tf, N)
+    with ops.exact_gemm():      # everything in front of the feature-space kNN is exact fp32
+        if net.t3d:
+            trans = transform_net_eval(net.t_net3d, xyz, B, N)
+            p = ops.apply_transform(xyz, trans, N)
+        f = seq(seq(p, net.conv1_lpd), net.conv2_lpd)
+        if net.tfea:
+            tf = transform_net_eval(net.t_net_fea, f, B, N)
+            f = ops.apply_transform(f, tf, N)
     idx_f = ops.knn(ops.transpose(f.view(B, N, 64)), k)
     pq = ops.linear(f, split_edge_weight(net.convDG1, "cat_cd"))                        # [M,128] = [P | Q]
     s1, b1 = bn_affine(net.convDG1[1])

@@ -88,8 +88,12 @@ def test_morton_sort_is_a_permutation_and_improves_locality(cuda):
                                           (77, 513, 128, False, False), (512, 64, 1024, False, True), (300, 1024, 512, False, False),
                                           (132, 72, 64, True, True), (1024, 64, 4096, True, True),
                                           (200, 64, 100, True, True), (96, 40, 52, False, False), (64, 64, 600, False, True)])
-def test_gemm_modes(cuda, M, N, K, ak, bk):
+@pytest.mark.parametrize("exact", [True, False], ids=["f32mfma", "bf16x3"])
+def test_gemm_modes(cuda, M, N, K, ak, bk, exact):
+    """exact: f32-input MFMA (one rounding per FMA); otherwise the split-bf16 three-product form, whose error against
+    fp64 is bounded here at 3e-5 of the output range (measured ~5e-6)."""
     ops = _ops()
+    tol = 1e-5 if exact else 3e-5
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn((K, M) if ak else (M, K), generator=g)
     Bm = torch.randn((K, N) if bk else (N, K), generator=g)
@@ -99,28 +103,33 @@ def test_gemm_modes(cuda, M, N, K, ak, bk):
     ref = (Al.double() @ Bl.double() + bias.double()) * scale.double() + shift.double()
     ref = torch.where(ref > 0, ref, ref * 0.01)
     out = ops.gemm(A.to(cuda), Bm.to(cuda), a_kmajor=ak, b_kmajor=bk, bias=bias.to(cuda), scale=scale.to(cuda),
-                   shift=shift.to(cuda), act=ops.ACT_LEAKY)
-    assert _rel(out, ref) < 1e-5
-    raw = ops.gemm(A.to(cuda), Bm.to(cuda), a_kmajor=ak, b_kmajor=bk)
-    assert _rel(raw, Al.double() @ Bl.double()) < 1e-5
+                   shift=shift.to(cuda), act=ops.ACT_LEAKY, exact=exact)
+    assert _rel(out, ref) < tol
+    raw = ops.gemm(A.to(cuda), Bm.to(cuda), a_kmajor=ak, b_kmajor=bk, exact=exact)
+    assert _rel(raw, Al.double() @ Bl.double()) < tol
+    with ops.exact_gemm():      # the context form of exact=True gives the same bits
+        again = ops.gemm(A.to(cuda), Bm.to(cuda), a_kmajor=ak, b_kmajor=bk)
+    assert torch.equal(again, raw) == exact or not exact
 
 
-def test_gemm_splitk_and_batched(cuda):
+@pytest.mark.parametrize("exact", [True, False], ids=["f32mfma", "bf16x3"])
+def test_gemm_splitk_and_batched(cuda, exact):
     ops = _ops()
+    tol = 1e-5 if exact else 3e-5
     g = torch.Generator().manual_seed(5)
     A = torch.randn(6, 8192, generator=g)
     W = torch.randn(8192, 256, generator=g) / 90
     sc, sh = torch.randn(256, generator=g), torch.randn(256, generator=g)
-    out = ops.gemm(A.to(cuda), W.to(cuda), b_kmajor=True, scale=sc.to(cuda), shift=sh.to(cuda), splits=16)
+    out = ops.gemm(A.to(cuda), W.to(cuda), b_kmajor=True, scale=sc.to(cuda), shift=sh.to(cuda), splits=16, exact=exact)
     ref = (A.double() @ W.double()) * sc.double() + sh.double()
-    assert _rel(out, ref) < 1e-5
+    assert _rel(out, ref) < tol
     # batched, A stored k-major (NetVLAD aggregation shape): [b][n][f]^T @ [b][n][c]
     X = torch.randn(3, 512, 256, generator=g)
     Act = torch.rand(3, 512, 64, generator=g)
-    out = ops.gemm(X.to(cuda), Act.to(cuda), a_kmajor=True, b_kmajor=True)
+    out = ops.gemm(X.to(cuda), Act.to(cuda), a_kmajor=True, b_kmajor=True, exact=exact)
     ref = torch.matmul(X.double().transpose(1, 2), Act.double())
     assert out.shape == (3, 256, 64)
-    assert _rel(out, ref) < 1e-5
+    assert _rel(out, ref) < tol
 
 
 def test_gemm_output_slice_and_strided_input(cuda):

@@ -142,10 +142,11 @@ def test_train_grads_vs_oracle(cuda, featnet, bq, P, Ng, N, variant):
         errs[name] = ((prm.grad.cpu().double() - want).norm() / want.norm()).item()
         assert errs[name] < GRAD_TOL, (name, errs[name])
     assert float(np.median(list(errs.values()))) < (GRAD_MEDIAN_TOL if len(variant) < 2 else 2 * GRAD_MEDIAN_TOL), errs
-    # everything before the first max-over-k (head) is tight
+    # everything before the first max-over-k (head) is tight: no arg-max flips, only rounding (the backward products
+    # run as split-bf16, ~5e-6 each, amplified by the B-row BatchNorms of the head: measured <= 2.7e-4)
     for name, e in errs.items():
         if name.startswith("net_vlad."):
-            assert e < 2e-4, (name, e)
+            assert e < 5e-4, (name, e)
     for name, b in m.named_buffers():
         if name.endswith(("running_mean", "running_var")):
             assert torch.allclose(b.cpu().double(), new_stats[name], rtol=2e-4, atol=2e-5), name
