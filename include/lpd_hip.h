@@ -74,6 +74,17 @@ int lpd_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
              int accumulate, void* stream);
 
 /*
+ * lpd_gemm on the bf16 MFMA: each fp32 operand is split hi + lo (two bf16) while it is staged into LDS and every
+ * product is the sum of three bf16 MFMA products (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi), fp32 accumulation.  Error
+ * ~5e-6 of the output range (the f32-input form: ~5e-7); 2e-6 on the final descriptors (DESIGN.md "GEMM precision").
+ * Same arguments and layouts as lpd_gemm.
+ */
+int lpd_gemm_bf16x3(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+             int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC, int splits,
+             float* splitk_ws, const float* bias, const float* scale, const float* shift, int act, float slope,
+             int accumulate, void* stream);
+
+/*
  * kNN-graph aggregation (K-agg).  Replaces the gather/repeat/cat of util/lpdnet_model.py:331-363
  * fused with a split edge convolution + BatchNorm + activation + max over k
  * (lpdnet_model.py:249-250 convDG1/x1, :257-258 convSN1/x3):
@@ -110,6 +121,10 @@ int lpd_pack_idx16(const int32_t* idx, uint16_t* idx16, long long M, int k, void
  *   W2 [CO][CM] torch [out,in] layout.  (CM,CO) in {(128,128),(64,64)}; k <= 128.
  */
 int lpd_edge_mlp(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
+                 const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo, int M,
+                 int N, int CM, int CO, int k, int act, float slope, void* stream);
+/* Same contract on the bf16 MFMA (split-bf16, three products per term, fp32 accumulate: see lpd_gemm_bf16x3). */
+int lpd_edge_mlp_bf16x3(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
                  const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo, int M,
                  int N, int CM, int CO, int k, int act, float slope, void* stream);
 

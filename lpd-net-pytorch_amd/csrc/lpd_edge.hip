@@ -411,6 +411,188 @@ int edge_mlp_launch(const EdgeMlpArgs& g, hipStream_t stream)
     return LPD_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// fused edge MLP on the bf16 MFMA (split-bf16, three products per term: see lpd_gemm.hip "bf16x3")
+//
+// Same contraction as edge_mlp_kernel, re-tiled for v_mfma_f32_32x32x16_bf16:
+//   * W2 never touches LDS: each wave owns ONE 32-column tile of the output and keeps its W2 fragments (CM/16 k-steps,
+//     hi and lo) in registers for the whole kernel, pre-multiplied by sgn(s2) so that a single running max serves the
+//     max/min selection (negation is exact in every product and sum);
+//   * the per-slot tile Y1_t [64 points][CM] is built in LDS as two bf16 images (hi, lo), rows k-contiguous with an
+//     80/272-byte stride (conflict-free ds_read_b128 operand fetches), double-buffered: 70 KiB per block at CM = 128,
+//     two blocks per CU;
+//   * CM = CO = 128: wave w -> all 64 points x columns 32w..32w+31 (2 m-tiles);  CM = CO = 64: wave (wp, wo) ->
+//     32 points x 32 columns.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 em_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 em_bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void em_split4(float x0, float x1, float x2, float x3, em_bf16x4& hi, em_bf16x4& lo)
+{
+    hi[0] = (__bf16)x0; hi[1] = (__bf16)x1; hi[2] = (__bf16)x2; hi[3] = (__bf16)x3;
+    lo[0] = (__bf16)(x0 - (float)hi[0]); lo[1] = (__bf16)(x1 - (float)hi[1]);
+    lo[2] = (__bf16)(x2 - (float)hi[2]); lo[3] = (__bf16)(x3 - (float)hi[3]);
+}
+
+template <int CM, int CO>
+struct EdgeMlpX3Cfg {
+    static constexpr int LDK = CM + 8;                      // bf16 per LDS row
+    static constexpr int IMG = EM_PTS * LDK;                // bf16 per image (hi or lo)
+    static constexpr int WM = CO == 128 ? 2 : 1;            // m-tiles (32 points) per wave
+    static constexpr int KS = CM / 16;                      // k-steps
+    static constexpr int F4_PER_ROW = CM / 4;
+    static constexpr int ROWS_PER_PASS = EM_THREADS / F4_PER_ROW;
+    static constexpr int PASSES = EM_PTS / ROWS_PER_PASS;
+};
+
+template <int CM, int CO>
+__global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs g)
+{
+    using Cfg = EdgeMlpX3Cfg<CM, CO>;
+    constexpr int LDK = Cfg::LDK, IMG = Cfg::IMG, WM = Cfg::WM, KS = Cfg::KS, PASSES = Cfg::PASSES;
+    static_assert((CM == 128 && CO == 128) || (CM == 64 && CO == 64), "edge_mlp_x3: built for 128->128 and 64->64");
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];   // [2 buffers][hi | lo][64][LDK], then idx
+    int* idxs = reinterpret_cast<int*>(smem16 + 4 * IMG);             // [EM_PTS][k]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int h = lane >> 5;
+    const int col = lane & 31;
+    const int ntile = CO == 128 ? wave : (wave >> 1);       // output-column tile of this wave
+    const int ptile = CO == 128 ? 0 : (wave & 1);           // first point tile of this wave
+    const int m0 = lpd_xcd_remap(blockIdx.x, gridDim.x) * EM_PTS;
+
+    // W2 fragments of this wave's column n = ntile*32 + col: k = 16 s + 8 h .. +7, sign-adjusted, split
+    const int n = ntile * 32 + col;
+    const float sc2 = g.s2[n], sh2 = g.b2[n];
+    const float sgn = sc2 >= 0.f ? 1.0f : -1.0f;
+    em_bf16x8 b_hi[KS], b_lo[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const float4 w0 = *reinterpret_cast<const float4*>(g.W2 + (size_t)n * CM + s * 16 + h * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(g.W2 + (size_t)n * CM + s * 16 + h * 8 + 4);
+        em_bf16x4 h0, l0, h1, l1;
+        em_split4(sgn * w0.x, sgn * w0.y, sgn * w0.z, sgn * w0.w, h0, l0);
+        em_split4(sgn * w1.x, sgn * w1.y, sgn * w1.z, sgn * w1.w, h1, l1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b_hi[s][e] = h0[e]; b_hi[s][4 + e] = h1[e]; b_lo[s][e] = l0[e]; b_lo[s][4 + e] = l1[e]; }
+    }
+
+    for (int f = tid; f < EM_PTS * g.k; f += EM_THREADS) {
+        int p = f / g.k, t = f - p * g.k;
+        int m = m0 + p;
+        m = m < g.M ? m : g.M - 1;
+        idxs[f] = (m / g.N) * g.N + g.idx[(size_t)m * g.k + t];  // global row of the neighbour
+    }
+
+    // gather role of this thread: float4 column c4 of rows prow + ROWS_PER_PASS * e
+    const int c4 = tid % Cfg::F4_PER_ROW;
+    const int prow = tid / Cfg::F4_PER_ROW;
+    const float4 s1 = *reinterpret_cast<const float4*>(g.s1 + c4 * 4);
+    const float4 b1 = *reinterpret_cast<const float4*>(g.b1 + c4 * 4);
+    const float ns = lpd_neg_slope(g.act, g.slope);
+    float4 qc[PASSES];  // centre term folded with the BN affine: s1 * Q + b1
+#pragma unroll
+    for (int e = 0; e < PASSES; ++e) {
+        int m = m0 + prow + Cfg::ROWS_PER_PASS * e;
+        m = m < g.M ? m : g.M - 1;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.Q) q = *reinterpret_cast<const float4*>(g.Q + (size_t)m * g.ldq + c4 * 4);
+        qc[e].x = s1.x * q.x + b1.x;
+        qc[e].y = s1.y * q.y + b1.y;
+        qc[e].z = s1.z * q.z + b1.z;
+        qc[e].w = s1.w * q.w + b1.w;
+    }
+    __syncthreads();  // idxs visible
+
+    float4 pg[PASSES];
+    auto gather = [&](int t) {
+#pragma unroll
+        for (int e = 0; e < PASSES; ++e) {
+            const int p = prow + Cfg::ROWS_PER_PASS * e;
+            const int row = idxs[p * g.k + t];
+            pg[e] = *reinterpret_cast<const float4*>(g.P + (size_t)row * g.ldp + c4 * 4);
+        }
+    };
+    auto build = [&](int buf) {
+        __bf16* hi_img = smem16 + buf * 2 * IMG;
+        __bf16* lo_img = hi_img + IMG;
+#pragma unroll
+        for (int e = 0; e < PASSES; ++e) {
+            const int p = prow + Cfg::ROWS_PER_PASS * e;
+            em_bf16x4 hh, ll;   // s (P + Q) + b  ==  s P + (s Q + b)
+            em_split4(lpd_act_pl(s1.x * pg[e].x + qc[e].x, ns), lpd_act_pl(s1.y * pg[e].y + qc[e].y, ns),
+                      lpd_act_pl(s1.z * pg[e].z + qc[e].z, ns), lpd_act_pl(s1.w * pg[e].w + qc[e].w, ns), hh, ll);
+            *reinterpret_cast<em_bf16x4*>(hi_img + p * LDK + c4 * 4) = hh;
+            *reinterpret_cast<em_bf16x4*>(lo_img + p * LDK + c4 * 4) = ll;
+        }
+    };
+
+    f32x16 zmax[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zmax[i][r] = -INFINITY;
+
+    gather(0);
+    build(0);
+    __syncthreads();
+
+    for (int t = 0; t < g.k; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < g.k) gather(t + 1);  // rows in flight under this slot's MFMAs
+        const __bf16* ah = smem16 + buf * 2 * IMG + (ptile * 32 + col) * LDK + h * 8;
+        const __bf16* al = ah + IMG;
+        f32x16 acc[WM];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const em_bf16x8 a_hi = *reinterpret_cast<const em_bf16x8*>(ah + i * 32 * LDK + s * 16);
+                const em_bf16x8 a_lo = *reinterpret_cast<const em_bf16x8*>(al + i * 32 * LDK + s * 16);
+                // accumulator rows = points, columns = output channels: A = Y tile, B = W2 fragment
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi[s], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo[s], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi[s], acc[i], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zmax[i][r] = fmaxf(zmax[i][r], acc[i][r]);
+        if (t + 1 < g.k) build(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (ptile + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= g.M) continue;
+            g.out[(size_t)m * g.ldo + n] = lpd_act_pl(sc2 * (sgn * zmax[i][r]) + sh2, ns);
+        }
+}
+
+template <int CM, int CO>
+int edge_mlp_x3_launch(const EdgeMlpArgs& g, hipStream_t stream)
+{
+    using Cfg = EdgeMlpX3Cfg<CM, CO>;
+    size_t lds = (size_t)4 * Cfg::IMG * sizeof(__bf16) + (size_t)EM_PTS * g.k * sizeof(int);
+    auto kern = edge_mlp_x3_kernel<CM, CO>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((g.M + EM_PTS - 1) / EM_PTS);
+    hipLaunchKernelGGL(kern, grid, dim3(EM_THREADS), lds, stream, g);
+    LPD_CHECK_LAUNCH("lpd_edge_mlp(bf16x3)");
+    return LPD_OK;
+}
+
 }  // namespace
 
 extern "C" int lpd_edge_gather_max(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, float* out,
@@ -438,9 +620,9 @@ extern "C" int lpd_edge_gather_max(const float* P, int ldp, const float* Q, int 
     return LPD_OK;
 }
 
-extern "C" int lpd_edge_mlp(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
-                            const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo,
-                            int M, int N, int CM, int CO, int k, int act, float slope, void* stream_)
+static int edge_mlp_entry(bool x3, const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
+                          const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo,
+                          int M, int N, int CM, int CO, int k, int act, float slope, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(P && idx && s1 && b1 && W2 && s2 && b2 && out, "lpd_edge_mlp: null pointer");
@@ -451,8 +633,8 @@ extern "C" int lpd_edge_mlp(const float* P, int ldp, const float* Q, int ldq, co
     LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)Q | (uintptr_t)s1 | (uintptr_t)b1 | (uintptr_t)W2) & 15) == 0,
                   "lpd_edge_mlp: pointers must be 16-byte aligned");
     EdgeMlpArgs g{P, Q, idx, s1, b1, W2, s2, b2, out, M, N, k, ldp, ldq, ldo, act, slope};
-    if (CM == 128 && CO == 128) return edge_mlp_launch<128, 128>(g, stream);
-    if (CM == 64 && CO == 64) return edge_mlp_launch<64, 64>(g, stream);
+    if (CM == 128 && CO == 128) return x3 ? edge_mlp_x3_launch<128, 128>(g, stream) : edge_mlp_launch<128, 128>(g, stream);
+    if (CM == 64 && CO == 64) return x3 ? edge_mlp_x3_launch<64, 64>(g, stream) : edge_mlp_launch<64, 64>(g, stream);
     lpd_set_error("lpd_edge_mlp: (CM=%d, CO=%d) unsupported; built for (128,128) and (64,64)", CM, CO);
     return LPD_ERR_UNSUPPORTED;
 }
@@ -500,4 +682,18 @@ extern "C" int lpd_edge_gather_max16(const float* P, int ldp, const float* Q, in
     }
     LPD_CHECK_LAUNCH("lpd_edge_gather_max16");
     return LPD_OK;
+}
+
+extern "C" int lpd_edge_mlp(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
+                            const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo,
+                            int M, int N, int CM, int CO, int k, int act, float slope, void* stream)
+{
+    return edge_mlp_entry(false, P, ldp, Q, ldq, idx, s1, b1, W2, s2, b2, out, ldo, M, N, CM, CO, k, act, slope, stream);
+}
+
+extern "C" int lpd_edge_mlp_bf16x3(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
+                                   const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo,
+                                   int M, int N, int CM, int CO, int k, int act, float slope, void* stream)
+{
+    return edge_mlp_entry(true, P, ldp, Q, ldq, idx, s1, b1, W2, s2, b2, out, ldo, M, N, CM, CO, k, act, slope, stream);
 }

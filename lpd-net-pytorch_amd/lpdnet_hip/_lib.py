@@ -36,6 +36,8 @@ SIGNATURES = {
     "lpd_pack_idx16": [_c_p, _c_p, ctypes.c_longlong, _c_int, _c_p],
     "lpd_edge_mlp": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int,
                      _c_int, _c_int, _c_int, _c_int, _c_f, _c_p],
+    "lpd_edge_mlp_bf16x3": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int,
+                     _c_int, _c_int, _c_int, _c_int, _c_f, _c_p],
     "lpd_linear_smallk": [_c_p, _c_int, _c_p, _c_int, _c_int, _c_ll, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int,
                           _c_p, _c_p, _c_p, _c_int, _c_f, _c_p],
     "lpd_transpose": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_p],

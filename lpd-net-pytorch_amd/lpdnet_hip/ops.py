@@ -285,7 +285,7 @@ def edge_gather_max16(P, Q, idx16, N, *, scale=None, shift=None, act=ACT_NONE, s
     return out
 
 
-def edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, *, act=ACT_LEAKY, slope=0.01, out=None):
+def edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, *, act=ACT_LEAKY, slope=0.01, out=None, exact=False):
     """Fused DG1-activation -> DG2 conv -> BN -> act -> max over k (include/lpd_hip.h lpd_edge_mlp)."""
     ldp = _rows(P, "P")
     ldq = _rows(Q, "Q") if Q is not None else 0
@@ -304,7 +304,8 @@ def edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, *, act=ACT_LEAKY, slope=0.01, out
     s1, b1 = _vec(s1, "s1", CM), _vec(b1, "b1", CM)
     s2, b2 = _vec(s2, "s2", CO), _vec(b2, "b2", CO)
     lib = _lib.load()
-    _call(f"edge_mlp[{CM}->{CO}]", lib.lpd_edge_mlp, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(s1), _ptr(b1), _ptr(W2), _ptr(s2),
+    x3 = GEMM_BF16X3 and not exact and _EXACT_DEPTH == 0
+    _call(f"edge_mlp{'x3' if x3 else ''}[{CM}->{CO}]", lib.lpd_edge_mlp_bf16x3 if x3 else lib.lpd_edge_mlp, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(s1), _ptr(b1), _ptr(W2), _ptr(s2),
                                 _ptr(b2), _ptr(out), ldo, M, N, CM, CO, k, act, float(slope), _stream())
     return out
 
