@@ -241,7 +241,10 @@ def main():
             "config": {"workload": ("BASELINE configs[1]" if (args.points, args.k) == (4096, 20) else "BASELINE configs[4] (stress)") +
                                    ": LPD-Net (featnet=lpdnet, emb_dims=1024, no T-Nets) eval forward, "
                                    f"N={args.points}, k={args.k}, eval_batch_size={args.batch} clouds/step/GPU",
-                       "clouds_per_step_per_gpu": args.batch, "num_points": args.points, "parallelism": f"shard-by-cloud x{world}"},
+                       "clouds_per_step_per_gpu": args.batch, "num_points": args.points, "parallelism": f"shard-by-cloud x{world}",
+                       "arithmetic": ("fp32 tensors; kNN distances and every layer in front of the feature-space kNN exact fp32; large dense "
+                                      "products as 3-product split-bf16 MFMA with fp32 accumulation (DESIGN.md 3.2)"
+                                      if ops.GEMM_BF16X3 else "fp32 tensors, every product on the f32-input MFMA / fp32 FMA")},
             "roofline": roof, "kernels": kern, "train": train,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -78,6 +78,46 @@ __device__ __forceinline__ void knn_insert(float (&v)[KMAX], int (&id)[KMAX], fl
     id[0] = ge0 ? id[0] : j;
 }
 
+// The same insertion written so that every list register is updated IN PLACE.  In the streaming kernel the lists are
+// loop-carried through the queue-drain loop; with the C++ form above the register allocator failed to coalesce the
+// loop PHIs and every drain iteration carried 161 v_mov_b32 on top of the ~120 useful instructions (ISA dump,
+// DESIGN.md 3.1).  Tied "+v" operands pin each list element to one register; per slot: one compare (reused as the next
+// slot's "current" mask), a median for the value -- new v[s] = med3(v[s-1], v[s], x) because v[s-1] >= v[s] -- and two
+// selects for the index.  The s_nop covers the VALU-writes-SGPR -> VALU-reads-it wait states the compiler would insert.
+template <int KMAX>
+__device__ __forceinline__ void knn_insert_inplace(float (&v)[KMAX], int (&id)[KMAX], float x, int j)
+{
+    unsigned long long cc, cp;
+    int ti;
+    asm volatile("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(cc) : "v"(v[KMAX - 1]), "v"(x));   // current slot keeps its entry?
+#pragma unroll
+    for (int s = KMAX - 1; s >= 1; --s) {
+        asm volatile(
+            "v_cmp_ge_f32_e64 %[cp], %[vp], %[x]\n\t"            // previous slot ranks before x?
+            "v_med3_f32 %[vs], %[vp], %[vs], %[x]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32_e64 %[ti], %[ip], %[j], %[cp]\n\t"    // incoming index: j if the previous slot stays, else its index
+            "v_cndmask_b32_e64 %[is], %[ti], %[is], %[cc]"       // keep the own index while the own value stays
+            : [vs] "+v"(v[s]), [is] "+v"(id[s]), [cp] "=&s"(cp), [ti] "=&v"(ti)
+            : [vp] "v"(v[s - 1]), [ip] "v"(id[s - 1]), [x] "v"(x), [j] "v"(j), [cc] "s"(cc));
+        cc = cp;
+    }
+    asm volatile(
+        "v_cndmask_b32_e64 %[i0], %[j], %[i0], %[cc]\n\t"
+        "v_max_f32 %[v0], %[v0], %[x]"
+        : [v0] "+v"(v[0]), [i0] "+v"(id[0])
+        : [x] "v"(x), [j] "v"(j), [cc] "s"(cc));
+}
+
+// values only (phase A: the admission threshold needs no indices)
+template <int KMAX>
+__device__ __forceinline__ void knn_insert_values(float (&v)[KMAX], float x)
+{
+#pragma unroll
+    for (int s = KMAX - 1; s >= 1; --s) v[s] = __builtin_amdgcn_fmed3f(v[s - 1], v[s], x);
+    v[0] = fmaxf(v[0], x);
+}
+
 // General insert (no ordering assumption on j): an element ranks before the candidate when its
 // value is larger, or equal with a smaller index.
 template <int KMAX>
@@ -430,7 +470,7 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __re
             // by -inf, which leaves the list unchanged.  No divergent region => the compiler keeps the lists in place
             // (inserting under `if` cost ~4x the useful instructions in v_mov copies at the control-flow join).
 #pragma unroll
-            for (int r = 0; r < 16; ++r) knn_insert<KMAX>(lv, li, pd[r] > lv[KMAX - 1] ? pd[r] : -INFINITY, 0);
+            for (int r = 0; r < 16; ++r) knn_insert_values<KMAX>(lv, pd[r] > lv[KMAX - 1] ? pd[r] : -INFINITY);   // NaN padding -> -inf
         }
     }
     // k-th best of my half; the larger of the two halves' values is reached by >= k candidates overall
@@ -449,11 +489,17 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __re
     int stat_adm = 0, stat_it = 0, stat_pass = 0;   // diagnostics (dbg&64): admissions of this lane, drain iterations / passing tiles of the wave
     auto drain = [&]() {
         stat_adm += cnt;
-        for (int e = 0; __any(e < cnt); ++e) {   // uniform trip count = the fullest queue of the wave
+        // uniform trip count = the fullest queue of the wave, computed ONCE: a counted loop keeps the lists in place
+        // (with `__any(e < cnt)` as the loop condition every iteration carried 160 register copies)
+        int nmax = cnt;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, __shfl_xor(nmax, m, 64));
+        nmax = __builtin_amdgcn_readfirstlane(nmax);
+        for (int e = 0; e < nmax; ++e) {
             ++stat_it;
             const float2 ent = myq[(e < cnt ? e : 0) * 64];
             const float pv = (e < cnt && ent.x > lv[KMAX - 1]) ? ent.x : -INFINITY;   // -inf: no-op insert (branch-free)
-            knn_insert<KMAX>(lv, li, pv, __float_as_int(ent.y));                       // FIFO => j ascending
+            knn_insert_inplace<KMAX>(lv, li, pv, __float_as_int(ent.y));               // FIFO => j ascending
         }
         cnt = 0;
     };
