@@ -47,13 +47,17 @@ const char* lpd_last_error(void);
  *   x      [B][C][N] channel-major (exactly the reference's argument layout)
  *   idx    [B][N][k] int32, the k largest pd = -|x_i - x_j|^2 (reference arithmetic order, see
  *          csrc/lpd_knn.hip), descending; self is included; ties -> lower index first.
- *   ws     workspace of B*N*(1 + 2*CP) floats, CP = 2 for C <= 4, 32 for C <= 64, 0 beyond: per-point sums of squares
- *          followed by the packed MFMA operand image xp[b][n][h][s] = x[b][2s+h][n]
- *   impl   0 = f32-MFMA distance tiles + queued selection (product path); 1 = VALU fmaf cross-check (k <= 20);
- *          2 = first-generation MFMA kernel with in-scan insertion (kept for A/B timing)
+ *   ws     workspace of lpd_knn_workspace_floats(B, C, N, k) floats: per-point sums of squares, the packed MFMA operand
+ *          image xp[b][n][h][s] = x[b][2s+h][n], and (best-first path) per-tile centroids / radii / visiting orders
+ *   impl   0 = product path: f32-MFMA distance tiles + queued selection; best-first tile order with exact skip bounds for
+ *          N <= 4096, k <= 20, C <= 64, ascending scan otherwise; 4 = ascending scan forced (A/B timing);
+ *          1 = VALU fmaf cross-check (k <= 20); 2 = first-generation MFMA kernel with in-scan insertion
  * Supported: C <= 256, k <= 64, k <= N.  Bit-exact vs the reference CPU path on tie-free rows.
  */
 int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* ws, int impl, void* stream);
+long long lpd_knn_workspace_floats(int B, int C, int N, int k);
+/* The same on point-major rows x_pm [B*N][ld] (the pipeline's activation layout; C <= 64, k <= 32): no transposes. */
+int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k, int32_t* idx, float* ws, int impl, void* stream);
 
 /*
  * Dense fp32 GEMM with fused epilogue:  C = act((A.B + bias) * scale + shift), per output column.

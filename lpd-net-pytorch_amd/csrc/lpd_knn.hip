@@ -337,6 +337,58 @@ __global__ void knn_pack_kernel(const float* __restrict__ x, float* __restrict__
         }
 }
 
+// Point-major input ([B*N][ld] rows, the layout the rest of the pipeline uses): squared norms (same summation order as
+// knn_sumsq_kernel) and the packed operand image in one pass, one thread per point, no transposes.
+template <int CP>
+__global__ void knn_prep_pm_kernel(const float* __restrict__ xpm, int ld, float* __restrict__ xx, float* __restrict__ xp, int C,
+                                   long long M)
+{
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float* row = xpm + m * ld;
+    float v[2 * CP];
+    if constexpr (CP == 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = c < C ? row[c] : 0.0f;
+    } else {
+        const bool vec = (ld & 3) == 0 && (C & 3) == 0;
+#pragma unroll
+        for (int g = 0; g < 2 * CP / 4; ++g) {
+            if (vec && 4 * g < C) {
+                const float4 t = *reinterpret_cast<const float4*>(row + 4 * g);
+                v[4 * g] = t.x; v[4 * g + 1] = t.y; v[4 * g + 2] = t.z; v[4 * g + 3] = t.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g + e] = (4 * g + e < C) ? row[4 * g + e] : 0.0f;
+            }
+        }
+    }
+    float total = 0.0f;
+#pragma unroll
+    for (int c0 = 0; c0 < 2 * CP; c0 += 16) {
+        if (c0 < C) {
+            float acc = __fmul_rn(v[c0], v[c0]);
+#pragma unroll
+            for (int c = c0 + 1; c < c0 + 16 && c < 2 * CP; ++c)
+                if (c < C) acc = __fadd_rn(acc, __fmul_rn(v[c], v[c]));
+            total = (c0 == 0) ? acc : __fadd_rn(total, acc);
+        }
+    }
+    xx[m] = total;
+    float* dst = xp + m * (2 * CP);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int s4 = 0; s4 < CP; s4 += (CP >= 4 ? 4 : CP)) {
+            if constexpr (CP >= 4) {
+                *reinterpret_cast<float4*>(dst + h * CP + s4) =
+                    make_float4(v[2 * s4 + h], v[2 * (s4 + 1) + h], v[2 * (s4 + 2) + h], v[2 * (s4 + 3) + h]);
+            } else {
+                *reinterpret_cast<float2*>(dst + h * CP) = make_float2(v[h], v[2 + h]);
+            }
+        }
+}
+
 // operand column of point j (clamped to N-1: padded candidates are neutralised through xx = NaN)
 template <int CP>
 __device__ __forceinline__ void knn3_ld_ops(const float* __restrict__ xpb, int N, int j, int h, float (&a)[CP])
@@ -770,6 +822,328 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void knn6_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Best-first kNN (product path for N <= 4096, k <= 20, C <= 64).
+//
+// The ascending scan above computes all N/32 distance tiles of every wave and rejects ~75 % of them afterwards; its
+// lanes with a poor admission threshold (queries at Z-curve jumps) insert ~K ln(N/K) candidates and set the trip count
+// of every queue drain.  Here each wave (32 queries = tile W of the Z-ordered cloud)
+//   * knows, per candidate tile T (32 consecutive points: centroid c_T, radius r_T from a tiny pre-pass), an UPPER bound
+//     of pd for each of its queries: ub[i][T] = -(max(0, |x_i - c_T| - r_T))^2 (+ fp32 slack), computed for all T by four
+//     MFMA tiles against the 128 centroids and kept in LDS as bf16 (rounded up);
+//   * visits the tiles in order of increasing centroid distance (order[W][*] from the pre-pass): the nearest tiles fill
+//     the lists at once, so the k-th-best thresholds are tight from the third tile on;
+//   * skips a tile, before loading or multiplying anything, when no query of the wave can gain from it
+//     (ub[i][T] < threshold_i for all i): one LDS read, a compare and a wave vote.
+// Exactness: a tile is skipped only if every pd in it is provably below the thresholds (the slack covers the rounding
+// of the fp32 pd evaluation), so the admitted SET equals that of the full scan.  The visiting order is no longer
+// ascending in j, which only matters for exact value ties (the lists rank a later arrival after equal values): every
+// insertion also compares for equality, and a wave that saw a tie is re-done by the ascending kernel (repair pass,
+// normally empty), whose FIFO order gives the reference's lower-index-first rule.
+// ---------------------------------------------------------------------------------------------
+constexpr bool KNN7_DEFAULT = false;   // impl 0 takes the ascending kernel; the best-first kernel is impl 6 (5: statistics)
+constexpr int KNN7_QCAP = 24;      // queue slots per lane
+constexpr int KNN7_MAXT = 128;     // candidate tiles per cloud (N <= 4096)
+constexpr int KNN7_WAVE_LDS = KNN7_MAXT * 32 * 2 + KNN7_QCAP * 64 * 8;   // bf16 bound table + queue = 20 KiB per wave
+
+// tile statistics: centroid (packed operand layout), |c|^2, radius (inflated), max |x|^2.  One wave per tile.
+template <int CP>
+__global__ __launch_bounds__(64) void knn7_tile_stats_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
+                                                            float* __restrict__ cenp, float* __restrict__ cnorm,
+                                                            float* __restrict__ rad, float* __restrict__ txmax, int N, int nt)
+{
+    constexpr int CH = 2 * CP;
+    __shared__ float cen[CH];
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cnt = min(32, N - t * 32);
+    const float* base = xp + ((size_t)b * N + (size_t)t * 32) * CH;
+    for (int c = tid; c < CH; c += 64) {
+        float sum = 0.f;
+        for (int i = 0; i < cnt; ++i) sum += base[(size_t)i * CH + c];
+        const float m = sum / (float)cnt;
+        cen[c] = m;
+        cenp[((size_t)b * nt + t) * CH + c] = m;
+    }
+    __syncthreads();
+    float d2 = 0.f, nx = 0.f, cn = 0.f;
+    if (tid < cnt) {
+        for (int c = 0; c < CH; ++c) {
+            const float d = base[(size_t)tid * CH + c] - cen[c];
+            d2 = fmaf(d, d, d2);
+        }
+        nx = xx[(size_t)b * N + t * 32 + tid];
+    }
+    for (int c = tid; c < CH; c += 64) cn = fmaf(cen[c], cen[c], cn);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        d2 = fmaxf(d2, __shfl_xor(d2, m, 64));
+        nx = fmaxf(nx, __shfl_xor(nx, m, 64));
+        cn += __shfl_xor(cn, m, 64);
+    }
+    if (tid == 0) {
+        rad[(size_t)b * nt + t] = sqrtf(d2) * 1.0001f + 1e-30f;   // upper bound of max |x_i - c| (the fmaf chain is good to ~1e-6)
+        cnorm[(size_t)b * nt + t] = cn;
+        txmax[(size_t)b * nt + t] = nx;
+    }
+}
+
+// order[W][s]: candidate tiles sorted by centroid distance from tile W (bitonic sort of 128 (distance, tile) keys in LDS)
+__global__ __launch_bounds__(KNN7_MAXT) void knn7_tile_order_kernel(const float* __restrict__ cenp, uint16_t* __restrict__ order,
+                                                                   int CH, int nt)
+{
+    __shared__ float key[KNN7_MAXT];
+    __shared__ int val[KNN7_MAXT];
+    const int W = blockIdx.x, b = blockIdx.y, T = threadIdx.x;
+    float d2 = INFINITY;
+    if (T < nt) {
+        const float* cw = cenp + ((size_t)b * nt + W) * CH;
+        const float* ct = cenp + ((size_t)b * nt + T) * CH;
+        d2 = 0.f;
+        for (int c = 0; c < CH; ++c) {
+            const float d = cw[c] - ct[c];
+            d2 = fmaf(d, d, d2);
+        }
+        if (T == W) d2 = -1.0f;   // the wave's own tile first
+    }
+    key[T] = d2;
+    val[T] = T;
+    __syncthreads();
+    for (int size = 2; size <= KNN7_MAXT; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int partner = T ^ stride;
+            if (partner > T) {
+                const bool up = (T & size) == 0;
+                const float ka = key[T], kb = key[partner];
+                const int va = val[T], vb = val[partner];
+                const bool a_after_b = (ka > kb) || (ka == kb && va > vb);
+                if (a_after_b == up) { key[T] = kb; key[partner] = ka; val[T] = vb; val[partner] = va; }
+            }
+            __syncthreads();
+        }
+    if (T < nt) order[((size_t)b * nt + W) * nt + T] = (uint16_t)val[T];
+}
+
+// in-place insertion with the full comparator (value descending, index ascending): the best-first visiting order is
+// not ascending in j, and exact value ties are common at wave granularity (pd is quantised at ulp(|x|^2), ~1e5 levels
+// across a top-20 range, so ~1 % of the queries see one).  An element ranks before the candidate when its value is
+// larger, or equal with a smaller index; the value list itself does not depend on the order among equals (med3).
+template <int KMAX>
+__device__ __forceinline__ void knn7_insert(float (&v)[KMAX], int (&id)[KMAX], float x, int j)
+{
+    unsigned long long cc, cp, eq, lt;
+    int ti;
+    asm volatile("v_cmp_gt_f32_e64 %[cc], %[vs], %[x]\n\t"
+                 "v_cmp_eq_f32_e64 %[eq], %[vs], %[x]\n\t"
+                 "v_cmp_lt_i32_e64 %[lt], %[is], %[j]\n\t"
+                 "s_and_b64 %[eq], %[eq], %[lt]\n\t"
+                 "s_or_b64 %[cc], %[cc], %[eq]"
+                 : [cc] "=&s"(cc), [eq] "=&s"(eq), [lt] "=&s"(lt)
+                 : [vs] "v"(v[KMAX - 1]), [is] "v"(id[KMAX - 1]), [x] "v"(x), [j] "v"(j)
+                 : "scc");
+#pragma unroll
+    for (int s = KMAX - 1; s >= 1; --s) {
+        asm volatile(
+            "v_cmp_gt_f32_e64 %[cp], %[vp], %[x]\n\t"
+            "v_cmp_eq_f32_e64 %[eq], %[vp], %[x]\n\t"
+            "v_cmp_lt_i32_e64 %[lt], %[ip], %[j]\n\t"
+            "v_med3_f32 %[vs], %[vp], %[vs], %[x]\n\t"
+            "s_and_b64 %[eq], %[eq], %[lt]\n\t"
+            "s_or_b64 %[cp], %[cp], %[eq]\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32_e64 %[ti], %[ip], %[j], %[cp]\n\t"
+            "v_cndmask_b32_e64 %[is], %[ti], %[is], %[cc]"
+            : [vs] "+v"(v[s]), [is] "+v"(id[s]), [cp] "=&s"(cp), [eq] "=&s"(eq), [lt] "=&s"(lt), [ti] "=&v"(ti)
+            : [vp] "v"(v[s - 1]), [ip] "v"(id[s - 1]), [x] "v"(x), [j] "v"(j), [cc] "s"(cc)
+            : "scc");
+        cc = cp;
+    }
+    asm volatile(
+        "v_cndmask_b32_e64 %[i0], %[j], %[i0], %[cc]\n\t"
+        "v_max_f32 %[v0], %[v0], %[x]"
+        : [v0] "+v"(v[0]), [i0] "+v"(id[0])
+        : [x] "v"(x), [j] "v"(j), [cc] "s"(cc));
+}
+
+template <int CP, int KMAX>
+__global__ __launch_bounds__(KNN3_THREADS, 2) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
+                                                             const float* __restrict__ cenp, const float* __restrict__ cnorm,
+                                                             const float* __restrict__ rad, const float* __restrict__ txmax,
+                                                             const uint16_t* __restrict__ order, int32_t* __restrict__ idx,
+                                                             int N, int k, int nt, int C, int blocks_per_cloud, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem7[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too
+    const int h = lane >> 5;
+    const int col = lane & 31;
+    const int vb = lpd_xcd_remap(blockIdx.x, gridDim.x);
+    const int b = vb / blocks_per_cloud;
+    const int qb = vb - b * blocks_per_cloud;
+    const int q0 = qb * (KNN3_WAVES * 32) + wave * 32;
+    const int W = q0 >> 5;
+    const bool wave_ok = q0 < N;                 // the last block of a cloud may hold waves without queries
+    const int q = q0 + col;
+    const bool q_ok = q < N;
+    const float* xpb = xp + (size_t)b * N * (2 * CP);
+    const float* xxb = xx + (size_t)b * N;
+    const float* cenb = cenp + (size_t)b * nt * (2 * CP);
+    const float* cnb = cnorm + (size_t)b * nt;
+    const float* radb = rad + (size_t)b * nt;
+    const bool vec_ok = (N & 3) == 0;
+    const bool vec_ok_t = (nt & 3) == 0;
+    uint16_t* ubt = reinterpret_cast<uint16_t*>(smem7 + (size_t)wave * KNN7_WAVE_LDS);                    // [MAXT][32]
+    float2* myq = reinterpret_cast<float2*>(smem7 + (size_t)wave * KNN7_WAVE_LDS + KNN7_MAXT * 32 * 2) + lane;   // slot s at myq[s*64]
+
+    float qreg[CP];
+    knn3_ld_ops<CP>(xpb, N, q, h, qreg);
+    const float xq = xxb[min(q, N - 1)];
+
+    // slack of the fp32 pd evaluation: |pd_computed - pd_true| <= E0 (fma chain of C terms, squared norms, two final ops;
+    // (|x| + |y|)^2 <= 4 max|x|^2)
+    float smax = 0.f;
+    for (int t = lane; t < nt; t += 64) smax = fmaxf(smax, txmax[(size_t)b * nt + t]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) smax = fmaxf(smax, __shfl_xor(smax, m, 64));
+    const float E0 = 8.0f * (float)(C + 8) * 1.1920929e-7f * smax + 1e-30f;
+
+    float a[CP];
+    float4 x4[4];
+    float pd[16];
+
+    // ---- bound table: pd of every query against every tile centroid (the centroids are a 'cloud' of nt points) ----
+    if (wave_ok) {
+        const int nct = (nt + 31) / 32;
+        for (int ct = 0; ct < nct; ++ct) {
+            float4 r4[4];
+            knn3_ld_ops<CP>(cenb, nt, ct * 32 + col, h, a);
+            knn3_ld_xx(cnb, nt, ct * 32, h, vec_ok_t, x4);
+            knn3_ld_xx(radb, nt, ct * 32, h, vec_ok_t, r4);
+            knn3_tile<CP>(a, x4, qreg, xq, cenb, cnb, nt, 0, false, col, h, vec_ok_t, pd);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int T = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float4 rv = r4[r >> 2];
+                const float rT = (r & 3) == 0 ? rv.x : (r & 3) == 1 ? rv.y : (r & 3) == 2 ? rv.z : rv.w;
+                const float dq = sqrtf(fmaxf(-pd[r] - E0, 0.0f)) * 0.99999f;    // lower bound of |x_i - c_T|
+                const float lb = fmaxf(dq - rT, 0.0f);
+                const float ub = -(lb * lb) * 0.99999f + E0;                     // upper bound of every computed pd in tile T
+                uint32_t bits = __float_as_uint(ub);
+                bits = (ub <= 0.0f) ? (bits >> 16) : 0x7f80u;                    // truncation rounds a negative value up; else +inf
+                if (T < nt) ubt[T * 32 + col] = (uint16_t)bits;
+            }
+        }
+    }
+
+    float lv[KMAX];
+    int li[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        lv[s] = -INFINITY;
+        li[s] = 0x7fffffff;
+    }
+    float thrv = q_ok ? -INFINITY : INFINITY;   // k-th best so far (admission + skip threshold); padded queries admit nothing
+    int cnt = 0;
+    int stat_tiles = 0, stat_it = 0, stat_adm = 0, stat_drains = 0;   // diagnostics (dbg): visited tiles, drain iterations, admitted, drains
+
+    // visiting order of this wave: lane l holds entries l and l + 64
+    const uint16_t* ord = order + ((size_t)b * nt + (wave_ok ? W : 0)) * nt;
+    const int ord0 = lane < nt ? ord[lane] : 0;
+    const int ord1 = lane + 64 < nt ? ord[lane + 64] : 0;
+    int spos = 0;
+    auto find_next = [&]() -> int {   // next tile in order that some query of the wave can still gain from; -1 at the end
+        while (spos < nt) {
+            const int T = spos < 64 ? __builtin_amdgcn_readlane(ord0, spos) : __builtin_amdgcn_readlane(ord1, spos - 64);
+            ++spos;
+            const float ub = __uint_as_float((uint32_t)ubt[T * 32 + col] << 16);
+            if (__any(ub >= thrv)) return T;
+        }
+        return -1;
+    };
+    auto drain = [&]() {
+        int nmax = cnt;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, __shfl_xor(nmax, m, 64));
+        nmax = __builtin_amdgcn_readfirstlane(nmax);
+        stat_it += nmax; stat_adm += cnt; ++stat_drains;
+        for (int e = 0; e < nmax; ++e) {
+            const float2 ent = myq[(e < cnt ? e : 0) * 64];
+            const float pv = (e < cnt && ent.x >= lv[KMAX - 1]) ? ent.x : -INFINITY;   // -inf: no-op insert (branch-free)
+            knn7_insert<KMAX>(lv, li, pv, __float_as_int(ent.y));
+        }
+        cnt = 0;
+        // Threshold of the QUERY, not of this half: the two half-lanes of a query each keep a top-K of their own 16 rows
+        // per tile.  The query's K-th best is at least either half's K-th best, and at least the smaller of the two
+        // ceil(K/2)-th bests (then both halves hold ceil(K/2) candidates >= it).  With neighbours split about evenly
+        // between the halves the latter is close to the true K-th best, and it exists after the first tile.
+        constexpr int HALF = (KMAX + 1) / 2;
+        const float tK = lv[KMAX - 1], tH = lv[HALF - 1];
+        const float pK = __shfl_xor(tK, 32, 64), pH = __shfl_xor(tH, 32, 64);
+        const float thr = fmaxf(fmaxf(tK, pK), fminf(tH, pH));
+        thrv = q_ok ? thr : INFINITY;
+    };
+
+    int cur = wave_ok ? find_next() : -1;
+    int nxt = cur >= 0 ? find_next() : -1;
+    if (cur >= 0) {
+        knn3_ld_ops<CP>(xpb, N, cur * 32 + col, h, a);
+        knn3_ld_xx(xxb, N, cur * 32, h, vec_ok, x4);
+    }
+    while (cur >= 0) {
+        ++stat_tiles;
+        knn3_tile<CP>(a, x4, qreg, xq, xpb, xxb, N, (nxt >= 0 ? nxt : 0) * 32, nxt >= 0, col, h, vec_ok, pd);
+        float mx = fmaxf(fmaxf(fmaxf(pd[0], pd[1]), fmaxf(pd[2], pd[3])), fmaxf(fmaxf(pd[4], pd[5]), fmaxf(pd[6], pd[7])));
+        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(pd[8], pd[9]), fmaxf(pd[10], pd[11])), fmaxf(fmaxf(pd[12], pd[13]), fmaxf(pd[14], pd[15]))));
+        if (__any(mx >= thrv)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (pd[r] >= thrv) {   // ties with the k-th best are admitted: the list decides (NaN padding never passes)
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    myq[cnt * 64] = make_float2(pd[r], __int_as_float(cur * 32 + row));
+                    ++cnt;
+                }
+            }
+            if (__any(cnt > KNN7_QCAP - 16)) drain();
+        }
+        cur = nxt;
+        nxt = cur >= 0 ? find_next() : -1;
+    }
+    drain();
+    // ---- merge the two half-lists (same as the ascending kernel); region: this wave's table + queue (20 KiB >= 64*KMAX*8) ----
+    float* mv = reinterpret_cast<float*>(smem7 + (size_t)wave * KNN7_WAVE_LDS);
+    int* mi = reinterpret_cast<int*>(mv + 64 * KMAX);
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        mv[lane * KMAX + s] = lv[s];
+        mi[lane * KMAX + s] = li[s];
+    }
+    __syncthreads();
+    if (dbg && q_ok) {   // diagnostics instead of indices
+        int32_t* o = idx + ((size_t)b * N + q) * k;
+        if (h == 0) { o[0] = stat_tiles; o[1] = stat_it; o[2] = stat_adm; o[3] = stat_drains; }
+        else o[4] = stat_adm;
+    } else
+    if (h == 0 && q_ok) {
+        const float* av = mv + lane * KMAX;
+        const int* ai = mi + lane * KMAX;
+        const float* bv = mv + (lane + 32) * KMAX;
+        const int* bi = mi + (lane + 32) * KMAX;
+        int pa = 0, pb = 0;
+        int32_t* out = idx + ((size_t)b * N + q) * k;
+        for (int s = 0; s < k; ++s) {
+            bool take_a;
+            if (pa >= KMAX) take_a = false;
+            else if (pb >= KMAX) take_a = true;
+            else {
+                const float va = av[pa], vb2 = bv[pb];
+                take_a = (va > vb2) || (va == vb2 && ai[pa] < bi[pb]);
+            }
+            if (take_a) out[s] = ai[pa++];
+            else out[s] = bi[pb++];
+        }
+    }
+}
+
 template <int CP, int KMAX>
 int knn6_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream)
 {
@@ -790,14 +1164,50 @@ int knn3_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
     static_assert(KNN3_QCAP * 128 >= 2 * 64 * KMAX, "merge region must fit the wave's queue region");
     // packed operands live behind the squared norms in the caller's workspace: [xx: B*N][xp: B*N*2*CP]
     float* xp = const_cast<float*>(xx) + (size_t)B * N;
-    hipLaunchKernelGGL(knn_pack_kernel<CP>, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xp, C, N);
-    LPD_CHECK_LAUNCH("lpd_knn(pack)");
+    if (x) {   // x == nullptr: already packed (point-major entry)
+        hipLaunchKernelGGL(knn_pack_kernel<CP>, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xp, C, N);
+        LPD_CHECK_LAUNCH("lpd_knn(pack)");
+    }
     size_t lds = (size_t)KNN3_WAVES * KNN3_QCAP * 64 * sizeof(float2);
     const int bpc = (N + KNN3_WAVES * 32 - 1) / (KNN3_WAVES * 32);
     auto kern = knn3_kernel<CP, KMAX>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(KNN3_THREADS), lds, stream, (const float*)xp, xx, idx, N, k, bpc, dbg);
     LPD_CHECK_LAUNCH("lpd_knn");
+    return LPD_OK;
+}
+
+// workspace behind [xx | xp]: centroids, |c|^2, radii, max |x|^2, visiting orders, repair list
+inline size_t knn7_extra_floats(int B, int N, int CP)
+{
+    const size_t nt = (size_t)(N + 31) / 32;
+    return (size_t)B * nt * (2 * CP + 3) + ((size_t)B * nt * nt + 1) / 2 + (size_t)B * nt + 8;
+}
+
+template <int CP, int KMAX>
+int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg = 0)
+{
+    static_assert(KNN7_WAVE_LDS >= 64 * KMAX * 8, "merge region must fit the wave's LDS region");
+    const int nt = (N + 31) / 32;
+    float* xp = const_cast<float*>(xx) + (size_t)B * N;
+    float* cenp = xp + (size_t)B * N * 2 * CP;
+    float* cnorm = cenp + (size_t)B * nt * 2 * CP;
+    float* rad = cnorm + (size_t)B * nt;
+    float* txmax = rad + (size_t)B * nt;
+    uint16_t* order = reinterpret_cast<uint16_t*>(txmax + (size_t)B * nt);   // [B][nt][nt]
+    if (x) hipLaunchKernelGGL(knn_pack_kernel<CP>, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xp, C, N);
+    hipLaunchKernelGGL(knn7_tile_stats_kernel<CP>, dim3(nt, B), dim3(64), 0, stream, (const float*)xp, xx, cenp, cnorm, rad, txmax, N, nt);
+    hipLaunchKernelGGL(knn7_tile_order_kernel, dim3(nt, B), dim3(KNN7_MAXT), 0, stream, (const float*)cenp, order, 2 * CP, nt);
+    LPD_CHECK_LAUNCH("lpd_knn(tile pre-pass)");
+    const int bpc = (N + KNN3_WAVES * 32 - 1) / (KNN3_WAVES * 32);
+    {
+        size_t lds = (size_t)KNN3_WAVES * KNN7_WAVE_LDS;
+        auto kern = knn7_kernel<CP, KMAX>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(KNN3_THREADS), lds, stream, (const float*)xp, xx, (const float*)cenp,
+                           (const float*)cnorm, (const float*)rad, (const float*)txmax, (const uint16_t*)order, idx, N, k, nt, C, bpc, dbg);
+        LPD_CHECK_LAUNCH("lpd_knn(best-first)");
+    }
     return LPD_OK;
 }
 
@@ -854,6 +1264,16 @@ int knn_dispatch_k(const float* x, const float* xx, int32_t* idx, int B, int C, 
 
 }  // namespace
 
+extern "C" long long lpd_knn_workspace_floats(int B, int C, int N, int k)
+{
+    (void)k;
+    if (B <= 0 || C <= 0 || N <= 0) return 0;
+    const int cp = C <= 4 ? 2 : (C <= 64 ? 32 : 0);
+    long long n = (long long)B * N * (1 + 2 * cp);
+    if (cp) n += (long long)knn7_extra_floats(B, N, cp);   // tile statistics / visiting orders / repair list of the best-first path
+    return n;
+}
+
 extern "C" int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* xx_ws, int impl,
                        void* stream_)
 {
@@ -864,7 +1284,11 @@ extern "C" int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
     LPD_CHECK_ARG(B <= 65535, "lpd_knn: B=%d exceeds grid.y", B);
     hipLaunchKernelGGL(knn_sumsq_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xx_ws, C, N);
     LPD_CHECK_LAUNCH("lpd_knn(sumsq)");
-    if (impl == 0) {
+    if (((impl == 0 && KNN7_DEFAULT) || impl == 5 || impl == 6) && k <= 20 && C <= 64 && N <= KNN7_MAXT * 32) {   // best-first (5: statistics)
+        if (C <= 4) return knn7_launch<2, 20>(x, xx_ws, idx, B, C, N, k, stream, impl == 5);
+        return knn7_launch<32, 20>(x, xx_ws, idx, B, C, N, k, stream, impl == 5);
+    }
+    if (impl == 0 || impl == 4) {   // ascending scan (larger clouds, k > 20; impl 4: forced, for A/B timing)
         if (C <= 4) return knn3_dispatch_k<2>(x, xx_ws, idx, B, C, N, k, stream);
         if (C <= 64) return knn3_dispatch_k<32>(x, xx_ws, idx, B, C, N, k, stream);
         if (C <= 256) return knn_dispatch_k<128>(x, xx_ws, idx, B, C, N, k, 0, stream);   // wide features: v1
@@ -882,4 +1306,27 @@ extern "C" int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
     }
     lpd_set_error("lpd_knn: C=%d > 256 unsupported", C);
     return LPD_ERR_UNSUPPORTED;
+}
+
+// Point-major entry: x_pm [B*N][ld] rows (C <= 64 channels used).  Same results as lpd_knn on the transposed input; skips
+// the channel-major round trip (transpose + pack) that the pipeline would otherwise pay for each graph.
+extern "C" int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k, int32_t* idx, float* ws, int impl, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(x_pm && idx && ws, "lpd_knn_pm: null pointer");
+    LPD_CHECK_ARG(B > 0 && C > 0 && N > 0 && ld >= C, "lpd_knn_pm: bad dims B=%d C=%d N=%d ld=%d", B, C, N, ld);
+    LPD_CHECK_ARG(k > 0 && k <= N, "lpd_knn_pm: need 0 < k <= N (k=%d N=%d)", k, N);
+    LPD_CHECK_ARG(C <= 64 && k <= 32, "lpd_knn_pm: built for C <= 64, k <= 32 (got C=%d k=%d); use lpd_knn on the channel-major tensor", C, k);
+    LPD_CHECK_ARG(C <= 4 || ((uintptr_t)x_pm & 15) == 0, "lpd_knn_pm: x_pm must be 16-byte aligned");
+    const long long M = (long long)B * N;
+    float* xp = ws + M;
+    if (C <= 4) hipLaunchKernelGGL(knn_prep_pm_kernel<2>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);
+    else hipLaunchKernelGGL(knn_prep_pm_kernel<32>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);
+    LPD_CHECK_LAUNCH("lpd_knn_pm(prep)");
+    if ((impl == 0 || impl == 5) && k <= 20 && N <= KNN7_MAXT * 32 && KNN7_DEFAULT) {
+        if (C <= 4) return knn7_launch<2, 20>(nullptr, ws, idx, B, C, N, k, stream, impl == 5);
+        return knn7_launch<32, 20>(nullptr, ws, idx, B, C, N, k, stream, impl == 5);
+    }
+    if (C <= 4) return knn3_dispatch_k<2>(nullptr, ws, idx, B, C, N, k, stream);
+    return knn3_dispatch_k<32>(nullptr, ws, idx, B, C, N, k, stream);
 }

@@ -336,7 +336,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         w2d = engine._w2d
         xyz = x.view(M, 3)
         f0, front = _Front.fwd(net, xyz, w2d(net.conv1_lpd), net.bn1_lpd, w2d(net.conv2_lpd), net.bn2_lpd, B, N, act, slope)
-        idx_f = ops.knn(ops.transpose(f0.view(B, N, 64)), k)
+        idx_f = engine._knn_rows(f0, B, N, 64, k)
         cat = torch.empty((M, 512), dtype=torch.float32, device=x.device)
         # DG1 (split projection, materialised edges)
         wcat1 = engine.split_edge_weight(net.convDG1, "cat_nc")
@@ -350,7 +350,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         stg2 = ops.bn_train_stats(z, net.convDG2[1])
         arg2 = ops.group_max(z, k, stg2.scale, stg2.shift, act, slope, cat[:, 128:256])           # x2
         # SN1 on the xyz graph
-        idx_x = ops.knn(ops.transpose(x.view(B, N, 3)), k)
+        idx_x = engine._knn_rows(x.view(B * N, 3), B, N, 3, k)
         wcat3 = engine.split_edge_weight(net.convSN1, "cat_nc")
         pq3 = ops.linear(cat[:, 128:256], wcat3)                                # [M,512]
         u3 = ops.edge_build(pq3[:, :256], pq3[:, 256:], idx_x, N)               # [E,256] raw
@@ -471,12 +471,12 @@ class _LPDNetOrignTrainFn(torch.autograd.Function):
         f0, S["front"] = _Front.fwd(net, xyz, w2d(net.conv1_lpd[0]), net.conv1_lpd[1], w2d(net.conv2_lpd[0]), net.conv2_lpd[1],
                                     B, N, act, slope)
         S["f0"] = f0
-        idx_f = ops.knn(ops.transpose(f0.view(B, N, 64)), k)
+        idx_f = engine._knn_rows(f0, B, N, 64, k)
         wcat1 = engine.split_edge_weight(net.convDG1, "cat_cd")
         pq1 = ops.linear(f0, wcat1)                                               # [M,128] = [P | Q]
         g = torch.empty((M, 64), dtype=torch.float32, device=x.device)
         S["dg"] = _EdgeChain.fwd(pq1, 64, True, idx_f, N, k, net.convDG1[1], w2d(net.convDG2[0]), net.convDG2[1], act, slope, g)
-        idx_x = ops.knn(ops.transpose(x.view(B, N, 3)), k)
+        idx_x = engine._knn_rows(x.view(B * N, 3), B, N, 3, k)
         wsn1 = engine.split_edge_weight(net.convSN1, "nbr")
         pn = ops.linear(g, wsn1)                                                  # [M,64] neighbours only
         h = torch.empty((M, 64), dtype=torch.float32, device=x.device)

@@ -147,6 +147,15 @@ def stn3d_eval(net, h, B, N):
 # ------------------------------------------------------------------------------------------------
 # trunks (return point-major features [B*N, E])
 # ------------------------------------------------------------------------------------------------
+def _knn_rows(rows, B, N, C, k):
+    """kNN graph of point-major rows [B*N, C] (util/lpdnet_model.py:317-326): the point-major C-ABI entry when it is built
+    for the shape (C <= 64, k <= 32), else the channel-major one on the transposed tensor."""
+    rows = rows.reshape(B * N, C)
+    if C <= 64 and k <= 32:
+        return ops.knn_pm(rows, B, N, k)
+    return ops.knn(ops.transpose(rows.view(B, N, C).contiguous()), k)
+
+
 def kagg(P, Q, idx, N, *, scale, shift, act, slope, out):
     """K-agg dispatch: the cloud-resident kernel when an 8-channel slice of one cloud fits LDS (N <= 5120) and k = 20,
     the direct gather otherwise (cfg5: N = 16384, k = 64).  Same bits either way."""
@@ -177,7 +186,7 @@ def lpdnet_features_eval(net, x):
             tf = transform_net_eval(net.t_net_fea, f, B, N)
             f = ops.apply_transform(f, tf, N)
     # dynamic graph in feature space
-    idx_f = ops.knn(ops.transpose(f.view(B, N, 64)), k)
+    idx_f = _knn_rows(f, B, N, 64, k)
     cat = torch.empty((M, 512), dtype=torch.float32, device=x.device)                   # [x1 | x2 | x3]
     pq = ops.linear(f, split_edge_weight(net.convDG1, "cat_nc"))                        # [M,256] = [P | Q]
     s1, b1 = bn_affine(net.convDG1[1])
@@ -186,7 +195,7 @@ def lpdnet_features_eval(net, x):
     ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope,
                  out=cat[:, 128:256])
     # static graph in Cartesian space (raw xyz even when t3d, lpdnet_model.py:226,255)
-    idx_x = ops.knn(ops.transpose(x.view(B, N, 3)), k)
+    idx_x = _knn_rows(x.view(B * N, 3), B, N, 3, k)
     pq = ops.linear(cat[:, 128:256], split_edge_weight(net.convSN1, "cat_nc"))          # [M,512]
     s3, b3 = bn_affine(net.convSN1[1])
     kagg(pq[:, :256], pq[:, 256:], idx_x, N, scale=s3, shift=b3, act=act, slope=slope, out=cat[:, 256:512])
@@ -217,12 +226,12 @@ def lpdnet_origin_features_eval(net, x):
         if net.tfea:
             tf = transform_net_eval(net.t_net_fea, f, B, N)
             f = ops.apply_transform(f, tf, N)
-    idx_f = ops.knn(ops.transpose(f.view(B, N, 64)), k)
+    idx_f = _knn_rows(f, B, N, 64, k)
     pq = ops.linear(f, split_edge_weight(net.convDG1, "cat_cd"))                        # [M,128] = [P | Q]
     s1, b1 = bn_affine(net.convDG1[1])
     s2, b2 = bn_affine(net.convDG2[1])
     g = ops.edge_mlp(pq[:, :64], pq[:, 64:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope)
-    idx_x = ops.knn(ops.transpose(x.view(B, N, 3)), k)
+    idx_x = _knn_rows(x.view(B * N, 3), B, N, 3, k)
     pn = ops.linear(g, split_edge_weight(net.convSN1, "nbr"))                           # [M,64] neighbours only
     s1, b1 = bn_affine(net.convSN1[1])
     s2, b2 = bn_affine(net.convSN2[1])

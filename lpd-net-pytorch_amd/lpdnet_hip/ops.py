@@ -69,11 +69,9 @@ def _vec(t, name, n):
 KNN_IMPL = int(__import__("os").environ.get("LPD_KNN_IMPL", "0"))   # A/B switch for benchmarking (0 = product kernel)
 
 
-def knn_workspace_floats(B, C, N):
-    """Workspace of lpd_knn: squared norms [B*N] + the packed MFMA operand image [B*N*2*CP] (CP = 2 for C <= 4,
-    32 for C <= 64; wider features use the first-generation kernel, which needs the norms only)."""
-    cp = 2 if C <= 4 else (32 if C <= 64 else 0)
-    return B * N * (1 + 2 * cp)
+def knn_workspace_floats(B, C, N, k=20):
+    """Workspace of lpd_knn in floats (squared norms, packed MFMA operand image, tile statistics of the best-first path)."""
+    return int(_lib.load().lpd_knn_workspace_floats(B, C, N, k))
 
 
 def knn(x_cm, k, impl=None):
@@ -89,6 +87,22 @@ def knn(x_cm, k, impl=None):
     ws = torch.empty((knn_workspace_floats(B, C, N),), dtype=torch.float32, device=x_cm.device)
     lib = _lib.load()
     _call(f"knn[C={C},k={k}]", lib.lpd_knn, _ptr(x_cm), B, C, N, k, _ptr(idx), _ptr(ws), impl, _stream())
+    return idx
+
+
+def knn_pm(x_pm, B, N, k, impl=None):
+    """kNN on point-major rows x_pm [B*N, C] (C <= 64, k <= 32): same indices as knn() on the transposed tensor, without
+    the transpose + pack round trip."""
+    if impl is None:
+        impl = KNN_IMPL
+    ld = _rows(x_pm, "x_pm")
+    M, C = x_pm.shape
+    if M != B * N:
+        raise ValueError("knn_pm: rows != B*N")
+    idx = torch.empty((B, N, k), dtype=torch.int32, device=x_pm.device)
+    ws = torch.empty((knn_workspace_floats(B, C, N),), dtype=torch.float32, device=x_pm.device)
+    lib = _lib.load()
+    _call(f"knn[C={C},k={k}]", lib.lpd_knn_pm, _ptr(x_pm), ld, B, C, N, k, _ptr(idx), _ptr(ws), impl, _stream())
     return idx
 
 

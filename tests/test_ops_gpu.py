@@ -29,12 +29,14 @@ def _rel(a, b):
 # ------------------------------------------------------------------ kNN
 @pytest.mark.parametrize("C,N,k,B", [(3, 4096, 20, 2), (64, 4096, 20, 2), (3, 100, 7, 3), (5, 333, 20, 2),
                                       (64, 1000, 20, 1), (3, 16384, 64, 1), (130, 512, 32, 1), (3, 64, 64, 1)])
-@pytest.mark.parametrize("impl", [0, 1, 2, 3])
+@pytest.mark.parametrize("impl", [0, 1, 2, 3, 6])
 def test_knn_bit_exact_vs_oracle(cuda, C, N, k, B, impl):
     """impl 0: streaming kernel (MFMA tiles + queued selection); 1: VALU fmaf cross-check; 2: first-generation MFMA kernel;
-    3: LDS-staged stream + admission threshold + queued selection."""
+    3: LDS-staged stream + admission threshold + queued selection; 6: best-first tile order with exact skip bounds."""
     if impl == 1 and (k > 20 or N > 4096):
         pytest.skip("VALU cross-check path is built for k <= 20 and is slow")
+    if impl == 6 and (k > 20 or C > 64 or N > 4096):
+        pytest.skip("the best-first kernel is built for k <= 20, C <= 64, N <= 4096")
     if impl == 3 and (k > 20 or C > 64):
         pytest.skip("impl 3 is built for k <= 20, C <= 64")
     ops = _ops()
@@ -48,6 +50,12 @@ def test_knn_bit_exact_vs_oracle(cuda, C, N, k, B, impl):
     assert bad.sum() == 0, f"{bad.sum()} tie-free rows differ (of {bad.size}); first: {np.argwhere(bad)[:3].tolist()}"
     # tie rows must still hold the right SET of pd values: compare as sets where no boundary tie exists
     assert rows_equal.mean() > 0.99
+    if impl in (0, 6) and C <= 64 and k <= 32:     # point-major entry (no transposes): the same bits, also from a column slice
+        buf = torch.zeros((B * N, C + 5), device=cuda) if C <= 4 else torch.zeros((B * N, 72), device=cuda)
+        off = 0 if C > 4 else 2
+        buf[:, off:off + C] = torch.from_numpy(x_pm.reshape(B * N, C)).to(cuda)
+        got = ops.knn_pm(buf[:, off:off + C], B, N, k, impl=impl).cpu().numpy()
+        assert (got == idx).all()
 
 
 @pytest.mark.parametrize("tag", ["knn_c3_n4096_k20", "knn_c64_n4096_k20", "knn_c3_n16384_k64", "knn_c3_n100_k7"])
