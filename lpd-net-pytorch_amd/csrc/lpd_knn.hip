@@ -841,7 +841,7 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void knn6_kernel(const float* __res
 // insertion also compares for equality, and a wave that saw a tie is re-done by the ascending kernel (repair pass,
 // normally empty), whose FIFO order gives the reference's lower-index-first rule.
 // ---------------------------------------------------------------------------------------------
-constexpr bool KNN7_DEFAULT = false;   // impl 0 takes the ascending kernel; the best-first kernel is impl 6 (5: statistics)
+constexpr bool KNN7_DEFAULT = true;    // impl 0 = best-first where it is built (N <= 4096, k <= 20, C <= 64); 4 forces the ascending kernel
 constexpr int KNN7_QCAP = 24;      // queue slots per lane
 constexpr int KNN7_MAXT = 128;     // candidate tiles per cloud (N <= 4096)
 constexpr int KNN7_WAVE_LDS = KNN7_MAXT * 32 * 2 + KNN7_QCAP * 64 * 8;   // bf16 bound table + queue = 20 KiB per wave
@@ -1047,13 +1047,20 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn7_kernel(const float* __re
     int stat_tiles = 0, stat_it = 0, stat_adm = 0, stat_drains = 0;   // diagnostics (dbg): visited tiles, drain iterations, admitted, drains
 
     // visiting order of this wave: lane l holds entries l and l + 64
-    const uint16_t* ord = order + ((size_t)b * nt + (wave_ok ? W : 0)) * nt;
-    const int ord0 = lane < nt ? ord[lane] : 0;
-    const int ord1 = lane + 64 < nt ? ord[lane + 64] : 0;
+    const uint16_t* ord = order ? order + ((size_t)b * nt + (wave_ok ? W : 0)) * nt : nullptr;
+    const int ord0 = (ord && lane < nt) ? ord[lane] : 0;
+    const int ord1 = (ord && lane + 64 < nt) ? ord[lane + 64] : 0;
     int spos = 0;
     auto find_next = [&]() -> int {   // next tile in order that some query of the wave can still gain from; -1 at the end
-        while (spos < nt) {
-            const int T = spos < 64 ? __builtin_amdgcn_readlane(ord0, spos) : __builtin_amdgcn_readlane(ord1, spos - 64);
+        while (spos < 2 * nt) {
+            int T;
+            if (order) {
+                if (spos >= nt) break;
+                T = spos < 64 ? __builtin_amdgcn_readlane(ord0, spos) : __builtin_amdgcn_readlane(ord1, spos - 64);
+            } else {   // no pre-sorted order: walk outwards along the Z-curve, W, W+1, W-1, W+2, ...
+                T = (spos & 1) ? W + ((spos + 1) >> 1) : W - (spos >> 1);
+                if (T < 0 || T >= nt) { ++spos; continue; }
+            }
             ++spos;
             const float ub = __uint_as_float((uint32_t)ubt[T * 32 + col] << 16);
             if (__any(ub >= thrv)) return T;
@@ -1197,7 +1204,8 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
     uint16_t* order = reinterpret_cast<uint16_t*>(txmax + (size_t)B * nt);   // [B][nt][nt]
     if (x) hipLaunchKernelGGL(knn_pack_kernel<CP>, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xp, C, N);
     hipLaunchKernelGGL(knn7_tile_stats_kernel<CP>, dim3(nt, B), dim3(64), 0, stream, (const float*)xp, xx, cenp, cnorm, rad, txmax, N, nt);
-    hipLaunchKernelGGL(knn7_tile_order_kernel, dim3(nt, B), dim3(KNN7_MAXT), 0, stream, (const float*)cenp, order, 2 * CP, nt);
+    const bool sorted = (dbg & 2) != 0;   // centroid-distance order from the pre-pass instead of the Z-curve walk
+    if (sorted) hipLaunchKernelGGL(knn7_tile_order_kernel, dim3(nt, B), dim3(KNN7_MAXT), 0, stream, (const float*)cenp, order, 2 * CP, nt);
     LPD_CHECK_LAUNCH("lpd_knn(tile pre-pass)");
     const int bpc = (N + KNN3_WAVES * 32 - 1) / (KNN3_WAVES * 32);
     {
@@ -1205,7 +1213,8 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
         auto kern = knn7_kernel<CP, KMAX>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(KNN3_THREADS), lds, stream, (const float*)xp, xx, (const float*)cenp,
-                           (const float*)cnorm, (const float*)rad, (const float*)txmax, (const uint16_t*)order, idx, N, k, nt, C, bpc, dbg);
+                           (const float*)cnorm, (const float*)rad, (const float*)txmax, sorted ? (const uint16_t*)order : (const uint16_t*)nullptr, idx, N, k, nt,
+                           C, bpc, dbg & 1);
         LPD_CHECK_LAUNCH("lpd_knn(best-first)");
     }
     return LPD_OK;
@@ -1284,9 +1293,10 @@ extern "C" int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
     LPD_CHECK_ARG(B <= 65535, "lpd_knn: B=%d exceeds grid.y", B);
     hipLaunchKernelGGL(knn_sumsq_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xx_ws, C, N);
     LPD_CHECK_LAUNCH("lpd_knn(sumsq)");
-    if (((impl == 0 && KNN7_DEFAULT) || impl == 5 || impl == 6) && k <= 20 && C <= 64 && N <= KNN7_MAXT * 32) {   // best-first (5: statistics)
-        if (C <= 4) return knn7_launch<2, 20>(x, xx_ws, idx, B, C, N, k, stream, impl == 5);
-        return knn7_launch<32, 20>(x, xx_ws, idx, B, C, N, k, stream, impl == 5);
+    if (((impl == 0 && KNN7_DEFAULT) || (impl >= 5 && impl <= 8)) && k <= 20 && C <= 64 && N <= KNN7_MAXT * 32) {   // best-first (5: statistics)
+        const int dbg7 = (impl == 5 ? 1 : 0) | (impl == 7 ? 2 : 0) | (impl == 8 ? 3 : 0);   // 7: sorted order, 8: sorted + statistics
+        if (C <= 4) return knn7_launch<2, 20>(x, xx_ws, idx, B, C, N, k, stream, dbg7);
+        return knn7_launch<32, 20>(x, xx_ws, idx, B, C, N, k, stream, dbg7);
     }
     if (impl == 0 || impl == 4) {   // ascending scan (larger clouds, k > 20; impl 4: forced, for A/B timing)
         if (C <= 4) return knn3_dispatch_k<2>(x, xx_ws, idx, B, C, N, k, stream);
@@ -1323,9 +1333,10 @@ extern "C" int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k,
     if (C <= 4) hipLaunchKernelGGL(knn_prep_pm_kernel<2>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);
     else hipLaunchKernelGGL(knn_prep_pm_kernel<32>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);
     LPD_CHECK_LAUNCH("lpd_knn_pm(prep)");
-    if ((impl == 0 || impl == 5) && k <= 20 && N <= KNN7_MAXT * 32 && KNN7_DEFAULT) {
-        if (C <= 4) return knn7_launch<2, 20>(nullptr, ws, idx, B, C, N, k, stream, impl == 5);
-        return knn7_launch<32, 20>(nullptr, ws, idx, B, C, N, k, stream, impl == 5);
+    if (((impl == 0 && KNN7_DEFAULT) || (impl >= 5 && impl <= 8)) && k <= 20 && N <= KNN7_MAXT * 32) {
+        const int dbg7 = (impl == 5 ? 1 : 0) | (impl == 7 ? 2 : 0) | (impl == 8 ? 3 : 0);
+        if (C <= 4) return knn7_launch<2, 20>(nullptr, ws, idx, B, C, N, k, stream, dbg7);
+        return knn7_launch<32, 20>(nullptr, ws, idx, B, C, N, k, stream, dbg7);
     }
     if (C <= 4) return knn3_dispatch_k<2>(nullptr, ws, idx, B, C, N, k, stream);
     return knn3_dispatch_k<32>(nullptr, ws, idx, B, C, N, k, stream);
