@@ -831,15 +831,14 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void knn6_kernel(const float* __res
 //   * knows, per candidate tile T (32 consecutive points: centroid c_T, radius r_T from a tiny pre-pass), an UPPER bound
 //     of pd for each of its queries: ub[i][T] = -(max(0, |x_i - c_T| - r_T))^2 (+ fp32 slack), computed for all T by four
 //     MFMA tiles against the 128 centroids and kept in LDS as bf16 (rounded up);
-//   * visits the tiles in order of increasing centroid distance (order[W][*] from the pre-pass): the nearest tiles fill
-//     the lists at once, so the k-th-best thresholds are tight from the third tile on;
+//   * visits the tiles outwards along the Z-curve (W, W+1, W-1, W+2, ...): the nearest tiles fill the lists at once, so
+//     the k-th-best thresholds are tight from the second tile on (a pre-sorted centroid-distance order visited the same
+//     ~40 of 128 tiles and cost a sort kernel);
 //   * skips a tile, before loading or multiplying anything, when no query of the wave can gain from it
 //     (ub[i][T] < threshold_i for all i): one LDS read, a compare and a wave vote.
 // Exactness: a tile is skipped only if every pd in it is provably below the thresholds (the slack covers the rounding
-// of the fp32 pd evaluation), so the admitted SET equals that of the full scan.  The visiting order is no longer
-// ascending in j, which only matters for exact value ties (the lists rank a later arrival after equal values): every
-// insertion also compares for equality, and a wave that saw a tie is re-done by the ascending kernel (repair pass,
-// normally empty), whose FIFO order gives the reference's lower-index-first rule.
+// of the fp32 pd evaluation), so the admitted SET equals that of the full scan; exact value ties are ranked by index
+// through the interval property of the walk (knn7_insert).
 // ---------------------------------------------------------------------------------------------
 constexpr bool KNN7_DEFAULT = true;    // impl 0 = best-first where it is built (N <= 4096, k <= 20, C <= 64); 4 forces the ascending kernel
 constexpr int KNN7_QCAP = 24;      // queue slots per lane
@@ -887,74 +886,29 @@ __global__ __launch_bounds__(64) void knn7_tile_stats_kernel(const float* __rest
     }
 }
 
-// order[W][s]: candidate tiles sorted by centroid distance from tile W (bitonic sort of 128 (distance, tile) keys in LDS)
-__global__ __launch_bounds__(KNN7_MAXT) void knn7_tile_order_kernel(const float* __restrict__ cenp, uint16_t* __restrict__ order,
-                                                                   int CH, int nt)
-{
-    __shared__ float key[KNN7_MAXT];
-    __shared__ int val[KNN7_MAXT];
-    const int W = blockIdx.x, b = blockIdx.y, T = threadIdx.x;
-    float d2 = INFINITY;
-    if (T < nt) {
-        const float* cw = cenp + ((size_t)b * nt + W) * CH;
-        const float* ct = cenp + ((size_t)b * nt + T) * CH;
-        d2 = 0.f;
-        for (int c = 0; c < CH; ++c) {
-            const float d = cw[c] - ct[c];
-            d2 = fmaf(d, d, d2);
-        }
-        if (T == W) d2 = -1.0f;   // the wave's own tile first
-    }
-    key[T] = d2;
-    val[T] = T;
-    __syncthreads();
-    for (int size = 2; size <= KNN7_MAXT; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const int partner = T ^ stride;
-            if (partner > T) {
-                const bool up = (T & size) == 0;
-                const float ka = key[T], kb = key[partner];
-                const int va = val[T], vb = val[partner];
-                const bool a_after_b = (ka > kb) || (ka == kb && va > vb);
-                if (a_after_b == up) { key[T] = kb; key[partner] = ka; val[T] = vb; val[partner] = va; }
-            }
-            __syncthreads();
-        }
-    if (T < nt) order[((size_t)b * nt + W) * nt + T] = (uint16_t)val[T];
-}
-
-// in-place insertion with the full comparator (value descending, index ascending): the best-first visiting order is
-// not ascending in j, and exact value ties are common at wave granularity (pd is quantised at ulp(|x|^2), ~1e5 levels
-// across a top-20 range, so ~1 % of the queries see one).  An element ranks before the candidate when its value is
-// larger, or equal with a smaller index; the value list itself does not depend on the order among equals (med3).
+// In-place insertion for the best-first kernel.  The tiles are visited W, W+1, W-1, W+2, ...: the set of visited tiles
+// is always an interval around W, so a candidate from a tile above W has a larger index than everything in the list
+// (ranks AFTER equal values: reference rule, lower index first) and one from a tile below W a smaller index than
+// everything (ranks BEFORE equal values; rows of such a tile are queued in descending order).  Both are ONE compare per
+// slot:  element ranks before the candidate  <=>  v >= y,  with y = x (after equals) or y = nextabove(x) (before
+// equals).  x = y = -inf is the no-op.  (Exact value ties are common: pd is quantised at ulp(|x|^2), ~1 % of the
+// queries see one among their admitted candidates.)
 template <int KMAX>
-__device__ __forceinline__ void knn7_insert(float (&v)[KMAX], int (&id)[KMAX], float x, int j)
+__device__ __forceinline__ void knn7_insert(float (&v)[KMAX], int (&id)[KMAX], float x, float y, int j)
 {
-    unsigned long long cc, cp, eq, lt;
+    unsigned long long cc, cp;
     int ti;
-    asm volatile("v_cmp_gt_f32_e64 %[cc], %[vs], %[x]\n\t"
-                 "v_cmp_eq_f32_e64 %[eq], %[vs], %[x]\n\t"
-                 "v_cmp_lt_i32_e64 %[lt], %[is], %[j]\n\t"
-                 "s_and_b64 %[eq], %[eq], %[lt]\n\t"
-                 "s_or_b64 %[cc], %[cc], %[eq]"
-                 : [cc] "=&s"(cc), [eq] "=&s"(eq), [lt] "=&s"(lt)
-                 : [vs] "v"(v[KMAX - 1]), [is] "v"(id[KMAX - 1]), [x] "v"(x), [j] "v"(j)
-                 : "scc");
+    asm volatile("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(cc) : "v"(v[KMAX - 1]), "v"(y));
 #pragma unroll
     for (int s = KMAX - 1; s >= 1; --s) {
         asm volatile(
-            "v_cmp_gt_f32_e64 %[cp], %[vp], %[x]\n\t"
-            "v_cmp_eq_f32_e64 %[eq], %[vp], %[x]\n\t"
-            "v_cmp_lt_i32_e64 %[lt], %[ip], %[j]\n\t"
+            "v_cmp_ge_f32_e64 %[cp], %[vp], %[y]\n\t"
             "v_med3_f32 %[vs], %[vp], %[vs], %[x]\n\t"
-            "s_and_b64 %[eq], %[eq], %[lt]\n\t"
-            "s_or_b64 %[cp], %[cp], %[eq]\n\t"
-            "s_nop 1\n\t"
+            "s_nop 0\n\t"
             "v_cndmask_b32_e64 %[ti], %[ip], %[j], %[cp]\n\t"
             "v_cndmask_b32_e64 %[is], %[ti], %[is], %[cc]"
-            : [vs] "+v"(v[s]), [is] "+v"(id[s]), [cp] "=&s"(cp), [eq] "=&s"(eq), [lt] "=&s"(lt), [ti] "=&v"(ti)
-            : [vp] "v"(v[s - 1]), [ip] "v"(id[s - 1]), [x] "v"(x), [j] "v"(j), [cc] "s"(cc)
-            : "scc");
+            : [vs] "+v"(v[s]), [is] "+v"(id[s]), [cp] "=&s"(cp), [ti] "=&v"(ti)
+            : [vp] "v"(v[s - 1]), [ip] "v"(id[s - 1]), [x] "v"(x), [y] "v"(y), [j] "v"(j), [cc] "s"(cc));
         cc = cp;
     }
     asm volatile(
@@ -968,7 +922,7 @@ template <int CP, int KMAX>
 __global__ __launch_bounds__(KNN3_THREADS, 2) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
                                                              const float* __restrict__ cenp, const float* __restrict__ cnorm,
                                                              const float* __restrict__ rad, const float* __restrict__ txmax,
-                                                             const uint16_t* __restrict__ order, int32_t* __restrict__ idx,
+                                                             int32_t* __restrict__ idx,
                                                              int N, int k, int nt, int C, int blocks_per_cloud, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem7[];
@@ -1046,22 +1000,14 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn7_kernel(const float* __re
     int cnt = 0;
     int stat_tiles = 0, stat_it = 0, stat_adm = 0, stat_drains = 0;   // diagnostics (dbg): visited tiles, drain iterations, admitted, drains
 
-    // visiting order of this wave: lane l holds entries l and l + 64
-    const uint16_t* ord = order ? order + ((size_t)b * nt + (wave_ok ? W : 0)) * nt : nullptr;
-    const int ord0 = (ord && lane < nt) ? ord[lane] : 0;
-    const int ord1 = (ord && lane + 64 < nt) ? ord[lane + 64] : 0;
+    // visiting order: outwards along the Z-curve, W, W+1, W-1, W+2, ... (the visited tiles always form an interval around
+    // W, which is what makes the one-compare insertion exact)
     int spos = 0;
     auto find_next = [&]() -> int {   // next tile in order that some query of the wave can still gain from; -1 at the end
         while (spos < 2 * nt) {
-            int T;
-            if (order) {
-                if (spos >= nt) break;
-                T = spos < 64 ? __builtin_amdgcn_readlane(ord0, spos) : __builtin_amdgcn_readlane(ord1, spos - 64);
-            } else {   // no pre-sorted order: walk outwards along the Z-curve, W, W+1, W-1, W+2, ...
-                T = (spos & 1) ? W + ((spos + 1) >> 1) : W - (spos >> 1);
-                if (T < 0 || T >= nt) { ++spos; continue; }
-            }
+            const int T = (spos & 1) ? W + ((spos + 1) >> 1) : W - (spos >> 1);
             ++spos;
+            if (T < 0 || T >= nt) continue;
             const float ub = __uint_as_float((uint32_t)ubt[T * 32 + col] << 16);
             if (__any(ub >= thrv)) return T;
         }
@@ -1076,7 +1022,13 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn7_kernel(const float* __re
         for (int e = 0; e < nmax; ++e) {
             const float2 ent = myq[(e < cnt ? e : 0) * 64];
             const float pv = (e < cnt && ent.x >= lv[KMAX - 1]) ? ent.x : -INFINITY;   // -inf: no-op insert (branch-free)
-            knn7_insert<KMAX>(lv, li, pv, __float_as_int(ent.y));
+            const int j = __float_as_int(ent.y);
+            // candidates from tiles below the wave's own rank before equal values: compare against nextabove(pv)
+            const int pb = __float_as_int(pv);
+            int nb = pb < 0 ? pb - 1 : pb + 1;
+            nb = (pb & 0x7fffffff) == 0 ? 1 : nb;                           // +-0 -> smallest positive
+            const float y = (j >= q0 || pv == -INFINITY) ? pv : __int_as_float(nb);
+            knn7_insert<KMAX>(lv, li, pv, y, j);
         }
         cnt = 0;
         // Threshold of the QUERY, not of this half: the two half-lanes of a query each keep a top-K of their own 16 rows
@@ -1102,12 +1054,23 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn7_kernel(const float* __re
         float mx = fmaxf(fmaxf(fmaxf(pd[0], pd[1]), fmaxf(pd[2], pd[3])), fmaxf(fmaxf(pd[4], pd[5]), fmaxf(pd[6], pd[7])));
         mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(pd[8], pd[9]), fmaxf(pd[10], pd[11])), fmaxf(fmaxf(pd[12], pd[13]), fmaxf(pd[14], pd[15]))));
         if (__any(mx >= thrv)) {
+            if (cur >= W) {   // rows ascending: later arrivals have larger indices
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (pd[r] >= thrv) {   // ties with the k-th best are admitted: the list decides (NaN padding never passes)
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    myq[cnt * 64] = make_float2(pd[r], __int_as_float(cur * 32 + row));
-                    ++cnt;
+                for (int r = 0; r < 16; ++r) {
+                    if (pd[r] >= thrv) {   // ties with the k-th best are admitted: the list decides (NaN padding never passes)
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        myq[cnt * 64] = make_float2(pd[r], __int_as_float(cur * 32 + row));
+                        ++cnt;
+                    }
+                }
+            } else {          // tile below the wave's own: rows descending, every arrival has the smallest index so far
+#pragma unroll
+                for (int r = 15; r >= 0; --r) {
+                    if (pd[r] >= thrv) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        myq[cnt * 64] = make_float2(pd[r], __int_as_float(cur * 32 + row));
+                        ++cnt;
+                    }
                 }
             }
             if (__any(cnt > KNN7_QCAP - 16)) drain();
@@ -1184,11 +1147,11 @@ int knn3_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
     return LPD_OK;
 }
 
-// workspace behind [xx | xp]: centroids, |c|^2, radii, max |x|^2, visiting orders, repair list
+// workspace behind [xx | xp]: centroids, |c|^2, radii, max |x|^2 per 32-point tile
 inline size_t knn7_extra_floats(int B, int N, int CP)
 {
     const size_t nt = (size_t)(N + 31) / 32;
-    return (size_t)B * nt * (2 * CP + 3) + ((size_t)B * nt * nt + 1) / 2 + (size_t)B * nt + 8;
+    return (size_t)B * nt * (2 * CP + 3) + 8;
 }
 
 template <int CP, int KMAX>
@@ -1201,11 +1164,8 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
     float* cnorm = cenp + (size_t)B * nt * 2 * CP;
     float* rad = cnorm + (size_t)B * nt;
     float* txmax = rad + (size_t)B * nt;
-    uint16_t* order = reinterpret_cast<uint16_t*>(txmax + (size_t)B * nt);   // [B][nt][nt]
     if (x) hipLaunchKernelGGL(knn_pack_kernel<CP>, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xp, C, N);
     hipLaunchKernelGGL(knn7_tile_stats_kernel<CP>, dim3(nt, B), dim3(64), 0, stream, (const float*)xp, xx, cenp, cnorm, rad, txmax, N, nt);
-    const bool sorted = (dbg & 2) != 0;   // centroid-distance order from the pre-pass instead of the Z-curve walk
-    if (sorted) hipLaunchKernelGGL(knn7_tile_order_kernel, dim3(nt, B), dim3(KNN7_MAXT), 0, stream, (const float*)cenp, order, 2 * CP, nt);
     LPD_CHECK_LAUNCH("lpd_knn(tile pre-pass)");
     const int bpc = (N + KNN3_WAVES * 32 - 1) / (KNN3_WAVES * 32);
     {
@@ -1213,8 +1173,7 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
         auto kern = knn7_kernel<CP, KMAX>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(KNN3_THREADS), lds, stream, (const float*)xp, xx, (const float*)cenp,
-                           (const float*)cnorm, (const float*)rad, (const float*)txmax, sorted ? (const uint16_t*)order : (const uint16_t*)nullptr, idx, N, k, nt,
-                           C, bpc, dbg & 1);
+                           (const float*)cnorm, (const float*)rad, (const float*)txmax, idx, N, k, nt, C, bpc, dbg);
         LPD_CHECK_LAUNCH("lpd_knn(best-first)");
     }
     return LPD_OK;
@@ -1293,10 +1252,9 @@ extern "C" int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
     LPD_CHECK_ARG(B <= 65535, "lpd_knn: B=%d exceeds grid.y", B);
     hipLaunchKernelGGL(knn_sumsq_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xx_ws, C, N);
     LPD_CHECK_LAUNCH("lpd_knn(sumsq)");
-    if (((impl == 0 && KNN7_DEFAULT) || (impl >= 5 && impl <= 8)) && k <= 20 && C <= 64 && N <= KNN7_MAXT * 32) {   // best-first (5: statistics)
-        const int dbg7 = (impl == 5 ? 1 : 0) | (impl == 7 ? 2 : 0) | (impl == 8 ? 3 : 0);   // 7: sorted order, 8: sorted + statistics
-        if (C <= 4) return knn7_launch<2, 20>(x, xx_ws, idx, B, C, N, k, stream, dbg7);
-        return knn7_launch<32, 20>(x, xx_ws, idx, B, C, N, k, stream, dbg7);
+    if (((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && k <= 20 && C <= 64 && N <= KNN7_MAXT * 32) {   // best-first (5: statistics)
+        if (C <= 4) return knn7_launch<2, 20>(x, xx_ws, idx, B, C, N, k, stream, impl == 5);
+        return knn7_launch<32, 20>(x, xx_ws, idx, B, C, N, k, stream, impl == 5);
     }
     if (impl == 0 || impl == 4) {   // ascending scan (larger clouds, k > 20; impl 4: forced, for A/B timing)
         if (C <= 4) return knn3_dispatch_k<2>(x, xx_ws, idx, B, C, N, k, stream);
@@ -1333,10 +1291,9 @@ extern "C" int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k,
     if (C <= 4) hipLaunchKernelGGL(knn_prep_pm_kernel<2>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);
     else hipLaunchKernelGGL(knn_prep_pm_kernel<32>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);
     LPD_CHECK_LAUNCH("lpd_knn_pm(prep)");
-    if (((impl == 0 && KNN7_DEFAULT) || (impl >= 5 && impl <= 8)) && k <= 20 && N <= KNN7_MAXT * 32) {
-        const int dbg7 = (impl == 5 ? 1 : 0) | (impl == 7 ? 2 : 0) | (impl == 8 ? 3 : 0);
-        if (C <= 4) return knn7_launch<2, 20>(nullptr, ws, idx, B, C, N, k, stream, dbg7);
-        return knn7_launch<32, 20>(nullptr, ws, idx, B, C, N, k, stream, dbg7);
+    if (((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && k <= 20 && N <= KNN7_MAXT * 32) {
+        if (C <= 4) return knn7_launch<2, 20>(nullptr, ws, idx, B, C, N, k, stream, impl == 5);
+        return knn7_launch<32, 20>(nullptr, ws, idx, B, C, N, k, stream, impl == 5);
     }
     if (C <= 4) return knn3_dispatch_k<2>(nullptr, ws, idx, B, C, N, k, stream);
     return knn3_dispatch_k<32>(nullptr, ws, idx, B, C, N, k, stream);

@@ -58,6 +58,25 @@ def test_knn_bit_exact_vs_oracle(cuda, C, N, k, B, impl):
         assert (got == idx).all()
 
 
+@pytest.mark.parametrize("impl", [0, 4, 2])
+@pytest.mark.parametrize("C,N", [(3, 1024), (3, 4096), (64, 700)])
+def test_knn_exact_ties_lower_index_first(cuda, C, N, impl):
+    """Clouds on a coarse lattice with duplicated points: thousands of exact pd ties, inside the lists and at the k-th
+    boundary.  Every row must equal the oracle's (value descending, lower index first) -- for the best-first kernel this
+    exercises both insertion rules (candidates from tiles above / below the wave's own)."""
+    ops = _ops()
+    g = np.random.default_rng(C + N)
+    x_pm = (g.integers(-4, 5, size=(2, N, C)) / 4.0).astype(np.float32)
+    x_pm[:, N // 2:N // 2 + 40] = x_pm[:, 3:43]                       # exact duplicates far apart in index
+    oidx, _ = orc.knn_np(x_pm, 20)
+    x_cm = torch.from_numpy(np.ascontiguousarray(x_pm.transpose(0, 2, 1))).to(cuda)
+    got = ops.knn(x_cm, 20, impl=impl).cpu().numpy()
+    assert (got == oidx).all(), f"{(got != oidx).any(-1).sum()} rows differ"
+    if impl == 0:
+        got_pm = ops.knn_pm(torch.from_numpy(x_pm.reshape(-1, C)).to(cuda).contiguous(), 2, N, 20).cpu().numpy()
+        assert (got_pm == oidx).all()
+
+
 @pytest.mark.parametrize("tag", ["knn_c3_n4096_k20", "knn_c64_n4096_k20", "knn_c3_n16384_k64", "knn_c3_n100_k7"])
 def test_knn_vs_reference_golden(cuda, golden_dir, tag):
     ops = _ops()

@@ -13,12 +13,12 @@ for name, feat in (("xyz", ops.transpose(xs.view(B, N, 3))), ("feat64", None)):
         W1 = torch.randn(64, 3, generator=g).cuda(); W2 = (torch.randn(64, 64, generator=g) / 8).cuda()
         f = torch.nn.functional.leaky_relu(torch.nn.functional.leaky_relu(xs.view(B * N, 3) @ W1.t(), 0.01) @ W2.t(), 0.01)
         feat = ops.transpose(f.view(B, N, 64).contiguous())
-    for simpl, label in ((5, "z-walk"), (8, "sorted")):
+    for simpl, label in ((5, "z-walk"),):
         st = ops.knn(feat, k, impl=simpl).view(B * N, k)[:, :5].float()
         w = st.view(-1, 32, 5)[:, 0, :]     # per wave (first query of each tile)
         print(name, label, "tiles visited/wave %.1f  drain iterations %.1f  drains %.1f  admitted per half-lane %.1f / %.1f" % (
             w[:, 0].mean(), w[:, 1].mean(), w[:, 3].mean(), st[:, 2].mean(), st[:, 4].mean()), flush=True)
-    for impl in (4, 6, 7):
+    for impl in (4, 6):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         for _ in range(2): ops.knn(feat, k, impl=impl)
         ev[0].record()
