@@ -638,6 +638,7 @@ class _NetVLADTrainFn(torch.autograd.Function):
 
     @staticmethod
     def _forward(ctx, vlad, B, N, feat, *params):
+        from . import engine
         E, K, O = vlad.feature_size, vlad.cluster_size, vlad.output_dim
         M = B * N
         dev = feat.device
@@ -645,7 +646,7 @@ class _NetVLADTrainFn(torch.autograd.Function):
         a0 = ops.gemm(feat, vlad.cluster_weights, b_kmajor=True)    # [M,K] raw
         sta = ops.bn_train_stats(a0, vlad.bn1)
         a = ops.softmax_affine(a0, sta.scale, sta.shift)
-        vraw = ops.gemm(feat.view(B, N, E), a.view(B, N, K), a_kmajor=True, b_kmajor=True)
+        vraw = ops.gemm(feat.view(B, N, E), a.view(B, N, K), a_kmajor=True, b_kmajor=True, splits=engine._pool_splits(B, N, E))
         aux = {}
         v = torch.zeros((Bp, E * K), dtype=torch.float32, device=dev)
         ops.vlad_finalize(vraw, a.view(B, N, K), vlad.cluster_weights2.view(E, K), out=v, aux=aux)

@@ -278,6 +278,16 @@ def _head_splits(K):
     return s
 
 
+def _pool_splits(B, N, E):
+    """split-K factor of the residual-pooling product act^T x ([E,N] x [N,K] per cloud): the plain launch has only
+    B * E/128 workgroups, each streaming N rows -- one per CU at B = 32, latency-bound at 2 TB/s."""
+    blocks = B * ((E + 127) // 128)
+    s = 1
+    while blocks * s < 1024 and N // (s * 2) >= 256:
+        s *= 2
+    return s
+
+
 def netvlad_eval(vlad, feat, B, N):
     """util/PointNetVlad.py:45-83 + GatingContext :103-115, eval mode.  feat [B*N, E] point-major."""
     if N != vlad.max_samples:
@@ -291,7 +301,7 @@ def netvlad_eval(vlad, feat, B, N):
         ones = _cached(vlad, "ones", (vlad.cluster_biases,), lambda: torch.ones_like(vlad.cluster_biases))
         a = ops.gemm(feat, vlad.cluster_weights, b_kmajor=True)
         a = ops.softmax_affine(a, ones, vlad.cluster_biases, out=a)
-    vraw = ops.gemm(feat.view(B, N, E), a.view(B, N, K), a_kmajor=True, b_kmajor=True)     # [B,E,K]
+    vraw = ops.gemm(feat.view(B, N, E), a.view(B, N, K), a_kmajor=True, b_kmajor=True, splits=_pool_splits(B, N, E))     # [B,E,K]
     v = ops.vlad_finalize(vraw, a.view(B, N, K), vlad.cluster_weights2.view(E, K))         # [B,E*K]
     s, b = bn_affine(vlad.bn2)
     h = ops.gemm(v, vlad.hidden1_weights, b_kmajor=True, scale=s, shift=b, splits=_head_splits(E * K))
