@@ -215,9 +215,11 @@ int lpd_bn_act_bwd(const float* dY, long long lddy, const float* X, long long ld
                    float slope, int has_bn, double* dbeta, double* dgamma, void* stream);
 
 /* Materialised edge tensor (training only): U[(i,t)] = P[nbr(i,t)] + Q[i], rows i*k+t, [M*k][C]
- * (the split form of util/lpdnet_model.py:350-357 + the 1x1 conv).  C in {64,128,256}. */
+ * (the split form of util/lpdnet_model.py:350-357 + the 1x1 conv).  C in {64,128,256}.
+ * sum / sumsq ([C] doubles, both or neither): the BatchNorm statistics of U, accumulated while the rows are written
+ * (what lpd_colstats would compute in a second pass over U). */
 int lpd_edge_build(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, float* U, long long M,
-                   int N, int C, int k, void* stream);
+                   int N, int C, int k, double* sum, double* sumsq, void* stream);
 
 /* out[i][c] = act(scale[c] * sel_t X[(i,t)][c] + shift[c]) over k consecutive rows (x.max(dim=-1) after
  * BatchNorm + activation, lpdnet_model.py:250,252,258); arg[i][c] = selected t (uint8). */
@@ -244,6 +246,15 @@ int lpd_group_sum(const float* dU, int k, float* dQ, long long ldq, long long M,
 /* dP[nbr(i,t)] += dU[(i,t)]  (transpose of the neighbour gather; float atomics; dP zeroed by the caller). */
 int lpd_scatter_add_rows(const float* dU, const int32_t* idx, float* dP, long long ldp, long long M, int N, int k, int C,
                          void* stream);
+
+/* Transposed kNN graph in CSR form: rowptr [M+1], edges [M*k] (edge id = i*k + t, grouped by the neighbour row they
+ * point to); ws: 2*M int32 scratch.  Built once per graph and training step. */
+int lpd_graph_transpose(const int32_t* idx, long long M, int N, int k, int32_t* rowptr, int32_t* edges, int32_t* ws,
+                        void* stream);
+/* dP[j] (+)= sum of dU[e] over the incoming edges e of row j: the same result as lpd_scatter_add_rows without float
+ * atomics (each dU row is read once).  dU [M*k][C] contiguous, C in {64,128,256}. */
+int lpd_gather_sum_rows(const float* dU, const int32_t* rowptr, const int32_t* edges, float* dP, long long ldp, long long M,
+                        int C, int accumulate, void* stream);
 
 /* dW[o][c] = sum_m dY[m][o] * X[m][c] for Kin <= 8 input channels (first layer weight gradient). */
 int lpd_dw_smallk(const float* dY, long long lddy, const float* X, long long ldx, long long M, int Co, int Kin, float* dW,

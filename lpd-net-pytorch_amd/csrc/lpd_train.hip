@@ -208,18 +208,23 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dY, long long 
 // edge tensors: rows (i, t) = i*k + t
 // ---------------------------------------------------------------------------------------------
 // U[(i,t)] = P[cloud(i)*N + idx[i][t]] + Q[i]      (lpdnet_model.py:350-357 gather + cat, in split form)
+// Optionally accumulates the BatchNorm statistics of U (column sums and sums of squares, fp64) while the rows are in
+// registers: the separate lpd_colstats pass over the 1.85 / 3.7 GB edge tensor disappears.
 template <int LPP>
 __global__ __launch_bounds__(256) void edge_build_kernel(const float* __restrict__ P, long long ldp,
                                                          const float* __restrict__ Q, long long ldq,
                                                          const int32_t* __restrict__ idx, float* __restrict__ U,
-                                                         long long M, int N, int k)
+                                                         long long M, int N, int k, double* __restrict__ sum,
+                                                         double* __restrict__ sumsq)
 {
     constexpr int PPW = 64 / LPP;
+    constexpr int C = LPP * 4;
+    __shared__ double red[256][8];
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPP, cl = lane % LPP;
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
-    const int C = LPP * 4;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     for (long long w = wave; w * PPW < M; w += nw) {
         const long long m = w * PPW + sub;
         const bool ok = m < M;
@@ -227,11 +232,38 @@ __global__ __launch_bounds__(256) void edge_build_kernel(const float* __restrict
         const long long base = (mm / N) * N;
         float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
         if (Q) q = *reinterpret_cast<const float4*>(Q + mm * ldq + cl * 4);
-        for (int t = 0; t < k; ++t) {
-            const int j = idx[mm * k + t];
-            float4 p = *reinterpret_cast<const float4*>(P + (base + j) * ldp + cl * 4);
-            p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w;
-            if (ok) *reinterpret_cast<float4*>(U + (mm * k + t) * C + cl * 4) = p;
+        for (int t0 = 0; t0 < k; t0 += LPP) {
+            // the point's next LPP neighbour indices: one coalesced load, broadcast by shuffle
+            const int my_idx = (t0 + cl < k) ? idx[mm * k + t0 + cl] : 0;
+            const int tn = min(k - t0, LPP);
+#pragma unroll 5
+            for (int t = 0; t < tn; ++t) {
+                const int j = __shfl(my_idx, sub * LPP + t, 64);
+                float4 p = *reinterpret_cast<const float4*>(P + (base + j) * ldp + cl * 4);
+                p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w;
+                if (ok) {
+                    *reinterpret_cast<float4*>(U + (mm * k + t0 + t) * C + cl * 4) = p;
+                    if (sum) {
+                        s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
+                        ss[0] += (double)p.x * p.x; ss[1] += (double)p.y * p.y; ss[2] += (double)p.z * p.z; ss[3] += (double)p.w * p.w;
+                    }
+                }
+            }
+        }
+    }
+    if (sum) {   // block reduction over the 256 / LPP lane groups that share a column quad, then one fp64 atomic per column
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s[e]; red[threadIdx.x][4 + e] = ss[e]; }
+        __syncthreads();
+        if (threadIdx.x < LPP) {
+            for (int g = 1; g < 256 / LPP; ++g)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[g * LPP + threadIdx.x][e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(&sum[threadIdx.x * 4 + e], red[threadIdx.x][e]);
+                atomicAdd(&sumsq[threadIdx.x * 4 + e], red[threadIdx.x][4 + e]);
+            }
         }
     }
 }
@@ -454,6 +486,94 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
             float* dst = dP + (base + j) * ldp;
             for (int c = lane; c < C; c += 64) atomicAdd(dst + c, src[c]);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transposed kNN graph (CSR): for every point j the list of edges (i,t) with nbr(i,t) = j.  Built once per graph and
+// step (three small kernels, int atomics only); the backward of the neighbour gather is then a GATHER-sum per row
+// (each dU row read once, 512 B - 1 KiB contiguous) instead of 3.6 M x C float atomics (1.3 TB/s ceiling:
+// MI355X_MICROARCH.md "Global float atomics").
+// ---------------------------------------------------------------------------------------------
+__global__ void csr_count_kernel(const int32_t* __restrict__ idx, int32_t* __restrict__ deg, long long E, int N, int k)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const long long i = e / k;
+    atomicAdd(deg + (i / N) * N + idx[e], 1);
+}
+
+// exclusive scan of the in-degrees of one cloud (block per cloud); rowptr[M] entries + rowptr[M] = E written by cloud B-1
+__global__ __launch_bounds__(1024) void csr_scan_kernel(const int32_t* __restrict__ deg, int32_t* __restrict__ rowptr,
+                                                        int32_t* __restrict__ cursor, int N, int k, long long M)
+{
+    __shared__ int part[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int per = (N + 1023) / 1024;
+    const int lo = min(tid * per, N), hi = min(lo + per, N);
+    const int32_t* d = deg + (long long)b * N;
+    int sum = 0;
+    for (int j = lo; j < hi; ++j) sum += d[j];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = (tid ? part[tid - 1] : 0) + b * N * k;   // every cloud owns exactly N*k edges
+    for (int j = lo; j < hi; ++j) {
+        rowptr[(long long)b * N + j] = run;
+        cursor[(long long)b * N + j] = run;
+        run += d[j];
+    }
+    if (b == gridDim.x - 1 && tid == 0) rowptr[M] = (int)(M * k);
+}
+
+__global__ void csr_fill_kernel(const int32_t* __restrict__ idx, int32_t* __restrict__ cursor, int32_t* __restrict__ edges,
+                                long long E, int N, int k)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const long long i = e / k;
+    const int slot = atomicAdd(cursor + (i / N) * N + idx[e], 1);
+    edges[slot] = (int32_t)e;
+}
+
+// dP[j] (+)= sum over the incoming edges e of dU[e]; one wave per row, float4 per lane, rows of C = 64 .. 256 floats
+template <int LPR>   // lanes per row = C / 4
+__global__ __launch_bounds__(256) void gather_sum_rows_kernel(const float* __restrict__ dU, const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ edges, float* __restrict__ dP,
+                                                              long long ldp, long long M, int accumulate)
+{
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, cl = lane % LPR;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long r0 = wave * RPW; r0 < M; r0 += nw * RPW) {
+        const long long j = r0 + sub;
+        if (j >= M) continue;
+        const int beg = rowptr[j], end = rowptr[j + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int p = beg;
+        for (; p + 3 < end; p += 4) {   // four independent row loads in flight
+            const int e0 = edges[p], e1 = edges[p + 1], e2 = edges[p + 2], e3 = edges[p + 3];
+            const float4 a = *reinterpret_cast<const float4*>(dU + (long long)e0 * (LPR * 4) + cl * 4);
+            const float4 b = *reinterpret_cast<const float4*>(dU + (long long)e1 * (LPR * 4) + cl * 4);
+            const float4 c = *reinterpret_cast<const float4*>(dU + (long long)e2 * (LPR * 4) + cl * 4);
+            const float4 d = *reinterpret_cast<const float4*>(dU + (long long)e3 * (LPR * 4) + cl * 4);
+            acc.x += (a.x + b.x) + (c.x + d.x); acc.y += (a.y + b.y) + (c.y + d.y);
+            acc.z += (a.z + b.z) + (c.z + d.z); acc.w += (a.w + b.w) + (c.w + d.w);
+        }
+        for (; p < end; ++p) {
+            const float4 a = *reinterpret_cast<const float4*>(dU + (long long)edges[p] * (LPR * 4) + cl * 4);
+            acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+        }
+        float4* dst = reinterpret_cast<float4*>(dP + j * ldp + cl * 4);
+        if (accumulate) { const float4 o = *dst; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+        *dst = acc;
     }
 }
 
@@ -725,16 +845,21 @@ extern "C" int lpd_bn_act_bwd(const float* dY, long long lddy, const float* X, l
 }
 
 extern "C" int lpd_edge_build(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, float* U,
-                              long long M, int N, int C, int k, void* stream)
+                              long long M, int N, int C, int k, double* sum, double* sumsq, void* stream)
 {
+    LPD_CHECK_ARG((sum == nullptr) == (sumsq == nullptr), "lpd_edge_build: sum and sumsq come in pairs");
+    if (sum) {
+        (void)hipMemsetAsync(sum, 0, sizeof(double) * C, ST(stream));
+        (void)hipMemsetAsync(sumsq, 0, sizeof(double) * C, ST(stream));
+    }
     LPD_CHECK_ARG(P && idx && U && M > 0 && N > 0 && k > 0 && M % N == 0, "lpd_edge_build: bad arguments");
     LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_build: C=%d unsupported (64/128/256)", C);
     LPD_CHECK_ARG(ldp % 4 == 0 && (!Q || ldq % 4 == 0), "lpd_edge_build: leading dims must be multiples of 4");
     const int lpp = C / 4;
     const int g = grid_for((M + 64 / lpp - 1) / (64 / lpp), 4);
-    if (lpp == 64) hipLaunchKernelGGL(edge_build_kernel<64>, dim3(g), dim3(256), 0, ST(stream), P, ldp, Q, ldq, idx, U, M, N, k);
-    else if (lpp == 32) hipLaunchKernelGGL(edge_build_kernel<32>, dim3(g), dim3(256), 0, ST(stream), P, ldp, Q, ldq, idx, U, M, N, k);
-    else hipLaunchKernelGGL(edge_build_kernel<16>, dim3(g), dim3(256), 0, ST(stream), P, ldp, Q, ldq, idx, U, M, N, k);
+    if (lpp == 64) hipLaunchKernelGGL(edge_build_kernel<64>, dim3(g), dim3(256), 0, ST(stream), P, ldp, Q, ldq, idx, U, M, N, k, sum, sumsq);
+    else if (lpp == 32) hipLaunchKernelGGL(edge_build_kernel<32>, dim3(g), dim3(256), 0, ST(stream), P, ldp, Q, ldq, idx, U, M, N, k, sum, sumsq);
+    else hipLaunchKernelGGL(edge_build_kernel<16>, dim3(g), dim3(256), 0, ST(stream), P, ldp, Q, ldq, idx, U, M, N, k, sum, sumsq);
     LPD_CHECK_LAUNCH("lpd_edge_build");
     return LPD_OK;
 }
@@ -795,6 +920,36 @@ extern "C" int lpd_scatter_add_rows(const float* dU, const int32_t* idx, float* 
     LPD_CHECK_ARG(dU && idx && dP && M > 0 && N > 0 && k > 0 && M % N == 0 && C > 0, "lpd_scatter_add_rows: bad arguments");
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for(M, 4)), dim3(256), 0, ST(stream), dU, idx, dP, ldp, M, N, k, C);
     LPD_CHECK_LAUNCH("lpd_scatter_add_rows");
+    return LPD_OK;
+}
+
+extern "C" int lpd_graph_transpose(const int32_t* idx, long long M, int N, int k, int32_t* rowptr, int32_t* edges, int32_t* ws,
+                                   void* stream)
+{
+    LPD_CHECK_ARG(idx && rowptr && edges && ws && M > 0 && N > 0 && k > 0 && M % N == 0, "lpd_graph_transpose: bad arguments");
+    LPD_CHECK_ARG(M * k < (1ll << 31), "lpd_graph_transpose: more than 2^31 edges");
+    const long long E = M * k;
+    int32_t* deg = ws;          // [M]
+    int32_t* cursor = ws + M;   // [M]
+    (void)hipMemsetAsync(deg, 0, sizeof(int32_t) * M, ST(stream));
+    hipLaunchKernelGGL(csr_count_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, ST(stream), idx, deg, E, N, k);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3((unsigned)(M / N)), dim3(1024), 0, ST(stream), (const int32_t*)deg, rowptr, cursor, N, k, M);
+    hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, ST(stream), idx, cursor, edges, E, N, k);
+    LPD_CHECK_LAUNCH("lpd_graph_transpose");
+    return LPD_OK;
+}
+
+extern "C" int lpd_gather_sum_rows(const float* dU, const int32_t* rowptr, const int32_t* edges, float* dP, long long ldp,
+                                   long long M, int C, int accumulate, void* stream)
+{
+    LPD_CHECK_ARG(dU && rowptr && edges && dP && M > 0, "lpd_gather_sum_rows: bad arguments");
+    LPD_CHECK_ARG((C == 64 || C == 128 || C == 256) && ldp % 4 == 0, "lpd_gather_sum_rows: C=%d unsupported (64/128/256), ldp %% 4", C);
+    const int rpw = 256 / C;   // rows per wave
+    const int grid = grid_for((M + rpw - 1) / rpw, 4);
+    if (C == 256) hipLaunchKernelGGL(gather_sum_rows_kernel<64>, dim3(grid), dim3(256), 0, ST(stream), dU, rowptr, edges, dP, ldp, M, accumulate);
+    else if (C == 128) hipLaunchKernelGGL(gather_sum_rows_kernel<32>, dim3(grid), dim3(256), 0, ST(stream), dU, rowptr, edges, dP, ldp, M, accumulate);
+    else hipLaunchKernelGGL(gather_sum_rows_kernel<16>, dim3(grid), dim3(256), 0, ST(stream), dU, rowptr, edges, dP, ldp, M, accumulate);
+    LPD_CHECK_LAUNCH("lpd_gather_sum_rows");
     return LPD_OK;
 }
 

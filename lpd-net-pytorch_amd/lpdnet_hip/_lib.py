@@ -53,13 +53,15 @@ SIGNATURES = {
     "lpd_affine_act": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p],
     "lpd_bn_act_bwd": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int,
                        _c_p, _c_p, _c_p],
-    "lpd_edge_build": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p],
+    "lpd_edge_build": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p],
     "lpd_group_max": [_c_p, _c_ll, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p],
     "lpd_group_max_bwd": [_c_p, _c_ll, _c_p, _c_int, _c_p, _c_ll, _c_int, _c_int, _c_p],
     "lpd_edge_bn_bwd": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int,
                         _c_f, _c_p, _c_p, _c_p],
     "lpd_group_sum": [_c_p, _c_int, _c_p, _c_ll, _c_ll, _c_int, _c_p],
     "lpd_scatter_add_rows": [_c_p, _c_p, _c_p, _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_p],
+    "lpd_graph_transpose": [_c_p, _c_ll, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
+    "lpd_gather_sum_rows": [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_ll, _c_int, _c_int, _c_p],
     "lpd_dw_smallk": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_int, _c_p, _c_p],
     "lpd_colmax_arg": [_c_p, _c_ll, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "lpd_colmax_bwd": [_c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p],

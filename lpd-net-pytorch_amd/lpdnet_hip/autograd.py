@@ -341,8 +341,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         # DG1 (split projection, materialised edges)
         wcat1 = engine.split_edge_weight(net.convDG1, "cat_nc")
         pq1 = ops.linear(f0, wcat1)                                             # [M,256] = [P | Q]
-        u1 = ops.edge_build(pq1[:, :128], pq1[:, 128:], idx_f, N)               # [E,128] raw
-        stg1 = ops.bn_train_stats(u1, net.convDG1[1])
+        u1, stg1 = ops.edge_build(pq1[:, :128], pq1[:, 128:], idx_f, N, bn=net.convDG1[1])   # [E,128] raw + its BN statistics
         arg1 = ops.group_max(u1, k, stg1.scale, stg1.shift, act, slope, cat[:, 0:128])            # x1
         y1e = ops.affine_act(u1, stg1.scale, stg1.shift, act, slope)            # [E,128] post-activation edges
         # DG2 on every edge
@@ -353,8 +352,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         idx_x = engine._knn_rows(x.view(B * N, 3), B, N, 3, k)
         wcat3 = engine.split_edge_weight(net.convSN1, "cat_nc")
         pq3 = ops.linear(cat[:, 128:256], wcat3)                                # [M,512]
-        u3 = ops.edge_build(pq3[:, :256], pq3[:, 256:], idx_x, N)               # [E,256] raw
-        stg3 = ops.bn_train_stats(u3, net.convSN1[1])
+        u3, stg3 = ops.edge_build(pq3[:, :256], pq3[:, 256:], idx_x, N, bn=net.convSN1[1])   # [E,256] raw + its BN statistics
         arg3 = ops.group_max(u3, k, stg3.scale, stg3.shift, act, slope, cat[:, 256:512])          # x3
         y3, st3, feat = _PointLayer.fwd(cat, w2d(net.conv3_lpd), net.bn3_lpd, act, slope)
         ctx.net, ctx.dims, ctx.actslope = net, (B, N, M, k), (act, slope)
@@ -377,9 +375,9 @@ class _LPDNetTrainFn(torch.autograd.Function):
         dcat, dw3, dg3, db3 = _PointLayer.bwd(dfeat, S["cat"], w2d(net.conv3_lpd), S["y3"], S["st3"], act, slope,
                                               inplace=False)
         # SN1: x3 = groupmax(act(BN(U3)))
-        dpq3 = torch.zeros((M, 512), dtype=torch.float32, device=dfeat.device)
+        dpq3 = torch.empty((M, 512), dtype=torch.float32, device=dfeat.device)    # both halves are fully written below
         du3, dgs3, dbs3 = ops.edge_bn_bwd(dcat[:, 256:512], S["arg3"], k, S["u3"], S["stg3"], act, slope, dQ=dpq3[:, 256:])
-        ops.scatter_add_rows(du3, S["idx_x"], dpq3[:, :256], N)
+        ops.gather_sum_rows(du3, ops.GraphT(S["idx_x"], N), dpq3[:, :256])        # transpose of the neighbour gather
         del du3
         x2 = S["cat"][:, 128:256]
         dwcat3 = _dweight(dpq3, x2)
@@ -390,10 +388,10 @@ class _LPDNetTrainFn(torch.autograd.Function):
         dy1e = ops.gemm(dz, w2d(net.convDG2[0]), b_kmajor=True)                 # [E,128]
         del dz
         # DG1: y1e = act(BN(U1)); consumers: DG2 (dense) and x1 = groupmax (sparse)
-        dpq1 = torch.zeros((M, 256), dtype=torch.float32, device=dfeat.device)
+        dpq1 = torch.empty((M, 256), dtype=torch.float32, device=dfeat.device)
         du1, dgs1, dbs1 = ops.edge_bn_bwd(dcat[:, 0:128], S["arg1"], k, S["u1"], S["stg1"], act, slope, dense=dy1e,
                                           dQ=dpq1[:, 128:])
-        ops.scatter_add_rows(du1, S["idx_f"], dpq1[:, :128], N)
+        ops.gather_sum_rows(du1, ops.GraphT(S["idx_f"], N), dpq1[:, :128])
         del du1, dy1e
         dwcat1 = _dweight(dpq1, S["f0"])
         df0 = ops.gemm(dpq1, S["wcat1"], b_kmajor=True)                         # [M,64]
@@ -423,8 +421,7 @@ class _EdgeChain:
 
     @staticmethod
     def fwd(pq, c, has_q, idx, N, k, bn_a, w_b, bn_b, act, slope, out):
-        u = ops.edge_build(pq[:, :c], pq[:, c:] if has_q else None, idx, N)       # [E,c] raw
-        st_a = ops.bn_train_stats(u, bn_a)
+        u, st_a = ops.edge_build(pq[:, :c], pq[:, c:] if has_q else None, idx, N, bn=bn_a)   # [E,c] raw + its BN statistics
         ya = ops.affine_act(u, st_a.scale, st_a.shift, act, slope)               # [E,c]
         z = ops.linear(ya, w_b)                                                   # [E,co] raw
         st_b = ops.bn_train_stats(z, bn_b)
@@ -440,10 +437,10 @@ class _EdgeChain:
         dya = ops.gemm(dz, w_b, b_kmajor=True)
         del dz
         du, dg_a, db_a = ops.bn_act_bwd(dya, S["u"], S["st_a"], act, slope, out=dya)
-        dpq = torch.zeros((M, 2 * c if has_q else c), dtype=torch.float32, device=dout.device)
+        dpq = torch.empty((M, 2 * c if has_q else c), dtype=torch.float32, device=dout.device)   # fully written below
         if has_q:
             ops.group_sum(du, k, dpq[:, c:])
-        ops.scatter_add_rows(du, idx, dpq[:, :c], N)
+        ops.gather_sum_rows(du, ops.GraphT(idx, N), dpq[:, :c])
         return dpq, dw_b, dg_b, db_b, dg_a, db_a
 
 

@@ -427,9 +427,15 @@ def bn_train_stats(X, bn, rows=None):
     C = X.shape[1]
     dev = X.device
     sums = torch.empty((2, C), dtype=torch.float64, device=dev)
-    out = torch.empty((4, C), dtype=torch.float32, device=dev)
     lib = _lib.load()
     _call("colstats", lib.lpd_colstats, _ptr(X), ld, R, C, _ptr(sums[0]), _ptr(sums[1]), _stream())
+    return _bn_finalize(sums, R, C, bn)
+
+
+def _bn_finalize(sums, R, C, bn):
+    """fp64 column sums / sums of squares over R rows -> BNStats (+ running-stat update)."""
+    out = torch.empty((4, C), dtype=torch.float32, device=sums.device)
+    lib = _lib.load()
     momentum = 0.1 if bn.momentum is None else bn.momentum
     track = bn.track_running_stats and bn.running_mean is not None
     _call("bn_finalize", lib.lpd_bn_finalize, _ptr(sums[0]), _ptr(sums[1]), float(R), C, _ptr(bn.weight), _ptr(bn.bias),
@@ -483,16 +489,22 @@ def bn_act_bwd(dY, X, st, act=ACT_NONE, slope=0.01, out=None, rows=None):
     return out, redf[1], redf[0]
 
 
-def edge_build(P, Q, idx, N):
+def edge_build(P, Q, idx, N, bn=None):
+    """U[(i,t)] = P[nbr(i,t)] + Q[i].  With `bn`: also the train-mode statistics of U for that BatchNorm, accumulated while
+    the rows are written (returns (U, BNStats)) -- no second pass over the edge tensor."""
     ldp = _rows(P, "P")
     ldq = _rows(Q, "Q") if Q is not None else 0
     idx = idx.reshape(-1, idx.shape[-1])
     M, C = P.shape
     k = idx.shape[1]
     U = torch.empty((M * k, C), dtype=torch.float32, device=P.device)
+    sums = torch.empty((2, C), dtype=torch.float64, device=P.device) if bn is not None else None
     lib = _lib.load()
-    _call(f"edge_build[C={C}]", lib.lpd_edge_build, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(U), M, N, C, k, _stream())
-    return U
+    _call(f"edge_build[C={C}]", lib.lpd_edge_build, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(U), M, N, C, k,
+          _ptr(sums[0]) if bn is not None else None, _ptr(sums[1]) if bn is not None else None, _stream())
+    if bn is None:
+        return U
+    return U, _bn_finalize(sums, M * k, C, bn)
 
 
 def group_max(X, k, scale, shift, act, slope, out):
@@ -552,6 +564,36 @@ def scatter_add_rows(dU, idx, dP, N):
     k = idx.shape[1]
     lib = _lib.load()
     _call(f"scatter_add_rows[C={C}]", lib.lpd_scatter_add_rows, _ptr(dU), _ptr(idx), _ptr(dP), ldp, M, N, k, C, _stream())
+    return dP
+
+
+class GraphT:
+    """Transposed kNN graph (CSR) of one index tensor: rowptr [M+1], edges [M*k]."""
+    __slots__ = ("rowptr", "edges", "M", "k")
+
+    def __init__(self, idx, N):
+        _req(idx, "idx", torch.int32)
+        idx = idx.reshape(-1, idx.shape[-1]).contiguous()
+        self.M, self.k = idx.shape
+        dev = idx.device
+        self.rowptr = torch.empty((self.M + 1,), dtype=torch.int32, device=dev)
+        self.edges = torch.empty((self.M * self.k,), dtype=torch.int32, device=dev)
+        ws = torch.empty((2 * self.M,), dtype=torch.int32, device=dev)
+        lib = _lib.load()
+        _call("graph_transpose", lib.lpd_graph_transpose, _ptr(idx), self.M, N, self.k, _ptr(self.rowptr), _ptr(self.edges), _ptr(ws),
+              _stream())
+
+
+def gather_sum_rows(dU, graph, dP, accumulate=False):
+    """dP[j] (+)= sum over incoming edges of dU rows (backward of the neighbour gather, no float atomics)."""
+    _req(dU, "dU")
+    ldp = _rows(dP, "dP")
+    M, C = dP.shape
+    if not dU.is_contiguous() or dU.shape[0] != graph.M * graph.k or dU.shape[1] != C or M != graph.M:
+        raise ValueError("gather_sum_rows: dU must be contiguous [M*k, C] matching the graph")
+    lib = _lib.load()
+    _call(f"gather_sum_rows[C={C}]", lib.lpd_gather_sum_rows, _ptr(dU), _ptr(graph.rowptr), _ptr(graph.edges), _ptr(dP), ldp, M, C,
+          int(bool(accumulate)), _stream())
     return dP
 
 

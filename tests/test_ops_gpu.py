@@ -292,3 +292,30 @@ def test_errors_are_loud(cuda):
         ops.knn(torch.zeros(1, 3, 8, device=cuda), 9)        # k > N
     with pytest.raises(LpdHipError):
         ops.gemm(torch.zeros(4, 50, device=cuda), torch.zeros(50, 8, device=cuda))  # leading dim not a multiple of 4
+
+
+@pytest.mark.parametrize("C,N,B,k", [(256, 512, 2, 20), (128, 1000, 3, 20), (64, 96, 2, 7)])
+def test_gather_sum_rows_is_the_transpose_of_the_neighbour_gather(cuda, C, N, B, k):
+    """CSR transposed graph + gather-sum == the atomic scatter (lpd_scatter_add_rows) == a dense reference, including rows
+    nobody points to (must come out zero) and accumulation into a column slice."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(C + N)
+    idx = torch.stack([torch.stack([torch.randperm(N, generator=g)[:k] for _ in range(N)]) for _ in range(B)]).to(torch.int32)
+    idx[:, :, 0] = idx[:, :1, 0]                       # a hub: every point of a cloud lists the same first neighbour
+    M = B * N
+    dU = torch.randn(M * k, C, generator=g)
+    ref = torch.zeros(M, C, dtype=torch.float64)
+    rows = (idx.long() + (torch.arange(B) * N).view(B, 1, 1)).reshape(-1)
+    ref.index_add_(0, rows, dU.double())
+    graph = ops.GraphT(idx.to(cuda), N)
+    assert int(graph.rowptr[-1]) == M * k and int(graph.rowptr[0]) == 0
+    e = graph.edges.cpu().long()
+    assert torch.equal(torch.sort(e)[0], torch.arange(M * k))                       # a permutation of the edge ids
+    buf = torch.full((M, C + 8), 3.0, device=cuda)
+    ops.gather_sum_rows(dU.to(cuda), graph, buf[:, 4:4 + C])
+    assert _rel(buf[:, 4:4 + C], ref) < 3e-6   # fp32 sums in edge-arrival order (the CSR fill uses int atomics)
+    assert (buf[:, :4] == 3.0).all() and (buf[:, 4 + C:] == 3.0).all()
+    ops.gather_sum_rows(dU.to(cuda), graph, buf[:, 4:4 + C], accumulate=True)
+    assert _rel(buf[:, 4:4 + C], 2 * ref) < 3e-6
+    old = ops.scatter_add_rows(dU.to(cuda), idx.to(cuda), torch.zeros(M, C, device=cuda), N)
+    assert _rel(old, ref) < 3e-6
