@@ -440,6 +440,164 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x3_kernel(GemmArgs g)
     gemm_epilogue<TN>(g, acc, C, m0 + wm * 64, n0 + wn * (32 * TN), h, col);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 GEMM with PRE-ARRANGED B fragments ("x3w"): C = act((A.B + bias) * scale + shift), A [M][K] row-major
+// activations, B a (small) weight matrix.  lpd_gemm_prep_b splits B once into hi/lo bf16 and stores it in MFMA
+// fragment order -- fragment (n-tile, k-step) = 64 lanes x 8 bf16 = 1 KiB contiguous -- so the main kernel never
+// stages B through LDS and never splits it: each wave owns one 32-column tile of the output and streams its
+// fragments straight from L2 into registers (one coalesced 16-B load per lane and fragment), while the A tile
+// (128 rows x 64 k, split hi/lo on the fly) is the only LDS traffic.  Same scheme as edge_mlp_x3_kernel (36 % of the
+// three-product bf16 peak there); the generic kernel above re-splits and re-stages B in every block (25 %).
+// ---------------------------------------------------------------------------------------------
+constexpr int X3W_KC = 64;                 // k per chunk (4 MFMA k-steps)
+constexpr int X3W_LDK = X3W_KC + 8;        // bf16 per LDS row of the A images (144 B: conflict-free ds_read_b128)
+constexpr int X3W_IMG = 128 * X3W_LDK;     // one image (hi or lo)
+
+// fragment order: frag[((nt * KS + ks) * 64 + lane) * 8 + j] = B[k = 16 ks + 8 (lane >> 5) + j][n = 32 nt + (lane & 31)]
+__global__ void gemm_prep_b_kernel(const float* __restrict__ B, int ldb, int b_kmajor, int N, int K, int KS,
+                                   __bf16* __restrict__ fhi, __bf16* __restrict__ flo, long long total)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (nt, ks, lane)
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const long long f = t >> 6;
+    const int ks = (int)(f % KS), nt = (int)(f / KS);
+    const int n = nt * 32 + (lane & 31);
+    const int k0 = ks * 16 + (lane >> 5) * 8;
+    bf16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        float v = 0.0f;
+        if (n < N && k < K) v = b_kmajor ? B[(long long)k * ldb + n] : B[(long long)n * ldb + k];
+        h[j] = (__bf16)v;
+        l[j] = (__bf16)(v - (float)h[j]);
+    }
+    *reinterpret_cast<bf16x8*>(fhi + t * 8) = h;
+    *reinterpret_cast<bf16x8*>(flo + t * 8) = l;
+}
+
+struct X3wArgs {
+    const float* A;
+    const __bf16* fhi;
+    const __bf16* flo;
+    float* C;
+    int M, N, K, KS;       // KS = ceil(K / 16) fragments per n-tile
+    int lda, ldc;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    int act;
+    float slope;
+    int accumulate;
+};
+
+template <bool KTAIL>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_kernel(X3wArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];   // [2 buffers][hi | lo][128][LDK]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int col = lane & 31;
+    const int m0 = blockIdx.y * 128;
+    const int nt = blockIdx.x * 4 + wave;          // this wave's 32-column tile
+    const int nchunks = (g.K + X3W_KC - 1) / X3W_KC;
+    const bool has_cols = nt * 32 < g.N;           // the last block may hold waves past N (they still help staging A)
+
+    // A staging: 128 x 64 fp32 per chunk = 8 float4 per thread; register e: row (e*256 + tid) / 16, k quad % 16
+    float4 ra[8];
+    auto load_a = [&](int kc) {
+        const int k0 = kc * X3W_KC;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int f = e * GEMM_THREADS + tid;
+            const int rr = f >> 4, kq = f & 15;
+            int row = m0 + rr;
+            row = row < g.M ? row : g.M - 1;
+            if constexpr (KTAIL) ra[e] = ld4_guard(g.A + (long long)row * g.lda, k0 + kq * 4, g.K);
+            else ra[e] = *reinterpret_cast<const float4*>(g.A + (long long)row * g.lda + k0 + kq * 4);
+        }
+    };
+    auto store_a = [&](int buf) {
+        __bf16* hi_img = smem16 + buf * 2 * X3W_IMG;
+        __bf16* lo_img = hi_img + X3W_IMG;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int f = e * GEMM_THREADS + tid;
+            const int rr = f >> 4, kq = f & 15;
+            bf16x4 hh, ll;
+            split4(ra[e].x, ra[e].y, ra[e].z, ra[e].w, hh, ll);
+            *reinterpret_cast<bf16x4*>(hi_img + rr * X3W_LDK + kq * 4) = hh;
+            *reinterpret_cast<bf16x4*>(lo_img + rr * X3W_LDK + kq * 4) = ll;
+        }
+    };
+    // B fragments of one chunk (4 k-steps, hi and lo): straight from the prepared arrays
+    bf16x8 b_hi[4], b_lo[4];
+    const __bf16* fh = g.fhi + ((long long)(has_cols ? nt : 0) * g.KS * 64 + lane) * 8;
+    const __bf16* fl = g.flo + ((long long)(has_cols ? nt : 0) * g.KS * 64 + lane) * 8;
+    auto load_b = [&](int kc) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ks = min(kc * 4 + s, g.KS - 1);   // past the end: any valid fragment (its A columns are zero)
+            b_hi[s] = *reinterpret_cast<const bf16x8*>(fh + (long long)ks * 512);
+            b_lo[s] = *reinterpret_cast<const bf16x8*>(fl + (long long)ks * 512);
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    load_a(0);
+    store_a(0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int buf = kc & 1;
+        load_b(kc);
+        if (kc + 1 < nchunks) load_a(kc + 1);
+        const __bf16* ah = smem16 + buf * 2 * X3W_IMG + col * X3W_LDK + h * 8;
+        const __bf16* al = ah + X3W_IMG;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(ah + i * 32 * X3W_LDK + s * 16);
+                const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(al + i * 32 * X3W_LDK + s * 16);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi[s], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo[s], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi[s], acc[i], 0, 0, 0);
+            }
+        }
+        if (kc + 1 < nchunks) store_a(buf ^ 1);
+        __syncthreads();
+    }
+    if (!has_cols) return;
+
+    const int n = nt * 32 + col;
+    if (n >= g.N) return;
+    float bi = 0.f, sc = 1.f, sh = 0.f;
+    if (g.bias) bi = g.bias[n];
+    if (g.scale) { sc = g.scale[n]; sh = g.shift[n]; }
+    const float ns = g.act == 0 ? 1.0f : (g.act == 1 ? 0.0f : g.slope);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= g.M) continue;
+            float v = acc[i][r] + bi;
+            v = v * sc + sh;
+            if (g.act == 3) v = lpd_sigmoid(v);
+            else v = fmaxf(v, 0.0f) + ns * fminf(v, 0.0f);
+            if (g.accumulate) v += g.C[(long long)m * g.ldc + n];
+            g.C[(long long)m * g.ldc + n] = v;
+        }
+}
+
 // sums split-K slabs and applies the epilogue.  one thread per output element.
 __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
                                           int ldc, int splits, long long slab_stride, long long sWs_batch,
@@ -574,4 +732,49 @@ extern "C" int lpd_gemm_bf16x3(const float* A, const float* B, float* C, int M, 
 {
     return gemm_entry(true, A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, batch, sA, sB, sC, splits, splitk_ws, bias,
                       scale, shift, act, slope, accumulate, stream);
+}
+
+// bytes of the fragment buffer for an N x K weight: hi and lo arrays of ceil(N/32) * ceil(K/16) fragments of 1 KiB
+extern "C" long long lpd_gemm_prep_b_bytes(int N, int K)
+{
+    if (N <= 0 || K <= 0) return 0;
+    return 2ll * ((N + 31) / 32) * ((K + 15) / 16) * 1024;
+}
+
+extern "C" int lpd_gemm_prep_b(const float* B, int ldb, int b_kmajor, int N, int K, void* frags, void* stream)
+{
+    LPD_CHECK_ARG(B && frags && N > 0 && K > 0, "lpd_gemm_prep_b: bad arguments");
+    LPD_CHECK_ARG(((uintptr_t)frags & 15) == 0, "lpd_gemm_prep_b: frags must be 16-byte aligned");
+    const int KS = (K + 15) / 16, NT = (N + 31) / 32;
+    const long long total = (long long)NT * KS * 64;
+    __bf16* fhi = reinterpret_cast<__bf16*>(frags);
+    __bf16* flo = fhi + total * 8;
+    hipLaunchKernelGGL(gemm_prep_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, ldb, b_kmajor, N,
+                       K, KS, fhi, flo, total);
+    LPD_CHECK_LAUNCH("lpd_gemm_prep_b");
+    return LPD_OK;
+}
+
+extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
+                            const float* scale, const float* shift, int act, float slope, int accumulate, void* stream)
+{
+    LPD_CHECK_ARG(A && frags && C && M > 0 && N > 0 && K > 0, "lpd_gemm_x3w: bad arguments");
+    LPD_CHECK_ARG(lda % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)frags & 15) == 0, "lpd_gemm_x3w: A must be 16-byte aligned, lda %% 4 == 0");
+    LPD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "lpd_gemm_x3w: scale and shift must be given together");
+    const int KS = (K + 15) / 16, NT = (N + 31) / 32;
+    const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
+    X3wArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, K, KS, lda, ldc, bias, scale, shift, act, slope, accumulate};
+    const size_t lds = (size_t)4 * X3W_IMG * sizeof(__bf16);
+    dim3 grid((NT + 3) / 4, (M + 127) / 128);
+    if (K % X3W_KC) {
+        auto kern = gemm_x3w_kernel<true>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, (hipStream_t)stream, g);
+    } else {
+        auto kern = gemm_x3w_kernel<false>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, (hipStream_t)stream, g);
+    }
+    LPD_CHECK_LAUNCH("lpd_gemm_x3w");
+    return LPD_OK;
 }

@@ -29,6 +29,9 @@ SIGNATURES = {
                  _c_ll, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_p],
 "lpd_gemm_bf16x3": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                  _c_ll, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_p],
+    "lpd_gemm_prep_b_bytes": [_c_int, _c_int],
+    "lpd_gemm_prep_b": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p],
+    "lpd_gemm_x3w": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_p],
     "lpd_knn_pm": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_int, _c_p],
     "lpd_knn_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
     "lpd_edge_gather_max": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int,
@@ -71,7 +74,8 @@ SIGNATURES = {
     "lpd_metric_loss": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_int, _c_int, _c_int,
                         _c_int, _c_f, _c_f, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
 }
-_RESTYPES = {"lpd_last_error": ctypes.c_char_p, "lpd_knn_workspace_floats": ctypes.c_longlong}
+_RESTYPES = {"lpd_last_error": ctypes.c_char_p, "lpd_knn_workspace_floats": ctypes.c_longlong,
+             "lpd_gemm_prep_b_bytes": ctypes.c_longlong}
 
 _lib = None
 

@@ -147,6 +147,30 @@ class train_forward_gemm(exact_gemm):
         return False
 
 
+_FRAG_CACHE = {}
+
+
+def _weight_frags(B2, b_kmajor, N, K):
+    """hi/lo bf16 MFMA fragments of a weight matrix (lpd_gemm_prep_b).  Cached only for nn.Parameters (or views of one):
+    their storage lives as long as the cache entry's reference and every update bumps `_version`; anything else (derived
+    weights, activations) may reuse an address with a fresh version counter, so it is prepared per call (~5 us)."""
+    base = B2._base if B2._base is not None else B2
+    cacheable = isinstance(base, torch.nn.Parameter)
+    key = (B2.data_ptr(), base._version, tuple(B2.shape), B2.stride(0), bool(b_kmajor)) if cacheable else None
+    if cacheable:
+        hit = _FRAG_CACHE.get(key)
+        if hit is not None:
+            return hit[0]
+        if len(_FRAG_CACHE) > 256:
+            _FRAG_CACHE.clear()
+    lib = _lib.load()
+    frags = torch.empty((int(lib.lpd_gemm_prep_b_bytes(N, K)),), dtype=torch.uint8, device=B2.device)
+    _call("gemm_prep_b", lib.lpd_gemm_prep_b, _ptr(B2), B2.stride(0), int(bool(b_kmajor)), N, K, _ptr(frags), _stream())
+    if cacheable:
+        _FRAG_CACHE[key] = (frags, base)     # the reference keeps the parameter's storage from being recycled under the key
+    return frags
+
+
 def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=None, act=ACT_NONE, slope=0.01,
          out=None, splits=1, accumulate=False, exact=False):
     """Single (2-D) or batched (3-D) GEMM with fused epilogue.
@@ -183,6 +207,16 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
         ws = torch.empty((nb * splits * M * N,), dtype=torch.float32, device=A.device)
     bias, scale, shift = _vec(bias, "bias", N), _vec(scale, "scale", N), _vec(shift, "shift", N)
     lib = _lib.load()
+    # weight-shaped B stored k-major (dX = dY W of the backward pass, the NetVLAD assignment): fragments of B prepared
+    # once, B never staged through LDS (lpd_gemm_x3w).  Measured against the generic split-bf16 kernel, whose k-major
+    # staging transposes in registers: 3.6M x 128 x 128 1.49 -> 1.15 ms, 180k x 512 x 1024 1.42 -> 0.72 ms; for row-major
+    # weights (forward layers) and K = 64 the generic kernel is as fast or faster, so those stay there.
+    if (GEMM_BF16X3 and not exact and _EXACT_DEPTH == 0 and not a_kmajor and b_kmajor and not batched and splits == 1
+            and M >= 1024 and N >= 64 and K >= 128 and N * K <= (1 << 22)):
+        frags = _weight_frags(B, b_kmajor, N, K)
+        _call(f"gemmx3w[{M}x{N}x{K}]", lib.lpd_gemm_x3w, _ptr(A), lda, _ptr(frags), _ptr(out), ldc, M, N, K, _ptr(bias), _ptr(scale),
+              _ptr(shift), act, float(slope), int(bool(accumulate)), _stream())
+        return out
     # split-bf16 where it is faster (measured, tools/gemm_bench.py): outputs of at least 128 x 128 with a row-major A
     # or with both operands k-major (weight gradients); skinny outputs (per-cloud rows, 64 clusters) and the k-major
     # pooling product stay on the f32-input MFMA

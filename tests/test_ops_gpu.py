@@ -319,3 +319,38 @@ def test_gather_sum_rows_is_the_transpose_of_the_neighbour_gather(cuda, C, N, B,
     assert _rel(buf[:, 4:4 + C], 2 * ref) < 3e-6
     old = ops.scatter_add_rows(dU.to(cuda), idx.to(cuda), torch.zeros(M, C, device=cuda), N)
     assert _rel(old, ref) < 3e-6
+
+
+@pytest.mark.parametrize("M,N,K,bk", [(4096, 512, 1024, True), (2048, 256, 128, True), (1500, 64, 1024, True), (3000, 200, 136, True),
+                                       (1024, 72, 148, True)])
+def test_gemm_weight_fragment_path(cuda, M, N, K, bk):
+    """Row-major activations times a weight matrix take lpd_gemm_x3w (B fragments prepared once, never staged in LDS):
+    same contract and error bound as the generic split-bf16 kernel; epilogue, output slice, accumulation, ragged N / K."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K + 4, generator=g)[:, :K]
+    W = torch.nn.Parameter(torch.randn((K, N) if bk else (N, K), generator=g).to(cuda) / K ** 0.5)
+    bias, scale, shift = torch.randn(N, generator=g), torch.randn(N, generator=g), torch.randn(N, generator=g)
+    Wl = (W.detach().cpu() if bk else W.detach().cpu().t()).double()
+    ref = (A.double() @ Wl + bias.double()) * scale.double() + shift.double()
+    ref = torch.where(ref > 0, ref, ref * 0.01)
+    Ad = torch.zeros(M, K + 4, device=cuda)
+    Ad[:, :K] = A.to(cuda)
+    prof = ops.PROFILE = {}
+    try:
+        buf = torch.zeros(M, N + 8, device=cuda)
+        with torch.no_grad():
+            ops.gemm(Ad[:, :K], W, b_kmajor=bk, bias=bias.to(cuda), scale=scale.to(cuda), shift=shift.to(cuda), act=ops.ACT_LEAKY,
+                     out=buf[:, 4:4 + N])
+            assert _rel(buf[:, 4:4 + N], ref) < 3e-5
+            assert buf[:, :4].abs().max().item() == 0 and buf[:, 4 + N:].abs().max().item() == 0
+            raw = ops.gemm(Ad[:, :K], W, b_kmajor=bk)
+            ops.gemm(Ad[:, :K], W, b_kmajor=bk, out=raw, accumulate=True)
+            assert _rel(raw, 2 * (A.double() @ Wl)) < 3e-5
+            W.mul_(2.0)                                         # an in-place parameter update (optimizer step, load_state_dict) bumps
+                                                                # _version and so invalidates the cached fragments
+            raw2 = ops.gemm(Ad[:, :K], W, b_kmajor=bk)
+            assert _rel(raw2, 2 * (A.double() @ Wl)) < 3e-5
+    finally:
+        ops.PROFILE = None
+    assert any(k.startswith("gemmx3w") for k in prof), list(prof)
