@@ -71,11 +71,17 @@ int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k, int32_t* i
  *   bias/scale/shift: [N] or NULL (scale and shift together)
  *   accumulate != 0: C += result (after the epilogue) -- gradient accumulation in the backward pass
  * Any M, N, K (tails are zero-filled / masked).  Requires lda/ldb/sA/sB % 4 == 0, A and B 16-byte aligned.
+ *   a_cloud / c_cloud != 0: A / C are in CLOUD-PANEL layout [cloud][cols/8][panel_ld][8] (lda / ldc ignored): rows
+ *   m = cloud * panel_n + n, n < panel_n <= panel_ld (the pad rows keep consecutive panels off the same HBM channels);
+ *   a_cloud / c_cloud = floats between clouds of that buffer (it may hold more panels than the operand uses: pass the
+ *   pointer to the operand's first panel).  An 8-channel slice of one cloud is one contiguous
+ *   32*panel_n-byte run -- what lpd_edge_gather_max16 streams -- and a whole cloud one contiguous block.  Needs
+ *   a_kmajor = 0, batch = 1, splits = 1, K % 32 == 0, panel_n % 128 == 0.
  */
 int lpd_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
              int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC, int splits,
              float* splitk_ws, const float* bias, const float* scale, const float* shift, int act, float slope,
-             int accumulate, void* stream);
+             int accumulate, int a_panels, int c_panels, void* stream);
 
 /*
  * lpd_gemm on the bf16 MFMA: each fp32 operand is split hi + lo (two bf16) while it is staged into LDS and every
@@ -86,7 +92,7 @@ int lpd_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
 int lpd_gemm_bf16x3(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
              int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC, int splits,
              float* splitk_ws, const float* bias, const float* scale, const float* shift, int act, float slope,
-             int accumulate, void* stream);
+             int accumulate, int a_panels, int c_panels, void* stream);
 
 /*
  * Split-bf16 GEMM for a weight-shaped B: lpd_gemm_prep_b splits B (either layout) once into hi/lo bf16 stored in MFMA
@@ -117,10 +123,12 @@ int lpd_edge_gather_max(const float* P, int ldp, const float* Q, int ldq, const 
  * workgroup keeps an 8-channel slice of ALL N rows of one cloud's P in LDS (N*32 bytes), so the k gathers per
  * point are LDS reads and P, Q, out cross the memory system once.  idx16: the blocked uint16 copy made by lpd_pack_idx16.
  * Built for k = 20, N <= 5120; bit-identical to lpd_edge_gather_max.
+ * p_cloud / q_cloud / o_cloud != 0: that operand is in cloud-panel layout [cloud][.][panel_ld][8] (floats between clouds; leading
+ * dim ignored): a block's 8-channel slice is then one contiguous 32*N-byte run instead of N pieces of 32 bytes.
  */
 int lpd_edge_gather_max16(const float* P, int ldp, const float* Q, int ldq, const uint16_t* idx16, float* out, int ldo,
-                          const float* scale, const float* shift, int M, int N, int C, int k, int act, float slope,
-                          void* stream);
+                          const float* scale, const float* shift, int M, int N, int C, int k, int act, float slope, long long p_cloud,
+                          long long q_cloud, long long o_cloud, int panel_ld, void* stream);
 
 /* int32 kNN indices [M][k] (local to the cloud, < 65536) -> the uint16 copy lpd_edge_gather_max16 reads:
  * blocked by 32 points, index quad i of point m at ((m/32)*5 + i)*32 + m%32 (uint2 units); idx16 holds
@@ -134,14 +142,15 @@ int lpd_pack_idx16(const int32_t* idx, uint16_t* idx16, long long M, int k, void
  *   y1[m][t][:] = act(s1 * (P[nbr(m,t)] + Q[m]) + b1)            (never materialised)
  *   out[m][o]   = act(s2[o] * sel_t (W2 y1[m][t])[o] + b2[o])
  *   W2 [CO][CM] torch [out,in] layout.  (CM,CO) in {(128,128),(64,64)}; k <= 128.
+ *   out_cloud != 0: out is in cloud-panel layout [cloud][.][panel_ld][8] with out_cloud floats between clouds (ldo ignored).
  */
 int lpd_edge_mlp(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
                  const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo, int M,
-                 int N, int CM, int CO, int k, int act, float slope, void* stream);
+                 int N, int CM, int CO, int k, int act, float slope, long long out_cloud, int panel_ld, void* stream);
 /* Same contract on the bf16 MFMA (split-bf16, three products per term, fp32 accumulate: see lpd_gemm_bf16x3). */
 int lpd_edge_mlp_bf16x3(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
                  const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo, int M,
-                 int N, int CM, int CO, int k, int act, float slope, void* stream);
+                 int N, int CM, int CO, int k, int act, float slope, long long out_cloud, int panel_ld, void* stream);
 
 /* Per-point linear layer with K <= 8 inputs (+bias, affine, activation): the 3 -> 64 first layers
  * (util/lpdnet_model.py:185,231; util/PointNetVlad.py:190,213; T-Net conv1 lpdnet_model.py:276) and the

@@ -44,6 +44,11 @@ struct GatherArgs {
     int ldp, ldq, ldo;
     int act;
     float slope;
+    // cloud-resident form only: float offsets between consecutive 8-channel slices and between consecutive clouds of
+    // P / Q / out.  Row-major operands: slice 8 (the next 8 columns of the row), cloud N * ld.  Cloud-panel operands
+    // [cloud][C/8][N][8]: slice N * 8 with a row stride of 8, cloud = floats between clouds in that buffer.
+    long long p_slice, q_slice, o_slice;
+    long long p_cloud, q_cloud, o_cloud;
 };
 
 // LPP = lanes per point = C / 4 (16, 32 or 64)
@@ -151,8 +156,8 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArg
     const int N = g.N;
     const int passes = (N + GROUPS - 1) / GROUPS;
     const uint2* idx2 = reinterpret_cast<const uint2*>(idx16);
-    const float* Qc = g.Q + col;
-    float* outc = g.out + col;
+    const float* Qc = g.Q + b * g.q_cloud + sl * g.q_slice + cl * 4;      // row n of the cloud at + n * ld
+    float* outc = g.out + b * g.o_cloud + sl * g.o_slice + cl * 4;
     const unsigned ldq = g.ldq, ldo = g.ldo;
 
     // A pass past the end of the cloud re-reads (and later re-stores, with identical values) the last point:
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArg
         const unsigned ib = (o.m >> 5) * (KQ * 32) + (o.m & 31);
 #pragma unroll
         for (int i = 0; i < KQ; ++i) o.ix[i] = idx2[ib + i * 32];
-        if (HAS_Q) o.q = *reinterpret_cast<const float4*>(Qc + o.m * ldq);
+        if (HAS_Q) o.q = *reinterpret_cast<const float4*>(Qc + (o.m - row0) * ldq);
     };
     CloudOps A, Bo, Co;
     load(A, 0);
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArg
     if (g.shift) sh = *reinterpret_cast<const float4*>(g.shift + col);
     const float4 sg = make_float4(sc.x >= 0.f ? 1.f : -1.f, sc.y >= 0.f ? 1.f : -1.f, sc.z >= 0.f ? 1.f : -1.f,
                                   sc.w >= 0.f ? 1.f : -1.f);
-    const float* Pc = g.P + (size_t)row0 * g.ldp + col;
+    const float* Pc = g.P + b * g.p_cloud + sl * g.p_slice + cl * 4;
     for (int r = grp; r < N; r += GROUPS) {
         float4 p = *reinterpret_cast<const float4*>(Pc + (size_t)r * g.ldp);
         p.x *= sg.x; p.y *= sg.y; p.z *= sg.z; p.w *= sg.w;
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArg
         r.y = fmaxf(r.y, 0.f) + ns * fminf(r.y, 0.f);
         r.z = fmaxf(r.z, 0.f) + ns * fminf(r.z, 0.f);
         r.w = fmaxf(r.w, 0.f) + ns * fminf(r.w, 0.f);
-        *reinterpret_cast<float4*>(outc + o.m * ldo) = r;
+        *reinterpret_cast<float4*>(outc + (o.m - row0) * ldo) = r;
     };
     for (int ps = 0; ps < passes; ps += 3) {
         load(Co, ps + 2);
@@ -247,7 +252,18 @@ struct EdgeMlpArgs {
     int ldp, ldq, ldo;
     int act;
     float slope;
+    long long out_cloud;  // 0: out row-major [M][ldo]; else cloud-panel [cloud][.][panel_ld][8] with this many floats between clouds
+    int panel_ld;         // rows allotted to one panel (>= N)
 };
+
+// m = m0 + (row inside the block); a block's 64 points lie in one cloud when the output is in cloud-panel form
+// (the host checks N % 64 == 0), so the cloud index comes from m0 alone.
+__device__ __forceinline__ float* edge_mlp_out(const EdgeMlpArgs& g, int m0, size_t m, int o)
+{
+    if (!g.out_cloud) return g.out + m * g.ldo + o;
+    const size_t b = (size_t)(m0 / g.N);
+    return g.out + b * g.out_cloud + ((size_t)(o >> 3) * g.panel_ld + (m - b * g.N)) * 8 + (o & 7);
+}
 
 constexpr int EM_PTS = 64;       // points per block
 constexpr int EM_THREADS = 256;
@@ -393,7 +409,7 @@ __global__ __launch_bounds__(EM_THREADS) void edge_mlp_kernel(EdgeMlpArgs g)
             const int m = m0 + wp * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m >= g.M) continue;
             const float z = sc >= 0.f ? zmax[j][r] : zmin[j][r];
-            g.out[(size_t)m * g.ldo + o] = lpd_act(sc * z + sh, g.act, g.slope);
+            *edge_mlp_out(g, m0, (size_t)m, o) = lpd_act(sc * z + sh, g.act, g.slope);
         }
     }
 }
@@ -576,7 +592,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + (ptile + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m >= g.M) continue;
-            g.out[(size_t)m * g.ldo + n] = lpd_act_pl(sc2 * (sgn * zmax[i][r]) + sh2, ns);
+            *edge_mlp_out(g, m0, (size_t)m, n) = lpd_act_pl(sc2 * (sgn * zmax[i][r]) + sh2, ns);
         }
 }
 
@@ -607,7 +623,7 @@ extern "C" int lpd_edge_gather_max(const float* P, int ldp, const float* Q, int 
     LPD_CHECK_ARG(ldp % 4 == 0 && ldo % 4 == 0 && (!Q || ldq % 4 == 0), "lpd_edge_gather_max: leading dims must be multiples of 4");
     LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)out | (uintptr_t)Q | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0,
                   "lpd_edge_gather_max: pointers must be 16-byte aligned");
-    GatherArgs g{P, Q, idx, out, scale, shift, M, N, C, k, ldp, ldq, ldo, act, slope};
+    GatherArgs g{P, Q, idx, out, scale, shift, M, N, C, k, ldp, ldq, ldo, act, slope, 0, 0, 0, 0, 0, 0};
     const int lpp = C / 4;
     const int nwork = (M + (64 / lpp) - 1) / (64 / lpp);
     int blocks = (nwork + 3) / 4;
@@ -622,7 +638,7 @@ extern "C" int lpd_edge_gather_max(const float* P, int ldp, const float* Q, int 
 
 static int edge_mlp_entry(bool x3, const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
                           const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo,
-                          int M, int N, int CM, int CO, int k, int act, float slope, void* stream_)
+                          int M, int N, int CM, int CO, int k, int act, float slope, long long out_cloud, int panel_ld, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(P && idx && s1 && b1 && W2 && s2 && b2 && out, "lpd_edge_mlp: null pointer");
@@ -632,7 +648,8 @@ static int edge_mlp_entry(bool x3, const float* P, int ldp, const float* Q, int 
     LPD_CHECK_ARG(ldp % 4 == 0 && (!Q || ldq % 4 == 0), "lpd_edge_mlp: leading dims must be multiples of 4");
     LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)Q | (uintptr_t)s1 | (uintptr_t)b1 | (uintptr_t)W2) & 15) == 0,
                   "lpd_edge_mlp: pointers must be 16-byte aligned");
-    EdgeMlpArgs g{P, Q, idx, s1, b1, W2, s2, b2, out, M, N, k, ldp, ldq, ldo, act, slope};
+    LPD_CHECK_ARG(!out_cloud || (N % EM_PTS == 0 && panel_ld >= N), "lpd_edge_mlp: cloud-panel out needs N %% 64 == 0 and panel_ld >= N");
+    EdgeMlpArgs g{P, Q, idx, s1, b1, W2, s2, b2, out, M, N, k, ldp, ldq, ldo, act, slope, out_cloud, panel_ld};
     if (CM == 128 && CO == 128) return x3 ? edge_mlp_x3_launch<128, 128>(g, stream) : edge_mlp_launch<128, 128>(g, stream);
     if (CM == 64 && CO == 64) return x3 ? edge_mlp_x3_launch<64, 64>(g, stream) : edge_mlp_launch<64, 64>(g, stream);
     lpd_set_error("lpd_edge_mlp: (CM=%d, CO=%d) unsupported; built for (128,128) and (64,64)", CM, CO);
@@ -653,21 +670,28 @@ extern "C" int lpd_pack_idx16(const int32_t* idx, uint16_t* idx16, long long M, 
 
 extern "C" int lpd_edge_gather_max16(const float* P, int ldp, const float* Q, int ldq, const uint16_t* idx16, float* out,
                                      int ldo, const float* scale, const float* shift, int M, int N, int C, int k, int act,
-                                     float slope, void* stream_)
+                                     float slope, long long p_cloud, long long q_cloud, long long o_cloud, int panel_ld, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(P && idx16 && out, "lpd_edge_gather_max16: null pointer");
     LPD_CHECK_ARG(M > 0 && N > 0 && k > 0 && M % N == 0, "lpd_edge_gather_max16: bad dims M=%d N=%d k=%d", M, N, k);
     LPD_CHECK_ARG(C > 0 && C % 8 == 0, "lpd_edge_gather_max16: C=%d must be a multiple of 8", C);
-    LPD_CHECK_ARG(ldp % 4 == 0 && ldo % 4 == 0 && (!Q || ldq % 4 == 0), "lpd_edge_gather_max16: leading dims must be multiples of 4");
+    LPD_CHECK_ARG((p_cloud || ldp % 4 == 0) && (o_cloud || ldo % 4 == 0) && (!Q || q_cloud || ldq % 4 == 0),
+                  "lpd_edge_gather_max16: leading dims must be multiples of 4");
     LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)out | (uintptr_t)Q | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0 &&
                   ((uintptr_t)idx16 & 7) == 0, "lpd_edge_gather_max16: pointers must be 16-byte aligned (idx16: 8)");
     LPD_CHECK_ARG(k == 20 && (size_t)N * 8 * sizeof(float) <= 160 * 1024,
                   "lpd_edge_gather_max16: built for k = 20 and N <= 5120 (an 8-channel slice of one cloud in LDS); got k=%d N=%d", k, N);
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_gather_max16: act=%d unsupported (none/ReLU/LeakyReLU)", act);
-    LPD_CHECK_ARG((unsigned long long)M * (unsigned long long)(ldo > ldq ? ldo : ldq) * 4ull < (1ull << 32) &&
+    LPD_CHECK_ARG((unsigned long long)N * (unsigned long long)(o_cloud ? 8 : ldo) * 4ull < (1ull << 32) &&
+                  (unsigned long long)N * (unsigned long long)(q_cloud ? 8 : ldq) * 4ull < (1ull << 32) &&
                   (unsigned long long)M * 40ull < (1ull << 32), "lpd_edge_gather_max16: M=%d too large for 32-bit row offsets", M);
-    GatherArgs g{P, Q, nullptr, out, scale, shift, M, N, C, k, ldp, ldq, ldo, act, slope};
+    // p_cloud / q_cloud / o_cloud != 0: that operand is in cloud-panel layout [cloud][.][N][8] with this many floats between
+    // clouds (its leading dim is then ignored)
+    const long long ps = (long long)panel_ld * 8;
+    GatherArgs g{P, Q, nullptr, out, scale, shift, M, N, C, k, p_cloud ? 8 : ldp, q_cloud ? 8 : ldq, o_cloud ? 8 : ldo, act, slope,
+                 p_cloud ? ps : 8, q_cloud ? ps : 8, o_cloud ? ps : 8,
+                 p_cloud ? p_cloud : (long long)N * ldp, q_cloud ? q_cloud : (long long)N * ldq, o_cloud ? o_cloud : (long long)N * ldo};
     const int nslices = C / 8;
     const size_t lds = (size_t)N * 8 * sizeof(float);
     const float ns = act == 0 ? 1.0f : (act == 1 ? 0.0f : slope);
@@ -686,14 +710,14 @@ extern "C" int lpd_edge_gather_max16(const float* P, int ldp, const float* Q, in
 
 extern "C" int lpd_edge_mlp(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
                             const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo,
-                            int M, int N, int CM, int CO, int k, int act, float slope, void* stream)
+                            int M, int N, int CM, int CO, int k, int act, float slope, long long out_cloud, int panel_ld, void* stream)
 {
-    return edge_mlp_entry(false, P, ldp, Q, ldq, idx, s1, b1, W2, s2, b2, out, ldo, M, N, CM, CO, k, act, slope, stream);
+    return edge_mlp_entry(false, P, ldp, Q, ldq, idx, s1, b1, W2, s2, b2, out, ldo, M, N, CM, CO, k, act, slope, out_cloud, panel_ld, stream);
 }
 
 extern "C" int lpd_edge_mlp_bf16x3(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
                                    const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo,
-                                   int M, int N, int CM, int CO, int k, int act, float slope, void* stream)
+                                   int M, int N, int CM, int CO, int k, int act, float slope, long long out_cloud, int panel_ld, void* stream)
 {
-    return edge_mlp_entry(true, P, ldp, Q, ldq, idx, s1, b1, W2, s2, b2, out, ldo, M, N, CM, CO, k, act, slope, stream);
+    return edge_mlp_entry(true, P, ldp, Q, ldq, idx, s1, b1, W2, s2, b2, out, ldo, M, N, CM, CO, k, act, slope, out_cloud, panel_ld, stream);
 }

@@ -43,7 +43,33 @@ struct GemmArgs {
     int act;
     float slope;
     int accumulate;       // C += result (applied after the epilogue)
+    // Cloud-panel operands [cloud][cols/8][Np][8] (the layout the cloud-resident K-agg kernel streams: an 8-channel slice
+    // of one cloud is one contiguous 32*Np-byte run, a whole cloud one contiguous block): a_cloud / c_cloud = floats
+    // between clouds (the buffer may hold more panels than this operand uses), panel_n = Np = points per cloud
+    // (a multiple of the 128-row block tile, so a block's rows share a cloud).  0 = row-major.
+    long long a_cloud, c_cloud;
+    int panel_n;
+    int panel_ld;   // rows allotted to one panel (>= panel_n; the pad keeps consecutive panels off the same HBM channels)
 };
+
+// PANELS (template): bit 0 = A panel-major, bit 1 = C panel-major; 0 compiles to the plain row-major addressing
+template <int PANELS>
+__device__ __forceinline__ float* gemm_c_ptr(const GemmArgs& g, float* C, int m, int n)
+{
+    if constexpr (PANELS & 2) {   // C already points at the block's cloud; m is the row inside the cloud
+        return C + ((long long)(n >> 3) * g.panel_ld + m) * 8 + (n & 7);
+    } else return C + (long long)m * g.ldc + n;
+}
+
+// float4 of A at (row m, k0 + 4 kq .. +3); k0 is the (uniform) start of a 32-deep k-tile.  Panel form: A points at the
+// block's cloud, m is the row inside the cloud; split so that the k-tile term is scalar and the rest loop-invariant.
+template <int PANELS>
+__device__ __forceinline__ const float* gemm_a_ptr(const float* A, int lda, int panel_ld, int m, int k0, int kq)
+{
+    if constexpr (PANELS & 1)
+        return A + (long long)(k0 >> 3) * panel_ld * 8 + (((kq >> 1) * panel_ld + m) * 8 + (kq & 1) * 4);
+    else return A + (long long)m * lda + k0 + kq * 4;
+}
 
 __device__ __forceinline__ float4 ld4_guard(const float* row, int i, int limit)
 {
@@ -59,8 +85,9 @@ __device__ __forceinline__ float4 ld4_guard(const float* row, int i, int limit)
 // Epilogue of one wave's 64 x (32*TN) accumulator block (32x32 MFMA tile layout: column = lane & 31, row =
 // (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)).  The activation code is uniform: the sigmoid (exp + divide per element)
 // lives behind a scalar branch, the other three are the branch-free  max(v,0) + ns * min(v,0).
-template <int TN, bool SIGMOID>
-__device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, const f32x16 (&acc)[2][TN], float* C, int mw, int nw, int h, int col)
+template <int TN, bool SIGMOID, int PANELS>
+__device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, const f32x16 (&acc)[2][TN], float* C, int mw, int nw, int h, int col,
+                                                int m_cloud0)
 {
     const bool raw = g.splits > 1;
     const float ns = g.act == 0 ? 1.0f : (g.act == 1 ? 0.0f : g.slope);
@@ -85,25 +112,26 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, const f32x16 
                     v = v * sc + sh;
                     if constexpr (SIGMOID) v = 1.0f / (1.0f + __expf(-v));
                     else v = fmaxf(v, 0.0f) + ns * fminf(v, 0.0f);
-                    if (g.accumulate) v += C[(long long)m * g.ldc + n];
+                    if (g.accumulate) v += *gemm_c_ptr<PANELS>(g, C, (PANELS & 2) ? m - m_cloud0 : m, n);
                 }
-                C[(long long)m * g.ldc + n] = v;
+                *gemm_c_ptr<PANELS>(g, C, (PANELS & 2) ? m - m_cloud0 : m, n) = v;
             }
         }
     }
 }
 
-template <int TN>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][TN], float* C, int mw, int nw, int h, int col)
+template <int TN, int PANELS>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][TN], float* C, int mw, int nw, int h, int col,
+                                              int m_cloud0)
 {
-    if (g.act == 3 && g.splits == 1) gemm_epilogue_t<TN, true>(g, acc, C, mw, nw, h, col);
-    else gemm_epilogue_t<TN, false>(g, acc, C, mw, nw, h, col);
+    if (g.act == 3 && g.splits == 1) gemm_epilogue_t<TN, true, PANELS>(g, acc, C, mw, nw, h, col, m_cloud0);
+    else gemm_epilogue_t<TN, false, PANELS>(g, acc, C, mw, nw, h, col, m_cloud0);
 }
 
 // TN: 32-wide n-tiles per wave (1 => BN = 64, 2 => BN = 128).  TM fixed at 2 (BM = 128).
 // KTAIL: the reduction length is not a multiple of 32 (ragged point counts); only then are the operand loads k-guarded
 // (the guards cost ~25 % on the big GEMMs when compiled in unconditionally).
-template <bool A_KMAJOR, bool B_KMAJOR, int TN, bool KTAIL>
+template <bool A_KMAJOR, bool B_KMAJOR, int TN, bool KTAIL, int PANELS = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
 {
     constexpr int BM = 128;
@@ -133,9 +161,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
     const int n0 = blockIdx.x * BN;
     const int kbase = split * g.K;
 
-    const float* A = g.A + (long long)batch * g.sA;
+    // cloud-panel operands: the block's 128 rows lie in one cloud (panel_n % 128 == 0)
+    const int m_cloud0 = (PANELS != 0) ? (m0 / g.panel_n) * g.panel_n : 0;
+    const float* A = g.A + (long long)batch * g.sA + ((PANELS & 1) ? (long long)(m0 / g.panel_n) * g.a_cloud : 0);
     const float* B = g.B + (long long)batch * g.sB;
-    float* C = g.C + (long long)batch * g.sC + (long long)split * g.sCsplit;
+    float* C = g.C + (long long)batch * g.sC + (long long)split * g.sCsplit + ((PANELS & 2) ? (long long)(m0 / g.panel_n) * g.c_cloud : 0);
 
     float4 ra[A_F4], rb[B_F4];
 
@@ -152,8 +182,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
                 int mm = f / (BK / 4), kq = f % (BK / 4);
                 int m = m0 + mm;
                 m = m < g.M ? m : g.M - 1;  // clamp: rows >= M are never stored
-                if constexpr (KTAIL) ra[e] = ld4_guard(A + (long long)m * g.lda, k0 + kq * 4, g.Ktot);
-                else ra[e] = *reinterpret_cast<const float4*>(A + (long long)m * g.lda + k0 + kq * 4);
+                if constexpr (KTAIL) ra[e] = ld4_guard(A + (long long)m * g.lda, k0 + kq * 4, g.Ktot);   // (ragged K: row-major only)
+                else ra[e] = *reinterpret_cast<const float4*>(gemm_a_ptr<PANELS>(A, g.lda, g.panel_ld, (PANELS & 1) ? m - m_cloud0 : m, k0, kq));
             }
         }
 #pragma unroll
@@ -241,7 +271,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
     }
 
     // ---- epilogue ----
-    gemm_epilogue<TN>(g, acc, C, m0 + wm * 64, n0 + wn * (32 * TN), h, col);
+    gemm_epilogue<TN, PANELS>(g, acc, C, m0 + wm * 64, n0 + wn * (32 * TN), h, col, m_cloud0);
 }
 
 
@@ -317,9 +347,9 @@ __device__ __forceinline__ void x3_store(const float4 (&r)[X3Regs<ROWS>::NR], __
 }
 
 // load one operand tile (ROWS x 32 at row0, k0) into r[]; `mem` is the operand base, ld its leading dim
-template <bool KMAJOR, int ROWS, bool KTAIL>
+template <bool KMAJOR, int ROWS, bool KTAIL, int PANELS = 0>
 __device__ __forceinline__ void x3_load(float4 (&r)[X3Regs<ROWS>::NR], const float* mem, int ld, int row0, int nrows, int k0,
-                                        int Ktot, int tid)
+                                        int Ktot, int tid, int panel_ld = 0, int cloud_row0 = 0)
 {
     if constexpr (KMAJOR) {        // memory [k][row]
         constexpr int NP = (2 * ROWS + GEMM_THREADS - 1) / GEMM_THREADS;
@@ -345,12 +375,12 @@ __device__ __forceinline__ void x3_load(float4 (&r)[X3Regs<ROWS>::NR], const flo
             int row = row0 + rr;
             row = row < nrows ? row : nrows - 1;   // clamp: rows past the end are never stored
             if constexpr (KTAIL) r[e] = ld4_guard(mem + (long long)row * ld, k0 + kq * 4, Ktot);
-            else r[e] = *reinterpret_cast<const float4*>(mem + (long long)row * ld + k0 + kq * 4);
+            else r[e] = *reinterpret_cast<const float4*>(gemm_a_ptr<PANELS>(mem, ld, panel_ld, (PANELS & 1) ? row - cloud_row0 : row, k0, kq));
         }
     }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, int TN, bool KTAIL>
+template <bool A_KMAJOR, bool B_KMAJOR, int TN, bool KTAIL, int PANELS = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x3_kernel(GemmArgs g)
 {
     constexpr int BM = 128;
@@ -376,14 +406,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x3_kernel(GemmArgs g)
     const int n0 = blockIdx.x * BN;
     const int kbase = split * g.K;
 
-    const float* A = g.A + (long long)batch * g.sA;
+    // cloud-panel operands: the block's 128 rows lie in one cloud (panel_n % 128 == 0)
+    const int m_cloud0 = (PANELS != 0) ? (m0 / g.panel_n) * g.panel_n : 0;
+    const float* A = g.A + (long long)batch * g.sA + ((PANELS & 1) ? (long long)(m0 / g.panel_n) * g.a_cloud : 0);
     const float* B = g.B + (long long)batch * g.sB;
-    float* C = g.C + (long long)batch * g.sC + (long long)split * g.sCsplit;
+    float* C = g.C + (long long)batch * g.sC + (long long)split * g.sCsplit + ((PANELS & 2) ? (long long)(m0 / g.panel_n) * g.c_cloud : 0);
 
     float4 ra[X3Regs<BM>::NR], rb[X3Regs<BN>::NR];
     auto load_tiles = [&](int kt) {
         const int k0 = kbase + kt * BK;
-        x3_load<A_KMAJOR, BM, KTAIL>(ra, A, g.lda, m0, g.M, k0, g.Ktot, tid);
+        x3_load<A_KMAJOR, BM, KTAIL, PANELS & 1>(ra, A, g.lda, m0, g.M, k0, g.Ktot, tid, g.panel_ld, m_cloud0);
         x3_load<B_KMAJOR, BN, KTAIL>(rb, B, g.ldb, n0, g.N, k0, g.Ktot, tid);
     };
     auto store_tiles = [&]() {
@@ -437,7 +469,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x3_kernel(GemmArgs g)
     }
 
     // ---- epilogue (accumulator layout identical to the f32-input 32x32 tile) ----
-    gemm_epilogue<TN>(g, acc, C, m0 + wm * 64, n0 + wn * (32 * TN), h, col);
+    gemm_epilogue<TN, PANELS>(g, acc, C, m0 + wm * 64, n0 + wn * (32 * TN), h, col, m_cloud0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -624,6 +656,29 @@ int gemm_launch_t(const GemmArgs& g, int batch, hipStream_t stream);
 template <bool AK, bool BK_, int TN, bool KTAIL>
 int gemm_x3_launch_t(const GemmArgs& g, int batch, hipStream_t stream);
 
+// panel-major A and/or C: row-major-A kernels only, 128-column tiles, whole k-tiles
+template <bool BK_, int PANELS>
+int gemm_panel_launch(const GemmArgs& g, bool x3, hipStream_t stream)
+{
+    constexpr int BM = 128, BN = 128;
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, 1);
+    if (x3) {
+        constexpr int LDK = GEMM_BK + 8;
+        size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(__bf16);
+        auto kern = gemm_bf16x3_kernel<false, BK_, 2, false, PANELS>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, stream, g);
+    } else {
+        constexpr int LDA = BM + 1, LDB = BK_ ? BN + 4 : BN + 1;
+        size_t lds = (size_t)2 * GEMM_BK * (LDA + LDB) * sizeof(float);
+        auto kern = gemm_f32_kernel<false, BK_, 2, false, PANELS>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, stream, g);
+    }
+    LPD_CHECK_LAUNCH("lpd_gemm(panels)");
+    return LPD_OK;
+}
+
 template <bool AK, bool BK_, int TN>
 int gemm_launch(const GemmArgs& g, int batch, bool x3, hipStream_t stream)
 {
@@ -669,8 +724,13 @@ int gemm_launch_t(const GemmArgs& g, int batch, hipStream_t stream)
 static int gemm_entry(bool x3, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                       int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC,
                       int splits, float* splitk_ws, const float* bias, const float* scale, const float* shift,
-                      int act, float slope, int accumulate, void* stream_)
+                      int act, float slope, int accumulate, long long a_cloud, long long c_cloud, int panel_n, int panel_ld, void* stream_)
 {
+    const bool a_panels = a_cloud != 0, c_panels = c_cloud != 0;
+    LPD_CHECK_ARG(!(a_panels || c_panels) || (!a_kmajor && batch == 1 && splits == 1 && K % 32 == 0 && panel_n > 0 &&
+                                              panel_n % 128 == 0 && M % panel_n == 0 && panel_ld >= panel_n),
+                  "lpd_gemm: cloud-panel A / C need a_kmajor = 0, batch = 1, splits = 1, K %% 32 == 0, points per cloud %% 128 == 0");
+    if (a_panels) lda = 4;   // unused; keeps the alignment checks below happy
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(A && B && C, "lpd_gemm: null pointer");
     LPD_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "lpd_gemm: bad dims M=%d N=%d K=%d batch=%d", M, N, K, batch);
@@ -692,10 +752,21 @@ static int gemm_entry(bool x3, const float* A, const float* B, float* C, int M, 
     g.splits = splits;
     g.bias = bias; g.scale = scale; g.shift = shift; g.act = act; g.slope = slope;
     g.accumulate = accumulate;
+    g.a_cloud = a_cloud;
+    g.c_cloud = c_cloud;
+    g.panel_n = panel_n > 0 ? panel_n : 1;
+    g.panel_ld = panel_ld;
     if (splits > 1) {
         g.C = splitk_ws; g.ldc = N; g.sC = (long long)splits * M * N; g.sCsplit = (long long)M * N;
     } else {
         g.C = C; g.ldc = ldc; g.sC = sC; g.sCsplit = 0;
+    }
+    if (a_panels || c_panels) {
+        const int pm = (a_panels ? 1 : 0) | (c_panels ? 2 : 0);
+        if (b_kmajor) return pm == 1 ? gemm_panel_launch<true, 1>(g, x3, stream) : pm == 2 ? gemm_panel_launch<true, 2>(g, x3, stream)
+                                                                                            : gemm_panel_launch<true, 3>(g, x3, stream);
+        return pm == 1 ? gemm_panel_launch<false, 1>(g, x3, stream) : pm == 2 ? gemm_panel_launch<false, 2>(g, x3, stream)
+                                                                              : gemm_panel_launch<false, 3>(g, x3, stream);
     }
     const int tn = N > 64 ? 2 : 1;
     int rc;
@@ -719,19 +790,19 @@ static int gemm_entry(bool x3, const float* A, const float* B, float* C, int M, 
 extern "C" int lpd_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                         int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC,
                         int splits, float* splitk_ws, const float* bias, const float* scale, const float* shift,
-                        int act, float slope, int accumulate, void* stream)
+                        int act, float slope, int accumulate, long long a_cloud, long long c_cloud, int panel_n, int panel_ld, void* stream)
 {
     return gemm_entry(false, A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, batch, sA, sB, sC, splits, splitk_ws, bias,
-                      scale, shift, act, slope, accumulate, stream);
+                      scale, shift, act, slope, accumulate, a_cloud, c_cloud, panel_n, panel_ld, stream);
 }
 
 extern "C" int lpd_gemm_bf16x3(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                                int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC,
                                int splits, float* splitk_ws, const float* bias, const float* scale, const float* shift,
-                               int act, float slope, int accumulate, void* stream)
+                               int act, float slope, int accumulate, long long a_cloud, long long c_cloud, int panel_n, int panel_ld, void* stream)
 {
     return gemm_entry(true, A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, batch, sA, sB, sC, splits, splitk_ws, bias,
-                      scale, shift, act, slope, accumulate, stream);
+                      scale, shift, act, slope, accumulate, a_cloud, c_cloud, panel_n, panel_ld, stream);
 }
 
 // bytes of the fragment buffer for an N x K weight: hi and lo arrays of ceil(N/32) * ceil(K/16) fragments of 1 KiB

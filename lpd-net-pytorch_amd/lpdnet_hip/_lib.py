@@ -26,9 +26,9 @@ SIGNATURES = {
     "lpd_last_error": [],
     "lpd_knn": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_int, _c_p],
     "lpd_gemm": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                 _c_ll, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_p],
+                 _c_ll, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_ll, _c_ll, _c_int, _c_int, _c_p],
 "lpd_gemm_bf16x3": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                 _c_ll, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_p],
+                 _c_ll, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_ll, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_prep_b_bytes": [_c_int, _c_int],
     "lpd_gemm_prep_b": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p],
     "lpd_gemm_x3w": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_p],
@@ -37,12 +37,12 @@ SIGNATURES = {
     "lpd_edge_gather_max": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int,
                             _c_int, _c_int, _c_f, _c_p],
     "lpd_edge_gather_max16": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int,
-                              _c_int, _c_int, _c_f, _c_p],
+                              _c_int, _c_int, _c_f, _c_ll, _c_ll, _c_ll, _c_int, _c_p],
     "lpd_pack_idx16": [_c_p, _c_p, ctypes.c_longlong, _c_int, _c_p],
     "lpd_edge_mlp": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int,
-                     _c_int, _c_int, _c_int, _c_int, _c_f, _c_p],
+                     _c_int, _c_int, _c_int, _c_int, _c_f, _c_ll, _c_int, _c_p],
     "lpd_edge_mlp_bf16x3": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int,
-                     _c_int, _c_int, _c_int, _c_int, _c_f, _c_p],
+                     _c_int, _c_int, _c_int, _c_int, _c_f, _c_ll, _c_int, _c_p],
     "lpd_linear_smallk": [_c_p, _c_int, _c_p, _c_int, _c_int, _c_ll, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int,
                           _c_p, _c_p, _c_p, _c_int, _c_f, _c_p],
     "lpd_transpose": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_p],

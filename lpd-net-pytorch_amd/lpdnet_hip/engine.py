@@ -156,11 +156,20 @@ def _knn_rows(rows, B, N, C, k):
     return ops.knn(ops.transpose(rows.view(B, N, C).contiguous()), k)
 
 
+# cloud-panel [B, C/8, N, 8] buffers for x1|x2|x3 and the SN1 projections (LPD_PANELS=0: row-major everywhere)
+PANEL_LAYOUT = __import__("os").environ.get("LPD_PANELS", "1") != "0"
+
+
+def _kagg_cloud_resident(idx, N, M, act):
+    """the cloud-resident K-agg kernel is built for this shape (an 8-channel slice of one cloud fits LDS, k = 20)"""
+    return (idx.shape[-1] == 20 and N * 32 <= 160 * 1024 and act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY)
+            and M * 512 * 4 < 2 ** 32)
+
+
 def kagg(P, Q, idx, N, *, scale, shift, act, slope, out):
     """K-agg dispatch: the cloud-resident kernel when an 8-channel slice of one cloud fits LDS (N <= 5120) and k = 20,
     the direct gather otherwise (cfg5: N = 16384, k = 64).  Same bits either way."""
-    k = idx.shape[-1]
-    if k == 20 and N * 32 <= 160 * 1024 and act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY) and P.shape[0] * 512 * 4 < 2 ** 32:
+    if _kagg_cloud_resident(idx, N, P.shape[0], act):
         return ops.edge_gather_max16(P, Q, ops.pack_idx16(idx), N, scale=scale, shift=shift, act=act, slope=slope, out=out)
     return ops.edge_gather_max(P, Q, idx, N, scale=scale, shift=shift, act=act, slope=slope, out=out)
 
@@ -187,22 +196,37 @@ def lpdnet_features_eval(net, x):
             f = ops.apply_transform(f, tf, N)
     # dynamic graph in feature space
     idx_f = _knn_rows(f, B, N, 64, k)
-    cat = torch.empty((M, 512), dtype=torch.float32, device=x.device)                   # [x1 | x2 | x3]
-    pq = ops.linear(f, split_edge_weight(net.convDG1, "cat_nc"))                        # [M,256] = [P | Q]
     s1, b1 = bn_affine(net.convDG1[1])
     s2, b2 = bn_affine(net.convDG2[1])
+    s3, b3 = bn_affine(net.convSN1[1])
+    sc, bc = bn_affine(net.bn3_lpd)
+    pq = ops.linear(f, split_edge_weight(net.convDG1, "cat_nc"))                        # [M,256] = [P | Q]
+    if PANEL_LAYOUT and N % 128 == 0 and _kagg_cloud_resident(idx_f, N, M, act):
+        # [x1 | x2 | x3] and the SN1 projections live in CLOUD-PANEL buffers [B, C/8, N, 8]: the cloud-resident K-agg kernel
+        # streams one 8-channel slice of a whole cloud per workgroup, which in this layout is ONE contiguous 32*N-byte run
+        # (row-major: N pieces of 32 bytes, ~4x slower through L1/L2), while a GEMM block's 128 rows x K still sit inside one
+        # cloud's contiguous block; the GEMMs read / write the panels directly.
+        cat = ops.panels_empty(B, N, 512, x.device)
+        ops.edge_gather_max16(pq[:, :128], pq[:, 128:], ops.pack_idx16(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
+        ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope, out=cat[:, 16:32])
+        idx_x = _knn_rows(x.view(B * N, 3), B, N, 3, k)      # static graph in Cartesian space (raw xyz even when t3d, :226,255)
+        pq3 = ops.gemm(cat[:, 16:32], split_edge_weight(net.convSN1, "cat_nc"), b_kmajor=False, a_panels=True, out_panels=True)
+        ops.edge_gather_max16(pq3[:, 0:32], pq3[:, 32:64], ops.pack_idx16(idx_x), N, scale=s3, shift=b3, act=act, slope=slope, out=cat[:, 32:64])
+        if DEBUG_AUX is not None:
+            DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=ops.panels_to_rows(cat))
+        feat = ops.gemm(cat, _w2d(net.conv3_lpd), b_kmajor=False, a_panels=True, scale=sc, shift=bc, act=act, slope=slope)
+        return feat, B, N
+    cat = torch.empty((M, 512), dtype=torch.float32, device=x.device)                   # [x1 | x2 | x3]
     kagg(pq[:, :128], pq[:, 128:], idx_f, N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:128])
     ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope,
                  out=cat[:, 128:256])
     # static graph in Cartesian space (raw xyz even when t3d, lpdnet_model.py:226,255)
     idx_x = _knn_rows(x.view(B * N, 3), B, N, 3, k)
     pq = ops.linear(cat[:, 128:256], split_edge_weight(net.convSN1, "cat_nc"))          # [M,512]
-    s3, b3 = bn_affine(net.convSN1[1])
     kagg(pq[:, :256], pq[:, 256:], idx_x, N, scale=s3, shift=b3, act=act, slope=slope, out=cat[:, 256:512])
     if DEBUG_AUX is not None:
         DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=cat)
-    s, b = bn_affine(net.bn3_lpd)
-    return ops.linear(cat, _w2d(net.conv3_lpd), scale=s, shift=b, act=act, slope=slope), B, N
+    return ops.linear(cat, _w2d(net.conv3_lpd), scale=sc, shift=bc, act=act, slope=slope), B, N
 
 
 def lpdnet_origin_features_eval(net, x):

@@ -172,14 +172,19 @@ def _weight_frags(B2, b_kmajor, N, K):
 
 
 def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=None, act=ACT_NONE, slope=0.01,
-         out=None, splits=1, accumulate=False, exact=False):
+         out=None, splits=1, accumulate=False, exact=False, a_panels=False, out_panels=False):
     """Single (2-D) or batched (3-D) GEMM with fused epilogue.
+
+    a_panels / out_panels: A / out are cloud-panel tensors [B, cols/8, N, 8] (the layout the cloud-resident K-agg kernel
+    streams; see panels_empty / panels_to_rows) instead of row-major matrices.
 
     A: [M,K] (a_kmajor False) or [K,M] (True); B: [K,N] (b_kmajor True) or [N,K] (False).
     3-D inputs add a leading batch dim (must be contiguous in that dim ordering).
     """
     _req(A, "A")
     _req(B, "B")
+    if a_panels or out_panels:
+        return _gemm_panels(A, B, a_kmajor, b_kmajor, bias, scale, shift, act, slope, out, accumulate, exact, a_panels, out_panels)
     batched = A.dim() == 3
     if batched:
         if B.dim() != 3 or A.shape[0] != B.shape[0]:
@@ -224,7 +229,89 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
           and (not a_kmajor or b_kmajor))
     _call(f"gemm{'x3' if x3 else ''}[{M}x{N}x{K}]", lib.lpd_gemm_bf16x3 if x3 else lib.lpd_gemm, _ptr(A), _ptr(B), _ptr(out), M, N, K, lda, ldb, ldc, int(a_kmajor), int(b_kmajor), nb,
                             sA, sB, sC, splits, _ptr(ws), _ptr(bias), _ptr(scale), _ptr(shift), act, float(slope),
-                            int(bool(accumulate)), _stream())
+                            int(bool(accumulate)), 0, 0, 0, 0, _stream())
+    return out
+
+
+PANEL_PAD_ROWS = 8   # 256 B between consecutive panels: a power-of-two panel stride would put them all on the same HBM channels
+
+
+def panels_empty(B, N, C, device):
+    """Uninitialised CLOUD-PANEL activation buffer, logically [B, C/8, N, 8]: element (cloud b, point n, channel c) at
+    [b, c // 8, n, c % 8].  A channel range c0:c1 (multiples of 8) is the view buf[:, c0//8:c1//8].  Panels are padded to
+    N + PANEL_PAD_ROWS rows in memory (the returned tensor is the [:, :, :N] view)."""
+    return torch.empty((B, C // 8, N + PANEL_PAD_ROWS, 8), dtype=torch.float32, device=device)[:, :, :N]
+
+
+def panels_to_rows(P):
+    """cloud-panel [B, C/8, N, 8] -> row-major [B*N, C] copy (diagnostics / tests)."""
+    Bc, Pn, N, _ = P.shape
+    return P.permute(0, 2, 1, 3).reshape(Bc * N, Pn * 8).contiguous()
+
+
+def rows_to_panels(X, B):
+    """row-major [B*N, C] -> cloud-panel [B, C/8, N, 8] copy (tests)."""
+    M, C = X.shape
+    out = panels_empty(B, M // B, C, X.device)
+    out.copy_(X.reshape(B, M // B, C // 8, 8).permute(0, 2, 1, 3))
+    return out
+
+
+def _is_panels(t):
+    """a (view of a) cloud-panel buffer: [B, P, N, 8] with strides (anything, panel_ld * 8 >= N * 8, 8, 1)"""
+    return (t is not None and t.dim() == 4 and t.shape[3] == 8 and t.stride(3) == 1 and t.stride(2) == 8
+            and t.stride(1) % 8 == 0 and t.stride(1) >= t.shape[2] * 8)
+
+
+def _panel_ld(*tensors):
+    """rows per panel in memory; all cloud-panel operands of one call must agree"""
+    lds = {t.stride(1) // 8 for t in tensors if t is not None and t.dim() == 4}
+    if len(lds) > 1:
+        raise ValueError("cloud-panel operands of one call must share the panel stride")
+    return lds.pop() if lds else 0
+
+
+def _gemm_panels(A, B, a_kmajor, b_kmajor, bias, scale, shift, act, slope, out, accumulate, exact, a_panels, out_panels):
+    if a_kmajor or B.dim() != 2:
+        raise ValueError("gemm: cloud-panel operands need a_kmajor=False and a 2-D B")
+    a_cloud = c_cloud = 0
+    if a_panels:
+        if not _is_panels(A):
+            raise ValueError("gemm: a_panels expects a cloud-panel [B, K/8, N, 8] tensor")
+        nc, Np = A.shape[0], A.shape[2]
+        M, K, lda, a_cloud = nc * Np, A.shape[1] * 8, 8, A.stride(0)
+    else:
+        lda = _rows(A, "A")
+        M, K = A.shape
+        nc = Np = None
+    ldb = _rows(B, "B")
+    Kb, N = (B.shape[0], B.shape[1]) if b_kmajor else (B.shape[1], B.shape[0])
+    if K != Kb:
+        raise ValueError(f"gemm: inner dims differ ({K} vs {Kb})")
+    if out_panels:
+        if out is None:
+            if nc is None:
+                raise ValueError("gemm: out_panels without a_panels needs an explicit cloud-panel out")
+            out = panels_empty(nc, Np, N, A.device)
+        if not _is_panels(out) or out.shape[1] * 8 != N or out.shape[0] * out.shape[2] != M:
+            raise ValueError("gemm: out_panels expects a cloud-panel [B, N/8, Np, 8] tensor")
+        if Np is not None and out.shape[2] != Np:
+            raise ValueError("gemm: A and out disagree on the points per cloud")
+        Np = out.shape[2]
+        ldc, c_cloud = 8, out.stride(0)
+    else:
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+        ldc = _rows(out, "out")
+    if K % 32 or Np % 128:
+        raise ValueError("gemm: cloud-panel operands need K % 32 == 0 and points per cloud % 128 == 0")
+    _req(out, "out")
+    bias, scale, shift = _vec(bias, "bias", N), _vec(scale, "scale", N), _vec(shift, "shift", N)
+    lib = _lib.load()
+    x3 = GEMM_BF16X3 and not exact and _EXACT_DEPTH == 0 and N >= 128 and M >= 128
+    _call(f"gemm{'x3' if x3 else ''}[{M}x{N}x{K}]", lib.lpd_gemm_bf16x3 if x3 else lib.lpd_gemm, _ptr(A), _ptr(B), _ptr(out), M, N, K, lda, ldb,
+          ldc, 0, int(b_kmajor), 1, 0, 0, 0, 1, None, _ptr(bias), _ptr(scale), _ptr(shift), act, float(slope), int(bool(accumulate)),
+          a_cloud, c_cloud, Np, _panel_ld(A if a_panels else None, out if out_panels else None), _stream())
     return out
 
 
@@ -315,25 +402,39 @@ def pack_idx16(idx):
 
 
 def edge_gather_max16(P, Q, idx16, N, *, scale=None, shift=None, act=ACT_NONE, slope=0.01, out=None):
-    """Cloud-resident K-agg (k = 20, N <= 5120): same result as edge_gather_max; idx16 from pack_idx16."""
-    ldp = _rows(P, "P")
-    ldq = _rows(Q, "Q") if Q is not None else 0
+    """Cloud-resident K-agg (k = 20, N <= 5120): same result as edge_gather_max; idx16 from pack_idx16.
+    P, Q and out are row-major [M, C] (2-D, column slices allowed) or cloud-panel views [B, C/8, N, 8] (4-D): with panels
+    a block's 8-channel slice is one contiguous 32*N-byte run."""
     _req(idx16, "idx16", torch.int16)
-    M, C = P.shape
+    pan_p, pan_q = P.dim() == 4, Q is not None and Q.dim() == 4
+    M, C = (P.shape[0] * P.shape[2], P.shape[1] * 8) if pan_p else P.shape
     k = idx16.shape[1]
     if idx16.dim() != 2 or idx16.shape[0] != (M + 31) // 32 * 32 or not idx16.is_contiguous():
         raise ValueError("edge_gather_max16: idx16 must come from pack_idx16 of this graph")
     if out is None:
         out = torch.empty((M, C), dtype=torch.float32, device=P.device)
-    ldo = _rows(out, "out")
+    pan_o = out.dim() == 4
+    for t, pan, name in ((P, pan_p, "P"), (Q, pan_q, "Q"), (out, pan_o, "out")):
+        _req(t, name)
+        if t is not None and pan and (not _is_panels(t) or t.shape[1] * 8 != C or t.shape[2] != N or t.shape[0] * N != M):
+            raise ValueError(f"edge_gather_max16: cloud-panel {name} must be a [B, C/8, N, 8] view")
+    ldp = 8 if pan_p else _rows(P, "P")
+    ldq = 0 if Q is None else (8 if pan_q else _rows(Q, "Q"))
+    ldo = 8 if pan_o else _rows(out, "out")
     scale, shift = _vec(scale, "scale", C), _vec(shift, "shift", C)
     lib = _lib.load()
     _call(f"edge_gather_max16[C={C}]", lib.lpd_edge_gather_max16, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx16), _ptr(out), ldo,
-          _ptr(scale), _ptr(shift), M, N, C, k, act, float(slope), _stream())
+          _ptr(scale), _ptr(shift), M, N, C, k, act, float(slope), P.stride(0) if pan_p else 0, Q.stride(0) if pan_q else 0,
+          out.stride(0) if pan_o else 0, _panel_ld(P, Q, out), _stream())
     return out
 
 
 def edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, *, act=ACT_LEAKY, slope=0.01, out=None, exact=False):
+    """(docstring below)  `out` may be a cloud-panel view [B, CO/8, N, 8]."""
+    return _edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, act, slope, out, exact)
+
+
+def _edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, act, slope, out, exact):
     """Fused DG1-activation -> DG2 conv -> BN -> act -> max over k (include/lpd_hip.h lpd_edge_mlp)."""
     ldp = _rows(P, "P")
     ldq = _rows(Q, "Q") if Q is not None else 0
@@ -348,13 +449,20 @@ def edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, *, act=ACT_LEAKY, slope=0.01, out
         raise ValueError("edge_mlp: W2 input width != P width")
     if out is None:
         out = torch.empty((M, CO), dtype=torch.float32, device=P.device)
-    ldo = _rows(out, "out")
+    out_cloud = 0
+    if out.dim() == 4:
+        if not _is_panels(out) or out.shape[1] * 8 != CO or out.shape[0] * out.shape[2] != M or out.shape[2] != N:
+            raise ValueError("edge_mlp: cloud-panel out must be a [B, CO/8, N, 8] view")
+        _req(out, "out")
+        ldo, out_cloud = 8, out.stride(0)
+    else:
+        ldo = _rows(out, "out")
     s1, b1 = _vec(s1, "s1", CM), _vec(b1, "b1", CM)
     s2, b2 = _vec(s2, "s2", CO), _vec(b2, "b2", CO)
     lib = _lib.load()
     x3 = GEMM_BF16X3 and not exact and _EXACT_DEPTH == 0
     _call(f"edge_mlp{'x3' if x3 else ''}[{CM}->{CO}]", lib.lpd_edge_mlp_bf16x3 if x3 else lib.lpd_edge_mlp, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(s1), _ptr(b1), _ptr(W2), _ptr(s2),
-                                _ptr(b2), _ptr(out), ldo, M, N, CM, CO, k, act, float(slope), _stream())
+                                _ptr(b2), _ptr(out), ldo, M, N, CM, CO, k, act, float(slope), out_cloud, _panel_ld(out), _stream())
     return out
 
 

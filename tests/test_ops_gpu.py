@@ -354,3 +354,52 @@ def test_gemm_weight_fragment_path(cuda, M, N, K, bk):
     finally:
         ops.PROFILE = None
     assert any(k.startswith("gemmx3w") for k in prof), list(prof)
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["f32mfma", "bf16x3"])
+def test_cloud_panel_operands(cuda, exact):
+    """Cloud-panel buffers [B, C/8, N, 8] through GEMM (A and C, also as panel sub-ranges of wider buffers), the fused edge
+    MLP (out) and the cloud-resident K-agg (P, Q, out in every combination): bit-identical to the row-major results (only
+    the addressing changes)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    Bc, Np, K, N = 3, 512, 128, 512
+    M = Bc * Np
+    X = torch.randn(M, K, generator=g).to(cuda)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    sc, sh = torch.randn(N, generator=g).to(cuda), torch.randn(N, generator=g).to(cuda)
+    want = ops.gemm(X, W, b_kmajor=False, scale=sc, shift=sh, act=ops.ACT_LEAKY, exact=exact)
+    big = ops.panels_empty(Bc, Np, K + 64, cuda)              # A as a panel sub-range of a wider buffer
+    big[:, 8:8 + K // 8] = ops.rows_to_panels(X, Bc)
+    got = ops.gemm(big[:, 8:8 + K // 8], W, b_kmajor=False, scale=sc, shift=sh, act=ops.ACT_LEAKY, exact=exact, a_panels=True, out_panels=True)
+    assert got.shape == (Bc, N // 8, Np, 8)
+    assert torch.equal(ops.panels_to_rows(got), want)
+    wide = ops.panels_empty(Bc, Np, N + 128, cuda)
+    ops.gemm(X, W, b_kmajor=False, scale=sc, shift=sh, act=ops.ACT_LEAKY, exact=exact, out=wide[:, 16:], out_panels=True)
+    assert torch.equal(ops.panels_to_rows(wide[:, 16:]), want)
+    rowm = ops.gemm(big[:, 8:8 + K // 8], W, b_kmajor=False, scale=sc, shift=sh, act=ops.ACT_LEAKY, exact=exact, a_panels=True)
+    assert torch.equal(rowm, want)
+    # K-agg: every combination of cloud-panel / row-major P, Q, out
+    B_, Nq, C, k = 2, 768, 256, 20
+    P, Q, idx, scale, shift = _edge_inputs(B_, Nq, C, k, 5)
+    P, Q, idx = P.to(cuda), Q.to(cuda), idx.to(cuda)
+    ref = ops.edge_gather_max(P, Q, idx, Nq, scale=scale.to(cuda), shift=shift.to(cuda), act=ops.ACT_LEAKY)
+    i16 = ops.pack_idx16(idx)
+    pqbuf = ops.panels_empty(B_, Nq, 2 * C, cuda)             # P and Q as the two panel halves of one buffer (like the pipeline)
+    pqbuf[:, :C // 8] = ops.rows_to_panels(P, B_)
+    pqbuf[:, C // 8:] = ops.rows_to_panels(Q, B_)
+    for lay in range(8):
+        p_ = pqbuf[:, :C // 8] if lay & 1 else P
+        q_ = pqbuf[:, C // 8:] if lay & 2 else Q
+        o_ = ops.panels_empty(B_, Nq, C, cuda) if lay & 4 else torch.empty(B_ * Nq, C, device=cuda)
+        ops.edge_gather_max16(p_, q_, i16, Nq, scale=scale.to(cuda), shift=shift.to(cuda), act=ops.ACT_LEAKY, out=o_)
+        assert torch.equal(ops.panels_to_rows(o_) if lay & 4 else o_, ref), lay
+    # edge MLP into a panel sub-range
+    P2, Q2, idx2, s1, b1 = _edge_inputs(2, 256, 128, 20, 9)
+    W2 = (torch.randn(128, 128, generator=g) / 11).to(cuda)
+    s2, b2 = torch.randn(128, generator=g).to(cuda), torch.randn(128, generator=g).to(cuda)
+    args = (P2.to(cuda), Q2.to(cuda), idx2.to(cuda), 256, s1.to(cuda), b1.to(cuda), W2, s2, b2)
+    rowm = ops.edge_mlp(*args, exact=exact)
+    pan = ops.panels_empty(2, 256, 512, cuda)
+    ops.edge_mlp(*args, exact=exact, out=pan[:, 16:32])
+    assert torch.equal(ops.panels_to_rows(pan[:, 16:32]), rowm)
