@@ -201,6 +201,15 @@ int lpd_metric_loss(const float* q, long long q_sb, const float* pos, long long 
                     int bq, int P, int Ng, int D, float m1, float m2, int use_min, int lazy, int ignore_zero, int quad,
                     float* loss, float* minmax, float* gq, float* gpos, float* gneg, float* gother, void* stream);
 
+/*
+ * Descriptor retrieval (evaluate.py:162-206: KDTree(database).query(query, k = 25) per query): the k nearest database
+ * descriptors of every query by squared Euclidean distance, ascending, ties -> lower index.
+ *   S [nq][ndb] = Q D^T (row-major, from lpd_gemm), Q [nq][ldq], D [ndb][ldd] the descriptors (for the norms),
+ *   idx [nq][k] int32, dist [nq][k] squared distances, ws nq + ndb floats.
+ */
+int lpd_retrieval_topk(const float* S, const float* Q, int ldq, const float* D, int ldd, int nq, int ndb, int dim, int k,
+                       int32_t* idx, float* dist, float* ws, void* stream);
+
 /* Per-cloud Morton (Z-order) reordering of the input points: out[b][r] = xyz[b][perm[b][r]].  The descriptor is
  * invariant to point order; sorting makes the neighbour gathers of the aggregation kernels cache-local.
  * xyz/out [B][N][3] (out != xyz), perm [B][N] int32 or NULL.  N <= 16384. */

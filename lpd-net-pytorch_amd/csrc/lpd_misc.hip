@@ -197,6 +197,56 @@ __global__ void mul_kernel(const float* __restrict__ a, const float* __restrict_
     if (i < n) o[i] = a[i] * b[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Descriptor retrieval (evaluate.py:162-206 builds a KDTree per database and queries recall_num = 25
+// neighbours per query): squared L2 distances from the score matrix S = Q D^T and the row norms, then the k smallest per
+// query by k passes of a wave-wide lexicographic (distance, index) arg-min.  nq and ndb are a few hundred to a few
+// thousand 256-d descriptors: one wave per query, rows stay in L2.
+// ---------------------------------------------------------------------------------------------
+__global__ void rownorm_kernel(const float* __restrict__ X, int ld, int n, int dim, float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int c = 0; c < dim; ++c) s = fmaf(X[(size_t)i * ld + c], X[(size_t)i * ld + c], s);
+    out[i] = s;
+}
+
+__global__ __launch_bounds__(256) void retrieval_topk_kernel(const float* __restrict__ S, const float* __restrict__ qn,
+                                                             const float* __restrict__ dn, int nq, int ndb, int k,
+                                                             int32_t* __restrict__ idx, float* __restrict__ dist)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float* s = S + (size_t)q * ndb;
+    const float nq2 = qn[q];
+    float last_v = -INFINITY;
+    int last_j = -1;
+    for (int r = 0; r < k; ++r) {
+        float best_v = INFINITY;
+        int best_j = 0x7fffffff;
+        for (int j = lane; j < ndb; j += 64) {
+            const float v = fmaxf(nq2 + dn[j] - 2.0f * s[j], 0.0f);
+            const bool after_last = v > last_v || (v == last_v && j > last_j);          // not yet emitted
+            const bool better = v < best_v || (v == best_v && j < best_j);
+            if (after_last && better) { best_v = v; best_j = j; }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = __shfl_xor(best_v, m, 64);
+            const int oj = __shfl_xor(best_j, m, 64);
+            if (ov < best_v || (ov == best_v && oj < best_j)) { best_v = ov; best_j = oj; }
+        }
+        if (lane == 0) {
+            idx[(size_t)q * k + r] = best_j == 0x7fffffff ? -1 : best_j;
+            dist[(size_t)q * k + r] = best_v;
+        }
+        last_v = best_v;
+        last_j = best_j;
+    }
+}
+
 }  // namespace
 
 extern "C" int lpd_linear_smallk(const float* X, int ldx, const float* W, int w_sn, int w_sk, long long w_sb,
@@ -277,5 +327,21 @@ extern "C" int lpd_mul(const float* a, const float* b, float* out, long long n, 
     LPD_CHECK_ARG(a && b && out && n > 0, "lpd_mul: bad arguments");
     hipLaunchKernelGGL(mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, b, out, n);
     LPD_CHECK_LAUNCH("lpd_mul");
+    return LPD_OK;
+}
+
+extern "C" int lpd_retrieval_topk(const float* S, const float* Q, int ldq, const float* D, int ldd, int nq, int ndb, int dim,
+                                  int k, int32_t* idx, float* dist, float* ws, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(S && Q && D && idx && dist && ws, "lpd_retrieval_topk: null pointer");
+    LPD_CHECK_ARG(nq > 0 && ndb > 0 && dim > 0 && k > 0 && k <= ndb, "lpd_retrieval_topk: bad dims nq=%d ndb=%d dim=%d k=%d", nq, ndb, dim, k);
+    float* qn = ws;            // [nq]
+    float* dn = ws + nq;       // [ndb]
+    hipLaunchKernelGGL(rownorm_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, Q, ldq, nq, dim, qn);
+    hipLaunchKernelGGL(rownorm_kernel, dim3((ndb + 255) / 256), dim3(256), 0, stream, D, ldd, ndb, dim, dn);
+    hipLaunchKernelGGL(retrieval_topk_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, S, (const float*)qn, (const float*)dn, nq, ndb, k, idx,
+                       dist);
+    LPD_CHECK_LAUNCH("lpd_retrieval_topk");
     return LPD_OK;
 }

@@ -8,6 +8,11 @@ AROUND the model call, with plain arguments:
   train_step         train_pointnetvlad.py:121-134   zero_grad / run_model / loss / backward / optimizer.step
   get_latent_vectors evaluate.py:96-159              eval mode, batched forward with a ragged tail, numpy out,
                                                      model.train() afterwards
+and the two "next" rows of SURVEY.md section 8f that sit right behind them:
+  get_recall         evaluate.py:162-206             Recall@N / top-1 similarity / one-percent recall of one (database run,
+                                                     query run) pair; the KDTree per pair becomes one GPU top-k launch
+  save_checkpoint /  train_pointnetvlad.py:64-77,    the reference's .ckpt dict (epoch, iter, state_dict, optimizer, recall)
+  load_pretrained    172-199                         and bare .t7 state_dicts, with or without the DataParallel `module.` prefix
 """
 import numpy as np
 import torch
@@ -67,3 +72,74 @@ def get_latent_vectors(model, clouds, batch_size):
     if not outs:
         return np.zeros((0, 0), dtype=np.float32)
     return np.concatenate(outs, axis=0)
+
+
+RECALL_NUM = 25   # evaluate.py:19
+
+
+def get_recall(m, n, DATABASE_VECTORS, QUERY_VECTORS, QUERY_SETS, recall_num=RECALL_NUM, device=None):
+    """evaluate.py:162-206 with the per-pair KDTree replaced by one launch of lpd_retrieval_topk.
+    DATABASE_VECTORS[m] [n_db, D], QUERY_VECTORS[n] [n_q, D] (numpy, as get_latent_vectors returns them);
+    QUERY_SETS[n][i][m] = indices of the true neighbours of query i of run n in run m.
+    -> (recall [recall_num] cumulative percent, top-1 similarity scores, one-percent recall)."""
+    from . import ops
+    database_output, queries_output = DATABASE_VECTORS[m], QUERY_VECTORS[n]
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    D = torch.as_tensor(np.ascontiguousarray(database_output), dtype=torch.float32, device=dev)
+    Q = torch.as_tensor(np.ascontiguousarray(queries_output), dtype=torch.float32, device=dev)
+    k = min(recall_num, len(database_output))
+    idx, _ = ops.retrieval_topk(Q, D, k)
+    indices = idx.cpu().numpy()
+    recall = [0] * recall_num
+    top1_similarity_score = []
+    one_percent_retrieved = 0
+    threshold = max(int(round(len(database_output) / 100.0)), 1)
+    num_evaluated = 0
+    for i in range(len(queries_output)):
+        true_neighbors = QUERY_SETS[n][i][m]
+        if len(true_neighbors) == 0:
+            continue
+        num_evaluated += 1
+        truth = set(int(t) for t in true_neighbors)
+        for j in range(k):
+            if int(indices[i][j]) in truth:
+                if j == 0:
+                    top1_similarity_score.append(float(np.dot(queries_output[i], database_output[indices[i][j]])))
+                recall[j] += 1
+                break
+        if truth.intersection(int(t) for t in indices[i][:threshold]):
+            one_percent_retrieved += 1
+    one_percent_recall = (one_percent_retrieved / float(num_evaluated)) * 100
+    recall = (np.cumsum(recall) / float(num_evaluated)) * 100
+    return recall, top1_similarity_score, one_percent_recall
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") and isinstance(model.module, torch.nn.Module) else model
+
+
+def _strip_module_prefix(state_dict):
+    """checkpoints written from an nn.DataParallel wrapper carry `module.` in front of every key (script.py:62-81)"""
+    if state_dict and all(k.startswith("module.") for k in state_dict):
+        return {k[len("module."):]: v for k, v in state_dict.items()}
+    return state_dict
+
+
+def save_checkpoint(path, model, optimizer, epoch, total_iterations, recall):
+    """train_pointnetvlad.py:172-199: the reference's .ckpt dictionary (weights of the unwrapped model)."""
+    torch.save({"epoch": epoch, "iter": total_iterations, "state_dict": _unwrap(model).state_dict(),
+                "optimizer": optimizer.state_dict(), "recall": recall}, path)
+
+
+def load_pretrained(model, path, optimizer=None, map_location="cpu"):
+    """train_pointnetvlad.py:64-77: a path ending in '7' (.t7) holds a bare state_dict (loaded with strict=False), anything
+    else the .ckpt dictionary (strict=True, optimizer state restored).  -> (starting_epoch, total_iterations)."""
+    target = _unwrap(model)
+    blob = torch.load(path, map_location=map_location)
+    if str(path)[-1] == "7":
+        target.load_state_dict(_strip_module_prefix(blob), strict=False)
+        return 0, 0
+    target.load_state_dict(_strip_module_prefix(blob["state_dict"]), strict=True)
+    if optimizer is not None:
+        optimizer.load_state_dict(blob["optimizer"])
+    return blob["epoch"] + 1, blob["iter"]

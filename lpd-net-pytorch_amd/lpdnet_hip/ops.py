@@ -110,7 +110,13 @@ def knn_pm(x_pm, B, N, k, impl=None):
 # descriptors, csrc/lpd_gemm.hip) unless the call asks for exact fp32 (layers whose output feeds the kNN) or this switch
 # is off (LPD_GEMM_FP32=1: every product on the f32-input MFMA, bit-for-bit the round-1 numerics).
 GEMM_BF16X3 = __import__("os").environ.get("LPD_GEMM_FP32", "0") != "1"
-_EXACT_DEPTH = 0
+
+
+class _ExactState(__import__("threading").local):   # per thread: nn.DataParallel runs one forward per device thread
+    depth = 0
+
+
+_EXACT = _ExactState()
 
 
 # Train-mode FORWARD products stay exact by default: batch statistics over a handful of clouds (B = 6 in the step-0
@@ -124,12 +130,10 @@ class exact_gemm:
     kNN: the neighbour indices must not depend on the GEMM precision switch)."""
 
     def __enter__(self):
-        global _EXACT_DEPTH
-        _EXACT_DEPTH += 1
+        _EXACT.depth += 1
 
     def __exit__(self, *exc):
-        global _EXACT_DEPTH
-        _EXACT_DEPTH -= 1
+        _EXACT.depth -= 1
         return False
 
 
@@ -216,7 +220,7 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
     # once, B never staged through LDS (lpd_gemm_x3w).  Measured against the generic split-bf16 kernel, whose k-major
     # staging transposes in registers: 3.6M x 128 x 128 1.49 -> 1.15 ms, 180k x 512 x 1024 1.42 -> 0.72 ms; for row-major
     # weights (forward layers) and K = 64 the generic kernel is as fast or faster, so those stay there.
-    if (GEMM_BF16X3 and not exact and _EXACT_DEPTH == 0 and not a_kmajor and b_kmajor and not batched and splits == 1
+    if (GEMM_BF16X3 and not exact and _EXACT.depth == 0 and not a_kmajor and b_kmajor and not batched and splits == 1
             and M >= 1024 and N >= 64 and K >= 128 and N * K <= (1 << 22)):
         frags = _weight_frags(B, b_kmajor, N, K)
         _call(f"gemmx3w[{M}x{N}x{K}]", lib.lpd_gemm_x3w, _ptr(A), lda, _ptr(frags), _ptr(out), ldc, M, N, K, _ptr(bias), _ptr(scale),
@@ -225,7 +229,7 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
     # split-bf16 where it is faster (measured, tools/gemm_bench.py): outputs of at least 128 x 128 with a row-major A
     # or with both operands k-major (weight gradients); skinny outputs (per-cloud rows, 64 clusters) and the k-major
     # pooling product stay on the f32-input MFMA
-    x3 = (GEMM_BF16X3 and not exact and _EXACT_DEPTH == 0 and N >= 128 and M >= 128
+    x3 = (GEMM_BF16X3 and not exact and _EXACT.depth == 0 and N >= 128 and M >= 128
           and (not a_kmajor or b_kmajor))
     _call(f"gemm{'x3' if x3 else ''}[{M}x{N}x{K}]", lib.lpd_gemm_bf16x3 if x3 else lib.lpd_gemm, _ptr(A), _ptr(B), _ptr(out), M, N, K, lda, ldb, ldc, int(a_kmajor), int(b_kmajor), nb,
                             sA, sB, sC, splits, _ptr(ws), _ptr(bias), _ptr(scale), _ptr(shift), act, float(slope),
@@ -308,7 +312,7 @@ def _gemm_panels(A, B, a_kmajor, b_kmajor, bias, scale, shift, act, slope, out, 
     _req(out, "out")
     bias, scale, shift = _vec(bias, "bias", N), _vec(scale, "scale", N), _vec(shift, "shift", N)
     lib = _lib.load()
-    x3 = GEMM_BF16X3 and not exact and _EXACT_DEPTH == 0 and N >= 128 and M >= 128
+    x3 = GEMM_BF16X3 and not exact and _EXACT.depth == 0 and N >= 128 and M >= 128
     _call(f"gemm{'x3' if x3 else ''}[{M}x{N}x{K}]", lib.lpd_gemm_bf16x3 if x3 else lib.lpd_gemm, _ptr(A), _ptr(B), _ptr(out), M, N, K, lda, ldb,
           ldc, 0, int(b_kmajor), 1, 0, 0, 0, 1, None, _ptr(bias), _ptr(scale), _ptr(shift), act, float(slope), int(bool(accumulate)),
           a_cloud, c_cloud, Np, _panel_ld(A if a_panels else None, out if out_panels else None), _stream())
@@ -460,7 +464,7 @@ def _edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, act, slope, out, exact):
     s1, b1 = _vec(s1, "s1", CM), _vec(b1, "b1", CM)
     s2, b2 = _vec(s2, "s2", CO), _vec(b2, "b2", CO)
     lib = _lib.load()
-    x3 = GEMM_BF16X3 and not exact and _EXACT_DEPTH == 0
+    x3 = GEMM_BF16X3 and not exact and _EXACT.depth == 0
     _call(f"edge_mlp{'x3' if x3 else ''}[{CM}->{CO}]", lib.lpd_edge_mlp_bf16x3 if x3 else lib.lpd_edge_mlp, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(s1), _ptr(b1), _ptr(W2), _ptr(s2),
                                 _ptr(b2), _ptr(out), ldo, M, N, CM, CO, k, act, float(slope), out_cloud, _panel_ld(out), _stream())
     return out
@@ -796,3 +800,21 @@ def vlad_finalize_bwd(dOut, v, aux, cw2, B, F, KC):
     _call("vlad_finalize_bwd", lib.lpd_vlad_finalize_bwd, _ptr(dOut), _ptr(v), _ptr(aux["inv_c"]), _ptr(aux["inv_g"]),
           _ptr(aux["asum"]), _ptr(cw2), _ptr(dVraw), _ptr(dasum), _ptr(dcw2), B, F, KC, _stream())
     return dVraw, dasum, dcw2
+
+
+def retrieval_topk(Q, D, k):
+    """k nearest database descriptors D [ndb, dim] of every query Q [nq, dim] (squared L2, ascending; ties -> lower index):
+    -> (idx int32 [nq, k], dist fp32 [nq, k]).  The score matrix Q D^T runs on the exact f32-input MFMA GEMM."""
+    ldq, ldd = _rows(Q, "Q"), _rows(D, "D")
+    nq, dim = Q.shape
+    ndb = D.shape[0]
+    if D.shape[1] != dim or k > ndb:
+        raise ValueError("retrieval_topk: Q and D must share the descriptor size and k <= len(D)")
+    S = gemm(Q, D, a_kmajor=False, b_kmajor=False, exact=True)
+    idx = torch.empty((nq, k), dtype=torch.int32, device=Q.device)
+    dist = torch.empty((nq, k), dtype=torch.float32, device=Q.device)
+    ws = torch.empty((nq + ndb,), dtype=torch.float32, device=Q.device)
+    lib = _lib.load()
+    _call("retrieval_topk", lib.lpd_retrieval_topk, _ptr(S), _ptr(Q), ldq, _ptr(D), ldd, nq, ndb, dim, k, _ptr(idx), _ptr(dist), _ptr(ws),
+          _stream())
+    return idx, dist

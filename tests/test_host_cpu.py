@@ -97,3 +97,52 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "lpd_oracle.so" not in text, f
+
+
+def test_retrieval_oracle_matches_the_kdtree_form():
+    """The numpy brute-force restatement of evaluate.py:162-206 (what the GPU path is compared with) gives exactly what the
+    reference's own library call (sklearn KDTree) gives, on synthetic runs with the reference's data structure."""
+    import numpy as np
+    from oracle import retrieval_oracle as ro
+    db, qv, qsets = ro.synthetic_runs(seed=3)
+    for m in range(3):
+        for n in range(3):
+            if m == n:
+                continue
+            a = ro.get_recall_kdtree(m, n, db, qv, qsets)
+            b = ro.get_recall_bruteforce(m, n, db, qv, qsets)
+            assert np.allclose(a[0], b[0]) and a[2] == b[2] and np.allclose(a[1], b[1])
+            assert 0 < b[0][0] <= b[0][-1] <= 100      # not vacuous: some but not all queries are answered at rank 1
+
+
+def test_checkpoint_interop_with_the_reference_format(tmp_path):
+    """save_checkpoint / load_pretrained (train_pointnetvlad.py:64-77,172-199): the .ckpt dictionary keys, strict load,
+    optimizer state, the `module.` prefix of DataParallel checkpoints, and bare .t7 state_dicts (strict=False)."""
+    from lpdnet_hip import harness
+    from util.PointNetVlad import PointNetVlad
+    m = PointNetVlad(num_points=256, featnet="lpdnet")
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    ck = tmp_path / "3-model.ckpt"
+    harness.save_checkpoint(ck, torch.nn.DataParallel(m) if False else m, opt, epoch=3, total_iterations=1234, recall=81.5)
+    blob = torch.load(ck)
+    assert set(blob) == {"epoch", "iter", "state_dict", "optimizer", "recall"} and blob["iter"] == 1234
+    assert list(blob["state_dict"]) == list(sd0)
+    m2 = PointNetVlad(num_points=256, featnet="lpdnet")
+    opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    assert harness.load_pretrained(m2, ck, opt2) == (4, 1234)
+    assert all(torch.equal(m2.state_dict()[k], v) for k, v in sd0.items())
+    # a checkpoint written from an nn.DataParallel wrapper ("module." keys), as the reference's script.py handles
+    blob["state_dict"] = {"module." + k: v for k, v in blob["state_dict"].items()}
+    ck2 = tmp_path / "dp.ckpt"
+    torch.save(blob, ck2)
+    m3 = PointNetVlad(num_points=256, featnet="lpdnet")
+    harness.load_pretrained(m3, ck2)
+    assert all(torch.equal(m3.state_dict()[k], v) for k, v in sd0.items())
+    # bare state_dict (.t7): non-strict, keys that are missing stay at their initial values
+    t7 = tmp_path / "weights.t7"
+    partial = {k: v for k, v in sd0.items() if k.startswith("net_vlad.")}
+    torch.save(partial, t7)
+    m4 = PointNetVlad(num_points=256, featnet="lpdnet")
+    assert harness.load_pretrained(m4, t7) == (0, 0)
+    assert torch.equal(m4.state_dict()["net_vlad.cluster_weights"], sd0["net_vlad.cluster_weights"])

@@ -255,3 +255,28 @@ def test_train_step_helper(cuda):
     loss = harness.train_step(m, opt, tup[:, :1], tup[:, 1:3], tup[:, 3:5], tup[:, 5:6])
     assert torch.isfinite(loss) and loss.item() > 0
     assert not torch.equal(before, m.net_vlad.hidden1_weights.detach())
+
+
+def test_get_recall_matches_the_oracle(cuda):
+    """harness.get_recall (GPU top-k per (database run, query run) pair, evaluate.py:162-206) against the brute-force oracle
+    (itself pinned to the reference's KDTree call in tests/test_host_cpu.py): identical recall curves, top-1 similarities
+    and one-percent recall; and the raw top-k against numpy, rank by rank."""
+    import numpy as np
+    from lpdnet_hip import harness, ops
+    from oracle import retrieval_oracle as ro
+    db, qv, qsets = ro.synthetic_runs(seed=7, runs=3, per_run=(300, 170, 410))
+    for m in range(3):
+        for n in range(3):
+            if m == n:
+                continue
+            got = harness.get_recall(m, n, db, qv, qsets)
+            want = ro.get_recall_bruteforce(m, n, db, qv, qsets)
+            assert np.allclose(got[0], want[0]) and got[2] == want[2]
+            assert np.allclose(got[1], want[1], atol=1e-6)
+    Q = torch.from_numpy(qv[1]).to(cuda)
+    D = torch.from_numpy(db[2]).to(cuda)
+    idx, dist = ops.retrieval_topk(Q, D, 25)
+    d2 = ((qv[1][:, None, :].astype(np.float64) - db[2][None].astype(np.float64)) ** 2).sum(-1)
+    order = np.argsort(d2, axis=1, kind="stable")[:, :25]
+    assert (idx.cpu().numpy() == order).all()
+    assert np.allclose(dist.cpu().numpy(), np.take_along_axis(d2, order, 1), rtol=1e-4, atol=1e-6)
