@@ -11,6 +11,8 @@ AROUND the model call, with plain arguments:
 and the two "next" rows of SURVEY.md section 8f that sit right behind them:
   get_recall         evaluate.py:162-206             Recall@N / top-1 similarity / one-percent recall of one (database run,
                                                      query run) pair; the KDTree per pair becomes one GPU top-k launch
+  get_random_hard_negatives  util/data.py:103-115    the hard_neg_num nearest of the sampled negatives of a query (KDTree over 4000
+                                                     latent vectors per item there; one GPU top-k launch here)
   save_checkpoint /  train_pointnetvlad.py:64-77,    the reference's .ckpt dict (epoch, iter, state_dict, optimizer, recall)
   load_pretrained    172-199                         and bare .t7 state_dicts, with or without the DataParallel `module.` prefix
 """
@@ -143,3 +145,21 @@ def load_pretrained(model, path, optimizer=None, map_location="cpu"):
     if optimizer is not None:
         optimizer.load_state_dict(blob["optimizer"])
     return blob["epoch"] + 1, blob["iter"]
+
+
+def get_random_hard_negatives(query_vec, random_negs, hard_neg_num, latent_vectors):
+    """util/data.py:103-115: among the training items `random_negs` (indices into the latent-vector table), the
+    `hard_neg_num` whose descriptors are nearest to `query_vec`, nearest first, as a list of item indices.
+    latent_vectors: the table of all training descriptors (the reference's global TRAINING_LATENT_VECTORS), a numpy array
+    or -- to keep it resident between calls -- a CUDA tensor [n_items, D]."""
+    from . import ops
+    if isinstance(latent_vectors, torch.Tensor) and latent_vectors.is_cuda:
+        table = latent_vectors
+    else:
+        table = torch.as_tensor(np.ascontiguousarray(latent_vectors), dtype=torch.float32,
+                                device=torch.device("cuda", torch.cuda.current_device()))
+    cand = torch.as_tensor(np.asarray(random_negs, dtype=np.int64), device=table.device)
+    D = table.index_select(0, cand).contiguous()
+    q = torch.as_tensor(np.asarray(query_vec, dtype=np.float32), device=table.device).reshape(1, -1)
+    idx, _ = ops.retrieval_topk(q, D, int(hard_neg_num))
+    return [int(random_negs[j]) for j in idx[0].cpu().tolist()]

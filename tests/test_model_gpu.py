@@ -280,3 +280,21 @@ def test_get_recall_matches_the_oracle(cuda):
     order = np.argsort(d2, axis=1, kind="stable")[:, :25]
     assert (idx.cpu().numpy() == order).all()
     assert np.allclose(dist.cpu().numpy(), np.take_along_axis(d2, order, 1), rtol=1e-4, atol=1e-6)
+
+
+def test_random_hard_negatives_match_the_kdtree_form(cuda):
+    """harness.get_random_hard_negatives (util/data.py:103-115) against the reference's own formulation (sklearn KDTree over
+    the sampled negatives' latent vectors), table given as numpy and as a resident CUDA tensor."""
+    import numpy as np
+    from sklearn.neighbors import KDTree
+    from lpdnet_hip import harness
+    g = np.random.default_rng(5)
+    table = g.standard_normal((6000, 256)).astype(np.float32)
+    table /= np.linalg.norm(table, axis=1, keepdims=True)
+    dev_table = torch.from_numpy(table).to(cuda)
+    for trial in range(3):
+        negs = g.choice(len(table), size=4000, replace=False).tolist()
+        query = table[g.integers(len(table))] + 0.05 * g.standard_normal(256).astype(np.float32)
+        want = np.array(negs)[KDTree(table[negs]).query(np.array([query]), k=10)[1][0]].tolist()
+        assert harness.get_random_hard_negatives(query, negs, 10, table) == want
+        assert harness.get_random_hard_negatives(query, negs, 10, dev_table) == want
