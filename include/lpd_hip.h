@@ -210,6 +210,9 @@ int lpd_metric_loss(const float* q, long long q_sb, const float* pos, long long 
 int lpd_retrieval_topk(const float* S, const float* Q, int ldq, const float* D, int ldd, int nq, int ndb, int dim, int k,
                        int32_t* idx, float* dist, float* ws, void* stream);
 
+/* float64 -> float32, n elements (submap files are float64, loading_pointclouds.py:26-35; evaluate.py:115 `.float()`). */
+int lpd_f64_to_f32(const double* in, float* out, long long n, void* stream);
+
 /* Per-cloud Morton (Z-order) reordering of the input points: out[b][r] = xyz[b][perm[b][r]].  The descriptor is
  * invariant to point order; sorting makes the neighbour gathers of the aggregation kernels cache-local.
  * xyz/out [B][N][3] (out != xyz), perm [B][N] int32 or NULL.  N <= 16384. */

@@ -247,6 +247,19 @@ __global__ __launch_bounds__(256) void retrieval_topk_kernel(const float* __rest
     }
 }
 
+// float64 -> float32 (round to nearest even, what numpy's astype / torch's .float() do): the Oxford submaps are stored as
+// 4096 x 3 float64 (loading_pointclouds.py:26-35); the raw bytes go over PCIe and are narrowed here.
+__global__ void f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, long long n)
+{
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i + 1 < n) {
+        const double2 v = *reinterpret_cast<const double2*>(in + i);
+        *reinterpret_cast<float2*>(out + i) = make_float2((float)v.x, (float)v.y);
+    } else if (i < n) {
+        out[i] = (float)in[i];
+    }
+}
+
 }  // namespace
 
 extern "C" int lpd_linear_smallk(const float* X, int ldx, const float* W, int w_sn, int w_sk, long long w_sb,
@@ -343,5 +356,15 @@ extern "C" int lpd_retrieval_topk(const float* S, const float* Q, int ldq, const
     hipLaunchKernelGGL(retrieval_topk_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, S, (const float*)qn, (const float*)dn, nq, ndb, k, idx,
                        dist);
     LPD_CHECK_LAUNCH("lpd_retrieval_topk");
+    return LPD_OK;
+}
+
+extern "C" int lpd_f64_to_f32(const double* in, float* out, long long n, void* stream)
+{
+    LPD_CHECK_ARG(in && out && n > 0, "lpd_f64_to_f32: bad arguments");
+    LPD_CHECK_ARG((((uintptr_t)in & 15) | ((uintptr_t)out & 7)) == 0, "lpd_f64_to_f32: in must be 16-byte, out 8-byte aligned");
+    const long long threads = (n + 1) / 2;
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, n);
+    LPD_CHECK_LAUNCH("lpd_f64_to_f32");
     return LPD_OK;
 }

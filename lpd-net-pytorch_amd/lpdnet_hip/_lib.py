@@ -33,6 +33,7 @@ SIGNATURES = {
     "lpd_gemm_prep_b": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p],
     "lpd_gemm_x3w": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_p],
     "lpd_retrieval_topk": [_c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
+    "lpd_f64_to_f32": [_c_p, _c_p, _c_ll, _c_p],
     "lpd_knn_pm": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_int, _c_p],
     "lpd_knn_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
     "lpd_edge_gather_max": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int,

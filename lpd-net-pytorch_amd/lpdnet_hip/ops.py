@@ -818,3 +818,14 @@ def retrieval_topk(Q, D, k):
     _call("retrieval_topk", lib.lpd_retrieval_topk, _ptr(S), _ptr(Q), ldq, _ptr(D), ldd, nq, ndb, dim, k, _ptr(idx), _ptr(dist), _ptr(ws),
           _stream())
     return idx, dist
+
+
+def f64_to_f32(x64, out=None):
+    """float64 CUDA tensor -> float32 (same shape), round to nearest even."""
+    _req(x64, "x", torch.float64)
+    x64 = x64.contiguous()
+    if out is None:
+        out = torch.empty(x64.shape, dtype=torch.float32, device=x64.device)
+    lib = _lib.load()
+    _call("f64_to_f32", lib.lpd_f64_to_f32, _ptr(x64), _ptr(out), x64.numel(), _stream())
+    return out

@@ -146,3 +146,20 @@ def test_checkpoint_interop_with_the_reference_format(tmp_path):
     m4 = PointNetVlad(num_points=256, featnet="lpdnet")
     assert harness.load_pretrained(m4, t7) == (0, 0)
     assert torch.equal(m4.state_dict()["net_vlad.cluster_weights"], sd0["net_vlad.cluster_weights"])
+
+
+def test_load_pc_file_contract(tmp_path):
+    """ingest.load_pc_file / load_pc_files (loading_pointclouds.py:26-47): float64 [4096,3] from a header-less little-endian
+    file, an empty array for a file of the wrong size, which load_pc_files skips."""
+    import numpy as np
+    from lpdnet_hip import ingest
+    g = np.random.default_rng(0)
+    good = g.standard_normal((2, 4096, 3))
+    good[0].tofile(tmp_path / "a.bin")
+    good[1].tofile(tmp_path / "c.bin")
+    g.standard_normal(100).tofile(tmp_path / "b.bin")
+    pc = ingest.load_pc_file("a.bin", str(tmp_path))
+    assert pc.dtype == np.float64 and pc.shape == (4096, 3) and np.array_equal(pc, good[0])
+    assert ingest.load_pc_file("b.bin", str(tmp_path)).shape == (0,)
+    pcs = ingest.load_pc_files(["a.bin", "b.bin", "c.bin"], str(tmp_path))
+    assert pcs.shape == (2, 4096, 3) and np.array_equal(pcs, good)

@@ -298,3 +298,35 @@ def test_random_hard_negatives_match_the_kdtree_form(cuda):
         want = np.array(negs)[KDTree(table[negs]).query(np.array([query]), k=10)[1][0]].tolist()
         assert harness.get_random_hard_negatives(query, negs, 10, table) == want
         assert harness.get_random_hard_negatives(query, negs, 10, dev_table) == want
+
+
+def test_submap_stream_and_latent_vectors_from_files(cuda, tmp_path):
+    """ingest.SubmapStream: float64 submap files -> pinned staging -> side-stream copy -> float32 on the GPU, identical to
+    np.fromfile(...).astype(float32) of the valid files in order, ragged tail, wrong-size files skipped; and
+    get_latent_vectors_from_files == get_latent_vectors on the loaded arrays."""
+    import numpy as np
+    from lpdnet_hip import harness, ingest
+    from util.PointNetVlad import PointNetVlad
+    g = np.random.default_rng(1)
+    N, names, clouds = 256, [], []
+    for i in range(11):
+        name = f"s{i}.bin"
+        if i in (3, 7):
+            g.standard_normal(50).tofile(tmp_path / name)            # wrong size: skipped
+        else:
+            c = g.uniform(-1, 1, (N, 3)) * (1.0 + 1e-9 * i)
+            c.tofile(tmp_path / name)
+            clouds.append(c)
+        names.append(name)
+    want = np.stack(clouds).astype(np.float32)
+    got = torch.cat([b.clone() for b in ingest.SubmapStream(names, 4, str(tmp_path), cuda, num_points=N)], 0)
+    assert got.shape == (9, 1, N, 3) and got.dtype == torch.float32
+    assert np.array_equal(got.cpu().numpy()[:, 0], want)
+    m = PointNetVlad(num_points=N, featnet="lpdnet").to(cuda).eval()
+    ref = harness.get_latent_vectors(m, np.stack(clouds), 4)
+    out = ingest.get_latent_vectors_from_files(m, names, 4, str(tmp_path), num_points=N)
+    assert out.shape == ref.shape and np.allclose(out, ref, atol=1e-6) and not m.training
+    # conversion kernel: round-to-nearest-even like numpy, odd element counts, large and tiny magnitudes
+    x = torch.tensor([1.0 + 2.0 ** -24, 1.0 + 3 * 2.0 ** -24, 1e300, -1e-300, 3.4028235677973366e38, 0.1, -7.25], dtype=torch.float64)
+    from lpdnet_hip import ops
+    assert np.array_equal(ops.f64_to_f32(x.to(cuda)).cpu().numpy(), x.numpy().astype(np.float32), equal_nan=True)
