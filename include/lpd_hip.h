@@ -56,7 +56,7 @@ const char* lpd_last_error(void);
  */
 int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* ws, int impl, void* stream);
 long long lpd_knn_workspace_floats(int B, int C, int N, int k);
-/* The same on point-major rows x_pm [B*N][ld] (the pipeline's activation layout; C <= 64, k <= 32): no transposes. */
+/* The same on point-major rows x_pm [B*N][ld] (the pipeline's activation layout; C <= 64, k <= 64): no transposes. */
 int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k, int32_t* idx, float* ws, int impl, void* stream);
 
 /*

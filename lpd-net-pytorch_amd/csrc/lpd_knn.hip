@@ -313,6 +313,9 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restric
 constexpr int KNN3_WAVES = 4;
 constexpr int KNN3_THREADS = KNN3_WAVES * 64;
 constexpr int KNN3_QCAP = 40;   // queue slots per lane; a tile can add 16
+// floats of LDS per wave: the queue (QCAP float2 per lane), reused at the end to merge the two half-lists (2 * 64 * KMAX)
+template <int KMAX>
+constexpr int knn3_wave_floats() { return KNN3_QCAP * 128 > 2 * 64 * KMAX ? KNN3_QCAP * 128 : 2 * 64 * KMAX; }
 
 // ---- packed operand layout -------------------------------------------------------------------------------
 // Ablations on MI355X (tools/knn_bench.py, impl 10..41) showed the scan is INSTRUCTION-ISSUE bound, not MFMA- or
@@ -464,8 +467,9 @@ __device__ __forceinline__ void knn3_tile(float (&a)[CP], float4 (&x4)[4], const
 }
 
 template <int CP, int KMAX>
-__global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
-                                                             int32_t* __restrict__ idx, int N, int k, int blocks_per_cloud, int dbg)
+__global__ __launch_bounds__(KNN3_THREADS, ((KMAX > 32 || (KMAX == 32 && CP == 32)) ? 1 : 2))   // long lists: one wave per SIMD
+void knn3_kernel(const float* __restrict__ xp, const float* __restrict__ xx, int32_t* __restrict__ idx, int N, int k,
+                 int blocks_per_cloud, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __re
     const float* xpb = xp + (size_t)b * N * (2 * CP);
     const float* xxb = xx + (size_t)b * N;
     const bool vec_ok = (N & 3) == 0;
-    float2* myq = reinterpret_cast<float2*>(smem) + (size_t)wave * KNN3_QCAP * 64 + lane;   // slot s at myq[s*64]
+    float2* myq = reinterpret_cast<float2*>(smem + (size_t)wave * knn3_wave_floats<KMAX>()) + lane;   // slot s at myq[s*64]
 
     float qreg[CP];
     knn3_ld_ops<CP>(xpb, N, q, h, qreg);
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn3_kernel(const float* __re
 
     // ---- merge the two half-lists: both halves publish their sorted lists in this wave's (now free) queue region and
     // the lower half-wave walks the two lists with a 2-pointer merge (k steps of two LDS reads and a compare) ----
-    float* mv = smem + (size_t)wave * KNN3_QCAP * 128;   // wave region: QCAP*64 float2 = QCAP*128 floats >= 2*64*KMAX
+    float* mv = smem + (size_t)wave * knn3_wave_floats<KMAX>();   // wave region >= 2*64*KMAX floats
     int* mi = reinterpret_cast<int*>(mv + 64 * KMAX);
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) {
@@ -1131,14 +1135,13 @@ int knn6_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
 template <int CP, int KMAX>
 int knn3_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg = 0)
 {
-    static_assert(KNN3_QCAP * 128 >= 2 * 64 * KMAX, "merge region must fit the wave's queue region");
     // packed operands live behind the squared norms in the caller's workspace: [xx: B*N][xp: B*N*2*CP]
     float* xp = const_cast<float*>(xx) + (size_t)B * N;
     if (x) {   // x == nullptr: already packed (point-major entry)
         hipLaunchKernelGGL(knn_pack_kernel<CP>, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xp, C, N);
         LPD_CHECK_LAUNCH("lpd_knn(pack)");
     }
-    size_t lds = (size_t)KNN3_WAVES * KNN3_QCAP * 64 * sizeof(float2);
+    size_t lds = (size_t)KNN3_WAVES * knn3_wave_floats<KMAX>() * sizeof(float);
     const int bpc = (N + KNN3_WAVES * 32 - 1) / (KNN3_WAVES * 32);
     auto kern = knn3_kernel<CP, KMAX>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1187,7 +1190,8 @@ int knn3_dispatch_k(const float* x, const float* xx, int32_t* idx, int B, int C,
 {
     if (k <= 20) return knn3_launch<CP, 20>(x, xx, idx, B, C, N, k, stream);
     if (k <= 32) return knn3_launch<CP, 32>(x, xx, idx, B, C, N, k, stream);
-    // k > 32: a 64-entry register list; the first-generation kernel (one wave per SIMD, 512 VGPRs) takes those
+    if (k <= 64) return knn3_launch<CP, 64>(x, xx, idx, B, C, N, k, stream);   // 64-entry lists: one wave per SIMD (stress config K = 64)
+    if (!x) { lpd_set_error("lpd_knn_pm: k=%d > 64 unsupported on the point-major entry", k); return LPD_ERR_UNSUPPORTED; }
     return knn_dispatch_k<CP>(x, xx, idx, B, C, N, k, 0, stream);
 }
 
@@ -1284,7 +1288,7 @@ extern "C" int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k,
     LPD_CHECK_ARG(x_pm && idx && ws, "lpd_knn_pm: null pointer");
     LPD_CHECK_ARG(B > 0 && C > 0 && N > 0 && ld >= C, "lpd_knn_pm: bad dims B=%d C=%d N=%d ld=%d", B, C, N, ld);
     LPD_CHECK_ARG(k > 0 && k <= N, "lpd_knn_pm: need 0 < k <= N (k=%d N=%d)", k, N);
-    LPD_CHECK_ARG(C <= 64 && k <= 32, "lpd_knn_pm: built for C <= 64, k <= 32 (got C=%d k=%d); use lpd_knn on the channel-major tensor", C, k);
+    LPD_CHECK_ARG(C <= 64 && k <= 64, "lpd_knn_pm: built for C <= 64, k <= 64 (got C=%d k=%d); use lpd_knn on the channel-major tensor", C, k);
     LPD_CHECK_ARG(C <= 4 || ((uintptr_t)x_pm & 15) == 0, "lpd_knn_pm: x_pm must be 16-byte aligned");
     const long long M = (long long)B * N;
     float* xp = ws + M;

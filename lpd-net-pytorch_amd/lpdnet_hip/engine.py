@@ -149,9 +149,9 @@ def stn3d_eval(net, h, B, N):
 # ------------------------------------------------------------------------------------------------
 def _knn_rows(rows, B, N, C, k):
     """kNN graph of point-major rows [B*N, C] (util/lpdnet_model.py:317-326): the point-major C-ABI entry when it is built
-    for the shape (C <= 64, k <= 32), else the channel-major one on the transposed tensor."""
+    for the shape (C <= 64, k <= 64), else the channel-major one on the transposed tensor."""
     rows = rows.reshape(B * N, C)
-    if C <= 64 and k <= 32:
+    if C <= 64 and k <= 64:
         return ops.knn_pm(rows, B, N, k)
     return ops.knn(ops.transpose(rows.view(B, N, C).contiguous()), k)
 
