@@ -77,6 +77,34 @@ def test_knn_exact_ties_lower_index_first(cuda, C, N, impl):
         assert (got_pm == oidx).all()
 
 
+@pytest.mark.parametrize("impl", [0, 4])
+@pytest.mark.parametrize("case", ["offset", "huge", "tiny", "identical", "line"])
+def test_knn_ill_conditioned_clouds(cuda, case, impl):
+    """Inputs on which the fp32 pd evaluation is badly conditioned or fully degenerate: a cloud far from the origin
+    (catastrophic cancellation: pd is quantised at ulp(|x|^2) ~ 1e-3, ties everywhere), very large and very small scales,
+    all points identical, all points on a line.  The skip bounds of the best-first kernel must stay conservative (their
+    slack scales with max |x|^2) and the tie rule must hold: every row equals the oracle's."""
+    ops = _ops()
+    g = np.random.default_rng(7)
+    N, C = 2048, 3
+    x = g.uniform(-1, 1, (2, N, C)).astype(np.float32)
+    if case == "offset":
+        x = (x + np.float32(100.0)).astype(np.float32)
+    elif case == "huge":
+        x = (x * np.float32(3e4)).astype(np.float32)
+    elif case == "tiny":
+        x = (x * np.float32(1e-4)).astype(np.float32)
+    elif case == "identical":
+        x[:] = np.float32(0.37)
+    elif case == "line":
+        x[:, :, 1:] = 0
+    oidx, _ = orc.knn_np(x, 20)
+    got = ops.knn_pm(torch.from_numpy(x.reshape(-1, C)).to(cuda), 2, N, 20, impl=impl).cpu().numpy()
+    assert (got == oidx).all(), f"{(got != oidx).any(-1).sum()} rows differ"
+    if case == "identical":
+        assert (got == np.arange(20)).all()
+
+
 @pytest.mark.parametrize("tag", ["knn_c3_n4096_k20", "knn_c64_n4096_k20", "knn_c3_n16384_k64", "knn_c3_n100_k7"])
 def test_knn_vs_reference_golden(cuda, golden_dir, tag):
     ops = _ops()
