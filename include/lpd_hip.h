@@ -98,12 +98,16 @@ int lpd_gemm_bf16x3(const float* A, const float* B, float* C, int M, int N, int 
  * Split-bf16 GEMM for a weight-shaped B: lpd_gemm_prep_b splits B (either layout) once into hi/lo bf16 stored in MFMA
  * fragment order (lpd_gemm_prep_b_bytes(N, K) bytes, 16-byte aligned); lpd_gemm_x3w then computes
  * C = act((A.B + bias) * scale + shift) for row-major A [M][lda] without staging or splitting B again (each wave streams
- * its 32-column fragments from L2 into registers).  Used for dX = dY.W in the backward pass and the NetVLAD assignment.
+ * its 32-column fragments from L2 into registers).  Used for the wide forward layers (conv3 512 -> 1024, the split edge
+ * projections) and for dX = dY.W in the backward pass.  a_cloud / c_cloud / panel_n / panel_ld: cloud-panel A / C as in
+ * lpd_gemm (0 = row-major).  impl: 0 = by shape (N >= 256: 128 x 256 blocks, each wave a 128 x 64 strip; else 128 x 128),
+ * 2 / 3 = 128 x 128 / 128 x 256 blocks forced.
  */
 long long lpd_gemm_prep_b_bytes(int N, int K);
 int lpd_gemm_prep_b(const float* B, int ldb, int b_kmajor, int N, int K, void* frags, void* stream);
 int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
-                 const float* scale, const float* shift, int act, float slope, int accumulate, void* stream);
+                 const float* scale, const float* shift, int act, float slope, int accumulate,
+                 long long a_cloud, long long c_cloud, int panel_n, int panel_ld, int impl, void* stream);
 
 /*
  * kNN-graph aggregation (K-agg).  Replaces the gather/repeat/cat of util/lpdnet_model.py:331-363

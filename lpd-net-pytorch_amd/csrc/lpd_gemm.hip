@@ -71,6 +71,21 @@ __device__ __forceinline__ const float* gemm_a_ptr(const float* A, int lda, int 
     else return A + (long long)m * lda + k0 + kq * 4;
 }
 
+// Tile coordinates of this workgroup.  Workgroups are dealt to the 8 XCDs round-robin by linear id, x fastest: with the
+// plain blockIdx mapping the column blocks of one row tile land on 8 different XCDs and every XCD's L2 pulls the whole
+// of A across the fabric (conv3: 8 x 268 MB).  Remapped so that each XCD owns a contiguous range of (z, row tile,
+// column block) triples: the column blocks of a row tile run next to each other on ONE L2 and A crosses the fabric once.
+__device__ __forceinline__ void gemm_block_coords(int& bx, int& by, int& bz)
+{
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int v = lpd_xcd_remap(lin, gx * gy * gridDim.z);
+    bx = v % gx;
+    const int t = v / gx;
+    by = t % gy;
+    bz = t / gy;
+}
+
 __device__ __forceinline__ float4 ld4_guard(const float* row, int i, int limit)
 {
     // row is 16-byte aligned and i % 4 == 0; elements >= limit read as zero
@@ -154,11 +169,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
     const int col = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int z = blockIdx.z;
+    int bx, by, z;
+    gemm_block_coords(bx, by, z);
     const int batch = z / g.splits;
     const int split = z - batch * g.splits;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
     const int kbase = split * g.K;
 
     // cloud-panel operands: the block's 128 rows lie in one cloud (panel_n % 128 == 0)
@@ -399,11 +415,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x3_kernel(GemmArgs g)
     const int col = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int z = blockIdx.z;
+    int bx, by, z;
+    gemm_block_coords(bx, by, z);
     const int batch = z / g.splits;
     const int split = z - batch * g.splits;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
     const int kbase = split * g.K;
 
     // cloud-panel operands: the block's 128 rows lie in one cloud (panel_n % 128 == 0)
@@ -476,15 +493,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x3_kernel(GemmArgs g)
 // Split-bf16 GEMM with PRE-ARRANGED B fragments ("x3w"): C = act((A.B + bias) * scale + shift), A [M][K] row-major
 // activations, B a (small) weight matrix.  lpd_gemm_prep_b splits B once into hi/lo bf16 and stores it in MFMA
 // fragment order -- fragment (n-tile, k-step) = 64 lanes x 8 bf16 = 1 KiB contiguous -- so the main kernel never
-// stages B through LDS and never splits it: each wave owns one 32-column tile of the output and streams its
-// fragments straight from L2 into registers (one coalesced 16-B load per lane and fragment), while the A tile
-// (128 rows x 64 k, split hi/lo on the fly) is the only LDS traffic.  Same scheme as edge_mlp_x3_kernel (36 % of the
-// three-product bf16 peak there); the generic kernel above re-splits and re-stages B in every block (25 %).
+// stages B through LDS and never splits it: each wave owns 32 WN columns of the output and streams their fragments
+// straight from L2 into registers (one coalesced 16-B load per lane and fragment), while the A tile (128 rows, split
+// hi/lo on the fly) is the only LDS traffic.  Same scheme as edge_mlp_x3_kernel; the generic kernel above re-splits
+// and re-stages B in every block.
 // ---------------------------------------------------------------------------------------------
-constexpr int X3W_KC = 64;                 // k per chunk (4 MFMA k-steps)
-constexpr int X3W_LDK = X3W_KC + 8;        // bf16 per LDS row of the A images (144 B: conflict-free ds_read_b128)
-constexpr int X3W_IMG = 128 * X3W_LDK;     // one image (hi or lo)
-
 // fragment order: frag[((nt * KS + ks) * 64 + lane) * 8 + j] = B[k = 16 ks + 8 (lane >> 5) + j][n = 32 nt + (lane & 31)]
 __global__ void gemm_prep_b_kernel(const float* __restrict__ B, int ldb, int b_kmajor, int N, int K, int KS,
                                    __bf16* __restrict__ fhi, __bf16* __restrict__ flo, long long total)
@@ -522,10 +535,30 @@ struct X3wArgs {
     int act;
     float slope;
     int accumulate;
+    long long a_cloud, c_cloud;   // cloud-panel operands (see GemmArgs); 0 = row-major
+    int panel_n, panel_ld;
 };
 
-template <bool KTAIL>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_kernel(X3wArgs g)
+// ---------------------------------------------------------------------------------------------
+// The kernel: block tile 128 x (128 WN), each wave a 128 x (32 WN) strip (4 x WN MFMA tiles), 32-deep chunks; WN = 2 for
+// N >= 256.  Why: the issue slots of a SIMD are shared by its waves and an MFMA's 32 cycles hide at most
+// ~6 other vector / LDS / memory instructions (MI355X_MICROARCH.md "vector-instruction ISSUE cost").  Per 16-deep k-step
+// a wave issues 8 ds_read_b128 (A hi/lo, 4 row tiles) + 2 WN fragment loads for 12 WN MFMAs; at WN = 2 that is 0.5
+// operand fetches per MFMA (the 128 x 128 kernels: 0.67 from LDS alone, plus their share of staging B).
+// Memory waits are counted, never drained (vmcnt retires in order): per chunk the queue is
+//     B(kc, step 1) | A(kc + 2) ............ | B(kc + 1, step 0)
+// B fragments (L2 hits) are requested one k-step ahead; the fp32 rows of A (HBM / remote L2) TWO chunks ahead into one
+// of two register sets, so the wait in front of the split + LDS store of chunk kc + 1 only covers loads issued a whole
+// chunk (48 WN MFMAs) earlier and leaves the younger ones in flight.  (The first version requested the fragments right
+// where it consumed them and drained A behind them every chunk: 640 us on conv3 against 505 us now, generic kernel 660.)
+// A may be cloud panels (PANELS & 1), C too (PANELS & 2): a block's 128 rows lie in one cloud.
+// ---------------------------------------------------------------------------------------------
+constexpr int X3V_KC = 32;                 // k per chunk (2 MFMA k-steps)
+constexpr int X3V_LDK = X3V_KC + 8;        // 80-byte LDS rows: conflict-free ds_read_b128
+constexpr int X3V_IMG = 128 * X3V_LDK;     // one image (hi or lo)
+
+template <int WN, bool KTAIL, int PANELS>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_wide_kernel(X3wArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];   // [2 buffers][hi | lo][128][LDK]
     const int tid = threadIdx.x;
@@ -533,101 +566,166 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_kernel(X3wArgs g)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const int col = lane & 31;
-    const int m0 = blockIdx.y * 128;
-    const int nt = blockIdx.x * 4 + wave;          // this wave's 32-column tile
-    const int nchunks = (g.K + X3W_KC - 1) / X3W_KC;
-    const bool has_cols = nt * 32 < g.N;           // the last block may hold waves past N (they still help staging A)
+    int bx, by, bz;
+    gemm_block_coords(bx, by, bz);
+    const int m0 = by * 128;
+    const int nt0 = (bx * 4 + wave) * WN;          // this wave's first 32-column tile
+    const int NT = (g.N + 31) >> 5;
+    const int nchunks = (g.K + X3V_KC - 1) / X3V_KC;
 
-    // A staging: 128 x 64 fp32 per chunk = 8 float4 per thread; register e: row (e*256 + tid) / 16, k quad % 16
-    float4 ra[8];
-    auto load_a = [&](int kc) {
-        const int k0 = kc * X3W_KC;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int f = e * GEMM_THREADS + tid;
-            const int rr = f >> 4, kq = f & 15;
-            int row = m0 + rr;
-            row = row < g.M ? row : g.M - 1;
-            if constexpr (KTAIL) ra[e] = ld4_guard(g.A + (long long)row * g.lda, k0 + kq * 4, g.K);
-            else ra[e] = *reinterpret_cast<const float4*>(g.A + (long long)row * g.lda + k0 + kq * 4);
-        }
-    };
-    auto store_a = [&](int buf) {
-        __bf16* hi_img = smem16 + buf * 2 * X3W_IMG;
-        __bf16* lo_img = hi_img + X3W_IMG;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int f = e * GEMM_THREADS + tid;
-            const int rr = f >> 4, kq = f & 15;
-            bf16x4 hh, ll;
-            split4(ra[e].x, ra[e].y, ra[e].z, ra[e].w, hh, ll);
-            *reinterpret_cast<bf16x4*>(hi_img + rr * X3W_LDK + kq * 4) = hh;
-            *reinterpret_cast<bf16x4*>(lo_img + rr * X3W_LDK + kq * 4) = ll;
-        }
-    };
-    // B fragments of one chunk (4 k-steps, hi and lo): straight from the prepared arrays
-    bf16x8 b_hi[4], b_lo[4];
-    const __bf16* fh = g.fhi + ((long long)(has_cols ? nt : 0) * g.KS * 64 + lane) * 8;
-    const __bf16* fl = g.flo + ((long long)(has_cols ? nt : 0) * g.KS * 64 + lane) * 8;
-    auto load_b = [&](int kc) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int ks = min(kc * 4 + s, g.KS - 1);   // past the end: any valid fragment (its A columns are zero)
-            b_hi[s] = *reinterpret_cast<const bf16x8*>(fh + (long long)ks * 512);
-            b_lo[s] = *reinterpret_cast<const bf16x8*>(fl + (long long)ks * 512);
-        }
-    };
+    const int cloud = (PANELS != 0) ? m0 / g.panel_n : 0;
+    const int m_cloud0 = cloud * g.panel_n;
+    const float* A = g.A + ((PANELS & 1) ? (long long)cloud * g.a_cloud : 0);
+    float* C = g.C + ((PANELS & 2) ? (long long)cloud * g.c_cloud : 0);
 
-    f32x16 acc[4];
+    // A staging: 128 x 32 fp32 per chunk = 4 float4 per thread, two sets (chunk parity).
+    //   row-major: register e holds row (e*256 + tid) / 8, k quad (e*256 + tid) % 8 (a row's 128 B are 8 lanes)
+    //   panels   : register e holds panel e of the chunk (8 channels), row tid / 2, half tid % 2 (one panel's 128 rows
+    //              x 32 B = 4 KiB contiguous per instruction)
+    float4 ra[2][4];
+    const float* a_base;        // loop-invariant part of this thread's A addresses
+    {
+        if constexpr (PANELS & 1) {
+            int row = m0 + (tid >> 1);
+            a_base = A + (long long)(row - m_cloud0) * 8 + (tid & 1) * 4;
+        } else a_base = A;
+    }
+    auto load_a = [&](int kc, float4 (&r)[4]) {
+        const int k0 = kc * X3V_KC;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-
-    load_a(0);
-    store_a(0);
-    __syncthreads();
-    for (int kc = 0; kc < nchunks; ++kc) {
-        const int buf = kc & 1;
-        load_b(kc);
-        if (kc + 1 < nchunks) load_a(kc + 1);
-        const __bf16* ah = smem16 + buf * 2 * X3W_IMG + col * X3W_LDK + h * 8;
-        const __bf16* al = ah + X3W_IMG;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(ah + i * 32 * X3W_LDK + s * 16);
-                const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(al + i * 32 * X3W_LDK + s * 16);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi[s], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo[s], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi[s], acc[i], 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (PANELS & 1) {
+                const int kp = (k0 >> 3) + e;          // panel index (K % 8 == 0)
+                if (!KTAIL || kp * 8 < g.K) r[e] = *reinterpret_cast<const float4*>(a_base + (long long)kp * g.panel_ld * 8);
+                else r[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const int f = e * GEMM_THREADS + tid;
+                int row = m0 + (f >> 3);
+                row = row < g.M ? row : g.M - 1;
+                if constexpr (KTAIL) r[e] = ld4_guard(a_base + (long long)row * g.lda, k0 + (f & 7) * 4, g.K);
+                else r[e] = *reinterpret_cast<const float4*>(a_base + (long long)row * g.lda + k0 + (f & 7) * 4);
             }
         }
-        if (kc + 1 < nchunks) store_a(buf ^ 1);
-        __syncthreads();
-    }
-    if (!has_cols) return;
+    };
+    auto store_a = [&](int buf, const float4 (&r)[4]) {
+        __bf16* hi_img = smem16 + buf * 2 * X3V_IMG;
+        __bf16* lo_img = hi_img + X3V_IMG;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int rr, k4;
+            if constexpr (PANELS & 1) { rr = tid >> 1; k4 = e * 2 + (tid & 1); }
+            else { const int f = e * GEMM_THREADS + tid; rr = f >> 3; k4 = f & 7; }
+            bf16x4 hh, ll;
+            split4(r[e].x, r[e].y, r[e].z, r[e].w, hh, ll);
+            *reinterpret_cast<bf16x4*>(hi_img + rr * X3V_LDK + k4 * 4) = hh;
+            *reinterpret_cast<bf16x4*>(lo_img + rr * X3V_LDK + k4 * 4) = ll;
+        }
+    };
 
-    const int n = nt * 32 + col;
-    if (n >= g.N) return;
-    float bi = 0.f, sc = 1.f, sh = 0.f;
-    if (g.bias) bi = g.bias[n];
-    if (g.scale) { sc = g.scale[n]; sh = g.shift[n]; }
-    const float ns = g.act == 0 ? 1.0f : (g.act == 1 ? 0.0f : g.slope);
+    // B fragments: set 0 = the chunk's first k-step, set 1 = its second
+    bf16x8 b_hi[2][WN], b_lo[2][WN];
+    const __bf16* fh[WN];
+    const __bf16* fl[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int nt = nt0 + j < NT ? nt0 + j : 0;   // strips past N read tile 0 (never stored)
+        fh[j] = g.fhi + ((long long)nt * g.KS * 64 + lane) * 8;
+        fl[j] = g.flo + ((long long)nt * g.KS * 64 + lane) * 8;
+    }
+    auto load_b = [&](int ks, int set) {
+        ks = min(ks, g.KS - 1);                       // past the end: any valid fragment (its A columns are zero)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            b_hi[set][j] = *reinterpret_cast<const bf16x8*>(fh[j] + (long long)ks * 512);
+            b_lo[set][j] = *reinterpret_cast<const bf16x8*>(fl[j] + (long long)ks * 512);
+        }
+    };
+
+    f32x16 acc[4][WN];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (m >= g.M) continue;
-            float v = acc[i][r] + bi;
-            v = v * sc + sh;
-            if (g.act == 3) v = lpd_sigmoid(v);
-            else v = fmaxf(v, 0.0f) + ns * fminf(v, 0.0f);
-            if (g.accumulate) v += g.C[(long long)m * g.ldc + n];
-            g.C[(long long)m * g.ldc + n] = v;
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto kstep = [&](const __bf16* ah, const __bf16* al, int s) {
+        bf16x8 a_hi[4], a_lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a_hi[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * X3V_LDK + s * 16);
+            a_lo[i] = *reinterpret_cast<const bf16x8*>(al + i * 32 * X3V_LDK + s * 16);
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[s][j], acc[i][j], 0, 0, 0);
+    };
+    // one chunk; `cur` / `nxt`: the register sets holding A(kc + 1) (loaded during the previous chunk) / receiving A(kc + 2)
+    auto chunk = [&](int kc, float4 (&nxt)[4], const float4 (&cur)[4]) {
+        const int buf = kc & 1;
+        const __bf16* ah = smem16 + buf * 2 * X3V_IMG + col * X3V_LDK + h * 8;
+        const __bf16* al = ah + X3V_IMG;
+        load_b(kc * 2 + 1, 1);
+        load_a(min(kc + 2, nchunks - 1), nxt);   // unconditional (the tail re-reads the last chunk): a branch here makes the
+                                                 // compiler count vmcnt for the path without these loads and over-wait
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(ah, al, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(kc * 2 + 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(ah, al, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kc + 1 < nchunks) store_a(buf ^ 1, cur);
+        __syncthreads();
+    };
+
+    load_b(0, 0);
+    load_a(0, ra[0]);
+    if (nchunks > 1) load_a(1, ra[1]);
+    store_a(0, ra[0]);
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; kc += 2) {
+        chunk(kc, ra[0], ra[1]);                          // A(kc + 1) sits in set 1, A(kc + 2) goes to set 0
+        if (kc + 1 < nchunks) chunk(kc + 1, ra[1], ra[0]);
+    }
+
+    const float ns = g.act == 0 ? 1.0f : (g.act == 1 ? 0.0f : g.slope);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = (nt0 + j) * 32 + col;
+        if (n >= g.N) continue;
+        float bi = 0.f, sc = 1.f, sh = 0.f;
+        if (g.bias) bi = g.bias[n];
+        if (g.scale) { sc = g.scale[n]; sh = g.shift[n]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= g.M) continue;
+                float v = acc[i][j][r] + bi;
+                v = v * sc + sh;
+                if (g.act == 3) v = lpd_sigmoid(v);
+                else v = fmaxf(v, 0.0f) + ns * fminf(v, 0.0f);
+                float* dst;
+                if constexpr (PANELS & 2) dst = C + ((long long)(n >> 3) * g.panel_ld + (m - m_cloud0)) * 8 + (n & 7);
+                else dst = C + (long long)m * g.ldc + n;
+                if (g.accumulate) v += *dst;
+                *dst = v;
+            }
+    }
 }
 
 // sums split-K slabs and applies the epilogue.  one thread per output element.
@@ -826,25 +924,58 @@ extern "C" int lpd_gemm_prep_b(const float* B, int ldb, int b_kmajor, int N, int
     return LPD_OK;
 }
 
-extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
-                            const float* scale, const float* shift, int act, float slope, int accumulate, void* stream)
+template <int WN, int PANELS>
+static void x3w_wide_launch(const X3wArgs& g, int NT, hipStream_t stream)
 {
+    const size_t lds = (size_t)4 * X3V_IMG * sizeof(__bf16);
+    dim3 grid((NT + 4 * WN - 1) / (4 * WN), (g.M + 127) / 128);
+    if (g.K % X3V_KC) {
+        auto kern = gemm_x3w_wide_kernel<WN, true, PANELS>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, stream, g);
+    } else {
+        auto kern = gemm_x3w_wide_kernel<WN, false, PANELS>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, stream, g);
+    }
+}
+
+extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
+                            const float* scale, const float* shift, int act, float slope, int accumulate,
+                            long long a_cloud, long long c_cloud, int panel_n, int panel_ld, int impl, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool a_panels = a_cloud != 0, c_panels = c_cloud != 0;
     LPD_CHECK_ARG(A && frags && C && M > 0 && N > 0 && K > 0, "lpd_gemm_x3w: bad arguments");
-    LPD_CHECK_ARG(lda % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)frags & 15) == 0, "lpd_gemm_x3w: A must be 16-byte aligned, lda %% 4 == 0");
+    LPD_CHECK_ARG(a_panels || (lda % 4 == 0), "lpd_gemm_x3w: lda %% 4 != 0");
+    LPD_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)frags & 15) == 0, "lpd_gemm_x3w: A and the fragments must be 16-byte aligned");
     LPD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "lpd_gemm_x3w: scale and shift must be given together");
+    LPD_CHECK_ARG(!(a_panels || c_panels) || (panel_n > 0 && panel_n % 128 == 0 && M % panel_n == 0 && panel_ld >= panel_n),
+                  "lpd_gemm_x3w: cloud-panel operands need points per cloud %% 128 == 0");
+    LPD_CHECK_ARG(!a_panels || K % 8 == 0, "lpd_gemm_x3w: cloud-panel A needs K %% 8 == 0");
+    LPD_CHECK_ARG(!c_panels || N % 8 == 0, "lpd_gemm_x3w: cloud-panel C needs N %% 8 == 0");
+    LPD_CHECK_ARG(impl == 0 || impl == 2 || impl == 3, "lpd_gemm_x3w: impl=%d", impl);
     const int KS = (K + 15) / 16, NT = (N + 31) / 32;
     const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
-    X3wArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, K, KS, lda, ldc, bias, scale, shift, act, slope, accumulate};
-    const size_t lds = (size_t)4 * X3W_IMG * sizeof(__bf16);
-    dim3 grid((NT + 3) / 4, (M + 127) / 128);
-    if (K % X3W_KC) {
-        auto kern = gemm_x3w_kernel<true>;
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, (hipStream_t)stream, g);
+    X3wArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, K, KS, lda, ldc, bias, scale, shift, act, slope, accumulate,
+              a_cloud, c_cloud, panel_n, panel_ld};
+    // impl: 0 = by shape, 2 = 128 x 128 blocks, 3 = 128 x 256 blocks
+    if (impl == 0) impl = N >= 256 ? 3 : 2;
+    const int panels = (a_panels ? 1 : 0) | (c_panels ? 2 : 0);
+    if (impl == 2) {
+        switch (panels) {
+            case 0: x3w_wide_launch<1, 0>(g, NT, stream); break;
+            case 1: x3w_wide_launch<1, 1>(g, NT, stream); break;
+            case 2: x3w_wide_launch<1, 2>(g, NT, stream); break;
+            default: x3w_wide_launch<1, 3>(g, NT, stream); break;
+        }
     } else {
-        auto kern = gemm_x3w_kernel<false>;
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, (hipStream_t)stream, g);
+        switch (panels) {
+            case 0: x3w_wide_launch<2, 0>(g, NT, stream); break;
+            case 1: x3w_wide_launch<2, 1>(g, NT, stream); break;
+            case 2: x3w_wide_launch<2, 2>(g, NT, stream); break;
+            default: x3w_wide_launch<2, 3>(g, NT, stream); break;
+        }
     }
     LPD_CHECK_LAUNCH("lpd_gemm_x3w");
     return LPD_OK;

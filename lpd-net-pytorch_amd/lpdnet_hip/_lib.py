@@ -31,7 +31,8 @@ SIGNATURES = {
                  _c_ll, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_ll, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_prep_b_bytes": [_c_int, _c_int],
     "lpd_gemm_prep_b": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p],
-    "lpd_gemm_x3w": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_p],
+    "lpd_gemm_x3w": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int,
+                     _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_p],
     "lpd_retrieval_topk": [_c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_f64_to_f32": [_c_p, _c_p, _c_ll, _c_p],
     "lpd_knn_pm": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_int, _c_p],

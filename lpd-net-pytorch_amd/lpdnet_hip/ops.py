@@ -3,6 +3,7 @@ autograd lives in autograd.py.  Every op requires CUDA fp32 tensors and raises o
 there is deliberately no CPU or eager-PyTorch fallback.
 """
 import ctypes
+import os
 
 import torch
 
@@ -152,6 +153,8 @@ class train_forward_gemm(exact_gemm):
 
 
 _FRAG_CACHE = {}
+X3W_FORWARD = os.environ.get("LPD_X3W_FWD", "1") != "0"    # forward layers with K >= 256 on the prepared-fragment kernel
+X3W_IMPL = int(os.environ.get("LPD_X3W_IMPL", "0"))         # lpd_gemm_x3w impl (0 = by shape); benchmarking only
 
 
 def _weight_frags(B2, b_kmajor, N, K):
@@ -216,15 +219,16 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
         ws = torch.empty((nb * splits * M * N,), dtype=torch.float32, device=A.device)
     bias, scale, shift = _vec(bias, "bias", N), _vec(scale, "scale", N), _vec(shift, "shift", N)
     lib = _lib.load()
-    # weight-shaped B stored k-major (dX = dY W of the backward pass, the NetVLAD assignment): fragments of B prepared
-    # once, B never staged through LDS (lpd_gemm_x3w).  Measured against the generic split-bf16 kernel, whose k-major
-    # staging transposes in registers: 3.6M x 128 x 128 1.49 -> 1.15 ms, 180k x 512 x 1024 1.42 -> 0.72 ms; for row-major
-    # weights (forward layers) and K = 64 the generic kernel is as fast or faster, so those stay there.
-    if (GEMM_BF16X3 and not exact and _EXACT.depth == 0 and not a_kmajor and b_kmajor and not batched and splits == 1
-            and M >= 1024 and N >= 64 and K >= 128 and N * K <= (1 << 22)):
+    # weight-shaped B (a layer's weights in either layout; dX = dY W of the backward pass) and a deep reduction:
+    # fragments of B prepared once, B never staged through LDS (lpd_gemm_x3w).  Measured (tools/x3w_bench.py, M = 131072):
+    # conv3 512 -> 1024 660 -> 505 us, dX 1024 -> 512 433 us; at K <= 128 the generic kernel is as fast or faster
+    # (SN1 projection 142 vs 149 us, DG1 projection 52 vs 58 us), and k-major weights transpose in registers there.
+    if (GEMM_BF16X3 and not exact and _EXACT.depth == 0 and not a_kmajor and not batched and splits == 1
+            and M >= 1024 and N >= 64 and N * K <= (1 << 22)
+            and ((b_kmajor and K >= 128) or (X3W_FORWARD and K >= 256))):
         frags = _weight_frags(B, b_kmajor, N, K)
         _call(f"gemmx3w[{M}x{N}x{K}]", lib.lpd_gemm_x3w, _ptr(A), lda, _ptr(frags), _ptr(out), ldc, M, N, K, _ptr(bias), _ptr(scale),
-              _ptr(shift), act, float(slope), int(bool(accumulate)), _stream())
+              _ptr(shift), act, float(slope), int(bool(accumulate)), 0, 0, 0, 0, X3W_IMPL, _stream())
         return out
     # split-bf16 where it is faster (measured, tools/gemm_bench.py): outputs of at least 128 x 128 with a row-major A
     # or with both operands k-major (weight gradients); skinny outputs (per-cloud rows, 64 clusters) and the k-major
@@ -313,9 +317,15 @@ def _gemm_panels(A, B, a_kmajor, b_kmajor, bias, scale, shift, act, slope, out, 
     bias, scale, shift = _vec(bias, "bias", N), _vec(scale, "scale", N), _vec(shift, "shift", N)
     lib = _lib.load()
     x3 = GEMM_BF16X3 and not exact and _EXACT.depth == 0 and N >= 128 and M >= 128
+    pld = _panel_ld(A if a_panels else None, out if out_panels else None)
+    if x3 and X3W_FORWARD and M >= 1024 and K >= 256 and N * K <= (1 << 22):
+        frags = _weight_frags(B, b_kmajor, N, K)
+        _call(f"gemmx3w[{M}x{N}x{K}]", lib.lpd_gemm_x3w, _ptr(A), lda, _ptr(frags), _ptr(out), ldc, M, N, K, _ptr(bias), _ptr(scale),
+              _ptr(shift), act, float(slope), int(bool(accumulate)), a_cloud, c_cloud, Np, pld, X3W_IMPL, _stream())
+        return out
     _call(f"gemm{'x3' if x3 else ''}[{M}x{N}x{K}]", lib.lpd_gemm_bf16x3 if x3 else lib.lpd_gemm, _ptr(A), _ptr(B), _ptr(out), M, N, K, lda, ldb,
           ldc, 0, int(b_kmajor), 1, 0, 0, 0, 1, None, _ptr(bias), _ptr(scale), _ptr(shift), act, float(slope), int(bool(accumulate)),
-          a_cloud, c_cloud, Np, _panel_ld(A if a_panels else None, out if out_panels else None), _stream())
+          a_cloud, c_cloud, Np, pld, _stream())
     return out
 
 

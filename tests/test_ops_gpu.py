@@ -350,7 +350,7 @@ def test_gather_sum_rows_is_the_transpose_of_the_neighbour_gather(cuda, C, N, B,
 
 
 @pytest.mark.parametrize("M,N,K,bk", [(4096, 512, 1024, True), (2048, 256, 128, True), (1500, 64, 1024, True), (3000, 200, 136, True),
-                                       (1024, 72, 148, True)])
+                                       (1024, 72, 148, True), (4096, 1024, 512, False), (2100, 300, 264, False), (1111, 136, 300, False)])
 def test_gemm_weight_fragment_path(cuda, M, N, K, bk):
     """Row-major activations times a weight matrix take lpd_gemm_x3w (B fragments prepared once, never staged in LDS):
     same contract and error bound as the generic split-bf16 kernel; epilogue, output slice, accumulation, ragged N / K."""
@@ -407,6 +407,28 @@ def test_cloud_panel_operands(cuda, exact):
     assert torch.equal(ops.panels_to_rows(wide[:, 16:]), want)
     rowm = ops.gemm(big[:, 8:8 + K // 8], W, b_kmajor=False, scale=sc, shift=sh, act=ops.ACT_LEAKY, exact=exact, a_panels=True)
     assert torch.equal(rowm, want)
+    # deep reduction (K >= 256): the prepared-fragment kernel, both block shapes, ragged column blocks (N = 320)
+    K2, N2 = 512, 320
+    X2 = torch.randn(M, K2, generator=g).to(cuda)
+    Wd = (torch.randn(N2, K2, generator=g) / K2 ** 0.5).to(cuda)
+    sc2, sh2 = torch.randn(N2, generator=g).to(cuda), torch.randn(N2, generator=g).to(cuda)
+    xp = ops.rows_to_panels(X2, Bc)
+    ref2 = (X2.double() @ Wd.double().t()) * sc2.double() + sh2.double()
+    ref2 = torch.where(ref2 > 0, ref2, ref2 * 0.01)
+    for impl in (0, 2, 3):
+        ops.X3W_IMPL = impl
+        prof = ops.PROFILE = {}
+        try:
+            want2 = ops.gemm(X2, Wd, b_kmajor=False, scale=sc2, shift=sh2, act=ops.ACT_LEAKY, exact=exact)
+            assert _rel(want2, ref2) < (2e-6 if exact else 3e-5)
+            got2 = ops.gemm(xp, Wd, b_kmajor=False, scale=sc2, shift=sh2, act=ops.ACT_LEAKY, exact=exact, a_panels=True, out_panels=True)
+            assert torch.equal(ops.panels_to_rows(got2), want2), impl
+            assert torch.equal(ops.gemm(xp, Wd, b_kmajor=False, scale=sc2, shift=sh2, act=ops.ACT_LEAKY, exact=exact, a_panels=True), want2), impl
+            acc2 = ops.gemm(X2, Wd, b_kmajor=False, exact=exact, out=got2.clone(), out_panels=True, accumulate=True)
+            assert _rel(ops.panels_to_rows(acc2), ref2 + X2.double() @ Wd.double().t()) < (2e-6 if exact else 3e-5), impl
+        finally:
+            ops.X3W_IMPL, ops.PROFILE = 0, None
+        assert exact or any(k.startswith("gemmx3w") for k in prof), list(prof)
     # K-agg: every combination of cloud-panel / row-major P, Q, out
     B_, Nq, C, k = 2, 768, 256, 20
     P, Q, idx, scale, shift = _edge_inputs(B_, Nq, C, k, 5)
