@@ -8,7 +8,7 @@
 // (lpd_edge.hip) are served by L1/L2 instead of the Infinity Cache.
 //
 // One 1024-thread block per cloud: bounding box -> 10 bits per axis -> 30-bit key -> bitonic sort of
-// (key, index) in LDS -> permuted copy of the cloud.  N <= 16384 (128 KiB of LDS).
+// (key, index) in registers / lane shuffles / LDS -> permuted copy of the cloud.  N <= 16384 (128 KiB of LDS).
 #include "lpd_common.h"
 #include <math.h>
 
@@ -24,12 +24,25 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v)
     return v;
 }
 
-__global__ __launch_bounds__(1024) void morton_sort_kernel(const float* __restrict__ xyz, float* __restrict__ out,
-                                                            int32_t* __restrict__ perm, int N, int NP)
+// One compare-exchange partner step of the bitonic network for an element held by this thread: `o` is the partner's
+// value, `lower` says whether this element has the smaller index of the pair, `up` the direction of the pair's block.
+__device__ __forceinline__ uint64_t bitonic_keep(uint64_t v, uint64_t o, bool lower, bool up)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
-    uint32_t* keys = sm;          // [NP]
-    uint32_t* vals = sm + NP;     // [NP]
+    const uint64_t mn = v < o ? v : o, mx = v < o ? o : v;
+    return (lower == up) ? mn : mx;
+}
+
+// E elements per thread (NP = 1024 E keys): thread t owns the E consecutive positions E t .. E t + E - 1 of the network.
+// Keys are (morton << 32 | index): one 64-bit compare orders by (key, index), so equal keys keep a deterministic order.
+// Strides below E exchange inside the thread's registers, strides below 64 E between lanes (two 32-bit shuffles), only
+// the strides that cross waves (10 of the 78 steps at N = 4096) go through LDS -- the first version ran every step
+// through LDS with a block barrier and half of the threads idle (84 us at B = 32, on 32 of the 256 CUs).
+template <int E>
+__global__ __launch_bounds__(1024) void morton_sort_kernel(const float* __restrict__ xyz, float* __restrict__ out,
+                                                            int32_t* __restrict__ perm, int N)
+{
+    constexpr int NP = 1024 * E;
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];   // [E][1024]
     __shared__ float red[6][16];
     __shared__ float box[6];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -59,7 +72,10 @@ __global__ __launch_bounds__(1024) void morton_sort_kernel(const float* __restri
         box[3 + tid] = z > a ? 1023.0f / (z - a) : 0.0f;
     }
     __syncthreads();
-    for (int i = tid; i < NP; i += 1024) {
+    uint64_t v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid * E + e;
         uint32_t key = 0xffffffffu;
         if (i < N) {
             uint32_t q[3];
@@ -71,33 +87,65 @@ __global__ __launch_bounds__(1024) void morton_sort_kernel(const float* __restri
             }
             key = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
         }
-        keys[i] = key;
-        vals[i] = (uint32_t)i;
+        v[e] = ((uint64_t)key << 32) | (uint32_t)i;
     }
-    __syncthreads();
-    // bitonic sort, ascending by (key, index): deterministic for equal keys
+    // bitonic sort, ascending
+#pragma unroll
     for (int k = 2; k <= NP; k <<= 1) {
+#pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < NP; i += 1024) {
-                int l = i ^ j;
-                if (l > i) {
-                    uint32_t ki = keys[i], kl = keys[l], vi = vals[i], vl = vals[l];
-                    bool up = (i & k) == 0;
-                    bool gt = (ki > kl) || (ki == kl && vi > vl);
-                    if (gt == up) { keys[i] = kl; keys[l] = ki; vals[i] = vl; vals[l] = vi; }
+            if (j < E) {                                     // both elements in this thread
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if ((e & j) == 0) {
+                        const bool up = ((tid * E + e) & k) == 0;
+                        const uint64_t a = v[e], c = v[e | j];
+                        const bool sw = (a > c) == up;
+                        v[e] = sw ? c : a;
+                        v[e | j] = sw ? a : c;
+                    }
+            } else if (j < 64 * E) {                         // partner in another lane of this wave
+                const int lj = j / E;
+                const bool lower = (tid & lj) == 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const uint32_t lo = __shfl_xor((uint32_t)v[e], lj, 64), hi = __shfl_xor((uint32_t)(v[e] >> 32), lj, 64);
+                    v[e] = bitonic_keep(v[e], ((uint64_t)hi << 32) | lo, lower, ((tid * E + e) & k) == 0);
                 }
+            } else {                                         // partner in another wave: through LDS
+                const int tj = j / E;
+                const bool lower = (tid & tj) == 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) lds[e * 1024 + tid] = v[e];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    v[e] = bitonic_keep(v[e], lds[e * 1024 + (tid ^ tj)], lower, ((tid * E + e) & k) == 0);
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
     float* o = out + (size_t)b * N * 3;
-    for (int r = tid; r < N; r += 1024) {
-        uint32_t src = vals[r];
-        o[r * 3 + 0] = p[src * 3 + 0];
-        o[r * 3 + 1] = p[src * 3 + 1];
-        o[r * 3 + 2] = p[src * 3 + 2];
-        if (perm) perm[(size_t)b * N + r] = (int32_t)src;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int r = tid * E + e;
+        if (r < N) {
+            const uint32_t src = (uint32_t)v[e];
+            o[r * 3 + 0] = p[src * 3 + 0];
+            o[r * 3 + 1] = p[src * 3 + 1];
+            o[r * 3 + 2] = p[src * 3 + 2];
+            if (perm) perm[(size_t)b * N + r] = (int32_t)src;
+        }
     }
+}
+
+template <int E>
+void morton_launch(const float* xyz, float* out, int32_t* perm, int B, int N, hipStream_t stream)
+{
+    const size_t lds = (size_t)E * 1024 * sizeof(uint64_t);
+    auto kern = morton_sort_kernel<E>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds, stream, xyz, out, perm, N);
 }
 
 }  // namespace
@@ -111,11 +159,11 @@ extern "C" int lpd_morton_sort(const float* xyz, float* out, int32_t* perm, int 
         lpd_set_error("lpd_morton_sort: N=%d > 16384 unsupported", N);
         return LPD_ERR_UNSUPPORTED;
     }
-    int NP = 1;
-    while (NP < N) NP <<= 1;
-    size_t lds = (size_t)NP * 2 * sizeof(uint32_t);
-    (void)hipFuncSetAttribute((const void*)morton_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(morton_sort_kernel, dim3(B), dim3(1024), lds, stream, xyz, out, perm, N, NP);
+    if (N <= 1024) morton_launch<1>(xyz, out, perm, B, N, stream);
+    else if (N <= 2048) morton_launch<2>(xyz, out, perm, B, N, stream);
+    else if (N <= 4096) morton_launch<4>(xyz, out, perm, B, N, stream);
+    else if (N <= 8192) morton_launch<8>(xyz, out, perm, B, N, stream);
+    else morton_launch<16>(xyz, out, perm, B, N, stream);
     LPD_CHECK_LAUNCH("lpd_morton_sort");
     return LPD_OK;
 }

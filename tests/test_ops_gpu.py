@@ -138,6 +138,38 @@ def test_morton_sort_is_a_permutation_and_improves_locality(cuda):
     assert same > 0.995   # equal up to rows with (near-)ties: pd depends on summation order only through ties
 
 
+def _morton_order_np(pts):
+    """numpy restatement of lpd_morton.hip: fp32 bounding box, 10 bits per axis, stable order by (key, index)."""
+    mn, mx = pts.min(0), pts.max(0)
+    with np.errstate(divide="ignore"):
+        scale = np.where(mx > mn, np.float32(1023.0) / (mx - mn).astype(np.float32), np.float32(0)).astype(np.float32)
+    q = np.clip((pts - mn).astype(np.float32) * scale, 0, 1023).astype(np.uint32)
+
+    def spread(v):
+        v = v & 0x3ff
+        v = (v | (v << 16)) & 0x030000ff
+        v = (v | (v << 8)) & 0x0300f00f
+        v = (v | (v << 4)) & 0x030c30c3
+        return (v | (v << 2)) & 0x09249249
+    key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    return np.argsort(key, kind="stable")
+
+
+@pytest.mark.parametrize("N", [1, 37, 1000, 1024, 1500, 4096, 5000, 16384])
+def test_morton_sort_order(cuda, N):
+    """Every instantiation of the sorting network (1..16 keys per thread, ragged N, duplicate points = equal keys) against
+    the numpy order, element for element."""
+    ops = _ops()
+    pts = synth.cloud(N + 3, 2, N).copy()
+    if N > 40:
+        pts[:, 7] = pts[:, 3]; pts[:, N - 1] = pts[:, 3]          # duplicated points: equal keys, index decides
+    out, perm = ops.morton_sort(torch.from_numpy(pts).to(cuda), want_perm=True)
+    for b in range(2):
+        want = _morton_order_np(pts[b])
+        assert np.array_equal(perm[b].cpu().numpy(), want.astype(np.int32)), (N, b)
+        assert np.array_equal(out[b].cpu().numpy(), pts[b][want])
+
+
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K,ak,bk", [(256, 128, 64, False, False), (1000, 200, 96, False, True), (128, 64, 32, False, False),
                                           (77, 513, 128, False, False), (512, 64, 1024, False, True), (300, 1024, 512, False, False),
