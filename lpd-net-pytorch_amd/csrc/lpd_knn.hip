@@ -922,8 +922,11 @@ __device__ __forceinline__ void knn7_insert(float (&v)[KMAX], int (&id)[KMAX], f
         : [x] "v"(x), [j] "v"(j), [cc] "s"(cc));
 }
 
-template <int CP, int KMAX>
-__global__ __launch_bounds__(KNN3_THREADS, 2) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
+// WAVES: waves per workgroup.  A workgroup's LDS and wave slots stay taken until its slowest wave is done and the tile
+// counts of neighbouring waves differ (C = 64: mean 51, p90 69, max 89 tiles): single-wave workgroups at C = 64
+// (638 -> 607 us), four waves at C = 3 (shorter waves; the larger groups launch faster: 278 vs 287 us).
+template <int CP, int KMAX, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
                                                              const float* __restrict__ cenp, const float* __restrict__ cnorm,
                                                              const float* __restrict__ rad, const float* __restrict__ txmax,
                                                              int32_t* __restrict__ idx,
@@ -938,7 +941,7 @@ __global__ __launch_bounds__(KNN3_THREADS, 2) void knn7_kernel(const float* __re
     const int vb = lpd_xcd_remap(blockIdx.x, gridDim.x);
     const int b = vb / blocks_per_cloud;
     const int qb = vb - b * blocks_per_cloud;
-    const int q0 = qb * (KNN3_WAVES * 32) + wave * 32;
+    const int q0 = qb * (WAVES * 32) + wave * 32;
     const int W = q0 >> 5;
     const bool wave_ok = q0 < N;                 // the last block of a cloud may hold waves without queries
     const int q = q0 + col;
@@ -1170,12 +1173,13 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
     if (x) hipLaunchKernelGGL(knn_pack_kernel<CP>, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xp, C, N);
     hipLaunchKernelGGL(knn7_tile_stats_kernel<CP>, dim3(nt, B), dim3(64), 0, stream, (const float*)xp, xx, cenp, cnorm, rad, txmax, N, nt);
     LPD_CHECK_LAUNCH("lpd_knn(tile pre-pass)");
-    const int bpc = (N + KNN3_WAVES * 32 - 1) / (KNN3_WAVES * 32);
+    constexpr int WAVES = CP >= 16 ? 1 : 4;
+    const int bpc = (N + WAVES * 32 - 1) / (WAVES * 32);
     {
-        size_t lds = (size_t)KNN3_WAVES * KNN7_WAVE_LDS;
-        auto kern = knn7_kernel<CP, KMAX>;
+        size_t lds = (size_t)WAVES * KNN7_WAVE_LDS;
+        auto kern = knn7_kernel<CP, KMAX, WAVES>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(KNN3_THREADS), lds, stream, (const float*)xp, xx, (const float*)cenp,
+        hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(WAVES * 64), lds, stream, (const float*)xp, xx, (const float*)cenp,
                            (const float*)cnorm, (const float*)rad, (const float*)txmax, idx, N, k, nt, C, bpc, dbg);
         LPD_CHECK_LAUNCH("lpd_knn(best-first)");
     }
