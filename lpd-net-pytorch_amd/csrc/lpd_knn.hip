@@ -890,6 +890,87 @@ __global__ __launch_bounds__(64) void knn7_tile_stats_kernel(const float* __rest
     }
 }
 
+// ---- longest-first launch order --------------------------------------------------------------------------------------
+// The waves of the best-first kernel visit very different numbers of candidate tiles (C = 64: mean 51, p90 69, max 89;
+// tools/knn_dist.py) and a launch is two rounds of waves over the chip's slots (B = 32: 4096 waves, 2048 slots): in
+// index order a long wave that starts in the second round runs on alone (list-scheduling simulation on measured tile
+// counts, tools/knn_predict.py: makespan 141 / 168 tile units at C = 3 / 64 against 98 / 120 for a perfect balance).
+// A tile-level estimate predicts the count well enough (correlation 0.72..0.77) to launch the long waves first:
+//   pred(W) = #{T : max(0, |c_W - c_T| - r_W - r_T) <= r_W / 2}        (centroids c, radii r of the 32-point tiles)
+// and each XCD's contiguous range of work items (lpd_xcd_remap) is sorted by it, descending, in chunks of 1024.
+template <int CP>
+__global__ __launch_bounds__(128) void knn7_predict_kernel(const float* __restrict__ cenp, const float* __restrict__ rad,
+                                                           int32_t* __restrict__ pred, int nt)
+{
+    constexpr int CH = 2 * CP;
+    __shared__ float cw[CH];
+    __shared__ int part[2];
+    const int W = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* cb = cenp + (size_t)b * nt * CH;
+    for (int c = tid; c < CH; c += 128) cw[c] = cb[(size_t)W * CH + c];
+    __syncthreads();
+    const float rw = rad[(size_t)b * nt + W];
+    int n = 0;
+    for (int T = tid; T < nt; T += 128) {
+        const float* ct = cb + (size_t)T * CH;
+        float d2 = 0.f;
+        if constexpr (CH % 4 == 0) {
+#pragma unroll 4
+            for (int c = 0; c < CH; c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(ct + c);
+                const float d0 = v.x - cw[c], d1 = v.y - cw[c + 1], d2_ = v.z - cw[c + 2], d3 = v.w - cw[c + 3];
+                d2 = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2_, d2_, fmaf(d3, d3, d2))));
+            }
+        } else {
+            for (int c = 0; c < CH; ++c) { const float d = ct[c] - cw[c]; d2 = fmaf(d, d, d2); }
+        }
+        const float gap = fmaxf(sqrtf(d2) - rw - rad[(size_t)b * nt + T], 0.0f);
+        n += gap <= 0.5f * rw ? 1 : 0;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) n += __shfl_xor(n, m, 64);
+    if ((tid & 63) == 0) part[tid >> 6] = n;
+    __syncthreads();
+    if (tid == 0) pred[(size_t)b * nt + W] = part[0] + part[1];
+}
+
+// order[range of XCD x] = that range's item ids sorted by pred descending (ties: id ascending), chunk by chunk.
+// grid (chunks, 8), 1024 threads: one key per thread; strides below 64 by lane shuffles, the rest through LDS.
+__global__ __launch_bounds__(1024) void knn7_order_kernel(const int32_t* __restrict__ pred, int32_t* __restrict__ order, int nitems)
+{
+    __shared__ unsigned long long sk[1024];
+    const int tid = threadIdx.x, xcd = blockIdx.y;
+    const int q = nitems / 8, r = nitems % 8;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int len = q + (xcd < r ? 1 : 0);
+    const int c0 = blockIdx.x * 1024;
+    if (c0 >= len) return;
+    const int cl = min(1024, len - c0);
+    unsigned long long v = ~0ull;                              // padding sorts to the end
+    if (tid < cl) {
+        const int item = base + c0 + tid;
+        v = ((unsigned long long)(0x7fffffffu - (unsigned)pred[item]) << 32) | (unsigned)item;
+    }
+    for (int k = 2; k <= 1024; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            unsigned long long o;
+            if (j < 64) {
+                const unsigned lo = __shfl_xor((unsigned)v, j, 64), hi = __shfl_xor((unsigned)(v >> 32), j, 64);
+                o = ((unsigned long long)hi << 32) | lo;
+            } else {
+                sk[tid] = v;
+                __syncthreads();
+                o = sk[tid ^ j];
+                __syncthreads();
+            }
+            const bool lower = (tid & j) == 0, up = (tid & k) == 0;
+            const unsigned long long mn = v < o ? v : o, mx = v < o ? o : v;
+            v = (lower == up) ? mn : mx;
+        }
+    }
+    if (tid < cl) order[base + c0 + tid] = (int32_t)(unsigned)v;
+}
+
 // In-place insertion for the best-first kernel.  The tiles are visited W, W+1, W-1, W+2, ...: the set of visited tiles
 // is always an interval around W, so a candidate from a tile above W has a larger index than everything in the list
 // (ranks AFTER equal values: reference rule, lower index first) and one from a tile below W a smaller index than
@@ -929,7 +1010,7 @@ template <int CP, int KMAX, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 2) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
                                                              const float* __restrict__ cenp, const float* __restrict__ cnorm,
                                                              const float* __restrict__ rad, const float* __restrict__ txmax,
-                                                             int32_t* __restrict__ idx,
+                                                             int32_t* __restrict__ idx, const int32_t* __restrict__ order,
                                                              int N, int k, int nt, int C, int blocks_per_cloud, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem7[];
@@ -938,7 +1019,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn7_kernel(const float* __rest
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too
     const int h = lane >> 5;
     const int col = lane & 31;
-    const int vb = lpd_xcd_remap(blockIdx.x, gridDim.x);
+    int vb = lpd_xcd_remap(blockIdx.x, gridDim.x);
+    if (order) vb = order[vb];                   // longest-first inside the XCD's range (single-wave workgroups)
     const int b = vb / blocks_per_cloud;
     const int qb = vb - b * blocks_per_cloud;
     const int q0 = qb * (WAVES * 32) + wave * 32;
@@ -1157,7 +1239,7 @@ int knn3_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
 inline size_t knn7_extra_floats(int B, int N, int CP)
 {
     const size_t nt = (size_t)(N + 31) / 32;
-    return (size_t)B * nt * (2 * CP + 3) + 8;
+    return (size_t)B * nt * (2 * CP + 3 + 2) + 16;   // + predicted tile counts and launch order (int32 each)
 }
 
 template <int CP, int KMAX>
@@ -1173,14 +1255,24 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
     if (x) hipLaunchKernelGGL(knn_pack_kernel<CP>, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xp, C, N);
     hipLaunchKernelGGL(knn7_tile_stats_kernel<CP>, dim3(nt, B), dim3(64), 0, stream, (const float*)xp, xx, cenp, cnorm, rad, txmax, N, nt);
     LPD_CHECK_LAUNCH("lpd_knn(tile pre-pass)");
-    constexpr int WAVES = CP >= 16 ? 1 : 4;
+    constexpr int WAVES = 1;
     const int bpc = (N + WAVES * 32 - 1) / (WAVES * 32);
+    static const bool lpt = !(getenv("LPD_KNN_ORDER") && atoi(getenv("LPD_KNN_ORDER")) == 0);
+    int32_t* pred = reinterpret_cast<int32_t*>(txmax + (size_t)B * nt + 4);
+    int32_t* order = pred + (size_t)B * nt;
+    const int nitems = bpc * B;
+    if (lpt) {
+        hipLaunchKernelGGL(knn7_predict_kernel<CP>, dim3(nt, B), dim3(128), 0, stream, (const float*)cenp, (const float*)rad, pred, nt);
+        hipLaunchKernelGGL(knn7_order_kernel, dim3((nitems / 8 + 1 + 1023) / 1024, 8), dim3(1024), 0, stream, (const int32_t*)pred, order, nitems);
+        LPD_CHECK_LAUNCH("lpd_knn(launch order)");
+    }
     {
         size_t lds = (size_t)WAVES * KNN7_WAVE_LDS;
         auto kern = knn7_kernel<CP, KMAX, WAVES>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(WAVES * 64), lds, stream, (const float*)xp, xx, (const float*)cenp,
-                           (const float*)cnorm, (const float*)rad, (const float*)txmax, idx, N, k, nt, C, bpc, dbg);
+                           (const float*)cnorm, (const float*)rad, (const float*)txmax, idx, (const int32_t*)(lpt ? order : nullptr),
+                           N, k, nt, C, bpc, dbg);
         LPD_CHECK_LAUNCH("lpd_knn(best-first)");
     }
     return LPD_OK;
