@@ -208,7 +208,7 @@ def main():
         kern[name] = {"launches": len(ms), "avg_us": round(1e3 * sum(ms) / len(ms), 2)}
     roof = None
     key, kname = "edge_gather_max16[C=256]", "edge_gather_max_cloud16_kernel (LDS-resident cloud slice)"
-    if key not in kern:     # k != 20 or N > 5120: the direct gather form
+    if key not in kern:     # k != 20 or N > 4096: the direct gather form
         key, kname = "edge_gather_max[C=256]", "edge_gather_max_kernel<64> (direct gather)"
     if key in kern:
         t_s = kern[key]["avg_us"] * 1e-6

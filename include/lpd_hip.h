@@ -126,7 +126,7 @@ int lpd_edge_gather_max(const float* P, int ldp, const float* Q, int ldq, const 
  * K-agg, cloud-resident form on row-major operands with 16-bit indices: as lpd_edge_gather_max, but one
  * workgroup keeps an 8-channel slice of ALL N rows of one cloud's P in LDS (N*32 bytes), so the k gathers per
  * point are LDS reads and P, Q, out cross the memory system once.  idx16: the blocked uint16 copy made by lpd_pack_idx16.
- * Built for k = 20, N <= 5120; bit-identical to lpd_edge_gather_max.
+ * Built for k = 20, N <= 4096; bit-identical to lpd_edge_gather_max.
  * p_cloud / q_cloud / o_cloud != 0: that operand is in cloud-panel layout [cloud][.][panel_ld][8] (floats between clouds; leading
  * dim ignored): a block's 8-channel slice is then one contiguous 32*N-byte run instead of N pieces of 32 bytes.
  */

@@ -133,6 +133,8 @@ __global__ __launch_bounds__(256) void edge_gather_max_kernel(GatherArgs g)
 // L2 -- 13 % misses cost more instructions than the hits save; panel-major P/Q -- no gain, the 32-B row pieces are
 // not over-fetched.)
 // ------------------------------------------------------------------------------------------
+constexpr unsigned KAGG_IMG1 = 65536 + 128;   // byte offset of the second LDS image (channels 4-7 of the slice)
+
 struct CloudOps {
     uint2 ix[5];    // 20 16-bit neighbour indices
     float4 q;
@@ -143,11 +145,17 @@ template <bool HAS_Q>
 __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArgs g, const uint16_t* __restrict__ idx16,
                                                                        int nslices, float ns)
 {
-    extern __shared__ float4 win[];   // [N][2]
-    constexpr int LPP = 2, GROUPS = 512, KQ = 5;
+    extern __shared__ float4 win[];   // two images [N][16 B]: channels 0-3 at byte 0, channels 4-7 at byte KAGG_IMG1
+    constexpr int GROUPS = 512, KQ = 5;
     const int tid = threadIdx.x;
     const int cl = tid & 1;
     const int grp = tid >> 1;
+    // The packed indices are BYTE offsets of the 16-byte row pieces (16 * j, lpd_pack_idx16): a gather address is one
+    // SDWA add of a 16-bit half to this lane's image base (the 32-byte-row form cost and + shift + add per gather, a
+    // fifth of the kernel's instructions; with no memory traffic at all the kernel ran 55 of its 107 us: issue-bound).
+    // The second image starts half a bank row (128 B) past 64 KiB so the two lanes of a point never share a bank.
+    const unsigned lbase = cl * KAGG_IMG1;
+    const char* winb = reinterpret_cast<const char*>(win);
     const int w = lpd_xcd_remap(blockIdx.x, gridDim.x);   // the slices of one cloud run next to each other on one XCD
     const int sl = w % nslices;
     const int b = w / nslices;
@@ -165,34 +173,45 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArg
     auto load = [&](CloudOps& o, int ps) {
         o.m = row0 + min(ps * GROUPS + grp, N - 1);
         // blocked index layout [M/32][5][32] uint2 (lpd_pack_idx16): a wave's load touches 4 lines instead of 20
-        const unsigned ib = (o.m >> 5) * (KQ * 32) + (o.m & 31);
+        const uint2* ip = idx2 + ((o.m >> 5) * (KQ * 32) + (o.m & 31));   // one address, five immediate offsets
 #pragma unroll
-        for (int i = 0; i < KQ; ++i) o.ix[i] = idx2[ib + i * 32];
+        for (int i = 0; i < KQ; ++i) o.ix[i] = ip[i * 32];
         if (HAS_Q) o.q = *reinterpret_cast<const float4*>(Qc + (o.m - row0) * ldq);
     };
-    CloudOps A, Bo, Co;
-    load(A, 0);
-    load(Bo, 1);
 
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.scale) sc = *reinterpret_cast<const float4*>(g.scale + col);
     if (g.shift) sh = *reinterpret_cast<const float4*>(g.shift + col);
     const float4 sg = make_float4(sc.x >= 0.f ? 1.f : -1.f, sc.y >= 0.f ? 1.f : -1.f, sc.z >= 0.f ? 1.f : -1.f,
                                   sc.w >= 0.f ? 1.f : -1.f);
+    // the cloud's slice of P: every row piece of the workgroup is requested before the first one is stored to LDS
     const float* Pc = g.P + b * g.p_cloud + sl * g.p_slice + cl * 4;
-    for (int r = grp; r < N; r += GROUPS) {
-        float4 p = *reinterpret_cast<const float4*>(Pc + (size_t)r * g.ldp);
-        p.x *= sg.x; p.y *= sg.y; p.z *= sg.z; p.w *= sg.w;
-        win[r * LPP + cl] = p;
+    {
+        constexpr int NP = 4096 / GROUPS;
+        float4 pr[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) pr[i] = *reinterpret_cast<const float4*>(Pc + (size_t)min(grp + i * GROUPS, N - 1) * g.ldp);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int r = grp + i * GROUPS;
+            float4 p = pr[i];
+            p.x *= sg.x; p.y *= sg.y; p.z *= sg.z; p.w *= sg.w;
+            if (r < N) *reinterpret_cast<float4*>(const_cast<char*>(winb) + lbase + r * 16) = p;
+        }
     }
+    CloudOps A, Bo, Co;
+    load(A, 0);
+    load(Bo, 1);
     __syncthreads();
 
     auto process = [&](const CloudOps& o) {
         float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
         for (int i = 0; i < KQ; ++i) {
-            const float4 a = win[(o.ix[i].x & 0xffffu) * LPP + cl], bq = win[(o.ix[i].x >> 16) * LPP + cl];
-            const float4 c = win[(o.ix[i].y & 0xffffu) * LPP + cl], d = win[(o.ix[i].y >> 16) * LPP + cl];
+            const float4 a = *reinterpret_cast<const float4*>(winb + ((o.ix[i].x & 0xffffu) + lbase));
+            const float4 bq = *reinterpret_cast<const float4*>(winb + ((o.ix[i].x >> 16) + lbase));
+            const float4 c = *reinterpret_cast<const float4*>(winb + ((o.ix[i].y & 0xffffu) + lbase));
+            const float4 d = *reinterpret_cast<const float4*>(winb + ((o.ix[i].y >> 16) + lbase));
             v.x = fmaxf(fmaxf(v.x, a.x), bq.x); v.y = fmaxf(fmaxf(v.y, a.y), bq.y);
             v.z = fmaxf(fmaxf(v.z, a.z), bq.z); v.w = fmaxf(fmaxf(v.w, a.w), bq.w);
             v.x = fmaxf(fmaxf(v.x, c.x), d.x); v.y = fmaxf(fmaxf(v.y, c.y), d.y);
@@ -220,7 +239,111 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArg
     }
 }
 
-// int32 [M][20] -> uint16, blocked for the kernel above: point m, index quad i (4 x u16 = uint2) at
+// Persistent form for 8-pass clouds (3584 < N <= 4096, the benchmark shape): a workgroup walks `per` consecutive
+// (cloud, slice) items and requests the NEXT item's P rows while it works through the current one -- one float4 per
+// thread and pass, parked in registers until the gathers of the current slice are done, then stored to LDS.  With one
+// workgroup per CU (128 KiB of LDS) nothing else can hide the fill (ablation at B = 32, C = 256: 107 us; without the
+// fill 80; without Q / out traffic 79; with no global memory traffic at all 55).  The last item of a workgroup
+// prefetches itself again (L2 hits; a branch around the loads would make the compiler's in-order vmcnt accounting
+// wait for them early).
+template <bool HAS_Q>
+__global__ __launch_bounds__(1024) void edge_gather_max_cloud16p_kernel(GatherArgs g, const uint16_t* __restrict__ idx16,
+                                                                        int nslices, float ns, int nwork, int per)
+{
+    extern __shared__ float4 win[];
+    constexpr int GROUPS = 512, KQ = 5, NP = 8;
+    const int tid = threadIdx.x;
+    const int cl = tid & 1;
+    const int grp = tid >> 1;
+    const unsigned lbase = cl * KAGG_IMG1;
+    char* winb = reinterpret_cast<char*>(win);
+    const int vb = lpd_xcd_remap(blockIdx.x, gridDim.x);    // consecutive items (the slices of a cloud) stay on one XCD
+    const int w_begin = vb * per;
+    const int w_end = min(w_begin + per, nwork);
+    if (w_begin >= w_end) return;
+    const int N = g.N;
+    const uint2* idx2 = reinterpret_cast<const uint2*>(idx16);
+    const unsigned ldq = g.ldq, ldo = g.ldo;
+    auto p_slice_ptr = [&](int w) { return g.P + (long long)(w / nslices) * g.p_cloud + (long long)(w % nslices) * g.p_slice + cl * 4; };
+
+    float4 pn[NP];
+    {
+        const float* Pc = p_slice_ptr(w_begin);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) pn[i] = *reinterpret_cast<const float4*>(Pc + (size_t)min(grp + i * GROUPS, N - 1) * g.ldp);
+    }
+    for (int w = w_begin; w < w_end; ++w) {
+        int grpw = grp;
+        asm volatile("" : "+v"(grpw));   // keeps the row offsets from being hoisted out of the item loop (register pressure)
+        const int sl = w % nslices;
+        const int b = w / nslices;
+        const int col = sl * 8 + cl * 4;
+        const unsigned row0 = (unsigned)b * N;
+        const float* Qc = g.Q + b * g.q_cloud + sl * g.q_slice + cl * 4;
+        float* outc = g.out + b * g.o_cloud + sl * g.o_slice + cl * 4;
+        const float* Pn = p_slice_ptr(min(w + 1, w_end - 1));
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.scale) sc = *reinterpret_cast<const float4*>(g.scale + col);
+        if (g.shift) sh = *reinterpret_cast<const float4*>(g.shift + col);
+        const float4 sg = make_float4(sc.x >= 0.f ? 1.f : -1.f, sc.y >= 0.f ? 1.f : -1.f, sc.z >= 0.f ? 1.f : -1.f,
+                                      sc.w >= 0.f ? 1.f : -1.f);
+        auto load = [&](CloudOps& o, int ps) {
+            o.m = row0 + min(ps * GROUPS + grpw, N - 1);
+            const uint2* ip = idx2 + ((o.m >> 5) * (KQ * 32) + (o.m & 31));
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) o.ix[i] = ip[i * 32];
+            if (HAS_Q) o.q = *reinterpret_cast<const float4*>(Qc + (o.m - row0) * ldq);
+        };
+        CloudOps ops3[3];
+        load(ops3[0], 0);
+        load(ops3[1], 1);
+        // this item's rows (requested during the previous item) -> LDS, sign-adjusted
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int r = grpw + i * GROUPS;
+            float4 pv = pn[i];
+            pv.x *= sg.x; pv.y *= sg.y; pv.z *= sg.z; pv.w *= sg.w;
+            if (r < N) *reinterpret_cast<float4*>(winb + lbase + r * 16) = pv;
+        }
+        __syncthreads();
+        auto process = [&](const CloudOps& o) {
+            float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) {
+                const float4 a = *reinterpret_cast<const float4*>(winb + ((o.ix[i].x & 0xffffu) + lbase));
+                const float4 bq = *reinterpret_cast<const float4*>(winb + ((o.ix[i].x >> 16) + lbase));
+                const float4 c = *reinterpret_cast<const float4*>(winb + ((o.ix[i].y & 0xffffu) + lbase));
+                const float4 d = *reinterpret_cast<const float4*>(winb + ((o.ix[i].y >> 16) + lbase));
+                v.x = fmaxf(fmaxf(v.x, a.x), bq.x); v.y = fmaxf(fmaxf(v.y, a.y), bq.y);
+                v.z = fmaxf(fmaxf(v.z, a.z), bq.z); v.w = fmaxf(fmaxf(v.w, a.w), bq.w);
+                v.x = fmaxf(fmaxf(v.x, c.x), d.x); v.y = fmaxf(fmaxf(v.y, c.y), d.y);
+                v.z = fmaxf(fmaxf(v.z, c.z), d.z); v.w = fmaxf(fmaxf(v.w, c.w), d.w);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float4 r;
+            r.x = sc.x * (sg.x * v.x + (HAS_Q ? o.q.x : 0.f)) + sh.x;
+            r.y = sc.y * (sg.y * v.y + (HAS_Q ? o.q.y : 0.f)) + sh.y;
+            r.z = sc.z * (sg.z * v.z + (HAS_Q ? o.q.z : 0.f)) + sh.z;
+            r.w = sc.w * (sg.w * v.w + (HAS_Q ? o.q.w : 0.f)) + sh.w;
+            r.x = fmaxf(r.x, 0.f) + ns * fminf(r.x, 0.f);
+            r.y = fmaxf(r.y, 0.f) + ns * fminf(r.y, 0.f);
+            r.z = fmaxf(r.z, 0.f) + ns * fminf(r.z, 0.f);
+            r.w = fmaxf(r.w, 0.f) + ns * fminf(r.w, 0.f);
+            *reinterpret_cast<float4*>(outc + (o.m - row0) * ldo) = r;
+        };
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ps + 2 < NP) load(ops3[(ps + 2) % 3], ps + 2);
+            pn[ps] = *reinterpret_cast<const float4*>(Pn + (size_t)min(grpw + ps * GROUPS, N - 1) * g.ldp);
+            __builtin_amdgcn_sched_barrier(0);
+            process(ops3[ps % 3]);
+        }
+        __syncthreads();   // every gather of this slice is done: LDS may be refilled
+    }
+}
+
+// int32 [M][20] -> uint16 (16 * index; indices < 4096), blocked for the kernel above: point m, index quad i (4 x u16 = uint2) at
 // ((m / 32) * 5 + i) * 32 + m % 32.  One thread per (point, quad).
 __global__ void pack_idx16_kernel(const int32_t* __restrict__ in, uint2* __restrict__ out, long long M)
 {
@@ -230,8 +353,8 @@ __global__ void pack_idx16_kernel(const int32_t* __restrict__ in, uint2* __restr
     if (m >= M) return;
     const int4 v = *reinterpret_cast<const int4*>(in + m * 20 + i * 4);
     uint2 o;
-    o.x = (uint32_t)(v.x & 0xffff) | ((uint32_t)v.y << 16);
-    o.y = (uint32_t)(v.z & 0xffff) | ((uint32_t)v.w << 16);
+    o.x = (uint32_t)((v.x << 4) & 0xffff) | ((uint32_t)v.y << 20);     // 16 * index: the byte offset of the row piece in LDS
+    o.y = (uint32_t)((v.z << 4) & 0xffff) | ((uint32_t)v.w << 20);
     out[((m >> 5) * 5 + i) * 32 + (m & 31)] = o;
 }
 
@@ -680,8 +803,8 @@ extern "C" int lpd_edge_gather_max16(const float* P, int ldp, const float* Q, in
                   "lpd_edge_gather_max16: leading dims must be multiples of 4");
     LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)out | (uintptr_t)Q | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0 &&
                   ((uintptr_t)idx16 & 7) == 0, "lpd_edge_gather_max16: pointers must be 16-byte aligned (idx16: 8)");
-    LPD_CHECK_ARG(k == 20 && (size_t)N * 8 * sizeof(float) <= 160 * 1024,
-                  "lpd_edge_gather_max16: built for k = 20 and N <= 5120 (an 8-channel slice of one cloud in LDS); got k=%d N=%d", k, N);
+    LPD_CHECK_ARG(k == 20 && N <= 4096,
+                  "lpd_edge_gather_max16: built for k = 20 and N <= 4096 (an 8-channel slice of one cloud in LDS, 16-bit byte offsets); got k=%d N=%d", k, N);
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_gather_max16: act=%d unsupported (none/ReLU/LeakyReLU)", act);
     LPD_CHECK_ARG((unsigned long long)N * (unsigned long long)(o_cloud ? 8 : ldo) * 4ull < (1ull << 32) &&
                   (unsigned long long)N * (unsigned long long)(q_cloud ? 8 : ldq) * 4ull < (1ull << 32) &&
@@ -693,9 +816,26 @@ extern "C" int lpd_edge_gather_max16(const float* P, int ldp, const float* Q, in
                  p_cloud ? ps : 8, q_cloud ? ps : 8, o_cloud ? ps : 8,
                  p_cloud ? p_cloud : (long long)N * ldp, q_cloud ? q_cloud : (long long)N * ldq, o_cloud ? o_cloud : (long long)N * ldo};
     const int nslices = C / 8;
-    const size_t lds = (size_t)N * 8 * sizeof(float);
+    const size_t lds = (size_t)KAGG_IMG1 + (size_t)N * 16;
     const float ns = act == 0 ? 1.0f : (act == 1 ? 0.0f : slope);
-    if (Q) {
+    // persistent form: one workgroup per CU, (items / 256 CUs) consecutive items each; LPD_KAGG_PERSIST = 0 disables, n forces n
+    static const int persist = getenv("LPD_KAGG_PERSIST") ? atoi(getenv("LPD_KAGG_PERSIST")) : -1;
+    const int nwork = (M / N) * nslices;
+    const int per_auto = (nwork + 255) / 256;
+    if (persist != 0 && N > 3584 && N <= 4096 && (persist > 0 ? persist : per_auto) >= 3) {   // eight passes of 512 points; with two items
+                                                                                              // per CU the dynamic launch is faster (C = 128: 61 vs 72 us)
+        const int per = persist > 0 ? persist : per_auto;
+        const int grid = (nwork + per - 1) / per;
+        if (Q) {
+            auto kern = edge_gather_max_cloud16p_kernel<true>;
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, stream, g, idx16, nslices, ns, nwork, per);
+        } else {
+            auto kern = edge_gather_max_cloud16p_kernel<false>;
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, stream, g, idx16, nslices, ns, nwork, per);
+        }
+    } else if (Q) {
         auto kern = edge_gather_max_cloud16_kernel<true>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3((M / N) * nslices), dim3(1024), lds, stream, g, idx16, nslices, ns);

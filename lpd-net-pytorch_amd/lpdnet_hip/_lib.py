@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblpd_hip.so")
+LIB_PATH = os.environ.get("LPD_HIP_LIB") or os.path.join(_HERE, "liblpd_hip.so")   # override: kernel-variant builds (tools/)
 
 _c_int = ctypes.c_int
 _c_ll = ctypes.c_longlong

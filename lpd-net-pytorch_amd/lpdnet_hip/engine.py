@@ -162,12 +162,12 @@ PANEL_LAYOUT = __import__("os").environ.get("LPD_PANELS", "1") != "0"
 
 def _kagg_cloud_resident(idx, N, M, act):
     """the cloud-resident K-agg kernel is built for this shape (an 8-channel slice of one cloud fits LDS, k = 20)"""
-    return (idx.shape[-1] == 20 and N * 32 <= 160 * 1024 and act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY)
+    return (idx.shape[-1] == 20 and N <= 4096 and act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY)
             and M * 512 * 4 < 2 ** 32)
 
 
 def kagg(P, Q, idx, N, *, scale, shift, act, slope, out):
-    """K-agg dispatch: the cloud-resident kernel when an 8-channel slice of one cloud fits LDS (N <= 5120) and k = 20,
+    """K-agg dispatch: the cloud-resident kernel when an 8-channel slice of one cloud fits LDS (N <= 4096) and k = 20,
     the direct gather otherwise (cfg5: N = 16384, k = 64).  Same bits either way."""
     if _kagg_cloud_resident(idx, N, P.shape[0], act):
         return ops.edge_gather_max16(P, Q, ops.pack_idx16(idx), N, scale=scale, shift=shift, act=act, slope=slope, out=out)

@@ -416,7 +416,7 @@ def pack_idx16(idx):
 
 
 def edge_gather_max16(P, Q, idx16, N, *, scale=None, shift=None, act=ACT_NONE, slope=0.01, out=None):
-    """Cloud-resident K-agg (k = 20, N <= 5120): same result as edge_gather_max; idx16 from pack_idx16.
+    """Cloud-resident K-agg (k = 20, N <= 4096): same result as edge_gather_max; idx16 from pack_idx16.
     P, Q and out are row-major [M, C] (2-D, column slices allowed) or cloud-panel views [B, C/8, N, 8] (4-D): with panels
     a block's 8-channel slice is one contiguous 32*N-byte run."""
     _req(idx16, "idx16", torch.int16)

@@ -267,7 +267,7 @@ def test_edge_gather_max(cuda, C, N, k, B):
     assert _rel(out2, _gather(P, idx, B, N).max(dim=1)[0]) == 0.0
 
 
-@pytest.mark.parametrize("C,N,B,act", [(256, 512, 2, 2), (128, 1000, 3, 1), (64, 37, 2, 0), (256, 4096, 2, 2), (64, 5120, 1, 2)])
+@pytest.mark.parametrize("C,N,B,act", [(256, 512, 2, 2), (128, 1000, 3, 1), (64, 37, 2, 0), (256, 4096, 2, 2), (64, 3000, 1, 2)])
 def test_edge_gather_max_cloud_resident_is_bit_identical(cuda, C, N, B, act):
     """lpd_edge_gather_max16 (LDS-resident cloud slice, uint16 indices) == lpd_edge_gather_max, bit for bit; ragged N,
     point counts that are not multiples of 32 or 512, output into a column slice, and the no-centre-term form."""

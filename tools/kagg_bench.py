@@ -42,7 +42,7 @@ for C in (256, 128):
     us = ev[0].elapsed_time(ev[1]) * 1e3 / R
     alg = M * (3 * C * 4 + 4 * k)
     # cloud-resident kernel
-    if k == 20 and N * 32 <= 160 * 1024:
+    if k == 20 and N <= 4096:
         idx16 = ops.pack_idx16(idx)
         out3 = torch.empty((M, C), device=dev)
         def run16():
