@@ -170,18 +170,22 @@ int lpd_transpose(const float* in, float* out, int batch, int R, int C, int ldi,
                   long long so, void* stream);
 
 /* NetVLAD soft-assignment: out[r][:] = softmax(scale * in[r][:] + shift), ncols <= 64
- * (util/PointNetVlad.py:51-58, eval-mode bn1 folded into scale/shift). In-place allowed. */
+ * (util/PointNetVlad.py:51-58, eval-mode bn1 folded into scale/shift). In-place allowed.
+ * colsum != NULL: rows come in groups (clouds) of group_rows (a multiple of 16) and colsum[g * colsum_ld + c] receives
+ * (+=, float atomics; the caller zeroes it) the column sums of `out` over group g -- NetVLAD's a_sum (:63) without a
+ * second pass over the assignments. */
 int lpd_softmax_affine(const float* in, float* out, int rows, int ncols, const float* scale, const float* shift,
-                       void* stream);
+                       int group_rows, float* colsum, int colsum_ld, void* stream);
 
 /* NetVLAD residual + normalisations (util/PointNetVlad.py:61-74).
  *   vraw [B][F][KC] = act^T x per cloud, act [B][N][KC], cw2 [F][KC] (cluster_weights2[0]),
  *   out [B][F*KC]: (vraw - a_sum*cw2), L2-normalised over F per cluster, flattened f*KC+c, L2-normalised. KC = 64.
- *   ws: workspace of B*2*KC floats (a_sum and per-cluster sums of squares, zeroed here).
+ *   ws: workspace of B*2*KC floats (a_sum and per-cluster sums of squares, zeroed here); asum_ready != 0: ws[b][0..KC)
+ *   already holds a_sum (lpd_softmax_affine with colsum = ws, colsum_ld = 2*KC), ws[b][KC..2KC) is zero, act may be NULL.
  *   aux_asum [B][KC], aux_inv_c [B][KC], aux_inv_g [B]: optional (NULL in inference) -- a_sum and the two
  *   reciprocal norms, saved for lpd_vlad_finalize_bwd. */
 int lpd_vlad_finalize(const float* vraw, const float* act, const float* cw2, float* out, float* ws, float* aux_asum,
-                      float* aux_inv_c, float* aux_inv_g, int B, int N, int F, int KC, void* stream);
+                      float* aux_inv_c, float* aux_inv_g, int B, int N, int F, int KC, int asum_ready, void* stream);
 
 /* Per-cloud max over the N points: in [B][N][ldi] -> out [B][C]
  * (util/PointNetVlad.py:137,162 mp1; util/lpdnet_model.py:300). */

@@ -243,9 +243,9 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArg
 // (cloud, slice) items and requests the NEXT item's P rows while it works through the current one -- one float4 per
 // thread and pass, parked in registers until the gathers of the current slice are done, then stored to LDS.  With one
 // workgroup per CU (128 KiB of LDS) nothing else can hide the fill (ablation at B = 32, C = 256: 107 us; without the
-// fill 80; without Q / out traffic 79; with no global memory traffic at all 55).  The last item of a workgroup
-// prefetches itself again (L2 hits; a branch around the loads would make the compiler's in-order vmcnt accounting
-// wait for them early).
+// fill 80; without Q / out traffic 79; with no global memory traffic at all 55).  During its last item a workgroup
+// keeps issuing the loads with a row stride of 0 (one 32-byte piece, no traffic): a branch around them would make the
+// compiler's in-order vmcnt accounting wait for them early.
 template <bool HAS_Q>
 __global__ __launch_bounds__(1024) void edge_gather_max_cloud16p_kernel(GatherArgs g, const uint16_t* __restrict__ idx16,
                                                                         int nslices, float ns, int nwork, int per)
@@ -282,6 +282,7 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16p_kernel(GatherAr
         const float* Qc = g.Q + b * g.q_cloud + sl * g.q_slice + cl * 4;
         float* outc = g.out + b * g.o_cloud + sl * g.o_slice + cl * 4;
         const float* Pn = p_slice_ptr(min(w + 1, w_end - 1));
+        const unsigned ldpn = w + 1 < w_end ? (unsigned)g.ldp : 0u;   // last item: every lane re-reads one row piece (no traffic)
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g.scale) sc = *reinterpret_cast<const float4*>(g.scale + col);
         if (g.shift) sh = *reinterpret_cast<const float4*>(g.shift + col);
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16p_kernel(GatherAr
         for (int ps = 0; ps < NP; ++ps) {
             __builtin_amdgcn_sched_barrier(0);
             if (ps + 2 < NP) load(ops3[(ps + 2) % 3], ps + 2);
-            pn[ps] = *reinterpret_cast<const float4*>(Pn + (size_t)min(grpw + ps * GROUPS, N - 1) * g.ldp);
+            pn[ps] = *reinterpret_cast<const float4*>(Pn + (size_t)((unsigned)min(grpw + ps * GROUPS, N - 1) * ldpn));
             __builtin_amdgcn_sched_barrier(0);
             process(ops3[ps % 3]);
         }

@@ -77,6 +77,84 @@ __global__ void softmax_affine_kernel(const float* __restrict__ in, float* __res
     if (lane < ncols) out[(size_t)row * ncols + lane] = e / s;
 }
 
+// The same with the per-cloud column sums of the result (NetVLAD's a_sum, util/PointNetVlad.py:63) accumulated on the way:
+// one wavefront walks SM_RPW consecutive rows of one cloud (lane = column), four rows in flight, and adds its 64 partial
+// sums to colsum[cloud][lane] with one atomic instruction -- the separate a_sum pass re-read the 33 MB of assignments
+// (28 us at B = 32; this kernel: the softmax's own time).
+constexpr int SM_RPW = 16;
+__global__ __launch_bounds__(256) void softmax_affine_colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                                                    int ncols, const float* scale, const float* shift,
+                                                                    int group_rows, float* __restrict__ colsum, int colsum_ld)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row0 = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * SM_RPW;
+    if (row0 >= rows) return;
+    const bool on = lane < ncols;
+    float sc = 1.0f, sh = 0.0f;
+    if (scale && on) { sc = scale[lane]; sh = shift[lane]; }
+    float acc = 0.0f;
+#pragma unroll 4
+    for (int r = 0; r < SM_RPW; ++r) {
+        const long long row = row0 + r;       // rows % SM_RPW == 0 (host check)
+        float v = on ? in[row * ncols + lane] * sc + sh : -INFINITY;
+        float mx = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float e = on ? expf(v - mx) : 0.0f;
+        float s = e;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float p = e / s;
+        if (on) out[row * ncols + lane] = p;
+        acc += p;
+    }
+    if (on) atomicAdd(&colsum[(row0 / group_rows) * colsum_ld + lane], acc);
+}
+
+// 64 columns: sixteen lanes per row (float4 each), four rows per wave-instruction -- 1 KiB loads / stores and four
+// shuffle steps per reduction instead of 256-byte accesses and six (36 -> 2x faster at 131072 rows).
+__global__ __launch_bounds__(256) void softmax_affine_colsum64_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                                                      const float* scale, const float* shift, int group_rows,
+                                                                      float* __restrict__ colsum, int colsum_ld)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = lane & 15, sub = lane >> 4;                  // column quad, row inside the group of four
+    const long long row0 = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * SM_RPW;   // rows % (4 SM_RPW) == 0
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) { sc = *reinterpret_cast<const float4*>(scale + 4 * q); sh = *reinterpret_cast<const float4*>(shift + 4 * q); }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < SM_RPW; r += 4) {
+        const long long row = row0 + r + sub;
+        float4 v = *reinterpret_cast<const float4*>(in + row * 64 + 4 * q);
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float4 e = make_float4(expf(v.x - mx), expf(v.y - mx), expf(v.z - mx), expf(v.w - mx));
+        float s = (e.x + e.y) + (e.z + e.w);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        e.x /= s; e.y /= s; e.z /= s; e.w /= s;
+        *reinterpret_cast<float4*>(out + row * 64 + 4 * q) = e;
+        acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
+    }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+        acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    // one 256-byte atomic instruction per workgroup (its 4 x SM_RPW rows lie in one cloud): every wave of a cloud adds
+    // into the same 64 floats, and the first version's four 16-lane atomics per WAVE cost more than the softmax itself
+    __shared__ float part[4][64];
+    if (sub == 0) *reinterpret_cast<float4*>(&part[threadIdx.x >> 6][4 * q]) = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        atomicAdd(colsum + (row0 / group_rows) * colsum_ld + lane, t);
+    }
+}
+
 // block reduce helper (sum) over 256 threads
 __device__ __forceinline__ float block_sum_256(float v, float* red)
 {
@@ -290,30 +368,44 @@ extern "C" int lpd_transpose(const float* in, float* out, int batch, int R, int 
     return LPD_OK;
 }
 
-extern "C" int lpd_softmax_affine(const float* in, float* out, int rows, int ncols, const float* scale,
-                                  const float* shift, void* stream_)
+extern "C" int lpd_softmax_affine(const float* in, float* out, int rows, int ncols, const float* scale, const float* shift,
+                                  int group_rows, float* colsum, int colsum_ld, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(in && out, "lpd_softmax_affine: null pointer");
     LPD_CHECK_ARG(rows > 0 && ncols > 0 && ncols <= 64, "lpd_softmax_affine: bad dims rows=%d ncols=%d (<= 64)", rows, ncols);
     LPD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "lpd_softmax_affine: scale and shift must be given together");
-    hipLaunchKernelGGL(softmax_affine_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, out, rows, ncols, scale, shift);
+    if (colsum) {
+        LPD_CHECK_ARG(group_rows > 0 && group_rows % SM_RPW == 0 && rows % group_rows == 0 && colsum_ld >= ncols,
+                      "lpd_softmax_affine: column sums need group_rows %% %d == 0 and rows %% group_rows == 0", SM_RPW);
+        const int waves = rows / SM_RPW;
+        if (ncols == 64 && group_rows % (4 * SM_RPW) == 0 && ((((uintptr_t)in | (uintptr_t)out | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0))
+            hipLaunchKernelGGL(softmax_affine_colsum64_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, in, out, rows, scale, shift,
+                               group_rows, colsum, colsum_ld);
+        else
+            hipLaunchKernelGGL(softmax_affine_colsum_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, in, out, rows, ncols, scale, shift,
+                               group_rows, colsum, colsum_ld);
+    } else {
+        hipLaunchKernelGGL(softmax_affine_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, out, rows, ncols, scale, shift);
+    }
     LPD_CHECK_LAUNCH("lpd_softmax_affine");
     return LPD_OK;
 }
 
 extern "C" int lpd_vlad_finalize(const float* vraw, const float* act, const float* cw2, float* out, float* ws,
                                  float* aux_asum, float* aux_inv_c, float* aux_inv_g, int B, int N, int F, int KC,
-                                 void* stream_)
+                                 int asum_ready, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    LPD_CHECK_ARG(vraw && act && cw2 && out && ws, "lpd_vlad_finalize: null pointer");
+    LPD_CHECK_ARG(vraw && (act || asum_ready) && cw2 && out && ws, "lpd_vlad_finalize: null pointer");
     LPD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && F > 0, "lpd_vlad_finalize: bad dims");
     LPD_CHECK_ARG(KC == 64, "lpd_vlad_finalize: cluster_size=%d unsupported (64)", KC);
-    (void)hipMemsetAsync(ws, 0, sizeof(float) * (size_t)B * 2 * KC, stream);
-    const int nchunks = N >= 1024 ? 16 : (N + 63) / 64;
-    hipLaunchKernelGGL(vlad_asum_kernel<64>, dim3(nchunks, B), dim3(256), 0, stream, act, ws, N);
-    LPD_CHECK_LAUNCH("lpd_vlad_finalize(asum)");
+    if (!asum_ready) {   // else ws[b][0..KC) already holds a_sum (lpd_softmax_affine with colsum) and ws[b][KC..2KC) is zero
+        (void)hipMemsetAsync(ws, 0, sizeof(float) * (size_t)B * 2 * KC, stream);
+        const int nchunks = N >= 1024 ? 16 : (N + 63) / 64;
+        hipLaunchKernelGGL(vlad_asum_kernel<64>, dim3(nchunks, B), dim3(256), 0, stream, act, ws, N);
+        LPD_CHECK_LAUNCH("lpd_vlad_finalize(asum)");
+    }
     const int FCH = 64;
     const int fblocks = (F + FCH - 1) / FCH;
     hipLaunchKernelGGL(vlad_resid_kernel<64>, dim3(fblocks, B), dim3(256), 0, stream, vraw, cw2, out, ws, F, FCH);

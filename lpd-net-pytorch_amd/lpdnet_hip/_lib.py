@@ -49,8 +49,8 @@ SIGNATURES = {
     "lpd_linear_smallk": [_c_p, _c_int, _c_p, _c_int, _c_int, _c_ll, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int,
                           _c_p, _c_p, _c_p, _c_int, _c_f, _c_p],
     "lpd_transpose": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_p],
-    "lpd_softmax_affine": [_c_p, _c_p, _c_int, _c_int, _c_p, _c_p, _c_p],
-    "lpd_vlad_finalize": [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "lpd_softmax_affine": [_c_p, _c_p, _c_int, _c_int, _c_p, _c_p, _c_int, _c_p, _c_int, _c_p],
+    "lpd_vlad_finalize": [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "lpd_colmax": [_c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_p],
     "lpd_mul": [_c_p, _c_p, _c_p, _c_ll, _c_p],
     "lpd_morton_sort": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p],

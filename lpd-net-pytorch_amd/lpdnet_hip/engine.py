@@ -318,15 +318,18 @@ def netvlad_eval(vlad, feat, B, N):
         raise ValueError(f"NetVLADLoupe was built for max_samples={vlad.max_samples}, got N={N}")
     E, K = vlad.feature_size, vlad.cluster_size
     if vlad.add_batch_norm:
-        a = ops.gemm(feat, vlad.cluster_weights, b_kmajor=True)
         s, b = bn_affine(vlad.bn1)
-        a = ops.softmax_affine(a, s, b, out=a)
     else:
-        ones = _cached(vlad, "ones", (vlad.cluster_biases,), lambda: torch.ones_like(vlad.cluster_biases))
-        a = ops.gemm(feat, vlad.cluster_weights, b_kmajor=True)
-        a = ops.softmax_affine(a, ones, vlad.cluster_biases, out=a)
+        s = _cached(vlad, "ones", (vlad.cluster_biases,), lambda: torch.ones_like(vlad.cluster_biases))
+        b = vlad.cluster_biases
+    a = ops.gemm(feat, vlad.cluster_weights, b_kmajor=True)
+    ws = None
+    if N % 16 == 0:      # a_sum (:63) falls out of the softmax pass
+        a, ws = ops.softmax_affine(a, s, b, out=a, colsum_rows=N)
+    else:
+        a = ops.softmax_affine(a, s, b, out=a)
     vraw = ops.gemm(feat.view(B, N, E), a.view(B, N, K), a_kmajor=True, b_kmajor=True, splits=_pool_splits(B, N, E))     # [B,E,K]
-    v = ops.vlad_finalize(vraw, a.view(B, N, K), vlad.cluster_weights2.view(E, K))         # [B,E*K]
+    v = ops.vlad_finalize(vraw, a.view(B, N, K), vlad.cluster_weights2.view(E, K), ws=ws)  # [B,E*K]
     s, b = bn_affine(vlad.bn2)
     h = ops.gemm(v, vlad.hidden1_weights, b_kmajor=True, scale=s, shift=b, splits=_head_splits(E * K))
     if not vlad.gating:

@@ -493,7 +493,11 @@ def transpose(x):
     return out
 
 
-def softmax_affine(x, scale=None, shift=None, out=None):
+def softmax_affine(x, scale=None, shift=None, out=None, colsum_rows=None):
+    """softmax(scale * x + shift) over the (<= 64) columns of every row.
+
+    colsum_rows = N: the rows are clouds of N consecutive points (N % 16 == 0); also returns the [B, 2*n] workspace of
+    vlad_finalize with the per-cloud column sums (NetVLAD's a_sum) in its first n columns -> (out, ws)."""
     _rows(x, "x")
     x = x.contiguous()
     rows, n = x.shape
@@ -501,15 +505,23 @@ def softmax_affine(x, scale=None, shift=None, out=None):
         out = torch.empty_like(x)
     scale, shift = _vec(scale, "scale", n), _vec(shift, "shift", n)
     lib = _lib.load()
-    _call("softmax_affine", lib.lpd_softmax_affine, _ptr(x), _ptr(out), rows, n, _ptr(scale), _ptr(shift), _stream())
-    return out
+    if colsum_rows is None:
+        _call("softmax_affine", lib.lpd_softmax_affine, _ptr(x), _ptr(out), rows, n, _ptr(scale), _ptr(shift), 0, None, 0, _stream())
+        return out
+    if colsum_rows % 16 or rows % colsum_rows:
+        raise ValueError("softmax_affine: colsum_rows must be a multiple of 16 that divides the row count")
+    ws = torch.zeros((rows // colsum_rows, 2 * n), dtype=torch.float32, device=x.device)
+    _call("softmax_affine", lib.lpd_softmax_affine, _ptr(x), _ptr(out), rows, n, _ptr(scale), _ptr(shift), colsum_rows, _ptr(ws), 2 * n,
+          _stream())
+    return out, ws
 
 
-def vlad_finalize(vraw, act, cw2, out=None, aux=None):
+def vlad_finalize(vraw, act, cw2, out=None, aux=None, ws=None):
     """vraw [B,F,KC], act [B,N,KC], cw2 [F,KC] -> [B,F*KC] normalised VLAD.
 
     out: optional preallocated [>=B, F*KC] buffer (rows beyond B untouched); aux: optional dict that
-    receives asum [B,KC], inv_c [B,KC], inv_g [B] for the backward pass."""
+    receives asum [B,KC], inv_c [B,KC], inv_g [B] for the backward pass; ws: the workspace returned by
+    softmax_affine(..., colsum_rows=N) (a_sum already accumulated: no pass over act)."""
     _req(vraw, "vraw"), _req(act, "act"), _req(cw2, "cw2")
     vraw, act, cw2 = vraw.contiguous(), act.contiguous(), cw2.contiguous()
     B, F, KC = vraw.shape
@@ -522,10 +534,15 @@ def vlad_finalize(vraw, act, cw2, out=None, aux=None):
         a2 = torch.empty((B, KC), dtype=torch.float32, device=vraw.device)
         a3 = torch.empty((B,), dtype=torch.float32, device=vraw.device)
         aux.update(asum=a1, inv_c=a2, inv_g=a3)
-    ws = torch.empty((B, 2 * KC), dtype=torch.float32, device=vraw.device)
+    ready = ws is not None
+    if ready:
+        if ws.shape != (B, 2 * KC) or not ws.is_contiguous():
+            raise ValueError("vlad_finalize: ws must be the [B, 2*KC] workspace of softmax_affine(colsum_rows=N)")
+    else:
+        ws = torch.empty((B, 2 * KC), dtype=torch.float32, device=vraw.device)
     lib = _lib.load()
     _call("vlad_finalize", lib.lpd_vlad_finalize, _ptr(vraw), _ptr(act), _ptr(cw2), _ptr(out), _ptr(ws), _ptr(a1), _ptr(a2),
-          _ptr(a3), B, N, F, KC, _stream())
+          _ptr(a3), B, N, F, KC, int(ready), _stream())
     return out
 
 

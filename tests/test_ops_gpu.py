@@ -343,6 +343,30 @@ def test_vlad_finalize(cuda):
     assert _rel(out, v) < 1e-5
 
 
+@pytest.mark.parametrize("ncols", [64, 40])
+def test_softmax_with_cluster_sums_feeds_vlad_finalize(cuda, ncols):
+    """softmax_affine(colsum_rows=N) = softmax_affine + the per-cloud column sums (a_sum); vlad_finalize(ws=...) on them
+    matches the two-pass form."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, N, F = 3, 208, 96
+    a = (torch.randn(B * N, ncols, generator=g) * 3).to(cuda)
+    sc, sh = torch.randn(ncols, generator=g).to(cuda), torch.randn(ncols, generator=g).to(cuda)
+    plain = ops.softmax_affine(a, sc, sh)
+    fused, ws = ops.softmax_affine(a, sc, sh, colsum_rows=N)
+    assert _rel(fused, plain) < 1e-6      # (the 64-column kernel sums a row in a different order)
+    assert ws.shape == (B, 2 * ncols) and ws[:, ncols:].abs().max().item() == 0
+    assert _rel(ws[:, :ncols], plain.double().view(B, N, ncols).sum(1)) < 1e-6
+    with pytest.raises(ValueError):
+        ops.softmax_affine(a, sc, sh, colsum_rows=N - 8)
+    if ncols == 64:
+        vraw = torch.randn(B, F, 64, generator=g).to(cuda)
+        cw2 = torch.randn(F, 64, generator=g).to(cuda)
+        two_pass = ops.vlad_finalize(vraw, plain.view(B, N, 64), cw2)
+        one_pass = ops.vlad_finalize(vraw, plain.view(B, N, 64), cw2, ws=ws)
+        assert _rel(one_pass, two_pass) < 1e-6
+
+
 def test_errors_are_loud(cuda):
     from lpdnet_hip import LpdHipError
     ops = _ops()
