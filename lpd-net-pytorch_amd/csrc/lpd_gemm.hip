@@ -728,8 +728,74 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_wide_kernel(X3wArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-K partial products for a FEW rows (M <= 64) against a k-major weight matrix: the NetVLAD hidden projection
+// [B, 65536] x [65536, 256] (util/PointNetVlad.py:76) and the T-Net fully-connected layers.  The MFMA kernel fills 32 of
+// its 128 tile rows and runs 128 workgroups, each streaming its weight slice through a 2-barrier LDS pipeline
+// (82 us at B = 32: 1.1 TB/s over the 67 MB of weights).  Here one workgroup owns one split (a KC-deep slice of K) and
+// 256 columns: the X slice sits in LDS ([M][KC], read as broadcast float4), every thread streams ONE column of W
+// (a wave reads 256 contiguous bytes per k) and keeps 16 rows of partial sums in registers; row groups of 16 share the
+// columns.  fp32 FMA chains in k order.  Slab layout = the MFMA kernel's ([split][M][N]), same reduce kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int SMALLM_KC = 256;   // k per split
+typedef float smallm_f2 __attribute__((ext_vector_type(2)));
+typedef float smallm_f4 __attribute__((ext_vector_type(4)));
+
+// RG row groups of 16 rows.  LDS image: row PAIRS interleaved per k ([pair][k][2]) so that one ds_read_b128 brings two
+// k steps of two rows and the partial sums advance two rows per v_pk_fma_f32.
+template <int RG>
+__global__ __launch_bounds__(256 * RG) void linear_smallm_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
+                                                                  float* __restrict__ slabs, int M, int N, int K)
+{
+    constexpr int KC = SMALLM_KC;
+    extern __shared__ __attribute__((aligned(16))) float xs_[];   // [8 RG pairs][KC][2]
+    const int tid = threadIdx.x;
+    const int c = tid & 255, rg = tid >> 8;
+    constexpr int nrows = RG * 16;
+    const int split = blockIdx.x;
+    const int k0 = split * KC;
+    for (int i = tid; i < nrows * KC; i += 256 * RG) {
+        const int r = i / KC, k = i % KC;
+        xs_[((r >> 1) * KC + k) * 2 + (r & 1)] = (r < M && k0 + k < K) ? X[(long long)r * ldx + k0 + k] : 0.0f;
+    }
+    __syncthreads();
+    const int n = blockIdx.y * 256 + c;
+    const float* wp = W + min(n, N - 1);
+    const float* xr = xs_ + rg * 8 * KC * 2;
+    smallm_f2 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) acc[p] = (smallm_f2)(0.0f);
+    // 16 weight rows in flight per thread (4 KiB per wave): with 4 the kernel ran at the latency-bound 1 TB/s
+    auto wrow = [&](int k) { return wp[(long long)min(k0 + k, K - 1) * ldw]; };   // rows past K meet zeros of X
+    float wn[16], wc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wn[j] = wrow(j);
+    for (int k = 0; k < KC; k += 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wc[j] = wn[j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wn[j] = wrow(min(k + 16 + j, KC - 1));   // (the last step re-reads: no branch around loads)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const smallm_f4 x = *reinterpret_cast<const smallm_f4*>(xr + (p * KC + k + 2 * q) * 2);
+                acc[p] = __builtin_elementwise_fma(x.lo, (smallm_f2)(wc[2 * q]), acc[p]);
+                acc[p] = __builtin_elementwise_fma(x.hi, (smallm_f2)(wc[2 * q + 1]), acc[p]);
+            }
+    }
+    if (n < N) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int m = rg * 16 + 2 * p;
+            if (m < M) slabs[((long long)split * M + m) * N + n] = acc[p].x;
+            if (m + 1 < M) slabs[((long long)split * M + m + 1) * N + n] = acc[p].y;
+        }
+    }
+}
+
 // sums split-K slabs and applies the epilogue.  one thread per output element.
-__global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
+__global__ void gemm_splitk_reduce_kernel(const float* slabs, float* C, int M, int N,   // (C may be the slabs: staged reduction)
                                           int ldc, int splits, long long slab_stride, long long sWs_batch,
                                           long long sC_batch, const float* bias, const float* scale,
                                           const float* shift, int act, float slope, int accumulate)
@@ -868,6 +934,20 @@ static int gemm_entry(bool x3, const float* A, const float* B, float* C, int M, 
     }
     const int tn = N > 64 ? 2 : 1;
     int rc;
+    if (splits > 1 && !x3 && !a_kmajor && b_kmajor && batch == 1 && M <= 64 && g.K == SMALLM_KC) {
+        const int rgs = (M + 15) / 16;
+        const size_t lds = (size_t)rgs * 16 * SMALLM_KC * sizeof(float);
+        const dim3 grid(splits, (N + 255) / 256);
+#define LPD_SMALLM(RG_)                                                                                                     \
+        hipLaunchKernelGGL(linear_smallm_kernel<RG_>, grid, dim3(256 * RG_), lds, stream, A, lda, B, ldb, splitk_ws, M, N, K)
+        if (rgs == 1) LPD_SMALLM(1);
+        else if (rgs == 2) LPD_SMALLM(2);
+        else if (rgs == 3) LPD_SMALLM(3);
+        else LPD_SMALLM(4);
+#undef LPD_SMALLM
+        LPD_CHECK_LAUNCH("lpd_gemm(small-M split-K)");
+        rc = LPD_OK;
+    } else {
 #define LPD_GEMM_CASE(AK, BK_)                                                       \
     rc = (tn == 2) ? gemm_launch<AK, BK_, 2>(g, batch, x3, stream) : gemm_launch<AK, BK_, 1>(g, batch, x3, stream)
     if (a_kmajor && b_kmajor) LPD_GEMM_CASE(true, true);
@@ -875,11 +955,24 @@ static int gemm_entry(bool x3, const float* A, const float* B, float* C, int M, 
     else if (b_kmajor) LPD_GEMM_CASE(false, true);
     else LPD_GEMM_CASE(false, false);
 #undef LPD_GEMM_CASE
+    }
     if (rc != LPD_OK) return rc;
     if (splits > 1) {
+        int nslab = splits;
+        long long stride = (long long)M * N;
+        if (batch == 1 && splits >= 64 && splits % 16 == 0) {
+            // many slabs, few outputs (M * N / 256 workgroups): first sum groups of 16 slabs in place (grid z = group; a
+            // thread overwrites the element of its group's first slab it has just read), then the group sums
+            dim3 grid1((N + 255) / 256, M, splits / 16);
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, grid1, dim3(256), 0, stream, (const float*)splitk_ws, splitk_ws, M, N, N, 16,
+                               stride, 16 * stride, 16 * stride, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
+                               0.0f, 0);
+            nslab = splits / 16;
+            stride *= 16;
+        }
         dim3 grid((N + 255) / 256, M, batch);
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, grid, dim3(256), 0, stream, (const float*)splitk_ws, C, M, N,
-                           ldc, splits, (long long)M * N, (long long)splits * M * N, sC, bias, scale, shift, act, slope, accumulate);
+                           ldc, nslab, stride, (long long)splits * M * N, sC, bias, scale, shift, act, slope, accumulate);
         LPD_CHECK_LAUNCH("lpd_gemm(splitk reduce)");
     }
     return LPD_OK;

@@ -199,6 +199,26 @@ def test_gemm_modes(cuda, M, N, K, ak, bk, exact):
     assert torch.equal(again, raw) == exact or not exact
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(1, 256, 4096, 16), (17, 200, 5000, 20), (32, 256, 65536, 256), (44, 256, 8200, 32),
+                                          (64, 72, 3000, 12), (65, 256, 4096, 16)])
+def test_gemm_splitk_few_rows(cuda, M, N, K, splits):
+    """Few rows against a k-major weight matrix (NetVLAD hidden projection, per-cloud layers): the column-streaming split-K
+    kernel for M <= 64 (M = 65: the MFMA kernel), ragged K / N, epilogue applied by the slab reduction, output slice."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K + 4, generator=g)[:, :K]
+    W = torch.randn(K, N + 8, generator=g)[:, 4:4 + N] / K ** 0.5
+    bias, sc, sh = torch.randn(N, generator=g), torch.randn(N, generator=g), torch.randn(N, generator=g)
+    ref = torch.clamp((A.double() @ W.double() + bias.double()) * sc.double() + sh.double(), min=0)
+    Ad = torch.zeros(M, K + 4, device=cuda); Ad[:, :K] = A.to(cuda)
+    Wd = torch.zeros(K, N + 8, device=cuda); Wd[:, 4:4 + N] = W.to(cuda)
+    buf = torch.full((M, N + 8), 7.0, device=cuda)
+    ops.gemm(Ad[:, :K], Wd[:, 4:4 + N], b_kmajor=True, bias=bias.to(cuda), scale=sc.to(cuda), shift=sh.to(cuda), act=ops.ACT_RELU,
+             splits=splits, exact=True, out=buf[:, 4:4 + N])
+    assert _rel(buf[:, 4:4 + N], ref) < 2e-6
+    assert (buf[:, :4] == 7).all() and (buf[:, 4 + N:] == 7).all()
+
+
 @pytest.mark.parametrize("exact", [True, False], ids=["f32mfma", "bf16x3"])
 def test_gemm_splitk_and_batched(cuda, exact):
     ops = _ops()
