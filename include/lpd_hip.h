@@ -191,6 +191,12 @@ int lpd_vlad_finalize(const float* vraw, const float* act, const float* cw2, flo
  * (util/PointNetVlad.py:137,162 mp1; util/lpdnet_model.py:300). */
 int lpd_colmax(const float* in, int ldi, float* out, int B, int N, int C, void* stream);
 
+/* Context gating in one launch (util/PointNetVlad.py:103-115): out[b][:] = h[b][:] * sigmoid((h[b][:] . Wg + bias) * scale + shift),
+ * h [B][ldh], Wg [D][ldw] (gating_weights, k-major), bias / (scale, shift) optional per-column vectors (the eval-mode bn1
+ * affine or gating_biases).  out may not alias h. */
+int lpd_gating(const float* h, int ldh, const float* Wg, int ldw, const float* bias, const float* scale, const float* shift,
+               float* out, int ldo, int B, int D, void* stream);
+
 /* out = a * b elementwise (context gating product, util/PointNetVlad.py:113). */
 int lpd_mul(const float* a, const float* b, float* out, long long n, void* stream);
 

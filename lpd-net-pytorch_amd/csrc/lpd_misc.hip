@@ -426,6 +426,59 @@ extern "C" int lpd_colmax(const float* in, int ldi, float* out, int B, int N, in
     return LPD_OK;
 }
 
+// Context gating in one launch (util/PointNetVlad.py:103-115): out = h * sigmoid((h . Wg + bias) * scale + shift), h [B][D],
+// Wg [D][D] k-major.  One workgroup per row, one output column per thread (a wave reads 256 contiguous bytes of Wg per
+// k; the 256 KiB of Wg stay in L2), the k range in four quarters (four 256-thread groups, summed through LDS).  The MFMA GEMM spent 30 us on this 4-MFLOP product
+// (two workgroups on the whole chip) and the product h * gates was a third launch.
+__global__ __launch_bounds__(1024) void gating_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ Wg, int ldw,
+                                                      const float* __restrict__ bias, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, float* __restrict__ out, int ldo, int D)
+{
+    extern __shared__ float hrow[];     // [D] then [4][256] partial sums
+    float* part = hrow + D;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int c = tid & 255, kq = tid >> 8;                 // column inside the 256-wide tile, quarter of the k range
+    for (int k = tid; k < D; k += 1024) hrow[k] = h[(long long)b * ldh + k];
+    __syncthreads();
+    const int kper = (D + 3) / 4;
+    const int kb = kq * kper, ke = min(kb + kper, D);
+    for (int n0 = 0; n0 < D; n0 += 256) {
+        const int n = n0 + c;
+        const float* w = Wg + min(n, D - 1);
+        float acc = 0.0f;
+        int k = kb;
+        for (; k + 8 <= ke; k += 8) {
+            float wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = w[(long long)(k + j) * ldw];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(hrow[k + j], wv[j], acc);
+        }
+        for (; k < ke; ++k) acc = fmaf(hrow[k], w[(long long)k * ldw], acc);
+        part[kq * 256 + c] = acc;
+        __syncthreads();
+        if (kq == 0 && n < D) {
+            float v = (part[c] + part[256 + c]) + (part[512 + c] + part[768 + c]);
+            if (bias) v += bias[n];
+            if (scale) v = v * scale[n] + shift[n];
+            out[(long long)b * ldo + n] = hrow[n] * lpd_sigmoid(v);
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int lpd_gating(const float* h, int ldh, const float* Wg, int ldw, const float* bias, const float* scale, const float* shift,
+                          float* out, int ldo, int B, int D, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(h && Wg && out && B > 0 && D > 0, "lpd_gating: bad arguments");
+    LPD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "lpd_gating: scale and shift must be given together");
+    LPD_CHECK_ARG(D <= 8192 && ldh >= D && ldw >= D && ldo >= D, "lpd_gating: D=%d (<= 8192), leading dims >= D", D);
+    hipLaunchKernelGGL(gating_kernel, dim3(B), dim3(1024), ((size_t)D + 1024) * sizeof(float), stream, h, ldh, Wg, ldw, bias, scale, shift, out, ldo, D);
+    LPD_CHECK_LAUNCH("lpd_gating");
+    return LPD_OK;
+}
+
 extern "C" int lpd_mul(const float* a, const float* b, float* out, long long n, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;

@@ -53,6 +53,7 @@ SIGNATURES = {
     "lpd_vlad_finalize": [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "lpd_colmax": [_c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_p],
     "lpd_mul": [_c_p, _c_p, _c_p, _c_ll, _c_p],
+    "lpd_gating": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "lpd_morton_sort": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p],
     "lpd_colstats": [_c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p],
     "lpd_bn_finalize": [_c_p, _c_p, ctypes.c_double, _c_int, _c_p, _c_p, _c_p, _c_p, _c_f, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p],

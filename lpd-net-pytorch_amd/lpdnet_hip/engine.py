@@ -342,10 +342,8 @@ def gating_eval(gc, h):
     """util/PointNetVlad.py:103-115."""
     if gc.add_batch_norm:
         s, b = bn_affine(gc.bn1)
-        gates = ops.gemm(h, gc.gating_weights, b_kmajor=True, scale=s, shift=b, act=ops.ACT_SIGMOID)
-    else:
-        gates = ops.gemm(h, gc.gating_weights, b_kmajor=True, bias=gc.gating_biases, act=ops.ACT_SIGMOID)
-    return ops.mul(h, gates)
+        return ops.gating(h, gc.gating_weights, scale=s, shift=b)
+    return ops.gating(h, gc.gating_weights, bias=gc.gating_biases)
 
 
 def to_channel_major(feat, B, N):

@@ -558,6 +558,19 @@ def colmax(x, B, N):
     return out
 
 
+def gating(h, Wg, bias=None, scale=None, shift=None):
+    """Context gating: h * sigmoid((h @ Wg + bias) * scale + shift); h [B,D] rows, Wg [D,D] (k-major)."""
+    ldh, ldw = _rows(h, "h"), _rows(Wg, "Wg")
+    B, D = h.shape
+    if Wg.shape != (D, D):
+        raise ValueError("gating: Wg must be [D, D]")
+    out = torch.empty((B, D), dtype=torch.float32, device=h.device)
+    bias, scale, shift = _vec(bias, "bias", D), _vec(scale, "scale", D), _vec(shift, "shift", D)
+    lib = _lib.load()
+    _call("gating", lib.lpd_gating, _ptr(h), ldh, _ptr(Wg), ldw, _ptr(bias), _ptr(scale), _ptr(shift), _ptr(out), D, B, D, _stream())
+    return out
+
+
 def mul(a, b):
     _req(a, "a"), _req(b, "b")
     a, b = a.contiguous(), b.contiguous()

@@ -387,6 +387,26 @@ def test_softmax_with_cluster_sums_feeds_vlad_finalize(cuda, ncols):
         assert _rel(one_pass, two_pass) < 1e-6
 
 
+@pytest.mark.parametrize("B,D,mode", [(32, 256, "bn"), (5, 200, "bias"), (1, 24, "plain")])
+def test_gating_context(cuda, B, D, mode):
+    """h * sigmoid(affine(h @ Wg)) in one launch (util/PointNetVlad.py:103-115) against fp64."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + D)
+    h = torch.randn(B, D + 4, generator=g)[:, :D]
+    Wg = torch.randn(D, D, generator=g) / D ** 0.5
+    bias, sc, sh = torch.randn(D, generator=g), torch.randn(D, generator=g), torch.randn(D, generator=g)
+    z = h.double() @ Wg.double()
+    kw = {}
+    if mode == "bn":
+        z = z * sc.double() + sh.double(); kw = dict(scale=sc.to(cuda), shift=sh.to(cuda))
+    elif mode == "bias":
+        z = z + bias.double(); kw = dict(bias=bias.to(cuda))
+    ref = h.double() * torch.sigmoid(z)
+    hd = torch.zeros(B, D + 4, device=cuda); hd[:, :D] = h.to(cuda)
+    out = ops.gating(hd[:, :D], Wg.to(cuda), **kw)
+    assert _rel(out, ref) < 2e-6
+
+
 def test_errors_are_loud(cuda):
     from lpdnet_hip import LpdHipError
     ops = _ops()
