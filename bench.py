@@ -207,7 +207,7 @@ def main():
         ms = [a.elapsed_time(b) for a, b in evs]
         kern[name] = {"launches": len(ms), "avg_us": round(1e3 * sum(ms) / len(ms), 2)}
     roof = None
-    key, kname = "edge_gather_max16[C=256]", "edge_gather_max_cloud16_kernel (LDS-resident cloud slice)"
+    key, kname = "edge_gather_max16[C=256]", "edge_gather_max_cloud16p_kernel (persistent workgroups, LDS-resident cloud slice)"
     if key not in kern:     # k != 20 or N > 4096: the direct gather form
         key, kname = "edge_gather_max[C=256]", "edge_gather_max_kernel<64> (direct gather)"
     if key in kern:
