@@ -537,6 +537,7 @@ struct X3wArgs {
     int accumulate;
     long long a_cloud, c_cloud;   // cloud-panel operands (see GemmArgs); 0 = row-major
     int panel_n, panel_ld;
+    int rotate;                   // start the reduction of row tile t at chunk 5 t mod chunks (see the kernel)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -553,13 +554,21 @@ struct X3wArgs {
 // where it consumed them and drained A behind them every chunk: 640 us on conv3 against 505 us now, generic kernel 660.)
 // A may be cloud panels (PANELS & 1), C too (PANELS & 2): a block's 128 rows lie in one cloud.
 // ---------------------------------------------------------------------------------------------
-constexpr int X3V_KC = 32;                 // k per chunk (2 MFMA k-steps)
-constexpr int X3V_LDK = X3V_KC + 8;        // 80-byte LDS rows: conflict-free ds_read_b128
-constexpr int X3V_IMG = 128 * X3V_LDK;     // one image (hi or lo)
-
-template <int WN, bool KTAIL, int PANELS>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_wide_kernel(X3wArgs g)
+// KC: k per chunk (2 or 4 MFMA k-steps); 32 everywhere (64-deep chunks -- 256 instead of 128 bytes per visit of a
+// row-major A row -- changed nothing on the NetVLAD assignment).
+template <int WN, bool KTAIL, int PANELS, int KC, bool TALL = false>
+__global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kernel(X3wArgs g)
 {
+    // TALL (N <= 64, WN = 1): two column tiles only -- the waves split the ROWS as well (wave = column tile + 2 x row half,
+    // two row tiles each) instead of two of the four multiplying tiles that are never stored.
+    constexpr int RT = TALL ? 2 : 4;            // row tiles per wave
+    static_assert(!TALL || WN == 1, "tall blocks are one column tile per wave");
+    constexpr int X3V_KC = KC;
+    constexpr int X3V_LDK = X3V_KC + 8;        // 80- / 144-byte LDS rows: conflict-free ds_read_b128
+    constexpr int X3V_IMG = 128 * X3V_LDK;     // one image (hi or lo)
+    constexpr int NF4 = 128 * KC / 4 / GEMM_THREADS;   // float4 of A per thread and chunk (4 or 8)
+    constexpr int KSC = KC / 16;               // k-steps per chunk
+    constexpr int QR = KC / 4;                 // float4 per row of the chunk
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];   // [2 buffers][hi | lo][128][LDK]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -569,9 +578,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_wide_kernel(X3wArgs 
     int bx, by, bz;
     gemm_block_coords(bx, by, bz);
     const int m0 = by * 128;
-    const int nt0 = (bx * 4 + wave) * WN;          // this wave's first 32-column tile
+    const int nt0 = TALL ? bx * 2 + (wave & 1) : (bx * 4 + wave) * WN;   // this wave's first 32-column tile
+    const int rt0 = TALL ? (wave >> 1) * 2 : 0;                          // ... and first 32-row tile
     const int NT = (g.N + 31) >> 5;
     const int nchunks = (g.K + X3V_KC - 1) / X3V_KC;
+    // Row tile `by` walks the reduction from chunk `skew` on (and wraps): with a row-major A whose row stride is a power
+    // of two (the 4-KiB rows of the 1024-wide feature map) the 128 row pieces of a chunk share their low address bits, and
+    // workgroups that all sweep k from 0 together keep landing on the same HBM channels.
+    const int skew = g.rotate ? (by * 5) % nchunks : 0;
+    auto phys = [&](int l) { const int c = l + skew; return c >= nchunks ? c - nchunks : c; };   // logical -> actual chunk
 
     const int cloud = (PANELS != 0) ? m0 / g.panel_n : 0;
     const int m_cloud0 = cloud * g.panel_n;
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_wide_kernel(X3wArgs 
     //   row-major: register e holds row (e*256 + tid) / 8, k quad (e*256 + tid) % 8 (a row's 128 B are 8 lanes)
     //   panels   : register e holds panel e of the chunk (8 channels), row tid / 2, half tid % 2 (one panel's 128 rows
     //              x 32 B = 4 KiB contiguous per instruction)
-    float4 ra[2][4];
+    float4 ra[2][NF4];
     const float* a_base;        // loop-invariant part of this thread's A addresses
     {
         if constexpr (PANELS & 1) {
@@ -590,31 +605,31 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_wide_kernel(X3wArgs 
             a_base = A + (long long)(row - m_cloud0) * 8 + (tid & 1) * 4;
         } else a_base = A;
     }
-    auto load_a = [&](int kc, float4 (&r)[4]) {
+    auto load_a = [&](int kc, float4 (&r)[NF4]) {
         const int k0 = kc * X3V_KC;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < NF4; ++e) {
             if constexpr (PANELS & 1) {
                 const int kp = (k0 >> 3) + e;          // panel index (K % 8 == 0)
                 if (!KTAIL || kp * 8 < g.K) r[e] = *reinterpret_cast<const float4*>(a_base + (long long)kp * g.panel_ld * 8);
                 else r[e] = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 const int f = e * GEMM_THREADS + tid;
-                int row = m0 + (f >> 3);
+                int row = m0 + f / QR;
                 row = row < g.M ? row : g.M - 1;
-                if constexpr (KTAIL) r[e] = ld4_guard(a_base + (long long)row * g.lda, k0 + (f & 7) * 4, g.K);
-                else r[e] = *reinterpret_cast<const float4*>(a_base + (long long)row * g.lda + k0 + (f & 7) * 4);
+                if constexpr (KTAIL) r[e] = ld4_guard(a_base + (long long)row * g.lda, k0 + (f % QR) * 4, g.K);
+                else r[e] = *reinterpret_cast<const float4*>(a_base + (long long)row * g.lda + k0 + (f % QR) * 4);
             }
         }
     };
-    auto store_a = [&](int buf, const float4 (&r)[4]) {
+    auto store_a = [&](int buf, const float4 (&r)[NF4]) {
         __bf16* hi_img = smem16 + buf * 2 * X3V_IMG;
         __bf16* lo_img = hi_img + X3V_IMG;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < NF4; ++e) {
             int rr, k4;
             if constexpr (PANELS & 1) { rr = tid >> 1; k4 = e * 2 + (tid & 1); }
-            else { const int f = e * GEMM_THREADS + tid; rr = f >> 3; k4 = f & 7; }
+            else { const int f = e * GEMM_THREADS + tid; rr = f / QR; k4 = f % QR; }
             bf16x4 hh, ll;
             split4(r[e].x, r[e].y, r[e].z, r[e].w, hh, ll);
             *reinterpret_cast<bf16x4*>(hi_img + rr * X3V_LDK + k4 * 4) = hh;
@@ -641,59 +656,59 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_wide_kernel(X3wArgs 
         }
     };
 
-    f32x16 acc[4][WN];
+    f32x16 acc[RT][WN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    auto kstep = [&](const __bf16* ah, const __bf16* al, int s) {
-        bf16x8 a_hi[4], a_lo[4];
+    auto kstep = [&](const __bf16* ah, const __bf16* al, int s, int set) {
+        bf16x8 a_hi[RT], a_lo[RT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a_hi[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * X3V_LDK + s * 16);
-            a_lo[i] = *reinterpret_cast<const bf16x8*>(al + i * 32 * X3V_LDK + s * 16);
+        for (int i = 0; i < RT; ++i) {
+            a_hi[i] = *reinterpret_cast<const bf16x8*>(ah + (rt0 + i) * 32 * X3V_LDK + s * 16);
+            a_lo[i] = *reinterpret_cast<const bf16x8*>(al + (rt0 + i) * 32 * X3V_LDK + s * 16);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[s][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[set][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[s][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[s][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[set][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[set][j], acc[i][j], 0, 0, 0);
     };
     // one chunk; `cur` / `nxt`: the register sets holding A(kc + 1) (loaded during the previous chunk) / receiving A(kc + 2)
-    auto chunk = [&](int kc, float4 (&nxt)[4], const float4 (&cur)[4]) {
+    auto chunk = [&](int kc, float4 (&nxt)[NF4], const float4 (&cur)[NF4]) {
         const int buf = kc & 1;
         const __bf16* ah = smem16 + buf * 2 * X3V_IMG + col * X3V_LDK + h * 8;
         const __bf16* al = ah + X3V_IMG;
-        load_b(kc * 2 + 1, 1);
-        load_a(min(kc + 2, nchunks - 1), nxt);   // unconditional (the tail re-reads the last chunk): a branch here makes the
+        load_b(phys(kc) * KSC + 1, 1);
+        load_a(phys(min(kc + 2, nchunks - 1)), nxt);   // unconditional (the tail re-reads the last chunk): a branch here makes the
                                                  // compiler count vmcnt for the path without these loads and over-wait
-        __builtin_amdgcn_sched_barrier(0);
-        kstep(ah, al, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(kc * 2 + 2, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        kstep(ah, al, 1);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KSC; ++s) {
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(ah, al, s, s & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < KSC) load_b((s + 2 < KSC ? phys(kc) : phys(min(kc + 1, nchunks - 1))) * KSC + (s + 2) % KSC, s & 1);   // the set just consumed receives the step after next
+        }
         if (kc + 1 < nchunks) store_a(buf ^ 1, cur);
         __syncthreads();
     };
 
-    load_b(0, 0);
-    load_a(0, ra[0]);
-    if (nchunks > 1) load_a(1, ra[1]);
+    load_b(phys(0) * KSC, 0);
+    load_a(phys(0), ra[0]);
+    if (nchunks > 1) load_a(phys(1), ra[1]);
     store_a(0, ra[0]);
     __syncthreads();
     for (int kc = 0; kc < nchunks; kc += 2) {
@@ -710,10 +725,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_x3w_wide_kernel(X3wArgs 
         if (g.bias) bi = g.bias[n];
         if (g.scale) { sc = g.scale[n]; sh = g.shift[n]; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int m = m0 + (rt0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m >= g.M) continue;
                 float v = acc[i][j][r] + bi;
                 v = v * sc + sh;
@@ -1017,20 +1032,29 @@ extern "C" int lpd_gemm_prep_b(const float* B, int ldb, int b_kmajor, int N, int
     return LPD_OK;
 }
 
-template <int WN, int PANELS>
-static void x3w_wide_launch(const X3wArgs& g, int NT, hipStream_t stream)
+template <int WN, int PANELS, int KC, bool TALL = false>
+static void x3w_wide_launch_kc(const X3wArgs& g, int NT, hipStream_t stream)
 {
-    const size_t lds = (size_t)4 * X3V_IMG * sizeof(__bf16);
-    dim3 grid((NT + 4 * WN - 1) / (4 * WN), (g.M + 127) / 128);
-    if (g.K % X3V_KC) {
-        auto kern = gemm_x3w_wide_kernel<WN, true, PANELS>;
+    const size_t lds = (size_t)4 * 128 * (KC + 8) * sizeof(__bf16);
+    dim3 grid(TALL ? (NT + 1) / 2 : (NT + 4 * WN - 1) / (4 * WN), (g.M + 127) / 128);
+    if (g.K % KC) {
+        auto kern = gemm_x3w_wide_kernel<WN, true, PANELS, KC, TALL>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, stream, g);
     } else {
-        auto kern = gemm_x3w_wide_kernel<WN, false, PANELS>;
+        auto kern = gemm_x3w_wide_kernel<WN, false, PANELS, KC, TALL>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, stream, g);
     }
+}
+
+template <int WN, int PANELS>
+static void x3w_wide_launch(const X3wArgs& g, int NT, hipStream_t stream)
+{
+    if constexpr (WN == 1) {
+        if (NT <= 2) { x3w_wide_launch_kc<1, PANELS, 32, true>(g, NT, stream); return; }   // N <= 64: the NetVLAD assignment
+    }
+    x3w_wide_launch_kc<WN, PANELS, 32>(g, NT, stream);
 }
 
 extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
@@ -1051,7 +1075,12 @@ extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C
     const int KS = (K + 15) / 16, NT = (N + 31) / 32;
     const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
     X3wArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, K, KS, lda, ldc, bias, scale, shift, act, slope, accumulate,
-              a_cloud, c_cloud, panel_n, panel_ld};
+              a_cloud, c_cloud, panel_n, panel_ld, 0};
+    {   // (it matters for a row-major A with a power-of-two row stride; applied to every layout so that the summation
+        //  order -- and with it every bit of the result -- does not depend on the layout of A)
+        static const int rot = getenv("LPD_X3W_ROTATE") ? atoi(getenv("LPD_X3W_ROTATE")) : 1;
+        g.rotate = rot;
+    }
     // impl: 0 = by shape, 2 = 128 x 128 blocks, 3 = 128 x 256 blocks
     if (impl == 0) impl = N >= 256 ? 3 : 2;
     const int panels = (a_panels ? 1 : 0) | (c_panels ? 2 : 0);
