@@ -185,7 +185,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
 
     float4 ra[A_F4], rb[B_F4];
 
+    // k-tiles are walked from `kskew` on (and wrap): workgroups that sweep the reduction in step over operands with a
+    // power-of-two row stride keep meeting on the same HBM channels otherwise (NetVLAD pooling: 4-KiB rows)
+    const int nkt = g.K / GEMM_BK;
+    const int kskew = (by * 5 + bx * 3) % nkt;
     auto load_tiles = [&](int kt) {
+        kt += kskew;
+        kt = kt >= nkt ? kt - nkt : kt;
         const int k0 = kbase + kt * BK;
 #pragma unroll
         for (int e = 0; e < A_F4; ++e) {
@@ -430,7 +436,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x3_kernel(GemmArgs g)
     float* C = g.C + (long long)batch * g.sC + (long long)split * g.sCsplit + ((PANELS & 2) ? (long long)(m0 / g.panel_n) * g.c_cloud : 0);
 
     float4 ra[X3Regs<BM>::NR], rb[X3Regs<BN>::NR];
+    // k-tiles are walked from `kskew` on (and wrap): workgroups that sweep the reduction in step over operands with a
+    // power-of-two row stride keep meeting on the same HBM channels otherwise (NetVLAD pooling: 4-KiB rows)
+    const int nkt = g.K / GEMM_BK;
+    const int kskew = (by * 5 + bx * 3) % nkt;
     auto load_tiles = [&](int kt) {
+        kt += kskew;
+        kt = kt >= nkt ? kt - nkt : kt;
         const int k0 = kbase + kt * BK;
         x3_load<A_KMAJOR, BM, KTAIL, PANELS & 1>(ra, A, g.lda, m0, g.M, k0, g.Ktot, tid, g.panel_ld, m_cloud0);
         x3_load<B_KMAJOR, BN, KTAIL>(rb, B, g.ldb, n0, g.N, k0, g.Ktot, tid);
