@@ -180,8 +180,10 @@ def main():
         step(i)
     torch.cuda.synchronize()
 
-    # per-kernel HIP-event timing of the K-agg launches, on the launch stream, inside the timed region
-    ops.PROFILE = {}
+    # HIP-event timing of the K-agg launches (the roofline kernel), on the launch stream, inside the timed region.  Only
+    # those: bracketing all ~45 launches of a step costs 1.6 ms of host time per step (event creation + two records per
+    # call) and made the host, not the GPU, the bottleneck of the timed region in some runs.
+    ops.PROFILE, ops.PROFILE_ONLY = {}, ("edge_gather_max",)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -193,6 +195,14 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = ops.PROFILE
+    # the per-op table of the JSON line comes from a separate, untimed pass with every launch bracketed
+    ops.PROFILE, ops.PROFILE_ONLY = {}, None
+    for i in range(min(args.steps, 5)):
+        step(i)
+    torch.cuda.synchronize()
+    prof_all = ops.PROFILE
+    prof_all.update({k_: v for k_, v in prof.items()})      # K-agg entries: the timed region's own measurements
+    prof = prof_all
     ops.PROFILE = None
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)

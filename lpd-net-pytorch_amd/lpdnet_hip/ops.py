@@ -16,9 +16,13 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 PROFILE = None
 
 
+PROFILE_ONLY = None   # tuple of label prefixes: only those calls get events (90 event pairs per eval step cost 1.6 ms of host
+                      # time -- more than the GPU needs for the step -- so a timed region brackets only what it reports)
+
+
 def _call(label, fn, *args):
     prof = PROFILE
-    if prof is None:
+    if prof is None or (PROFILE_ONLY is not None and not label.startswith(PROFILE_ONLY)):
         _lib.check(fn(*args), fn.__name__)
         return
     a = torch.cuda.Event(enable_timing=True)
