@@ -19,6 +19,10 @@ for name, rows, C in (("xyz", xs.view(B, N, 3), 3), ("feat64", f.view(B, N, 64),
     rad = (t - cen.unsqueeze(2)).norm(dim=-1).amax(2)                     # [B, nt]
     d = torch.cdist(cen, cen)                                             # [B, nt, nt]
     gap = (d - rad.unsqueeze(1) - rad.unsqueeze(2)).clamp_min(0)          # lower bound of point distances between tiles
+    for nm, pr in (("radius only", rad), ("mean gap to the 16 curve neighbours", torch.stack([gap[:, torch.arange(gap.shape[1]), (torch.arange(gap.shape[1]) + o).clamp(0, gap.shape[1] - 1)] for o in range(-8, 9) if o], 0).mean(0))):
+        a, p_ = actual.flatten(), pr.flatten()
+        order = torch.argsort(p_, descending=True)
+        print(f"{name} predictor '{nm}': corr {torch.corrcoef(torch.stack([a, p_]))[0, 1].item():.3f}  top-half {a[order[: len(a) // 2]].mean().item():.1f} bottom-half {a[order[len(a) // 2:]].mean().item():.1f}")
     for alpha in (0.5, 0.75, 1.0, 1.5):
         pred = (gap <= alpha * rad.unsqueeze(2)).float().sum(2)           # tiles within alpha * own radius
         a, p = actual.flatten(), pred.flatten()
