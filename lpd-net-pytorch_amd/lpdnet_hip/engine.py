@@ -158,6 +158,16 @@ def _knn_rows(rows, B, N, C, k):
 
 # cloud-panel [B, C/8, N, 8] buffers for x1|x2|x3 and the SN1 projections (LPD_PANELS=0: row-major everywhere)
 PANEL_LAYOUT = __import__("os").environ.get("LPD_PANELS", "1") != "0"
+SIDE_STREAM = __import__("os").environ.get("LPD_SIDE_STREAM", "1") != "0"   # xyz kNN on a second HIP stream (eval path)
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 def _kagg_cloud_resident(idx, N, M, act):
@@ -183,6 +193,16 @@ def lpdnet_features_eval(net, x):
     act, slope = (ops.ACT_RELU, 0.0) if net.use_relu else (ops.ACT_LEAKY, LEAKY_SLOPE)
     xyz = x.view(M, 3)
     p = xyz
+    side_job = None
+    if SIDE_STREAM and PANEL_LAYOUT and N % 128 == 0 and k == 20 and N <= 4096:
+        # The static graph in Cartesian space depends on the input alone: its kNN (wave-slot-bound, two waves per SIMD) runs
+        # on a second HIP stream next to the per-point layers and the feature-space kNN and is joined in front of the SN1 K-agg.
+        main, side = torch.cuda.current_stream(), _side_stream(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            idx_x = _knn_rows(xyz, B, N, 3, k)
+            i16_x = ops.pack_idx16(idx_x)
+        side_job = (side, idx_x, i16_x)
     with ops.exact_gemm():      # everything in front of the feature-space kNN is exact fp32
         if net.t3d:
             trans = transform_net_eval(net.t_net3d, xyz, B, N)
@@ -209,9 +229,17 @@ def lpdnet_features_eval(net, x):
         cat = ops.panels_empty(B, N, 512, x.device)
         ops.edge_gather_max16(pq[:, :128], pq[:, 128:], ops.pack_idx16(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
         ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope, out=cat[:, 16:32])
-        idx_x = _knn_rows(x.view(B * N, 3), B, N, 3, k)      # static graph in Cartesian space (raw xyz even when t3d, :226,255)
         pq3 = ops.gemm(cat[:, 16:32], split_edge_weight(net.convSN1, "cat_nc"), b_kmajor=False, a_panels=True, out_panels=True)
-        ops.edge_gather_max16(pq3[:, 0:32], pq3[:, 32:64], ops.pack_idx16(idx_x), N, scale=s3, shift=b3, act=act, slope=slope, out=cat[:, 32:64])
+        if side_job is not None:
+            side, idx_x, i16_x = side_job
+            main = torch.cuda.current_stream()
+            main.wait_stream(side)
+            idx_x.record_stream(main)
+            i16_x.record_stream(main)
+        else:
+            idx_x = _knn_rows(xyz, B, N, 3, k)      # static graph in Cartesian space (raw xyz even when t3d, :226,255)
+            i16_x = ops.pack_idx16(idx_x)
+        ops.edge_gather_max16(pq3[:, 0:32], pq3[:, 32:64], i16_x, N, scale=s3, shift=b3, act=act, slope=slope, out=cat[:, 32:64])
         if DEBUG_AUX is not None:
             DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=ops.panels_to_rows(cat))
         feat = ops.gemm(cat, _w2d(net.conv3_lpd), b_kmajor=False, a_panels=True, scale=sc, shift=bc, act=act, slope=slope)
@@ -221,7 +249,12 @@ def lpdnet_features_eval(net, x):
     ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope,
                  out=cat[:, 128:256])
     # static graph in Cartesian space (raw xyz even when t3d, lpdnet_model.py:226,255)
-    idx_x = _knn_rows(x.view(B * N, 3), B, N, 3, k)
+    if side_job is not None:
+        side, idx_x, _ = side_job
+        torch.cuda.current_stream().wait_stream(side)
+        idx_x.record_stream(torch.cuda.current_stream())
+    else:
+        idx_x = _knn_rows(x.view(B * N, 3), B, N, 3, k)
     pq = ops.linear(cat[:, 128:256], split_edge_weight(net.convSN1, "cat_nc"))          # [M,512]
     kagg(pq[:, :256], pq[:, 256:], idx_x, N, scale=s3, shift=b3, act=act, slope=slope, out=cat[:, 256:512])
     if DEBUG_AUX is not None:
