@@ -214,20 +214,43 @@ def lpdnet_features_eval(net, x):
         if net.tfea:
             tf = transform_net_eval(net.t_net_fea, f, B, N)
             f = ops.apply_transform(f, tf, N)
-    # dynamic graph in feature space
-    idx_f = _knn_rows(f, B, N, 64, k)
     s1, b1 = bn_affine(net.convDG1[1])
     s2, b2 = bn_affine(net.convDG2[1])
     s3, b3 = bn_affine(net.convSN1[1])
     sc, bc = bn_affine(net.bn3_lpd)
-    pq = ops.linear(f, split_edge_weight(net.convDG1, "cat_nc"))                        # [M,256] = [P | Q]
+    wdg1 = split_edge_weight(net.convDG1, "cat_nc")
+    pq = None
+    if side_job is not None:
+        # the DG1 projection needs F0 only: it follows the xyz kNN on the second stream, under the feature-space kNN
+        main, side = torch.cuda.current_stream(), side_job[0]
+        side.wait_stream(main)
+        f.record_stream(side)
+        with torch.cuda.stream(side):
+            pq = ops.linear(f, wdg1)                                                      # [M,256] = [P | Q]
+    # dynamic graph in feature space
+    idx_f = _knn_rows(f, B, N, 64, k)
+    if pq is None:
+        pq = ops.linear(f, wdg1)                                                          # [M,256] = [P | Q]
     if PANEL_LAYOUT and N % 128 == 0 and _kagg_cloud_resident(idx_f, N, M, act):
         # [x1 | x2 | x3] and the SN1 projections live in CLOUD-PANEL buffers [B, C/8, N, 8]: the cloud-resident K-agg kernel
         # streams one 8-channel slice of a whole cloud per workgroup, which in this layout is ONE contiguous 32*N-byte run
         # (row-major: N pieces of 32 bytes, ~4x slower through L1/L2), while a GEMM block's 128 rows x K still sit inside one
         # cloud's contiguous block; the GEMMs read / write the panels directly.
         cat = ops.panels_empty(B, N, 512, x.device)
-        ops.edge_gather_max16(pq[:, :128], pq[:, 128:], ops.pack_idx16(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
+        i16_f = ops.pack_idx16(idx_f)
+        if side_job is not None:
+            # the DG1-stage K-agg (HBM-bound) runs on the second stream next to the fused edge MLP (MFMA / VALU-bound); both
+            # read pq and the feature-space graph and write different panels of `cat`
+            main, side = torch.cuda.current_stream(), side_job[0]
+            main.wait_stream(side)                       # pq (and the xyz graph) are ready
+            pq.record_stream(main)
+            side.wait_stream(main)                       # ... and so are idx_f / i16_f / cat for the second stream
+            for t in (i16_f, cat):
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                ops.edge_gather_max16(pq[:, :128], pq[:, 128:], i16_f, N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
+        else:
+            ops.edge_gather_max16(pq[:, :128], pq[:, 128:], i16_f, N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
         ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope, out=cat[:, 16:32])
         pq3 = ops.gemm(cat[:, 16:32], split_edge_weight(net.convSN1, "cat_nc"), b_kmajor=False, a_panels=True, out_panels=True)
         if side_job is not None:
@@ -244,6 +267,9 @@ def lpdnet_features_eval(net, x):
             DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=ops.panels_to_rows(cat))
         feat = ops.gemm(cat, _w2d(net.conv3_lpd), b_kmajor=False, a_panels=True, scale=sc, shift=bc, act=act, slope=slope)
         return feat, B, N
+    if side_job is not None:
+        torch.cuda.current_stream().wait_stream(side_job[0])
+        pq.record_stream(torch.cuda.current_stream())
     cat = torch.empty((M, 512), dtype=torch.float32, device=x.device)                   # [x1 | x2 | x3]
     kagg(pq[:, :128], pq[:, 128:], idx_f, N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:128])
     ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope,
