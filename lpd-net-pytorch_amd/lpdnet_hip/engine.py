@@ -166,7 +166,9 @@ def _side_stream(device):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     st = _SIDE.get(key)
     if st is None:
-        st = _SIDE[key] = torch.cuda.Stream(device=device)
+        # high priority: its kernels are the short ones that fill in next to the long kernels of the main stream (measured:
+        # 2.39 -> 2.33 ms per step; at default priority the overlap even turned into a loss once RCCL's own streams existed)
+        st = _SIDE[key] = torch.cuda.Stream(device=device, priority=int(__import__('os').environ.get('LPD_SIDE_PRIO', '-1')))
     return st
 
 
