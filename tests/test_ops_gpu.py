@@ -309,6 +309,32 @@ def test_edge_gather_max_cloud_resident_is_bit_identical(cuda, C, N, B, act):
         ops.edge_gather_max16(PQ[:, :C], None, idx16, N, act=ops.ACT_SIGMOID)
 
 
+@pytest.mark.parametrize("N,layout", [(4096, "panels"), (4000, "rows"), (3600, "panels")])
+def test_kagg_persistent_workgroups(cuda, N, layout):
+    """Enough (cloud, slice) items for the persistent form (>= 3 per CU: 24 clouds x 32 slices) on 8-pass clouds, ragged last
+    pass included: bit-identical to the direct gather kernel; P/Q/out as cloud panels or row-major."""
+    ops = _ops()
+    B, C, k = 24, 256, 20
+    g = torch.Generator().manual_seed(N)
+    idx = torch.randint(0, N, (B * N, k), generator=g, dtype=torch.int32).to(cuda)
+    P = torch.randn(B * N, C, generator=g).to(cuda)
+    Q = torch.randn(B * N, C, generator=g).to(cuda)
+    scale, shift = (torch.rand(C, generator=g) - 0.3).to(cuda), torch.randn(C, generator=g).to(cuda)
+    want = ops.edge_gather_max(P, Q, idx, N, scale=scale, shift=shift, act=ops.ACT_LEAKY, slope=0.01)
+    i16 = ops.pack_idx16(idx)
+    if layout == "panels":
+        pq = ops.panels_empty(B, N, 2 * C, cuda)
+        pq[:, :C // 8] = ops.rows_to_panels(P, B)
+        pq[:, C // 8:] = ops.rows_to_panels(Q, B)
+        out = ops.panels_empty(B, N, C, cuda)
+        ops.edge_gather_max16(pq[:, :C // 8], pq[:, C // 8:], i16, N, scale=scale, shift=shift, act=ops.ACT_LEAKY, slope=0.01, out=out)
+        assert torch.equal(ops.panels_to_rows(out), want)
+    else:
+        out = torch.empty(B * N, C, device=cuda)
+        ops.edge_gather_max16(P, Q, i16, N, scale=scale, shift=shift, act=ops.ACT_LEAKY, slope=0.01, out=out)
+        assert torch.equal(out, want)
+
+
 @pytest.mark.parametrize("CM,CO,N,k,B,useQ", [(128, 128, 256, 20, 2, True), (64, 64, 200, 20, 2, True), (64, 64, 128, 20, 1, False),
                                                (128, 128, 100, 7, 1, True)])
 @pytest.mark.parametrize("exact", [True, False], ids=["f32mfma", "bf16x3"])
@@ -446,7 +472,8 @@ def test_gather_sum_rows_is_the_transpose_of_the_neighbour_gather(cuda, C, N, B,
 
 
 @pytest.mark.parametrize("M,N,K,bk", [(4096, 512, 1024, True), (2048, 256, 128, True), (1500, 64, 1024, True), (3000, 200, 136, True),
-                                       (1024, 72, 148, True), (4096, 1024, 512, False), (2100, 300, 264, False), (1111, 136, 300, False)])
+                                       (1024, 72, 148, True), (4096, 1024, 512, False), (2100, 300, 264, False), (1111, 136, 300, False),
+                                       (2050, 64, 288, True), (1300, 64, 520, False)])
 def test_gemm_weight_fragment_path(cuda, M, N, K, bk):
     """Row-major activations times a weight matrix take lpd_gemm_x3w (B fragments prepared once, never staged in LDS):
     same contract and error bound as the generic split-bf16 kernel; epilogue, output slice, accumulation, ragged N / K."""
