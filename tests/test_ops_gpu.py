@@ -77,6 +77,18 @@ def test_knn_exact_ties_lower_index_first(cuda, C, N, impl):
         assert (got_pm == oidx).all()
 
 
+def test_knn_many_small_clouds(cuda):
+    """More work items per XCD than one sorting chunk of the longest-first launch order holds (1100 clouds x 8 tiles =
+    8800 items, 1100 per XCD > 1024): best-first == ascending scan, row for row."""
+    ops = _ops()
+    B, N, k = 1100, 256, 20
+    g = torch.Generator().manual_seed(3)
+    rows = (torch.rand(B * N, 3, generator=g) * 2 - 1).to(cuda)
+    a = ops.knn_pm(rows, B, N, k, impl=0)
+    b = ops.knn_pm(rows, B, N, k, impl=4)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("impl", [0, 4])
 @pytest.mark.parametrize("case", ["offset", "huge", "tiny", "identical", "line"])
 def test_knn_ill_conditioned_clouds(cuda, case, impl):
