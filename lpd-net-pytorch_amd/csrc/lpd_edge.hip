@@ -575,6 +575,27 @@ __device__ __forceinline__ void em_split4(float x0, float x1, float x2, float x3
     lo[2] = (__bf16)(x2 - (float)hi[2]); lo[3] = (__bf16)(x3 - (float)hi[3]);
 }
 
+// The same split on packed pairs, spelled out: one v_cvt_pk_bf16_f32 per pair for hi, shift / mask back to fp32, one packed
+// subtract, one v_cvt_pk for lo -- 2.5 instructions per element.  Written element-wise (above) around computed values the
+// compiler converted every element on its own and re-packed with perm / alignbit / mov: 11 per element, which made the
+// tile builder of the fused edge MLP issue twice the cycles of its MFMAs (750 VALU instructions per 48 MFMAs).
+typedef __bf16 em_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float em_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void em_split4_packed(float x0, float x1, float x2, float x3, uint2& hi, uint2& lo)
+{
+    const em_bf16x2 h01 = __builtin_convertvector((em_f32x2){x0, x1}, em_bf16x2), h23 = __builtin_convertvector((em_f32x2){x2, x3}, em_bf16x2);
+    const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
+    const float r0 = x0 - __uint_as_float(u01 << 16), r1 = x1 - __uint_as_float(u01 & 0xffff0000u);
+    const float r2 = x2 - __uint_as_float(u23 << 16), r3 = x3 - __uint_as_float(u23 & 0xffff0000u);
+    const em_bf16x2 l01 = __builtin_convertvector((em_f32x2){r0, r1}, em_bf16x2), l23 = __builtin_convertvector((em_f32x2){r2, r3}, em_bf16x2);
+    hi = make_uint2(u01, u23);
+    lo = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+}
+// max(a, b) as v_med3_f32(a, b, +inf): one instruction, without the canonicalising self-max the compiler puts in front of
+// fmaxf on values it cannot prove quiet (MFMA results, loaded data).  (An inline-asm v_max_f32 is NOT an option on an MFMA
+// result: the hazard recogniser does not see inside the asm and the read came too early -- wrong maxima.)
+__device__ __forceinline__ float em_vmax(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
+
 template <int CM, int CO>
 struct EdgeMlpX3Cfg {
     static constexpr int LDK = CM + 8;                      // bf16 per LDS row
@@ -662,11 +683,13 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
 #pragma unroll
         for (int e = 0; e < PASSES; ++e) {
             const int p = prow + Cfg::ROWS_PER_PASS * e;
-            em_bf16x4 hh, ll;   // s (P + Q) + b  ==  s P + (s Q + b)
-            em_split4(lpd_act_pl(s1.x * pg[e].x + qc[e].x, ns), lpd_act_pl(s1.y * pg[e].y + qc[e].y, ns),
-                      lpd_act_pl(s1.z * pg[e].z + qc[e].z, ns), lpd_act_pl(s1.w * pg[e].w + qc[e].w, ns), hh, ll);
-            *reinterpret_cast<em_bf16x4*>(hi_img + p * LDK + c4 * 4) = hh;
-            *reinterpret_cast<em_bf16x4*>(lo_img + p * LDK + c4 * 4) = ll;
+            // s (P + Q) + b  ==  s P + (s Q + b) as one fma; LeakyReLU / ReLU / identity as max(v, ns v) (0 <= ns <= 1)
+            const float y0 = fmaf(s1.x, pg[e].x, qc[e].x), y1 = fmaf(s1.y, pg[e].y, qc[e].y);
+            const float y2 = fmaf(s1.z, pg[e].z, qc[e].z), y3 = fmaf(s1.w, pg[e].w, qc[e].w);
+            uint2 hh, ll;
+            em_split4_packed(em_vmax(y0, ns * y0), em_vmax(y1, ns * y1), em_vmax(y2, ns * y2), em_vmax(y3, ns * y3), hh, ll);
+            *reinterpret_cast<uint2*>(hi_img + p * LDK + c4 * 4) = hh;
+            *reinterpret_cast<uint2*>(lo_img + p * LDK + c4 * 4) = ll;
         }
     };
 
@@ -705,7 +728,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) zmax[i][r] = fmaxf(zmax[i][r], acc[i][r]);
+            for (int r = 0; r < 16; ++r) zmax[i][r] = em_vmax(zmax[i][r], acc[i][r]);
         if (t + 1 < g.k) build(buf ^ 1);
         __syncthreads();
     }
@@ -769,6 +792,7 @@ static int edge_mlp_entry(bool x3, const float* P, int ldp, const float* Q, int 
     LPD_CHECK_ARG(M > 0 && N > 0 && k > 0 && M % N == 0, "lpd_edge_mlp: bad dims M=%d N=%d k=%d", M, N, k);
     LPD_CHECK_ARG(k <= 128, "lpd_edge_mlp: k=%d > 128 unsupported", k);
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_mlp: act=%d unsupported (none/ReLU/LeakyReLU)", act);
+    LPD_CHECK_ARG(act != 2 || (slope >= 0.0f && slope <= 1.0f), "lpd_edge_mlp: LeakyReLU slope %g outside [0, 1]", (double)slope);
     LPD_CHECK_ARG(ldp % 4 == 0 && (!Q || ldq % 4 == 0), "lpd_edge_mlp: leading dims must be multiples of 4");
     LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)Q | (uintptr_t)s1 | (uintptr_t)b1 | (uintptr_t)W2) & 15) == 0,
                   "lpd_edge_mlp: pointers must be 16-byte aligned");
