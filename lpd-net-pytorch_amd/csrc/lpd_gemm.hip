@@ -315,11 +315,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// hi = bf16(x) (RNE), lo = bf16(x - hi), on packed pairs: v_cvt_pk_bf16_f32 for two elements at a time, the hi halves
+// widened back to fp32 by a shift / mask (written element by element the compiler converts some elements singly and
+// re-packs them with perm / alignbit / mov; see lpd_edge.hip).  Same values either way.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, bf16x4& hi, bf16x4& lo)
 {
-    hi[0] = (__bf16)x0; hi[1] = (__bf16)x1; hi[2] = (__bf16)x2; hi[3] = (__bf16)x3;
-    lo[0] = (__bf16)(x0 - (float)hi[0]); lo[1] = (__bf16)(x1 - (float)hi[1]);
-    lo[2] = (__bf16)(x2 - (float)hi[2]); lo[3] = (__bf16)(x3 - (float)hi[3]);
+    const bf16x2 h01 = __builtin_convertvector((f32x2_){x0, x1}, bf16x2), h23 = __builtin_convertvector((f32x2_){x2, x3}, bf16x2);
+    const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
+    const float r0 = x0 - __uint_as_float(u01 << 16), r1 = x1 - __uint_as_float(u01 & 0xffff0000u);
+    const float r2 = x2 - __uint_as_float(u23 << 16), r3 = x3 - __uint_as_float(u23 & 0xffff0000u);
+    const bf16x2 l01 = __builtin_convertvector((f32x2_){r0, r1}, bf16x2), l23 = __builtin_convertvector((f32x2_){r2, r3}, bf16x2);
+    const uint2 hp = make_uint2(u01, u23), lp = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+    hi = __builtin_bit_cast(bf16x4, hp);
+    lo = __builtin_bit_cast(bf16x4, lp);
 }
 
 // Register staging of one operand tile (ROWS x 32): NR = max(ROWS / 32, 4 for k-major with ROWS = 64) float4 per thread.
