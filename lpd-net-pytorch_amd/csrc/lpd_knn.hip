@@ -848,6 +848,16 @@ constexpr bool KNN7_DEFAULT = true;    // impl 0 = best-first where it is built 
 constexpr int KNN7_QCAP = 24;      // queue slots per lane
 constexpr int KNN7_MAXT = 128;     // candidate tiles per cloud (N <= 4096)
 constexpr int KNN7_WAVE_LDS = KNN7_MAXT * 32 * 2 + KNN7_QCAP * 64 * 8;   // bf16 bound table + queue = 20 KiB per wave
+// Three coordinates (CP = 2): the bound of a tile is recomputed from its centroid where it is tested (a dozen instructions)
+// instead of being tabulated, and the queue holds 20 slots: 10 KiB per wave, so that LDS admits the four waves per SIMD
+// the kernel's 120 VGPRs allow (the search is wait-bound: at 20 KiB it ran two).
+constexpr int KNN7_QCAP_XYZ = 20;
+constexpr int KNN7_WAVE_LDS_XYZ = KNN7_QCAP_XYZ * 64 * 8;
+template <int CP> struct Knn7Lds {
+    static constexpr int QCAP = CP == 2 ? KNN7_QCAP_XYZ : KNN7_QCAP;
+    static constexpr int WAVE = CP == 2 ? KNN7_WAVE_LDS_XYZ : KNN7_WAVE_LDS;
+    static constexpr int QOFF = CP == 2 ? 0 : KNN7_MAXT * 32 * 2;      // byte offset of the queue inside the wave's region
+};
 
 // tile statistics: centroid (packed operand layout), |c|^2, radius (inflated), max |x|^2.  One wave per tile.
 template <int CP>
@@ -1007,7 +1017,7 @@ __device__ __forceinline__ void knn7_insert(float (&v)[KMAX], int (&id)[KMAX], f
 // counts of neighbouring waves differ (C = 64: mean 51, p90 69, max 89 tiles): single-wave workgroups at C = 64
 // (638 -> 607 us), four waves at C = 3 (shorter waves; the larger groups launch faster: 278 vs 287 us).
 template <int CP, int KMAX, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 2) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
+__global__ __launch_bounds__(WAVES * 64, CP == 2 ? 4 : 2) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
                                                              const float* __restrict__ cenp, const float* __restrict__ cnorm,
                                                              const float* __restrict__ rad, const float* __restrict__ txmax,
                                                              int32_t* __restrict__ idx, const int32_t* __restrict__ order,
@@ -1035,8 +1045,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn7_kernel(const float* __rest
     const float* radb = rad + (size_t)b * nt;
     const bool vec_ok = (N & 3) == 0;
     const bool vec_ok_t = (nt & 3) == 0;
-    uint16_t* ubt = reinterpret_cast<uint16_t*>(smem7 + (size_t)wave * KNN7_WAVE_LDS);                    // [MAXT][32]
-    float2* myq = reinterpret_cast<float2*>(smem7 + (size_t)wave * KNN7_WAVE_LDS + KNN7_MAXT * 32 * 2) + lane;   // slot s at myq[s*64]
+    using L = Knn7Lds<CP>;
+    uint16_t* ubt = reinterpret_cast<uint16_t*>(smem7 + (size_t)wave * L::WAVE);                          // [MAXT][32] (CP > 2)
+    float2* myq = reinterpret_cast<float2*>(smem7 + (size_t)wave * L::WAVE + L::QOFF) + lane;             // slot s at myq[s*64]
 
     float qreg[CP];
     knn3_ld_ops<CP>(xpb, N, q, h, qreg);
@@ -1049,13 +1060,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn7_kernel(const float* __rest
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) smax = fmaxf(smax, __shfl_xor(smax, m, 64));
     const float E0 = 8.0f * (float)(C + 8) * 1.1920929e-7f * smax + 1e-30f;
+    float4 qc3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (CP == 2) qc3 = *reinterpret_cast<const float4*>(xpb + (size_t)min(q, N - 1) * 4);
 
     float a[CP];
     float4 x4[4];
     float pd[16];
 
     // ---- bound table: pd of every query against every tile centroid (the centroids are a 'cloud' of nt points) ----
-    if (wave_ok) {
+    if (wave_ok && CP != 2) {
         const int nct = (nt + 31) / 32;
         for (int ct = 0; ct < nct; ++ct) {
             float4 r4[4];
@@ -1097,7 +1110,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn7_kernel(const float* __rest
             const int T = (spos & 1) ? W + ((spos + 1) >> 1) : W - (spos >> 1);
             ++spos;
             if (T < 0 || T >= nt) continue;
-            const float ub = __uint_as_float((uint32_t)ubt[T * 32 + col] << 16);
+            float ub;
+            if constexpr (CP == 2) {   // centroid in operand order (c0, c2 | c1, 0), like the query's own row
+                const float4 cen = *reinterpret_cast<const float4*>(cenb + (size_t)T * 4);
+                const float e0 = qc3.x - cen.x, e1 = qc3.y - cen.y, e2 = qc3.z - cen.z;
+                const float d2 = fmaf(e2, e2, fmaf(e1, e1, e0 * e0));
+                const float dq = sqrtf(fmaxf(d2 - E0, 0.0f)) * 0.99999f;          // lower bound of |x_i - c_T|
+                const float lb = fmaxf(dq - radb[T], 0.0f);
+                ub = -(lb * lb) * 0.99999f + E0;                                  // upper bound of every computed pd in tile T
+            } else ub = __uint_as_float((uint32_t)ubt[T * 32 + col] << 16);
             if (__any(ub >= thrv)) return T;
         }
         return -1;
@@ -1162,14 +1183,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn7_kernel(const float* __rest
                     }
                 }
             }
-            if (__any(cnt > KNN7_QCAP - 16)) drain();
+            if (__any(cnt > L::QCAP - 16)) drain();
         }
         cur = nxt;
         nxt = cur >= 0 ? find_next() : -1;
     }
     drain();
     // ---- merge the two half-lists (same as the ascending kernel); region: this wave's table + queue (20 KiB >= 64*KMAX*8) ----
-    float* mv = reinterpret_cast<float*>(smem7 + (size_t)wave * KNN7_WAVE_LDS);
+    float* mv = reinterpret_cast<float*>(smem7 + (size_t)wave * L::WAVE);
     int* mi = reinterpret_cast<int*>(mv + 64 * KMAX);
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) {
@@ -1245,7 +1266,7 @@ inline size_t knn7_extra_floats(int B, int N, int CP)
 template <int CP, int KMAX>
 int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg = 0)
 {
-    static_assert(KNN7_WAVE_LDS >= 64 * KMAX * 8, "merge region must fit the wave's LDS region");
+    static_assert(Knn7Lds<CP>::WAVE >= 64 * KMAX * 8, "merge region must fit the wave's LDS region");
     const int nt = (N + 31) / 32;
     float* xp = const_cast<float*>(xx) + (size_t)B * N;
     float* cenp = xp + (size_t)B * N * 2 * CP;
@@ -1267,7 +1288,7 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
         LPD_CHECK_LAUNCH("lpd_knn(launch order)");
     }
     {
-        size_t lds = (size_t)WAVES * KNN7_WAVE_LDS;
+        size_t lds = (size_t)WAVES * Knn7Lds<CP>::WAVE;
         auto kern = knn7_kernel<CP, KMAX, WAVES>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(WAVES * 64), lds, stream, (const float*)xp, xx, (const float*)cenp,
