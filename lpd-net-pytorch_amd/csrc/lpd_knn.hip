@@ -853,10 +853,15 @@ constexpr int KNN7_WAVE_LDS = KNN7_MAXT * 32 * 2 + KNN7_QCAP * 64 * 8;   // bf16
 // the kernel's 120 VGPRs allow (the search is wait-bound: at 20 KiB it ran two).
 constexpr int KNN7_QCAP_XYZ = 20;
 constexpr int KNN7_WAVE_LDS_XYZ = KNN7_QCAP_XYZ * 64 * 8;
+// The same for 64 channels (a 64-term distance per tested tile, half per half-lane) measured WORSE than the table:
+// 627 us against 566 at two waves per SIMD, 703 us at three (168 VGPRs, spills) -- off.
+constexpr bool KNN7_ONFLY64 = false;
 template <int CP> struct Knn7Lds {
+    static constexpr bool ONFLY = CP == 2 || (CP == 32 && KNN7_ONFLY64);
     static constexpr int QCAP = CP == 2 ? KNN7_QCAP_XYZ : KNN7_QCAP;
-    static constexpr int WAVE = CP == 2 ? KNN7_WAVE_LDS_XYZ : KNN7_WAVE_LDS;
-    static constexpr int QOFF = CP == 2 ? 0 : KNN7_MAXT * 32 * 2;      // byte offset of the queue inside the wave's region
+    static constexpr int WAVE = CP == 2 ? KNN7_WAVE_LDS_XYZ : (ONFLY ? KNN7_QCAP * 64 * 8 : KNN7_WAVE_LDS);
+    static constexpr int QOFF = ONFLY ? 0 : KNN7_MAXT * 32 * 2;      // byte offset of the queue inside the wave's region
+    static constexpr int WAVES_PER_SIMD = CP == 2 ? 4 : 2;
 };
 
 // tile statistics: centroid (packed operand layout), |c|^2, radius (inflated), max |x|^2.  One wave per tile.
@@ -1017,7 +1022,7 @@ __device__ __forceinline__ void knn7_insert(float (&v)[KMAX], int (&id)[KMAX], f
 // counts of neighbouring waves differ (C = 64: mean 51, p90 69, max 89 tiles): single-wave workgroups at C = 64
 // (638 -> 607 us), four waves at C = 3 (shorter waves; the larger groups launch faster: 278 vs 287 us).
 template <int CP, int KMAX, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, CP == 2 ? 4 : 2) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
+__global__ __launch_bounds__(WAVES * 64, Knn7Lds<CP>::WAVES_PER_SIMD) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
                                                              const float* __restrict__ cenp, const float* __restrict__ cnorm,
                                                              const float* __restrict__ rad, const float* __restrict__ txmax,
                                                              int32_t* __restrict__ idx, const int32_t* __restrict__ order,
@@ -1068,7 +1073,7 @@ __global__ __launch_bounds__(WAVES * 64, CP == 2 ? 4 : 2) void knn7_kernel(const
     float pd[16];
 
     // ---- bound table: pd of every query against every tile centroid (the centroids are a 'cloud' of nt points) ----
-    if (wave_ok && CP != 2) {
+    if (wave_ok && !Knn7Lds<CP>::ONFLY) {
         const int nct = (nt + 31) / 32;
         for (int ct = 0; ct < nct; ++ct) {
             float4 r4[4];
@@ -1118,6 +1123,19 @@ __global__ __launch_bounds__(WAVES * 64, CP == 2 ? 4 : 2) void knn7_kernel(const
                 const float dq = sqrtf(fmaxf(d2 - E0, 0.0f)) * 0.99999f;          // lower bound of |x_i - c_T|
                 const float lb = fmaxf(dq - radb[T], 0.0f);
                 ub = -(lb * lb) * 0.99999f + E0;                                  // upper bound of every computed pd in tile T
+            } else if constexpr (Knn7Lds<CP>::ONFLY) {   // this half-lane's CP channels, the other half by shuffle
+                const float* ct = cenb + (size_t)T * (2 * CP) + h * CP;
+                float part = 0.0f;
+#pragma unroll
+                for (int g4 = 0; g4 < CP / 4; ++g4) {
+                    const float4 cv = *reinterpret_cast<const float4*>(ct + 4 * g4);
+                    const float e0 = qreg[4 * g4] - cv.x, e1 = qreg[4 * g4 + 1] - cv.y, e2 = qreg[4 * g4 + 2] - cv.z, e3 = qreg[4 * g4 + 3] - cv.w;
+                    part = fmaf(e3, e3, fmaf(e2, e2, fmaf(e1, e1, fmaf(e0, e0, part))));
+                }
+                const float d2 = part + __shfl_xor(part, 32, 64);
+                const float dq = sqrtf(fmaxf(d2 - E0, 0.0f)) * 0.99999f;
+                const float lb = fmaxf(dq - radb[T], 0.0f);
+                ub = -(lb * lb) * 0.99999f + E0;
             } else ub = __uint_as_float((uint32_t)ubt[T * 32 + col] << 16);
             if (__any(ub >= thrv)) return T;
         }
