@@ -239,20 +239,19 @@ def lpdnet_features_eval(net, x):
         # (row-major: N pieces of 32 bytes, ~4x slower through L1/L2), while a GEMM block's 128 rows x K still sit inside one
         # cloud's contiguous block; the GEMMs read / write the panels directly.
         cat = ops.panels_empty(B, N, 512, x.device)
-        i16_f = ops.pack_idx16(idx_f)
         if side_job is not None:
             # the DG1-stage K-agg (HBM-bound) runs on the second stream next to the fused edge MLP (MFMA / VALU-bound); both
             # read pq and the feature-space graph and write different panels of `cat`
             main, side = torch.cuda.current_stream(), side_job[0]
             main.wait_stream(side)                       # pq (and the xyz graph) are ready
             pq.record_stream(main)
-            side.wait_stream(main)                       # ... and so are idx_f / i16_f / cat for the second stream
-            for t in (i16_f, cat):
+            side.wait_stream(main)                       # ... and so are idx_f / cat for the second stream
+            for t in (idx_f, cat):
                 t.record_stream(side)
             with torch.cuda.stream(side):
-                ops.edge_gather_max16(pq[:, :128], pq[:, 128:], i16_f, N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
+                ops.edge_gather_max16(pq[:, :128], pq[:, 128:], ops.pack_idx16(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
         else:
-            ops.edge_gather_max16(pq[:, :128], pq[:, 128:], i16_f, N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
+            ops.edge_gather_max16(pq[:, :128], pq[:, 128:], ops.pack_idx16(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
         ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope, out=cat[:, 16:32])
         pq3 = ops.gemm(cat[:, 16:32], split_edge_weight(net.convSN1, "cat_nc"), b_kmajor=False, a_panels=True, out_panels=True)
         if side_job is not None:
