@@ -11,6 +11,11 @@ already resident in HBM; random-init weights of the architecture.  One "step" = 
 32-cloud batch -> 32 global descriptors.  Multi-GPU = one process per GPU, each rank embeds its own
 shard of clouds (the path shards by cloud, no data-path collective): weak scaling.
 
+`--gpus N` with N > 1 and no RANK in the environment: this process is a LAUNCHER -- it touches no GPU, starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` as a child process (one rank per
+GPU over RCCL), passes rank 0's JSON line through and exits with the children's status.  Launched by torch.distributed.run
+directly (RANK set) it is a worker.
+
 Prints ONE JSON line on rank 0.  `roofline` is for the kNN-aggregation kernel BASELINE.json names
 (edge_gather_max on the SN1 stage): algorithmic bytes = 3152 B/point / average launch
 time measured with HIP events on the launch stream inside the timed region.  `cpu_baseline` is the
@@ -44,11 +49,42 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary quadruplet train-step measurement")
     ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--no-train-bf16", action="store_true", help="skip the bf16-storage train-step measurement (configs[2] as stated)")
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """--gpus N > 1 without RANK: start the N ranks as a CHILD process tree (never exec / re-use a process that has touched
+    the GPU; this parent makes no HIP call -- torch.cuda.device_count() does not initialise the runtime on this image)."""
+    import socket
+    import subprocess
+    n_vis = torch.cuda.device_count()
+    if n_vis < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible on this node")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def host_cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(model, points, seconds_target=20.0):
-    """Oracle (CPU port of the reference path) on a bounded sample of the same workload."""
+    """Oracle (CPU port of the reference path) on a bounded sample of the same workload: median of 3 timed runs after a
+    warm-up, at the fastest of the tried thread counts."""
     from oracle import lpd_oracle as orc  # checker-only import, cpu_baseline leg
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(4321)
@@ -67,26 +103,45 @@ def cpu_baseline(model, points, seconds_target=20.0):
             os.environ["OMP_NUM_THREADS"] = str(threads)
             ref = orc.pointnetvlad_forward(sd, x, featnet="lpdnet", train=False)   # warm-up
             times = []
-            for _ in range(2):
+            for _ in range(3):
                 t0 = time.time()
                 orc.pointnetvlad_forward(sd, x, featnet="lpdnet", train=False)
                 times.append(time.time() - t0)
-            t = min(times)
+            t = sorted(times)[1]
             if best is None or t < best[0]:
                 best = (t, threads)
             if time.time() - budget_t0 > seconds_target:
                 break
     t, threads = best
     return {"value": round(Bs / t, 3), "unit": "descriptors/s", "cores": threads, "kind": "port",
-            "sample": f"eval forward of {Bs} clouds x {points} pts, torch-CPU oracle (port of the reference path), best of 2 "
+            "host_cpu": host_cpu_model(), "host_cores": avail,
+            "sample": f"eval forward of {Bs} clouds x {points} pts, torch-CPU oracle (port of the reference path), median of 3 "
                       f"after warm-up at the fastest of the tried thread counts ({threads} of {avail} host cores)"}, x, ref
 
 
-def train_bench(dev, dist, world, rank, points, steps, warmup=2):
+def _time_steps(step, first, n, dist, dev):
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    out = [step(first + i) for i in range(n)]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el, out
+
+
+def train_bench(dev, dist, world, rank, points, steps, warmup=2, storage="f32"):
     """Secondary metric of BASELINE.json: quadruplet train-steps/s (configs[2]: bq=2, P=2, Ng=18 -> 44 clouds/rank,
-    lazy quadruplet loss, Adam), data-parallel across ranks with the RCCL gradient all-reduce."""
+    lazy quadruplet loss, Adam), data-parallel across ranks with the RCCL gradient all-reduce (configs[3])."""
     from util.PointNetVlad import PointNetVlad
     import loss.pointnetvlad_loss as L
+    from lpdnet_hip import autograd
     bq, P, Ng = 2, 2, 18
     B = bq * (1 + P + Ng + 1)
     torch.manual_seed(1234)
@@ -99,47 +154,84 @@ def train_bench(dev, dist, world, rank, points, steps, warmup=2):
     gen = torch.Generator().manual_seed(777 + rank)
     # a fresh tuple batch every step (2 MB each, resident in HBM): a fixed batch is memorised within a few Adam
     # steps and the hinge goes inactive (loss exactly 0), which would make the gradients trivial
-    clouds = [(torch.rand((B, 1, points, 3), generator=gen) * 2 - 1).to(dev) for _ in range(steps + warmup)]
-    losses = []
+    nbatch = steps + warmup
+    clouds = [(torch.rand((B, 1, points, 3), generator=gen) * 2 - 1).to(dev) for _ in range(nbatch)]
 
-    def step(i):
-        opt.zero_grad(set_to_none=True)
-        out = net(clouds[i]).view(bq, -1, 256)
-        q, p, n, o = torch.split(out, [1, P, Ng, 1], dim=1)
-        loss = L.quadruplet_loss(q, p, n, o, 0.5, 0.2, use_min=True, lazy=True, ignore_zero_loss=False)
-        loss.backward()
-        opt.step()
-        return loss
-    for i in range(warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        losses.append(step(warmup + i))
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    losses = [round(float(l.item()), 4) for l in losses]
-    if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    peak = torch.cuda.max_memory_allocated(dev) / 2**30
+    def make_step(fwd):
+        def step(i):
+            opt.zero_grad(set_to_none=True)
+            out = fwd(clouds[i % nbatch]).view(bq, -1, 256)
+            q, p, n, o = torch.split(out, [1, P, Ng, 1], dim=1)
+            loss = L.quadruplet_loss(q, p, n, o, 0.5, 0.2, use_min=True, lazy=True, ignore_zero_loss=False)
+            loss.backward()
+            opt.step()
+            return loss
+        return step
+    prev_storage = autograd.set_train_storage(storage)
+    try:
+        step = make_step(net)
+        for i in range(warmup):
+            step(i)
+        torch.cuda.reset_peak_memory_stats(dev)
+        el, losses = _time_steps(step, warmup, steps, dist, dev)
+        losses = [round(float(l.item()), 4) for l in losses]
+        peak = torch.cuda.max_memory_allocated(dev) / 2**30
+        comm = None
+        if dist is not None and world > 1:
+            # (a) the step without its exchange (bare model, no hooks fire): what the all-reduce costs that backward does not hide
+            net.enabled = False
+            el0, _ = _time_steps(step, 0, steps, dist, dev)
+            net.enabled = True
+            # (b) the step's two all-reduces by themselves on an idle GPU (67 MB hidden1_weights gradient + the 3.3 MB bucket)
+            big = torch.zeros_like(model.net_vlad.hidden1_weights)
+            small = torch.zeros((sum(p.numel() for p in model.parameters()) - big.numel(),), device=dev)
+            for _ in range(2):
+                dist.all_reduce(big), dist.all_reduce(small)
+            torch.cuda.synchronize()
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 5
+            e0.record()
+            for _ in range(reps):
+                dist.all_reduce(big), dist.all_reduce(small)
+            e1.record()
+            torch.cuda.synchronize()
+            ar_ms = e0.elapsed_time(e1) / reps
+            t = torch.tensor([ar_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            nbytes = 4 * (big.numel() + small.numel())
+            comm = {"allreduce_ms_per_step_isolated": round(float(t.item()), 3), "gradient_bytes": nbytes,
+                    "allreduce_busbw_GBps": round(2 * (world - 1) / world * nbytes / (float(t.item()) * 1e-3) / 1e9, 1),
+                    "ms_per_step_without_exchange": round(1e3 * el0 / steps, 2),
+                    "allreduce_exposed_ms_per_step": round(1e3 * (el - el0) / steps, 3),
+                    "backend": "nccl (RCCL)", "buckets": "hidden1_weights (67 MB) from its post-accumulate hook, overlapped "
+                    "with the trunk's backward; the other 3.3 MB flattened into one bucket at the end of backward"}
+    finally:
+        autograd.set_train_storage(prev_storage)
     return {"metric": "quadruplet train-steps/sec", "value": round(steps / el, 3), "unit": "steps/s",
             "tuples_per_s": round(bq * world * steps / el, 3), "ms_per_step": round(1e3 * el / steps, 2), "steps": steps,
-            "config": f"BASELINE configs[2]: bq={bq} P={P} Ng={Ng} -> {B} clouds/rank, N={points}, lazy quadruplet, Adam, fp32; "
-                      f"x{world} ranks data-parallel (per-rank BN, gradient all-reduce)",
-            "dtype": "f32", "losses": losses, "peak_hbm_gib": round(peak, 2)}
+            "config": f"BASELINE configs[{2 if world == 1 else 3}]: bq={bq} P={P} Ng={Ng} -> {B} clouds/rank, N={points}, lazy quadruplet, "
+                      f"Adam, {storage} storage; x{world} ranks data-parallel (per-rank BN, gradient all-reduce)",
+            "dtype": storage, "losses": losses, "peak_hbm_gib": round(peak, 2), "exchange": comm}
+
+
+def kernel_table(prof):
+    kern = {}
+    for name, evs in prof.items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        kern[name] = {"launches": len(ms), "avg_us": round(1e3 * sum(ms) / len(ms), 2)}
+    return kern
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))            # launcher: no GPU call in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" in os.environ and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -152,7 +244,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from lpdnet_hip import ops
+    from lpdnet_hip import engine, ops
     from util.PointNetVlad import PointNetVlad
 
     torch.manual_seed(1234)  # reference util/initPara.py:86
@@ -191,56 +283,90 @@ def main():
     for i in range(args.steps):
         out = step(i)
     torch.cuda.synchronize()
+    my_elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = ops.PROFILE
-    # the per-op table of the JSON line comes from a separate, untimed pass with every launch bracketed
+    # the per-op tables of the JSON line come from separate, untimed passes with every launch bracketed:
+    # (a) as the forward runs (two HIP streams: entries of kernels that overlap include the time they share the chip),
+    # (b) on ONE stream (engine.SIDE_STREAM off): clean per-op durations
     ops.PROFILE, ops.PROFILE_ONLY = {}, None
     for i in range(min(args.steps, 5)):
         step(i)
     torch.cuda.synchronize()
     prof_all = ops.PROFILE
     prof_all.update({k_: v for k_, v in prof.items()})      # K-agg entries: the timed region's own measurements
-    prof = prof_all
+    side_was = engine.SIDE_STREAM
+    engine.SIDE_STREAM = False
+    ops.PROFILE = {}
+    for i in range(min(args.steps, 5) + 1):
+        step(i)
+    torch.cuda.synchronize()
+    prof_serial = ops.PROFILE
+    engine.SIDE_STREAM = side_was
     ops.PROFILE = None
+    per_rank = [round(args.batch * args.steps / my_elapsed, 1)]
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([my_elapsed], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [round(args.batch * args.steps / float(x.item()), 1) for x in allr]
 
     total_desc = args.batch * args.steps * world
     value = total_desc / elapsed
 
-    kern = {}
-    for name, evs in prof.items():
-        ms = [a.elapsed_time(b) for a, b in evs]
-        kern[name] = {"launches": len(ms), "avg_us": round(1e3 * sum(ms) / len(ms), 2)}
+    kern = kernel_table(prof_all)
+    kern1 = kernel_table(prof_serial)
     roof = None
     key, kname = "edge_gather_max16[C=256]", "edge_gather_max_cloud16p_kernel (persistent workgroups, LDS-resident cloud slice)"
-    if key not in kern:     # k != 20 or N > 4096: the direct gather form
-        key, kname = "edge_gather_max[C=256]", "edge_gather_max_kernel<64> (direct gather)"
+    if key not in kern:     # k != 20 or N > 4096
+        key = next((k_ for k_ in kern if k_.startswith("edge_gather_max") and k_.endswith("[C=256]")), None)
+        kname = ops.KAGG_KERNEL_NAMES.get(key.split("[")[0], key) if key else None
     if key in kern:
         t_s = kern[key]["avg_us"] * 1e-6
-        alg = (KAGG_ROW_BYTES + 4 * args.k) * args.batch * args.points
+        pts = args.batch * args.points
+        alg = (KAGG_ROW_BYTES + 4 * args.k) * pts
+        alg_direct = (128 * 4 + 256 * 4 + 4 * args.k) * pts      # SURVEY 8d direct form: x2 row in, indices, x3 row out
         ach = alg / t_s / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "kagg_pmc.json")
-        if os.path.exists(pmc) and (args.batch, args.points, args.k) == (32, 4096, 20):   # PMC run is for the default workload
+        if os.path.exists(pmc):          # PMC passes are kept per workload: {"runs": [{batch, points, k, bench_key, hbm_bytes_per_launch}]}
             try:
                 rec = json.load(open(pmc))
-                traffic = rec.get("hbm_bytes_per_launch") if rec.get("bench_key") == key else None
+                for r in rec.get("runs", [rec]):
+                    if (r.get("batch", 32), r.get("points", 4096), r.get("k", 20)) == (args.batch, args.points, args.k) \
+                            and r.get("bench_key") == key:
+                        traffic = r.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roof = {"kernel": f"{kname}, SN1 stage, C=256, k={args.k}", "bound": "hbm", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg, "avg_launch_us": kern[key]["avg_us"]}
+                "algorithmic_bytes_per_launch": alg, "avg_launch_us": kern[key]["avg_us"],
+                "numerator": "split form: P row + Q row + out row + int32 indices per point (the rows this kernel reads and "
+                             "writes once; P and Q exist because the SN1 convolution is split, DESIGN.md 3.3)",
+                "frac_direct_form": round(alg_direct / t_s / 1e9 / HBM_PEAK_GBS, 4),
+                "direct_form_bytes_per_launch": alg_direct}
+        # the SN1 stage as a whole: projection GEMM + K-agg for the stage's own inputs/outputs (x2 in, indices, x3 out)
+        pk = next((k_ for k_ in kern1 if k_.startswith("gemm") and k_.endswith(f"[{pts}x512x128]")), None)
+        if pk is not None and key in kern1:
+            t_stage = (kern1[pk]["avg_us"] + kern1[key]["avg_us"]) * 1e-6
+            roof["stage"] = {"kernels": [pk, key], "us": round(t_stage * 1e6, 1),
+                             "frac_direct_form": round(alg_direct / t_stage / 1e9 / HBM_PEAK_GBS, 4)}
 
     train = None
     if not args.no_train:
         del out
         torch.cuda.empty_cache()
         train = train_bench(dev, dist, world, rank, args.points, args.train_steps)
+        train_bf16 = None
+        from lpdnet_hip import autograd as _ag
+        if not args.no_train_bf16 and "bf16" in _ag.TRAIN_STORAGES:
+            torch.cuda.empty_cache()
+            train_bf16 = train_bench(dev, dist, world, rank, args.points, args.train_steps, storage="bf16")
 
     if rank == 0:
         line = {
@@ -251,12 +377,16 @@ def main():
             "config": {"workload": ("BASELINE configs[1]" if (args.points, args.k) == (4096, 20) else "BASELINE configs[4] (stress)") +
                                    ": LPD-Net (featnet=lpdnet, emb_dims=1024, no T-Nets) eval forward, "
                                    f"N={args.points}, k={args.k}, eval_batch_size={args.batch} clouds/step/GPU",
-                       "clouds_per_step_per_gpu": args.batch, "num_points": args.points, "parallelism": f"shard-by-cloud x{world}",
+                       "clouds_per_step_per_gpu": args.batch, "num_points": args.points,
+                       "parallelism": f"shard-by-cloud x{world} (one process per GPU, no data-path collective)",
                        "arithmetic": ("fp32 tensors; kNN distances and every layer in front of the feature-space kNN exact fp32; large dense "
                                       "products as 3-product split-bf16 MFMA with fp32 accumulation (DESIGN.md 3.2)"
                                       if ops.GEMM_BF16X3 else "fp32 tensors, every product on the f32-input MFMA / fp32 FMA")},
-            "roofline": roof, "kernels": kern, "train": train,
+            "descriptors_per_s_per_rank": per_rank,
+            "roofline": roof, "kernels": kern, "kernels_one_stream": kern1, "train": train,
         }
+        if train is not None and train_bf16 is not None:
+            line["train_bf16"] = train_bf16
         if world == 1 and not args.no_cpu_baseline:
             base, xs, ref = cpu_baseline(model, args.points)
             with torch.no_grad():
@@ -264,7 +394,7 @@ def main():
             rel = ((got - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)).max().item()
             line["cpu_baseline"] = base
             line["parity_norm_rel_vs_oracle"] = float(f"{rel:.3e}")
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -81,7 +81,7 @@ int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k, int32_t* i
 int lpd_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
              int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC, int splits,
              float* splitk_ws, const float* bias, const float* scale, const float* shift, int act, float slope,
-             int accumulate, int a_panels, int c_panels, void* stream);
+             int accumulate, long long a_cloud, long long c_cloud, int panel_n, int panel_ld, void* stream);
 
 /*
  * lpd_gemm on the bf16 MFMA: each fp32 operand is split hi + lo (two bf16) while it is staged into LDS and every
@@ -92,7 +92,7 @@ int lpd_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
 int lpd_gemm_bf16x3(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
              int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC, int splits,
              float* splitk_ws, const float* bias, const float* scale, const float* shift, int act, float slope,
-             int accumulate, int a_panels, int c_panels, void* stream);
+             int accumulate, long long a_cloud, long long c_cloud, int panel_n, int panel_ld, void* stream);
 
 /*
  * Split-bf16 GEMM for a weight-shaped B: lpd_gemm_prep_b splits B (either layout) once into hi/lo bf16 stored in MFMA

@@ -5,10 +5,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
-#define LPD_OK 0
-#define LPD_ERR_ARG (-1)
-#define LPD_ERR_LAUNCH (-2)
-#define LPD_ERR_UNSUPPORTED (-3)
+// The public C-ABI: every extern "C" definition in csrc/ is compiled against its declaration, so a prototype that drifts
+// from the definition is a compile error (conflicting types), not a corrupted call in a C caller.
+#include "../../include/lpd_hip.h"
 
 // thread-local last-error text (lpd_last_error()); defined in lpd_abi.hip
 void lpd_set_error(const char* fmt, ...);

@@ -13,6 +13,10 @@ CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 LIB_PATH = os.path.join(HERE, "liblpd_hip.so")
 OBJ_DIR = os.path.join(CSRC, "build")
 ARCH = "gfx950"
+REPO = os.path.dirname(os.path.dirname(HERE))
+PUBLIC_HEADER = os.path.join(REPO, "include", "lpd_hip.h")      # every csrc/*.hip is compiled against it (lpd_common.h)
+ABI_SMOKE_SRC = os.path.join(REPO, "tests", "abi_smoke.c")
+ABI_SMOKE_BIN = os.path.join(REPO, "tests", "abi_smoke")
 # -ffp-contract=off: the kNN arithmetic contract distinguishes fused from non-fused operations
 # (HIP's __fmul_rn/__fadd_rn are plain operators and DO get contracted otherwise); explicit fmaf /
 # MFMA are unaffected.
@@ -43,7 +47,7 @@ def build(force=False, verbose=False):
     """Compile every csrc/*.hip for gfx950 and link liblpd_hip.so. Incremental by content hash."""
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [PUBLIC_HEADER]
     jobs, objs = [], []
     for src in _sources():
         obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
@@ -76,6 +80,19 @@ def build(force=False, verbose=False):
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
     return LIB_PATH
+
+
+def build_abi_smoke():
+    """gcc tests/abi_smoke.c against include/lpd_hip.h + liblpd_hip.so: a plain C caller of the C-ABI (run on the GPU box by
+    tests/test_abi_gpu.py; `--symbols` runs without a GPU)."""
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["gcc", "-O1", "-std=c11", "-Wall", "-Werror", ABI_SMOKE_SRC, f"-I{rocm}/include", f"-L{HERE}", "-llpd_hip",
+           f"-L{rocm}/lib", "-lamdhip64", "-lm", "-Wl,-rpath,$ORIGIN/../lpd-net-pytorch_amd/lpdnet_hip",
+           f"-Wl,-rpath,{rocm}/lib", "-o", ABI_SMOKE_BIN]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"gcc failed for {ABI_SMOKE_SRC}:\n{r.stderr}")
+    return ABI_SMOKE_BIN
 
 
 if __name__ == "__main__":

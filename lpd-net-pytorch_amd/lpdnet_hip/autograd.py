@@ -92,6 +92,29 @@ def best_pos_distance(query, pos_vecs):
 # ------------------------------------------------------------------------------------------------
 LEAKY = 0.01
 
+# Storage type of the large saved / materialised training tensors (edge tensors, their gradients, saved activations):
+# "f32" (default: what the 1e-4 parity gates are written for) or "bf16" (BASELINE configs[2] as stated: bf16 storage,
+# statistics / accumulations / kNN in fp32-fp64; looser stated tolerance, tests/test_train_gpu.py).
+TRAIN_STORAGES = ("f32",)
+TRAIN_STORAGE = "f32"
+
+
+def set_train_storage(kind):
+    """-> the previous setting"""
+    global TRAIN_STORAGE
+    if kind not in TRAIN_STORAGES:
+        raise NotImplementedError(f"training storage {kind!r} is not built (available: {TRAIN_STORAGES})")
+    prev, TRAIN_STORAGE = TRAIN_STORAGE, kind
+    return prev
+
+
+def _saved(ctx):
+    """The forward's saved tensors live in a plain dict on ctx (freed at the end of backward: several GB of edge tensors)."""
+    if ctx.saved is None:
+        raise RuntimeError("Trying to backward through the LPD-Net HIP graph a second time: the saved edge tensors were freed "
+                           "after the first backward (retain_graph=True is not supported on this path; run the forward again)")
+    return ctx.saved
+
 
 def _pick_splits(R, tiles):
     """split-K factor for a reduction over R rows: ~512 blocks, >= 8 k-tiles per block, R % (32*s) == 0."""
@@ -366,7 +389,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeat):
         from . import engine
-        net, S = ctx.net, ctx.saved
+        net, S = ctx.net, _saved(ctx)
         B, N, M, k = ctx.dims
         act, slope = ctx.actslope
         w2d = engine._w2d
@@ -490,7 +513,7 @@ class _LPDNetOrignTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeat):
         from . import engine
-        net, S = ctx.net, ctx.saved
+        net, S = ctx.net, _saved(ctx)
         B, N, M, k = ctx.dims
         act, slope = ctx.actslope
         w2d = engine._w2d
@@ -519,10 +542,10 @@ class _LPDNetOrignTrainFn(torch.autograd.Function):
         return (None, None) + grads + tuple(extra)
 
 
-def lpdnet_origin_features_train(net, x):
+def lpdnet_origin_features_train(net, x, reorder=True):
     """LPDNetOrign training-mode forward: ([B*N, E] features with autograd, B, N)."""
     from . import engine
-    x = engine.reorder_points(engine._check_input(x))
+    x = engine.reorder_points(engine._check_input(x), reorder)
     params = _named(net, list(_LPDNetOrignTrainFn.PARAMS) + _Front.tnet_param_names(net))
     feat = _LPDNetOrignTrainFn.apply(net, x, *params)
     return feat, x.shape[0], x.shape[2]
@@ -538,10 +561,10 @@ def _named(module, names):
     return out
 
 
-def lpdnet_features_train(net, x):
+def lpdnet_features_train(net, x, reorder=True):
     """LPDNet training-mode forward: ([B*N, E] features with autograd, B, N)."""
     from . import engine
-    x = engine.reorder_points(engine._check_input(x))
+    x = engine.reorder_points(engine._check_input(x), reorder)
     names = list(_LPDNetTrainFn.PARAMS) + _Front.tnet_param_names(net)
     feat = _LPDNetTrainFn.apply(net, x, *_named(net, names))
     return feat, x.shape[0], x.shape[2]
@@ -588,7 +611,7 @@ class _PointNetTrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dfeat):
-        net, S = ctx.net, ctx.saved
+        net, S = ctx.net, _saved(ctx)
         B, N = ctx.dims
         R = ops.ACT_RELU
         dfeat = dfeat.contiguous()
@@ -663,7 +686,7 @@ class _NetVLADTrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        vlad, S = ctx.vlad, ctx.saved
+        vlad, S = ctx.vlad, _saved(ctx)
         B, N, M, E, K, O, Bp = ctx.dims
         gc = vlad.context_gating
         dev = dout.device

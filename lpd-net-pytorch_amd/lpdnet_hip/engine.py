@@ -24,9 +24,10 @@ MORTON_ORDER = True
 MORTON_MAX_POINTS = 16384
 
 
-def reorder_points(x):
-    """x [B,1,N,3] -> Z-ordered copy (or x itself when disabled / too large)."""
-    if MORTON_ORDER and 64 <= x.shape[2] <= MORTON_MAX_POINTS:
+def reorder_points(x, reorder=True):
+    """x [B,1,N,3] -> Z-ordered copy (or x itself when disabled / too large).  reorder=False: the caller needs the per-point
+    output in ITS point order (the public LPDNet.forward / LPDNetOrign.forward); PointNetVlad's descriptor is order-invariant."""
+    if reorder and MORTON_ORDER and 64 <= x.shape[2] <= MORTON_MAX_POINTS:
         return ops.morton_sort(x)
     return x
 
@@ -61,7 +62,12 @@ def bn_affine(bn):
         scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
         shift = bn.bias - bn.running_mean * scale
         return scale.contiguous(), shift.contiguous()
-    return _cached(bn, "affine", (bn.weight, bn.bias, bn.running_mean, bn.running_var), build)
+    # num_batches_tracked is in the signature because the training path updates running_mean / running_var through raw
+    # pointers (lpd_bn_finalize), which does not bump their _version; the counter is bumped with `+= 1` on every such update
+    src = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    if bn.num_batches_tracked is not None:
+        src = src + (bn.num_batches_tracked,)
+    return _cached(bn, "affine", src, build)
 
 
 def _w2d(conv):
@@ -160,15 +166,17 @@ def _knn_rows(rows, B, N, C, k):
 PANEL_LAYOUT = __import__("os").environ.get("LPD_PANELS", "1") != "0"
 SIDE_STREAM = __import__("os").environ.get("LPD_SIDE_STREAM", "1") != "0"   # xyz kNN on a second HIP stream (eval path)
 _SIDE = {}
+_SIDE_LOCK = __import__("threading").Lock()      # nn.DataParallel calls forward from one host thread per device
 
 
 def _side_stream(device):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    st = _SIDE.get(key)
-    if st is None:
-        # high priority: its kernels are the short ones that fill in next to the long kernels of the main stream (measured:
-        # 2.39 -> 2.33 ms per step; at default priority the overlap even turned into a loss once RCCL's own streams existed)
-        st = _SIDE[key] = torch.cuda.Stream(device=device, priority=int(__import__('os').environ.get('LPD_SIDE_PRIO', '-1')))
+    with _SIDE_LOCK:
+        st = _SIDE.get(key)
+        if st is None:
+            # high priority: its kernels are the short ones that fill in next to the long kernels of the main stream (measured:
+            # 2.39 -> 2.33 ms per step; at default priority the overlap even turned into a loss once RCCL's own streams existed)
+            st = _SIDE[key] = torch.cuda.Stream(device=device, priority=int(__import__('os').environ.get('LPD_SIDE_PRIO', '-1')))
     return st
 
 
@@ -186,9 +194,9 @@ def kagg(P, Q, idx, N, *, scale, shift, act, slope, out):
     return ops.edge_gather_max(P, Q, idx, N, scale=scale, shift=shift, act=act, slope=slope, out=out)
 
 
-def lpdnet_features_eval(net, x):
+def lpdnet_features_eval(net, x, reorder=True):
     """util/lpdnet_model.py:211-268 (LPDNet.forward), eval mode."""
-    x = reorder_points(_check_input(x))
+    x = reorder_points(_check_input(x), reorder)
     B, N = x.shape[0], x.shape[2]
     M = B * N
     k = net.k
@@ -289,9 +297,9 @@ def lpdnet_features_eval(net, x):
     return ops.linear(cat, _w2d(net.conv3_lpd), scale=sc, shift=bc, act=act, slope=slope), B, N
 
 
-def lpdnet_origin_features_eval(net, x):
+def lpdnet_origin_features_eval(net, x, reorder=True):
     """util/lpdnet_model.py:68-114 (LPDNetOrign.forward), eval mode."""
-    x = reorder_points(_check_input(x))
+    x = reorder_points(_check_input(x), reorder)
     B, N = x.shape[0], x.shape[2]
     M = B * N
     k = net.k

@@ -130,14 +130,17 @@ def _strip_module_prefix(state_dict):
 def save_checkpoint(path, model, optimizer, epoch, total_iterations, recall):
     """train_pointnetvlad.py:172-199: the reference's .ckpt dictionary (weights of the unwrapped model)."""
     torch.save({"epoch": epoch, "iter": total_iterations, "state_dict": _unwrap(model).state_dict(),
-                "optimizer": optimizer.state_dict(), "recall": recall}, path)
+                "optimizer": optimizer.state_dict(), "recall": float(recall)}, path)
 
 
 def load_pretrained(model, path, optimizer=None, map_location="cpu"):
     """train_pointnetvlad.py:64-77: a path ending in '7' (.t7) holds a bare state_dict (loaded with strict=False), anything
     else the .ckpt dictionary (strict=True, optimizer state restored).  -> (starting_epoch, total_iterations)."""
     target = _unwrap(model)
-    blob = torch.load(path, map_location=map_location)
+    # weights_only=False: the reference's .ckpt stores `recall` as numpy.float64 (np.mean, train_pointnetvlad.py:172-199) and
+    # the optimizer state as a plain pickle; torch >= 2.6 refuses those under the weights-only default.  Like the
+    # reference's own torch.load, this trusts the file: load checkpoints from sources you trust.
+    blob = torch.load(path, map_location=map_location, weights_only=False)
     if str(path)[-1] == "7":
         target.load_state_dict(_strip_module_prefix(blob), strict=False)
         return 0, 0

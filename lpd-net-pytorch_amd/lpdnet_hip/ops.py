@@ -157,6 +157,7 @@ class train_forward_gemm(exact_gemm):
 
 
 _FRAG_CACHE = {}
+_FRAG_LOCK = __import__("threading").Lock()     # nn.DataParallel-style callers: one forward per device thread
 X3W_FORWARD = os.environ.get("LPD_X3W_FWD", "1") != "0"    # forward layers with K >= 256 on the prepared-fragment kernel
 X3W_IMPL = int(os.environ.get("LPD_X3W_IMPL", "0"))         # lpd_gemm_x3w impl (0 = by shape); benchmarking only
 
@@ -169,16 +170,18 @@ def _weight_frags(B2, b_kmajor, N, K):
     cacheable = isinstance(base, torch.nn.Parameter)
     key = (B2.data_ptr(), base._version, tuple(B2.shape), B2.stride(0), bool(b_kmajor)) if cacheable else None
     if cacheable:
-        hit = _FRAG_CACHE.get(key)
+        with _FRAG_LOCK:
+            hit = _FRAG_CACHE.get(key)
         if hit is not None:
             return hit[0]
-        if len(_FRAG_CACHE) > 256:
-            _FRAG_CACHE.clear()
     lib = _lib.load()
     frags = torch.empty((int(lib.lpd_gemm_prep_b_bytes(N, K)),), dtype=torch.uint8, device=B2.device)
     _call("gemm_prep_b", lib.lpd_gemm_prep_b, _ptr(B2), B2.stride(0), int(bool(b_kmajor)), N, K, _ptr(frags), _stream())
     if cacheable:
-        _FRAG_CACHE[key] = (frags, base)     # the reference keeps the parameter's storage from being recycled under the key
+        with _FRAG_LOCK:
+            if len(_FRAG_CACHE) > 256:
+                _FRAG_CACHE.clear()
+            _FRAG_CACHE[key] = (frags, base)     # the reference keeps the parameter's storage from being recycled under the key
     return frags
 
 
@@ -385,6 +388,12 @@ def apply_transform(x, trans, rows_per_cloud, out=None):
         raise ValueError("apply_transform: x must be contiguous for the batched GEMM")
     y = gemm(x.view(Bn, rows_per_cloud, K), trans, a_kmajor=False, b_kmajor=True)
     return y.view(M, K)
+
+
+# bench.py's roofline line names the kernel behind each K-agg wrapper
+KAGG_KERNEL_NAMES = {"edge_gather_max16": "edge_gather_max_cloud16p_kernel (persistent workgroups, LDS-resident cloud slice)",
+                     "edge_gather_max": "edge_gather_max_kernel (direct gather, one part-wavefront per point)",
+                     "edge_gather_maxw": "edge_gather_max_window_kernel (Z-order window of P rows in LDS, misses from L2)"}
 
 
 def edge_gather_max(P, Q, idx, N, *, scale=None, shift=None, act=ACT_NONE, slope=0.01, out=None):
@@ -626,13 +635,19 @@ def _bn_finalize(sums, R, C, bn):
     """fp64 column sums / sums of squares over R rows -> BNStats (+ running-stat update)."""
     out = torch.empty((4, C), dtype=torch.float32, device=sums.device)
     lib = _lib.load()
-    momentum = 0.1 if bn.momentum is None else bn.momentum
     track = bn.track_running_stats and bn.running_mean is not None
+    if R <= 1:
+        raise ValueError(f"Expected more than 1 value per channel when training, got {R} row(s) of {C} channels")   # torch's rule
+    if bn.momentum is None:      # torch: cumulative moving average, factor 1 / num_batches_tracked (after the increment)
+        momentum = 1.0 / (int(bn.num_batches_tracked) + 1) if track else 0.0
+    else:
+        momentum = bn.momentum
     _call("bn_finalize", lib.lpd_bn_finalize, _ptr(sums[0]), _ptr(sums[1]), float(R), C, _ptr(bn.weight), _ptr(bn.bias),
           _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None, float(momentum),
           float(bn.eps), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _stream())
     if track:
         bn.num_batches_tracked += 1
+        bn.__dict__.pop("_lpd_cache", None)      # the folded eval-mode affine (engine.bn_affine) is stale now
     return BNStats(out[0], out[1], out[2], out[3], R)
 
 

@@ -21,7 +21,12 @@ import torch.nn as nn
 
 
 class GradAllReduce(nn.Module):
-    def __init__(self, module, process_group=None, big_bytes=8 << 20, broadcast_from=0):
+    """module: the replica of this rank (already on its device).  big_bytes: gradients at least this large get their own
+    all-reduce, launched from the post-accumulate hook; reduce_when_single: issue the collectives even at world size 1
+    (exercises the RCCL path on a one-GPU box; the result is unchanged).  `.enabled = False` turns the exchange off
+    (bench.py times the step without it)."""
+
+    def __init__(self, module, process_group=None, big_bytes=8 << 20, broadcast_from=0, reduce_when_single=False):
         super().__init__()
         if not dist.is_initialized():
             raise RuntimeError("GradAllReduce needs torch.distributed to be initialised (one process per GPU)")
@@ -29,7 +34,10 @@ class GradAllReduce(nn.Module):
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.big_bytes = big_bytes
-        self._handles = []
+        self.enabled = True
+        self.reduce_when_single = reduce_when_single
+        self.stats = {"steps": 0, "big_reduced": 0, "bucket_elems": 0}
+        self._handles = []          # (work handle, flat bucket or None, [parameters reduced by it])
         self._small = []
         self._finalize_queued = False
         # identical replicas to start from
@@ -45,36 +53,40 @@ class GradAllReduce(nn.Module):
 
     # -- hooks ------------------------------------------------------------------------------------
     def _on_grad(self, p):
-        if self.world == 1:
+        if not self.enabled or (self.world == 1 and not self.reduce_when_single):
             return
         if not self._finalize_queued:
             self._finalize_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
         if p.grad.numel() * p.grad.element_size() >= self.big_bytes:
-            self._handles.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+            h = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._handles.append((h, None, [p]))
         else:
             self._small.append(p)
 
     def _finalize(self):
-        """End of backward: reduce the bucket of small gradients, wait for everything, divide by world."""
+        """End of backward: reduce the bucket of small gradients, wait for everything, divide by world -- only the
+        gradients that were reduced in THIS backward (a parameter left out of the graph keeps its stale .grad untouched)."""
         try:
             if self._small:
                 flat = torch.cat([p.grad.reshape(-1) for p in self._small])
                 h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self._handles.append((h, flat, list(self._small)))
+                self.stats["bucket_elems"] = flat.numel()
             inv = 1.0 / self.world
-            big = []
             for h, flat, plist in self._handles:
                 h.wait()
-                if flat is not None:
+                if flat is None:
+                    for p in plist:
+                        p.grad.mul_(inv)
+                        self.stats["big_reduced"] += 1
+                else:
+                    flat.mul_(inv)
                     off = 0
                     for p in plist:
                         n = p.grad.numel()
                         p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                        p.grad.mul_(inv)
                         off += n
-            for p in self.module.parameters():
-                if p.grad is not None and p.grad.numel() * p.grad.element_size() >= self.big_bytes:
-                    p.grad.mul_(inv)
+            self.stats["steps"] += 1
         finally:
             self._handles, self._small, self._finalize_queued = [], [], False

@@ -120,15 +120,17 @@ class LPDNet(nn.Module):
         self.bn2_lpd = nn.BatchNorm1d(64)
         self.bn3_lpd = nn.BatchNorm1d(self.emb_dims)
 
-    def _features(self, x):
-        """Point-major features ([B*N, E], B, N): what NetVLADLoupe consumes without a layout change."""
+    def _features(self, x, reorder=True):
+        """Point-major features ([B*N, E], B, N): what NetVLADLoupe consumes without a layout change.  reorder: the points of
+        each cloud may be Z-ordered internally (rows of the result then follow that order, not the caller's) -- legal for
+        PointNetVlad, whose descriptor is invariant to point order."""
         if self.training:
             from lpdnet_hip import autograd
-            return autograd.lpdnet_features_train(self, x)
-        return engine.lpdnet_features_eval(self, x)
+            return autograd.lpdnet_features_train(self, x, reorder)
+        return engine.lpdnet_features_eval(self, x, reorder)
 
     def forward(self, x):
-        feat, B, N = self._features(x)
+        feat, B, N = self._features(x, reorder=False)      # column n of the result belongs to input point n, like the reference
         return engine.to_channel_major(feat, B, N)
 
 
@@ -168,12 +170,12 @@ class LPDNetOrign(nn.Module):
         self.conv4_lpd = c1(64, 128)
         self.conv5_lpd = c1(128, self.emb_dims)
 
-    def _features(self, x):
+    def _features(self, x, reorder=True):
         if self.training:
             from lpdnet_hip import autograd
-            return autograd.lpdnet_origin_features_train(self, x)
-        return engine.lpdnet_origin_features_eval(self, x)
+            return autograd.lpdnet_origin_features_train(self, x, reorder)
+        return engine.lpdnet_origin_features_eval(self, x, reorder)
 
     def forward(self, x):
-        feat, B, N = self._features(x)
+        feat, B, N = self._features(x, reorder=False)      # per-point output in the caller's point order
         return engine.to_channel_major(feat, B, N)

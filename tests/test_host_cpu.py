@@ -132,6 +132,16 @@ def test_checkpoint_interop_with_the_reference_format(tmp_path):
     opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
     assert harness.load_pretrained(m2, ck, opt2) == (4, 1234)
     assert all(torch.equal(m2.state_dict()[k], v) for k, v in sd0.items())
+    # the reference stores `recall` as numpy.float64 (np.mean of the per-run recalls, train_pointnetvlad.py:172-199): a
+    # checkpoint written by the reference itself must load (torch >= 2.6 refuses numpy scalars under weights_only=True)
+    import numpy as np
+    ref_blob = dict(blob, recall=np.float64(81.5))
+    ck_ref = tmp_path / "ref.ckpt"
+    torch.save(ref_blob, ck_ref)
+    m_ref = PointNetVlad(num_points=256, featnet="lpdnet")
+    assert harness.load_pretrained(m_ref, ck_ref) == (4, 1234)
+    harness.save_checkpoint(tmp_path / "np.ckpt", m, opt, epoch=0, total_iterations=1, recall=np.float64(12.5))
+    assert type(torch.load(tmp_path / "np.ckpt")["recall"]) is float
     # a checkpoint written from an nn.DataParallel wrapper ("module." keys), as the reference's script.py handles
     blob["state_dict"] = {"module." + k: v for k, v in blob["state_dict"].items()}
     ck2 = tmp_path / "dp.ckpt"

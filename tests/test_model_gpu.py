@@ -65,7 +65,7 @@ def test_eval_descriptors_vs_reference_golden(cuda, golden_dir, tag, featnet, kw
         # feature-space kNN inherits upstream conv rounding: report agreement
         idx_f = aux["idx_feat"].cpu().numpy()
         agree = (idx_f == g["idx_feat"].astype(np.int32)).all(-1).mean()
-        assert agree > 0.98, f"feature-space kNN rows equal to the reference: {agree:.4f}"
+        assert agree >= 0.995, f"feature-space kNN rows equal to the reference: {agree:.4f}"    # measured 0.999
 
 
 @pytest.mark.parametrize("featnet,kw,B,N", [("lpdnet", {}, 3, 512), ("lpdnet", dict(xyz_trans=True), 2, 256),
@@ -330,3 +330,72 @@ def test_submap_stream_and_latent_vectors_from_files(cuda, tmp_path):
     x = torch.tensor([1.0 + 2.0 ** -24, 1.0 + 3 * 2.0 ** -24, 1e300, -1e-300, 3.4028235677973366e38, 0.1, -7.25], dtype=torch.float64)
     from lpdnet_hip import ops
     assert np.array_equal(ops.f64_to_f32(x.to(cuda)).cpu().numpy(), x.numpy().astype(np.float32), equal_nan=True)
+
+
+def test_bn_cache_follows_running_stats_updated_by_a_train_forward(cuda):
+    """eval forward (folds BN into a cached affine) -> train-mode forward WITHOUT an optimizer step (running statistics
+    move through raw pointers, no parameter version changes) -> eval forward must use the NEW statistics."""
+    N = 256
+    m, _ = _model("lpdnet", N, cuda)
+    x = torch.from_numpy(synth.cloud(9, 6, N)).unsqueeze(1).to(cuda)
+    with torch.no_grad():
+        d0 = m(x)
+        m.train()
+        m(x)                                   # updates running_mean / running_var only
+        m.eval()
+        d1 = m(x)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = orc.pointnetvlad_forward(sd, x.cpu(), featnet="lpdnet", train=False)
+    assert _norm_rel(d1, ref) < DESC_TOL               # the oracle on the module's CURRENT statistics
+    assert _norm_rel(d1, d0) > 1e-3                    # and they did move
+
+
+def test_public_trunk_forward_keeps_the_callers_point_order(cuda):
+    """LPDNet.forward / LPDNetOrign.forward return [B,E,N,1] with column n belonging to input point n (the Z-ordering of the
+    points is an internal matter of the PointNetVlad fast path)."""
+    from lpdnet_hip import engine
+    N = 512
+    assert engine.MORTON_ORDER
+    for featnet in ("lpdnet", "lpdnetorigin"):
+        m, sd = _model(featnet, N, cuda)
+        xc = torch.from_numpy(synth.cloud(13, 2, N)).unsqueeze(1)
+        with torch.no_grad():
+            got = m.emb_nn(xc.to(cuda))
+            perm = torch.randperm(N)
+            got_p = m.emb_nn(xc[:, :, perm].to(cuda))
+        assert got.shape == (2, 1024, N, 1)
+        # permuting the input permutes the columns of the output the same way
+        d = (got[:, :, perm.to(cuda)] - got_p).abs().amax().item() / got.abs().amax().item()
+        assert d < 1e-4, (featnet, d)
+
+
+def test_batchnorm_momentum_none_and_single_row(cuda):
+    """BatchNorm(momentum=None) = cumulative moving average (factor 1/num_batches_tracked) like torch; one row per channel
+    in train mode raises like torch does."""
+    from lpdnet_hip import ops
+    bn = torch.nn.BatchNorm1d(8, momentum=None).to(cuda).train()
+    ref = torch.nn.BatchNorm1d(8, momentum=None).train()
+    g = torch.Generator().manual_seed(0)
+    for _ in range(3):
+        x = torch.randn(32, 8, generator=g)
+        ops.bn_train_stats(x.to(cuda), bn)
+        ref(x)
+    assert int(bn.num_batches_tracked) == 3
+    assert torch.allclose(bn.running_mean.cpu(), ref.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var.cpu(), ref.running_var, rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        ops.bn_train_stats(torch.randn(1, 8, device=cuda), bn)
+
+
+def test_second_backward_raises_a_clear_error(cuda):
+    import loss.pointnetvlad_loss as L
+    m, _ = _model("lpdnet", 256, cuda)
+    m.train()
+    x = torch.from_numpy(synth.cloud(3, 6, 256)).unsqueeze(1).to(cuda)
+    out = m(x).view(1, -1, 256)
+    q, p, n, o = torch.split(out, [1, 2, 2, 1], dim=1)
+    loss = L.quadruplet_loss(q, p, n, o, 0.5, 0.2, use_min=True, lazy=True)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()

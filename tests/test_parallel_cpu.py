@@ -67,3 +67,107 @@ def test_grad_allreduce_gloo_world2(tmp_path, same_data):
     expect = [e / world for e in expect]
     for got, want in zip(r[0]["grads"], expect):
         assert torch.allclose(got, want, rtol=1e-5, atol=1e-7)
+
+
+def _pnv_stub_forward(model, x):
+    """A parameter-touching stand-in for PointNetVlad.forward (the real one needs the GPU): every parameter enters the
+    output, scaled by the data, so that every gradient is non-zero and differs between ranks with different data."""
+    acc = x.new_zeros(())
+    for i, p in enumerate(model.parameters()):
+        acc = acc + (p * p).mean() * (1.0 + 0.1 * (i % 7)) * x.mean()
+    return acc
+
+
+def _pnv_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "lpd-net-pytorch_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import types
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lpdnet_hip.parallel import GradAllReduce
+    from util.PointNetVlad import PointNetVlad
+    torch.manual_seed(50 + rank)
+    model = PointNetVlad(num_points=64, featnet="lpdnet")             # the real module tree: 55 state_dict keys, 17.6 M parameters
+    model.forward = types.MethodType(_pnv_stub_forward, model)
+    ddp = GradAllReduce(model)                                        # default thresholds: hidden1_weights (67 MB) is the one big tensor
+    x = torch.full((4,), 1.0 + rank)
+    ddp(x).backward()
+    big = [n for n, p in model.named_parameters() if p.numel() * 4 >= ddp.big_bytes]
+    torch.save({"big": big, "stats": dict(ddp.stats),
+                "gnorm": {n: p.grad.double().norm().item() for n, p in model.named_parameters()},
+                "probe": {n: p.grad.reshape(-1)[:4].clone() for n, p in model.named_parameters()},
+                "w": {n: p.detach().reshape(-1)[:4].clone() for n, p in model.named_parameters()}},
+               os.path.join(out_dir, f"pnv{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_wraps_the_real_pointnetvlad(tmp_path):
+    """GradAllReduce on PointNetVlad itself (module tree on CPU, forward replaced by a parameter-touching stub): rank 0's
+    weights everywhere, hidden1_weights reduced from its hook as the one big tensor, everything else in one bucket, and the
+    result is the mean of the per-rank gradients."""
+    world, port = 2, _free_port()
+    mp.spawn(_pnv_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"pnv{i}.pt")) for i in range(world)]
+    assert r[0]["big"] == ["net_vlad.hidden1_weights"]
+    assert r[0]["stats"]["steps"] == 1 and r[0]["stats"]["big_reduced"] == 1
+    assert r[0]["stats"]["bucket_elems"] == 17605184 - 65536 * 256
+    sys.path.insert(0, os.path.join(ROOT, "lpd-net-pytorch_amd"))
+    from util.PointNetVlad import PointNetVlad
+    torch.manual_seed(50)
+    ref = PointNetVlad(num_points=64, featnet="lpdnet")
+    for n, p in ref.named_parameters():
+        assert torch.equal(r[1]["w"][n], p.detach().reshape(-1)[:4]), n        # rank 1 holds rank 0's weights
+    # gradient of the stub: d/dp = 2 p / numel * c_i * mean(x); mean over ranks of mean(x) = 1.5
+    for i, (n, p) in enumerate(ref.named_parameters()):
+        want = 2 * p.detach().reshape(-1)[:4] / p.numel() * (1.0 + 0.1 * (i % 7)) * 1.5
+        assert torch.allclose(r[0]["probe"][n], want, rtol=1e-5, atol=1e-12), n
+        assert torch.equal(r[0]["probe"][n], r[1]["probe"][n]), n
+
+
+def test_stale_gradients_are_not_rescaled():
+    """A parameter that takes no part in this backward keeps its earlier .grad untouched."""
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "lpd-net-pytorch_amd"))
+    from lpdnet_hip.parallel import GradAllReduce
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        a, b = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+        both = torch.nn.ModuleList([a, b])
+        ddp = GradAllReduce(both, big_bytes=1, reduce_when_single=True)
+        b.weight.grad = torch.full_like(b.weight, 3.0)
+        a(torch.ones(2, 4)).sum().backward()
+        assert torch.equal(b.weight.grad, torch.full_like(b.weight, 3.0))
+        assert ddp.stats["steps"] == 1 and ddp.stats["big_reduced"] == 2
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_launcher_builds_the_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` without RANK is a launcher: no GPU call, one child process tree of N ranks on 127.0.0.1."""
+    import importlib
+    import subprocess
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class R:
+        returncode = 0
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("RANK", raising=False)
+    args = bench.parse()
+    assert bench.launch_ranks(args) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit):
+        bench.launch_ranks(args)

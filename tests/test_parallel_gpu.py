@@ -1,0 +1,61 @@
+"""The data-parallel training wrapper on the REAL model with a REAL process group on the GPU box (world size 1: the
+collectives are issued over RCCL and must leave the gradients of the single-process step unchanged).  -m gpu only.
+The N > 1 arithmetic is covered by the gloo world-2 tests in tests/test_parallel_cpu.py; the N-rank launch by
+`python bench.py --gpus N` (the launcher test there)."""
+import os
+import socket
+
+import pytest
+import torch
+
+from oracle import lpd_oracle as orc
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(net, x, bq, P, Ng):
+    import loss.pointnetvlad_loss as L
+    out = net(x).view(bq, -1, 256)
+    q, p, n, o = torch.split(out, [1, P, Ng, 1], dim=1)
+    loss = L.quadruplet_loss(q, p, n, o, 0.5, 0.2, use_min=True, lazy=True, ignore_zero_loss=False)
+    loss.backward()
+    return loss
+
+
+def test_grad_allreduce_on_pointnetvlad_over_rccl_world1(cuda):
+    import torch.distributed as dist
+    from lpdnet_hip.parallel import GradAllReduce
+    from util.PointNetVlad import PointNetVlad
+    N, bq, P, Ng = 512, 1, 2, 2
+    B = bq * (1 + P + Ng + 1)
+    sd = orc.synthetic_state("lpdnet", num_points=N)
+    x = torch.from_numpy(synth.cloud(21, B, N)).unsqueeze(1).to(cuda)
+
+    def fresh():
+        m = PointNetVlad(num_points=N, featnet="lpdnet")
+        m.load_state_dict(sd, strict=True)
+        return m.to(cuda).train()
+    plain = fresh()
+    l0 = _step(plain, x, bq, P, Ng)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=cuda)
+    try:
+        wrapped = fresh()
+        ddp = GradAllReduce(wrapped, reduce_when_single=True)
+        for _ in range(2):                                    # twice: bucket / hook state resets between backward passes
+            wrapped.zero_grad(set_to_none=True)
+            l1 = _step(ddp, x, bq, P, Ng)
+        torch.cuda.synchronize()
+        assert dist.get_backend() == "nccl"
+        assert ddp.stats["steps"] == 2 and ddp.stats["big_reduced"] == 2      # hidden1_weights, once per step
+        assert ddp.stats["bucket_elems"] == 17605184 - 65536 * 256
+    finally:
+        dist.destroy_process_group()
+    assert abs(l0.item() - l1.item()) < 1e-5 * abs(l0.item())
+    for (n, a), (_, b) in zip(plain.named_parameters(), wrapped.named_parameters()):
+        err = (a.grad - b.grad).norm().item() / max(a.grad.norm().item(), 1e-20)
+        assert err < 1e-4, (n, err)            # not bitwise: BatchNorm sums use fp64 atomics, summation order varies run to run
