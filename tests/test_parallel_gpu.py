@@ -58,4 +58,7 @@ def test_grad_allreduce_on_pointnetvlad_over_rccl_world1(cuda):
     assert abs(l0.item() - l1.item()) < 1e-5 * abs(l0.item())
     for (n, a), (_, b) in zip(plain.named_parameters(), wrapped.named_parameters()):
         err = (a.grad - b.grad).norm().item() / max(a.grad.norm().item(), 1e-20)
-        assert err < 1e-4, (n, err)            # not bitwise: BatchNorm sums use fp64 atomics, summation order varies run to run
+        # not bitwise: BatchNorm sums use fp64 atomics whose order varies run to run; behind the max over k a last-bit
+        # difference can re-route a gradient entry to another arg-max edge (tests/test_train_gpu.py header), so the trunk
+        # gets the trunk tolerance and the head (in front of every max) the tight one
+        assert err < (1e-4 if n.startswith("net_vlad.") else 1e-2), (n, err)
