@@ -383,7 +383,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
                          u1=u1, stg1=stg1, arg1=arg1, y1e=y1e, z=z, stg2=stg2, arg2=arg2, wcat3=wcat3, u3=u3, stg3=stg3,
                          arg3=arg3, cat=cat, y3=y3, st3=st3)
         if engine.DEBUG_AUX is not None:
-            engine.DEBUG_AUX.update(F0=f0, idx_feat=idx_f, idx_xyz=idx_x, cat=cat)
+            engine.DEBUG_AUX.update(F0=f0, idx_feat=idx_f, idx_xyz=idx_x, cat=cat, argsel=dict(x1=arg1, x2=arg2, x3=arg3))
         return feat
 
     @staticmethod
@@ -507,7 +507,7 @@ class _LPDNetOrignTrainFn(torch.autograd.Function):
         S.update(g=g, h=h, h3=h3, h4=h4, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1, wsn1=wsn1)
         ctx.net, ctx.dims, ctx.actslope, ctx.saved = net, (B, N, M, k), (act, slope), S
         if engine.DEBUG_AUX is not None:
-            engine.DEBUG_AUX.update(F0=f0, idx_feat=idx_f, idx_xyz=idx_x)
+            engine.DEBUG_AUX.update(F0=f0, idx_feat=idx_f, idx_xyz=idx_x, argsel=dict(dg=S["dg"]["arg"], sn=S["sn"]["arg"]))
         return feat
 
     @staticmethod

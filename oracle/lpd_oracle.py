@@ -168,7 +168,16 @@ def transform_net(sd, pre, x_bcn, train, new_stats):
     return h.reshape(-1, kdim, kdim)
 
 
-def lpdnet_features(sd, x, *, train=False, t3d=False, tfea=False, k=20, new_stats=None, aux=None, pre="emb_nn."):
+def _max_k(e, name, argsel):
+    """max over the k neighbours (lpdnet_model.py:250,252,258).  argsel[name] ([B,C,N] int64), when given, prescribes WHICH
+    neighbour slot is taken for every (cloud, channel, point): tests use it to evaluate the oracle on the arg-max choices the
+    GPU made, which removes the last-bit arg-max flips from a gradient comparison (tests/test_train_gpu.py)."""
+    if argsel is not None and name in argsel:
+        return torch.gather(e, -1, argsel[name].unsqueeze(-1))
+    return e.max(dim=-1, keepdim=True)[0]
+
+
+def lpdnet_features(sd, x, *, train=False, t3d=False, tfea=False, k=20, new_stats=None, aux=None, pre="emb_nn.", argsel=None):
     """LPDNet.forward (lpdnet_model.py:211-268), useBN=True, cat_or_stack=True.  x [B,1,N,3] -> [B,E,N,1]."""
     p = x.squeeze(1).transpose(1, 2)                               # [B,3,N]
     xyz = p                                                        # raw xyz even when t3d (:226)
@@ -183,13 +192,13 @@ def lpdnet_features(sd, x, *, train=False, t3d=False, tfea=False, k=20, new_stat
     idx_feat = knn(f, k)
     e = graph_feature(f, k, idx_feat)                              # [B,128,N,k]
     e = _act_leaky(_bn(sd, pre + "convDG1.1", _conv1x1(sd, pre + "convDG1.0", e), train, new_stats))
-    x1 = e.max(dim=-1, keepdim=True)[0]
+    x1 = _max_k(e, "x1", argsel)
     e = _act_leaky(_bn(sd, pre + "convDG2.1", _conv1x1(sd, pre + "convDG2.0", e), train, new_stats))
-    x2 = e.max(dim=-1, keepdim=True)[0]
+    x2 = _max_k(e, "x2", argsel)
     idx_xyz = knn(xyz, k)
     e = graph_feature(x2, k, idx_xyz)                              # [B,256,N,k]
     e = _act_leaky(_bn(sd, pre + "convSN1.1", _conv1x1(sd, pre + "convSN1.0", e), train, new_stats))
-    x3 = e.max(dim=-1, keepdim=True)[0]
+    x3 = _max_k(e, "x3", argsel)
     cat = torch.cat((x1, x2, x3), dim=1).squeeze(-1)               # [B,512,N]
     out = _act_leaky(_bn(sd, pre + "bn3_lpd", _conv1x1(sd, pre + "conv3_lpd", cat), train, new_stats))
     if aux is not None:
@@ -197,7 +206,7 @@ def lpdnet_features(sd, x, *, train=False, t3d=False, tfea=False, k=20, new_stat
     return out.unsqueeze(-1)
 
 
-def lpdnet_origin_features(sd, x, *, train=False, t3d=False, tfea=False, k=20, new_stats=None, aux=None, pre="emb_nn."):
+def lpdnet_origin_features(sd, x, *, train=False, t3d=False, tfea=False, k=20, new_stats=None, aux=None, pre="emb_nn.", argsel=None):
     """LPDNetOrign.forward (lpdnet_model.py:68-114), useBN=True."""
     def seq(name, h):
         return _act_leaky(_bn(sd, pre + name + ".1", _conv1x1(sd, pre + name + ".0", h), train, new_stats))
@@ -215,12 +224,12 @@ def lpdnet_origin_features(sd, x, *, train=False, t3d=False, tfea=False, k=20, n
     e = graph_feature_origin(f, k, idx_feat)                       # [B,128,N,k]
     e = seq("convDG1", e)
     e = seq("convDG2", e)
-    g = e.max(dim=-1, keepdim=True)[0]                             # [B,64,N,1]
+    g = _max_k(e, "dg", argsel)                                    # [B,64,N,1]
     idx_xyz = knn(xyz, k)
     e = graph_feature_origin(g, k, idx_xyz, cat=False)             # [B,64,N,k]
     e = seq("convSN1", e)
     e = seq("convSN2", e)
-    h = e.max(dim=-1, keepdim=True)[0].squeeze(-1)                 # [B,64,N]
+    h = _max_k(e, "sn", argsel).squeeze(-1)                        # [B,64,N]
     h = seq("conv3_lpd", h)
     h = seq("conv4_lpd", h)
     h = seq("conv5_lpd", h)
@@ -298,12 +307,14 @@ def netvlad(sd, feat, *, train=False, new_stats=None, aux=None, pre="net_vlad.")
 
 
 def pointnetvlad_forward(sd, x, *, featnet="lpdnet", train=False, feature_transform=False, xyz_trans=False, k=20,
-                         new_stats=None, aux=None):
+                         new_stats=None, aux=None, argsel=None):
     """PointNetVlad.forward (PointNetVlad.py:261-270). x [B,1,N,3] fp32 -> [B,output_dim]."""
     if featnet == "lpdnet":
-        f = lpdnet_features(sd, x, train=train, t3d=xyz_trans, tfea=feature_transform, k=k, new_stats=new_stats, aux=aux)
+        f = lpdnet_features(sd, x, train=train, t3d=xyz_trans, tfea=feature_transform, k=k, new_stats=new_stats, aux=aux,
+                            argsel=argsel)
     elif featnet == "lpdnetorigin":
-        f = lpdnet_origin_features(sd, x, train=train, t3d=xyz_trans, tfea=feature_transform, k=k, new_stats=new_stats, aux=aux)
+        f = lpdnet_origin_features(sd, x, train=train, t3d=xyz_trans, tfea=feature_transform, k=k, new_stats=new_stats, aux=aux,
+                                   argsel=argsel)
     elif featnet == "pointnet":
         f = pointnet_features(sd, x, train=train, feature_transform=feature_transform, new_stats=new_stats)
     else:

@@ -68,6 +68,37 @@ def test_eval_descriptors_vs_reference_golden(cuda, golden_dir, tag, featnet, kw
         assert agree >= 0.995, f"feature-space kNN rows equal to the reference: {agree:.4f}"    # measured 0.999
 
 
+@pytest.mark.parametrize("tag", ["eval_lpdnet_k64_b2_n2048", "eval_lpdnet_k64_b1_n16384"])
+def test_eval_k64_vs_reference_golden(cuda, golden_dir, tag):
+    """BASELINE configs[4] (stress: N = 16384, k = 64) as a parity case: the full LPD-Net forward with 64 neighbours per point
+    against the REFERENCE run with emb_nn.k = 64 (tests/golden/make_golden_r2.py) -- descriptors 1e-4, the xyz-space graph
+    bit-exact on tie-free rows, the feature-space graph >= 99 % of rows (it inherits upstream conv rounding)."""
+    from lpdnet_hip import engine
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    B, N, k, st = int(g["B"]), int(g["N"]), int(g["k"]), int(g["row_stride"])
+    m, _ = _model("lpdnet", N, cuda)
+    m.emb_nn.k = k
+    x = torch.from_numpy(synth.cloud(int(g["seed"]), B, N)).unsqueeze(1).to(cuda)
+    engine.DEBUG_AUX = {}
+    engine.MORTON_ORDER = False
+    try:
+        with torch.no_grad():
+            desc = m(x)
+        aux = engine.DEBUG_AUX
+    finally:
+        engine.DEBUG_AUX = None
+        engine.MORTON_ORDER = True
+    assert _norm_rel(desc, torch.from_numpy(g["desc"])) < DESC_TOL
+    idx_x = aux["idx_xyz"].cpu().numpy()[:, ::st]
+    assert idx_x.shape[-1] == k
+    ok = (idx_x == g["idx_xyz"].astype(np.int32)).all(-1)
+    assert (~ok & ~g["tie_xyz"]).sum() == 0
+    agree = (aux["idx_feat"].cpu().numpy()[:, ::st] == g["idx_feat"].astype(np.int32)).all(-1).mean()
+    assert agree >= 0.99, agree
+    with torch.no_grad():      # and with the points Z-ordered internally (the product setting)
+        assert _norm_rel(m(x), torch.from_numpy(g["desc"])) < DESC_TOL
+
+
 @pytest.mark.parametrize("featnet,kw,B,N", [("lpdnet", {}, 3, 512), ("lpdnet", dict(xyz_trans=True), 2, 256),
                                             ("lpdnetorigin", dict(feature_transform=True), 2, 256),
                                             ("pointnet", {}, 5, 256)])

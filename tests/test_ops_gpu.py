@@ -28,7 +28,8 @@ def _rel(a, b):
 
 # ------------------------------------------------------------------ kNN
 @pytest.mark.parametrize("C,N,k,B", [(3, 4096, 20, 2), (64, 4096, 20, 2), (3, 100, 7, 3), (5, 333, 20, 2),
-                                      (64, 1000, 20, 1), (3, 16384, 64, 1), (130, 512, 32, 1), (3, 64, 64, 1)])
+                                      (64, 1000, 20, 1), (3, 16384, 64, 1), (130, 512, 32, 1), (3, 64, 64, 1),
+                                      (64, 2048, 64, 1), (64, 16384, 64, 1), (3, 5000, 33, 2)])
 @pytest.mark.parametrize("impl", [0, 1, 2, 3, 6])
 def test_knn_bit_exact_vs_oracle(cuda, C, N, k, B, impl):
     """impl 0: streaming kernel (MFMA tiles + queued selection); 1: VALU fmaf cross-check; 2: first-generation MFMA kernel;
@@ -50,7 +51,7 @@ def test_knn_bit_exact_vs_oracle(cuda, C, N, k, B, impl):
     assert bad.sum() == 0, f"{bad.sum()} tie-free rows differ (of {bad.size}); first: {np.argwhere(bad)[:3].tolist()}"
     # tie rows must still hold the right SET of pd values: compare as sets where no boundary tie exists
     assert rows_equal.mean() > 0.99
-    if impl in (0, 6) and C <= 64 and k <= 32:     # point-major entry (no transposes): the same bits, also from a column slice
+    if impl in (0, 6) and C <= 64 and k <= 64:     # point-major entry (no transposes): the same bits, also from a column slice
         buf = torch.zeros((B * N, C + 5), device=cuda) if C <= 4 else torch.zeros((B * N, 72), device=cuda)
         off = 0 if C > 4 else 2
         buf[:, off:off + C] = torch.from_numpy(x_pm.reshape(B * N, C)).to(cuda)
@@ -348,7 +349,7 @@ def test_kagg_persistent_workgroups(cuda, N, layout):
 
 
 @pytest.mark.parametrize("CM,CO,N,k,B,useQ", [(128, 128, 256, 20, 2, True), (64, 64, 200, 20, 2, True), (64, 64, 128, 20, 1, False),
-                                               (128, 128, 100, 7, 1, True)])
+                                               (128, 128, 100, 7, 1, True), (128, 128, 192, 64, 1, True), (64, 64, 130, 64, 2, False)])
 @pytest.mark.parametrize("exact", [True, False], ids=["f32mfma", "bf16x3"])
 def test_edge_mlp(cuda, CM, CO, N, k, B, useQ, exact):
     ops = _ops()

@@ -64,17 +64,61 @@ def test_oracle_eval_forward_vs_reference(golden_dir, tag, featnet, kw):
         assert (aux["idx_feat"].numpy() == g["idx_feat"].astype(np.int64)).all(-1).mean() > 0.99
 
 
-@pytest.mark.parametrize("tag,featnet", [("train_lpdnet_bq1_p2_n2_n1024", "lpdnet"), ("train_pointnet_bq1_p2_n2_n4096", "pointnet")])
-def test_oracle_train_step0_vs_reference(golden_dir, tag, featnet):
+def test_oracle_eval_k64_vs_reference(golden_dir):
+    """The reference run with emb_nn.k = 64 (tests/golden/make_golden_r2.py): the stress configuration's neighbourhood size."""
+    g = _load(golden_dir, "eval_lpdnet_k64_b2_n2048")
+    B, N, k, st = int(g["B"]), int(g["N"]), int(g["k"]), int(g["row_stride"])
+    sd = orc.synthetic_state("lpdnet", num_points=N)
+    x = torch.from_numpy(synth.cloud(int(g["seed"]), B, N)).unsqueeze(1)
+    aux = {}
+    with torch.no_grad():
+        desc = orc.pointnetvlad_forward(sd, x, featnet="lpdnet", train=False, k=k, aux=aux)
+    ref = torch.from_numpy(g["desc"])
+    assert ((desc - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)).max().item() < 1e-5
+    ok = (aux["idx_xyz"].numpy()[:, ::st] == g["idx_xyz"].astype(np.int64)).all(-1)
+    assert (~ok & ~g["tie_xyz"]).sum() == 0
+    assert (aux["idx_feat"].numpy()[:, ::st] == g["idx_feat"].astype(np.int64)).all(-1).mean() > 0.99
+
+
+def test_oracle_max_over_k_override_is_the_max_on_its_own_choices():
+    """argsel (oracle._max_k) fed with the oracle's own arg-max reproduces the plain forward bit for bit."""
+    N, B = 128, 2
+    sd = orc.synthetic_state("lpdnet", num_points=N)
+    x = torch.from_numpy(synth.cloud(3, B, N)).unsqueeze(1)
+    with torch.no_grad():
+        aux = {}
+        f = orc.lpdnet_features(sd, x, aux=aux)
+        calls = {}
+        orig = orc._max_k
+
+        def rec(e, name, argsel):
+            calls[name] = e.argmax(dim=-1)
+            return orig(e, name, argsel)
+        orc._max_k = rec
+        try:
+            orc.lpdnet_features(sd, x)
+        finally:
+            orc._max_k = orig
+        f2 = orc.lpdnet_features(sd, x, argsel=calls)
+    assert set(calls) == {"x1", "x2", "x3"} and torch.equal(f, f2)
+
+
+TRAIN_CASES = [("train_lpdnet_bq1_p2_n2_n1024", "lpdnet", {}), ("train_pointnet_bq1_p2_n2_n4096", "pointnet", {}),
+               ("train_lpdnetorigin_bq1_p2_n2_n1024", "lpdnetorigin", {}),
+               ("train_lpdnet_t3d_bq1_p2_n2_n1024", "lpdnet", dict(xyz_trans=True))]
+
+
+@pytest.mark.parametrize("tag,featnet,kw", TRAIN_CASES)
+def test_oracle_train_step0_vs_reference(golden_dir, tag, featnet, kw):
     g = _load(golden_dir, tag)
     bq, P, Ng, N = [int(v) for v in g["dims"]]
     B = bq * (1 + P + Ng + 1)
-    sd0 = orc.synthetic_state(featnet, num_points=N)
+    sd0 = orc.synthetic_state(featnet, num_points=N, **kw)
     sd = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var")) else v.clone())
           for k, v in sd0.items()}
     x = torch.from_numpy(synth.cloud(int(g["seed"]), B, N)).unsqueeze(1)
     new_stats = {}
-    desc = orc.pointnetvlad_forward(sd, x, featnet=featnet, train=True, new_stats=new_stats)
+    desc = orc.pointnetvlad_forward(sd, x, featnet=featnet, train=True, new_stats=new_stats, **kw)
     q, p, n, o = torch.split(desc.view(bq, -1, 256), [1, P, Ng, 1], dim=1)
     loss = orc.quadruplet_loss(q, p, n, o, 0.5, 0.2, use_min=True, lazy=True, ignore_zero_loss=False)
     loss.backward()
@@ -87,12 +131,12 @@ def test_oracle_train_step0_vs_reference(golden_dir, tag, featnet):
             name = key[5:]
             got, want = sd[name].grad.numpy(), g[key]
             err = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
-            assert err < 5e-3, (name, err)
+            assert err < (1e-2 if kw else 5e-3), (name, err)      # the T-Net case: 7e-3 between the two fp32 evaluations
             checked += 1
         elif key.startswith("gsum/"):
             name = key[5:]
             l2 = sd[name].grad.double().pow(2).sum().sqrt().item()
-            assert abs(l2 - g[key][2]) < 5e-3 * max(g[key][2], 1e-6), (name, l2, g[key][2])
+            assert abs(l2 - g[key][2]) < (1e-2 if kw else 5e-3) * max(g[key][2], 1e-6), (name, l2, g[key][2])
             checked += 1
         elif key.startswith("buf/"):
             name = key[4:]
