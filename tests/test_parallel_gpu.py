@@ -55,7 +55,7 @@ def test_grad_allreduce_on_pointnetvlad_over_rccl_world1(cuda):
         assert ddp.stats["bucket_elems"] == 17605184 - 65536 * 256
     finally:
         dist.destroy_process_group()
-    assert abs(l0.item() - l1.item()) < 1e-5 * abs(l0.item())
+    assert abs(l0.item() - l1.item()) < 1e-4 * abs(l0.item())     # run-to-run: fp64-atomic summation order
     for (n, a), (_, b) in zip(plain.named_parameters(), wrapped.named_parameters()):
         err = (a.grad - b.grad).norm().item() / max(a.grad.norm().item(), 1e-20)
         # not bitwise: BatchNorm sums use fp64 atomics whose order varies run to run; behind the max over k a last-bit
