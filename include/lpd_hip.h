@@ -325,6 +325,64 @@ int lpd_softmax_bwd(const float* A, const float* dA, const float* dasum, float* 
 int lpd_vlad_finalize_bwd(const float* dOut, const float* v, const float* inv_c, const float* inv_g, const float* asum,
                           const float* cw2, float* dVraw, float* dasum, float* dcw2, int B, int F, int KC, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training path, second generation (csrc/lpd_train2.hip).
+ * ------------------------------------------------------------------------------------------------ */
+
+/*
+ * SPLIT-FORM edge stage in train mode: x3 = max_k act(BN_train(convSN1(cat(f_j, f_i)))) (util/lpdnet_model.py:256-258)
+ * without the [M*k][C] edge tensor U[(i,t)] = P[nbr(i,t)] + Q[i].  One gather pass:
+ *   S[i] = sum_t P[nbr(i,t)];  usel[i] = sel_t P[nbr(i,t)] + Q[i] (sel = max where gamma[c] >= 0, min where < 0 -- the sign of
+ *   the BatchNorm scale), arg[i] = the selected slot;  sum / sumsq [C] doubles = the batch statistics of U in closed form
+ *   (sum U = sum_i (S_i + k Q_i), sum U^2 = sum_i (sum_t P_nbr^2 + 2 Q_i S_i + k Q_i^2)) for lpd_bn_finalize with count M*k.
+ * x3 = act(scale * usel + shift) is then lpd_affine_act on [M][C].  S, usel [M][C] contiguous; C in {64,128,256}; k <= 255.
+ */
+int lpd_edge_split_fwd(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, const float* gamma,
+                       float* S, float* usel, uint8_t* arg, long long M, int N, int C, int k, double* sum, double* sumsq,
+                       void* stream);
+
+/*
+ * Backward of the split-form stage: dOut [M][ldo] = gradient of x3.  G [M][C] (scratch, receives dpre = dOut * act'),
+ * dbeta / dgamma [C] doubles (the BatchNorm parameter gradients), dP [M][lddp] and dQ [M][lddq]:
+ *   dQ_i = s (dpre_i - k m1 - m2 invstd (S_i + k (Q_i - mu)))
+ *   dP_j = s (A_j - deg_j m1 - m2 invstd (deg_j (P_j - mu) + R_j)),  A_j / R_j summed over the incoming edges of j in the
+ *   transposed graph (rowptr, edges from lpd_graph_transpose), m1 = dbeta / (M k), m2 = dgamma / (M k).  No float atomics.
+ */
+int lpd_edge_split_bwd(const float* dOut, long long ldo, const float* usel, const uint8_t* arg, const float* S, const float* P,
+                       long long ldp, const float* Q, long long ldq, const int32_t* rowptr, const int32_t* edges, float* G,
+                       float* dP, long long lddp, float* dQ, long long lddq, long long M, int C, int k, const float* scale,
+                       const float* shift, const float* mean, const float* invstd, int act, float slope, double* dbeta,
+                       double* dgamma, void* stream);
+
+/*
+ * bf16 STORAGE of the per-edge tensors that must exist (BASELINE.json configs[2]: the DG1 -> DG2 chain, where convDG2
+ * consumes every post-activation edge, lpdnet_model.py:249-252).  bf16 tensors are uint16_t* ([rows][C] contiguous);
+ * statistics, reductions and accumulations stay fp32 / fp64.
+ */
+/* lpd_edge_build with a bf16 result; the statistics are those of the stored (rounded) values */
+int lpd_edge_build_bf16(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, uint16_t* U, long long M,
+                        int N, int C, int k, double* sum, double* sumsq, void* stream);
+/* one pass over U: Y = act(scale U + shift) (bf16, the dense consumer's input) and out[i] = act(scale sel_t U + shift), arg[i] */
+int lpd_edge_act_max_bf16(const uint16_t* U, int k, const float* scale, const float* shift, int act, float slope, uint16_t* Y,
+                          float* out, long long ldo, uint8_t* arg, long long M, int C, void* stream);
+/* one pass over the raw conv output Z: batch statistics (sum, sumsq) and the raw selected value sel[i] = sel_t Z[(i,t)] with its
+ * slot (max where gamma >= 0, else min); BatchNorm + activation of sel is an [M][C] lpd_affine_act afterwards */
+int lpd_group_sel_stats_bf16(const uint16_t* Z, int k, const float* gamma, float* sel, long long lds, uint8_t* arg, long long M, int C,
+                             double* sum, double* sumsq, void* stream);
+/* lpd_edge_bn_bwd on bf16 tensors (dDense optional; dX may alias dDense) */
+int lpd_edge_bn_bwd_bf16(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* dDense, const uint16_t* X, uint16_t* dX,
+                         float* dQ, long long ldq, int k, long long M, int C, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, int act, float slope, double* dbeta, double* dgamma, void* stream);
+/* lpd_gather_sum_rows with a bf16 edge-gradient tensor (fp32 sums) */
+int lpd_gather_sum_rows_bf16(const uint16_t* dU, const int32_t* rowptr, const int32_t* edges, float* dP, long long ldp, long long M,
+                             int C, int accumulate, void* stream);
+/* C [M][N] (bf16) = A [M][K] (bf16) x W, W fp32 [N][ldw] (b_kmajor = 0, torch conv weight) or [K][ldw] (1): the weight is split
+ * hi + lo (two products on v_mfma_f32_32x32x16_bf16, fp32 accumulation).  (N, K) in {(128,128), (64,64)}. */
+int lpd_gemm_bf16s(const uint16_t* A, const float* W, int ldw, int b_kmajor, uint16_t* C, long long M, int N, int K, void* stream);
+/* dW [KA][KB] (fp32) = sum_m A[m][:]^T B[m][:], A [M][KA], B [M][KB] bf16; ws: lpd_gemm_tn_bf16_ws_floats(M, KA, KB) floats */
+long long lpd_gemm_tn_bf16_ws_floats(long long M, int KA, int KB);
+int lpd_gemm_tn_bf16(const uint16_t* A, const uint16_t* B, float* dW, float* ws, long long M, int KA, int KB, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

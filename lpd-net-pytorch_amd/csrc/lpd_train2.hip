@@ -1,0 +1,843 @@
+// lpd_train2.hip -- training path, second generation:
+//
+//  (1) SPLIT-FORM edge stage for x3 = max_k act(BN_train(convSN1(cat(f_j, f_i))))  (util/lpdnet_model.py:256-258) that never
+//      materialises the [B*N*k, 256] edge tensor U[(i,t)] = P[nbr(i,t)] + Q[i]:
+//        * forward: ONE gather pass gives, per point, S_i = sum_t P_nbr, the selected raw value  usel_i = sel_t P_nbr + Q_i
+//          (sel = max where gamma >= 0, min where gamma < 0: the sign of the BatchNorm scale is the sign of gamma, known
+//          before the statistics), its slot arg_i, and the batch statistics of U in closed form
+//              sum U   = sum_i (S_i + k Q_i),     sum U^2 = sum_i (sum_t P_nbr^2 + 2 Q_i S_i + k Q_i^2)        (fp64);
+//          x3 = act(scale * usel + shift) is then an [M, C] elementwise pass.
+//        * backward: with dpre_i = dx3_i * act'(pre_i) living on the arg-max edge only and the BatchNorm means
+//          m1 = mean(dpre), m2 = mean(dpre * xhat) over all E = M k edges,
+//              dU[(i,t)] = s (delta_{t,arg} dpre_i - m1 - xhat[(i,t)] m2),   xhat = (P_nbr + Q_i - mu) invstd
+//          sums in closed form to
+//              dQ_i = s (dpre_i - k m1 - m2 invstd (S_i + k Q_i - k mu))
+//              dP_j = s (A_j - deg_j m1 - m2 invstd (deg_j (P_j - mu) + R_j)),
+//              A_j = sum over incoming edges (i,t) with arg_i = t of dpre_i,   R_j = sum over incoming edges of Q_i,
+//          one pass over the transposed graph (no float atomics).
+//      Replaces edge_build + group_max + edge_bn_bwd + gather_sum_rows on 3.7 GB tensors (B = 44) by [M, C] passes and two
+//      gathers.
+//
+//  (2) bf16 STORAGE of the DG1 -> DG2 chain's edge tensors (BASELINE.json configs[2] "bf16"): the per-edge tensors that
+//      must exist (convDG2 consumes every post-activation edge, lpdnet_model.py:249-252) are kept as bf16, every statistic /
+//      reduction / accumulation stays fp32-fp64: the two dense products on them run on v_mfma_f32_32x32x16_bf16
+//      (lpd_gemm_bf16s: activations bf16 x weights split hi+lo; lpd_gemm_tn_bf16: dW = dZ^T Y).
+#include "lpd_common.h"
+#include <math.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float act_grad2(float pre, int act, float slope)
+{
+    return pre > 0.0f ? 1.0f : lpd_neg_slope(act, slope);
+}
+
+__device__ __forceinline__ float bf2f(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+__device__ __forceinline__ float4 ld4_bf16(const uint16_t* p)
+{
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf2f(u.x & 0xffffu), bf2f(u.x >> 16), bf2f(u.y & 0xffffu), bf2f(u.y >> 16));
+}
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b)   // RNE (v_cvt_pk_bf16_f32)
+{
+    const bf16x2v h = __builtin_convertvector((f32x2v){a, b}, bf16x2v);
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ void st4_bf16(uint16_t* p, float4 v)
+{
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+}
+__device__ __forceinline__ float rbf(float x) { return bf2f(pack_bf16(x, 0.0f) & 0xffffu); }   // value after bf16 storage
+
+// block reduction of per-thread fp64 partials [8] that belong to column quad (threadIdx.x % LQ) -> fp64 atomics
+template <int NT>
+__device__ __forceinline__ void reduce_quads(double (&red)[NT][8], const double (&a)[4], const double (&b)[4], int LQ,
+                                             double* __restrict__ o0, double* __restrict__ o1)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = a[e]; red[threadIdx.x][4 + e] = b[e]; }
+    __syncthreads();
+    if ((int)threadIdx.x < LQ) {
+        for (int g = 1; g < NT / LQ; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[g * LQ + threadIdx.x][e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&o0[threadIdx.x * 4 + e], red[threadIdx.x][e]);
+            atomicAdd(&o1[threadIdx.x * 4 + e], red[threadIdx.x][4 + e]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (1) split-form edge stage
+// ---------------------------------------------------------------------------------------------
+template <int LPP>
+__global__ __launch_bounds__(256) void edge_split_fwd_kernel(const float* __restrict__ P, long long ldp, const float* __restrict__ Q,
+                                                             long long ldq, const int32_t* __restrict__ idx,
+                                                             const float* __restrict__ gamma, float* __restrict__ S,
+                                                             float* __restrict__ usel, uint8_t* __restrict__ arg, long long M,
+                                                             int N, int k, double* __restrict__ sum, double* __restrict__ sumsq)
+{
+    constexpr int PPW = 64 / LPP;
+    constexpr int C = LPP * 4;
+    __shared__ double red[256][8];
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPP, cl = lane % LPP;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + cl * 4);
+    const bool up[4] = {gm.x >= 0.f, gm.y >= 0.f, gm.z >= 0.f, gm.w >= 0.f};
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    const float kf = (float)k;
+    for (long long w = wave; w * PPW < M; w += nw) {
+        const long long m = w * PPW + sub;
+        const bool ok = m < M;
+        const long long mm = ok ? m : M - 1;
+        const long long base = (mm / N) * N;
+        const float4 q4 = *reinterpret_cast<const float4*>(Q + mm * ldq + cl * 4);
+        float sp[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+        float best[4];
+        int ab[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) best[c] = up[c] ? -INFINITY : INFINITY;
+        for (int t0 = 0; t0 < k; t0 += LPP) {
+            const int my_idx = (t0 + cl < k) ? idx[mm * k + t0 + cl] : 0;
+            const int tn = min(k - t0, LPP);
+#pragma unroll 5
+            for (int t = 0; t < tn; ++t) {
+                const int j = __shfl(my_idx, sub * LPP + t, 64);
+                const float4 p4 = *reinterpret_cast<const float4*>(P + (base + j) * ldp + cl * 4);
+                const float p[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    sp[c] += p[c];
+                    sq[c] = fmaf(p[c], p[c], sq[c]);
+                    const bool take = up[c] ? (p[c] > best[c]) : (p[c] < best[c]);   // first extremum, like torch.max
+                    best[c] = take ? p[c] : best[c];
+                    ab[c] = take ? t0 + t : ab[c];
+                }
+            }
+        }
+        if (ok) {
+            const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            *reinterpret_cast<float4*>(S + mm * C + cl * 4) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            *reinterpret_cast<float4*>(usel + mm * C + cl * 4) = make_float4(best[0] + q[0], best[1] + q[1], best[2] + q[2], best[3] + q[3]);
+            *reinterpret_cast<uchar4*>(arg + mm * C + cl * 4) = make_uchar4((uint8_t)ab[0], (uint8_t)ab[1], (uint8_t)ab[2], (uint8_t)ab[3]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s[c] += (double)sp[c] + (double)kf * q[c];
+                ss[c] += (double)sq[c] + 2.0 * (double)q[c] * sp[c] + (double)kf * q[c] * q[c];
+            }
+        }
+    }
+    reduce_quads<256>(red, s, ss, LPP, sum, sumsq);
+}
+
+// G = dOut * act'(scale * usel + shift);  dbeta = sum G,  dgamma = sum G * (usel - mean) * invstd    (fp64)
+__global__ __launch_bounds__(256) void edge_split_bwd_reduce_kernel(const float* __restrict__ dOut, long long ldo,
+                                                                    const float* __restrict__ usel, float* __restrict__ G,
+                                                                    long long M, int C, const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd, int act, float slope,
+                                                                    double* __restrict__ dbeta, double* __restrict__ dgamma)
+{
+    __shared__ double red[256][8];
+    const int LQ = C >> 2;
+    const int RG = 256 / LQ;
+    const int q = threadIdx.x % LQ, rg = threadIdx.x / LQ;
+    float sc[4], sh[4], mu[4], is[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { sc[c] = scale[q * 4 + c]; sh[c] = shift[q * 4 + c]; mu[c] = mean[q * 4 + c]; is[c] = invstd[q * 4 + c]; }
+    double sb[4] = {0, 0, 0, 0}, sg[4] = {0, 0, 0, 0};
+    for (long long i = (long long)blockIdx.x * RG + rg; i < M; i += (long long)gridDim.x * RG) {
+        const float4 g4 = *reinterpret_cast<const float4*>(dOut + i * ldo + q * 4);
+        const float4 u4 = *reinterpret_cast<const float4*>(usel + i * C + q * 4);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        const float u[4] = {u4.x, u4.y, u4.z, u4.w};
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            o[c] = g[c] * act_grad2(sc[c] * u[c] + sh[c], act, slope);
+            sb[c] += o[c];
+            sg[c] += (double)o[c] * ((u[c] - mu[c]) * is[c]);
+        }
+        *reinterpret_cast<float4*>(G + i * C + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    reduce_quads<256>(red, sb, sg, LQ, dbeta, dgamma);
+}
+
+// one (part of a) wave per point j: dQ_j (own row) and dP_j (over the incoming edges of the transposed graph)
+template <int LPR>
+__global__ __launch_bounds__(256) void edge_split_bwd_apply_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ edges,
+                                                                   const float* __restrict__ G, const uint8_t* __restrict__ arg,
+                                                                   const float* __restrict__ S, const float* __restrict__ P,
+                                                                   long long ldp, const float* __restrict__ Q, long long ldq,
+                                                                   float* __restrict__ dP, long long lddp, float* __restrict__ dQ,
+                                                                   long long lddq, long long M, int k,
+                                                                   const float* __restrict__ scale, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, const double* __restrict__ dbeta,
+                                                                   const double* __restrict__ dgamma)
+{
+    constexpr int RPW = 64 / LPR;
+    constexpr int C = LPR * 4;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, cl = lane % LPR;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+    const double E = (double)M * (double)k;
+    float sc[4], mu[4], is[4], m1[4], m2i[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = cl * 4 + c;
+        sc[c] = scale[ch]; mu[c] = mean[ch]; is[c] = invstd[ch];
+        m1[c] = (float)(dbeta[ch] / E);
+        m2i[c] = (float)(dgamma[ch] / E) * is[c];
+    }
+    const float kf = (float)k;
+    const unsigned ku = (unsigned)k;
+    for (long long r0 = wave * RPW; r0 < M; r0 += nw * RPW) {
+        const long long j = r0 + sub;
+        if (j >= M) continue;
+        const int beg = rowptr[j], end = rowptr[j + 1];
+        float A[4] = {0, 0, 0, 0}, R[4] = {0, 0, 0, 0};
+        for (int p = beg; p < end; ++p) {
+            const unsigned e = (unsigned)edges[p];
+            const unsigned i = e / ku, t = e - i * ku;
+            const float4 q4 = *reinterpret_cast<const float4*>(Q + (long long)i * ldq + cl * 4);
+            const float4 g4 = *reinterpret_cast<const float4*>(G + (long long)i * C + cl * 4);
+            const uchar4 a4 = *reinterpret_cast<const uchar4*>(arg + (long long)i * C + cl * 4);
+            R[0] += q4.x; R[1] += q4.y; R[2] += q4.z; R[3] += q4.w;
+            A[0] += a4.x == t ? g4.x : 0.f; A[1] += a4.y == t ? g4.y : 0.f;
+            A[2] += a4.z == t ? g4.z : 0.f; A[3] += a4.w == t ? g4.w : 0.f;
+        }
+        const float deg = (float)(end - beg);
+        const float4 p4 = *reinterpret_cast<const float4*>(P + j * ldp + cl * 4);
+        const float4 q4 = *reinterpret_cast<const float4*>(Q + j * ldq + cl * 4);
+        const float4 g4 = *reinterpret_cast<const float4*>(G + j * C + cl * 4);
+        const float4 s4 = *reinterpret_cast<const float4*>(S + j * C + cl * 4);
+        const float pj[4] = {p4.x, p4.y, p4.z, p4.w}, qj[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float gj[4] = {g4.x, g4.y, g4.z, g4.w}, sj[4] = {s4.x, s4.y, s4.z, s4.w};
+        float op[4], oq[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            op[c] = sc[c] * (A[c] - deg * m1[c] - m2i[c] * (deg * (pj[c] - mu[c]) + R[c]));
+            oq[c] = sc[c] * (gj[c] - kf * m1[c] - m2i[c] * (sj[c] + kf * (qj[c] - mu[c])));
+        }
+        *reinterpret_cast<float4*>(dP + j * lddp + cl * 4) = make_float4(op[0], op[1], op[2], op[3]);
+        *reinterpret_cast<float4*>(dQ + j * lddq + cl * 4) = make_float4(oq[0], oq[1], oq[2], oq[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (2) bf16-storage edge kernels (rows (i,t) = i*k + t, [E][C] bf16, C in {64, 128, 256})
+// ---------------------------------------------------------------------------------------------
+// U = P[nbr] + Q as bf16, BatchNorm statistics of the STORED (rounded) values accumulated on the way (fp64)
+template <int LPP>
+__global__ __launch_bounds__(256) void edge_build_bf16_kernel(const float* __restrict__ P, long long ldp, const float* __restrict__ Q,
+                                                              long long ldq, const int32_t* __restrict__ idx, uint16_t* __restrict__ U,
+                                                              long long M, int N, int k, double* __restrict__ sum,
+                                                              double* __restrict__ sumsq)
+{
+    constexpr int PPW = 64 / LPP;
+    constexpr int C = LPP * 4;
+    __shared__ double red[256][8];
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPP, cl = lane % LPP;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (long long w = wave; w * PPW < M; w += nw) {
+        const long long m = w * PPW + sub;
+        const bool ok = m < M;
+        const long long mm = ok ? m : M - 1;
+        const long long base = (mm / N) * N;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (Q) q = *reinterpret_cast<const float4*>(Q + mm * ldq + cl * 4);
+        for (int t0 = 0; t0 < k; t0 += LPP) {
+            const int my_idx = (t0 + cl < k) ? idx[mm * k + t0 + cl] : 0;
+            const int tn = min(k - t0, LPP);
+#pragma unroll 5
+            for (int t = 0; t < tn; ++t) {
+                const int j = __shfl(my_idx, sub * LPP + t, 64);
+                float4 p = *reinterpret_cast<const float4*>(P + (base + j) * ldp + cl * 4);
+                p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w;
+                if (ok) {
+                    const uint2 pk = make_uint2(pack_bf16(p.x, p.y), pack_bf16(p.z, p.w));
+                    *reinterpret_cast<uint2*>(U + (mm * k + t0 + t) * C + cl * 4) = pk;
+                    if (sum) {
+                        const float r[4] = {bf2f(pk.x & 0xffffu), bf2f(pk.x >> 16), bf2f(pk.y & 0xffffu), bf2f(pk.y >> 16)};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { s[c] += r[c]; ss[c] += (double)r[c] * r[c]; }
+                    }
+                }
+            }
+        }
+    }
+    if (sum) reduce_quads<256>(red, s, ss, LPP, sum, sumsq);
+}
+
+// One pass over U (bf16): Y = act(scale * U + shift) as bf16 (the dense consumer's input) AND
+// out[i] = act(scale * sel_t U + shift), arg[i] (the max over k of the same values).
+__global__ __launch_bounds__(256) void edge_act_max_bf16_kernel(const uint16_t* __restrict__ U, int k, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int act, float slope,
+                                                                uint16_t* __restrict__ Y, float* __restrict__ out, long long ldo,
+                                                                uint8_t* __restrict__ arg, long long M, int C)
+{
+    const int LQ = C >> 2;
+    const int RG = 256 / LQ;
+    const int q = threadIdx.x % LQ, rg = threadIdx.x / LQ;
+    const float ns = lpd_neg_slope(act, slope);
+    float sc[4], sh[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { sc[c] = scale[q * 4 + c]; sh[c] = shift[q * 4 + c]; }
+    for (long long i = (long long)blockIdx.x * RG + rg; i < M; i += (long long)gridDim.x * RG) {
+        float mx[4], mn[4];
+        int amx[4] = {0, 0, 0, 0}, amn[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { mx[c] = -INFINITY; mn[c] = INFINITY; }
+        for (int t = 0; t < k; ++t) {
+            const long long off = (i * k + t) * C + q * 4;
+            const float4 v4 = ld4_bf16(U + off);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            float y[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (v[c] > mx[c]) { mx[c] = v[c]; amx[c] = t; }
+                if (v[c] < mn[c]) { mn[c] = v[c]; amn[c] = t; }
+                y[c] = lpd_act_pl(sc[c] * v[c] + sh[c], ns);
+            }
+            st4_bf16(Y + off, make_float4(y[0], y[1], y[2], y[3]));
+        }
+        float o[4];
+        uint8_t a[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool usemax = sc[c] >= 0.0f;
+            o[c] = lpd_act_pl(sc[c] * (usemax ? mx[c] : mn[c]) + sh[c], ns);
+            a[c] = (uint8_t)(usemax ? amx[c] : amn[c]);
+        }
+        *reinterpret_cast<float4*>(out + i * ldo + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uchar4*>(arg + i * C + q * 4) = make_uchar4(a[0], a[1], a[2], a[3]);
+    }
+}
+
+// One pass over Z (bf16, raw conv output): batch statistics of Z (fp64) and the raw selected value per point
+// sel[i] = sel_t Z[(i,t)] (max where gamma >= 0, min where gamma < 0) with its slot; the BatchNorm + activation of the
+// selected values is an [M, C] pass afterwards (the sign of the scale is the sign of gamma).
+__global__ __launch_bounds__(256) void group_sel_stats_bf16_kernel(const uint16_t* __restrict__ Z, int k, const float* __restrict__ gamma,
+                                                                   float* __restrict__ sel, long long lds, uint8_t* __restrict__ arg,
+                                                                   long long M, int C, double* __restrict__ sum,
+                                                                   double* __restrict__ sumsq)
+{
+    __shared__ double red[256][8];
+    const int LQ = C >> 2;
+    const int RG = 256 / LQ;
+    const int q = threadIdx.x % LQ, rg = threadIdx.x / LQ;
+    bool up[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) up[c] = gamma[q * 4 + c] >= 0.0f;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (long long i = (long long)blockIdx.x * RG + rg; i < M; i += (long long)gridDim.x * RG) {
+        float best[4], ps[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};
+        int ab[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) best[c] = up[c] ? -INFINITY : INFINITY;
+        for (int t = 0; t < k; ++t) {
+            const float4 v4 = ld4_bf16(Z + (i * k + t) * C + q * 4);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool take = up[c] ? (v[c] > best[c]) : (v[c] < best[c]);
+                best[c] = take ? v[c] : best[c];
+                ab[c] = take ? t : ab[c];
+                ps[c] += v[c];
+                pq[c] = fmaf(v[c], v[c], pq[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { s[c] += ps[c]; ss[c] += pq[c]; }
+        *reinterpret_cast<float4*>(sel + i * lds + q * 4) = make_float4(best[0], best[1], best[2], best[3]);
+        *reinterpret_cast<uchar4*>(arg + i * C + q * 4) = make_uchar4((uint8_t)ab[0], (uint8_t)ab[1], (uint8_t)ab[2], (uint8_t)ab[3]);
+    }
+    reduce_quads<256>(red, s, ss, LQ, sum, sumsq);
+}
+
+// fused backward of out[i] = max_t act(BN(X[(i,t)])) (+ optional dense gradient) on bf16 tensors (cf. lpd_edge_bn_bwd)
+__global__ __launch_bounds__(256) void edge_bn_bwd_reduce_bf16_kernel(const float* __restrict__ dOut, long long ldo,
+                                                                      const uint8_t* __restrict__ arg, const uint16_t* __restrict__ dDense,
+                                                                      const uint16_t* __restrict__ X, int k, long long M, int C,
+                                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                      int act, float slope, double* __restrict__ dbeta,
+                                                                      double* __restrict__ dgamma)
+{
+    __shared__ double red[256][8];
+    const int LQ = C >> 2;
+    const int RG = 256 / LQ;
+    const int q = threadIdx.x % LQ, rg = threadIdx.x / LQ;
+    float sc[4], sh[4], mu[4], is[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { sc[c] = scale[q * 4 + c]; sh[c] = shift[q * 4 + c]; mu[c] = mean[q * 4 + c]; is[c] = invstd[q * 4 + c]; }
+    double sb[4] = {0, 0, 0, 0}, sg[4] = {0, 0, 0, 0};
+    for (long long i = (long long)blockIdx.x * RG + rg; i < M; i += (long long)gridDim.x * RG) {
+        const float4 g4 = *reinterpret_cast<const float4*>(dOut + i * ldo + q * 4);
+        const uchar4 a4 = *reinterpret_cast<const uchar4*>(arg + i * C + q * 4);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        const int a[4] = {a4.x, a4.y, a4.z, a4.w};
+        if (dDense) {
+            for (int t = 0; t < k; ++t) {
+                const float4 xv = ld4_bf16(X + (i * k + t) * C + q * 4);
+                const float4 dv = ld4_bf16(dDense + (i * k + t) * C + q * 4);
+                const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+                const float d[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float gy = d[c] + (a[c] == t ? g[c] : 0.0f);
+                    const float dpre = gy * act_grad2(sc[c] * x[c] + sh[c], act, slope);
+                    sb[c] += dpre;
+                    sg[c] += (double)dpre * ((x[c] - mu[c]) * is[c]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float x = bf2f(X[(i * k + a[c]) * C + q * 4 + c]);
+                const float dpre = g[c] * act_grad2(sc[c] * x + sh[c], act, slope);
+                sb[c] += dpre;
+                sg[c] += (double)dpre * ((x - mu[c]) * is[c]);
+            }
+        }
+    }
+    reduce_quads<256>(red, sb, sg, LQ, dbeta, dgamma);
+}
+
+__global__ __launch_bounds__(256) void edge_bn_bwd_apply_bf16_kernel(const float* __restrict__ dOut, long long ldo,
+                                                                     const uint8_t* __restrict__ arg, const uint16_t* __restrict__ dDense,
+                                                                     const uint16_t* __restrict__ X, uint16_t* __restrict__ dX,
+                                                                     float* __restrict__ dQ, long long ldq, int k, long long M, int C,
+                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                     const double* __restrict__ dbeta, const double* __restrict__ dgamma,
+                                                                     double count, int act, float slope)
+{
+    const int LQ = C >> 2;
+    const int RG = 256 / LQ;
+    const int q = threadIdx.x % LQ, rg = threadIdx.x / LQ;
+    float sc[4], sh[4], mu[4], is[4], mb[4], mg[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = q * 4 + c;
+        sc[c] = scale[ch]; sh[c] = shift[ch]; mu[c] = mean[ch]; is[c] = invstd[ch];
+        mb[c] = (float)(dbeta[ch] / count);
+        mg[c] = (float)(dgamma[ch] / count);
+    }
+    for (long long i = (long long)blockIdx.x * RG + rg; i < M; i += (long long)gridDim.x * RG) {
+        const float4 g4 = *reinterpret_cast<const float4*>(dOut + i * ldo + q * 4);
+        const uchar4 a4 = *reinterpret_cast<const uchar4*>(arg + i * C + q * 4);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        const int a[4] = {a4.x, a4.y, a4.z, a4.w};
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < k; ++t) {
+            const long long off = (i * k + t) * C + q * 4;
+            const float4 xv = ld4_bf16(X + off);
+            float d[4] = {0.f, 0.f, 0.f, 0.f};
+            if (dDense) {
+                const float4 dv = ld4_bf16(dDense + off);
+                d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
+            }
+            const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float gy = d[c] + (a[c] == t ? g[c] : 0.0f);
+                const float dpre = gy * act_grad2(sc[c] * x[c] + sh[c], act, slope);
+                o[c] = sc[c] * (dpre - mb[c] - (x[c] - mu[c]) * is[c] * mg[c]);
+                sum[c] += o[c];      // the centre-term gradient sums the fp32 values, not the rounded ones
+            }
+            st4_bf16(dX + off, make_float4(o[0], o[1], o[2], o[3]));
+        }
+        if (dQ) *reinterpret_cast<float4*>(dQ + i * ldq + q * 4) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void gather_sum_rows_bf16_kernel(const uint16_t* __restrict__ dU, const int32_t* __restrict__ rowptr,
+                                                                   const int32_t* __restrict__ edges, float* __restrict__ dP,
+                                                                   long long ldp, long long M, int accumulate)
+{
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, cl = lane % LPR;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long r0 = wave * RPW; r0 < M; r0 += nw * RPW) {
+        const long long j = r0 + sub;
+        if (j >= M) continue;
+        const int beg = rowptr[j], end = rowptr[j + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int p = beg;
+        for (; p + 3 < end; p += 4) {
+            const int e0 = edges[p], e1 = edges[p + 1], e2 = edges[p + 2], e3 = edges[p + 3];
+            const float4 a = ld4_bf16(dU + (long long)e0 * (LPR * 4) + cl * 4);
+            const float4 b = ld4_bf16(dU + (long long)e1 * (LPR * 4) + cl * 4);
+            const float4 c = ld4_bf16(dU + (long long)e2 * (LPR * 4) + cl * 4);
+            const float4 d = ld4_bf16(dU + (long long)e3 * (LPR * 4) + cl * 4);
+            acc.x += (a.x + b.x) + (c.x + d.x); acc.y += (a.y + b.y) + (c.y + d.y);
+            acc.z += (a.z + b.z) + (c.z + d.z); acc.w += (a.w + b.w) + (c.w + d.w);
+        }
+        for (; p < end; ++p) {
+            const float4 a = ld4_bf16(dU + (long long)edges[p] * (LPR * 4) + cl * 4);
+            acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+        }
+        float4* dst = reinterpret_cast<float4*>(dP + j * ldp + cl * 4);
+        if (accumulate) { const float4 o = *dst; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+        *dst = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 MFMA products on the stored edge tensors
+// ---------------------------------------------------------------------------------------------
+// C[m][n] (bf16) = sum_k A[m][k] (bf16) * W(n, k)  with W split hi + lo (two bf16 MFMA products, fp32 accumulation).
+// One wave owns 32 rows of A and all N <= 128 columns.  The MFMA computes the TRANSPOSED tile (rows = output channels,
+// columns = data rows): a lane then holds, for ONE data row, 4 consecutive output channels per accumulator quad and
+// stores them as 8 bytes; with its partner half-wave 16 contiguous bytes of the output row.  A row halves are loaded
+// straight into registers: lane (row, h) owns the contiguous K/2 * 2 bytes [h * K/2, (h+1) * K/2) of its row, i.e. the
+// contraction index is permuted (k = h * K/2 + 8 s + e), the same permutation is applied to the LDS images of W.
+template <int K, int N>
+__global__ __launch_bounds__(256) void gemm_bf16s_kernel(const uint16_t* __restrict__ A, const float* __restrict__ W, int ldw,
+                                                         int b_kmajor, uint16_t* __restrict__ Cout, long long M)
+{
+    constexpr int KS = K / 16;            // MFMA k-steps
+    constexpr int NT = N / 32;            // output-channel tiles
+    constexpr int LDW = K + 8;            // bf16 per LDS row (16-byte pad: conflict-free ds_read_b128)
+    extern __shared__ __attribute__((aligned(16))) __bf16 wimg[];   // hi image, then lo image: 2 * N * LDW bf16 (68 KiB at 128 x 128)
+    __bf16* whi = wimg;
+    __bf16* wlo = wimg + N * LDW;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < N * K; e += 256) {
+        const int n = e / K, kk = e % K;
+        const float w = b_kmajor ? W[(size_t)kk * ldw + n] : W[(size_t)n * ldw + kk];
+        const __bf16 hi = (__bf16)w;
+        const __bf16 lo = (__bf16)(w - (float)hi);
+        whi[n * LDW + kk] = hi;
+        wlo[n * LDW + kk] = lo;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const long long ntile = (M + 31) / 32;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
+        const long long row = tile * 32 + col;
+        const long long rr = row < M ? row : M - 1;
+        const uint16_t* ap = A + rr * K + h * (K / 2);
+        bf16x8 a[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const bf16x8*>(ap + s * 8);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int off = (j * 32 + col) * LDW + h * (K / 2) + s * 8;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(whi + off);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wlo + off);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, a[s], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, a[s], acc[j], 0, 0, 0);
+            }
+        }
+        if (row < M) {
+            uint16_t* cp = Cout + row * N;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {   // accumulator rows 8g + 4h + {0..3} = output channels j*32 + 8g + 4h + ...
+                    const uint2 pk = make_uint2(pack_bf16(acc[j][4 * g], acc[j][4 * g + 1]), pack_bf16(acc[j][4 * g + 2], acc[j][4 * g + 3]));
+                    *reinterpret_cast<uint2*>(cp + j * 32 + 8 * g + 4 * h) = pk;
+                }
+        }
+    }
+}
+
+// dW[a][b] = sum_m A[m][a] * B[m][b]  (A [M][KA], B [M][KB] bf16 row-major; KA, KB in {64, 128}); fp32 slabs per block,
+// summed by gemm_tn_reduce_kernel.  A block walks chunks of 64 rows: the chunk is written to LDS TRANSPOSED ([channel][row],
+// rows contiguous) so that the MFMA operands (8 consecutive m of one channel) are single ds_read_b128.
+template <int KA, int KB>
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                           float* __restrict__ slabs, long long M, long long rows_per_block)
+{
+    constexpr int CH = 64;                 // rows per chunk
+    constexpr int LDT = CH + 8;            // bf16 per transposed LDS row (pad)
+    constexpr int TA = KA / 32, TB = KB / 32;
+    constexpr int TILES = TA * TB;         // 32x32 output tiles; 4 waves share them
+    constexpr int TPW = (TILES + 3) / 4;   // tiles per wave
+    __shared__ __attribute__((aligned(16))) uint16_t at[KA * LDT];
+    __shared__ __attribute__((aligned(16))) uint16_t bt[KB * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const long long m_begin = (long long)blockIdx.x * rows_per_block;
+    const long long m_end = min(M, m_begin + rows_per_block);
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    for (long long m0 = m_begin; m0 < m_end; m0 += CH) {
+        __syncthreads();
+        // stage: thread loads 8 channels (16 B) of one row and scatters them into the transposed images
+        for (int e = tid; e < CH * (KA / 8); e += 256) {
+            const int r = e / (KA / 8), c8 = e % (KA / 8);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m0 + r < m_end) v = *reinterpret_cast<const uint4*>(A + (m0 + r) * KA + c8 * 8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                at[(c8 * 8 + 2 * i) * LDT + r] = (uint16_t)(w[i] & 0xffffu);
+                at[(c8 * 8 + 2 * i + 1) * LDT + r] = (uint16_t)(w[i] >> 16);
+            }
+        }
+        for (int e = tid; e < CH * (KB / 8); e += 256) {
+            const int r = e / (KB / 8), c8 = e % (KB / 8);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m0 + r < m_end) v = *reinterpret_cast<const uint4*>(B + (m0 + r) * KB + c8 * 8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bt[(c8 * 8 + 2 * i) * LDT + r] = (uint16_t)(w[i] & 0xffffu);
+                bt[(c8 * 8 + 2 * i + 1) * LDT + r] = (uint16_t)(w[i] >> 16);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            const int tile = wave * TPW + j;
+            if (tile < TILES) {
+                const int ta = tile / TB, tb = tile % TB;
+#pragma unroll
+                for (int s = 0; s < CH / 16; ++s) {
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(at + (ta * 32 + col) * LDT + s * 16 + h * 8);
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bt + (tb * 32 + col) * LDT + s * 16 + h * 8);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* slab = slabs + (size_t)blockIdx.x * KA * KB;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int tile = wave * TPW + j;
+        if (tile < TILES) {
+            const int ta = tile / TB, tb = tile % TB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int arow = ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                slab[(size_t)arow * KB + tb * 32 + col] = acc[j][r];
+            }
+        }
+    }
+}
+
+__global__ void gemm_tn_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int n, int nslabs)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nslabs; ++b) s += slabs[(size_t)b * n + e];
+    out[e] = (float)s;
+}
+
+inline int grid_for(long long items, int per_block, int cap = 4096)
+{
+    long long g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int lpd_edge_split_fwd(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx,
+                                  const float* gamma, float* S, float* usel, uint8_t* arg, long long M, int N, int C, int k,
+                                  double* sum, double* sumsq, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(P && Q && idx && gamma && S && usel && arg && sum && sumsq, "lpd_edge_split_fwd: null pointer");
+    LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_split_fwd: C=%d unsupported", C);
+    LPD_CHECK_ARG(M > 0 && N > 0 && k > 0 && k <= 255 && M % N == 0 && ldp % 4 == 0 && ldq % 4 == 0, "lpd_edge_split_fwd: bad dims");
+    (void)hipMemsetAsync(sum, 0, sizeof(double) * C, stream);
+    (void)hipMemsetAsync(sumsq, 0, sizeof(double) * C, stream);
+    const int lpp = C / 4;
+    const int grid = grid_for(M, 4 * (64 / lpp) * 4, 2048);
+    if (C == 64) hipLaunchKernelGGL(edge_split_fwd_kernel<16>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, gamma, S, usel, arg, M, N, k, sum, sumsq);
+    else if (C == 128) hipLaunchKernelGGL(edge_split_fwd_kernel<32>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, gamma, S, usel, arg, M, N, k, sum, sumsq);
+    else hipLaunchKernelGGL(edge_split_fwd_kernel<64>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, gamma, S, usel, arg, M, N, k, sum, sumsq);
+    LPD_CHECK_LAUNCH("lpd_edge_split_fwd");
+    return LPD_OK;
+}
+
+extern "C" int lpd_edge_split_bwd(const float* dOut, long long ldo, const float* usel, const uint8_t* arg, const float* S,
+                                  const float* P, long long ldp, const float* Q, long long ldq, const int32_t* rowptr,
+                                  const int32_t* edges, float* G, float* dP, long long lddp, float* dQ, long long lddq, long long M,
+                                  int C, int k, const float* scale, const float* shift, const float* mean, const float* invstd,
+                                  int act, float slope, double* dbeta, double* dgamma, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(dOut && usel && arg && S && P && Q && rowptr && edges && G && dP && dQ && dbeta && dgamma,
+                  "lpd_edge_split_bwd: null pointer");
+    LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_split_bwd: C=%d unsupported", C);
+    LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_split_bwd: activation %d unsupported", act);
+    LPD_CHECK_ARG(ldo % 4 == 0 && ldp % 4 == 0 && ldq % 4 == 0 && lddp % 4 == 0 && lddq % 4 == 0, "lpd_edge_split_bwd: leading dims % 4");
+    (void)hipMemsetAsync(dbeta, 0, sizeof(double) * C, stream);
+    (void)hipMemsetAsync(dgamma, 0, sizeof(double) * C, stream);
+    const int rg = 256 / (C / 4);
+    hipLaunchKernelGGL(edge_split_bwd_reduce_kernel, dim3(grid_for(M, rg * 8, 2048)), dim3(256), 0, stream, dOut, ldo, usel, G, M, C,
+                       scale, shift, mean, invstd, act, slope, dbeta, dgamma);
+    LPD_CHECK_LAUNCH("lpd_edge_split_bwd(reduce)");
+    const int lpr = C / 4;
+    const int grid = grid_for(M, 4 * (64 / lpr) * 2, 8192);
+    if (C == 64) hipLaunchKernelGGL(edge_split_bwd_apply_kernel<16>, dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
+    else if (C == 128) hipLaunchKernelGGL(edge_split_bwd_apply_kernel<32>, dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
+    else hipLaunchKernelGGL(edge_split_bwd_apply_kernel<64>, dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
+    LPD_CHECK_LAUNCH("lpd_edge_split_bwd(apply)");
+    return LPD_OK;
+}
+
+extern "C" int lpd_edge_build_bf16(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, uint16_t* U,
+                                   long long M, int N, int C, int k, double* sum, double* sumsq, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(P && idx && U, "lpd_edge_build_bf16: null pointer");
+    LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_build_bf16: C=%d unsupported", C);
+    LPD_CHECK_ARG((sum == nullptr) == (sumsq == nullptr), "lpd_edge_build_bf16: sum and sumsq come together");
+    if (sum) {
+        (void)hipMemsetAsync(sum, 0, sizeof(double) * C, stream);
+        (void)hipMemsetAsync(sumsq, 0, sizeof(double) * C, stream);
+    }
+    const int lpp = C / 4;
+    const int grid = grid_for(M, 4 * (64 / lpp) * 4, 2048);
+    if (C == 64) hipLaunchKernelGGL(edge_build_bf16_kernel<16>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, U, M, N, k, sum, sumsq);
+    else if (C == 128) hipLaunchKernelGGL(edge_build_bf16_kernel<32>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, U, M, N, k, sum, sumsq);
+    else hipLaunchKernelGGL(edge_build_bf16_kernel<64>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, U, M, N, k, sum, sumsq);
+    LPD_CHECK_LAUNCH("lpd_edge_build_bf16");
+    return LPD_OK;
+}
+
+extern "C" int lpd_edge_act_max_bf16(const uint16_t* U, int k, const float* scale, const float* shift, int act, float slope,
+                                     uint16_t* Y, float* out, long long ldo, uint8_t* arg, long long M, int C, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(U && scale && shift && Y && out && arg, "lpd_edge_act_max_bf16: null pointer");
+    LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && k <= 255 && ldo % 4 == 0, "lpd_edge_act_max_bf16: bad dims");
+    LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_act_max_bf16: activation %d unsupported", act);
+    const int rg = 256 / (C / 4);
+    hipLaunchKernelGGL(edge_act_max_bf16_kernel, dim3(grid_for(M, rg, 8192)), dim3(256), 0, stream, U, k, scale, shift, act, slope, Y, out,
+                       ldo, arg, M, C);
+    LPD_CHECK_LAUNCH("lpd_edge_act_max_bf16");
+    return LPD_OK;
+}
+
+extern "C" int lpd_group_sel_stats_bf16(const uint16_t* Z, int k, const float* gamma, float* sel, long long lds, uint8_t* arg,
+                                        long long M, int C, double* sum, double* sumsq, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(Z && gamma && sel && arg && sum && sumsq, "lpd_group_sel_stats_bf16: null pointer");
+    LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && k <= 255 && lds % 4 == 0, "lpd_group_sel_stats_bf16: bad dims");
+    (void)hipMemsetAsync(sum, 0, sizeof(double) * C, stream);
+    (void)hipMemsetAsync(sumsq, 0, sizeof(double) * C, stream);
+    const int rg = 256 / (C / 4);
+    hipLaunchKernelGGL(group_sel_stats_bf16_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, Z, k, gamma, sel, lds, arg, M, C,
+                       sum, sumsq);
+    LPD_CHECK_LAUNCH("lpd_group_sel_stats_bf16");
+    return LPD_OK;
+}
+
+extern "C" int lpd_edge_bn_bwd_bf16(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* dDense, const uint16_t* X,
+                                    uint16_t* dX, float* dQ, long long ldq, int k, long long M, int C, const float* scale,
+                                    const float* shift, const float* mean, const float* invstd, int act, float slope, double* dbeta,
+                                    double* dgamma, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(dOut && arg && X && dX && scale && shift && mean && invstd && dbeta && dgamma, "lpd_edge_bn_bwd_bf16: null pointer");
+    LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && k <= 255 && ldo % 4 == 0 && ldq % 4 == 0, "lpd_edge_bn_bwd_bf16: bad dims");
+    LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_bn_bwd_bf16: activation %d unsupported", act);
+    (void)hipMemsetAsync(dbeta, 0, sizeof(double) * C, stream);
+    (void)hipMemsetAsync(dgamma, 0, sizeof(double) * C, stream);
+    const int rg = 256 / (C / 4);
+    hipLaunchKernelGGL(edge_bn_bwd_reduce_bf16_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, dOut, ldo, arg, dDense, X, k, M,
+                       C, scale, shift, mean, invstd, act, slope, dbeta, dgamma);
+    LPD_CHECK_LAUNCH("lpd_edge_bn_bwd_bf16(reduce)");
+    hipLaunchKernelGGL(edge_bn_bwd_apply_bf16_kernel, dim3(grid_for(M, rg, 8192)), dim3(256), 0, stream, dOut, ldo, arg, dDense, X, dX, dQ,
+                       ldq, k, M, C, scale, shift, mean, invstd, (const double*)dbeta, (const double*)dgamma, (double)M * (double)k, act,
+                       slope);
+    LPD_CHECK_LAUNCH("lpd_edge_bn_bwd_bf16(apply)");
+    return LPD_OK;
+}
+
+extern "C" int lpd_gather_sum_rows_bf16(const uint16_t* dU, const int32_t* rowptr, const int32_t* edges, float* dP, long long ldp,
+                                        long long M, int C, int accumulate, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(dU && rowptr && edges && dP, "lpd_gather_sum_rows_bf16: null pointer");
+    LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_gather_sum_rows_bf16: C=%d unsupported", C);
+    const int lpr = C / 4;
+    const int grid = grid_for(M, 4 * (64 / lpr) * 2, 8192);
+    if (C == 64) hipLaunchKernelGGL(gather_sum_rows_bf16_kernel<16>, dim3(grid), dim3(256), 0, stream, dU, rowptr, edges, dP, ldp, M, accumulate);
+    else if (C == 128) hipLaunchKernelGGL(gather_sum_rows_bf16_kernel<32>, dim3(grid), dim3(256), 0, stream, dU, rowptr, edges, dP, ldp, M, accumulate);
+    else hipLaunchKernelGGL(gather_sum_rows_bf16_kernel<64>, dim3(grid), dim3(256), 0, stream, dU, rowptr, edges, dP, ldp, M, accumulate);
+    LPD_CHECK_LAUNCH("lpd_gather_sum_rows_bf16");
+    return LPD_OK;
+}
+
+extern "C" int lpd_gemm_bf16s(const uint16_t* A, const float* W, int ldw, int b_kmajor, uint16_t* C, long long M, int N, int K,
+                              void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(A && W && C && M > 0, "lpd_gemm_bf16s: null pointer");
+    LPD_CHECK_ARG((N == 128 && K == 128) || (N == 64 && K == 64), "lpd_gemm_bf16s: built for (N, K) = (128, 128) and (64, 64), got (%d, %d)", N, K);
+    const int grid = grid_for((M + 31) / 32, 4 * 8, 2048);
+    const size_t lds = (size_t)2 * N * (K + 8) * sizeof(uint16_t);
+    if (N == 128) {
+        auto kern = gemm_bf16s_kernel<128, 128>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, A, W, ldw, b_kmajor, C, M);
+    } else {
+        auto kern = gemm_bf16s_kernel<64, 64>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, A, W, ldw, b_kmajor, C, M);
+    }
+    LPD_CHECK_LAUNCH("lpd_gemm_bf16s");
+    return LPD_OK;
+}
+
+extern "C" long long lpd_gemm_tn_bf16_ws_floats(long long M, int KA, int KB)
+{
+    const long long blocks = M / 2048 > 1024 ? 1024 : (M / 2048 < 1 ? 1 : M / 2048);
+    return blocks * KA * KB;
+}
+
+extern "C" int lpd_gemm_tn_bf16(const uint16_t* A, const uint16_t* B, float* dW, float* ws, long long M, int KA, int KB, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(A && B && dW && ws && M > 0, "lpd_gemm_tn_bf16: null pointer");
+    LPD_CHECK_ARG((KA == 128 && KB == 128) || (KA == 64 && KB == 64), "lpd_gemm_tn_bf16: built for 128 x 128 and 64 x 64");
+    const long long blocks = lpd_gemm_tn_bf16_ws_floats(M, KA, KB) / ((long long)KA * KB);
+    long long rpb = (M + blocks - 1) / blocks;
+    rpb = (rpb + 63) / 64 * 64;
+    if (KA == 128) hipLaunchKernelGGL((gemm_tn_bf16_kernel<128, 128>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, ws, M, rpb);
+    else hipLaunchKernelGGL((gemm_tn_bf16_kernel<64, 64>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, ws, M, rpb);
+    LPD_CHECK_LAUNCH("lpd_gemm_tn_bf16");
+    const int n = KA * KB;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)ws, dW, n, (int)blocks);
+    LPD_CHECK_LAUNCH("lpd_gemm_tn_bf16(reduce)");
+    return LPD_OK;
+}

@@ -75,11 +75,23 @@ SIGNATURES = {
     "lpd_cloud_outer": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_int, _c_int, _c_int, _c_p],
     "lpd_softmax_bwd": [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_p],
     "lpd_vlad_finalize_bwd": [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
+    "lpd_edge_split_fwd": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p],
+    "lpd_edge_split_bwd": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_ll,
+                           _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_p],
+    "lpd_edge_build_bf16": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p],
+    "lpd_edge_act_max_bf16": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p],
+    "lpd_group_sel_stats_bf16": [_c_p, _c_int, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p, _c_p, _c_p],
+    "lpd_edge_bn_bwd_bf16": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int,
+                             _c_f, _c_p, _c_p, _c_p],
+    "lpd_gather_sum_rows_bf16": [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_ll, _c_int, _c_int, _c_p],
+    "lpd_gemm_bf16s": [_c_p, _c_p, _c_int, _c_int, _c_p, _c_ll, _c_int, _c_int, _c_p],
+    "lpd_gemm_tn_bf16_ws_floats": [_c_ll, _c_int, _c_int],
+    "lpd_gemm_tn_bf16": [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_p],
     "lpd_metric_loss": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_int, _c_int, _c_int,
                         _c_int, _c_f, _c_f, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
 }
 _RESTYPES = {"lpd_last_error": ctypes.c_char_p, "lpd_knn_workspace_floats": ctypes.c_longlong,
-             "lpd_gemm_prep_b_bytes": ctypes.c_longlong}
+             "lpd_gemm_prep_b_bytes": ctypes.c_longlong, "lpd_gemm_tn_bf16_ws_floats": ctypes.c_longlong}
 
 _lib = None
 

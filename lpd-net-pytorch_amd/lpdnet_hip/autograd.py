@@ -95,7 +95,7 @@ LEAKY = 0.01
 # Storage type of the large saved / materialised training tensors (edge tensors, their gradients, saved activations):
 # "f32" (default: what the 1e-4 parity gates are written for) or "bf16" (BASELINE configs[2] as stated: bf16 storage,
 # statistics / accumulations / kNN in fp32-fp64; looser stated tolerance, tests/test_train_gpu.py).
-TRAIN_STORAGES = ("f32",)
+TRAIN_STORAGES = ("f32", "bf16")
 TRAIN_STORAGE = "f32"
 
 
@@ -347,6 +347,8 @@ class _LPDNetTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, x, *params):
+        if TRAIN_STORAGE == "bf16":      # bf16 storage: the dense products behind the kNN run split-bf16 in the forward as well
+            return _LPDNetTrainFn._forward(ctx, net, x, *params)
         with ops.train_forward_gemm():
             return _LPDNetTrainFn._forward(ctx, net, x, *params)
 
@@ -356,32 +358,41 @@ class _LPDNetTrainFn(torch.autograd.Function):
         B, N = x.shape[0], x.shape[2]
         M, k = B * N, net.k
         act, slope = (ops.ACT_RELU, 0.0) if net.use_relu else (ops.ACT_LEAKY, LEAKY)
+        bf16 = TRAIN_STORAGE == "bf16"
         w2d = engine._w2d
         xyz = x.view(M, 3)
         f0, front = _Front.fwd(net, xyz, w2d(net.conv1_lpd), net.bn1_lpd, w2d(net.conv2_lpd), net.bn2_lpd, B, N, act, slope)
         idx_f = engine._knn_rows(f0, B, N, 64, k)
         cat = torch.empty((M, 512), dtype=torch.float32, device=x.device)
-        # DG1 (split projection, materialised edges)
+        # DG1 -> DG2 (split projection; convDG2 consumes EVERY post-activation edge, so these edge tensors must exist:
+        # fp32, or bf16 under set_train_storage("bf16"))
         wcat1 = engine.split_edge_weight(net.convDG1, "cat_nc")
         pq1 = ops.linear(f0, wcat1)                                             # [M,256] = [P | Q]
-        u1, stg1 = ops.edge_build(pq1[:, :128], pq1[:, 128:], idx_f, N, bn=net.convDG1[1])   # [E,128] raw + its BN statistics
-        arg1 = ops.group_max(u1, k, stg1.scale, stg1.shift, act, slope, cat[:, 0:128])            # x1
-        y1e = ops.affine_act(u1, stg1.scale, stg1.shift, act, slope)            # [E,128] post-activation edges
-        # DG2 on every edge
-        z = ops.linear(y1e, w2d(net.convDG2[0]))                                # [E,128] raw
-        stg2 = ops.bn_train_stats(z, net.convDG2[1])
-        arg2 = ops.group_max(z, k, stg2.scale, stg2.shift, act, slope, cat[:, 128:256])           # x2
-        # SN1 on the xyz graph
+        if bf16:
+            u1, stg1 = ops.edge_build_bf16(pq1[:, :128], pq1[:, 128:], idx_f, N, bn=net.convDG1[1])   # [E,128] raw + its BN statistics
+            y1e, arg1 = ops.edge_act_max_bf16(u1, k, stg1, act, slope, out=cat[:, 0:128])             # post-activation edges + x1
+            z = ops.gemm_bf16s(y1e, w2d(net.convDG2[0]))                        # [E,128] raw, bf16 MFMA
+            zsel, arg2, stg2 = ops.group_sel_stats_bf16(z, k, net.convDG2[1])   # statistics of z + the raw selected values
+            ops.affine_act(zsel, stg2.scale, stg2.shift, act, slope, out=cat[:, 128:256])             # x2
+            del zsel
+        else:
+            u1, stg1 = ops.edge_build(pq1[:, :128], pq1[:, 128:], idx_f, N, bn=net.convDG1[1])   # [E,128] raw + its BN statistics
+            arg1 = ops.group_max(u1, k, stg1.scale, stg1.shift, act, slope, cat[:, 0:128])            # x1
+            y1e = ops.affine_act(u1, stg1.scale, stg1.shift, act, slope)        # [E,128] post-activation edges
+            z = ops.linear(y1e, w2d(net.convDG2[0]))                            # [E,128] raw
+            stg2 = ops.bn_train_stats(z, net.convDG2[1])
+            arg2 = ops.group_max(z, k, stg2.scale, stg2.shift, act, slope, cat[:, 128:256])           # x2
+        # SN1 on the xyz graph, split form: statistics, max and arg-max from one gather pass, no [E,256] tensor
         idx_x = engine._knn_rows(x.view(B * N, 3), B, N, 3, k)
         wcat3 = engine.split_edge_weight(net.convSN1, "cat_nc")
-        pq3 = ops.linear(cat[:, 128:256], wcat3)                                # [M,512]
-        u3, stg3 = ops.edge_build(pq3[:, :256], pq3[:, 256:], idx_x, N, bn=net.convSN1[1])   # [E,256] raw + its BN statistics
-        arg3 = ops.group_max(u3, k, stg3.scale, stg3.shift, act, slope, cat[:, 256:512])          # x3
+        pq3 = ops.linear(cat[:, 128:256], wcat3)                                # [M,512] = [P | Q]
+        s3, usel3, arg3, stg3 = ops.edge_split_fwd(pq3[:, :256], pq3[:, 256:], idx_x, N, bn=net.convSN1[1])
+        ops.affine_act(usel3, stg3.scale, stg3.shift, act, slope, out=cat[:, 256:512])                # x3
         y3, st3, feat = _PointLayer.fwd(cat, w2d(net.conv3_lpd), net.bn3_lpd, act, slope)
-        ctx.net, ctx.dims, ctx.actslope = net, (B, N, M, k), (act, slope)
+        ctx.net, ctx.dims, ctx.actslope, ctx.bf16 = net, (B, N, M, k), (act, slope), bf16
         ctx.saved = dict(front=front, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1,
-                         u1=u1, stg1=stg1, arg1=arg1, y1e=y1e, z=z, stg2=stg2, arg2=arg2, wcat3=wcat3, u3=u3, stg3=stg3,
-                         arg3=arg3, cat=cat, y3=y3, st3=st3)
+                         u1=u1, stg1=stg1, arg1=arg1, y1e=y1e, z=z, stg2=stg2, arg2=arg2, wcat3=wcat3, pq3=pq3, s3=s3, usel3=usel3,
+                         stg3=stg3, arg3=arg3, cat=cat, y3=y3, st3=st3)
         if engine.DEBUG_AUX is not None:
             engine.DEBUG_AUX.update(F0=f0, idx_feat=idx_f, idx_xyz=idx_x, cat=cat, argsel=dict(x1=arg1, x2=arg2, x3=arg3))
         return feat
@@ -397,24 +408,34 @@ class _LPDNetTrainFn(torch.autograd.Function):
         # conv3 + bn3 (the incoming gradient buffer belongs to autograd: not modified in place)
         dcat, dw3, dg3, db3 = _PointLayer.bwd(dfeat, S["cat"], w2d(net.conv3_lpd), S["y3"], S["st3"], act, slope,
                                               inplace=False)
-        # SN1: x3 = groupmax(act(BN(U3)))
+        # SN1: x3 = max_k act(BN(P[nbr] + Q)), split form (closed-form sums over the edges, one pass over the transposed graph)
         dpq3 = torch.empty((M, 512), dtype=torch.float32, device=dfeat.device)    # both halves are fully written below
-        du3, dgs3, dbs3 = ops.edge_bn_bwd(dcat[:, 256:512], S["arg3"], k, S["u3"], S["stg3"], act, slope, dQ=dpq3[:, 256:])
-        ops.gather_sum_rows(du3, ops.GraphT(S["idx_x"], N), dpq3[:, :256])        # transpose of the neighbour gather
-        del du3
+        pq3 = S["pq3"]
+        dgs3, dbs3 = ops.edge_split_bwd(dcat[:, 256:512], S["usel3"], S["arg3"], S["s3"], pq3[:, :256], pq3[:, 256:],
+                                        ops.GraphT(S["idx_x"], N), S["stg3"], act, slope, k, dP=dpq3[:, :256], dQ=dpq3[:, 256:])
         x2 = S["cat"][:, 128:256]
         dwcat3 = _dweight(dpq3, x2)
         ops.gemm(dpq3, S["wcat3"], b_kmajor=True, out=dcat[:, 128:256], accumulate=True)   # dx2 += dPQ3 Wcat3
-        # DG2: x2 = groupmax(act(BN(Z))), Z = Y1e W2^T
-        dz, dgs2, dbs2 = ops.edge_bn_bwd(dcat[:, 128:256], S["arg2"], k, S["z"], S["stg2"], act, slope)
-        dw2 = _dweight(dz, S["y1e"])
-        dy1e = ops.gemm(dz, w2d(net.convDG2[0]), b_kmajor=True)                 # [E,128]
-        del dz
-        # DG1: y1e = act(BN(U1)); consumers: DG2 (dense) and x1 = groupmax (sparse)
         dpq1 = torch.empty((M, 256), dtype=torch.float32, device=dfeat.device)
-        du1, dgs1, dbs1 = ops.edge_bn_bwd(dcat[:, 0:128], S["arg1"], k, S["u1"], S["stg1"], act, slope, dense=dy1e,
-                                          dQ=dpq1[:, 128:])
-        ops.gather_sum_rows(du1, ops.GraphT(S["idx_f"], N), dpq1[:, :128])
+        if ctx.bf16:
+            # DG2: x2 = groupmax(act(BN(Z))), Z = Y1e W2^T  (bf16 edge tensors, bf16 MFMA products)
+            dz, dgs2, dbs2 = ops.edge_bn_bwd_bf16(dcat[:, 128:256], S["arg2"], k, S["z"], S["stg2"], act, slope)
+            dw2 = ops.gemm_tn_bf16(dz, S["y1e"])                                # [Co,Ci] = dZ^T Y1e
+            dy1e = ops.gemm_bf16s(dz, w2d(net.convDG2[0]), b_kmajor=True)       # [E,128] = dZ W2
+            del dz
+            du1, dgs1, dbs1 = ops.edge_bn_bwd_bf16(dcat[:, 0:128], S["arg1"], k, S["u1"], S["stg1"], act, slope, dense=dy1e,
+                                                   dQ=dpq1[:, 128:])
+            ops.gather_sum_rows_bf16(du1, ops.GraphT(S["idx_f"], N), dpq1[:, :128])
+        else:
+            # DG2: x2 = groupmax(act(BN(Z))), Z = Y1e W2^T
+            dz, dgs2, dbs2 = ops.edge_bn_bwd(dcat[:, 128:256], S["arg2"], k, S["z"], S["stg2"], act, slope)
+            dw2 = _dweight(dz, S["y1e"])
+            dy1e = ops.gemm(dz, w2d(net.convDG2[0]), b_kmajor=True)             # [E,128]
+            del dz
+            # DG1: y1e = act(BN(U1)); consumers: DG2 (dense) and x1 = groupmax (sparse)
+            du1, dgs1, dbs1 = ops.edge_bn_bwd(dcat[:, 0:128], S["arg1"], k, S["u1"], S["stg1"], act, slope, dense=dy1e,
+                                              dQ=dpq1[:, 128:])
+            ops.gather_sum_rows(du1, ops.GraphT(S["idx_f"], N), dpq1[:, :128])
         del du1, dy1e
         dwcat1 = _dweight(dpq1, S["f0"])
         df0 = ops.gemm(dpq1, S["wcat1"], b_kmajor=True)                         # [M,64]
@@ -653,6 +674,8 @@ class _NetVLADTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, vlad, B, N, feat, *params):
+        if TRAIN_STORAGE == "bf16":
+            return _NetVLADTrainFn._forward(ctx, vlad, B, N, feat, *params)
         with ops.train_forward_gemm():
             return _NetVLADTrainFn._forward(ctx, vlad, B, N, feat, *params)
 

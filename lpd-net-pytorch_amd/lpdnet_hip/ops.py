@@ -802,6 +802,152 @@ def gather_sum_rows(dU, graph, dP, accumulate=False):
     return dP
 
 
+# ------------------------------------------------------------------------------------------------
+# training path, second generation (csrc/lpd_train2.hip): split-form edge stage, bf16-storage edge tensors
+# ------------------------------------------------------------------------------------------------
+def _bf16_rows(t, name, C=None):
+    _req(t, name, torch.bfloat16)
+    if t.dim() != 2 or not t.is_contiguous() or (C is not None and t.shape[1] != C):
+        raise ValueError(f"{name}: expected a contiguous 2-D bfloat16 tensor" + (f" with {C} columns" if C else ""))
+
+
+def edge_split_fwd(P, Q, idx, N, bn):
+    """Train-mode split-form edge stage, forward half (include/lpd_hip.h lpd_edge_split_fwd): one gather pass over the graph
+    -> (S [M,C] = sum_t P[nbr], usel [M,C] = sel_t P[nbr] + Q, arg [M,C] uint8, BNStats of U = P[nbr] + Q over all M*k edges);
+    the [M*k, C] edge tensor is never built.  Updates bn's running statistics like torch."""
+    ldp, ldq = _rows(P, "P"), _rows(Q, "Q")
+    _req(idx, "idx", torch.int32)
+    idx = idx.reshape(-1, idx.shape[-1]).contiguous()
+    M, C = P.shape
+    k = idx.shape[1]
+    dev = P.device
+    S = torch.empty((M, C), dtype=torch.float32, device=dev)
+    usel = torch.empty((M, C), dtype=torch.float32, device=dev)
+    arg = torch.empty((M, C), dtype=torch.uint8, device=dev)
+    sums = torch.empty((2, C), dtype=torch.float64, device=dev)
+    lib = _lib.load()
+    _call(f"edge_split_fwd[C={C}]", lib.lpd_edge_split_fwd, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(bn.weight), _ptr(S), _ptr(usel),
+          _ptr(arg), M, N, C, k, _ptr(sums[0]), _ptr(sums[1]), _stream())
+    return S, usel, arg, _bn_finalize(sums, M * k, C, bn)
+
+
+def edge_split_bwd(dOut, usel, arg, S, P, Q, graph, st, act, slope, k, dP, dQ):
+    """Backward half: dOut [M,C] (view allowed) -> fills dP, dQ ([M,C] views), returns (dgamma, dbeta) fp32."""
+    ldo, ldp, ldq, lddp, lddq = _rows(dOut, "dOut"), _rows(P, "P"), _rows(Q, "Q"), _rows(dP, "dP"), _rows(dQ, "dQ")
+    M, C = usel.shape
+    G = torch.empty((M, C), dtype=torch.float32, device=usel.device)
+    red = torch.empty((2, C), dtype=torch.float64, device=usel.device)
+    lib = _lib.load()
+    _call(f"edge_split_bwd[C={C}]", lib.lpd_edge_split_bwd, _ptr(dOut), ldo, _ptr(usel), _ptr(arg), _ptr(S), _ptr(P), ldp, _ptr(Q), ldq,
+          _ptr(graph.rowptr), _ptr(graph.edges), _ptr(G), _ptr(dP), lddp, _ptr(dQ), lddq, M, C, k, _ptr(st.scale), _ptr(st.shift),
+          _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(red[0]), _ptr(red[1]), _stream())
+    redf = red.float()
+    return redf[1], redf[0]
+
+
+def edge_build_bf16(P, Q, idx, N, bn):
+    """edge_build with bf16 storage: (U [M*k, C] bfloat16, BNStats of the stored values)."""
+    ldp = _rows(P, "P")
+    ldq = _rows(Q, "Q") if Q is not None else 0
+    idx = idx.reshape(-1, idx.shape[-1]).contiguous()
+    M, C = P.shape
+    k = idx.shape[1]
+    U = torch.empty((M * k, C), dtype=torch.bfloat16, device=P.device)
+    sums = torch.empty((2, C), dtype=torch.float64, device=P.device)
+    lib = _lib.load()
+    _call(f"edge_build_bf16[C={C}]", lib.lpd_edge_build_bf16, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(U), M, N, C, k, _ptr(sums[0]),
+          _ptr(sums[1]), _stream())
+    return U, _bn_finalize(sums, M * k, C, bn)
+
+
+def edge_act_max_bf16(U, k, st, act, slope, out):
+    """One pass over U (bf16): -> (Y = act(BN(U)) bf16 [M*k, C], arg uint8 [M, C]); out [M, C] receives max_k of the same values."""
+    _bf16_rows(U, "U")
+    ldo = _rows(out, "out")
+    M, C = out.shape
+    if U.shape != (M * k, C):
+        raise ValueError("edge_act_max_bf16: shape mismatch")
+    Y = torch.empty_like(U)
+    arg = torch.empty((M, C), dtype=torch.uint8, device=U.device)
+    lib = _lib.load()
+    _call(f"edge_act_max_bf16[C={C}]", lib.lpd_edge_act_max_bf16, _ptr(U), k, _ptr(st.scale), _ptr(st.shift), act, float(slope), _ptr(Y),
+          _ptr(out), ldo, _ptr(arg), M, C, _stream())
+    return Y, arg
+
+
+def group_sel_stats_bf16(Z, k, bn):
+    """One pass over the raw conv output Z (bf16 [M*k, C]): -> (sel [M,C] raw selected values, arg, BNStats of Z)."""
+    _bf16_rows(Z, "Z")
+    C = Z.shape[1]
+    M = Z.shape[0] // k
+    sel = torch.empty((M, C), dtype=torch.float32, device=Z.device)
+    arg = torch.empty((M, C), dtype=torch.uint8, device=Z.device)
+    sums = torch.empty((2, C), dtype=torch.float64, device=Z.device)
+    lib = _lib.load()
+    _call(f"group_sel_stats_bf16[C={C}]", lib.lpd_group_sel_stats_bf16, _ptr(Z), k, _ptr(bn.weight), _ptr(sel), C, _ptr(arg), M, C,
+          _ptr(sums[0]), _ptr(sums[1]), _stream())
+    return sel, arg, _bn_finalize(sums, M * k, C, bn)
+
+
+def edge_bn_bwd_bf16(dOut, arg, k, X, st, act, slope, dense=None, dQ=None):
+    """edge_bn_bwd on bf16 tensors: -> (dX bf16 [M*k, C] (aliases `dense` when given), dgamma, dbeta)."""
+    ldo = _rows(dOut, "dOut")
+    M, C = arg.shape
+    _bf16_rows(X, "X", C)
+    if dense is not None:
+        _bf16_rows(dense, "dense", C)
+    dX = dense if dense is not None else torch.empty((M * k, C), dtype=torch.bfloat16, device=X.device)
+    ldq = _rows(dQ, "dQ") if dQ is not None else 0
+    red = torch.empty((2, C), dtype=torch.float64, device=X.device)
+    lib = _lib.load()
+    _call(f"edge_bn_bwd_bf16[C={C}]", lib.lpd_edge_bn_bwd_bf16, _ptr(dOut), ldo, _ptr(arg), _ptr(dense), _ptr(X), _ptr(dX), _ptr(dQ), ldq,
+          k, M, C, _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(red[0]), _ptr(red[1]),
+          _stream())
+    redf = red.float()
+    return dX, redf[1], redf[0]
+
+
+def gather_sum_rows_bf16(dU, graph, dP, accumulate=False):
+    ldp = _rows(dP, "dP")
+    M, C = dP.shape
+    _bf16_rows(dU, "dU", C)
+    if dU.shape[0] != graph.M * graph.k or M != graph.M:
+        raise ValueError("gather_sum_rows_bf16: dU must be [M*k, C] matching the graph")
+    lib = _lib.load()
+    _call(f"gather_sum_rows_bf16[C={C}]", lib.lpd_gather_sum_rows_bf16, _ptr(dU), _ptr(graph.rowptr), _ptr(graph.edges), _ptr(dP), ldp, M,
+          C, int(bool(accumulate)), _stream())
+    return dP
+
+
+def gemm_bf16s(A, W, b_kmajor=False):
+    """C [M,N] (bf16) = A [M,K] (bf16) x W: W [N,K] (b_kmajor False: torch conv weight) or [K,N] (True), fp32, split hi + lo."""
+    _bf16_rows(A, "A")
+    _req(W, "W")
+    W = W.reshape(W.shape[0], -1).contiguous()
+    M, K = A.shape
+    N = W.shape[1] if b_kmajor else W.shape[0]
+    if (W.shape[0] if b_kmajor else W.shape[1]) != K:
+        raise ValueError("gemm_bf16s: inner dims differ")
+    C = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    lib = _lib.load()
+    _call(f"gemm_bf16s[{M}x{N}x{K}]", lib.lpd_gemm_bf16s, _ptr(A), _ptr(W), W.stride(0), int(bool(b_kmajor)), _ptr(C), M, N, K, _stream())
+    return C
+
+
+def gemm_tn_bf16(A, B):
+    """dW [KA,KB] (fp32) = A^T B over the rows; A [M,KA], B [M,KB] bf16."""
+    _bf16_rows(A, "A"), _bf16_rows(B, "B")
+    M, KA = A.shape
+    KB = B.shape[1]
+    if B.shape[0] != M:
+        raise ValueError("gemm_tn_bf16: row counts differ")
+    lib = _lib.load()
+    ws = torch.empty((int(lib.lpd_gemm_tn_bf16_ws_floats(M, KA, KB)),), dtype=torch.float32, device=A.device)
+    dW = torch.empty((KA, KB), dtype=torch.float32, device=A.device)
+    _call(f"gemm_tn_bf16[{KA}x{KB}x{M}]", lib.lpd_gemm_tn_bf16, _ptr(A), _ptr(B), _ptr(dW), _ptr(ws), M, KA, KB, _stream())
+    return dW
+
+
 def dw_smallk(dY, X):
     lddy, ldx = _rows(dY, "dY"), _rows(X, "X")
     M, Co = dY.shape

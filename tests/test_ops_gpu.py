@@ -589,3 +589,113 @@ def test_cloud_panel_operands(cuda, exact):
     pan = ops.panels_empty(2, 256, 512, cuda)
     ops.edge_mlp(*args, exact=exact, out=pan[:, 16:32])
     assert torch.equal(ops.panels_to_rows(pan[:, 16:32]), rowm)
+
+
+# ------------------------------------------------------------------ training path, second generation
+def _bn_for(C, seed):
+    g = torch.Generator().manual_seed(seed)
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data.copy_(torch.rand(C, generator=g) - 0.3)      # ~30 % negative scales: the min-selection path
+    bn.bias.data.copy_(torch.randn(C, generator=g) * 0.1)
+    return bn
+
+
+@pytest.mark.parametrize("C,N,k,B", [(256, 512, 20, 2), (128, 300, 20, 3), (64, 128, 7, 2), (256, 256, 64, 1)])
+def test_split_form_edge_stage_equals_the_materialised_one(cuda, C, N, k, B):
+    """lpd_edge_split_fwd / _bwd (no [M*k, C] edge tensor; closed-form BatchNorm sums, one pass over the transposed graph)
+    against the materialised formulation edge_build -> group_max -> edge_bn_bwd -> gather_sum_rows: outputs, arg-max,
+    batch statistics, running statistics, dP, dQ, dgamma, dbeta."""
+    ops = _ops()
+    M = B * N
+    P, Q, idx, _, _ = _edge_inputs(B, N, C, k, 5 * C + N + k)
+    P, Q, idx = P.to(cuda), Q.to(cuda), idx.to(cuda)
+    g = torch.Generator().manual_seed(C + k)
+    dOut = torch.randn(M, C + 8, generator=g).to(cuda)[:, 4:4 + C]        # a strided view, like dcat[:, 256:512]
+    act, slope = ops.ACT_LEAKY, 0.01
+    bn_a, bn_b = _bn_for(C, 3).to(cuda).train(), _bn_for(C, 3).to(cuda).train()
+    # materialised reference (validated against the oracle by the training tests)
+    U, st_a = ops.edge_build(P, Q, idx, N, bn=bn_a)
+    out_a = torch.empty(M, C, device=cuda)
+    arg_a = ops.group_max(U, k, st_a.scale, st_a.shift, act, slope, out_a)
+    dQ_a = torch.empty(M, C, device=cuda)
+    dU, dg_a, db_a = ops.edge_bn_bwd(dOut, arg_a, k, U, st_a, act, slope, dQ=dQ_a)
+    dP_a = torch.empty(M, C, device=cuda)
+    ops.gather_sum_rows(dU, ops.GraphT(idx, N), dP_a)
+    # split form
+    S, usel, arg_b, st_b = ops.edge_split_fwd(P, Q, idx, N, bn_b)
+    out_b = ops.affine_act(usel, st_b.scale, st_b.shift, act, slope)
+    buf = torch.zeros(M, 2 * C + 8, device=cuda)
+    dg_b, db_b = ops.edge_split_bwd(dOut, usel, arg_b, S, P, Q, ops.GraphT(idx, N), st_b, act, slope, k, dP=buf[:, 4:4 + C],
+                                    dQ=buf[:, 4 + C:4 + 2 * C])
+    assert torch.equal(arg_a, arg_b)
+    for a, b in ((st_a.mean, st_b.mean), (st_a.invstd, st_b.invstd), (st_a.scale, st_b.scale), (st_a.shift, st_b.shift)):
+        assert _rel(b, a) < 1e-5
+    assert _rel(bn_b.running_mean, bn_a.running_mean) < 1e-5 and _rel(bn_b.running_var, bn_a.running_var) < 1e-5
+    assert int(bn_b.num_batches_tracked) == 1
+    assert _rel(out_b, out_a) < 1e-5
+    assert _rel(buf[:, 4:4 + C], dP_a) < 2e-5 and _rel(buf[:, 4 + C:4 + 2 * C], dQ_a) < 2e-5
+    assert _rel(dg_b, dg_a) < 1e-5 and _rel(db_b, db_a) < 1e-5
+    assert (buf[:, :4] == 0).all() and (buf[:, 4 + 2 * C:] == 0).all()
+
+
+def test_bf16_storage_edge_kernels(cuda):
+    """The bf16-storage kernels of the DG1 -> DG2 chain against their fp32 counterparts evaluated on the same (rounded) values:
+    statistics, selections and gradients must agree to fp32 accuracy -- only the STORED tensors are bf16."""
+    ops = _ops()
+    C, N, k, B = 128, 320, 20, 2
+    M = B * N
+    P, Q, idx, _, _ = _edge_inputs(B, N, C, k, 77)
+    P, Q, idx = P.to(cuda), Q.to(cuda), idx.to(cuda)
+    act, slope = ops.ACT_LEAKY, 0.01
+    bn_a, bn_b = _bn_for(C, 5).to(cuda).train(), _bn_for(C, 5).to(cuda).train()
+    U16, st16 = ops.edge_build_bf16(P, Q, idx, N, bn_a)
+    U32 = ops.edge_build(P, Q, idx, N)
+    assert U16.dtype == torch.bfloat16 and torch.equal(U16, U32.to(torch.bfloat16))          # round to nearest even
+    Ur = U16.float()
+    st32 = ops.bn_train_stats(Ur, bn_b)
+    assert _rel(st16.mean, st32.mean) < 1e-5 and _rel(st16.invstd, st32.invstd) < 1e-5
+    # Y = act(BN(U)) + max over k in one pass
+    out16 = torch.empty(M, C, device=cuda)
+    Y16, arg16 = ops.edge_act_max_bf16(U16, k, st32, act, slope, out16)
+    out32 = torch.empty(M, C, device=cuda)
+    arg32 = ops.group_max(Ur, k, st32.scale, st32.shift, act, slope, out32)
+    Y32 = ops.affine_act(Ur, st32.scale, st32.shift, act, slope)
+    assert torch.equal(arg16, arg32) and _rel(out16, out32) < 1e-6 and torch.equal(Y16, Y32.to(torch.bfloat16))
+    # z = Y W^T on the bf16 MFMA (weight split hi + lo), dY = dZ W, dW = dZ^T Y
+    g = torch.Generator().manual_seed(9)
+    W = (torch.randn(C, C, generator=g) / C ** 0.5).to(cuda)
+    Z16 = ops.gemm_bf16s(Y16, W)
+    Zref = Y16.double() @ W.double().t()
+    assert _rel(Z16.double(), Zref) < 6e-3                       # bf16 rounding of the stored result (2^-9 relative)
+    assert _rel(Z16, Zref.float().to(torch.bfloat16)) < 8e-3
+    dY16 = ops.gemm_bf16s(Z16, W, b_kmajor=True)
+    assert _rel(dY16.double(), Z16.double() @ W.double()) < 6e-3
+    dW = ops.gemm_tn_bf16(Z16, Y16)
+    assert _rel(dW, Z16.double().t() @ Y16.double()) < 1e-5      # fp32 accumulation of exact bf16 products
+    # statistics + raw selection of Z in one pass
+    bn_z1, bn_z2 = _bn_for(C, 6).to(cuda).train(), _bn_for(C, 6).to(cuda).train()
+    sel, argz, stz = ops.group_sel_stats_bf16(Z16, k, bn_z1)
+    stz32 = ops.bn_train_stats(Z16.float(), bn_z2)
+    assert _rel(stz.mean, stz32.mean) < 1e-5 and _rel(stz.invstd, stz32.invstd) < 1e-5
+    x2a = ops.affine_act(sel, stz.scale, stz.shift, act, slope)
+    x2b = torch.empty(M, C, device=cuda)
+    argzb = ops.group_max(Z16.float(), k, stz32.scale, stz32.shift, act, slope, x2b)
+    assert torch.equal(argz, argzb) and _rel(x2a, x2b) < 1e-5
+    # backward through max + act + BN on bf16 tensors
+    dOut = torch.randn(M, C, generator=g).to(cuda)
+    dense = torch.randn(M * k, C, generator=g).to(cuda).to(torch.bfloat16)
+    dQ16 = torch.empty(M, C, device=cuda)
+    dX16, dg16, db16 = ops.edge_bn_bwd_bf16(dOut, arg16, k, U16, st32, act, slope, dense=dense.clone(), dQ=dQ16)
+    dQ32 = torch.empty(M, C, device=cuda)
+    dX32, dg32, db32 = ops.edge_bn_bwd(dOut, arg16, k, Ur, st32, act, slope, dense=dense.float(), dQ=dQ32)
+    assert _rel(dg16, dg32) < 1e-5 and _rel(db16, db32) < 1e-5 and _rel(dQ16, dQ32) < 1e-5
+    assert torch.equal(dX16, dX32.to(torch.bfloat16))
+    dX16b, _, _ = ops.edge_bn_bwd_bf16(dOut, argz, k, Z16, stz, act, slope)                    # sparse form (no dense gradient)
+    dX32b, _, _ = ops.edge_bn_bwd(dOut, argz, k, Z16.float(), stz, act, slope)
+    assert torch.equal(dX16b, dX32b.to(torch.bfloat16))
+    gt = ops.GraphT(idx, N)
+    a = torch.empty(M, C, device=cuda)
+    b = torch.empty(M, C, device=cuda)
+    ops.gather_sum_rows_bf16(dX16, gt, a)
+    ops.gather_sum_rows(dX16.float(), gt, b)
+    assert _rel(a, b) < 1e-6

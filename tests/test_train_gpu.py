@@ -240,6 +240,64 @@ def test_train_grads_flip_free_vs_oracle(cuda, featnet, bq, P, Ng, N):
     assert float(np.median(list(errs.values()))) < FLIP_FREE_MEDIAN, errs
 
 
+BF16_DESC_TOL = 5e-3      # bf16 storage of the DG-chain edge tensors (2^-9 relative rounding each): descriptors vs the fp64 oracle
+BF16_GRAD_TOL = 5e-2      # relative L2 per gradient tensor (median 2e-2); kNN graphs stay exact fp32 in this mode too
+
+
+@pytest.mark.parametrize("bq,P,Ng,N", [(1, 2, 2, 512), (2, 2, 4, 1024)])
+def test_train_bf16_storage_vs_oracle(cuda, bq, P, Ng, N):
+    """BASELINE configs[2] as stated (bf16): autograd.set_train_storage("bf16") keeps the DG1 -> DG2 edge tensors and their
+    gradients in bf16 and runs the products on them on the bf16 MFMA; statistics, reductions, the split-form SN1 stage and the
+    kNN stay fp32 / fp64.  Compared with the fp64 oracle on the GPU's kNN graphs at the stated (looser) bf16 tolerances; the
+    feature-space graph itself must be the one the fp32 mode builds (bit-identical indices)."""
+    from lpdnet_hip import autograd, engine
+    B = bq * (1 + P + Ng + 1)
+    xc = torch.from_numpy(synth.cloud(21, B, N)).unsqueeze(1)
+    runs = {}
+    for storage in ("f32", "bf16"):
+        m, sd0 = _train_model(N, cuda, "lpdnet")
+        prev = autograd.set_train_storage(storage)
+        engine.DEBUG_AUX = {}
+        engine.MORTON_ORDER = False
+        try:
+            out, loss = _step(m, xc.to(cuda), bq, P, Ng)
+            runs[storage] = (m, out, loss, engine.DEBUG_AUX)
+        finally:
+            engine.DEBUG_AUX = None
+            engine.MORTON_ORDER = True
+            autograd.set_train_storage(prev)
+    m, out, loss, aux = runs["bf16"]
+    assert torch.equal(aux["idx_feat"], runs["f32"][3]["idx_feat"]) and torch.equal(aux["idx_xyz"], runs["f32"][3]["idx_xyz"])
+    graphs = iter([aux["idx_feat"].cpu().long(), aux["idx_xyz"].cpu().long()])
+    dt = torch.float64
+    sd = {kk: (v.to(dt).requires_grad_(True) if v.dtype == torch.float32 and not kk.endswith(("running_mean", "running_var"))
+               else (v.to(dt) if v.dtype == torch.float32 else v.clone())) for kk, v in sd0.items()}
+    orig = orc.knn
+    orc.knn = lambda xx, kk: next(graphs)
+    try:
+        od = orc.pointnetvlad_forward(sd, xc.to(dt), featnet="lpdnet", train=True)
+    finally:
+        orc.knn = orig
+    q, p, n, o = torch.split(od.view(bq, -1, 256), [1, P, Ng, 1], dim=1)
+    ol = orc.quadruplet_loss(q, p, n, o, 0.5, 0.2, use_min=True, lazy=True, ignore_zero_loss=False)
+    ol.backward()
+    rel = ((out.detach().cpu().double() - od.detach()).abs().amax(dim=1) / od.detach().abs().amax(dim=1)).max().item()
+    assert rel < BF16_DESC_TOL, rel
+    assert abs(loss.item() - ol.item()) < 2e-2 * abs(ol.item())
+    errs = {}
+    for name, prm in m.named_parameters():
+        want = sd[name].grad
+        if want is None or want.norm().item() < 1e-6 * max(1.0, sd[name].detach().norm().item()):
+            continue
+        errs[name] = ((prm.grad.cpu().double() - want).norm() / want.norm()).item()
+    if os.environ.get("LPD_TEST_VERBOSE"):
+        print("bf16", N, "desc", rel, sorted(((round(e, 5), n_) for n_, e in errs.items()), reverse=True)[:8])
+    assert max(errs.values()) < BF16_GRAD_TOL and float(np.median(list(errs.values()))) < 2e-2, errs
+    # and the two storage modes agree with each other at the bf16 tolerance
+    d32 = runs["f32"][1].detach()
+    assert ((out.detach() - d32).abs().amax(dim=1) / d32.abs().amax(dim=1)).max().item() < BF16_DESC_TOL
+
+
 def test_train_then_eval_roundtrip_and_adam_step(cuda):
     """model.train() step + optimizer.step(), then model.eval() forward uses the updated running statistics."""
     N, bq, P, Ng = 256, 1, 2, 2
