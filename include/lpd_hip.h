@@ -94,6 +94,13 @@ int lpd_gemm_bf16x3(const float* A, const float* B, float* C, int M, int N, int 
              float* splitk_ws, const float* bias, const float* scale, const float* shift, int act, float slope,
              int accumulate, long long a_cloud, long long c_cloud, int panel_n, int panel_ld, void* stream);
 
+/* The same kernel with ONE product per term (a_hi * b_hi: the operands rounded to bf16, fp32 accumulation): the bf16-storage
+ * training mode (BASELINE.json configs[2]).  ~4e-3 relative per operand. */
+int lpd_gemm_bf16x1(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+             int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC, int splits,
+             float* splitk_ws, const float* bias, const float* scale, const float* shift, int act, float slope,
+             int accumulate, long long a_cloud, long long c_cloud, int panel_n, int panel_ld, void* stream);
+
 /*
  * Split-bf16 GEMM for a weight-shaped B: lpd_gemm_prep_b splits B (either layout) once into hi/lo bf16 stored in MFMA
  * fragment order (lpd_gemm_prep_b_bytes(N, K) bytes, 16-byte aligned); lpd_gemm_x3w then computes
@@ -101,7 +108,7 @@ int lpd_gemm_bf16x3(const float* A, const float* B, float* C, int M, int N, int 
  * its 32-column fragments from L2 into registers).  Used for the wide forward layers (conv3 512 -> 1024, the split edge
  * projections) and for dX = dY.W in the backward pass.  a_cloud / c_cloud / panel_n / panel_ld: cloud-panel A / C as in
  * lpd_gemm (0 = row-major).  impl: 0 = by shape (N >= 256: 128 x 256 blocks, each wave a 128 x 64 strip; else 128 x 128),
- * 2 / 3 = 128 x 128 / 128 x 256 blocks forced.
+ * 2 / 3 = 128 x 128 / 128 x 256 blocks forced; impl | 16: one product per term (a_hi * b_hi, see lpd_gemm_bf16x1).
  */
 long long lpd_gemm_prep_b_bytes(int N, int K);
 int lpd_gemm_prep_b(const float* B, int ldb, int b_kmajor, int N, int K, void* frags, void* stream);

@@ -50,6 +50,8 @@ struct GemmArgs {
     long long a_cloud, c_cloud;
     int panel_n;
     int panel_ld;   // rows allotted to one panel (>= panel_n; the pad keeps consecutive panels off the same HBM channels)
+    int prods;      // split-bf16 kernel: 3 = a_lo b_hi + a_hi b_lo + a_hi b_hi (fp32-grade), 1 = a_hi b_hi only (plain bf16 operands:
+                    // the bf16-storage training mode, lpd_gemm_bf16x1)
 };
 
 // PANELS (template): bit 0 = A panel-major, bit 1 = C panel-major; 0 compiles to the plain row-major addressing
@@ -487,15 +489,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x3_kernel(GemmArgs g)
         for (int s = 0; s < BK / 16; ++s) {
             bf16x8 a_hi[2], a_lo[2], b_hi[TN], b_lo[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a_hi[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * LDK + s * 16);
-                a_lo[i] = *reinterpret_cast<const bf16x8*>(al + i * 32 * LDK + s * 16);
+            for (int i = 0; i < 2; ++i) a_hi[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * LDK + s * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b_hi[j] = *reinterpret_cast<const bf16x8*>(bh + j * 32 * LDK + s * 16);
+            if (g.prods == 1) {      // uniform: plain bf16 operands
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+                continue;
             }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                b_hi[j] = *reinterpret_cast<const bf16x8*>(bh + j * 32 * LDK + s * 16);
-                b_lo[j] = *reinterpret_cast<const bf16x8*>(bl + j * 32 * LDK + s * 16);
-            }
+            for (int i = 0; i < 2; ++i) a_lo[i] = *reinterpret_cast<const bf16x8*>(al + i * 32 * LDK + s * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b_lo[j] = *reinterpret_cast<const bf16x8*>(bl + j * 32 * LDK + s * 16);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -560,6 +568,7 @@ struct X3wArgs {
     long long a_cloud, c_cloud;   // cloud-panel operands (see GemmArgs); 0 = row-major
     int panel_n, panel_ld;
     int rotate;                   // start the reduction of row tile t at chunk 5 t mod chunks (see the kernel)
+    int prods;                    // 3 = split-bf16 (fp32-grade), 1 = a_hi b_hi only (bf16-storage training mode)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -693,16 +702,18 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
             a_hi[i] = *reinterpret_cast<const bf16x8*>(ah + (rt0 + i) * 32 * X3V_LDK + s * 16);
             a_lo[i] = *reinterpret_cast<const bf16x8*>(al + (rt0 + i) * 32 * X3V_LDK + s * 16);
         }
+        if (g.prods != 1) {      // uniform
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[set][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[set][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[set][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[set][j], acc[i][j], 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -922,11 +933,12 @@ int gemm_launch_t(const GemmArgs& g, int batch, hipStream_t stream)
 }  // namespace
 
 // C-ABI: see include/lpd_hip.h for the contract.
-static int gemm_entry(bool x3, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+static int gemm_entry(int mode /* 0 f32-input MFMA, 3 split-bf16, 1 plain bf16 */, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                       int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC,
                       int splits, float* splitk_ws, const float* bias, const float* scale, const float* shift,
                       int act, float slope, int accumulate, long long a_cloud, long long c_cloud, int panel_n, int panel_ld, void* stream_)
 {
+    const bool x3 = mode != 0;
     const bool a_panels = a_cloud != 0, c_panels = c_cloud != 0;
     LPD_CHECK_ARG(!(a_panels || c_panels) || (!a_kmajor && batch == 1 && splits == 1 && K % 32 == 0 && panel_n > 0 &&
                                               panel_n % 128 == 0 && M % panel_n == 0 && panel_ld >= panel_n),
@@ -957,6 +969,7 @@ static int gemm_entry(bool x3, const float* A, const float* B, float* C, int M, 
     g.c_cloud = c_cloud;
     g.panel_n = panel_n > 0 ? panel_n : 1;
     g.panel_ld = panel_ld;
+    g.prods = mode == 1 ? 1 : 3;
     if (splits > 1) {
         g.C = splitk_ws; g.ldc = N; g.sC = (long long)splits * M * N; g.sCsplit = (long long)M * N;
     } else {
@@ -1020,7 +1033,7 @@ extern "C" int lpd_gemm(const float* A, const float* B, float* C, int M, int N, 
                         int splits, float* splitk_ws, const float* bias, const float* scale, const float* shift,
                         int act, float slope, int accumulate, long long a_cloud, long long c_cloud, int panel_n, int panel_ld, void* stream)
 {
-    return gemm_entry(false, A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, batch, sA, sB, sC, splits, splitk_ws, bias,
+    return gemm_entry(0, A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, batch, sA, sB, sC, splits, splitk_ws, bias,
                       scale, shift, act, slope, accumulate, a_cloud, c_cloud, panel_n, panel_ld, stream);
 }
 
@@ -1029,7 +1042,16 @@ extern "C" int lpd_gemm_bf16x3(const float* A, const float* B, float* C, int M, 
                                int splits, float* splitk_ws, const float* bias, const float* scale, const float* shift,
                                int act, float slope, int accumulate, long long a_cloud, long long c_cloud, int panel_n, int panel_ld, void* stream)
 {
-    return gemm_entry(true, A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, batch, sA, sB, sC, splits, splitk_ws, bias,
+    return gemm_entry(3, A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, batch, sA, sB, sC, splits, splitk_ws, bias,
+                      scale, shift, act, slope, accumulate, a_cloud, c_cloud, panel_n, panel_ld, stream);
+}
+
+extern "C" int lpd_gemm_bf16x1(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                               int a_kmajor, int b_kmajor, int batch, long long sA, long long sB, long long sC,
+                               int splits, float* splitk_ws, const float* bias, const float* scale, const float* shift,
+                               int act, float slope, int accumulate, long long a_cloud, long long c_cloud, int panel_n, int panel_ld, void* stream)
+{
+    return gemm_entry(1, A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, batch, sA, sB, sC, splits, splitk_ws, bias,
                       scale, shift, act, slope, accumulate, a_cloud, c_cloud, panel_n, panel_ld, stream);
 }
 
@@ -1093,11 +1115,13 @@ extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C
                   "lpd_gemm_x3w: cloud-panel operands need points per cloud %% 128 == 0");
     LPD_CHECK_ARG(!a_panels || K % 8 == 0, "lpd_gemm_x3w: cloud-panel A needs K %% 8 == 0");
     LPD_CHECK_ARG(!c_panels || N % 8 == 0, "lpd_gemm_x3w: cloud-panel C needs N %% 8 == 0");
+    const int prods = (impl & 16) ? 1 : 3;   // impl | 16: plain bf16 operands (a_hi b_hi only)
+    impl &= 15;
     LPD_CHECK_ARG(impl == 0 || impl == 2 || impl == 3, "lpd_gemm_x3w: impl=%d", impl);
     const int KS = (K + 15) / 16, NT = (N + 31) / 32;
     const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
     X3wArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, K, KS, lda, ldc, bias, scale, shift, act, slope, accumulate,
-              a_cloud, c_cloud, panel_n, panel_ld, 0};
+              a_cloud, c_cloud, panel_n, panel_ld, 0, prods};
     {   // (it matters for a row-major A with a power-of-two row stride; applied to every layout so that the summation
         //  order -- and with it every bit of the result -- does not depend on the layout of A)
         static const int rot = getenv("LPD_X3W_ROTATE") ? atoi(getenv("LPD_X3W_ROTATE")) : 1;

@@ -347,8 +347,9 @@ class _LPDNetTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, x, *params):
-        if TRAIN_STORAGE == "bf16":      # bf16 storage: the dense products behind the kNN run split-bf16 in the forward as well
-            return _LPDNetTrainFn._forward(ctx, net, x, *params)
+        if TRAIN_STORAGE == "bf16":      # bf16 mode: the dense products behind the kNN take bf16 operands (one MFMA product)
+            with ops.bf16_gemm():
+                return _LPDNetTrainFn._forward(ctx, net, x, *params)
         with ops.train_forward_gemm():
             return _LPDNetTrainFn._forward(ctx, net, x, *params)
 
@@ -399,6 +400,13 @@ class _LPDNetTrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dfeat):
+        if ctx.bf16:
+            with ops.bf16_gemm():
+                return _LPDNetTrainFn._backward(ctx, dfeat)
+        return _LPDNetTrainFn._backward(ctx, dfeat)
+
+    @staticmethod
+    def _backward(ctx, dfeat):
         from . import engine
         net, S = ctx.net, _saved(ctx)
         B, N, M, k = ctx.dims
@@ -674,8 +682,10 @@ class _NetVLADTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, vlad, B, N, feat, *params):
-        if TRAIN_STORAGE == "bf16":
-            return _NetVLADTrainFn._forward(ctx, vlad, B, N, feat, *params)
+        ctx.bf16 = TRAIN_STORAGE == "bf16"
+        if ctx.bf16:      # the big per-point products (assignment, pooling) take bf16 operands; the B-row head products stay
+            with ops.bf16_gemm():      # on the exact / split path by their shapes (ops.gemm's policy: skinny outputs)
+                return _NetVLADTrainFn._forward(ctx, vlad, B, N, feat, *params)
         with ops.train_forward_gemm():
             return _NetVLADTrainFn._forward(ctx, vlad, B, N, feat, *params)
 
@@ -709,6 +719,13 @@ class _NetVLADTrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.bf16:
+            with ops.bf16_gemm():
+                return _NetVLADTrainFn._backward(ctx, dout)
+        return _NetVLADTrainFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         vlad, S = ctx.vlad, _saved(ctx)
         B, N, M, E, K, O, Bp = ctx.dims
         gc = vlad.context_gating

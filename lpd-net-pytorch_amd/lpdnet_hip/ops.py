@@ -130,6 +130,34 @@ _EXACT = _ExactState()
 TRAIN_FWD_BF16X3 = __import__("os").environ.get("LPD_TRAIN_FWD_X3", "0") == "1"
 
 
+class _FastState(__import__("threading").local):
+    depth = 0
+
+
+_FAST = _FastState()
+
+
+# Measured on the bf16 training step (B = 44, N = 4096): one product instead of three changes the fp32-operand GEMMs by
+# -0.4 ms of 18.6 (conv3 forward 0.70 -> 0.56 ms, its dX 0.57 -> 0.43; the k-major weight-gradient products not at all: they are
+# bound by staging, not by the MFMA) and costs another factor ~2 on the loss error, so it is off unless LPD_BF16_X1=1.
+BF16_SINGLE_PRODUCT = os.environ.get("LPD_BF16_X1", "0") == "1"
+
+
+class bf16_gemm:
+    """with ops.bf16_gemm(): (LPD_BF16_X1=1 only) split-bf16 products on fp32 operands run with ONE bf16 product per term
+    (operands rounded to bf16, fp32 accumulation) instead of three.  exact_gemm() regions inside stay exact."""
+
+    def __enter__(self):
+        self.on = BF16_SINGLE_PRODUCT
+        if self.on:
+            _FAST.depth += 1
+
+    def __exit__(self, *exc):
+        if self.on:
+            _FAST.depth -= 1
+        return False
+
+
 class exact_gemm:
     """with ops.exact_gemm(): every GEMM inside runs on the f32-input MFMA (the layers in front of the feature-space
     kNN: the neighbour indices must not depend on the GEMM precision switch)."""
@@ -234,17 +262,20 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
             and M >= 1024 and N >= 64 and N * K <= (1 << 22)
             and ((b_kmajor and K >= 128) or (X3W_FORWARD and K >= 256))):
         frags = _weight_frags(B, b_kmajor, N, K)
-        _call(f"gemmx3w[{M}x{N}x{K}]", lib.lpd_gemm_x3w, _ptr(A), lda, _ptr(frags), _ptr(out), ldc, M, N, K, _ptr(bias), _ptr(scale),
-              _ptr(shift), act, float(slope), int(bool(accumulate)), 0, 0, 0, 0, X3W_IMPL, _stream())
+        fast = _FAST.depth > 0
+        _call(f"gemmx{'1' if fast else '3'}w[{M}x{N}x{K}]", lib.lpd_gemm_x3w, _ptr(A), lda, _ptr(frags), _ptr(out), ldc, M, N, K, _ptr(bias), _ptr(scale),
+              _ptr(shift), act, float(slope), int(bool(accumulate)), 0, 0, 0, 0, X3W_IMPL | (16 if fast else 0), _stream())
         return out
     # split-bf16 where it is faster (measured, tools/gemm_bench.py): outputs of at least 128 x 128 with a row-major A
     # or with both operands k-major (weight gradients); skinny outputs (per-cloud rows, 64 clusters) stay on the f32-input MFMA
     # (the batched k-major pooling product act^T x, 64 clusters wide: 1 % of the eval step faster in split form)
     x3 = (GEMM_BF16X3 and not exact and _EXACT.depth == 0 and M >= 128 and (not a_kmajor or b_kmajor)
           and N >= (64 if (batched and a_kmajor and b_kmajor) else 128))
-    _call(f"gemm{'x3' if x3 else ''}[{M}x{N}x{K}]", lib.lpd_gemm_bf16x3 if x3 else lib.lpd_gemm, _ptr(A), _ptr(B), _ptr(out), M, N, K, lda, ldb, ldc, int(a_kmajor), int(b_kmajor), nb,
-                            sA, sB, sC, splits, _ptr(ws), _ptr(bias), _ptr(scale), _ptr(shift), act, float(slope),
-                            int(bool(accumulate)), 0, 0, 0, 0, _stream())
+    x1 = x3 and _FAST.depth > 0
+    _call(f"gemm{('x1' if x1 else 'x3') if x3 else ''}[{M}x{N}x{K}]", (lib.lpd_gemm_bf16x1 if x1 else lib.lpd_gemm_bf16x3) if x3 else lib.lpd_gemm,
+          _ptr(A), _ptr(B), _ptr(out), M, N, K, lda, ldb, ldc, int(a_kmajor), int(b_kmajor), nb,
+          sA, sB, sC, splits, _ptr(ws), _ptr(bias), _ptr(scale), _ptr(shift), act, float(slope),
+          int(bool(accumulate)), 0, 0, 0, 0, _stream())
     return out
 
 

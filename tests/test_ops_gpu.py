@@ -699,3 +699,22 @@ def test_bf16_storage_edge_kernels(cuda):
     ops.gather_sum_rows_bf16(dX16, gt, a)
     ops.gather_sum_rows(dX16.float(), gt, b)
     assert _rel(a, b) < 1e-6
+
+
+def test_single_product_bf16_gemm_entry(cuda):
+    """lpd_gemm_bf16x1 / lpd_gemm_x3w(impl | 16): operands rounded to bf16, fp32 accumulation -- equal to the product of the
+    bf16-rounded operands to fp32 accuracy, and ~4e-3 from the fp32 product."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    A = torch.randn(512, 256, generator=g).to(cuda)
+    W = (torch.randn(384, 256, generator=g) / 16).to(cuda)
+    ref_r = A.to(torch.bfloat16).double() @ W.to(torch.bfloat16).double().t()
+    ops._FAST.depth += 1
+    try:
+        out = ops.gemm(A, W, b_kmajor=False)                      # M >= 1024 not met: generic kernel
+        out_w = ops.gemm(torch.cat([A, A]), W, b_kmajor=False)    # M = 1024, K = 256: prepared-fragment kernel
+    finally:
+        ops._FAST.depth -= 1
+    assert _rel(out, ref_r) < 1e-5 and _rel(out_w[:512], ref_r) < 1e-5
+    assert 1e-4 < _rel(out, A.double() @ W.double().t()) < 2e-2
+    assert _rel(ops.gemm(A, W, b_kmajor=False), A.double() @ W.double().t()) < 2e-5      # outside the region: three products

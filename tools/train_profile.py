@@ -7,6 +7,8 @@ from oracle import synth
 from lpdnet_hip import ops, harness
 from util.PointNetVlad import PointNetVlad
 featnet = sys.argv[1] if len(sys.argv) > 1 else "lpdnet"
+from lpdnet_hip import autograd
+autograd.set_train_storage(sys.argv[2] if len(sys.argv) > 2 else "f32")
 dev = torch.device("cuda:0")
 N, bq, P, Ng = 4096, 2, 2, 18
 m = PointNetVlad(num_points=N, featnet=featnet).to(dev).train()
@@ -24,5 +26,5 @@ prof, ops.PROFILE = ops.PROFILE, None
 rows = sorted(((sum(a.elapsed_time(b) for a, b in evs), len(evs), name) for name, evs in prof.items()), reverse=True)
 tot = sum(r[0] for r in rows)
 print(f"step {t0.elapsed_time(t1):.2f} ms (with event overhead); kernels {tot:.2f} ms")
-for ms, n, name in rows[:40]:
+for ms, n, name in rows[:60]:
     print(f"{ms*1e3:9.1f} us  x{n:<3d} {name}")
