@@ -147,6 +147,19 @@ int lpd_edge_gather_max16(const float* P, int ldp, const float* Q, int ldq, cons
 int lpd_pack_idx16(const int32_t* idx, uint16_t* idx16, long long M, int k, void* stream);
 
 /*
+ * K-agg for LARGE clouds (N > 4096, e.g. BASELINE configs[4]: N = 16384, k = 64): a Z-order WINDOW of 4095 rows of the cloud's
+ * 8-channel slice in LDS, neighbours outside the window from L2 (csrc/lpd_edge_win.hip).  Same result, bit for bit, as
+ * lpd_edge_gather_max; operands as lpd_edge_gather_max16 (row-major or cloud-panel).  idx16: the RAW uint16 copy of the
+ * indices made by lpd_pack_idx16w (blocked by 32 points, quad i of point m at ((m/32)*(k/4) + i)*32 + m%32, uint2 units;
+ * ceil(M/32)*32*k uint16).  k in {20, 32, 64}; N <= 57344; the clouds should be Z-ordered (lpd_morton_sort) for the window to
+ * catch most neighbours -- correctness does not depend on it.
+ */
+int lpd_pack_idx16w(const int32_t* idx, uint16_t* idx16, long long M, int k, void* stream);
+int lpd_edge_gather_maxw(const float* P, int ldp, const float* Q, int ldq, const uint16_t* idx16, float* out, int ldo,
+                         const float* scale, const float* shift, int M, int N, int C, int k, int act, float slope, long long p_cloud,
+                         long long q_cloud, long long o_cloud, int panel_ld, void* stream);
+
+/*
  * Fused per-edge MLP: stage-1 BatchNorm+activation on the fly, stage-2 1x1 conv on the f32 MFMA,
  * BatchNorm + activation + max over k.  Replaces util/lpdnet_model.py:251-252 (convDG2 applied to
  * the un-maxed convDG1 output, then max) and the LPDNetOrign chains lpdnet_model.py:97-100,105-107:

@@ -44,6 +44,9 @@ SIGNATURES = {
     "lpd_edge_gather_max16": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int,
                               _c_int, _c_int, _c_f, _c_ll, _c_ll, _c_ll, _c_int, _c_p],
     "lpd_pack_idx16": [_c_p, _c_p, ctypes.c_longlong, _c_int, _c_p],
+    "lpd_pack_idx16w": [_c_p, _c_p, ctypes.c_longlong, _c_int, _c_p],
+    "lpd_edge_gather_maxw": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int,
+                             _c_int, _c_int, _c_f, _c_ll, _c_ll, _c_ll, _c_int, _c_p],
     "lpd_edge_mlp": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int,
                      _c_int, _c_int, _c_int, _c_int, _c_f, _c_ll, _c_int, _c_p],
     "lpd_edge_mlp_bf16x3": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int,

@@ -186,11 +186,24 @@ def _kagg_cloud_resident(idx, N, M, act):
             and M * 512 * 4 < 2 ** 32)
 
 
-def kagg(P, Q, idx, N, *, scale, shift, act, slope, out):
-    """K-agg dispatch: the cloud-resident kernel when an 8-channel slice of one cloud fits LDS (N <= 4096) and k = 20,
-    the direct gather otherwise (cfg5: N = 16384, k = 64).  Same bits either way."""
+KAGG_WINDOW = __import__("os").environ.get("LPD_KAGG_WINDOW", "1") != "0"
+
+
+def _kagg_windowed(idx, N, act):
+    """the windowed K-agg (Z-order window of 4095 rows in LDS + out-of-window neighbours from L2) is built for these shapes"""
+    return (KAGG_WINDOW and idx.shape[-1] in (20, 32, 64) and 64 <= N <= 57344
+            and act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY))
+
+
+def kagg(P, Q, idx, N, *, scale, shift, act, slope, out, idx16w=None):
+    """K-agg dispatch: the cloud-resident kernel when an 8-channel slice of one cloud fits LDS (N <= 4096) and k = 20; the
+    windowed kernel for larger clouds / k in {32, 64} (cfg5: N = 16384, k = 64); the direct gather otherwise.  Same bits."""
     if _kagg_cloud_resident(idx, N, P.shape[0], act):
         return ops.edge_gather_max16(P, Q, ops.pack_idx16(idx), N, scale=scale, shift=shift, act=act, slope=slope, out=out)
+    if _kagg_windowed(idx, N, act):
+        if idx16w is None:
+            idx16w = ops.pack_idx16w(idx)
+        return ops.edge_gather_maxw(P, Q, idx16w, N, scale=scale, shift=shift, act=act, slope=slope, out=out)
     return ops.edge_gather_max(P, Q, idx, N, scale=scale, shift=shift, act=act, slope=slope, out=out)
 
 

@@ -487,6 +487,45 @@ def edge_gather_max16(P, Q, idx16, N, *, scale=None, shift=None, act=ACT_NONE, s
     return out
 
 
+def pack_idx16w(idx):
+    """int32 kNN indices [..., k] (k in {20, 32, 64}) -> the blocked RAW uint16 copy the windowed K-agg reads."""
+    _req(idx, "idx", torch.int32)
+    k = idx.shape[-1]
+    idx = idx.reshape(-1, k).contiguous()
+    M = idx.shape[0]
+    out = torch.empty(((M + 31) // 32 * 32, k), dtype=torch.int16, device=idx.device)
+    lib = _lib.load()
+    _call("pack_idx16w", lib.lpd_pack_idx16w, _ptr(idx), _ptr(out), M, k, _stream())
+    return out
+
+
+def edge_gather_maxw(P, Q, idx16, N, *, scale=None, shift=None, act=ACT_NONE, slope=0.01, out=None):
+    """Windowed K-agg for large clouds (include/lpd_hip.h lpd_edge_gather_maxw): same result as edge_gather_max; idx16 from
+    pack_idx16w.  P, Q, out row-major [M, C] (column slices allowed) or cloud-panel views [B, C/8, N, 8]."""
+    _req(idx16, "idx16", torch.int16)
+    pan_p, pan_q = P.dim() == 4, Q is not None and Q.dim() == 4
+    M, C = (P.shape[0] * P.shape[2], P.shape[1] * 8) if pan_p else P.shape
+    k = idx16.shape[1]
+    if idx16.dim() != 2 or idx16.shape[0] != (M + 31) // 32 * 32 or not idx16.is_contiguous():
+        raise ValueError("edge_gather_maxw: idx16 must come from pack_idx16w of this graph")
+    if out is None:
+        out = torch.empty((M, C), dtype=torch.float32, device=P.device)
+    pan_o = out.dim() == 4
+    for t, pan, name in ((P, pan_p, "P"), (Q, pan_q, "Q"), (out, pan_o, "out")):
+        _req(t, name)
+        if t is not None and pan and (not _is_panels(t) or t.shape[1] * 8 != C or t.shape[2] != N or t.shape[0] * N != M):
+            raise ValueError(f"edge_gather_maxw: cloud-panel {name} must be a [B, C/8, N, 8] view")
+    ldp = 8 if pan_p else _rows(P, "P")
+    ldq = 0 if Q is None else (8 if pan_q else _rows(Q, "Q"))
+    ldo = 8 if pan_o else _rows(out, "out")
+    scale, shift = _vec(scale, "scale", C), _vec(shift, "shift", C)
+    lib = _lib.load()
+    _call(f"edge_gather_maxw[C={C}]", lib.lpd_edge_gather_maxw, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx16), _ptr(out), ldo,
+          _ptr(scale), _ptr(shift), M, N, C, k, act, float(slope), P.stride(0) if pan_p else 0, Q.stride(0) if pan_q else 0,
+          out.stride(0) if pan_o else 0, _panel_ld(P, Q, out), _stream())
+    return out
+
+
 def edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, *, act=ACT_LEAKY, slope=0.01, out=None, exact=False):
     """(docstring below)  `out` may be a cloud-panel view [B, CO/8, N, 8]."""
     return _edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, act, slope, out, exact)

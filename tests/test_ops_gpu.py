@@ -718,3 +718,40 @@ def test_single_product_bf16_gemm_entry(cuda):
     assert _rel(out, ref_r) < 1e-5 and _rel(out_w[:512], ref_r) < 1e-5
     assert 1e-4 < _rel(out, A.double() @ W.double().t()) < 2e-2
     assert _rel(ops.gemm(A, W, b_kmajor=False), A.double() @ W.double().t()) < 2e-5      # outside the region: three products
+
+
+@pytest.mark.parametrize("C,N,k,B,graph", [(256, 16384, 64, 1, "local"), (128, 5000, 20, 2, "local"), (256, 2048, 64, 2, "random"),
+                                           (64, 9000, 32, 1, "random"), (256, 4100, 64, 1, "local")])
+def test_windowed_kagg_is_bit_identical(cuda, C, N, k, B, graph):
+    """lpd_edge_gather_maxw (Z-order window of 4095 rows in LDS, out-of-window neighbours from L2) == lpd_edge_gather_max, bit for
+    bit: graphs whose neighbours are near in index (mostly LDS hits, misses at the window borders), uniformly random graphs
+    (almost every gather of a multi-window cloud is a miss), ragged last windows, one-window clouds, output into a column
+    slice, negative scales, the no-centre-term form."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + k)
+    M = B * N
+    if graph == "local":
+        off = torch.randint(-600, 601, (M, k), generator=g)
+        base = torch.arange(N).repeat(B).view(M, 1)
+        idx = (base + off).clamp_(0, N - 1).to(torch.int32)
+        idx[:, 0] = base[:, 0]
+    else:
+        idx = torch.randint(0, N, (M, k), generator=g, dtype=torch.int32)
+    idx = idx.to(cuda)
+    PQ = torch.randn(M, 2 * C, generator=g).to(cuda)
+    scale, shift = (torch.rand(C, generator=g) - 0.3).to(cuda), torch.randn(C, generator=g).to(cuda)
+    i16 = ops.pack_idx16w(idx)
+    for q in (PQ[:, C:], None):
+        want = ops.edge_gather_max(PQ[:, :C], q, idx, N, scale=scale, shift=shift, act=ops.ACT_LEAKY, slope=0.01)
+        buf = torch.full((M, C + 8), -7.0, device=cuda)
+        ops.edge_gather_maxw(PQ[:, :C], q, i16, N, scale=scale, shift=shift, act=ops.ACT_LEAKY, slope=0.01, out=buf[:, 4:4 + C])
+        assert torch.equal(buf[:, 4:4 + C], want)
+        assert (buf[:, :4] == -7.0).all() and (buf[:, 4 + C:] == -7.0).all()
+    if N % 128 == 0:      # cloud-panel operands
+        pq = ops.panels_empty(B, N, 2 * C, cuda)
+        pq[:, :C // 8] = ops.rows_to_panels(PQ[:, :C].contiguous(), B)
+        pq[:, C // 8:] = ops.rows_to_panels(PQ[:, C:].contiguous(), B)
+        out = ops.panels_empty(B, N, C, cuda)
+        ops.edge_gather_maxw(pq[:, :C // 8], pq[:, C // 8:], i16, N, scale=scale, shift=shift, act=ops.ACT_LEAKY, slope=0.01, out=out)
+        want = ops.edge_gather_max(PQ[:, :C], PQ[:, C:], idx, N, scale=scale, shift=shift, act=ops.ACT_LEAKY, slope=0.01)
+        assert torch.equal(ops.panels_to_rows(out), want)
