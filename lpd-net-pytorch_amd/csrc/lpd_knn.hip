@@ -856,12 +856,18 @@ constexpr int KNN7_WAVE_LDS_XYZ = KNN7_QCAP_XYZ * 64 * 8;
 // The same for 64 channels (a 64-term distance per tested tile, half per half-lane) measured WORSE than the table:
 // 627 us against 566 at two waves per SIMD, 703 us at three (168 VGPRs, spills) -- off.
 constexpr bool KNN7_ONFLY64 = false;
-template <int CP> struct Knn7Lds {
-    static constexpr bool ONFLY = CP == 2 || (CP == 32 && KNN7_ONFLY64);
-    static constexpr int QCAP = CP == 2 ? KNN7_QCAP_XYZ : KNN7_QCAP;
-    static constexpr int WAVE = CP == 2 ? KNN7_WAVE_LDS_XYZ : (ONFLY ? KNN7_QCAP * 64 * 8 : KNN7_WAVE_LDS);
-    static constexpr int QOFF = ONFLY ? 0 : KNN7_MAXT * 32 * 2;      // byte offset of the queue inside the wave's region
-    static constexpr int WAVES_PER_SIMD = CP == 2 ? 4 : 2;
+// Per-wave LDS of the best-first kernel.  ONFLY: the bound of a tile is recomputed from its centroid where the walk tests it
+// instead of being tabulated -- always for three coordinates (a dozen instructions), and for 64 channels when the table
+// ([tiles][32] bf16) would not fit: N > 4096.  KMAX > 20 (k up to 64: the stress configuration): 128 list registers per lane,
+// one wave per SIMD, and the wave's region must hold the two half-lists for the final merge (64 * KMAX * 8 bytes).
+template <int CP, int KMAX, bool ONFLY> struct Knn7Cfg {
+    static constexpr int QCAP = (CP == 2 && KMAX <= 20) ? KNN7_QCAP_XYZ : KNN7_QCAP;
+    static constexpr int QBYTES = QCAP * 64 * 8;
+    static constexpr int TBYTES = ONFLY ? 0 : KNN7_MAXT * 32 * 2;
+    static constexpr int MERGE = 64 * KMAX * 8;
+    static constexpr int WAVE = (TBYTES + QBYTES) > MERGE ? (TBYTES + QBYTES) : MERGE;
+    static constexpr int QOFF = TBYTES;      // byte offset of the queue inside the wave's region
+    static constexpr int WAVES_PER_SIMD = KMAX > 20 ? 1 : (CP == 2 ? 4 : 2);
 };
 
 // tile statistics: centroid (packed operand layout), |c|^2, radius (inflated), max |x|^2.  One wave per tile.
@@ -1021,8 +1027,8 @@ __device__ __forceinline__ void knn7_insert(float (&v)[KMAX], int (&id)[KMAX], f
 // WAVES: waves per workgroup.  A workgroup's LDS and wave slots stay taken until its slowest wave is done and the tile
 // counts of neighbouring waves differ (C = 64: mean 51, p90 69, max 89 tiles): single-wave workgroups at C = 64
 // (638 -> 607 us), four waves at C = 3 (shorter waves; the larger groups launch faster: 278 vs 287 us).
-template <int CP, int KMAX, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, Knn7Lds<CP>::WAVES_PER_SIMD) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
+template <int CP, int KMAX, int WAVES, bool ONFLY>
+__global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SIMD)) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
                                                              const float* __restrict__ cenp, const float* __restrict__ cnorm,
                                                              const float* __restrict__ rad, const float* __restrict__ txmax,
                                                              int32_t* __restrict__ idx, const int32_t* __restrict__ order,
@@ -1050,7 +1056,8 @@ __global__ __launch_bounds__(WAVES * 64, Knn7Lds<CP>::WAVES_PER_SIMD) void knn7_
     const float* radb = rad + (size_t)b * nt;
     const bool vec_ok = (N & 3) == 0;
     const bool vec_ok_t = (nt & 3) == 0;
-    using L = Knn7Lds<CP>;
+    using L = Knn7Cfg<CP, KMAX, ONFLY>;
+    static_assert(CP != 2 || ONFLY, "three coordinates: bounds on the fly");
     uint16_t* ubt = reinterpret_cast<uint16_t*>(smem7 + (size_t)wave * L::WAVE);                          // [MAXT][32] (CP > 2)
     float2* myq = reinterpret_cast<float2*>(smem7 + (size_t)wave * L::WAVE + L::QOFF) + lane;             // slot s at myq[s*64]
 
@@ -1073,7 +1080,7 @@ __global__ __launch_bounds__(WAVES * 64, Knn7Lds<CP>::WAVES_PER_SIMD) void knn7_
     float pd[16];
 
     // ---- bound table: pd of every query against every tile centroid (the centroids are a 'cloud' of nt points) ----
-    if (wave_ok && !Knn7Lds<CP>::ONFLY) {
+    if (wave_ok && !ONFLY) {
         const int nct = (nt + 31) / 32;
         for (int ct = 0; ct < nct; ++ct) {
             float4 r4[4];
@@ -1123,7 +1130,7 @@ __global__ __launch_bounds__(WAVES * 64, Knn7Lds<CP>::WAVES_PER_SIMD) void knn7_
                 const float dq = sqrtf(fmaxf(d2 - E0, 0.0f)) * 0.99999f;          // lower bound of |x_i - c_T|
                 const float lb = fmaxf(dq - radb[T], 0.0f);
                 ub = -(lb * lb) * 0.99999f + E0;                                  // upper bound of every computed pd in tile T
-            } else if constexpr (Knn7Lds<CP>::ONFLY) {   // this half-lane's CP channels, the other half by shuffle
+            } else if constexpr (ONFLY) {   // this half-lane's CP channels, the other half by shuffle
                 const float* ct = cenb + (size_t)T * (2 * CP) + h * CP;
                 float part = 0.0f;
 #pragma unroll
@@ -1281,10 +1288,11 @@ inline size_t knn7_extra_floats(int B, int N, int CP)
     return (size_t)B * nt * (2 * CP + 3 + 2) + 16;   // + predicted tile counts and launch order (int32 each)
 }
 
-template <int CP, int KMAX>
+template <int CP, int KMAX, bool ONFLY>
 int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg = 0)
 {
-    static_assert(Knn7Lds<CP>::WAVE >= 64 * KMAX * 8, "merge region must fit the wave's LDS region");
+    using L = Knn7Cfg<CP, KMAX, ONFLY>;
+    static_assert(L::WAVE >= 64 * KMAX * 8, "merge region must fit the wave's LDS region");
     const int nt = (N + 31) / 32;
     float* xp = const_cast<float*>(xx) + (size_t)B * N;
     float* cenp = xp + (size_t)B * N * 2 * CP;
@@ -1306,8 +1314,8 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
         LPD_CHECK_LAUNCH("lpd_knn(launch order)");
     }
     {
-        size_t lds = (size_t)WAVES * Knn7Lds<CP>::WAVE;
-        auto kern = knn7_kernel<CP, KMAX, WAVES>;
+        size_t lds = (size_t)WAVES * L::WAVE;
+        auto kern = knn7_kernel<CP, KMAX, WAVES, ONFLY>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(WAVES * 64), lds, stream, (const float*)xp, xx, (const float*)cenp,
                            (const float*)cnorm, (const float*)rad, (const float*)txmax, idx, (const int32_t*)(lpt ? order : nullptr),
@@ -1315,6 +1323,18 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
         LPD_CHECK_LAUNCH("lpd_knn(best-first)");
     }
     return LPD_OK;
+}
+
+// best-first dispatch: the tabulated-bound kernel for N <= 4096, k <= 20 (round 1); bounds on the fly and 64-entry lists for
+// larger clouds and neighbourhoods (BASELINE configs[4]: N = 16384, k = 64)
+constexpr int KNN7_MAXN = 65536;
+inline bool knn7_applies(int C, int N, int k) { return C <= 64 && k <= 64 && N <= KNN7_MAXN; }
+inline int knn7_dispatch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg)
+{
+    const bool small = k <= 20 && N <= KNN7_MAXT * 32;
+    if (C <= 4) return k <= 20 ? knn7_launch<2, 20, true>(x, xx, idx, B, C, N, k, stream, dbg) : knn7_launch<2, 64, true>(x, xx, idx, B, C, N, k, stream, dbg);
+    if (small) return knn7_launch<32, 20, false>(x, xx, idx, B, C, N, k, stream, dbg);
+    return k <= 20 ? knn7_launch<32, 20, true>(x, xx, idx, B, C, N, k, stream, dbg) : knn7_launch<32, 64, true>(x, xx, idx, B, C, N, k, stream, dbg);
 }
 
 template <int CP>
@@ -1391,10 +1411,8 @@ extern "C" int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
     LPD_CHECK_ARG(B <= 65535, "lpd_knn: B=%d exceeds grid.y", B);
     hipLaunchKernelGGL(knn_sumsq_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xx_ws, C, N);
     LPD_CHECK_LAUNCH("lpd_knn(sumsq)");
-    if (((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && k <= 20 && C <= 64 && N <= KNN7_MAXT * 32) {   // best-first (5: statistics)
-        if (C <= 4) return knn7_launch<2, 20>(x, xx_ws, idx, B, C, N, k, stream, impl == 5);
-        return knn7_launch<32, 20>(x, xx_ws, idx, B, C, N, k, stream, impl == 5);
-    }
+    if (((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && knn7_applies(C, N, k))   // best-first (5: statistics)
+        return knn7_dispatch(x, xx_ws, idx, B, C, N, k, stream, impl == 5);
     if (impl == 0 || impl == 4) {   // ascending scan (larger clouds, k > 20; impl 4: forced, for A/B timing)
         if (C <= 4) return knn3_dispatch_k<2>(x, xx_ws, idx, B, C, N, k, stream);
         if (C <= 64) return knn3_dispatch_k<32>(x, xx_ws, idx, B, C, N, k, stream);
@@ -1430,10 +1448,8 @@ extern "C" int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k,
     if (C <= 4) hipLaunchKernelGGL(knn_prep_pm_kernel<2>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);
     else hipLaunchKernelGGL(knn_prep_pm_kernel<32>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);
     LPD_CHECK_LAUNCH("lpd_knn_pm(prep)");
-    if (((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && k <= 20 && N <= KNN7_MAXT * 32) {
-        if (C <= 4) return knn7_launch<2, 20>(nullptr, ws, idx, B, C, N, k, stream, impl == 5);
-        return knn7_launch<32, 20>(nullptr, ws, idx, B, C, N, k, stream, impl == 5);
-    }
+    if (((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && knn7_applies(C, N, k))
+        return knn7_dispatch(nullptr, ws, idx, B, C, N, k, stream, impl == 5);
     if (C <= 4) return knn3_dispatch_k<2>(nullptr, ws, idx, B, C, N, k, stream);
     return knn3_dispatch_k<32>(nullptr, ws, idx, B, C, N, k, stream);
 }

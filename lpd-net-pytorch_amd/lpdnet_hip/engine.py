@@ -180,10 +180,13 @@ def _side_stream(device):
     return st
 
 
+def _resident_shape(k, N, M, act):
+    return k == 20 and N <= 4096 and act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY) and M * 512 * 4 < 2 ** 32
+
+
 def _kagg_cloud_resident(idx, N, M, act):
     """the cloud-resident K-agg kernel is built for this shape (an 8-channel slice of one cloud fits LDS, k = 20)"""
-    return (idx.shape[-1] == 20 and N <= 4096 and act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY)
-            and M * 512 * 4 < 2 ** 32)
+    return _resident_shape(idx.shape[-1], N, M, act)
 
 
 KAGG_WINDOW = __import__("os").environ.get("LPD_KAGG_WINDOW", "1") != "0"
@@ -217,7 +220,7 @@ def lpdnet_features_eval(net, x, reorder=True):
     xyz = x.view(M, 3)
     p = xyz
     side_job = None
-    if SIDE_STREAM and PANEL_LAYOUT and N % 128 == 0 and k == 20 and N <= 4096:
+    if SIDE_STREAM and PANEL_LAYOUT and N % 128 == 0 and _resident_shape(k, N, M, act):
         # The static graph in Cartesian space depends on the input alone: its kNN (wave-slot-bound, two waves per SIMD) runs
         # on a second HIP stream next to the per-point layers and the feature-space kNN and is joined in front of the SN1 K-agg.
         main, side = torch.cuda.current_stream(), _side_stream(x.device)
@@ -254,7 +257,11 @@ def lpdnet_features_eval(net, x, reorder=True):
     idx_f = _knn_rows(f, B, N, 64, k)
     if pq is None:
         pq = ops.linear(f, wdg1)                                                          # [M,256] = [P | Q]
-    if PANEL_LAYOUT and N % 128 == 0 and _kagg_cloud_resident(idx_f, N, M, act):
+    resident = _kagg_cloud_resident(idx_f, N, M, act)
+    if PANEL_LAYOUT and N % 128 == 0 and (resident or _kagg_windowed(idx_f, N, act)):
+        # K-agg on cloud panels: the cloud-resident kernel (N <= 4096, k = 20) or the windowed one (larger clouds, k = 64)
+        pack = ops.pack_idx16 if resident else ops.pack_idx16w
+        kagg_p = ops.edge_gather_max16 if resident else ops.edge_gather_maxw
         # [x1 | x2 | x3] and the SN1 projections live in CLOUD-PANEL buffers [B, C/8, N, 8]: the cloud-resident K-agg kernel
         # streams one 8-channel slice of a whole cloud per workgroup, which in this layout is ONE contiguous 32*N-byte run
         # (row-major: N pieces of 32 bytes, ~4x slower through L1/L2), while a GEMM block's 128 rows x K still sit inside one
@@ -270,9 +277,9 @@ def lpdnet_features_eval(net, x, reorder=True):
             for t in (idx_f, cat):
                 t.record_stream(side)
             with torch.cuda.stream(side):
-                ops.edge_gather_max16(pq[:, :128], pq[:, 128:], ops.pack_idx16(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
+                kagg_p(pq[:, :128], pq[:, 128:], pack(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
         else:
-            ops.edge_gather_max16(pq[:, :128], pq[:, 128:], ops.pack_idx16(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
+            kagg_p(pq[:, :128], pq[:, 128:], pack(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
         ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope, out=cat[:, 16:32])
         pq3 = ops.gemm(cat[:, 16:32], split_edge_weight(net.convSN1, "cat_nc"), b_kmajor=False, a_panels=True, out_panels=True)
         if side_job is not None:
@@ -283,8 +290,8 @@ def lpdnet_features_eval(net, x, reorder=True):
             i16_x.record_stream(main)
         else:
             idx_x = _knn_rows(xyz, B, N, 3, k)      # static graph in Cartesian space (raw xyz even when t3d, :226,255)
-            i16_x = ops.pack_idx16(idx_x)
-        ops.edge_gather_max16(pq3[:, 0:32], pq3[:, 32:64], i16_x, N, scale=s3, shift=b3, act=act, slope=slope, out=cat[:, 32:64])
+            i16_x = pack(idx_x)
+        kagg_p(pq3[:, 0:32], pq3[:, 32:64], i16_x, N, scale=s3, shift=b3, act=act, slope=slope, out=cat[:, 32:64])
         if DEBUG_AUX is not None:
             DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=ops.panels_to_rows(cat))
         feat = ops.gemm(cat, _w2d(net.conv3_lpd), b_kmajor=False, a_panels=True, scale=sc, shift=bc, act=act, slope=slope)

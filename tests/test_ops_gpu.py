@@ -36,8 +36,8 @@ def test_knn_bit_exact_vs_oracle(cuda, C, N, k, B, impl):
     3: LDS-staged stream + admission threshold + queued selection; 6: best-first tile order with exact skip bounds."""
     if impl == 1 and (k > 20 or N > 4096):
         pytest.skip("VALU cross-check path is built for k <= 20 and is slow")
-    if impl == 6 and (k > 20 or C > 64 or N > 4096):
-        pytest.skip("the best-first kernel is built for k <= 20, C <= 64, N <= 4096")
+    if impl == 6 and (k > 64 or C > 64):
+        pytest.skip("the best-first kernel is built for k <= 64, C <= 64")
     if impl == 3 and (k > 20 or C > 64):
         pytest.skip("impl 3 is built for k <= 20, C <= 64")
     ops = _ops()
@@ -60,21 +60,24 @@ def test_knn_bit_exact_vs_oracle(cuda, C, N, k, B, impl):
 
 
 @pytest.mark.parametrize("impl", [0, 4, 2])
-@pytest.mark.parametrize("C,N", [(3, 1024), (3, 4096), (64, 700)])
-def test_knn_exact_ties_lower_index_first(cuda, C, N, impl):
+@pytest.mark.parametrize("C,N,k", [(3, 1024, 20), (3, 4096, 20), (64, 700, 20), (3, 6000, 64), (64, 5000, 64), (64, 4500, 20), (3, 900, 40)])
+def test_knn_exact_ties_lower_index_first(cuda, C, N, k, impl):
     """Clouds on a coarse lattice with duplicated points: thousands of exact pd ties, inside the lists and at the k-th
     boundary.  Every row must equal the oracle's (value descending, lower index first) -- for the best-first kernel this
-    exercises both insertion rules (candidates from tiles above / below the wave's own)."""
+    exercises both insertion rules (candidates from tiles above / below the wave's own); the k = 64 / N > 4096 cases run its
+    large-cloud instantiations (bounds on the fly, 64-entry lists)."""
+    if impl == 2 and k > 20 and C > 4:
+        pytest.skip("first-generation kernel: slow at this size")
     ops = _ops()
     g = np.random.default_rng(C + N)
     x_pm = (g.integers(-4, 5, size=(2, N, C)) / 4.0).astype(np.float32)
     x_pm[:, N // 2:N // 2 + 40] = x_pm[:, 3:43]                       # exact duplicates far apart in index
-    oidx, _ = orc.knn_np(x_pm, 20)
+    oidx, _ = orc.knn_np(x_pm, k)
     x_cm = torch.from_numpy(np.ascontiguousarray(x_pm.transpose(0, 2, 1))).to(cuda)
-    got = ops.knn(x_cm, 20, impl=impl).cpu().numpy()
+    got = ops.knn(x_cm, k, impl=impl).cpu().numpy()
     assert (got == oidx).all(), f"{(got != oidx).any(-1).sum()} rows differ"
     if impl == 0:
-        got_pm = ops.knn_pm(torch.from_numpy(x_pm.reshape(-1, C)).to(cuda).contiguous(), 2, N, 20).cpu().numpy()
+        got_pm = ops.knn_pm(torch.from_numpy(x_pm.reshape(-1, C)).to(cuda).contiguous(), 2, N, k).cpu().numpy()
         assert (got_pm == oidx).all()
 
 
