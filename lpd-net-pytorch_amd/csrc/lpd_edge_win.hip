@@ -13,9 +13,8 @@
 // 4095 points of the window take their neighbours from LDS when they fall inside it (a 16-bit byte offset, one SDWA add per
 // gather) and from global memory / L2 otherwise.  Row 4095 of each image holds -inf: an out-of-window index is CLAMPED onto
 // it (off = min(j - w0, 4095) * 16, packed 16-bit arithmetic on index pairs), so the LDS phase is branch-free; lanes that saw
-// a clamped index then run the miss phase, which re-walks the index quads and loads the missing row pieces (a lane without
-// a miss at a slot re-loads its FIRST neighbour's piece, a member of the set either way, so no select is needed and the
-// four loads of a quad are in flight together).  Bit-identical to lpd_edge_gather_max (max / min are exact).
+// a clamped index then run the miss phase, which re-walks the index quads and loads the missing row pieces (exec-masked,
+// the four loads of a quad in flight together).  Bit-identical to lpd_edge_gather_max (max / min are exact).
 #include "lpd_common.h"
 #include <math.h>
 
@@ -129,9 +128,15 @@ __global__ __launch_bounds__(1024) void edge_gather_max_window_kernel(WinArgs g,
         }
         const bool lane_miss = far.x >= KW_ROWS || far.y >= KW_ROWS;
         if (__any(lane_miss)) {
-            // ---- miss phase: neighbours outside the window, from global memory (L2).  A lane without a miss at a slot loads
-            // its first neighbour's piece again (a member of the set, so the maximum is unchanged) ----
-            const unsigned j_first = ix[0].x & 0xffffu;
+            // ---- miss phase: neighbours outside the window, from global memory (L2), only by the lanes that miss them: the
+            // other lanes of the quad keep a neutral element (negs: sg * negs = -inf); the four loads of a quad are in flight
+            // together.  Measured at B = 16, N = 16384, k = 64 (tools/kaggw_bench.py; 7.8 % of the gathers miss): hit phase alone
+            // 400 us (an all-hit graph: the LDS gather floor, bank conflicts included), + 340 us for the misses = one memory round
+            // trip per quad of a wave with a border point.  Tried and dropped: every lane loading at every slot (a member of
+            // its own set where it had no miss): same time on panels, slower on row-major operands; per-point miss lists
+            // compacted into LDS and walked four or eight at a time: 1.4 ms (points near a window corner miss more than the
+            // list holds and fall back, the list walk is as serial as the quads). ----
+            const float4 negs = make_float4(-INFINITY * sg.x, -INFINITY * sg.y, -INFINITY * sg.z, -INFINITY * sg.w);
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
                 const unsigned jj[4] = {ix[i].x & 0xffffu, ix[i].x >> 16, ix[i].y & 0xffffu, ix[i].y >> 16};
@@ -142,7 +147,10 @@ __global__ __launch_bounds__(1024) void edge_gather_max_window_kernel(WinArgs g,
                 if (!__any(anym)) continue;
                 float4 p[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) p[e] = *reinterpret_cast<const float4*>(Pc + (size_t)(ms[e] ? jj[e] : j_first) * ldp);
+                for (int e = 0; e < 4; ++e) {
+                    p[e] = negs;
+                    if (ms[e]) p[e] = *reinterpret_cast<const float4*>(Pc + (size_t)jj[e] * ldp);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v.x = fmaxf(v.x, sg.x * p[e].x); v.y = fmaxf(v.y, sg.y * p[e].y);
