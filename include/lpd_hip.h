@@ -244,6 +244,15 @@ int lpd_metric_loss(const float* q, long long q_sb, const float* pos, long long 
 int lpd_retrieval_topk(const float* S, const float* Q, int ldq, const float* D, int ldd, int nq, int ndb, int dim, int k,
                        int32_t* idx, float* dist, float* ws, void* stream);
 
+/*
+ * Batched hard-negative selection (util/data.py:103-115, called for every item of the second training phase with 4000 sampled
+ * negatives: a KDTree per query there): for query b, among the rows cand[b][0..nc) of the latent-vector table, the k nearest to
+ * Q[b] by squared Euclidean distance, nearest first, as POSITIONS into cand[b] (ties -> lower position); dist [bq][k].
+ *   table [n_items][ldt] (the descriptors of the whole training set, kept on the device), Q [bq][ldq], cand [bq][nc] int32.
+ */
+int lpd_hard_negatives(const float* table, long long ldt, const float* Q, long long ldq, const int32_t* cand, int bq, int nc, int dim,
+                       int k, int32_t* pos, float* dist, void* stream);
+
 /* float64 -> float32, n elements (submap files are float64, loading_pointclouds.py:26-35; evaluate.py:115 `.float()`). */
 int lpd_f64_to_f32(const double* in, float* out, long long n, void* stream);
 

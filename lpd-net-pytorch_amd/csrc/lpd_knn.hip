@@ -852,6 +852,7 @@ constexpr int KNN7_WAVE_LDS = KNN7_MAXT * 32 * 2 + KNN7_QCAP * 64 * 8;   // bf16
 // instead of being tabulated, and the queue holds 20 slots: 10 KiB per wave, so that LDS admits the four waves per SIMD
 // the kernel's 120 VGPRs allow (the search is wait-bound: at 20 KiB it ran two).
 constexpr int KNN7_QCAP_XYZ = 20;
+constexpr int KNN7_QCAP_BIG = 48;
 constexpr int KNN7_WAVE_LDS_XYZ = KNN7_QCAP_XYZ * 64 * 8;
 // The same for 64 channels (a 64-term distance per tested tile, half per half-lane) measured WORSE than the table:
 // 627 us against 566 at two waves per SIMD, 703 us at three (168 VGPRs, spills) -- off.
@@ -861,7 +862,9 @@ constexpr bool KNN7_ONFLY64 = false;
 // ([tiles][32] bf16) would not fit: N > 4096.  KMAX > 20 (k up to 64: the stress configuration): 128 list registers per lane,
 // one wave per SIMD, and the wave's region must hold the two half-lists for the final merge (64 * KMAX * 8 bytes).
 template <int CP, int KMAX, bool ONFLY> struct Knn7Cfg {
-    static constexpr int QCAP = (CP == 2 && KMAX <= 20) ? KNN7_QCAP_XYZ : KNN7_QCAP;
+    // 64-entry lists: the region is 32 KiB for the merge anyway, so the queue may be twice as deep -- fewer, better balanced
+    // drains (a drain runs max-over-lanes iterations of a 64-slot insertion)
+    static constexpr int QCAP = KMAX > 20 ? KNN7_QCAP_BIG : ((CP == 2) ? KNN7_QCAP_XYZ : KNN7_QCAP);
     static constexpr int QBYTES = QCAP * 64 * 8;
     static constexpr int TBYTES = ONFLY ? 0 : KNN7_MAXT * 32 * 2;
     static constexpr int MERGE = 64 * KMAX * 8;

@@ -325,6 +325,63 @@ __global__ __launch_bounds__(256) void retrieval_topk_kernel(const float* __rest
     }
 }
 
+// Batched hard-negative selection (util/data.py:103-115 inside every __getitem__ of the second training phase: a KDTree over
+// the 4000 sampled negatives of ONE query per call): query b has its OWN candidate list cand[b][0..nc) (row numbers of the
+// latent-vector table); the hard_neg_num candidates nearest to its descriptor come out nearest first, as POSITIONS into
+// cand[b].  One workgroup per query: squared distances (direct form sum (t - q)^2, one wave per candidate row) into LDS, then
+// k rounds of a block-wide lexicographic (distance, position) arg-min.
+__global__ __launch_bounds__(256) void hard_negatives_kernel(const float* __restrict__ table, long long ldt, const float* __restrict__ Q,
+                                                             long long ldq, const int32_t* __restrict__ cand, int nc, int dim, int k,
+                                                             int32_t* __restrict__ pos, float* __restrict__ dist)
+{
+    extern __shared__ float dsm[];          // [nc] distances, then [8] reduction scratch
+    __shared__ float rv[4];
+    __shared__ int rj[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* q = Q + (long long)b * ldq;
+    const int32_t* cb = cand + (long long)b * nc;
+    for (int c = wave; c < nc; c += 4) {
+        const float* row = table + (long long)cb[c] * ldt;
+        float s = 0.f;
+        for (int d = lane; d < dim; d += 64) { const float t = row[d] - q[d]; s = fmaf(t, t, s); }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (lane == 0) dsm[c] = s;
+    }
+    __syncthreads();
+    float last_v = -INFINITY;
+    int last_j = -1;
+    for (int r = 0; r < k; ++r) {
+        float best_v = INFINITY;
+        int best_j = 0x7fffffff;
+        for (int j = tid; j < nc; j += 256) {
+            const float v = dsm[j];
+            const bool after_last = v > last_v || (v == last_v && j > last_j);
+            const bool better = v < best_v || (v == best_v && j < best_j);
+            if (after_last && better) { best_v = v; best_j = j; }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = __shfl_xor(best_v, m, 64);
+            const int oj = __shfl_xor(best_j, m, 64);
+            if (ov < best_v || (ov == best_v && oj < best_j)) { best_v = ov; best_j = oj; }
+        }
+        if (lane == 0) { rv[wave] = best_v; rj[wave] = best_j; }
+        __syncthreads();
+        best_v = rv[0]; best_j = rj[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (rv[w] < best_v || (rv[w] == best_v && rj[w] < best_j)) { best_v = rv[w]; best_j = rj[w]; }
+        if (tid == 0) {
+            pos[(long long)b * k + r] = best_j == 0x7fffffff ? -1 : best_j;
+            dist[(long long)b * k + r] = best_v;
+        }
+        last_v = best_v;
+        last_j = best_j;
+        __syncthreads();
+    }
+}
+
 // float64 -> float32 (round to nearest even, what numpy's astype / torch's .float() do): the Oxford submaps are stored as
 // 4096 x 3 float64 (loading_pointclouds.py:26-35); the raw bytes go over PCIe and are narrowed here.
 __global__ void f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, long long n)
@@ -501,6 +558,19 @@ extern "C" int lpd_retrieval_topk(const float* S, const float* Q, int ldq, const
     hipLaunchKernelGGL(retrieval_topk_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, S, (const float*)qn, (const float*)dn, nq, ndb, k, idx,
                        dist);
     LPD_CHECK_LAUNCH("lpd_retrieval_topk");
+    return LPD_OK;
+}
+
+extern "C" int lpd_hard_negatives(const float* table, long long ldt, const float* Q, long long ldq, const int32_t* cand, int bq, int nc,
+                                  int dim, int k, int32_t* pos, float* dist, void* stream_)
+{
+    LPD_CHECK_ARG(table && Q && cand && pos && dist, "lpd_hard_negatives: null pointer");
+    LPD_CHECK_ARG(bq > 0 && nc > 0 && dim > 0 && k > 0 && k <= nc, "lpd_hard_negatives: bad dims bq=%d nc=%d dim=%d k=%d", bq, nc, dim, k);
+    LPD_CHECK_ARG(nc <= 36864, "lpd_hard_negatives: nc=%d candidates exceed the LDS distance table (36864)", nc);
+    const size_t lds = (size_t)nc * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)hard_negatives_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(hard_negatives_kernel, dim3(bq), dim3(256), lds, (hipStream_t)stream_, table, ldt, Q, ldq, cand, nc, dim, k, pos, dist);
+    LPD_CHECK_LAUNCH("lpd_hard_negatives");
     return LPD_OK;
 }
 

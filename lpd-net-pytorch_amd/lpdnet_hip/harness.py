@@ -150,6 +150,52 @@ def load_pretrained(model, path, optimizer=None, map_location="cpu"):
     return blob["epoch"] + 1, blob["iter"]
 
 
+def update_vectors(model, clouds, batch_num, device=None):
+    """util/data.py:277-354: re-embed the WHOLE training set with the current weights (eval mode, no grad) into the
+    latent-vector table the hard-negative mining searches; train mode afterwards.  clouds [n, N, 3] (array-like, float64 or
+    float32; the reference's TRAINING_POINT_CLOUD); batch_num = eval_batch_size * (1 + positives + negatives) clouds per
+    forward (:291).  The reference runs the tail (n % batch_num clouds) one cloud per forward; eval-mode descriptors do not
+    depend on the batch composition, so the tail is one forward here.  Returns the table as a CUDA tensor [n, D]: it stays on
+    the device for get_hard_negatives_batched (the reference keeps a numpy array and rebuilds a KDTree per item)."""
+    was_training = model.training
+    model.eval()
+    dev = next(model.parameters()).device if device is None else device
+    clouds = np.asarray(clouds)
+    outs = []
+    try:
+        with torch.no_grad():
+            for s in range(0, clouds.shape[0], batch_num):
+                chunk = torch.from_numpy(np.ascontiguousarray(clouds[s:s + batch_num])).to(dev)
+                outs.append(model(chunk.float().unsqueeze(1)))
+    finally:
+        model.train()          # the reference leaves the model in train mode (:345)
+    if not was_training:
+        model.eval()
+    return torch.cat(outs, dim=0) if outs else torch.zeros((0, 0), device=dev)
+
+
+def get_hard_negatives_batched(query_vecs, random_negs, hard_neg_num, latent_vectors):
+    """The selection step of util/data.py:103-115 for a whole batch of queries in ONE launch: query b (descriptor
+    query_vecs[b]) has its own list random_negs[b] of sampled negatives (item numbers into the latent-vector table, all lists
+    of one length, 4000 in the reference); returns for every query the hard_neg_num items nearest to it, nearest first, as a
+    list of lists of item numbers.  latent_vectors: the table from update_vectors (CUDA tensor) or a numpy array."""
+    from . import ops
+    if isinstance(latent_vectors, torch.Tensor) and latent_vectors.is_cuda:
+        table = latent_vectors
+    else:
+        table = torch.as_tensor(np.ascontiguousarray(latent_vectors), dtype=torch.float32,
+                                device=torch.device("cuda", torch.cuda.current_device()))
+    cand_np = np.asarray(random_negs, dtype=np.int32)
+    if cand_np.ndim != 2:
+        raise ValueError("get_hard_negatives_batched: random_negs must be [bq, n_sampled] (equal-length lists)")
+    cand = torch.from_numpy(cand_np).to(table.device)
+    q = torch.as_tensor(np.asarray(query_vecs.detach().cpu() if isinstance(query_vecs, torch.Tensor) else query_vecs, dtype=np.float32),
+                        device=table.device).reshape(cand_np.shape[0], -1)
+    pos, _ = ops.hard_negatives(table.float().contiguous(), q.contiguous(), cand, int(hard_neg_num))
+    pos = pos.cpu().numpy()
+    return [[int(cand_np[b, j]) for j in pos[b]] for b in range(cand_np.shape[0])]
+
+
 def get_random_hard_negatives(query_vec, random_negs, hard_neg_num, latent_vectors):
     """util/data.py:103-115: among the training items `random_negs` (indices into the latent-vector table), the
     `hard_neg_num` whose descriptors are nearest to `query_vec`, nearest first, as a list of item indices.

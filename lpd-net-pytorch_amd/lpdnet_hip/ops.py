@@ -1095,6 +1095,23 @@ def retrieval_topk(Q, D, k):
     return idx, dist
 
 
+def hard_negatives(table, Q, cand, k):
+    """For every query row Q[b]: the k rows of `table` nearest to it among cand[b] (int32 [bq, nc] row numbers), nearest first
+    -> (positions into cand[b] int32 [bq, k], squared distances [bq, k]).  One launch for the whole batch."""
+    ldt, ldq = _rows(table, "table"), _rows(Q, "Q")
+    _req(cand, "cand", torch.int32)
+    if cand.dim() != 2 or cand.shape[0] != Q.shape[0] or table.shape[1] != Q.shape[1]:
+        raise ValueError("hard_negatives: cand must be [bq, nc] and table / Q must share the descriptor size")
+    cand = cand.contiguous()
+    bq, nc = cand.shape
+    pos = torch.empty((bq, k), dtype=torch.int32, device=Q.device)
+    dist = torch.empty((bq, k), dtype=torch.float32, device=Q.device)
+    lib = _lib.load()
+    _call("hard_negatives", lib.lpd_hard_negatives, _ptr(table), ldt, _ptr(Q), ldq, _ptr(cand), bq, nc, Q.shape[1], k, _ptr(pos), _ptr(dist),
+          _stream())
+    return pos, dist
+
+
 def f64_to_f32(x64, out=None):
     """float64 CUDA tensor -> float32 (same shape), round to nearest even."""
     _req(x64, "x", torch.float64)

@@ -334,6 +334,38 @@ def test_random_hard_negatives_match_the_kdtree_form(cuda):
         assert harness.get_random_hard_negatives(query, negs, 10, dev_table) == want
 
 
+def test_update_vectors_and_batched_hard_negatives(cuda):
+    """harness.update_vectors (util/data.py:277-354: the whole training set re-embedded in eval mode, train mode afterwards,
+    ragged tail) feeding harness.get_hard_negatives_batched (one launch for a [bq, 4000] batch of candidate lists) against
+    the reference's per-item formulation (sklearn KDTree over the sampled negatives' latent vectors)."""
+    import numpy as np
+    from sklearn.neighbors import KDTree
+    from lpdnet_hip import harness
+    N = 256
+    m, sd = _model("lpdnet", N, cuda)
+    m.train()
+    clouds = synth.cloud(41, 23, N).astype(np.float64)                       # 23 training submaps, batches of 6 + a tail of 5
+    table = harness.update_vectors(m, clouds, batch_num=6)
+    assert m.training and table.is_cuda and table.shape == (23, 256)
+    with torch.no_grad():
+        ref = orc.pointnetvlad_forward(sd, torch.from_numpy(clouds).float().unsqueeze(1), featnet="lpdnet", train=False)
+    assert _norm_rel(table, ref) < DESC_TOL
+    # selection on a big synthetic table (the 23-item one is too small for 4000 sampled negatives)
+    g = np.random.default_rng(6)
+    big = g.standard_normal((7000, 256)).astype(np.float32)
+    big /= np.linalg.norm(big, axis=1, keepdims=True)
+    dev_big = torch.from_numpy(big).to(cuda)
+    bq = 5
+    negs = [g.choice(len(big), size=4000, replace=False).tolist() for _ in range(bq)]
+    queries = big[g.integers(len(big), size=bq)] + 0.05 * g.standard_normal((bq, 256)).astype(np.float32)
+    got = harness.get_hard_negatives_batched(queries, negs, 10, dev_big)
+    for b in range(bq):
+        want = np.array(negs[b])[KDTree(big[negs[b]]).query(queries[b:b + 1], k=10)[1][0]].tolist()
+        assert got[b] == want
+        assert harness.get_random_hard_negatives(queries[b], negs[b], 10, dev_big) == want       # the one-query call agrees
+    assert harness.get_hard_negatives_batched(torch.from_numpy(queries).to(cuda), negs, 10, big) == got
+
+
 def test_submap_stream_and_latent_vectors_from_files(cuda, tmp_path):
     """ingest.SubmapStream: float64 submap files -> pinned staging -> side-stream copy -> float32 on the GPU, identical to
     np.fromfile(...).astype(float32) of the valid files in order, ragged tail, wrong-size files skipped; and

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
 from oracle import synth
 from lpdnet_hip import ops
-B, N, k = 32, 4096, 20
+B, N, k = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (32, 4096, 20)))
 x = torch.from_numpy(synth.cloud(1234, B, N)).unsqueeze(1).cuda()
 xs = ops.morton_sort(x)
 for name, feat in (("xyz", ops.transpose(xs.view(B, N, 3))), ("feat64", None)):
