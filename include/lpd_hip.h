@@ -235,6 +235,11 @@ int lpd_metric_loss(const float* q, long long q_sb, const float* pos, long long 
                     int bq, int P, int Ng, int D, float m1, float m2, int use_min, int lazy, int ignore_zero, int quad,
                     float* loss, float* minmax, float* gq, float* gpos, float* gneg, float* gother, void* stream);
 
+/* Backward of best_pos_distance (loss/pointnetvlad_loss.py:6-12) given the gradients of (min_pos, max_pos) [bq] each:
+ * gq [bq][D], gpos [bq][P][D] (contiguous); q / pos addressed like lpd_metric_loss; P <= 64. */
+int lpd_best_pos_bwd(const float* q, long long q_sb, const float* pos, long long pos_sb, long long pos_st, const float* gmin,
+                     const float* gmax, int bq, int P, int D, float* gq, float* gpos, void* stream);
+
 /*
  * Descriptor retrieval (evaluate.py:162-206: KDTree(database).query(query, k = 25) per query): the k nearest database
  * descriptors of every query by squared Euclidean distance, ascending, ties -> lower index.

@@ -167,6 +167,45 @@ __global__ __launch_bounds__(256) void metric_loss_kernel(LossArgs a)
     }
 }
 
+// Backward of best_pos_distance (loss/pointnetvlad_loss.py:6-12): min_pos[b] = min_p |pos_p - q|^2, max_pos[b] = max_p ...;
+// given the upstream gradients gmin[b], gmax[b]:  d/dq = -2 gmin (pos_amin - q) - 2 gmax (pos_amax - q),
+// d/dpos_amin += 2 gmin (pos_amin - q), d/dpos_amax += 2 gmax (pos_amax - q), zero for the other positives.
+// First arg-min / arg-max, like torch.min / torch.max.  One block per query tuple.
+__global__ __launch_bounds__(256) void best_pos_bwd_kernel(const float* __restrict__ q, long long q_sb, const float* __restrict__ pos,
+                                                           long long pos_sb, long long pos_st, const float* __restrict__ gmin,
+                                                           const float* __restrict__ gmax, int P, int D, float* __restrict__ gq,
+                                                           float* __restrict__ gpos)
+{
+    __shared__ float d2[64];
+    __shared__ float part[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* qb = q + b * q_sb;
+    for (int p = 0; p < P; ++p) {
+        const float* pp = pos + b * pos_sb + p * pos_st;
+        float s = 0.f;
+        for (int d = tid; d < D; d += 256) { const float t = pp[d] - qb[d]; s += t * t; }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (lane == 0) part[wave] = s;
+        __syncthreads();
+        if (tid == 0) d2[p] = (part[0] + part[1]) + (part[2] + part[3]);
+        __syncthreads();
+    }
+    int amin = 0, amax = 0;
+    for (int p = 1; p < P; ++p) {
+        if (d2[p] < d2[amin]) amin = p;
+        if (d2[p] > d2[amax]) amax = p;
+    }
+    const float gm = gmin[b], gx = gmax[b];
+    for (int d = tid; d < D; d += 256) {
+        const float qd = qb[d];
+        const float dmin = pos[b * pos_sb + amin * pos_st + d] - qd, dmax = pos[b * pos_sb + amax * pos_st + d] - qd;
+        gq[(long long)b * D + d] = -2.0f * (gm * dmin + gx * dmax);
+        for (int p = 0; p < P; ++p)
+            gpos[((long long)b * P + p) * D + d] = (p == amin ? 2.0f * gm * dmin : 0.0f) + (p == amax ? 2.0f * gx * dmax : 0.0f);
+    }
+}
+
 }  // namespace
 
 extern "C" int lpd_metric_loss(const float* q, long long q_sb, const float* pos, long long pos_sb, long long pos_st,
@@ -185,5 +224,16 @@ extern "C" int lpd_metric_loss(const float* q, long long q_sb, const float* pos,
                use_min, lazy, ignore_zero, quad, loss, minmax, gq, gpos, gneg, gother};
     hipLaunchKernelGGL(metric_loss_kernel, dim3(1), dim3(256), floats * sizeof(float), stream, a);
     LPD_CHECK_LAUNCH("lpd_metric_loss");
+    return LPD_OK;
+}
+
+extern "C" int lpd_best_pos_bwd(const float* q, long long q_sb, const float* pos, long long pos_sb, long long pos_st, const float* gmin,
+                                const float* gmax, int bq, int P, int D, float* gq, float* gpos, void* stream_)
+{
+    LPD_CHECK_ARG(q && pos && gmin && gmax && gq && gpos, "lpd_best_pos_bwd: null pointer");
+    LPD_CHECK_ARG(bq > 0 && P > 0 && P <= 64 && D > 0, "lpd_best_pos_bwd: bad dims bq=%d P=%d D=%d (P <= 64)", bq, P, D);
+    hipLaunchKernelGGL(best_pos_bwd_kernel, dim3(bq), dim3(256), 0, (hipStream_t)stream_, q, q_sb, pos, pos_sb, pos_st, gmin, gmax, P, D,
+                       gq, gpos);
+    LPD_CHECK_LAUNCH("lpd_best_pos_bwd");
     return LPD_OK;
 }

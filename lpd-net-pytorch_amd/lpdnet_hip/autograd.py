@@ -60,8 +60,36 @@ def metric_loss(q, pos, neg, other, m1, m2, use_min, lazy, ignore_zero, quad):
     return _MetricLoss.apply(q, pos, neg, other, m1, m2, use_min, lazy, ignore_zero, quad)
 
 
+class _BestPos(torch.autograd.Function):
+    """(min_pos, max_pos) of loss/pointnetvlad_loss.py:6-12 with their gradients: d min_pos / dq = -2 (pos_argmin - q), etc."""
+
+    @staticmethod
+    def forward(ctx, query, pos_vecs):
+        mn, mx = _best_pos_values(query, pos_vecs)
+        ctx.save_for_backward(query, pos_vecs)
+        return mn, mx
+
+    @staticmethod
+    def backward(ctx, gmin, gmax):
+        query, pos = ctx.saved_tensors
+        q, p = _rows3(query, "query"), _rows3(pos, "pos_vecs")
+        bq, P, D = p.shape
+        gq = torch.empty((bq, 1, D), dtype=torch.float32, device=q.device)
+        gp = torch.empty((bq, P, D), dtype=torch.float32, device=q.device)
+        lib = _lib.load()
+        _lib.check(lib.lpd_best_pos_bwd(_ptr(q), q.stride(0), _ptr(p), p.stride(0), p.stride(1), _ptr(gmin.contiguous().float()),
+                                        _ptr(gmax.contiguous().float()), bq, P, D, _ptr(gq), _ptr(gp), _stream()), "lpd_best_pos_bwd")
+        return gq, gp
+
+
 def best_pos_distance(query, pos_vecs):
-    """min / max squared distance to the positives (no autograd: the losses above carry their own)."""
+    """min / max squared distance to the positives (loss/pointnetvlad_loss.py:6-12), differentiable like the reference's."""
+    if torch.is_grad_enabled() and (query.requires_grad or pos_vecs.requires_grad):
+        return _BestPos.apply(query, pos_vecs)
+    return _best_pos_values(query, pos_vecs)
+
+
+def _best_pos_values(query, pos_vecs):
     q, pos = _rows3(query, "query"), _rows3(pos_vecs, "pos_vecs")
     bq, P, D = pos.shape
     dev = q.device
@@ -636,6 +664,7 @@ class _PointNetTrainFn(torch.autograd.Function):
         S["r4"], S["s4"], S["a4"] = _Dense.fwd(S["a3"], net.conv4, net.bn4, ops.ACT_RELU)
         S["r5"], S["s5"], out = _Dense.fwd(S["a4"], net.conv5, net.bn5, ops.ACT_NONE)
         ctx.net, ctx.saved, ctx.dims = net, S, (B, N)
+        _LAST.trans = S["trans"]
         return out
 
     @staticmethod
@@ -674,11 +703,52 @@ def pointnet_features_train(net, x):
     return feat, B, N
 
 
-class _NetVLADTrainFn(torch.autograd.Function):
-    """NetVLADLoupe.forward + GatingContext in train mode (util/PointNetVlad.py:45-83,103-115)."""
+class _Last(__import__("threading").local):
+    trans = None      # the input alignment matrix of the latest PointNet train-mode forward on this thread
 
-    PARAMS = ("cluster_weights", "cluster_weights2", "hidden1_weights", "bn1.weight", "bn1.bias", "bn2.weight", "bn2.bias",
-              "context_gating.gating_weights", "context_gating.bn1.weight", "context_gating.bn1.bias")
+
+_LAST = _Last()
+
+
+class _CloudMaxFn(torch.autograd.Function):
+    """per-cloud max over the N points of point-major rows [B*N, C] -> [B, C] (MaxPool2d((num_points,1)), PointNetVlad.py:235)"""
+
+    @staticmethod
+    def forward(ctx, feat, B, N):
+        out, arg = ops.colmax_arg(feat, B, N)
+        ctx.arg, ctx.N = arg, N
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.colmax_bwd(dout.contiguous(), ctx.arg, ctx.N), None, None
+
+
+def pointnet_global_train(net, x):
+    """PointNetfeat(max_pool=True, global_feat=True) in train mode (PointNetVlad.py:204-239): (global feature [B, emb_dims] with
+    autograd, trans [B,3,3]).  The alignment matrix is returned as a constant (no gradient flows from a caller's use of it;
+    the reference returns it attached -- nothing on the PointNetVLAD path consumes it)."""
+    feat, B, N = pointnet_features_train(net, x)
+    trans = _LAST.trans.detach()
+    _LAST.trans = None
+    return _CloudMaxFn.apply(feat, B, N), trans
+
+
+class _NetVLADTrainFn(torch.autograd.Function):
+    """NetVLADLoupe.forward + GatingContext in train mode (util/PointNetVlad.py:45-83,103-115): with BatchNorm + gating (what
+    PointNetVlad constructs) and the other constructor variants -- add_batch_norm=False (cluster_biases / gating_biases in place
+    of the two BatchNorms, :33-36,55-56,94-96,108-109) and gating=False (:80-81)."""
+
+    @staticmethod
+    def param_names(vlad):
+        names = ["cluster_weights", "cluster_weights2", "hidden1_weights"]
+        names += ["bn1.weight", "bn1.bias"] if vlad.add_batch_norm else ["cluster_biases"]
+        names += ["bn2.weight", "bn2.bias"]
+        if vlad.gating:
+            names += ["context_gating.gating_weights"]
+            names += ["context_gating.bn1.weight", "context_gating.bn1.bias"] if vlad.context_gating.add_batch_norm else \
+                ["context_gating.gating_biases"]
+        return names
 
     @staticmethod
     def forward(ctx, vlad, B, N, feat, *params):
@@ -697,25 +767,36 @@ class _NetVLADTrainFn(torch.autograd.Function):
         dev = feat.device
         Bp = (B + 31) // 32 * 32                                    # rows padded so K = Bp weight-gradient GEMMs are legal
         a0 = ops.gemm(feat, vlad.cluster_weights, b_kmajor=True)    # [M,K] raw
-        sta = ops.bn_train_stats(a0, vlad.bn1)
-        a = ops.softmax_affine(a0, sta.scale, sta.shift)
+        if vlad.add_batch_norm:
+            sta = ops.bn_train_stats(a0, vlad.bn1)
+            a = ops.softmax_affine(a0, sta.scale, sta.shift)
+        else:
+            sta = None
+            a = ops.softmax_affine(a0, torch.ones_like(vlad.cluster_biases), vlad.cluster_biases)
         vraw = ops.gemm(feat.view(B, N, E), a.view(B, N, K), a_kmajor=True, b_kmajor=True, splits=engine._pool_splits(B, N, E))
         aux = {}
         v = torch.zeros((Bp, E * K), dtype=torch.float32, device=dev)
         ops.vlad_finalize(vraw, a.view(B, N, K), vlad.cluster_weights2.view(E, K), out=v, aux=aux)
-        from . import engine
         h0 = ops.gemm(v, vlad.hidden1_weights, b_kmajor=True, splits=engine._head_splits(E * K))     # [Bp,O] raw
         sth = ops.bn_train_stats(h0, vlad.bn2, rows=B)
         h = torch.zeros((Bp, O), dtype=torch.float32, device=dev)
         ops.affine_act(h0, sth.scale, sth.shift, out=h, rows=B)
+        ctx.vlad, ctx.dims = vlad, (B, N, M, E, K, O, Bp)
+        S = dict(feat=feat, a0=a0, sta=sta, a=a, aux=aux, v=v, h0=h0, sth=sth, h=h)
+        ctx.saved = S
+        if not vlad.gating:
+            return h[:B].clone()
         gc = vlad.context_gating
         g0 = ops.gemm(h, gc.gating_weights, b_kmajor=True)           # [Bp,O] raw
-        stg = ops.bn_train_stats(g0, gc.bn1, rows=B)
-        gates = ops.affine_act(g0, stg.scale, stg.shift, ops.ACT_SIGMOID, rows=B)
-        out = ops.mul(h[:B], gates[:B])
-        ctx.vlad, ctx.dims = vlad, (B, N, M, E, K, O, Bp)
-        ctx.saved = dict(feat=feat, a0=a0, sta=sta, a=a, aux=aux, v=v, h0=h0, sth=sth, h=h, g0=g0, stg=stg, gates=gates)
-        return out
+        if gc.add_batch_norm:
+            stg = ops.bn_train_stats(g0, gc.bn1, rows=B)
+            gates = ops.affine_act(g0, stg.scale, stg.shift, ops.ACT_SIGMOID, rows=B)
+        else:
+            stg = None
+            g0 = ops.affine_act(g0, torch.ones_like(gc.gating_biases), gc.gating_biases, ops.ACT_NONE, out=g0, rows=B)   # pre-activation
+            gates = ops.affine_act(g0, None, None, ops.ACT_SIGMOID, rows=B)
+        S.update(g0=g0, stg=stg, gates=gates)
+        return ops.mul(h[:B], gates[:B])
 
     @staticmethod
     def backward(ctx, dout):
@@ -728,19 +809,24 @@ class _NetVLADTrainFn(torch.autograd.Function):
     def _backward(ctx, dout):
         vlad, S = ctx.vlad, _saved(ctx)
         B, N, M, E, K, O, Bp = ctx.dims
-        gc = vlad.context_gating
         dev = dout.device
         dout = dout.contiguous()
-        h, gates = S["h"], S["gates"]
-        # out = h * gates
-        dgates = torch.zeros((Bp, O), dtype=torch.float32, device=dev)
-        dgates[:B] = ops.mul(dout, h[:B])
+        h = S["h"]
         dh = torch.zeros((Bp, O), dtype=torch.float32, device=dev)
-        dh[:B] = ops.mul(dout, gates[:B])
-        # gates = sigmoid(BN(g0)), g0 = h Wg
-        dg0, dgam_g, dbet_g = ops.bn_act_bwd(dgates, S["g0"], S["stg"], ops.ACT_SIGMOID, out=dgates, rows=B)
-        dwg = ops.gemm(h, dg0, a_kmajor=True, b_kmajor=True)                       # h^T dG0  [O,O]  (K = Bp, zero rows pad)
-        ops.gemm(dg0, gc.gating_weights, b_kmajor=False, out=dh, accumulate=True)  # dh += dG0 Wg^T
+        g_gate = []
+        if vlad.gating:
+            gc, gates = vlad.context_gating, S["gates"]
+            # out = h * gates
+            dgates = torch.zeros((Bp, O), dtype=torch.float32, device=dev)
+            dgates[:B] = ops.mul(dout, h[:B])
+            dh[:B] = ops.mul(dout, gates[:B])
+            # gates = sigmoid(BN(g0)) or sigmoid(g0 + bias), g0 = h Wg
+            dg0, dgam_g, dbet_g = ops.bn_act_bwd(dgates, S["g0"], S["stg"], ops.ACT_SIGMOID, out=dgates, rows=B)
+            dwg = ops.gemm(h, dg0, a_kmajor=True, b_kmajor=True)                       # h^T dG0  [O,O]  (K = Bp, zero rows pad)
+            ops.gemm(dg0, gc.gating_weights, b_kmajor=False, out=dh, accumulate=True)  # dh += dG0 Wg^T
+            g_gate = [dwg, dgam_g, dbet_g] if gc.add_batch_norm else [dwg, dbet_g]     # no BN: the sum of dpre is the bias gradient
+        else:
+            dh[:B] = dout
         # h = BN(h0), h0 = v Wh
         dh0, dgam_h, dbet_h = ops.bn_act_bwd(dh, S["h0"], S["sth"], ops.ACT_NONE, out=dh, rows=B)
         if Bp > B:
@@ -755,19 +841,21 @@ class _NetVLADTrainFn(torch.autograd.Function):
         da = ops.gemm(feat.view(B, N, E), dvraw, a_kmajor=False, b_kmajor=True)    # [B,N,K]
         dfeat = ops.gemm(a.view(B, N, K), dvraw, a_kmajor=False, b_kmajor=False)   # [B,N,E] = a dVraw^T
         ds = ops.softmax_bwd(a, da.view(M, K), dasum, N)
-        da0, dgam_a, dbet_a = ops.bn_act_bwd(ds, S["a0"], S["sta"], ops.ACT_NONE, out=ds)
+        if vlad.add_batch_norm:
+            da0, dgam_a, dbet_a = ops.bn_act_bwd(ds, S["a0"], S["sta"], ops.ACT_NONE, out=ds)
+            g_assign = [dgam_a, dbet_a]
+        else:
+            da0 = ds                                                               # a = softmax(a0 + cluster_biases)
+            g_assign = [ops.colsum(ds)]
         dwc = _dweight(feat, da0)                                                  # feat^T dA0 [E,K]
         dfeat = dfeat.view(M, E)
         ops.gemm(da0, vlad.cluster_weights, b_kmajor=False, out=dfeat, accumulate=True)   # += dA0 Wc^T
         ctx.saved = None
-        return (None, None, None, dfeat, dwc, dcw2.view(1, E, K), dwh, dgam_a, dbet_a, dgam_h, dbet_h, dwg, dgam_g, dbet_g)
+        return (None, None, None, dfeat, dwc, dcw2.view(1, E, K), dwh) + tuple(g_assign) + (dgam_h, dbet_h) + tuple(g_gate)
 
 
 def netvlad_train(vlad, feat, B, N):
-    if not (vlad.add_batch_norm and vlad.gating):
-        raise NotImplementedError("NetVLADLoupe training on the HIP path is built for add_batch_norm=True, gating=True "
-                                  "(what PointNetVlad constructs, reference PointNetVlad.py:257-259)")
     if N != vlad.max_samples:
         raise ValueError(f"NetVLADLoupe was built for max_samples={vlad.max_samples}, got N={N}")
-    params = _named(vlad, _NetVLADTrainFn.PARAMS)
+    params = _named(vlad, _NetVLADTrainFn.param_names(vlad))
     return _NetVLADTrainFn.apply(vlad, B, N, feat, *params)

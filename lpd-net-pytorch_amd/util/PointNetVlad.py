@@ -153,11 +153,21 @@ class PointNetfeat(nn.Module):
         return feat, B, N
 
     def forward(self, x):
-        if self.max_pool:
-            raise NotImplementedError("PointNetfeat(max_pool=True) (the classification-style global feature, reference "
-                                      "PointNetVlad.py:234-241) is not on the PointNetVLAD path and is not built")
-        feat, B, N = self._features(x)
-        return engine.to_channel_major(feat, B, N)
+        if not self.max_pool:
+            feat, B, N = self._features(x)
+            return engine.to_channel_major(feat, B, N)
+        # max_pool=True (reference PointNetVlad.py:234-239): the per-cloud max over the points of the bn5 output, returned with
+        # the input alignment matrix.  global_feat=False concatenates a 3-D with a 4-D tensor in the reference (:240-241) and
+        # cannot run there either.
+        if not self.global_feat:
+            raise NotImplementedError("PointNetfeat(max_pool=True, global_feat=False) fails in the reference itself "
+                                      "(torch.cat of a 3-D and a 4-D tensor, PointNetVlad.py:240-241)")
+        if self.training:
+            from lpdnet_hip import autograd
+            return autograd.pointnet_global_train(self, x)
+        feat, B, N, trans = engine.pointnet_features_eval(self, x)
+        from lpdnet_hip import ops
+        return ops.colmax(feat, B, N), trans
 
 
 class PointNetVlad(nn.Module):

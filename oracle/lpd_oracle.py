@@ -289,7 +289,10 @@ def netvlad(sd, feat, *, train=False, new_stats=None, aux=None, pre="net_vlad.")
     x = feat.squeeze(-1).transpose(1, 2)                           # [B,N,E]
     a = torch.matmul(x, sd[pre + "cluster_weights"])               # [B,N,K]
     K = a.shape[-1]
-    a = _bn(sd, pre + "bn1", a.reshape(-1, K), train, new_stats).reshape(B, N, K)
+    if pre + "cluster_biases" in sd:                               # add_batch_norm=False (PointNetVlad.py:33-36,55-56)
+        a = a + sd[pre + "cluster_biases"]
+    else:
+        a = _bn(sd, pre + "bn1", a.reshape(-1, K), train, new_stats).reshape(B, N, K)
     a = torch.softmax(a, dim=-1)
     a_sum = a.sum(dim=1, keepdim=True)                             # [B,1,K]
     res = a_sum * sd[pre + "cluster_weights2"]                     # [B,E,K]
@@ -301,8 +304,13 @@ def netvlad(sd, feat, *, train=False, new_stats=None, aux=None, pre="net_vlad.")
         aux.update(vlad=v)
     h = torch.matmul(v, sd[pre + "hidden1_weights"])
     h = _bn(sd, pre + "bn2", h, train, new_stats)
+    if pre + "context_gating.gating_weights" not in sd:            # gating=False (PointNetVlad.py:80-81)
+        return h
     g = torch.matmul(h, sd[pre + "context_gating.gating_weights"])
-    g = _bn(sd, pre + "context_gating.bn1", g, train, new_stats)
+    if pre + "context_gating.gating_biases" in sd:                 # GatingContext(add_batch_norm=False) (:94-96,108-109)
+        g = g + sd[pre + "context_gating.gating_biases"]
+    else:
+        g = _bn(sd, pre + "context_gating.bn1", g, train, new_stats)
     return h * torch.sigmoid(g)
 
 

@@ -324,12 +324,93 @@ def test_train_then_eval_roundtrip_and_adam_step(cuda):
     assert torch.isfinite(d).all() and d.shape == (bq * (P + Ng + 2), 256)
 
 
-def test_unbuilt_training_variants_fail_loudly(cuda):
-    """What the HIP training path does not build raises a clear error, never a silent fallback."""
-    from util.PointNetVlad import NetVLADLoupe, PointNetfeat
-    x = torch.from_numpy(synth.cloud(1, 2, 256)).unsqueeze(1).to(cuda)
+@pytest.mark.parametrize("gating,add_bn", [(True, False), (False, True), (False, False)])
+def test_netvlad_constructor_variants_train_and_eval(cuda, gating, add_bn):
+    """NetVLADLoupe(gating=..., add_batch_norm=...) (PointNetVlad.py:33-36,55-56,80-81,94-96,108-109): the variants
+    PointNetVlad itself never constructs -- train-mode forward + backward and eval forward against the oracle."""
+    from util.PointNetVlad import NetVLADLoupe
+    E, N, K, O, B = 64, 256, 16, 32, 6
+    g = torch.Generator().manual_seed(5)
+    head = NetVLADLoupe(feature_size=E, max_samples=N, cluster_size=K, output_dim=O, gating=gating, add_batch_norm=add_bn)
+    sd = {"net_vlad." + k: v.detach().clone() for k, v in head.state_dict().items()}
+    x = torch.randn(B, E, N, 1, generator=g)
+    for train in (True, False):
+        head = head.to(cuda).train(train)
+        dt = torch.float64
+        osd = {k: (v.to(dt).requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else v.clone())
+               for k, v in sd.items()}
+        xo = x.to(dt).requires_grad_(True)
+        want = orc.netvlad(osd, xo, train=train)
+        xg = x.to(cuda).requires_grad_(True)
+        got = head(xg)
+        assert got.shape == (B, O)
+        rel = ((got.detach().cpu().double() - want.detach()).abs().amax(dim=1) / want.detach().abs().amax(dim=1)).max().item()
+        assert rel < 1e-4, (train, rel)
+        if train:
+            w = torch.randn(B, O, generator=g)
+            (got * w.to(cuda)).sum().backward()
+            (want * w.to(dt)).sum().backward()
+            assert ((xg.grad.cpu().double() - xo.grad).norm() / xo.grad.norm()).item() < 5e-4
+            n = 0
+            for name, prm in head.named_parameters():
+                ref = osd["net_vlad." + name].grad
+                err = ((prm.grad.cpu().double() - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+                assert err < 1e-3, (name, err)
+                n += 1
+            assert n == 3 + (2 if add_bn else 1) + 2 + ((1 + (2 if add_bn else 1)) if gating else 0)
+
+
+def test_pointnetfeat_max_pool_and_best_pos_distance_autograd(cuda):
+    """PointNetfeat(max_pool=True) (PointNetVlad.py:234-239: global max over the points + the alignment matrix), eval and
+    train with gradients through the max; best_pos_distance carries gradients like the reference's (pointnetvlad_loss.py:6-12)."""
+    import loss.pointnetvlad_loss as L
+    from util.PointNetVlad import PointNetfeat
+    N, B = 256, 4
+    net = PointNetfeat(num_points=N, max_pool=True, emb_dims=1024)
+    full = orc.synthetic_state("pointnet", num_points=N)
+    net.load_state_dict({k[len("point_net."):]: v for k, v in full.items() if k.startswith("point_net.")}, strict=True)
+    net = net.to(cuda)
+    xc = torch.from_numpy(synth.cloud(8, B, N)).unsqueeze(1)
+    for train in (False, True):
+        net.train(train)
+        dt = torch.float64
+        osd = {k: (v.to(dt).requires_grad_(True) if v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var"))
+                   else (v.to(dt) if v.dtype == torch.float32 else v.clone())) for k, v in full.items()}
+        want = orc.pointnet_features(osd, xc.to(dt), train=train).squeeze(-1).max(dim=2)[0]          # [B, E]
+        got, trans = net(xc.to(cuda))
+        assert got.shape == (B, 1024) and trans.shape == (B, 3, 3)
+        assert _desc_rel(got, want) < 1e-4
+        if train:
+            g = torch.Generator().manual_seed(1)
+            w = torch.randn(B, 1024, generator=g)
+            (got * w.to(cuda)).sum().backward()
+            (want * w.to(dt)).sum().backward()
+            for name in ("conv5.weight", "conv1.weight", "bn3.weight", "stn.fc1.weight"):
+                a, b = dict(net.named_parameters())[name].grad.cpu().double(), osd["point_net." + name].grad
+                assert ((a - b).norm() / b.norm()).item() < 2e-3, name
     with pytest.raises(NotImplementedError):
-        PointNetfeat(num_points=256, max_pool=True).to(cuda).train()(x)
-    head = NetVLADLoupe(feature_size=64, max_samples=256, cluster_size=8, output_dim=16, gating=False).to(cuda).train()
+        PointNetfeat(num_points=N, max_pool=True, global_feat=False).to(cuda).eval()(xc.to(cuda))
+    # best_pos_distance with autograd
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(3, 1, 256, generator=g)
+    p = torch.randn(3, 4, 256, generator=g)
+    qg, pg = q.to(cuda).requires_grad_(True), p.to(cuda).requires_grad_(True)
+    qo, po = q.double().requires_grad_(True), p.double().requires_grad_(True)
+    mn, mx = L.best_pos_distance(qg, pg)
+    omn, omx = orc.best_pos_distance(qo, po)
+    assert torch.allclose(mn.detach().cpu().double(), omn.detach(), rtol=1e-5) and torch.allclose(mx.detach().cpu().double(), omx.detach(), rtol=1e-5)
+    (2.0 * mn.sum() - 0.5 * mx.sum()).backward()
+    (2.0 * omn.sum() - 0.5 * omx.sum()).backward()
+    assert torch.allclose(qg.grad.cpu().double(), qo.grad, rtol=1e-4, atol=1e-5) and torch.allclose(pg.grad.cpu().double(), po.grad, rtol=1e-4, atol=1e-5)
+
+
+def _desc_rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().amax(dim=1) / b.abs().amax(dim=1)).max().item()
+
+
+def test_unbuilt_variants_fail_loudly(cuda):
+    """What the HIP path does not build raises a clear error, never a silent fallback."""
+    from util.lpdnet_model import LPDNet
     with pytest.raises(NotImplementedError):
-        head(torch.zeros(2, 64, 256, 1, device=cuda))
+        LPDNet(use_mFea=True)
