@@ -77,8 +77,9 @@ class _BestPos(torch.autograd.Function):
         gq = torch.empty((bq, 1, D), dtype=torch.float32, device=q.device)
         gp = torch.empty((bq, P, D), dtype=torch.float32, device=q.device)
         lib = _lib.load()
-        _lib.check(lib.lpd_best_pos_bwd(_ptr(q), q.stride(0), _ptr(p), p.stride(0), p.stride(1), _ptr(gmin.contiguous().float()),
-                                        _ptr(gmax.contiguous().float()), bq, P, D, _ptr(gq), _ptr(gp), _stream()), "lpd_best_pos_bwd")
+        gmin, gmax = gmin.contiguous().float(), gmax.contiguous().float()      # named: the buffers must outlive the launch call
+        _lib.check(lib.lpd_best_pos_bwd(_ptr(q), q.stride(0), _ptr(p), p.stride(0), p.stride(1), _ptr(gmin), _ptr(gmax), bq, P, D,
+                                        _ptr(gq), _ptr(gp), _stream()), "lpd_best_pos_bwd")
         return gq, gp
 
 
@@ -97,11 +98,12 @@ def _best_pos_values(query, pos_vecs):
     minmax = torch.empty((2, bq), dtype=torch.float32, device=dev)
     gq = torch.empty((bq, 1, D), dtype=torch.float32, device=dev)
     gpos = torch.empty((bq, P, D), dtype=torch.float32, device=dev)
+    gneg = torch.empty_like(gpos)
     lib = _lib.load()
     # reuse the fused kernel with the positives standing in as negatives (triplet form)
     _lib.check(lib.lpd_metric_loss(_ptr(q), q.stride(0), _ptr(pos), pos.stride(0), pos.stride(1), _ptr(pos), pos.stride(0),
                                    pos.stride(1), None, 0, bq, P, P, D, 0.0, 0.0, 0, 0, 0, 0, _ptr(scratch), _ptr(minmax),
-                                   _ptr(gq), _ptr(gpos), _ptr(torch.empty_like(gpos)), None, _stream()), "lpd_metric_loss")
+                                   _ptr(gq), _ptr(gpos), _ptr(gneg), None, _stream()), "lpd_metric_loss")
     return minmax[0], minmax[1]
 
 
@@ -701,6 +703,26 @@ def pointnet_features_train(net, x):
         raise ValueError(f"PointNetfeat was built for num_points={net.num_points}, got N={N} (MaxPool2d((num_points,1)))")
     feat = _PointNetTrainFn.apply(net, x, *_named(net, _PointNetTrainFn.param_names(net)))
     return feat, B, N
+
+
+class _ToPointMajor(torch.autograd.Function):
+    """[B, E, N] channel-major -> [B*N, E] point-major rows with a gradient (the standalone NetVLADLoupe.forward in train mode;
+    inside PointNetVlad the trunk hands its rows over directly)."""
+
+    @staticmethod
+    def forward(ctx, x3):
+        ctx.shape = x3.shape
+        return ops.transpose(x3).view(x3.shape[0] * x3.shape[2], x3.shape[1])
+
+    @staticmethod
+    def backward(ctx, d):
+        B, E, N = ctx.shape
+        return ops.transpose(d.contiguous().view(B, N, E))
+
+
+def to_point_major_train(x4):
+    B, E, N = x4.shape[0], x4.shape[1], x4.shape[2]
+    return _ToPointMajor.apply(x4.reshape(B, E, N).float().contiguous()), B, N
 
 
 class _Last(__import__("threading").local):

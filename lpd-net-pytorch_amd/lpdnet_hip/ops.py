@@ -1044,7 +1044,8 @@ def colmax_bwd(dOut, arg, N):
     B, C = arg.shape
     dIn = torch.zeros((B * N, C), dtype=torch.float32, device=dOut.device)
     lib = _lib.load()
-    _call("colmax_bwd", lib.lpd_colmax_bwd, _ptr(dOut.contiguous()), _ptr(arg), _ptr(dIn), C, B, N, C, _stream())
+    dOut = dOut.contiguous()
+    _call("colmax_bwd", lib.lpd_colmax_bwd, _ptr(dOut), _ptr(arg), _ptr(dIn), C, B, N, C, _stream())
     return dIn
 
 

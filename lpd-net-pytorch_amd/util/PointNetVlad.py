@@ -70,7 +70,11 @@ class NetVLADLoupe(nn.Module):
         return engine.netvlad_eval(self, feat, B, N)
 
     def forward(self, x):
-        feat, B, N = engine.to_point_major(x)
+        if self.training and x.requires_grad:
+            from lpdnet_hip import autograd
+            feat, B, N = autograd.to_point_major_train(x)
+        else:
+            feat, B, N = engine.to_point_major(x)
         return self._pool(feat, B, N)
 
 

@@ -329,7 +329,7 @@ def test_netvlad_constructor_variants_train_and_eval(cuda, gating, add_bn):
     """NetVLADLoupe(gating=..., add_batch_norm=...) (PointNetVlad.py:33-36,55-56,80-81,94-96,108-109): the variants
     PointNetVlad itself never constructs -- train-mode forward + backward and eval forward against the oracle."""
     from util.PointNetVlad import NetVLADLoupe
-    E, N, K, O, B = 64, 256, 16, 32, 6
+    E, N, K, O, B = 128, 256, 64, 32, 6      # cluster_size 64: what lpd_vlad_finalize is built for
     g = torch.Generator().manual_seed(5)
     head = NetVLADLoupe(feature_size=E, max_samples=N, cluster_size=K, output_dim=O, gating=gating, add_batch_norm=add_bn)
     sd = {"net_vlad." + k: v.detach().clone() for k, v in head.state_dict().items()}
@@ -337,6 +337,8 @@ def test_netvlad_constructor_variants_train_and_eval(cuda, gating, add_bn):
     for train in (True, False):
         head = head.to(cuda).train(train)
         dt = torch.float64
+        if not train:      # the train-mode pass moved the running statistics: the eval oracle takes the module's current state
+            sd = {"net_vlad." + k: v.detach().cpu().clone() for k, v in head.state_dict().items()}
         osd = {k: (v.to(dt).requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else v.clone())
                for k, v in sd.items()}
         xo = x.to(dt).requires_grad_(True)
