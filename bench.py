@@ -83,40 +83,63 @@ def host_cpu_model():
 
 
 def cpu_baseline(model, points, seconds_target=20.0):
-    """Oracle (CPU port of the reference path) on a bounded sample of the same workload: median of 3 timed runs after a
-    warm-up, at the fastest of the tried thread counts."""
+    """The reference path on this box's host cores, on a bounded sample of the same workload:
+      * primary ("port"): the plain-C restatement of the whole eval path (oracle/lpd_forward.c: the reference's own formulation,
+        gcc -O3 -march=native + OpenMP, one cloud per thread), one cloud per available core, median of 3 timed runs;
+      * cross-check: the torch-CPU oracle (ATen: MKL / oneDNN) at the fastest of a few thread counts, median of 3.
+    Both are checked against each other; the returned reference descriptors are the torch oracle's."""
+    import ctypes
+    import tempfile
+    import numpy as np
     from oracle import lpd_oracle as orc  # checker-only import, cpu_baseline leg
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(4321)
-    Bs = 4
-    x = torch.rand((Bs, 1, points, 3), generator=g) * 2 - 1
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    # torch's intra-op pool oversubscribes badly on very wide hosts: try a few widths, keep the fastest
+    # ---- C restatement, one cloud per core ----
+    native = orc.build_c_oracle_native(os.path.join(tempfile.gettempdir(), f"liblpd_oracle_native_{os.getpid()}.so"))
+    lib = ctypes.CDLL(native)
+    nC = max(1, min(avail, 256))
+    xc = torch.rand((nC, 1, points, 3), generator=g) * 2 - 1
+    t0 = time.time()
+    dc, used = orc.forward_lpdnet_c(sd, xc, k=model.emb_nn.k, threads=nC, lib=lib)      # warm-up (page faults, weights into cache)
+    first = time.time() - t0
+    times = []
+    for _ in range(3 if first < seconds_target / 3 else 1):
+        t0 = time.time()
+        orc.forward_lpdnet_c(sd, xc, k=model.emb_nn.k, threads=nC, lib=lib)
+        times.append(time.time() - t0)
+    tc = sorted(times)[len(times) // 2]
+    # ---- torch-CPU oracle (cross-check and the reference descriptors for the parity figure) ----
+    Bs = 4
+    x = xc[:Bs].clone()
     best = None
     budget_t0 = time.time()
     with torch.no_grad():
         for threads in sorted({min(avail, t) for t in (16, 32, 64)}):
             torch.set_num_threads(threads)
-            os.environ["OMP_NUM_THREADS"] = str(threads)
-            ref = orc.pointnetvlad_forward(sd, x, featnet="lpdnet", train=False)   # warm-up
-            times = []
+            ref = orc.pointnetvlad_forward(sd, x, featnet="lpdnet", train=False, k=model.emb_nn.k)   # warm-up
+            ts = []
             for _ in range(3):
                 t0 = time.time()
-                orc.pointnetvlad_forward(sd, x, featnet="lpdnet", train=False)
-                times.append(time.time() - t0)
-            t = sorted(times)[1]
+                orc.pointnetvlad_forward(sd, x, featnet="lpdnet", train=False, k=model.emb_nn.k)
+                ts.append(time.time() - t0)
+            t = sorted(ts)[1]
             if best is None or t < best[0]:
                 best = (t, threads)
             if time.time() - budget_t0 > seconds_target:
                 break
     t, threads = best
-    return {"value": round(Bs / t, 3), "unit": "descriptors/s", "cores": threads, "kind": "port",
+    agree = float((np.abs(dc[:Bs] - ref.numpy()).max(1) / np.abs(ref.numpy()).max(1)).max())
+    return {"value": round(nC / tc, 3), "unit": "descriptors/s", "cores": used, "kind": "port",
             "host_cpu": host_cpu_model(), "host_cores": avail,
-            "sample": f"eval forward of {Bs} clouds x {points} pts, torch-CPU oracle (port of the reference path), median of 3 "
-                      f"after warm-up at the fastest of the tried thread counts ({threads} of {avail} host cores)"}, x, ref
+            "sample": f"eval forward of {nC} clouds x {points} pts by the plain-C restatement of the reference path (oracle/lpd_forward.c, "
+                      f"gcc -O3 -march=native, OpenMP: one cloud per thread, {used} threads of {avail} host cores), median of {len(times)} after a warm-up run",
+            "torch_cpu_cross_check": {"value": round(Bs / t, 3), "unit": "descriptors/s", "cores": threads,
+                                      "sample": f"torch-CPU oracle (ATen), {Bs} clouds, median of 3 at the fastest of the tried thread counts"},
+            "c_vs_torch_oracle_norm_rel": float(f"{agree:.3e}")}, x, ref
 
 
 def _time_steps(step, first, n, dist, dev):

@@ -30,12 +30,53 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
+_C_SOURCES = ("lpd_oracle.c", "lpd_forward.c", "lpd_oracle_knn.h")
+
+
 def build_c_oracle(force=False):
     """gcc-build oracle/liblpd_oracle.so (recipe = oracle/Makefile)."""
-    src = os.path.join(_HERE, "lpd_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in _C_SOURCES)
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < newest:
         subprocess.run(["make", "-C", _HERE, "-B", "liblpd_oracle.so"], check=True, capture_output=True)
     return _LIB_PATH
+
+
+def build_c_oracle_native(out_path):
+    """The same library compiled for THIS host's CPU (-march=native) into out_path: what bench.py's cpu_baseline leg times."""
+    subprocess.run(["make", "-C", _HERE, "-B", "liblpd_oracle.so", "ARCH=native", f"OUT={out_path}"], check=True, capture_output=True)
+    return out_path
+
+
+_W_ORDER = (["emb_nn.conv1_lpd.weight"] + [f"emb_nn.bn1_lpd.{s}" for s in ("weight", "bias", "running_mean", "running_var")] +
+            ["emb_nn.conv2_lpd.weight"] + [f"emb_nn.bn2_lpd.{s}" for s in ("weight", "bias", "running_mean", "running_var")] +
+            ["emb_nn.convDG1.0.weight"] + [f"emb_nn.convDG1.1.{s}" for s in ("weight", "bias", "running_mean", "running_var")] +
+            ["emb_nn.convDG2.0.weight"] + [f"emb_nn.convDG2.1.{s}" for s in ("weight", "bias", "running_mean", "running_var")] +
+            ["emb_nn.convSN1.0.weight"] + [f"emb_nn.convSN1.1.{s}" for s in ("weight", "bias", "running_mean", "running_var")] +
+            ["emb_nn.conv3_lpd.weight"] + [f"emb_nn.bn3_lpd.{s}" for s in ("weight", "bias", "running_mean", "running_var")] +
+            ["net_vlad.cluster_weights"] + [f"net_vlad.bn1.{s}" for s in ("weight", "bias", "running_mean", "running_var")] +
+            ["net_vlad.cluster_weights2", "net_vlad.hidden1_weights"] +
+            [f"net_vlad.bn2.{s}" for s in ("weight", "bias", "running_mean", "running_var")] +
+            ["net_vlad.context_gating.gating_weights"] +
+            [f"net_vlad.context_gating.bn1.{s}" for s in ("weight", "bias", "running_mean", "running_var")])
+
+
+def forward_lpdnet_c(sd, x, k=20, threads=0, lib=None):
+    """The plain-C restatement of the whole eval path (oracle/lpd_forward.c: the reference's formulation, one cloud per OpenMP
+    thread): sd = state_dict of PointNetVlad(featnet='lpdnet') without T-Nets, x [B,1,N,3] -> (descriptors [B,256] float32
+    numpy, threads used)."""
+    lib = lib if lib is not None else _clib()
+    xs = np.ascontiguousarray(x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else x, dtype=np.float32).reshape(-1, x.shape[-2], 3)
+    B, N = xs.shape[0], xs.shape[1]
+    keep = [np.ascontiguousarray((sd[n].detach().cpu().numpy() if isinstance(sd[n], torch.Tensor) else sd[n]), dtype=np.float32) for n in _W_ORDER]
+    E = keep[25].shape[0]
+    ptrs = (ctypes.c_void_p * len(keep))(*[a.ctypes.data_as(ctypes.c_void_p) for a in keep])
+    desc = np.empty((B, 256), np.float32)
+    fn = lib.lpd_oracle_forward_lpdnet
+    fn.restype = ctypes.c_int
+    used = fn(xs.ctypes.data_as(ctypes.c_void_p), B, N, int(k), int(E), ptrs, desc.ctypes.data_as(ctypes.c_void_p), int(threads))
+    if used < 0:
+        raise MemoryError("lpd_oracle_forward_lpdnet: allocation failed")
+    return desc, used
 
 
 def _clib():

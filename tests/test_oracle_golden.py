@@ -64,6 +64,20 @@ def test_oracle_eval_forward_vs_reference(golden_dir, tag, featnet, kw):
         assert (aux["idx_feat"].numpy() == g["idx_feat"].astype(np.int64)).all(-1).mean() > 0.99
 
 
+def test_c_restatement_of_the_whole_path_vs_reference(golden_dir):
+    """oracle/lpd_forward.c (plain C, the reference's own formulation, the timed CPU baseline of bench.py) against the
+    reference's golden descriptors: LPD-Net eval at N = 4096 / k = 20 and N = 2048 / k = 64."""
+    for tag, k in (("eval_lpdnet_b2_n4096", 20), ("eval_lpdnet_k64_b2_n2048", 64)):
+        g = _load(golden_dir, tag)
+        B, N = int(g["B"]), int(g["N"])
+        sd = orc.synthetic_state("lpdnet", num_points=N)
+        x = torch.from_numpy(synth.cloud(int(g["seed"]), B, N)).unsqueeze(1)
+        d, used = orc.forward_lpdnet_c(sd, x, k=k)
+        assert used >= 1
+        rel = (np.abs(d - g["desc"]).max(1) / np.abs(g["desc"]).max(1)).max()
+        assert rel < 1e-5, (tag, rel)
+
+
 def test_oracle_eval_k64_vs_reference(golden_dir):
     """The reference run with emb_nn.k = 64 (tests/golden/make_golden_r2.py): the stress configuration's neighbourhood size."""
     g = _load(golden_dir, "eval_lpdnet_k64_b2_n2048")
