@@ -60,6 +60,30 @@ static void matvec(const float *restrict W, const float *restrict x, float *rest
     }
 }
 
+/* Y[p][o] = sum_i W[o][i] * X[p][i] for P rows of X (stride ldx) at once: a weight row is loaded once for a group of 8 rows
+ * and the 8 dot products are independent accumulation chains -- a plain matvec per point re-reads W (2 MiB for conv3) for
+ * every point and runs one latency-bound chain (first version: 28 s per cloud with all cores busy, bound by L3 traffic). */
+static void matmat(const float *restrict W, const float *restrict X, int ldx, float *restrict Y, int ldy, int O, int I, int P)
+{
+    for (int p0 = 0; p0 < P; p0 += 8) {
+        const int np = P - p0 < 8 ? P - p0 : 8;
+        const float *x[8];
+        for (int r = 0; r < 8; ++r) x[r] = X + (size_t)(p0 + (r < np ? r : 0)) * ldx;
+        for (int o = 0; o < O; ++o) {
+            const float *w = W + (size_t)o * I;
+            float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+#pragma omp simd reduction(+ : a0, a1, a2, a3, a4, a5, a6, a7)
+            for (int i = 0; i < I; ++i) {
+                const float wi = w[i];
+                a0 += wi * x[0][i]; a1 += wi * x[1][i]; a2 += wi * x[2][i]; a3 += wi * x[3][i];
+                a4 += wi * x[4][i]; a5 += wi * x[5][i]; a6 += wi * x[6][i]; a7 += wi * x[7][i];
+            }
+            const float acc[8] = {a0, a1, a2, a3, a4, a5, a6, a7};
+            for (int r = 0; r < np; ++r) Y[(size_t)(p0 + r) * ldy + o] = acc[r];
+        }
+    }
+}
+
 /* eval-mode BatchNorm + optional LeakyReLU, in place, C channels; bn = {weight, bias, mean, var} */
 static void bn_act(float *restrict y, const float *const *bn, int C, int act)
 {
@@ -69,27 +93,53 @@ static void bn_act(float *restrict y, const float *const *bn, int C, int act)
     }
 }
 
+/* kNN of one cloud, the reference's arithmetic (lpd_oracle_knn.h: a c-ordered fmaf chain per pair), organised so that the
+ * chains of 64 candidates j run side by side (vectorised over j on a channel-major copy; every chain keeps its order). */
 static void knn_cloud(const float *x, int N, int C, int k, int32_t *idx)
 {
-    float *xx = (float *)malloc(sizeof(float) * (size_t)N);
+    enum { JB = 64 };
+    const int Np = (N + JB - 1) / JB * JB;
+    float *xx = (float *)malloc(sizeof(float) * (size_t)Np);
+    float *xt = (float *)calloc((size_t)C * Np, sizeof(float));           /* [C][Np] channel-major, zero padded */
     float *bv = (float *)malloc(sizeof(float) * (size_t)k);
     int *bi = (int *)malloc(sizeof(int) * (size_t)k);
-    for (int i = 0; i < N; ++i) xx[i] = oracle_sumsq(x + (size_t)i * C, C);
+    for (int i = 0; i < N; ++i) {
+        xx[i] = oracle_sumsq(x + (size_t)i * C, C);
+        for (int c = 0; c < C; ++c) xt[(size_t)c * Np + i] = x[(size_t)i * C + c];
+    }
     for (int i = 0; i < N; ++i) {
         int cnt = 0;
         const float *xi = x + (size_t)i * C;
-        for (int j = 0; j < N; ++j) {
-            float pd = oracle_pd(xi, x + (size_t)j * C, xx[i], xx[j], C);
-            if (cnt == k && !oracle_before(pd, j, bv[k - 1], bi[k - 1])) continue;
-            int pos = cnt < k ? cnt : k - 1;
-            while (pos > 0 && oracle_before(pd, j, bv[pos - 1], bi[pos - 1])) { bv[pos] = bv[pos - 1]; bi[pos] = bi[pos - 1]; --pos; }
-            bv[pos] = pd;
-            bi[pos] = j;
-            if (cnt < k) ++cnt;
+        const float xxi = xx[i];
+        for (int j0 = 0; j0 < N; j0 += JB) {
+            float dot[JB], pdv[JB];
+            for (int jj = 0; jj < JB; ++jj) dot[jj] = 0.0f;
+            for (int c = 0; c < C; ++c) {
+                const float xic = xi[c];
+                const float *row = xt + (size_t)c * Np + j0;
+#pragma omp simd
+                for (int jj = 0; jj < JB; ++jj) dot[jj] = fmaf(xic, row[jj], dot[jj]);
+            }
+            const int jn = N - j0 < JB ? N - j0 : JB;
+            for (int jj = 0; jj < jn; ++jj) {
+                const float inner = -2.0f * dot[jj];
+                const float t = (-xx[j0 + jj]) - inner;
+                pdv[jj] = t - xxi;
+            }
+            for (int jj = 0; jj < jn; ++jj) {
+                const float pd = pdv[jj];
+                const int j = j0 + jj;
+                if (cnt == k && !oracle_before(pd, j, bv[k - 1], bi[k - 1])) continue;
+                int pos = cnt < k ? cnt : k - 1;
+                while (pos > 0 && oracle_before(pd, j, bv[pos - 1], bi[pos - 1])) { bv[pos] = bv[pos - 1]; bi[pos] = bi[pos - 1]; --pos; }
+                bv[pos] = pd;
+                bi[pos] = j;
+                if (cnt < k) ++cnt;
+            }
         }
         for (int t = 0; t < k; ++t) idx[(size_t)i * k + t] = bi[t];
     }
-    free(xx); free(bv); free(bi);
+    free(xx); free(xt); free(bv); free(bi);
 }
 
 /* one cloud: x [N][3] -> desc [256]; returns 0, or -1 when out of memory */
@@ -113,44 +163,54 @@ static int forward_cloud(const float *x, int N, int k, int E, const float *const
     }
     /* dynamic graph in feature space: edge (neighbour, centre) -> convDG1 -> max; convDG2 on every edge -> max (:246-252) */
     knn_cloud(f0, N, 64, k, idx);
+    float *eb = (float *)malloc(sizeof(float) * (size_t)k * 256 * 3);     /* the k edges of one point: input, layer 1, layer 2 */
+    if (!eb) return -1;
     for (int n = 0; n < N; ++n) {
-        float e[128], y1[128], z[128];
+        float *e = eb, *y1 = eb + (size_t)k * 256, *z = eb + (size_t)k * 512;
         float *x1 = cat + (size_t)n * 512, *x2 = x1 + 128;
         for (int c = 0; c < 128; ++c) { x1[c] = -INFINITY; x2[c] = -INFINITY; }
-        memcpy(e + 64, f0 + (size_t)n * 64, sizeof(float) * 64);
+        for (int t = 0; t < k; ++t) {                                     /* the [k][128] edge tensor of this point (:350-357) */
+            memcpy(e + (size_t)t * 128, f0 + (size_t)idx[(size_t)n * k + t] * 64, sizeof(float) * 64);
+            memcpy(e + (size_t)t * 128 + 64, f0 + (size_t)n * 64, sizeof(float) * 64);
+        }
+        matmat(w[LPD_W_DG1], e, 128, y1, 128, 128, 128, k);
+        for (int t = 0; t < k; ++t) bn_act(y1 + (size_t)t * 128, w + LPD_W_BNDG1, 128, 1);
+        matmat(w[LPD_W_DG2], y1, 128, z, 128, 128, 128, k);
         for (int t = 0; t < k; ++t) {
-            memcpy(e, f0 + (size_t)idx[(size_t)n * k + t] * 64, sizeof(float) * 64);
-            matvec(w[LPD_W_DG1], e, y1, 128, 128);
-            bn_act(y1, w + LPD_W_BNDG1, 128, 1);
-            matvec(w[LPD_W_DG2], y1, z, 128, 128);
-            bn_act(z, w + LPD_W_BNDG2, 128, 1);
-            for (int c = 0; c < 128; ++c) { x1[c] = fmaxf(x1[c], y1[c]); x2[c] = fmaxf(x2[c], z[c]); }
+            bn_act(z + (size_t)t * 128, w + LPD_W_BNDG2, 128, 1);
+            for (int c = 0; c < 128; ++c) { x1[c] = fmaxf(x1[c], y1[(size_t)t * 128 + c]); x2[c] = fmaxf(x2[c], z[(size_t)t * 128 + c]); }
         }
     }
     /* static graph in Cartesian space (raw xyz): edge (x2 neighbour, x2 centre) -> convSN1 -> max (:255-258) */
     knn_cloud(x, N, 3, k, idx);
     for (int n = 0; n < N; ++n) {
-        float e[256], y[256];
+        float *e = eb, *y = eb + (size_t)k * 256;
         float *x3 = cat + (size_t)n * 512 + 256;
         for (int c = 0; c < 256; ++c) x3[c] = -INFINITY;
-        memcpy(e + 128, cat + (size_t)n * 512 + 128, sizeof(float) * 128);
         for (int t = 0; t < k; ++t) {
-            memcpy(e, cat + (size_t)idx[(size_t)n * k + t] * 512 + 128, sizeof(float) * 128);
-            matvec(w[LPD_W_SN1], e, y, 256, 256);
-            bn_act(y, w + LPD_W_BNSN1, 256, 1);
-            for (int c = 0; c < 256; ++c) x3[c] = fmaxf(x3[c], y[c]);
+            memcpy(e + (size_t)t * 256, cat + (size_t)idx[(size_t)n * k + t] * 512 + 128, sizeof(float) * 128);
+            memcpy(e + (size_t)t * 256 + 128, cat + (size_t)n * 512 + 128, sizeof(float) * 128);
+        }
+        matmat(w[LPD_W_SN1], e, 256, y, 256, 256, 256, k);
+        for (int t = 0; t < k; ++t) {
+            bn_act(y + (size_t)t * 256, w + LPD_W_BNSN1, 256, 1);
+            for (int c = 0; c < 256; ++c) x3[c] = fmaxf(x3[c], y[(size_t)t * 256 + c]);
         }
     }
+    free(eb);
     /* conv3 / bn3 / act (:260-262) and the NetVLAD soft assignment (PointNetVlad.py:48-58): a[n] = softmax(bn1(feat[n] . Wc)) */
     float *wct = (float *)malloc(sizeof(float) * (size_t)K * E);       /* cluster_weights transposed: [K][E] */
     if (!wct) return -1;
     for (int e2 = 0; e2 < E; ++e2)
         for (int c = 0; c < K; ++c) wct[(size_t)c * E + e2] = w[LPD_W_CW][(size_t)e2 * K + c];
+    for (int n0 = 0; n0 < N; n0 += 32) {      /* 32 points per block: the 2 MiB conv3 weight is streamed once per block */
+        const int np = N - n0 < 32 ? N - n0 : 32;
+        matmat(w[LPD_W_CONV3], cat + (size_t)n0 * 512, 512, feat + (size_t)n0 * E, E, E, 512, np);
+        for (int r = 0; r < np; ++r) bn_act(feat + (size_t)(n0 + r) * E, w + LPD_W_BN3, E, 1);
+        matmat(wct, feat + (size_t)n0 * E, E, a + (size_t)n0 * K, K, K, E, np);
+    }
     for (int n = 0; n < N; ++n) {
-        float *fn = feat + (size_t)n * E, *an = a + (size_t)n * K;
-        matvec(w[LPD_W_CONV3], cat + (size_t)n * 512, fn, E, 512);
-        bn_act(fn, w + LPD_W_BN3, E, 1);
-        matvec(wct, fn, an, K, E);
+        float *an = a + (size_t)n * K;
         bn_act(an, w + LPD_W_VBN1, K, 0);
         float mx = an[0], s = 0.0f;
         for (int c = 1; c < K; ++c) mx = fmaxf(mx, an[c]);
