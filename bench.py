@@ -257,6 +257,11 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
+    # stdout carries exactly ONE line (the JSON): libraries that print banners to fd 1 (RCCL prints its version block when the
+    # first communicator is created) are sent to stderr; the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -417,7 +422,8 @@ def main():
             rel = ((got - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)).max().item()
             line["cpu_baseline"] = base
             line["parity_norm_rel_vs_oracle"] = float(f"{rel:.3e}")
-        print(json.dumps(line), flush=True)
+        line_out.write(json.dumps(line) + "\n")
+        line_out.flush()
     if dist is not None:
         dist.destroy_process_group()
 
