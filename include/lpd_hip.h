@@ -417,6 +417,11 @@ int lpd_gemm_bf16s(const uint16_t* A, const float* W, int ldw, int b_kmajor, uin
 long long lpd_gemm_tn_bf16_ws_floats(long long M, int KA, int KB);
 int lpd_gemm_tn_bf16(const uint16_t* A, const uint16_t* B, float* dW, float* ws, long long M, int KA, int KB, void* stream);
 
+/* dW [KA][KB] (fp32) = sum_m A[m][:]^T B[m][:] for fp32 operands A [M][lda], B [M][ldb] in split-bf16 form (three MFMA products per
+ * term, fp32-grade): the weight gradients dW = dY^T X.  KA %% 128 == 0, KB %% 64 == 0; ws: lpd_gemm_tn_ws_floats(M, KA, KB) floats. */
+long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB);
+int lpd_gemm_tn(const float* A, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -597,7 +597,10 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint16_t* __res
     const bool active = tid < KA + KB;
     const uint16_t* src = (isA ? A : B) + c8 * 8;
     const int ldsrc = isA ? KA : KB;
-    uint16_t* dst = (isA ? at : bt) + (c8 * 8) * LDT + rg * 8;
+    // column blocks (8 rows of m = 16 bytes) are XOR-swizzled with the channel group: a wave's sixteen lanes with consecutive
+    // c8 write rows 8 * 144 bytes apart, i.e. onto only two of the sixteen 16-byte bank groups (8-way conflicts on every
+    // ds_write_b128: 8 of the 15 k cycles per chunk); the readers apply the same swizzle
+    uint16_t* dst = (isA ? at : bt) + (c8 * 8) * LDT + ((rg ^ (c8 >> 1)) & 7) * 8;
     uint4 pr[8];
     auto load_patch = [&](long long m0) {
 #pragma unroll
@@ -641,8 +644,9 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint16_t* __res
                 const int ta = tile / TB, tb = tile % TB;
 #pragma unroll
                 for (int s = 0; s < CH / 16; ++s) {
-                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(at + (ta * 32 + col) * LDT + s * 16 + h * 8);
-                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bt + (tb * 32 + col) * LDT + s * 16 + h * 8);
+                    const int ca = ta * 32 + col, cb = tb * 32 + col;
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(at + ca * LDT + (((s * 2 + h) ^ (ca >> 4)) & 7) * 8);
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bt + cb * LDT + (((s * 2 + h) ^ (cb >> 4)) & 7) * 8);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
                 }
             }
@@ -661,6 +665,127 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint16_t* __res
             }
         }
     }
+}
+
+// The same product for fp32 operands in split-bf16 form (hi + lo of both operands, three MFMA products per term: fp32-grade,
+// lpd_gemm.hip "bf16x3"): dW[a][b] = sum_m A[m][a] * B[m][b], A [M][lda], B [M][ldb] fp32 row-major -- the weight gradients
+// dW = dY^T X of the point layers and of the projections (reduction over B*N = 180 224 rows, or over the 3.6 M edges).
+// The generic kernel stages k-major operands as 4 x 4 fp32 patches with 8-byte LDS writes and is bound by that staging
+// (dW3 [1024 x 512 x 180224]: 1.7 ms with three products AND with one).  Here a block owns a 128 x KBT output tile and an m-range
+// (split over grid.z); per 64-row chunk a thread loads an 8 x 8 fp32 patch (sixteen 16-byte loads, requested one chunk
+// ahead), converts it to packed bf16 hi / lo pairs, transposes both in registers (v_perm_b32) and writes sixteen 16-byte
+// channel pieces into four [channel][row] LDS images.
+template <int KBT>
+__global__ __launch_bounds__(256) void gemm_tn_x3_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B,
+                                                         long long ldb, float* __restrict__ slabs, long long M, int KA, int KB,
+                                                         long long rows_per_split)
+{
+    constexpr int CH = 64, LDT = CH + 8;
+    constexpr int TB = KBT / 32;               // output tiles along b; 4 along a
+    constexpr int TPW = TB;                    // tiles per wave: wave w owns a-tile w, all b-tiles
+    __shared__ __attribute__((aligned(16))) uint16_t ah[128 * LDT];
+    __shared__ __attribute__((aligned(16))) uint16_t al[128 * LDT];
+    __shared__ __attribute__((aligned(16))) uint16_t bh[KBT * LDT];
+    __shared__ __attribute__((aligned(16))) uint16_t bl[KBT * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    // XCD-aware order: the output tiles of ONE m-range run next to each other on one XCD, so the rows they all read (A re-read by
+    // every b-tile, B by every a-tile) come from that XCD's L2 once (in (x, y, z) grid order the 32 tiles of a range were dealt
+    // to all eight XCDs: 5.9 GB through the fabric for the 1.1 GB dW3 operands, 1.12 ms)
+    const int ntile_a = KA / 128, ntile_b = KB / KBT;
+    const int lin = lpd_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = lin % (ntile_a * ntile_b), zsplit = lin / (ntile_a * ntile_b);
+    const int a0 = (tile % ntile_a) * 128, b0 = (tile / ntile_a) * KBT;
+    const long long m_begin = (long long)zsplit * rows_per_split;
+    const long long m_end = min(M, m_begin + rows_per_split);
+    const bool isA = tid < 128;
+    const int pt = isA ? tid : tid - 128;
+    const int ncg = (isA ? 128 : KBT) / 8;
+    const int c8 = pt % ncg, rg = pt / ncg;
+    const bool active = isA || pt < KBT;       // KBT = 64: threads 192.. have no patch
+    const float* src = isA ? A + a0 + c8 * 8 : B + b0 + c8 * 8;
+    const long long ldsrc = isA ? lda : ldb;
+    const int swz = ((rg ^ (c8 >> 1)) & 7) * 8;      // XOR-swizzled column block (see gemm_tn_bf16_kernel)
+    uint16_t* dhi = (isA ? ah : bh) + (c8 * 8) * LDT + swz;
+    uint16_t* dlo = (isA ? al : bl) + (c8 * 8) * LDT + swz;
+    float4 pr[16];
+    auto load_patch = [&](long long m0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long m = m0 + rg * 8 + i;
+            const bool ok = active && m < m_end;
+            pr[2 * i] = ok ? *reinterpret_cast<const float4*>(src + m * ldsrc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pr[2 * i + 1] = ok ? *reinterpret_cast<const float4*>(src + m * ldsrc + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_patch = [&]() {
+        if (!active) return;
+        uint32_t wh[8][4], wl[8][4];           // row i, channel pair p: packed bf16 (channel 2p | channel 2p+1 << 16)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v[8] = {pr[2 * i].x, pr[2 * i].y, pr[2 * i].z, pr[2 * i].w, pr[2 * i + 1].x, pr[2 * i + 1].y, pr[2 * i + 1].z, pr[2 * i + 1].w};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t hp = pack_bf16(v[2 * p], v[2 * p + 1]);
+                const float r0 = v[2 * p] - __uint_as_float(hp << 16), r1 = v[2 * p + 1] - __uint_as_float(hp & 0xffff0000u);
+                wh[i][p] = hp;
+                wl[i][p] = pack_bf16(r0, r1);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint4 lo, hi;
+            lo.x = __builtin_amdgcn_perm(wh[1][p], wh[0][p], 0x05040100u); hi.x = __builtin_amdgcn_perm(wh[1][p], wh[0][p], 0x07060302u);
+            lo.y = __builtin_amdgcn_perm(wh[3][p], wh[2][p], 0x05040100u); hi.y = __builtin_amdgcn_perm(wh[3][p], wh[2][p], 0x07060302u);
+            lo.z = __builtin_amdgcn_perm(wh[5][p], wh[4][p], 0x05040100u); hi.z = __builtin_amdgcn_perm(wh[5][p], wh[4][p], 0x07060302u);
+            lo.w = __builtin_amdgcn_perm(wh[7][p], wh[6][p], 0x05040100u); hi.w = __builtin_amdgcn_perm(wh[7][p], wh[6][p], 0x07060302u);
+            *reinterpret_cast<uint4*>(dhi + (2 * p) * LDT) = lo;
+            *reinterpret_cast<uint4*>(dhi + (2 * p + 1) * LDT) = hi;
+            lo.x = __builtin_amdgcn_perm(wl[1][p], wl[0][p], 0x05040100u); hi.x = __builtin_amdgcn_perm(wl[1][p], wl[0][p], 0x07060302u);
+            lo.y = __builtin_amdgcn_perm(wl[3][p], wl[2][p], 0x05040100u); hi.y = __builtin_amdgcn_perm(wl[3][p], wl[2][p], 0x07060302u);
+            lo.z = __builtin_amdgcn_perm(wl[5][p], wl[4][p], 0x05040100u); hi.z = __builtin_amdgcn_perm(wl[5][p], wl[4][p], 0x07060302u);
+            lo.w = __builtin_amdgcn_perm(wl[7][p], wl[6][p], 0x05040100u); hi.w = __builtin_amdgcn_perm(wl[7][p], wl[6][p], 0x07060302u);
+            *reinterpret_cast<uint4*>(dlo + (2 * p) * LDT) = lo;
+            *reinterpret_cast<uint4*>(dlo + (2 * p + 1) * LDT) = hi;
+        }
+    };
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    load_patch(m_begin);
+    for (long long m0 = m_begin; m0 < m_end; m0 += CH) {
+        __syncthreads();
+        store_patch();
+        __syncthreads();
+        if (m0 + CH < m_end) load_patch(m0 + CH);
+#pragma unroll
+        for (int s = 0; s < CH / 16; ++s) {
+            const int ca = wave * 32 + col;
+            const int oa = ca * LDT + (((s * 2 + h) ^ (ca >> 4)) & 7) * 8;
+            const bf16x8 avh = *reinterpret_cast<const bf16x8*>(ah + oa);
+            const bf16x8 avl = *reinterpret_cast<const bf16x8*>(al + oa);
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                const int cb = j * 32 + col;
+                const int ob = cb * LDT + (((s * 2 + h) ^ (cb >> 4)) & 7) * 8;
+                const bf16x8 bvh = *reinterpret_cast<const bf16x8*>(bh + ob);
+                const bf16x8 bvl = *reinterpret_cast<const bf16x8*>(bl + ob);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl, bvh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avh, bvl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avh, bvh, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    float* slab = slabs + (size_t)zsplit * KA * KB;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int arow = a0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            slab[(size_t)arow * KB + b0 + j * 32 + col] = acc[j][r];
+        }
 }
 
 __global__ void gemm_tn_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int n, int nslabs)
@@ -856,5 +981,32 @@ extern "C" int lpd_gemm_tn_bf16(const uint16_t* A, const uint16_t* B, float* dW,
     const int n = KA * KB;
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)ws, dW, n, (int)blocks);
     LPD_CHECK_LAUNCH("lpd_gemm_tn_bf16(reduce)");
+    return LPD_OK;
+}
+
+extern "C" long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB)
+{
+    long long tiles = (long long)(KA / 128) * ((KB + 127) / 128);
+    long long splits = 1;
+    while (tiles * splits * 2 <= 1024 && M / (splits * 2) >= 1024) splits *= 2;
+    return splits * KA * KB;
+}
+
+extern "C" int lpd_gemm_tn(const float* A, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
+                           void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(A && B && dW && ws && M > 0, "lpd_gemm_tn: null pointer");
+    LPD_CHECK_ARG(KA > 0 && KA % 128 == 0 && KB > 0 && KB % 64 == 0, "lpd_gemm_tn: KA %% 128 and KB %% 64 required (KA=%d KB=%d)", KA, KB);
+    LPD_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0, "lpd_gemm_tn: operands must be 16-byte aligned rows");
+    const long long splits = lpd_gemm_tn_ws_floats(M, KA, KB) / ((long long)KA * KB);
+    long long rps = (M + splits - 1) / splits;
+    rps = (rps + 63) / 64 * 64;
+    if (KB % 128 == 0) hipLaunchKernelGGL((gemm_tn_x3_kernel<128>), dim3((unsigned)((KA / 128) * (KB / 128) * splits)), dim3(256), 0, stream, A, lda, B, ldb, ws, M, KA, KB, rps);
+    else hipLaunchKernelGGL((gemm_tn_x3_kernel<64>), dim3((unsigned)((KA / 128) * (KB / 64) * splits)), dim3(256), 0, stream, A, lda, B, ldb, ws, M, KA, KB, rps);
+    LPD_CHECK_LAUNCH("lpd_gemm_tn");
+    const int n = KA * KB;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)ws, dW, n, (int)splits);
+    LPD_CHECK_LAUNCH("lpd_gemm_tn(reduce)");
     return LPD_OK;
 }

@@ -160,6 +160,8 @@ def _dweight(dY, X, rows=None):
     Co, Kin = dY.shape[1], X.shape[1]
     if Kin <= 8:
         return ops.dw_smallk(dY[:R], X[:R])
+    if ops.gemm_tn_applies(dY, X, R):       # long reductions: the register-transposing split-bf16 kernel
+        return ops.gemm_tn(dY, X, rows=R)
     tiles = ((Co + 127) // 128) * ((Kin + 127) // 128)
     return ops.gemm(dY[:R], X[:R], a_kmajor=True, b_kmajor=True, splits=_pick_splits(R, tiles))
 

@@ -1018,6 +1018,28 @@ def gemm_tn_bf16(A, B):
     return dW
 
 
+GEMM_TN = os.environ.get("LPD_GEMM_TN", "1") != "0"      # weight gradients on the register-transposing kernel (lpd_gemm_tn)
+
+
+def gemm_tn(A, B, rows=None):
+    """dW [KA, KB] = A^T B over the (first `rows`) rows; A [M, KA], B [M, KB] fp32 row-major (column slices allowed);
+    KA % 128 == 0, KB % 64 == 0.  Split-bf16 (three products): the accuracy of lpd_gemm_bf16x3."""
+    lda, ldb = _rows(A, "A"), _rows(B, "B")
+    M = A.shape[0] if rows is None else rows
+    KA, KB = A.shape[1], B.shape[1]
+    lib = _lib.load()
+    ws = torch.empty((int(lib.lpd_gemm_tn_ws_floats(M, KA, KB)),), dtype=torch.float32, device=A.device)
+    dW = torch.empty((KA, KB), dtype=torch.float32, device=A.device)
+    _call(f"gemm_tn[{KA}x{KB}x{M}]", lib.lpd_gemm_tn, _ptr(A), lda, _ptr(B), ldb, _ptr(dW), _ptr(ws), M, KA, KB, _stream())
+    return dW
+
+
+def gemm_tn_applies(A, B, rows):
+    return (GEMM_TN and GEMM_BF16X3 and _EXACT.depth == 0 and A.dim() == 2 and B.dim() == 2 and A.shape[1] % 128 == 0
+            and B.shape[1] % 64 == 0 and rows >= 4096 and A.stride(1) == 1 and B.stride(1) == 1 and A.stride(0) % 4 == 0
+            and B.stride(0) % 4 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
 def dw_smallk(dY, X):
     lddy, ldx = _rows(dY, "dY"), _rows(X, "X")
     M, Co = dY.shape

@@ -758,3 +758,20 @@ def test_windowed_kagg_is_bit_identical(cuda, C, N, k, B, graph):
         ops.edge_gather_maxw(pq[:, :C // 8], pq[:, C // 8:], i16, N, scale=scale, shift=shift, act=ops.ACT_LEAKY, slope=0.01, out=out)
         want = ops.edge_gather_max(PQ[:, :C], PQ[:, C:], idx, N, scale=scale, shift=shift, act=ops.ACT_LEAKY, slope=0.01)
         assert torch.equal(ops.panels_to_rows(out), want)
+
+
+@pytest.mark.parametrize("M,KA,KB", [(8192, 128, 64), (20000, 256, 128), (4096 + 37, 1024, 512), (70000, 512, 128)])
+def test_gemm_tn_weight_gradient_kernel(cuda, M, KA, KB):
+    """lpd_gemm_tn: dW = A^T B over the rows (register-transposed staging, split-bf16): fp32-grade against fp64, ragged row
+    counts, column-slice operands, and agreement with the generic k-major product."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + KA)
+    wide = torch.randn(M, KA + KB + 8, generator=g).to(cuda)
+    A, B = wide[:, 4:4 + KA], wide[:, 4 + KA:4 + KA + KB]
+    ref = A.double().t() @ B.double()
+    got = ops.gemm_tn(A, B)
+    assert _rel(got, ref) < 2e-5
+    got_r = ops.gemm_tn(A, B, rows=M - 100)
+    assert _rel(got_r, A[:M - 100].double().t() @ B[:M - 100].double()) < 2e-5
+    old = ops.gemm(A.contiguous(), B.contiguous(), a_kmajor=True, b_kmajor=True, splits=8)
+    assert _rel(got, old) < 2e-5
