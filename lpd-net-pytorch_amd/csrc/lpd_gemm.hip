@@ -1098,6 +1098,8 @@ static void x3w_wide_launch(const X3wArgs& g, int NT, hipStream_t stream)
     if constexpr (WN == 1) {
         if (NT <= 2) { x3w_wide_launch_kc<1, PANELS, 32, true>(g, NT, stream); return; }   // N <= 64: the NetVLAD assignment
     }
+    static const int kc64 = getenv("LPD_X3W_KC") ? atoi(getenv("LPD_X3W_KC")) == 64 : 0;   // experiment: 64-deep chunks
+    if (kc64 && g.K % 64 == 0) { x3w_wide_launch_kc<WN, PANELS, 64>(g, NT, stream); return; }
     x3w_wide_launch_kc<WN, PANELS, 32>(g, NT, stream);
 }
 
