@@ -862,16 +862,47 @@ constexpr bool KNN7_ONFLY64 = false;
 // ([tiles][32] bf16) would not fit: N > 4096.  KMAX > 20 (k up to 64: the stress configuration): 128 list registers per lane,
 // one wave per SIMD, and the wave's region must hold the two half-lists for the final merge (64 * KMAX * 8 bytes).
 template <int CP, int KMAX, bool ONFLY> struct Knn7Cfg {
-    // 64-entry lists: the region is 32 KiB for the merge anyway, so the queue may be twice as deep -- fewer, better balanced
-    // drains (a drain runs max-over-lanes iterations of a 64-slot insertion)
-    static constexpr int QCAP = KMAX > 20 ? KNN7_QCAP_BIG : ((CP == 2) ? KNN7_QCAP_XYZ : KNN7_QCAP);
+    // 64-entry lists: the two half-lists are merged IN REGISTERS (knn_merge_halves_bitonic: no LDS region), so the wave's LDS is its
+    // queue alone.  64 channels run one wave per SIMD (304 registers) and take a deep queue (fewer, better balanced drains: a drain
+    // runs max-over-lanes iterations of a 64-slot insertion); three coordinates fit two waves per SIMD (240 registers) with 16 KiB each.
+    static constexpr int QCAP = KMAX > 20 ? (CP == 2 ? 32 : KNN7_QCAP_BIG) : ((CP == 2) ? KNN7_QCAP_XYZ : KNN7_QCAP);
     static constexpr int QBYTES = QCAP * 64 * 8;
     static constexpr int TBYTES = ONFLY ? 0 : KNN7_MAXT * 32 * 2;
-    static constexpr int MERGE = 64 * KMAX * 8;
+    static constexpr int MERGE = KMAX > 20 ? 0 : 64 * KMAX * 8;
     static constexpr int WAVE = (TBYTES + QBYTES) > MERGE ? (TBYTES + QBYTES) : MERGE;
     static constexpr int QOFF = TBYTES;      // byte offset of the queue inside the wave's region
-    static constexpr int WAVES_PER_SIMD = KMAX > 20 ? 1 : (CP == 2 ? 4 : 2);
+    static constexpr int WAVES_PER_SIMD = KMAX > 20 ? (CP == 2 ? 2 : 1) : (CP == 2 ? 4 : 2);
 };
+
+// Merge of the two half-lists of every query (lanes l and l + 32 hold disjoint candidate subsets, each sorted by (value descending,
+// index ascending)) without LDS: a bitonic merge on registers.  Stage 1 (half-cleaner against the partner's REVERSED list, read by
+// lane shuffles) leaves the 64 best of the union as a bitonic sequence in both half-lanes; six compare-exchange stages on static
+// register indices sort it.  Indices are distinct across the halves, so the order is total and the result is the reference's.
+__device__ __forceinline__ bool knn_before(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
+
+__device__ __forceinline__ void knn_merge_halves_bitonic(float (&v)[64], int (&id)[64])
+{
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {       // pairs (s, 63 - s): both partner values are read before either of mine is replaced
+        const int r = 63 - s;
+        const float pv_r = __shfl_xor(v[r], 32, 64), pv_s = __shfl_xor(v[s], 32, 64);
+        const int pi_r = __shfl_xor(id[r], 32, 64), pi_s = __shfl_xor(id[s], 32, 64);
+        const bool ks = knn_before(v[s], id[s], pv_r, pi_r);      // slot s: the better of mine[s] and partner[63 - s]
+        const bool kr = knn_before(v[r], id[r], pv_s, pi_s);      // slot 63 - s: the better of mine[63 - s] and partner[s]
+        v[s] = ks ? v[s] : pv_r; id[s] = ks ? id[s] : pi_r;
+        v[r] = kr ? v[r] : pv_s; id[r] = kr ? id[r] : pi_s;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+        for (int s = 0; s < 64; ++s)
+            if ((s & d) == 0) {
+                const bool sw = knn_before(v[s + d], id[s + d], v[s], id[s]);
+                const float tv = v[s]; const int ti = id[s];
+                v[s] = sw ? v[s + d] : tv; id[s] = sw ? id[s + d] : ti;
+                v[s + d] = sw ? tv : v[s + d]; id[s + d] = sw ? ti : id[s + d];
+            }
+}
 
 // tile statistics: centroid (packed operand layout), |c|^2, radius (inflated), max |x|^2.  One wave per tile.
 template <int CP>
@@ -1217,6 +1248,23 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
         nxt = cur >= 0 ? find_next() : -1;
     }
     drain();
+    if constexpr (KMAX == 64) {
+        // ---- merge the two half-lists in registers (no LDS region) ----
+        if (dbg && q_ok) {   // diagnostics instead of indices
+            int32_t* o = idx + ((size_t)b * N + q) * k;
+            if (h == 0) { o[0] = stat_tiles; o[1] = stat_it; o[2] = stat_adm; o[3] = stat_drains; }
+            else o[4] = stat_adm;
+            return;
+        }
+        knn_merge_halves_bitonic(lv, li);
+        if (h == 0 && q_ok) {
+            int32_t* out = idx + ((size_t)b * N + q) * k;
+#pragma unroll
+            for (int s = 0; s < 64; ++s)
+                if (s < k) out[s] = li[s];
+        }
+        return;
+    } else {
     // ---- merge the two half-lists (same as the ascending kernel); region: this wave's table + queue (20 KiB >= 64*KMAX*8) ----
     float* mv = reinterpret_cast<float*>(smem7 + (size_t)wave * L::WAVE);
     int* mi = reinterpret_cast<int*>(mv + 64 * KMAX);
@@ -1250,6 +1298,7 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
             else out[s] = bi[pb++];
         }
     }
+    }   // KMAX != 64
 }
 
 template <int CP, int KMAX>
@@ -1295,7 +1344,7 @@ template <int CP, int KMAX, bool ONFLY>
 int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg = 0)
 {
     using L = Knn7Cfg<CP, KMAX, ONFLY>;
-    static_assert(L::WAVE >= 64 * KMAX * 8, "merge region must fit the wave's LDS region");
+    static_assert(L::WAVE >= L::MERGE, "merge region must fit the wave's LDS region");
     const int nt = (N + 31) / 32;
     float* xp = const_cast<float*>(xx) + (size_t)B * N;
     float* cenp = xp + (size_t)B * N * 2 * CP;
