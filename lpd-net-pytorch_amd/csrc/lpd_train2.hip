@@ -532,27 +532,34 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(const uint16_t* __restr
     const int lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
     const long long ntile = (M + 31) / 32;
-    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
-        const long long row = tile * 32 + col;
+    const long long stride = (long long)gridDim.x * 4;
+    long long tile = (long long)blockIdx.x * 4 + wave;
+    bf16x8 a[KS], an[KS];
+    auto load_rows = [&](long long t, bf16x8 (&dst)[KS]) {
+        const long long row = t * 32 + col;
         const long long rr = row < M ? row : M - 1;
         const uint16_t* ap = A + rr * K + h * (K / 2);
-        bf16x8 a[KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const bf16x8*>(ap + s * 8);
+        for (int s2 = 0; s2 < KS; ++s2) dst[s2] = *reinterpret_cast<const bf16x8*>(ap + s2 * 8);
+    };
+    if (tile < ntile) load_rows(tile, a);
+    for (; tile < ntile; tile += stride) {
+        const long long row = tile * 32 + col;
+        load_rows(tile + stride < ntile ? tile + stride : tile, an);     // the next tile's rows, in flight under this tile's MFMAs
         f32x16 acc[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
+        for (int s2 = 0; s2 < KS; ++s2) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int off = (j * 32 + col) * LDW + h * (K / 2) + s * 8;
+                const int off = (j * 32 + col) * LDW + h * (K / 2) + s2 * 8;
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(whi + off);
                 const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wlo + off);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, a[s], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, a[s], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, a[s2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, a[s2], acc[j], 0, 0, 0);
             }
         }
         if (row < M) {
@@ -565,6 +572,8 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(const uint16_t* __restr
                     *reinterpret_cast<uint2*>(cp + j * 32 + 8 * g + 4 * h) = pk;
                 }
         }
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) a[s2] = an[s2];
     }
 }
 
