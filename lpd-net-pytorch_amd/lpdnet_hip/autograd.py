@@ -328,12 +328,14 @@ class _Front:
         return names
 
     @staticmethod
-    def fwd(net, xyz, w1, bn1, w2, bn2, B, N, act, slope):
-        S = dict(xyz=xyz, p_in=xyz)
+    def fwd(net, xyz, w1, bn1, w2, bn2, B, N, act, slope, p_all=None):
+        """p_all: the [M, 8] input rows under use_mFea (xyz + 5 features, lpdnet_model.py:215-224); conv1 then sees 8 columns"""
+        from . import engine
+        S = dict(xyz=xyz, p_in=xyz if p_all is None else p_all)
         with ops.exact_gemm():      # F0 feeds the feature-space kNN: exact fp32 (the backward may use the fast GEMM)
             if net.t3d:
                 S["trans3"], S["S3"] = _TNet.fwd(net.t_net3d, xyz, B, N, True)
-                S["p_in"] = ops.apply_transform(xyz, S["trans3"], N)
+                S["p_in"] = engine._aligned_input(ops.apply_transform(xyz, S["trans3"], N), p_all, p_all is not None)
             S["y1"], S["st1"], S["f1"] = _PointLayer.fwd(S["p_in"], w1, bn1, act, slope)
             S["y2"], S["st2"], f0 = _PointLayer.fwd(S["f1"], w2, bn2, act, slope)
             if net.tfea:
@@ -353,9 +355,12 @@ class _Front:
         if net.t3d:    # p = xyz @ trans3 feeds conv1: gradient to trans3 only (the cloud itself needs none)
             dy1, dg1, db1 = ops.bn_act_bwd(df1, S["y1"], S["st1"], act, slope, out=df1)
             dwc1 = _dweight(dy1, S["p_in"])
-            w1p = torch.zeros((w1.shape[0], 4), dtype=torch.float32, device=w1.device)
-            w1p[:, :3] = w1
-            dp = ops.gemm(dy1, w1p, b_kmajor=True)[:, :3]
+            if w1.shape[1] % 4 == 0:      # use_mFea: 8 input columns, the gradient of the 3 aligned coordinates is the first 3
+                dp = ops.gemm(dy1, w1.contiguous(), b_kmajor=True)[:, :3]
+            else:
+                w1p = torch.zeros((w1.shape[0], 4), dtype=torch.float32, device=w1.device)
+                w1p[:, :3] = w1
+                dp = ops.gemm(dy1, w1p, b_kmajor=True)[:, :3]
             dt3 = ops.cloud_outer(S["xyz"], dp, B, N)
             _, g_3 = _TNet.bwd(net.t_net3d, dt3, S["S3"], B, N, True, need_dh=False)
         else:
@@ -393,8 +398,13 @@ class _LPDNetTrainFn(torch.autograd.Function):
         act, slope = (ops.ACT_RELU, 0.0) if net.use_relu else (ops.ACT_LEAKY, LEAKY)
         bf16 = TRAIN_STORAGE == "bf16"
         w2d = engine._w2d
-        xyz = x.view(M, 3)
-        f0, front = _Front.fwd(net, xyz, w2d(net.conv1_lpd), net.bn1_lpd, w2d(net.conv2_lpd), net.bn2_lpd, B, N, act, slope)
+        p_all = None
+        if x.shape[3] == 8:       # use_mFea
+            xyz, p_all = engine.split_mfea(x)
+            x = xyz.view(B, 1, N, 3)
+        else:
+            xyz = x.view(M, 3)
+        f0, front = _Front.fwd(net, xyz, w2d(net.conv1_lpd), net.bn1_lpd, w2d(net.conv2_lpd), net.bn2_lpd, B, N, act, slope, p_all)
         idx_f = engine._knn_rows(f0, B, N, 64, k)
         cat = torch.empty((M, 512), dtype=torch.float32, device=x.device)
         # DG1 -> DG2 (split projection; convDG2 consumes EVERY post-activation edge, so these edge tensors must exist:
@@ -547,10 +557,15 @@ class _LPDNetOrignTrainFn(torch.autograd.Function):
         M, k = B * N, net.k
         act, slope = (ops.ACT_RELU, 0.0) if net.use_relu else (ops.ACT_LEAKY, LEAKY)
         w2d = engine._w2d
-        xyz = x.view(M, 3)
+        p_all = None
+        if x.shape[3] == 8:       # use_mFea
+            xyz, p_all = engine.split_mfea(x)
+            x = xyz.view(B, 1, N, 3)
+        else:
+            xyz = x.view(M, 3)
         S = {}
         f0, S["front"] = _Front.fwd(net, xyz, w2d(net.conv1_lpd[0]), net.conv1_lpd[1], w2d(net.conv2_lpd[0]), net.conv2_lpd[1],
-                                    B, N, act, slope)
+                                    B, N, act, slope, p_all)
         S["f0"] = f0
         idx_f = engine._knn_rows(f0, B, N, 64, k)
         wcat1 = engine.split_edge_weight(net.convDG1, "cat_cd")
@@ -606,7 +621,7 @@ class _LPDNetOrignTrainFn(torch.autograd.Function):
 def lpdnet_origin_features_train(net, x, reorder=True):
     """LPDNetOrign training-mode forward: ([B*N, E] features with autograd, B, N)."""
     from . import engine
-    x = engine.reorder_points(engine._check_input(x), reorder)
+    x = engine._check_input(x, 8) if net.use_mFea else engine.reorder_points(engine._check_input(x), reorder)
     params = _named(net, list(_LPDNetOrignTrainFn.PARAMS) + _Front.tnet_param_names(net))
     feat = _LPDNetOrignTrainFn.apply(net, x, *params)
     return feat, x.shape[0], x.shape[2]
@@ -625,7 +640,7 @@ def _named(module, names):
 def lpdnet_features_train(net, x, reorder=True):
     """LPDNet training-mode forward: ([B*N, E] features with autograd, B, N)."""
     from . import engine
-    x = engine.reorder_points(engine._check_input(x), reorder)
+    x = engine._check_input(x, 8) if net.use_mFea else engine.reorder_points(engine._check_input(x), reorder)
     names = list(_LPDNetTrainFn.PARAMS) + _Front.tnet_param_names(net)
     feat = _LPDNetTrainFn.apply(net, x, *_named(net, names))
     return feat, x.shape[0], x.shape[2]
@@ -720,6 +735,24 @@ class _ToPointMajor(torch.autograd.Function):
     def backward(ctx, d):
         B, E, N = ctx.shape
         return ops.transpose(d.contiguous().view(B, N, E))
+
+
+class _ToChannelMajor(torch.autograd.Function):
+    """[B*N, E] point-major rows -> the reference's [B, E, N, 1] with a gradient (the public trunk forwards in train mode)"""
+
+    @staticmethod
+    def forward(ctx, feat, B, N):
+        ctx.dims = (B, N, feat.shape[1])
+        return ops.transpose(feat.view(B, N, feat.shape[1])).unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, d):
+        B, N, E = ctx.dims
+        return ops.transpose(d.reshape(B, E, N).contiguous()).view(B * N, E), None, None
+
+
+def to_channel_major_train(feat, B, N):
+    return _ToChannelMajor.apply(feat, B, N)
 
 
 def to_point_major_train(x4):

@@ -104,9 +104,9 @@ def _need_eval(module, what):
             f"{what}: training-mode forward goes through lpdnet_hip.autograd; call .eval() for inference")
 
 
-def _check_input(x):
-    if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 1 or x.shape[3] != 3:
-        raise ValueError(f"expected input [B,1,N,3], got {tuple(x.shape) if isinstance(x, torch.Tensor) else type(x)}")
+def _check_input(x, dims=3):
+    if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 1 or x.shape[3] != dims:
+        raise ValueError(f"expected input [B,1,N,{dims}], got {tuple(x.shape) if isinstance(x, torch.Tensor) else type(x)}")
     if not x.is_cuda:
         raise ops._lib.LpdHipError(
             f"input is on {x.device}: the LPD-Net HIP path runs on MI355X only (no CPU fallback)")
@@ -210,15 +210,26 @@ def kagg(P, Q, idx, N, *, scale, shift, act, slope, out, idx16w=None):
     return ops.edge_gather_max(P, Q, idx, N, scale=scale, shift=shift, act=act, slope=slope, out=out)
 
 
+def split_mfea(x):
+    """use_mFea inputs [B,1,N,8] (lpdnet_model.py:215-218): -> (xyz rows [B*N,3] contiguous, all 8 columns [B*N,8])"""
+    rows = x.view(-1, 8)
+    return rows[:, :3].contiguous(), rows
+
+
 def lpdnet_features_eval(net, x, reorder=True):
     """util/lpdnet_model.py:211-268 (LPDNet.forward), eval mode."""
-    x = reorder_points(_check_input(x), reorder)
+    mfea = getattr(net, "use_mFea", False)
+    x = _check_input(x, 8) if mfea else reorder_points(_check_input(x), reorder)
     B, N = x.shape[0], x.shape[2]
     M = B * N
     k = net.k
     act, slope = (ops.ACT_RELU, 0.0) if net.use_relu else (ops.ACT_LEAKY, LEAKY_SLOPE)
-    xyz = x.view(M, 3)
-    p = xyz
+    if mfea:
+        xyz, p = split_mfea(x)
+        x = xyz.view(B, 1, N, 3)
+    else:
+        xyz = x.view(M, 3)
+        p = xyz
     side_job = None
     if SIDE_STREAM and PANEL_LAYOUT and N % 128 == 0 and _resident_shape(k, N, M, act):
         # The static graph in Cartesian space depends on the input alone: its kNN (wave-slot-bound, two waves per SIMD) runs
@@ -232,7 +243,7 @@ def lpdnet_features_eval(net, x, reorder=True):
     with ops.exact_gemm():      # everything in front of the feature-space kNN is exact fp32
         if net.t3d:
             trans = transform_net_eval(net.t_net3d, xyz, B, N)
-            p = ops.apply_transform(xyz, trans, N)
+            p = _aligned_input(ops.apply_transform(xyz, trans, N), p, mfea)
         s, b = bn_affine(net.bn1_lpd)
         f = ops.linear(p, _w2d(net.conv1_lpd), scale=s, shift=b, act=act, slope=slope)
         s, b = bn_affine(net.bn2_lpd)
@@ -317,9 +328,16 @@ def lpdnet_features_eval(net, x, reorder=True):
     return ops.linear(cat, _w2d(net.conv3_lpd), scale=sc, shift=bc, act=act, slope=slope), B, N
 
 
+def _aligned_input(xyz_t, p_all, mfea):
+    """conv1 input after the coordinate T-Net: the aligned xyz, with the 5 feature columns behind it under use_mFea
+    (lpdnet_model.py:221-222; an 8-float row per point: input plumbing)"""
+    return torch.cat((xyz_t, p_all[:, 3:]), dim=1).contiguous() if mfea else xyz_t
+
+
 def lpdnet_origin_features_eval(net, x, reorder=True):
     """util/lpdnet_model.py:68-114 (LPDNetOrign.forward), eval mode."""
-    x = reorder_points(_check_input(x), reorder)
+    mfea = getattr(net, "use_mFea", False)
+    x = _check_input(x, 8) if mfea else reorder_points(_check_input(x), reorder)
     B, N = x.shape[0], x.shape[2]
     M = B * N
     k = net.k
@@ -328,12 +346,16 @@ def lpdnet_origin_features_eval(net, x, reorder=True):
     def seq(h, block):
         s, b = bn_affine(block[1])
         return ops.linear(h, _w2d(block[0]), scale=s, shift=b, act=act, slope=slope)
-    xyz = x.view(M, 3)
-    p = xyz
+    if mfea:
+        xyz, p = split_mfea(x)
+        x = xyz.view(B, 1, N, 3)
+    else:
+        xyz = x.view(M, 3)
+        p = xyz
     with ops.exact_gemm():      # everything in front of the feature-space kNN is exact fp32
         if net.t3d:
             trans = transform_net_eval(net.t_net3d, xyz, B, N)
-            p = ops.apply_transform(xyz, trans, N)
+            p = _aligned_input(ops.apply_transform(xyz, trans, N), p, mfea)
         f = seq(seq(p, net.conv1_lpd), net.conv2_lpd)
         if net.tfea:
             tf = transform_net_eval(net.t_net_fea, f, B, N)

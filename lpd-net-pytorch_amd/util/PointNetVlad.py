@@ -159,7 +159,8 @@ class PointNetfeat(nn.Module):
     def forward(self, x):
         if not self.max_pool:
             feat, B, N = self._features(x)
-            return engine.to_channel_major(feat, B, N)
+            from util.lpdnet_model import _channel_major
+            return _channel_major(self, feat, B, N)
         # max_pool=True (reference PointNetVlad.py:234-239): the per-cloud max over the points of the bn5 output, returned with
         # the input alignment matrix.  global_feat=False concatenates a 3-D with a 4-D tensor in the reference (:240-241) and
         # cannot run there either.

@@ -10,6 +10,7 @@ Differences from the reference, on purpose:
   * no pynvml / MemTracker import side effects, no hard-coded torch.device('cuda')
     (reference lpdnet_model.py:10-14,123,307,338);
   * `k` is a constructor keyword (hard-coded 20 at reference lpdnet_model.py:31,156);
+  * `use_mFea=True` takes [B,1,N,8] inputs (xyz + 5 features) like the reference; the points are then not Z-ordered internally;
   * inputs must live on the GPU: there is no CPU fallback.
 The dead registration model (`LPD`, reference lpdnet_model.py:366-582) is out of scope.
 """
@@ -58,6 +59,14 @@ def get_graph_feature_Origin(x, k=20, idx=None, cat=True):
     return nbr.permute(0, 3, 1, 2)
 
 
+def _channel_major(module, feat, B, N):
+    """point-major rows -> [B,E,N,1]; in train mode through an autograd node so that the public trunk output carries gradients"""
+    if module.training and feat.requires_grad:
+        from lpdnet_hip import autograd
+        return autograd.to_channel_major_train(feat, B, N)
+    return engine.to_channel_major(feat, B, N)
+
+
 def _make_act(use_relu, slope):
     return nn.ReLU(inplace=True) if use_relu else nn.LeakyReLU(negative_slope=slope, inplace=True)
 
@@ -94,9 +103,6 @@ class LPDNet(nn.Module):
 
     def __init__(self, emb_dims=512, use_mFea=False, t3d=True, tfea=False, use_relu=False, k=20):
         super().__init__()
-        if use_mFea:
-            raise NotImplementedError("use_mFea (8-d handcrafted input features) is never enabled by PointNetVlad "
-                                      "(reference PointNetVlad.py:248) and is not built")
         self.negative_slope = 1e-2
         self.use_relu = use_relu
         self.act_f = _make_act(use_relu, self.negative_slope)
@@ -113,7 +119,8 @@ class LPDNet(nn.Module):
         self.convDG1 = nn.Sequential(nn.Conv2d(128, 128, kernel_size=1, bias=False), nn.BatchNorm2d(128), self.act_f)
         self.convDG2 = nn.Sequential(nn.Conv2d(128, 128, kernel_size=1, bias=False), nn.BatchNorm2d(128), self.act_f)
         self.convSN1 = nn.Sequential(nn.Conv2d(256, 256, kernel_size=1, bias=False), nn.BatchNorm2d(256), self.act_f)
-        self.conv1_lpd = nn.Conv1d(3, 64, kernel_size=1, bias=False)
+        # use_mFea: [B,1,N,8] inputs = xyz + 5 handcrafted features (reference lpdnet_model.py:183-186,215-224)
+        self.conv1_lpd = nn.Conv1d(8 if use_mFea else 3, 64, kernel_size=1, bias=False)
         self.conv2_lpd = nn.Conv1d(64, 64, kernel_size=1, bias=False)
         self.conv3_lpd = nn.Conv1d(512, self.emb_dims, kernel_size=1, bias=False)
         self.bn1_lpd = nn.BatchNorm1d(64)
@@ -131,7 +138,7 @@ class LPDNet(nn.Module):
 
     def forward(self, x):
         feat, B, N = self._features(x, reorder=False)      # column n of the result belongs to input point n, like the reference
-        return engine.to_channel_major(feat, B, N)
+        return _channel_major(self, feat, B, N)
 
 
 class LPDNetOrign(nn.Module):
@@ -139,8 +146,6 @@ class LPDNetOrign(nn.Module):
 
     def __init__(self, emb_dims=512, use_mFea=False, t3d=True, tfea=False, use_relu=False, k=20):
         super().__init__()
-        if use_mFea:
-            raise NotImplementedError("use_mFea is never enabled by PointNetVlad and is not built")
         self.negative_slope = 1e-2
         self.use_relu = use_relu
         self.act_f = _make_act(use_relu, self.negative_slope)
@@ -164,7 +169,7 @@ class LPDNetOrign(nn.Module):
         self.convDG2 = c2(64, 64)
         self.convSN1 = c2(64, 64)
         self.convSN2 = c2(64, 64)
-        self.conv1_lpd = c1(3, 64)
+        self.conv1_lpd = c1(8 if use_mFea else 3, 64)
         self.conv2_lpd = c1(64, 64)
         self.conv3_lpd = c1(64, 64)
         self.conv4_lpd = c1(64, 128)
@@ -178,4 +183,4 @@ class LPDNetOrign(nn.Module):
 
     def forward(self, x):
         feat, B, N = self._features(x, reorder=False)      # per-point output in the caller's point order
-        return engine.to_channel_major(feat, B, N)
+        return _channel_major(self, feat, B, N)

@@ -218,13 +218,25 @@ def _max_k(e, name, argsel):
     return e.max(dim=-1, keepdim=True)[0]
 
 
-def lpdnet_features(sd, x, *, train=False, t3d=False, tfea=False, k=20, new_stats=None, aux=None, pre="emb_nn.", argsel=None):
-    """LPDNet.forward (lpdnet_model.py:211-268), useBN=True, cat_or_stack=True.  x [B,1,N,3] -> [B,E,N,1]."""
-    p = x.squeeze(1).transpose(1, 2)                               # [B,3,N]
-    xyz = p                                                        # raw xyz even when t3d (:226)
+def _front_input(sd, x, pre, t3d, train, new_stats):
+    """lpdnet_model.py:212-229 / :69-86: x [B,1,N,3] or, with use_mFea, [B,1,N,8] (xyz + 5 handcrafted features) ->
+    (conv1 input [B,3|8,N], raw xyz [B,3,N]); the coordinate T-Net acts on the xyz part only."""
+    p = x.squeeze(1).transpose(1, 2)                               # [B,dims,N]
+    if p.shape[1] > 3:
+        xyz, feature = p[:, :3], p[:, 3:]
+        if t3d:
+            trans = transform_net(sd, pre + "t_net3d.", xyz, train, new_stats)
+            return torch.cat([torch.bmm(xyz.transpose(1, 2), trans).transpose(1, 2), feature], dim=1), xyz
+        return p, xyz
     if t3d:
         trans = transform_net(sd, pre + "t_net3d.", p, train, new_stats)
-        p = torch.bmm(p.transpose(1, 2), trans).transpose(1, 2)
+        return torch.bmm(p.transpose(1, 2), trans).transpose(1, 2), p
+    return p, p
+
+
+def lpdnet_features(sd, x, *, train=False, t3d=False, tfea=False, k=20, new_stats=None, aux=None, pre="emb_nn.", argsel=None):
+    """LPDNet.forward (lpdnet_model.py:211-268), useBN=True, cat_or_stack=True.  x [B,1,N,3|8] -> [B,E,N,1]."""
+    p, xyz = _front_input(sd, x, pre, t3d, train, new_stats)       # raw xyz feeds the second graph even when t3d (:226)
     f = _act_leaky(_bn(sd, pre + "bn1_lpd", _conv1x1(sd, pre + "conv1_lpd", p), train, new_stats))
     f = _act_leaky(_bn(sd, pre + "bn2_lpd", _conv1x1(sd, pre + "conv2_lpd", f), train, new_stats))
     if tfea:
@@ -251,11 +263,7 @@ def lpdnet_origin_features(sd, x, *, train=False, t3d=False, tfea=False, k=20, n
     """LPDNetOrign.forward (lpdnet_model.py:68-114), useBN=True."""
     def seq(name, h):
         return _act_leaky(_bn(sd, pre + name + ".1", _conv1x1(sd, pre + name + ".0", h), train, new_stats))
-    p = x.squeeze(1).transpose(1, 2)
-    xyz = p
-    if t3d:
-        trans = transform_net(sd, pre + "t_net3d.", p, train, new_stats)
-        p = torch.bmm(p.transpose(1, 2), trans).transpose(1, 2)
+    p, xyz = _front_input(sd, x, pre, t3d, train, new_stats)
     f = seq("conv1_lpd", p)
     f = seq("conv2_lpd", f)
     if tfea:
@@ -414,7 +422,7 @@ def quadruplet_loss(q, pos, neg, other_neg, m1, m2, use_min=False, lazy=False, i
 # helpers for tests
 # --------------------------------------------------------------------------------------------
 def state_shapes(featnet="lpdnet", *, emb_dims=1024, num_points=4096, output_dim=256, feature_transform=False,
-                 xyz_trans=False):
+                 xyz_trans=False, use_mFea=False):
     """{key: shape} of the reference state_dict for a configuration."""
     E = emb_dims
     shapes = {}
@@ -444,7 +452,7 @@ def state_shapes(featnet="lpdnet", *, emb_dims=1024, num_points=4096, output_dim
         for name, (o, i) in (("convDG1", (128, 128)), ("convDG2", (128, 128)), ("convSN1", (256, 256))):
             shapes[f"emb_nn.{name}.0.weight"] = (o, i, 1, 1)
             bn(f"emb_nn.{name}.1", o)
-        shapes["emb_nn.conv1_lpd.weight"] = (64, 3, 1)
+        shapes["emb_nn.conv1_lpd.weight"] = (64, 8 if use_mFea else 3, 1)
         shapes["emb_nn.conv2_lpd.weight"] = (64, 64, 1)
         shapes["emb_nn.conv3_lpd.weight"] = (E, 512, 1)
         bn("emb_nn.bn1_lpd", 64)
@@ -458,7 +466,7 @@ def state_shapes(featnet="lpdnet", *, emb_dims=1024, num_points=4096, output_dim
         for name, (o, i) in (("convDG1", (64, 128)), ("convDG2", (64, 64)), ("convSN1", (64, 64)), ("convSN2", (64, 64))):
             shapes[f"emb_nn.{name}.0.weight"] = (o, i, 1, 1)
             bn(f"emb_nn.{name}.1", o)
-        for name, (o, i) in (("conv1_lpd", (64, 3)), ("conv2_lpd", (64, 64)), ("conv3_lpd", (64, 64)),
+        for name, (o, i) in (("conv1_lpd", (64, 8 if use_mFea else 3)), ("conv2_lpd", (64, 64)), ("conv3_lpd", (64, 64)),
                              ("conv4_lpd", (128, 64)), ("conv5_lpd", (E, 128))):
             shapes[f"emb_nn.{name}.0.weight"] = (o, i, 1)
             bn(f"emb_nn.{name}.1", o)

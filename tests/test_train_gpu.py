@@ -411,8 +411,39 @@ def _desc_rel(a, b):
     return ((a - b).abs().amax(dim=1) / b.abs().amax(dim=1)).max().item()
 
 
-def test_unbuilt_variants_fail_loudly(cuda):
-    """What the HIP path does not build raises a clear error, never a silent fallback."""
-    from util.lpdnet_model import LPDNet
-    with pytest.raises(NotImplementedError):
-        LPDNet(use_mFea=True)
+@pytest.mark.parametrize("cls,t3d", [("LPDNet", False), ("LPDNet", True), ("LPDNetOrign", True)])
+def test_use_mfea_trunks_eval_and_train(cuda, cls, t3d):
+    """LPDNet / LPDNetOrign(use_mFea=True) (lpdnet_model.py:26-30,183-186,215-224): [B,1,N,8] inputs = xyz + 5 handcrafted
+    features; conv1 takes 8 columns, the coordinate T-Net and the second graph see the xyz part only.  PointNetVlad never
+    enables it; the trunks are checked on their own against the oracle, eval and train (with gradients)."""
+    from util import lpdnet_model as lm
+    featnet = "lpdnet" if cls == "LPDNet" else "lpdnetorigin"
+    N, B = 256, 4
+    net = getattr(lm, cls)(emb_dims=1024, use_mFea=True, t3d=t3d, tfea=False)
+    full = orc.synthetic_state(featnet, num_points=N, xyz_trans=t3d, use_mFea=True)
+    net.load_state_dict({k[len("emb_nn."):]: v for k, v in full.items() if k.startswith("emb_nn.")}, strict=True)
+    net = net.to(cuda)
+    g = torch.Generator().manual_seed(2)
+    x8 = torch.cat((torch.from_numpy(synth.cloud(5, B, N)), torch.rand(B, N, 5, generator=g) - 0.5), dim=2).unsqueeze(1)     # [B,1,N,8]
+    fn = orc.lpdnet_features if cls == "LPDNet" else orc.lpdnet_origin_features
+    for train in (False, True):
+        net.train(train)
+        dt = torch.float64
+        osd = {k: (v.to(dt).requires_grad_(True) if v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var"))
+                   else (v.to(dt) if v.dtype == torch.float32 else v.clone())) for k, v in full.items()}
+        got = net(x8.to(cuda))                                                    # [B,E,N,1]
+        assert got.shape == (B, 1024, N, 1)
+        with torch.enable_grad():
+            want = fn(osd, x8.to(dt), train=train, t3d=t3d)
+        err = (got.detach().cpu().double() - want.detach()).abs().max().item() / want.detach().abs().max().item()
+        assert err < 2e-4, (train, err)      # per-point features (feature-space kNN flips move single entries)
+        if train:
+            w = torch.randn(B, 1024, N, 1, generator=g)
+            (got * w.to(cuda)).sum().backward()
+            (want * w.to(dt)).sum().backward()
+            name = "conv1_lpd.weight" if cls == "LPDNet" else "conv1_lpd.0.weight"
+            a, b = dict(net.named_parameters())[name].grad.cpu().double(), osd["emb_nn." + name].grad
+            assert a.shape == b.shape and a.shape[1] == 8
+            assert ((a - b).norm() / b.norm()).item() < 2e-2, name
+    with pytest.raises(ValueError):
+        net.eval()(x8[..., :3].to(cuda))
