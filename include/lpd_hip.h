@@ -418,9 +418,12 @@ long long lpd_gemm_tn_bf16_ws_floats(long long M, int KA, int KB);
 int lpd_gemm_tn_bf16(const uint16_t* A, const uint16_t* B, float* dW, float* ws, long long M, int KA, int KB, void* stream);
 
 /* dW [KA][KB] (fp32) = sum_m A[m][:]^T B[m][:] for fp32 operands A [M][lda], B [M][ldb] in split-bf16 form (three MFMA products per
- * term, fp32-grade): the weight gradients dW = dY^T X.  KA %% 128 == 0, KB %% 64 == 0; ws: lpd_gemm_tn_ws_floats(M, KA, KB) floats. */
-long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB);
-int lpd_gemm_tn(const float* A, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB, void* stream);
+ * term, fp32-grade): the weight gradients dW = dY^T X of the training path and, batched over the clouds, the NetVLAD residual
+ * pooling act^T x (util/PointNetVlad.py:64-67).  batch problems at strides sA / sB (elements) write dW [batch][KA][KB].
+ * KA %% 128 == 0, KB %% 64 == 0; ws: lpd_gemm_tn_ws_floats(M, KA, KB, batch) floats. */
+long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB, int batch);
+int lpd_gemm_tn(const float* A, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
+                int batch, long long sA, long long sB, void* stream);
 
 #ifdef __cplusplus
 }

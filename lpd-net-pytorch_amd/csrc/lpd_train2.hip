@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint16_t* __res
 template <int KBT>
 __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B,
                                                          long long ldb, float* __restrict__ slabs, long long M, int KA, int KB,
-                                                         long long rows_per_split)
+                                                         long long rows_per_split, int nsplit, long long sA, long long sB)
 {
     constexpr int CH = 64, LDT = CH + 8;
     constexpr int TB = KBT / 32;               // output tiles along b; 4 along a
@@ -703,7 +703,10 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(const float* __restrict
     // to all eight XCDs: 5.9 GB through the fabric for the 1.1 GB dW3 operands, 1.12 ms)
     const int ntile_a = KA / 128, ntile_b = KB / KBT;
     const int lin = lpd_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = lin % (ntile_a * ntile_b), zsplit = lin / (ntile_a * ntile_b);
+    const int tile = lin % (ntile_a * ntile_b), zall = lin / (ntile_a * ntile_b);      // zall = batch * nsplit + split
+    const int zsplit = zall % nsplit, zb = zall / nsplit;
+    A += (long long)zb * sA;
+    B += (long long)zb * sB;
     const int a0 = (tile % ntile_a) * 128, b0 = (tile / ntile_a) * KBT;
     const long long m_begin = (long long)zsplit * rows_per_split;
     const long long m_end = min(M, m_begin + rows_per_split);
@@ -787,7 +790,7 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(const float* __restrict
             }
         }
     }
-    float* slab = slabs + (size_t)zsplit * KA * KB;
+    float* slab = slabs + (size_t)zall * KA * KB;
 #pragma unroll
     for (int j = 0; j < TPW; ++j)
 #pragma unroll
@@ -799,11 +802,12 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(const float* __restrict
 
 __global__ void gemm_tn_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int n, int nslabs)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;      // blockIdx.y = problem of a batch (its slabs are consecutive)
     if (e >= n) return;
+    slabs += (size_t)blockIdx.y * nslabs * n;
     double s = 0.0;
     for (int b = 0; b < nslabs; ++b) s += slabs[(size_t)b * n + e];
-    out[e] = (float)s;
+    out[(size_t)blockIdx.y * n + e] = (float)s;
 }
 
 inline int grid_for(long long items, int per_block, int cap = 4096)
@@ -993,29 +997,39 @@ extern "C" int lpd_gemm_tn_bf16(const uint16_t* A, const uint16_t* B, float* dW,
     return LPD_OK;
 }
 
-extern "C" long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB)
+static long long gemm_tn_splits(long long M, int KA, int KB, int batch)
 {
-    long long tiles = (long long)(KA / 128) * ((KB + 127) / 128);
+    long long tiles = (long long)(KA / 128) * ((KB + 127) / 128) * batch;
     long long splits = 1;
     while (tiles * splits * 2 <= 1024 && M / (splits * 2) >= 1024) splits *= 2;
-    return splits * KA * KB;
+    return splits;
+}
+
+extern "C" long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB, int batch)
+{
+    if (batch < 1) batch = 1;
+    return gemm_tn_splits(M, KA, KB, batch) * batch * KA * KB;
 }
 
 extern "C" int lpd_gemm_tn(const float* A, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
-                           void* stream_)
+                           int batch, long long sA, long long sB, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    LPD_CHECK_ARG(A && B && dW && ws && M > 0, "lpd_gemm_tn: null pointer");
+    LPD_CHECK_ARG(A && B && dW && ws && M > 0 && batch >= 1, "lpd_gemm_tn: bad arguments");
     LPD_CHECK_ARG(KA > 0 && KA % 128 == 0 && KB > 0 && KB % 64 == 0, "lpd_gemm_tn: KA %% 128 and KB %% 64 required (KA=%d KB=%d)", KA, KB);
-    LPD_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0, "lpd_gemm_tn: operands must be 16-byte aligned rows");
-    const long long splits = lpd_gemm_tn_ws_floats(M, KA, KB) / ((long long)KA * KB);
+    LPD_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && sA % 4 == 0 && sB % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
+                  "lpd_gemm_tn: operands must be 16-byte aligned rows");
+    const long long splits = gemm_tn_splits(M, KA, KB, batch);
     long long rps = (M + splits - 1) / splits;
     rps = (rps + 63) / 64 * 64;
-    if (KB % 128 == 0) hipLaunchKernelGGL((gemm_tn_x3_kernel<128>), dim3((unsigned)((KA / 128) * (KB / 128) * splits)), dim3(256), 0, stream, A, lda, B, ldb, ws, M, KA, KB, rps);
-    else hipLaunchKernelGGL((gemm_tn_x3_kernel<64>), dim3((unsigned)((KA / 128) * (KB / 64) * splits)), dim3(256), 0, stream, A, lda, B, ldb, ws, M, KA, KB, rps);
+    const int kbt = KB % 128 == 0 ? 128 : 64;
+    const long long blocks = (long long)(KA / 128) * (KB / kbt) * splits * batch;
+    LPD_CHECK_ARG(blocks < (1ll << 31), "lpd_gemm_tn: too many blocks");
+    if (kbt == 128) hipLaunchKernelGGL((gemm_tn_x3_kernel<128>), dim3((unsigned)blocks), dim3(256), 0, stream, A, lda, B, ldb, ws, M, KA, KB, rps, (int)splits, sA, sB);
+    else hipLaunchKernelGGL((gemm_tn_x3_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, stream, A, lda, B, ldb, ws, M, KA, KB, rps, (int)splits, sA, sB);
     LPD_CHECK_LAUNCH("lpd_gemm_tn");
     const int n = KA * KB;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)ws, dW, n, (int)splits);
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, stream, (const float*)ws, dW, n, (int)splits);
     LPD_CHECK_LAUNCH("lpd_gemm_tn(reduce)");
     return LPD_OK;
 }

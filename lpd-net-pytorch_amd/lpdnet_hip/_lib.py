@@ -94,8 +94,8 @@ SIGNATURES = {
     "lpd_gemm_bf16s": [_c_p, _c_p, _c_int, _c_int, _c_p, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_tn_bf16_ws_floats": [_c_ll, _c_int, _c_int],
     "lpd_gemm_tn_bf16": [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_p],
-    "lpd_gemm_tn_ws_floats": [_c_ll, _c_int, _c_int],
-    "lpd_gemm_tn": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_p],
+    "lpd_gemm_tn_ws_floats": [_c_ll, _c_int, _c_int, _c_int],
+    "lpd_gemm_tn": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_p],
     "lpd_metric_loss": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_int, _c_int, _c_int,
                         _c_int, _c_f, _c_f, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
 }

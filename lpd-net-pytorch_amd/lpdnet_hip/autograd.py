@@ -830,7 +830,9 @@ class _NetVLADTrainFn(torch.autograd.Function):
         else:
             sta = None
             a = ops.softmax_affine(a0, torch.ones_like(vlad.cluster_biases), vlad.cluster_biases)
-        vraw = ops.gemm(feat.view(B, N, E), a.view(B, N, K), a_kmajor=True, b_kmajor=True, splits=engine._pool_splits(B, N, E))
+        vraw = ops.pool_tn(feat.view(B, N, E), a.view(B, N, K))
+        if vraw is None:
+            vraw = ops.gemm(feat.view(B, N, E), a.view(B, N, K), a_kmajor=True, b_kmajor=True, splits=engine._pool_splits(B, N, E))
         aux = {}
         v = torch.zeros((Bp, E * K), dtype=torch.float32, device=dev)
         ops.vlad_finalize(vraw, a.view(B, N, K), vlad.cluster_weights2.view(E, K), out=v, aux=aux)

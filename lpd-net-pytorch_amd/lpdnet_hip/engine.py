@@ -439,7 +439,9 @@ def netvlad_eval(vlad, feat, B, N):
         a, ws = ops.softmax_affine(a, s, b, out=a, colsum_rows=N)
     else:
         a = ops.softmax_affine(a, s, b, out=a)
-    vraw = ops.gemm(feat.view(B, N, E), a.view(B, N, K), a_kmajor=True, b_kmajor=True, splits=_pool_splits(B, N, E))     # [B,E,K]
+    vraw = ops.pool_tn(feat.view(B, N, E), a.view(B, N, K))                                                              # [B,E,K]
+    if vraw is None:
+        vraw = ops.gemm(feat.view(B, N, E), a.view(B, N, K), a_kmajor=True, b_kmajor=True, splits=_pool_splits(B, N, E))
     v = ops.vlad_finalize(vraw, a.view(B, N, K), vlad.cluster_weights2.view(E, K), ws=ws)  # [B,E*K]
     s, b = bn_affine(vlad.bn2)
     h = ops.gemm(v, vlad.hidden1_weights, b_kmajor=True, scale=s, shift=b, splits=_head_splits(E * K))

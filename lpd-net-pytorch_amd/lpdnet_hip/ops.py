@@ -1024,13 +1024,24 @@ GEMM_TN = os.environ.get("LPD_GEMM_TN", "1") != "0"      # weight gradients on t
 def gemm_tn(A, B, rows=None):
     """dW [KA, KB] = A^T B over the (first `rows`) rows; A [M, KA], B [M, KB] fp32 row-major (column slices allowed);
     KA % 128 == 0, KB % 64 == 0.  Split-bf16 (three products): the accuracy of lpd_gemm_bf16x3."""
-    lda, ldb = _rows(A, "A"), _rows(B, "B")
-    M = A.shape[0] if rows is None else rows
-    KA, KB = A.shape[1], B.shape[1]
+    if A.dim() == 3:      # batched: A [nb, M, KA], B [nb, M, KB] -> [nb, KA, KB]
+        nb = A.shape[0]
+        lda, ldb = _rows(A[0], "A"), _rows(B[0], "B")
+        M, KA, KB, sA, sB = A.shape[1], A.shape[2], B.shape[2], A.stride(0), B.stride(0)
+        if B.shape[0] != nb or B.shape[1] != M:
+            raise ValueError("gemm_tn: batched operands must agree on batch and rows")
+        shape = (nb, KA, KB)
+    else:
+        nb, sA, sB = 1, 0, 0
+        lda, ldb = _rows(A, "A"), _rows(B, "B")
+        M = A.shape[0] if rows is None else rows
+        KA, KB = A.shape[1], B.shape[1]
+        shape = (KA, KB)
     lib = _lib.load()
-    ws = torch.empty((int(lib.lpd_gemm_tn_ws_floats(M, KA, KB)),), dtype=torch.float32, device=A.device)
-    dW = torch.empty((KA, KB), dtype=torch.float32, device=A.device)
-    _call(f"gemm_tn[{KA}x{KB}x{M}]", lib.lpd_gemm_tn, _ptr(A), lda, _ptr(B), ldb, _ptr(dW), _ptr(ws), M, KA, KB, _stream())
+    ws = torch.empty((int(lib.lpd_gemm_tn_ws_floats(M, KA, KB, nb)),), dtype=torch.float32, device=A.device)
+    dW = torch.empty(shape, dtype=torch.float32, device=A.device)
+    _call(f"gemm_tn[{KA}x{KB}x{M}]" + (f"x{nb}" if nb > 1 else ""), lib.lpd_gemm_tn, _ptr(A), lda, _ptr(B), ldb, _ptr(dW), _ptr(ws), M, KA,
+          KB, nb, sA, sB, _stream())
     return dW
 
 
@@ -1038,6 +1049,18 @@ def gemm_tn_applies(A, B, rows):
     return (GEMM_TN and GEMM_BF16X3 and _EXACT.depth == 0 and A.dim() == 2 and B.dim() == 2 and A.shape[1] % 128 == 0
             and B.shape[1] % 64 == 0 and rows >= 4096 and A.stride(1) == 1 and B.stride(1) == 1 and A.stride(0) % 4 == 0
             and B.stride(0) % 4 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def pool_tn(feat3, act3):
+    """NetVLAD residual pooling act^T x per cloud (util/PointNetVlad.py:64-67) -> [B, E, K]: feat3 [B, N, E], act3 [B, N, K].
+    The register-transposing kernel where it applies (split-bf16 products allowed, E % 128 == 0, K % 64 == 0), else the generic
+    batched k-major product."""
+    B, N, E = feat3.shape
+    K = act3.shape[2]
+    if (GEMM_TN and GEMM_BF16X3 and _EXACT.depth == 0 and E % 128 == 0 and K % 64 == 0 and N >= 256 and feat3.is_contiguous()
+            and act3.is_contiguous()):
+        return gemm_tn(feat3, act3)
+    return None
 
 
 def dw_smallk(dY, X):

@@ -775,3 +775,10 @@ def test_gemm_tn_weight_gradient_kernel(cuda, M, KA, KB):
     assert _rel(got_r, A[:M - 100].double().t() @ B[:M - 100].double()) < 2e-5
     old = ops.gemm(A.contiguous(), B.contiguous(), a_kmajor=True, b_kmajor=True, splits=8)
     assert _rel(got, old) < 2e-5
+    if M <= 20000:      # batched form (the NetVLAD pooling: one problem per cloud)
+        nb = 3
+        A3 = torch.randn(nb, M // 4, KA, generator=g).to(cuda)
+        B3 = torch.randn(nb, M // 4, KB, generator=g).to(cuda)
+        got3 = ops.gemm_tn(A3, B3)
+        assert got3.shape == (nb, KA, KB)
+        assert _rel(got3, torch.einsum("bma,bmc->bac", A3.double(), B3.double())) < 2e-5
