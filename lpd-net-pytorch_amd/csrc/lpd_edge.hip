@@ -594,7 +594,15 @@ __device__ __forceinline__ void em_split4_packed(float x0, float x1, float x2, f
 // max(a, b) as v_med3_f32(a, b, +inf): one instruction, without the canonicalising self-max the compiler puts in front of
 // fmaxf on values it cannot prove quiet (MFMA results, loaded data).  (An inline-asm v_max_f32 is NOT an option on an MFMA
 // result: the hazard recogniser does not see inside the asm and the read came too early -- wrong maxima.)
-__device__ __forceinline__ float em_vmax(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
+// The +inf operand has to come from a register the optimiser cannot see through (em_opaque_inf): with the literal, this
+// compiler folds med3(a, b, +inf) back to maxnum and re-adds the two canonicalising self-maxes -- three v_max_f32 per element.
+__device__ __forceinline__ float em_opaque_inf()
+{
+    float v = INFINITY;
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float em_vmax(float a, float b, float pinf) { return __builtin_amdgcn_fmed3f(a, b, pinf); }
 
 template <int CM, int CO>
 struct EdgeMlpX3Cfg {
@@ -654,6 +662,8 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
     const float4 s1 = *reinterpret_cast<const float4*>(g.s1 + c4 * 4);
     const float4 b1 = *reinterpret_cast<const float4*>(g.b1 + c4 * 4);
     const float ns = lpd_neg_slope(g.act, g.slope);
+    const float pinf = em_opaque_inf();
+    const em_f32x2 s1a = {s1.x, s1.y}, s1b = {s1.z, s1.w}, ns2 = {ns, ns};
     float4 qc[PASSES];  // centre term folded with the BN affine: s1 * Q + b1
 #pragma unroll
     for (int e = 0; e < PASSES; ++e) {
@@ -684,10 +694,13 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
         for (int e = 0; e < PASSES; ++e) {
             const int p = prow + Cfg::ROWS_PER_PASS * e;
             // s (P + Q) + b  ==  s P + (s Q + b) as one fma; LeakyReLU / ReLU / identity as max(v, ns v) (0 <= ns <= 1)
-            const float y0 = fmaf(s1.x, pg[e].x, qc[e].x), y1 = fmaf(s1.y, pg[e].y, qc[e].y);
-            const float y2 = fmaf(s1.z, pg[e].z, qc[e].z), y3 = fmaf(s1.w, pg[e].w, qc[e].w);
+            // (packed pairs: v_pk_fma_f32 / v_pk_mul_f32 round each element exactly as the scalar forms do)
+            const em_f32x2 ya = __builtin_elementwise_fma(s1a, (em_f32x2){pg[e].x, pg[e].y}, (em_f32x2){qc[e].x, qc[e].y});
+            const em_f32x2 yb = __builtin_elementwise_fma(s1b, (em_f32x2){pg[e].z, pg[e].w}, (em_f32x2){qc[e].z, qc[e].w});
+            const em_f32x2 na = ns2 * ya, nb = ns2 * yb;
             uint2 hh, ll;
-            em_split4_packed(em_vmax(y0, ns * y0), em_vmax(y1, ns * y1), em_vmax(y2, ns * y2), em_vmax(y3, ns * y3), hh, ll);
+            em_split4_packed(em_vmax(ya[0], na[0], pinf), em_vmax(ya[1], na[1], pinf), em_vmax(yb[0], nb[0], pinf),
+                             em_vmax(yb[1], nb[1], pinf), hh, ll);
             *reinterpret_cast<uint2*>(hi_img + p * LDK + c4 * 4) = hh;
             *reinterpret_cast<uint2*>(lo_img + p * LDK + c4 * 4) = ll;
         }
@@ -728,7 +741,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) zmax[i][r] = em_vmax(zmax[i][r], acc[i][r]);
+            for (int r = 0; r < 16; ++r) zmax[i][r] = em_vmax(zmax[i][r], acc[i][r], pinf);
         if (t + 1 < g.k) build(buf ^ 1);
         __syncthreads();
     }
