@@ -117,6 +117,18 @@ int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, 
                  long long a_cloud, long long c_cloud, int panel_n, int panel_ld, int impl, void* stream);
 
 /*
+ * The same product for a SHORT reduction with cloud-panel A and C (the neighbour / centre projection of the split SN1 edge
+ * convolution, util/lpdnet_model.py:257: K = 128 -> N = 512), computed transposed: the prepared weight fragments are the MFMA's
+ * row operand, each wave keeps its 32 data rows (split hi / lo once) in registers for all N columns and stores whole KiB runs of
+ * a panel -- no LDS, no barrier.  lpd_gemm_x3t_applies: K in {64, 128}, N % 32 == 0, both operands cloud panels, clouds of a
+ * multiple of 128 points, act none / ReLU / LeakyReLU.  frags: lpd_gemm_prep_b(W [N][K], b_kmajor = 0).
+ */
+int lpd_gemm_x3t_applies(int M, int N, int K, int act, long long a_cloud, long long c_cloud, int panel_n);
+int lpd_gemm_x3t(const float* A, const void* frags, float* C, int M, int N, int K, const float* bias, const float* scale,
+                 const float* shift, int act, float slope, long long a_cloud, long long c_cloud, int panel_n, int panel_ld,
+                 void* stream);
+
+/*
  * kNN-graph aggregation (K-agg).  Replaces the gather/repeat/cat of util/lpdnet_model.py:331-363
  * fused with a split edge convolution + BatchNorm + activation + max over k
  * (lpdnet_model.py:249-250 convDG1/x1, :257-258 convSN1/x3):

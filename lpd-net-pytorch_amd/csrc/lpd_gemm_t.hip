@@ -1,0 +1,223 @@
+// lpd_gemm_t.hip -- split-bf16 product of cloud-panel activations with a small weight matrix, computed TRANSPOSED:
+//     C_panels[M][N] = act((A_panels[M][K] . W[N][K]^T + bias) * scale + shift),   K = 64 or 128.
+//
+// The neighbour / centre projection of the split SN1 edge convolution (util/lpdnet_model.py:257: 128 -> 2 x 256 columns for
+// every point) writes four times the bytes it reads and multiplies over a SHORT reduction: on the 128 x 128 block tile of
+// lpd_gemm_bf16x3 it spends its time in the two barriers per 32-deep k-tile (four k-tiles in all), in re-splitting A for
+// each of the four column blocks and in an epilogue of 64 single-float stores per lane that fill a 128-byte line in four
+// instructions (164 us at 32 clouds, 15 % MFMA busy, HBM floor 42 us).
+//
+// Here the MFMA computes C^T: the WEIGHTS are the A operand (rows of the MFMA tile = output columns n; the fragments
+// lpd_gemm_prep_b writes have exactly that shape) and the DATA rows are the B operand (columns of the tile = points m).
+//   * result: lane (m, h) holds columns 8 q + 4 h + {0..3} of row m -- four consecutive floats of panel q.  One float4 store
+//     per lane and (tile, q); the 64 lanes of the instruction write 32 rows x 32 bytes = ONE contiguous KiB of the panel.
+//   * the workgroup's 128 rows x K are read once (a lane's float4 of every panel), split hi / lo and kept in LDS for all N
+//     columns ([row][K + 8] bf16 images, conflict-free ds_read_b128 operand fetches); ONE barrier in the whole kernel.
+//   * each wave owns every fourth 32-column tile and holds that tile's weight fragments (K / 16 k-steps, hi and lo) in
+//     registers while it multiplies them with the four row tiles; the next tile's fragments are requested before.  Weight
+//     traffic from L2: N K 4 bytes per workgroup.  (First version: a wave kept its 32 data rows in registers instead and
+//     streamed ALL fragments, no LDS at all: 121 us, of which 50 us were the 1.07 GB of fragment reads from L2 -- with the
+//     fragment address pinned the same kernel took 72 us.)
+// Summation order: k ascending, per term lo.hi, hi.lo, hi.hi (the order of the other split-bf16 kernels' k-steps).
+#include "lpd_common.h"
+
+namespace {
+
+typedef __bf16 xt_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 xt_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float xt_f32x2 __attribute__((ext_vector_type(2)));
+
+// hi / lo split of eight consecutive channels on packed pairs (2.5 instructions per element; see lpd_edge.hip)
+__device__ __forceinline__ void xt_split8(const float4& a, const float4& b, xt_bf16x8& hi, xt_bf16x8& lo)
+{
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned hu[4], lu[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const xt_bf16x2 h2 = __builtin_convertvector((xt_f32x2){x[2 * p], x[2 * p + 1]}, xt_bf16x2);
+        const unsigned u = __builtin_bit_cast(unsigned, h2);
+        const float r0 = x[2 * p] - __uint_as_float(u << 16), r1 = x[2 * p + 1] - __uint_as_float(u & 0xffff0000u);
+        const xt_bf16x2 l2 = __builtin_convertvector((xt_f32x2){r0, r1}, xt_bf16x2);
+        hu[p] = u;
+        lu[p] = __builtin_bit_cast(unsigned, l2);
+    }
+    const uint4 hv = make_uint4(hu[0], hu[1], hu[2], hu[3]), lv = make_uint4(lu[0], lu[1], lu[2], lu[3]);
+    hi = __builtin_bit_cast(xt_bf16x8, hv);
+    lo = __builtin_bit_cast(xt_bf16x8, lv);
+}
+
+struct X3tArgs {
+    const float* A;
+    const __bf16* fhi;
+    const __bf16* flo;
+    float* C;
+    int M, N;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    float ns;                      // negative-side slope of the piecewise-linear activation (1 none, 0 ReLU, slope LeakyReLU)
+    long long a_cloud, c_cloud;    // floats between clouds
+    int panel_n, panel_ld;
+};
+
+constexpr int XT_THREADS = 256;    // 128 rows per workgroup (a panel cloud is a multiple of 128 rows)
+
+// hi / lo split of four consecutive channels (one float4 of a panel row)
+__device__ __forceinline__ void xt_split4(const float4& a, uint2& hi, uint2& lo)
+{
+    const xt_bf16x2 h01 = __builtin_convertvector((xt_f32x2){a.x, a.y}, xt_bf16x2), h23 = __builtin_convertvector((xt_f32x2){a.z, a.w}, xt_bf16x2);
+    const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
+    const float r0 = a.x - __uint_as_float(u01 << 16), r1 = a.y - __uint_as_float(u01 & 0xffff0000u);
+    const float r2 = a.z - __uint_as_float(u23 << 16), r3 = a.w - __uint_as_float(u23 & 0xffff0000u);
+    const xt_bf16x2 l01 = __builtin_convertvector((xt_f32x2){r0, r1}, xt_bf16x2), l23 = __builtin_convertvector((xt_f32x2){r2, r3}, xt_bf16x2);
+    hi = make_uint2(u01, u23);
+    lo = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+}
+
+template <int KS>
+__global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
+{
+    constexpr int K = KS * 16, LDK = K + 8, IMG = 128 * LDK;
+    extern __shared__ __attribute__((aligned(16))) __bf16 img[];     // [hi | lo][128 rows][LDK]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int col = lane & 31;
+    const int m0 = lpd_xcd_remap(blockIdx.x, gridDim.x) * 128;
+    const int cloud = m0 / g.panel_n;
+    const int mc0 = m0 - cloud * g.panel_n;             // first row of the workgroup inside its cloud
+    const float* A = g.A + (long long)cloud * g.a_cloud;
+    float* C = g.C + (long long)cloud * g.c_cloud + (long long)(mc0 + col) * 8 + 4 * h;
+
+    // ---- weight fragments of this wave's first tile: fragment (tile nt, k-step s) = 1 KiB at ((nt * KS + s) * 64 + lane) * 8 ----
+    const int NT = g.N >> 5;
+    const __bf16* fh = g.fhi + (long long)lane * 8;
+    const __bf16* fl = g.flo + (long long)lane * 8;
+    xt_bf16x8 w_hi[KS], w_lo[KS];
+    auto load_w = [&](int nt, int s) {       // one register set: step s of the NEXT tile is requested right behind the MFMAs of step s
+        nt = nt < NT ? nt : NT - 1;           // past the end: any valid tile (never multiplied)
+        const long long off = ((long long)nt * KS + s) * 512;
+        w_hi[s] = *reinterpret_cast<const xt_bf16x8*>(fh + off);
+        w_lo[s] = *reinterpret_cast<const xt_bf16x8*>(fl + off);
+    };
+#pragma unroll
+    for (int s = 0; s < KS; ++s) load_w(wave, s);
+
+    // ---- the 128 rows, split once: thread -> (row tid / 2, float4 half tid % 2) of every panel ----
+    {
+        const int row = tid >> 1, half = tid & 1;
+        const float* src = A + (long long)(mc0 + row) * 8 + half * 4;
+        float4 v[K / 8];
+#pragma unroll
+        for (int p = 0; p < K / 8; ++p) v[p] = *reinterpret_cast<const float4*>(src + (long long)p * g.panel_ld * 8);
+#pragma unroll
+        for (int p = 0; p < K / 8; ++p) {
+            uint2 hh, ll;
+            xt_split4(v[p], hh, ll);
+            *reinterpret_cast<uint2*>(img + row * LDK + p * 8 + half * 4) = hh;
+            *reinterpret_cast<uint2*>(img + IMG + row * LDK + p * 8 + half * 4) = ll;
+        }
+    }
+    __syncthreads();
+
+    const __bf16* dh = img + col * LDK + h * 8;
+    const bool plain = !g.bias && !g.scale && g.ns == 1.0f;
+    for (int nt = wave; nt < NT; nt += 4) {
+        // (the operand fetches do not depend on the tile: left visible, the compiler hoists all of them out of this loop -- 256
+        //  registers of data fragments, spilled)
+        int opq = 0;
+        asm volatile("" : "+v"(opq));            // (an opaque OFFSET: an opaque pointer loses the LDS address space -> flat loads)
+        const __bf16* dhi = dh + opq;
+        const __bf16* dlo = dhi + IMG;
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            xt_bf16x8 d_hi[4], d_lo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d_hi[i] = *reinterpret_cast<const xt_bf16x8*>(dhi + i * 32 * LDK + s * 16);
+                d_lo[i] = *reinterpret_cast<const xt_bf16x8*>(dlo + i * 32 * LDK + s * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo[s], d_hi[i], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[s], d_lo[i], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[s], d_hi[i], acc[i], 0, 0, 0);
+            load_w(nt + 4, s);
+        }
+        // ---- epilogue: registers 4 q .. 4 q + 3 of row tile i are columns 32 nt + 8 q + 4 h + {0..3} of row 32 i + col ----
+        if (plain) {                              // uniform: the bare product (the edge projections)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float* dst = C + (long long)(nt * 4 + q) * g.panel_ld * 8;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(dst + i * 32 * 8) = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = nt * 32 + 8 * q + 4 * h;
+            float4 bi = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bi;
+            if (g.bias) bi = *reinterpret_cast<const float4*>(g.bias + n);
+            if (g.scale) { sc = *reinterpret_cast<const float4*>(g.scale + n); sh = *reinterpret_cast<const float4*>(g.shift + n); }
+            float* dst = C + (long long)(nt * 4 + q) * g.panel_ld * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 v = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
+                v.x = (v.x + bi.x) * sc.x + sh.x; v.y = (v.y + bi.y) * sc.y + sh.y;
+                v.z = (v.z + bi.z) * sc.z + sh.z; v.w = (v.w + bi.w) * sc.w + sh.w;
+                v.x = lpd_act_pl(v.x, g.ns); v.y = lpd_act_pl(v.y, g.ns); v.z = lpd_act_pl(v.z, g.ns); v.w = lpd_act_pl(v.w, g.ns);
+                *reinterpret_cast<float4*>(dst + i * 32 * 8) = v;
+            }
+        }
+    }
+}
+
+template <int KS>
+void x3t_launch(const X3tArgs& g, hipStream_t stream)
+{
+    const size_t lds = (size_t)2 * 128 * (KS * 16 + 8) * sizeof(__bf16);
+    auto kern = gemm_x3t_kernel<KS>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(g.M / 128), dim3(XT_THREADS), lds, stream, g);
+}
+
+}  // namespace
+
+extern "C" int lpd_gemm_x3t_applies(int M, int N, int K, int act, long long a_cloud, long long c_cloud, int panel_n)
+{
+    return a_cloud != 0 && c_cloud != 0 && (K == 64 || K == 128) && N > 0 && N % 32 == 0 && M > 0 && M % 128 == 0 &&
+           panel_n > 0 && panel_n % 128 == 0 && M % panel_n == 0 && act >= 0 && act <= 2;
+}
+
+extern "C" int lpd_gemm_x3t(const float* A, const void* frags, float* C, int M, int N, int K, const float* bias, const float* scale,
+                            const float* shift, int act, float slope, long long a_cloud, long long c_cloud, int panel_n, int panel_ld,
+                            void* stream_)
+{
+    LPD_CHECK_ARG(A && frags && C, "lpd_gemm_x3t: null pointer");
+    LPD_CHECK_ARG(lpd_gemm_x3t_applies(M, N, K, act, a_cloud, c_cloud, panel_n),
+                  "lpd_gemm_x3t: built for cloud-panel A and C, K in {64, 128}, N %% 32 == 0, clouds of a multiple of 128 points, "
+                  "act none / ReLU / LeakyReLU (M=%d N=%d K=%d act=%d)", M, N, K, act);
+    LPD_CHECK_ARG(panel_ld >= panel_n, "lpd_gemm_x3t: panel_ld < panel_n");
+    LPD_CHECK_ARG(act != 2 || (slope >= 0.0f && slope <= 1.0f), "lpd_gemm_x3t: LeakyReLU slope %g outside [0, 1]", (double)slope);
+    LPD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "lpd_gemm_x3t: scale and shift must be given together");
+    LPD_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)frags & 15) == 0 && ((uintptr_t)C & 15) == 0 &&
+                      ((uintptr_t)bias & 15) == 0 && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
+                  "lpd_gemm_x3t: pointers must be 16-byte aligned");
+    const int KS = K / 16, NT = N / 32;
+    const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
+    X3tArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, bias, scale, shift, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), a_cloud, c_cloud, panel_n, panel_ld};
+    hipStream_t stream = (hipStream_t)stream_;
+    if (KS == 8) x3t_launch<8>(g, stream);
+    else x3t_launch<4>(g, stream);
+    LPD_CHECK_LAUNCH("lpd_gemm_x3t");
+    return LPD_OK;
+}

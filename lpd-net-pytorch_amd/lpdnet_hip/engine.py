@@ -52,6 +52,8 @@ def _cached(module, key, tensors, build):
         return hit[1]
     with torch.no_grad():
         val = build()
+    if isinstance(val, torch.Tensor):
+        val._lpd_stable = True      # one object per version of its sources: ops._weight_frags may cache its MFMA fragments
     c[key] = (sig, val)
     return val
 

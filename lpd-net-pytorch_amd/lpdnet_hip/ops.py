@@ -188,14 +188,17 @@ _FRAG_CACHE = {}
 _FRAG_LOCK = __import__("threading").Lock()     # nn.DataParallel-style callers: one forward per device thread
 X3W_FORWARD = os.environ.get("LPD_X3W_FWD", "1") != "0"    # forward layers with K >= 256 on the prepared-fragment kernel
 X3W_IMPL = int(os.environ.get("LPD_X3W_IMPL", "0"))         # lpd_gemm_x3w impl (0 = by shape); benchmarking only
+X3T_PANELS = os.environ.get("LPD_X3T", "1") != "0"          # short-reduction panel-to-panel products on lpd_gemm_x3t
 
 
 def _weight_frags(B2, b_kmajor, N, K):
     """hi/lo bf16 MFMA fragments of a weight matrix (lpd_gemm_prep_b).  Cached only for nn.Parameters (or views of one):
     their storage lives as long as the cache entry's reference and every update bumps `_version`; anything else (derived
-    weights, activations) may reuse an address with a fresh version counter, so it is prepared per call (~5 us)."""
+    weights, activations) may reuse an address with a fresh version counter, so it is prepared per call (~5 us) -- unless
+    the engine marks it `_lpd_stable` (a derived weight it caches itself: ONE tensor object per version of its sources,
+    e.g. the stacked [neighbour ; centre] edge weights), which the cache entry then keeps alive like a parameter."""
     base = B2._base if B2._base is not None else B2
-    cacheable = isinstance(base, torch.nn.Parameter)
+    cacheable = isinstance(base, torch.nn.Parameter) or bool(getattr(base, "_lpd_stable", False))
     key = (B2.data_ptr(), base._version, tuple(B2.shape), B2.stride(0), bool(b_kmajor)) if cacheable else None
     if cacheable:
         with _FRAG_LOCK:
@@ -356,6 +359,13 @@ def _gemm_panels(A, B, a_kmajor, b_kmajor, bias, scale, shift, act, slope, out, 
     lib = _lib.load()
     x3 = GEMM_BF16X3 and not exact and _EXACT.depth == 0 and N >= 128 and M >= 128
     pld = _panel_ld(A if a_panels else None, out if out_panels else None)
+    if (x3 and X3T_PANELS and not accumulate and M >= 1024
+            and lib.lpd_gemm_x3t_applies(M, N, K, act, a_cloud, c_cloud, Np)):
+        # short reduction, panels in and out (the SN1 projection): the transposed product, no LDS (164 -> see DESIGN.md 9.6a)
+        frags = _weight_frags(B, b_kmajor, N, K)
+        _call(f"gemmx3t[{M}x{N}x{K}]", lib.lpd_gemm_x3t, _ptr(A), _ptr(frags), _ptr(out), M, N, K, _ptr(bias), _ptr(scale), _ptr(shift),
+              act, float(slope), a_cloud, c_cloud, Np, pld, _stream())
+        return out
     if x3 and X3W_FORWARD and M >= 1024 and K >= 256 and N * K <= (1 << 22):
         frags = _weight_frags(B, b_kmajor, N, K)
         _call(f"gemmx3w[{M}x{N}x{K}]", lib.lpd_gemm_x3w, _ptr(A), lda, _ptr(frags), _ptr(out), ldc, M, N, K, _ptr(bias), _ptr(scale),

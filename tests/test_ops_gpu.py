@@ -523,6 +523,51 @@ def test_gemm_weight_fragment_path(cuda, M, N, K, bk):
     assert any(k.startswith("gemmx3w") for k in prof), list(prof)
 
 
+@pytest.mark.parametrize("K,N,act", [(128, 512, 2), (64, 128, 1), (128, 160, 0)])
+def test_gemm_x3t_panels(cuda, K, N, act):
+    """lpd_gemm_x3t (short reduction, cloud panels in and out, computed transposed: the SN1 projection): fp32-grade against a
+    float64 product, every epilogue term, A and C as panel sub-ranges of wider buffers, untouched neighbours; exact mode and
+    LPD_X3T = 0 keep the generic kernels."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(41 + K + N)
+    Bc, Np = 5, 384
+    M = Bc * Np
+    X = torch.randn(M, K, generator=g).to(cuda) * 3.0
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    bi, sc, sh = (torch.randn(N, generator=g).to(cuda) for _ in range(3))
+    ref = ((X.double() @ W.double().t()) + bi.double()) * sc.double() + sh.double()
+    ref = ref if act == 0 else torch.where(ref > 0, ref, ref * (0.0 if act == 1 else 0.2))
+    big = ops.panels_empty(Bc, Np, K + 64, cuda)
+    big.fill_(float("nan"))
+    big[:, 8:8 + K // 8] = ops.rows_to_panels(X, Bc)
+    wide = ops.panels_empty(Bc, Np, N + 128, cuda)
+    wide.fill_(-7.0)
+    prof = ops.PROFILE = {}
+    try:
+        ops.gemm(big[:, 8:8 + K // 8], W, b_kmajor=False, bias=bi, scale=sc, shift=sh, act=act, slope=0.2, a_panels=True,
+                 out=wide[:, 8:8 + N // 8], out_panels=True)
+        plain = ops.gemm(big[:, 8:8 + K // 8], W, b_kmajor=False, a_panels=True, out_panels=True)
+    finally:
+        ops.PROFILE = None
+    assert sum(k.startswith("gemmx3t") for k in prof) == 1 and len(prof[f"gemmx3t[{M}x{N}x{K}]"]) == 2, list(prof)
+    assert _rel(ops.panels_to_rows(wide[:, 8:8 + N // 8]), ref) < 2e-5
+    assert _rel(ops.panels_to_rows(plain), X.double() @ W.double().t()) < 2e-5
+    assert bool((wide[:, :8] == -7.0).all()) and bool((wide[:, 8 + N // 8:] == -7.0).all())
+    # the same call on the generic kernels (switch off / exact mode): same values to rounding
+    ops.X3T_PANELS = False
+    try:
+        gen = ops.gemm(big[:, 8:8 + K // 8], W, b_kmajor=False, a_panels=True, out_panels=True)
+    finally:
+        ops.X3T_PANELS = True
+    assert _rel(ops.panels_to_rows(plain), ops.panels_to_rows(gen).double()) < 2e-5
+    prof = ops.PROFILE = {}
+    try:
+        ops.gemm(big[:, 8:8 + K // 8], W, b_kmajor=False, a_panels=True, out_panels=True, exact=True)
+    finally:
+        ops.PROFILE = None
+    assert not any(k.startswith("gemmx3t") for k in prof), list(prof)
+
+
 @pytest.mark.parametrize("exact", [True, False], ids=["f32mfma", "bf16x3"])
 def test_cloud_panel_operands(cuda, exact):
     """Cloud-panel buffers [B, C/8, N, 8] through GEMM (A and C, also as panel sub-ranges of wider buffers), the fused edge
@@ -538,7 +583,11 @@ def test_cloud_panel_operands(cuda, exact):
     want = ops.gemm(X, W, b_kmajor=False, scale=sc, shift=sh, act=ops.ACT_LEAKY, exact=exact)
     big = ops.panels_empty(Bc, Np, K + 64, cuda)              # A as a panel sub-range of a wider buffer
     big[:, 8:8 + K // 8] = ops.rows_to_panels(X, Bc)
-    got = ops.gemm(big[:, 8:8 + K // 8], W, b_kmajor=False, scale=sc, shift=sh, act=ops.ACT_LEAKY, exact=exact, a_panels=True, out_panels=True)
+    ops.X3T_PANELS = False      # (the transposed short-reduction kernel sums in another order: test_gemm_x3t_panels)
+    try:
+        got = ops.gemm(big[:, 8:8 + K // 8], W, b_kmajor=False, scale=sc, shift=sh, act=ops.ACT_LEAKY, exact=exact, a_panels=True, out_panels=True)
+    finally:
+        ops.X3T_PANELS = True
     assert got.shape == (Bc, N // 8, Np, 8)
     assert torch.equal(ops.panels_to_rows(got), want)
     wide = ops.panels_empty(Bc, Np, N + 128, cuda)
