@@ -904,6 +904,140 @@ __device__ __forceinline__ void knn_merge_halves_bitonic(float (&v)[64], int (&i
             }
 }
 
+// ---- tight tile bounds from a low-precision pass (64 channels, N <= 4096) -----------------------------------------------
+// The centroid / radius bound lets ~47 of a cloud's 128 candidate tiles through for the average wave, but only ~17 hold a
+// candidate that beats some query's k-th best (tools/knn_prefilter_study.py): in 64 dimensions a ball around the centroid
+// is a loose description of 32 points.  And a visited tile is expensive far beyond its 32 f32 MFMAs: ~10 k cycles of a
+// wave's life, of which ~2.7 k are the exposed latency of the operand prefetch (s_memtime per phase, tools/knn7_stats.py).
+// The SAME distance tile on bf16 operands is five 32x32x16 MFMAs (160 matrix cycles against 2048) and bounds every exact
+// value of the tile from above:
+//     S(q, c) = sum_i bf16(q_i) bf16(c_i) + hi(-xx_c / 2) + lo(-xx_c / 2)     (fp32 accumulation; the last two terms ride in
+//                                                                              a fifth k-step against a query operand of ones)
+//     | S - (q.c - xx_c / 2) | <= |q| |c| 2^-7.8 + xx_c 2^-17                  (operand rounding 2 x 2^-9 per product, fp32
+//                                                                              accumulation, Cauchy-Schwarz; two-term split of xx_c / 2)
+//     computed pd(q, c) <= 2 S - xx_q + 2 (|q| |c|_max 2^-7.8 + xx_max 2^-17) + 2 E0        (E0: slack of the fp32 evaluation)
+// knn7_bound_kernel evaluates the right-hand side for ALL (query, candidate tile) pairs of a cloud -- a dense N x N x 64 bf16
+// product with a max over each tile's 32 candidates in the epilogue, no data-dependent control -- and writes the table the
+// best-first kernel keeps in LDS ([query tile][candidate tile][32 queries], bf16 rounded up), in place of the centroid
+// bounds: ~20 of the 47 tiles remain.  Non-finite inputs make the tile's xx_max (and with it the bound) +inf or NaN: the tile
+// is visited.  Image xb: per (point, k-half) 32 channels in packed operand order + 8 extras (hi, lo, 0 ...; zero in the
+// second half) = the lane's five 16-byte MFMA operands, stored fragment-major ([tile][k-step][lane][8]).
+constexpr int KNN7_XB = 80;   // bf16 per point: 2 halves x 40
+typedef __bf16 knn_bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void knn7_bf16_kernel(const float* __restrict__ xp, const float* __restrict__ xx, __bf16* __restrict__ xb,
+                                                        int N, int nt)
+{
+    // one thread per (tile, lane) of cloud blockIdx.y; lane = (point of the tile, k-half).  Fragment-major image: the operand
+    // of (tile T, k-step s) is 64 lanes x 16 bytes = ONE contiguous KiB (a lane-strided image -- 80 bytes per (point, half) --
+    // made every operand load touch 40 cache lines for its 1 KiB and the bound kernel L1-bound: 113 us)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt * 64) return;
+    const int b = blockIdx.y;
+    const int T = t >> 6, lane = t & 63, h = lane >> 5;
+    const int pt = min(T * 32 + (lane & 31), N - 1);                  // rows past the cloud repeat its last point (a valid candidate)
+    const float* src = xp + (((size_t)b * N + pt) * 2 + h) * 32;
+    __bf16* dst = xb + (((size_t)b * nt + T) * 5 * 64 + lane) * 8;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 a = *reinterpret_cast<const float4*>(src + 8 * g), c = *reinterpret_cast<const float4*>(src + 8 * g + 4);
+        knn_bf16x8 v;
+        v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+        v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
+        *reinterpret_cast<knn_bf16x8*>(dst + (size_t)g * 512) = v;
+    }
+    knn_bf16x8 e;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = (__bf16)0.0f;
+    if (h == 0) {
+        const float v = -0.5f * xx[(size_t)b * N + pt];
+        const __bf16 hi = (__bf16)v;
+        e[0] = hi;
+        e[1] = (__bf16)(v - (float)hi);
+    }
+    *reinterpret_cast<knn_bf16x8*>(dst + (size_t)4 * 512) = e;
+}
+
+// grid (ceil(nt / 8), B), 256 threads: wave w of block x bounds query tiles 8 x + 2 w, + 1 against every candidate tile; two
+// waves per SIMD (one multiplies while the other finishes a tile: max over its candidates, bound, bf16 round-up, store).
+// (Four query tiles per wave at one wave per SIMD, software-pipelined by hand, was slower: 133 us against 113.)
+constexpr int KNN7_BQT = 2;
+__global__ __launch_bounds__(256, 2) void knn7_bound_kernel(const __bf16* __restrict__ xb, const float* __restrict__ xx,
+                                                            const float* __restrict__ txmax, uint16_t* __restrict__ ubq, int N, int nt, int C)
+{
+    constexpr int QT = KNN7_BQT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, col = lane & 31;
+    const int b = blockIdx.y;
+    const int W0 = (blockIdx.x * 4 + wave) * QT;
+    if (W0 >= nt) return;
+    const __bf16* xbb = xb + ((size_t)b * nt * 5 * 64 + lane) * 8;
+    const float* txb = txmax + (size_t)b * nt;
+    float smax = 0.f;
+    for (int t = lane; t < nt; t += 64) smax = fmaxf(smax, txb[t]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) smax = fmaxf(smax, __shfl_xor(smax, m, 64));
+    const float E0 = 8.0f * (float)(C + 8) * 1.1920929e-7f * smax + 1e-30f;       // the best-first kernel's slack (same expression)
+
+    knn_bf16x8 qop[QT][4], ones;
+    float xq[QT], kq[QT];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)((h == 0 && e < 2) ? 1.0f : 0.0f);
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        const int Wq = min(W0 + i, nt - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qop[i][s] = *reinterpret_cast<const knn_bf16x8*>(xbb + ((size_t)Wq * 5 + s) * 512);
+        xq[i] = xx[(size_t)b * N + min(Wq * 32 + col, N - 1)];
+        kq[i] = (sqrtf(xq[i]) * 1.0001f + 1e-30f) * 4.487102e-3f;                 // |q| 2^-7.8
+    }
+    float pinf = INFINITY;
+    asm volatile("" : "+v"(pinf));
+    // max as v_med3(a, b, +inf) with the +inf in a register the optimiser cannot see through: fmaxf on MFMA results costs three
+    // v_max each (two canonicalising self-maxes)
+    auto mx2 = [&](float a_, float b_) { return __builtin_amdgcn_fmed3f(a_, b_, pinf); };
+    // candidate operands: a ring of RING register sets, requested RING - 1 tiles ahead (one tile ahead -- a copy at the end of
+    // the trip -- made every trip as long as an L2 round trip: 105 us, 1640 cycles per tile for 10 MFMAs)
+    constexpr int RING = 4;
+    knn_bf16x8 cop[RING][5];
+    auto load_c = [&](int T, knn_bf16x8 (&c)[5]) {
+        T = T < nt ? T : nt - 1;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) c[s] = *reinterpret_cast<const knn_bf16x8*>(xbb + ((size_t)T * 5 + s) * 512);
+    };
+    const float tx_lo = txb[min(lane, nt - 1)], tx_hi = txb[min(64 + lane, nt - 1)];      // nt <= 128
+    auto one_tile = [&](int T, const knn_bf16x8 (&c)[5]) {
+        // xx_max of the tile out of the lanes' registers (a load here would be a dependent round trip per tile)
+        const float tx = __builtin_amdgcn_readlane(T < 64 ? tx_lo : tx_hi, T & 63);
+        const float ncT = sqrtf(tx) * 1.0001f;
+        const float cT = 2.0f * (tx * 7.62939453125e-6f + E0);
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+            f32x16 sa = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c[s], qop[i][s], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c[4], ones, sa, 0, 0, 0);
+            float m = mx2(mx2(mx2(sa[0], sa[1]), mx2(sa[2], sa[3])), mx2(mx2(sa[4], sa[5]), mx2(sa[6], sa[7])));
+            m = mx2(m, mx2(mx2(mx2(sa[8], sa[9]), mx2(sa[10], sa[11])), mx2(mx2(sa[12], sa[13]), mx2(sa[14], sa[15]))));
+            m = mx2(m, __shfl_xor(m, 32, 64));                                    // all 32 candidates of the tile
+            float ub = 2.0f * m - xq[i] + (2.0f * (kq[i] * ncT) + cT);
+            ub += fabsf(ub) * 9.5367431640625e-7f;                                // the rounding of this expression itself
+            uint32_t bits = __float_as_uint(ub);
+            bits = (ub <= 0.0f) ? (bits >> 16) : 0x7f80u;                         // truncation rounds a negative value up; else (or NaN) +inf
+            if (h == 0 && W0 + i < nt) ubq[(((size_t)b * nt + (W0 + i)) * nt + T) * 32 + col] = (uint16_t)bits;
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < RING - 1; ++d) load_c(d, cop[d]);
+    for (int T0 = 0; T0 < nt; T0 += RING) {
+#pragma unroll
+        for (int d = 0; d < RING; ++d) {
+            load_c(T0 + d + RING - 1, cop[(d + RING - 1) % RING]);      // the set tile T0 + d - 1 has just released
+            if (T0 + d < nt) one_tile(T0 + d, cop[d]);
+        }
+    }
+}
+
 // tile statistics: centroid (packed operand layout), |c|^2, radius (inflated), max |x|^2.  One wave per tile.
 template <int CP>
 __global__ __launch_bounds__(64) void knn7_tile_stats_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
@@ -938,10 +1072,11 @@ __global__ __launch_bounds__(64) void knn7_tile_stats_kernel(const float* __rest
         nx = fmaxf(nx, __shfl_xor(nx, m, 64));
         cn += __shfl_xor(cn, m, 64);
     }
+    const bool bad = __any(tid < cnt && !(fabsf(xx[(size_t)b * N + t * 32 + tid]) <= 3.0e38f));   // NaN / inf in the tile
     if (tid == 0) {
         rad[(size_t)b * nt + t] = sqrtf(d2) * 1.0001f + 1e-30f;   // upper bound of max |x_i - c| (the fmaf chain is good to ~1e-6)
         cnorm[(size_t)b * nt + t] = cn;
-        txmax[(size_t)b * nt + t] = nx;
+        txmax[(size_t)b * nt + t] = bad ? INFINITY : nx;          // (every bound that uses it becomes +inf: the tile is visited)
     }
 }
 
@@ -1066,7 +1201,8 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
                                                              const float* __restrict__ cenp, const float* __restrict__ cnorm,
                                                              const float* __restrict__ rad, const float* __restrict__ txmax,
                                                              int32_t* __restrict__ idx, const int32_t* __restrict__ order,
-                                                             int N, int k, int nt, int C, int blocks_per_cloud, int dbg)
+                                                             int N, int k, int nt, int C, int blocks_per_cloud, int dbg,
+                                                             const uint16_t* __restrict__ ubq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem7[];
     const int tid = threadIdx.x;
@@ -1113,8 +1249,14 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
     float4 x4[4];
     float pd[16];
 
-    // ---- bound table: pd of every query against every tile centroid (the centroids are a 'cloud' of nt points) ----
-    if (wave_ok && !ONFLY) {
+    // ---- bound table: from the low-precision pass (knn7_bound_kernel) when it ran ... ----
+    if (wave_ok && !ONFLY && ubq) {
+        const uint16_t* src = ubq + ((size_t)b * nt + W) * nt * 32;
+        for (int e = lane * 8; e < nt * 32; e += 64 * 8)       // 16 bytes per lane and trip (nt * 32 % 8 == 0)
+            *reinterpret_cast<uint4*>(ubt + e) = *reinterpret_cast<const uint4*>(src + e);
+    }
+    // ---- ... else pd of every query against every tile centroid (the centroids are a 'cloud' of nt points) ----
+    if (wave_ok && !ONFLY && !ubq) {
         const int nct = (nt + 31) / 32;
         for (int ct = 0; ct < nct; ++ct) {
             float4 r4[4];
@@ -1146,7 +1288,7 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
     }
     float thrv = q_ok ? -INFINITY : INFINITY;   // k-th best so far (admission + skip threshold); padded queries admit nothing
     int cnt = 0;
-    int stat_tiles = 0, stat_it = 0, stat_adm = 0, stat_drains = 0;   // diagnostics (dbg): visited tiles, drain iterations, admitted, drains
+    int stat_tiles = 0, stat_it = 0, stat_adm = 0, stat_drains = 0, stat_fn = 0;   // diagnostics (dbg): visited tiles, drain iterations, admitted, drains
 
     // visiting order: outwards along the Z-curve, W, W+1, W-1, W+2, ... (the visited tiles always form an interval around
     // W, which is what makes the one-compare insertion exact)
@@ -1156,6 +1298,7 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
             const int T = (spos & 1) ? W + ((spos + 1) >> 1) : W - (spos >> 1);
             ++spos;
             if (T < 0 || T >= nt) continue;
+            if constexpr ((CP == 32) && !ONFLY) ++stat_fn;
             float ub;
             if constexpr (CP == 2) {   // centroid in operand order (c0, c2 | c1, 0), like the query's own row
                 const float4 cen = *reinterpret_cast<const float4*>(cenb + (size_t)T * 4);
@@ -1211,17 +1354,40 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
         thrv = q_ok ? thr : INFINITY;
     };
 
+    long long tm_adv = 0, tm_tile = 0, tm_sel = 0, tm_drain = 0, tm0 = 0, tm_start = 0;   // dbg: cycles per phase (s_memtime)
+    constexpr bool TIMERS = (CP == 32) && !ONFLY;     // (the phase clocks cost the xyz kernel registers it does not have: 128 at four waves per SIMD)
+    auto tick = [&]() -> long long { return (TIMERS && dbg) ? (long long)__builtin_readcyclecounter() : 0; };
+    tm_start = tick();
+    // Operands two tiles ahead (TWO register sets, 64 channels with short lists only: 226 registers): a tile's operands are
+    // requested while the tile BEFORE the previous one is multiplied.  One tile ahead, the copy of the loop-carried registers at
+    // the back-edge waited ~2.7 k cycles per tile for the youngest loads (an L2 round trip under load is longer than the
+    // selection that follows the MFMAs): a quarter of a wave's life (s_memtime per phase, tools/knn7_stats.py).
+    constexpr bool TWO_AHEAD = (CP == 32) && KMAX <= 20 && !ONFLY;
+    float a2[TWO_AHEAD ? CP : 1];
+    float4 x42[4];
     int cur = wave_ok ? find_next() : -1;
     int nxt = cur >= 0 ? find_next() : -1;
+    int nxt2 = (TWO_AHEAD && nxt >= 0) ? find_next() : -1;
+    tm_adv += tick() - tm_start;
     if (cur >= 0) {
         knn3_ld_ops<CP>(xpb, N, cur * 32 + col, h, a);
         knn3_ld_xx(xxb, N, cur * 32, h, vec_ok, x4);
     }
-    while (cur >= 0) {
+    if constexpr (TWO_AHEAD) {
+        if (nxt >= 0) {
+            knn3_ld_ops<CP>(xpb, N, nxt * 32 + col, h, a2);
+            knn3_ld_xx(xxb, N, nxt * 32, h, vec_ok, x42);
+        }
+    }
+    // one tile: `cur` sits in (aa, xx4), which the product refills with the operands of the tile TWO_AHEAD ? nxt2 : nxt
+    auto visit = [&](auto& aa, float4 (&xx4)[4]) {
         ++stat_tiles;
-        knn3_tile<CP>(a, x4, qreg, xq, xpb, xxb, N, (nxt >= 0 ? nxt : 0) * 32, nxt >= 0, col, h, vec_ok, pd);
+        tm0 = tick();
+        const int pf = TWO_AHEAD ? nxt2 : nxt;
+        knn3_tile<CP>(aa, xx4, qreg, xq, xpb, xxb, N, (pf >= 0 ? pf : 0) * 32, pf >= 0, col, h, vec_ok, pd);
         float mx = fmaxf(fmaxf(fmaxf(pd[0], pd[1]), fmaxf(pd[2], pd[3])), fmaxf(fmaxf(pd[4], pd[5]), fmaxf(pd[6], pd[7])));
         mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(pd[8], pd[9]), fmaxf(pd[10], pd[11])), fmaxf(fmaxf(pd[12], pd[13]), fmaxf(pd[14], pd[15]))));
+        if (TIMERS && dbg) { const long long t = tick(); tm_tile += t - tm0; tm0 = t; }
         if (__any(mx >= thrv)) {
             if (cur >= W) {   // rows ascending: later arrivals have larger indices
 #pragma unroll
@@ -1242,12 +1408,64 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
                     }
                 }
             }
+            if (TIMERS && dbg) { const long long t = tick(); tm_sel += t - tm0; tm0 = t; }
             if (__any(cnt > L::QCAP - 16)) drain();
+            if (TIMERS && dbg) { const long long t = tick(); tm_drain += t - tm0; tm0 = t; }
         }
         cur = nxt;
-        nxt = cur >= 0 ? find_next() : -1;
+        if constexpr (TWO_AHEAD) {
+            nxt = nxt2;
+            nxt2 = nxt >= 0 ? find_next() : -1;
+        } else nxt = cur >= 0 ? find_next() : -1;
+        if (TIMERS && dbg) { const long long t = tick(); tm_adv += t - tm0; tm0 = t; }
+    };
+    if constexpr (TWO_AHEAD) {
+        while (cur >= 0) {
+            visit(a, x4);
+            if (cur < 0) break;
+            visit(a2, x42);          // the sets swap roles: static names, no copies of registers with loads in flight
+        }
+    } else {
+        while (cur >= 0) {
+            ++stat_tiles;
+            tm0 = tick();
+            const int pf = nxt;
+            knn3_tile<CP>(a, x4, qreg, xq, xpb, xxb, N, (pf >= 0 ? pf : 0) * 32, pf >= 0, col, h, vec_ok, pd);
+            float mx = fmaxf(fmaxf(fmaxf(pd[0], pd[1]), fmaxf(pd[2], pd[3])), fmaxf(fmaxf(pd[4], pd[5]), fmaxf(pd[6], pd[7])));
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(pd[8], pd[9]), fmaxf(pd[10], pd[11])), fmaxf(fmaxf(pd[12], pd[13]), fmaxf(pd[14], pd[15]))));
+            if (TIMERS && dbg) { const long long t = tick(); tm_tile += t - tm0; tm0 = t; }
+            if (__any(mx >= thrv)) {
+                if (cur >= W) {   // rows ascending: later arrivals have larger indices
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (pd[r] >= thrv) {   // ties with the k-th best are admitted: the list decides (NaN padding never passes)
+                            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                            myq[cnt * 64] = make_float2(pd[r], __int_as_float(cur * 32 + row));
+                            ++cnt;
+                        }
+                    }
+                } else {          // tile below the wave's own: rows descending, every arrival has the smallest index so far
+    #pragma unroll
+                    for (int r = 15; r >= 0; --r) {
+                        if (pd[r] >= thrv) {
+                            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                            myq[cnt * 64] = make_float2(pd[r], __int_as_float(cur * 32 + row));
+                            ++cnt;
+                        }
+                    }
+                }
+                if (TIMERS && dbg) { const long long t = tick(); tm_sel += t - tm0; tm0 = t; }
+                if (__any(cnt > L::QCAP - 16)) drain();
+                if (TIMERS && dbg) { const long long t = tick(); tm_drain += t - tm0; tm0 = t; }
+            }
+            cur = nxt;
+            nxt = cur >= 0 ? find_next() : -1;
+            if (TIMERS && dbg) { const long long t = tick(); tm_adv += t - tm0; tm0 = t; }
     }
+    }
+    tm0 = tick();
     drain();
+    tm_drain += tick() - tm0;
     if constexpr (KMAX == 64) {
         // ---- merge the two half-lists in registers (no LDS region) ----
         if (dbg && q_ok) {   // diagnostics instead of indices
@@ -1276,8 +1494,10 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
     __syncthreads();
     if (dbg && q_ok) {   // diagnostics instead of indices
         int32_t* o = idx + ((size_t)b * N + q) * k;
-        if (h == 0) { o[0] = stat_tiles; o[1] = stat_it; o[2] = stat_adm; o[3] = stat_drains; }
-        else o[4] = stat_adm;
+        if (h == 0) {   // (the phase clocks are not ordered against vector work: the wait for the operand prefetch lands in 'advance')
+            o[0] = stat_tiles; o[1] = stat_it; o[2] = stat_adm; o[3] = stat_drains;
+            if (k >= 12) { o[5] = 0; o[6] = (int)tm_adv; o[7] = (int)tm_tile; o[8] = (int)tm_sel; o[9] = (int)tm_drain; o[10] = (int)(tick() - tm_start); o[11] = stat_fn; }
+        } else o[4] = stat_adm;
     } else
     if (h == 0 && q_ok) {
         const float* av = mv + lane * KMAX;
@@ -1337,7 +1557,10 @@ int knn3_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
 inline size_t knn7_extra_floats(int B, int N, int CP)
 {
     const size_t nt = (size_t)(N + 31) / 32;
-    return (size_t)B * nt * (2 * CP + 3 + 2) + 16;   // + predicted tile counts and launch order (int32 each)
+    size_t n = (size_t)B * nt * (2 * CP + 3 + 2) + 16;   // + predicted tile counts and launch order (int32 each)
+    if (CP == 32 && N <= KNN7_MAXT * 32)                 // low-precision pass: bf16 image of the operands + the bound table
+        n += (size_t)B * nt * 32 * (KNN7_XB / 2) + (size_t)B * nt * nt * 16 + 16;
+    return n;
 }
 
 template <int CP, int KMAX, bool ONFLY>
@@ -1360,6 +1583,19 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
     int32_t* pred = reinterpret_cast<int32_t*>(txmax + (size_t)B * nt + 4);
     int32_t* order = pred + (size_t)B * nt;
     const int nitems = bpc * B;
+    uint16_t* ubq = nullptr;
+    if constexpr (CP == 32 && !ONFLY) {
+        static const bool tight = !(getenv("LPD_KNN_PRE") && atoi(getenv("LPD_KNN_PRE")) == 0);
+        if (tight) {
+            const uintptr_t a0 = (reinterpret_cast<uintptr_t>(order + nitems + 4) + 15) & ~(uintptr_t)15;
+            __bf16* xb = reinterpret_cast<__bf16*>(a0);
+            ubq = reinterpret_cast<uint16_t*>(xb + (size_t)B * nt * 32 * KNN7_XB);
+            hipLaunchKernelGGL(knn7_bf16_kernel, dim3((nt * 64 + 255) / 256, B), dim3(256), 0, stream, (const float*)xp, xx, xb, N, nt);
+            hipLaunchKernelGGL(knn7_bound_kernel, dim3((nt + 4 * KNN7_BQT - 1) / (4 * KNN7_BQT), B), dim3(256), 0, stream, (const __bf16*)xb, xx,
+                               (const float*)txmax, ubq, N, nt, C);
+            LPD_CHECK_LAUNCH("lpd_knn(low-precision bounds)");
+        }
+    }
     if (lpt) {
         hipLaunchKernelGGL(knn7_predict_kernel<CP>, dim3(nt, B), dim3(128), 0, stream, (const float*)cenp, (const float*)rad, pred, nt);
         hipLaunchKernelGGL(knn7_order_kernel, dim3((nitems / 8 + 1 + 1023) / 1024, 8), dim3(1024), 0, stream, (const int32_t*)pred, order, nitems);
@@ -1371,7 +1607,7 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(WAVES * 64), lds, stream, (const float*)xp, xx, (const float*)cenp,
                            (const float*)cnorm, (const float*)rad, (const float*)txmax, idx, (const int32_t*)(lpt ? order : nullptr),
-                           N, k, nt, C, bpc, dbg);
+                           N, k, nt, C, bpc, dbg, (const uint16_t*)ubq);
         LPD_CHECK_LAUNCH("lpd_knn(best-first)");
     }
     return LPD_OK;

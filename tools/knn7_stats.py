@@ -14,8 +14,12 @@ for name, feat in (("xyz", ops.transpose(xs.view(B, N, 3))), ("feat64", None)):
         f = torch.nn.functional.leaky_relu(torch.nn.functional.leaky_relu(xs.view(B * N, 3) @ W1.t(), 0.01) @ W2.t(), 0.01)
         feat = ops.transpose(f.view(B, N, 64).contiguous())
     for simpl, label in ((5, "z-walk"),):
-        st = ops.knn(feat, k, impl=simpl).view(B * N, k)[:, :5].float()
+        raw = ops.knn(feat, k, impl=simpl).view(B * N, k)
+        st = raw[:, :5].float()
         w = st.view(-1, 32, 5)[:, 0, :]     # per wave (first query of each tile)
+        if k >= 12:
+            ph = raw.view(-1, 32, k)[:, 0, 5:12].float()
+            print(name, "low-precision tests/wave %.1f; cycles/wave: advance %.0f  exact tile %.0f  select+queue %.0f  drain %.0f  total %.0f; bound tests %.1f" % tuple(ph.mean(0).tolist()), flush=True)
         print(name, label, "tiles visited/wave %.1f  drain iterations %.1f  drains %.1f  admitted per half-lane %.1f / %.1f" % (
             w[:, 0].mean(), w[:, 1].mean(), w[:, 3].mean(), st[:, 2].mean(), st[:, 4].mean()), flush=True)
     for impl in (4, 6):
