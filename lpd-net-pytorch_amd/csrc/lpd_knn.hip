@@ -913,9 +913,12 @@ __device__ __forceinline__ void knn_merge_halves_bitonic(float (&v)[64], int (&i
 // value of the tile from above:
 //     S(q, c) = sum_i bf16(q_i) bf16(c_i) + hi(-xx_c / 2) + lo(-xx_c / 2)     (fp32 accumulation; the last two terms ride in
 //                                                                              a fifth k-step against a query operand of ones)
-//     | S - (q.c - xx_c / 2) | <= |q| |c| 2^-7.8 + xx_c 2^-17                  (operand rounding 2 x 2^-9 per product, fp32
-//                                                                              accumulation, Cauchy-Schwarz; two-term split of xx_c / 2)
-//     computed pd(q, c) <= 2 S - xx_q + 2 (|q| |c|_max 2^-7.8 + xx_max 2^-17) + 2 E0        (E0: slack of the fp32 evaluation)
+//     | S - (q.c - xx_c / 2) | <= 7.9e-3 |q| |c| + xx_c 2^-17                  (bf16 unit roundoff u = 2^-8: (1 + u)^2 - 1 = 7.83e-3
+//                                                                              per product, Cauchy-Schwarz, + fp32 accumulation;
+//                                                                              two-term split of xx_c / 2: u^2 / 2)
+//     computed pd(q, c) <= 2 S - xx_q + 2 (7.9e-3 |q| |c|_max + xx_max 2^-17) + 2 E0        (E0: slack of the fp32 evaluation)
+// (The first version used 2^-7.8: half the true bound -- u is 2^-8, not 2^-9.  Random clouds never noticed; a cloud of identical
+//  points, where every product errs by the maximum in the same direction, did: tests/test_ops_gpu.py 'identical', C = 64.)
 // knn7_bound_kernel evaluates the right-hand side for ALL (query, candidate tile) pairs of a cloud -- a dense N x N x 64 bf16
 // product with a max over each tile's 32 candidates in the epilogue, no data-dependent control -- and writes the table the
 // best-first kernel keeps in LDS ([query tile][candidate tile][32 queries], bf16 rounded up), in place of the centroid
@@ -989,7 +992,7 @@ __global__ __launch_bounds__(256, 2) void knn7_bound_kernel(const __bf16* __rest
 #pragma unroll
         for (int s = 0; s < 4; ++s) qop[i][s] = *reinterpret_cast<const knn_bf16x8*>(xbb + ((size_t)Wq * 5 + s) * 512);
         xq[i] = xx[(size_t)b * N + min(Wq * 32 + col, N - 1)];
-        kq[i] = (sqrtf(xq[i]) * 1.0001f + 1e-30f) * 4.487102e-3f;                 // |q| 2^-7.8
+        kq[i] = (sqrtf(xq[i]) * 1.0001f + 1e-30f) * 7.9e-3f;                      // |q| (2 u + u^2 + accumulation), u = 2^-8
     }
     float pinf = INFINITY;
     asm volatile("" : "+v"(pinf));

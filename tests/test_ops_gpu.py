@@ -94,15 +94,19 @@ def test_knn_many_small_clouds(cuda):
 
 
 @pytest.mark.parametrize("impl", [0, 4])
-@pytest.mark.parametrize("case", ["offset", "huge", "tiny", "identical", "line"])
-def test_knn_ill_conditioned_clouds(cuda, case, impl):
+@pytest.mark.parametrize("case", ["offset", "huge", "tiny", "identical", "line", "clusters", "shells"])
+@pytest.mark.parametrize("C", [3, 64])
+def test_knn_ill_conditioned_clouds(cuda, case, impl, C):
     """Inputs on which the fp32 pd evaluation is badly conditioned or fully degenerate: a cloud far from the origin
     (catastrophic cancellation: pd is quantised at ulp(|x|^2) ~ 1e-3, ties everywhere), very large and very small scales,
     all points identical, all points on a line.  The skip bounds of the best-first kernel must stay conservative (their
-    slack scales with max |x|^2) and the tie rule must hold: every row equals the oracle's."""
+    slack scales with max |x|^2) and the tie rule must hold: every row equals the oracle's.  C = 64: the tile bounds come from
+    the low-precision pass (bf16 operands, error bound 7.9e-3 |q||c|): far from the origin that bound is useless -- and must be;
+    identical points put every product at the maximum rounding error in the same direction (this case caught a bound that was half
+    the true one)."""
     ops = _ops()
     g = np.random.default_rng(7)
-    N, C = 2048, 3
+    N = 2048
     x = g.uniform(-1, 1, (2, N, C)).astype(np.float32)
     if case == "offset":
         x = (x + np.float32(100.0)).astype(np.float32)
@@ -114,6 +118,12 @@ def test_knn_ill_conditioned_clouds(cuda, case, impl):
         x[:] = np.float32(0.37)
     elif case == "line":
         x[:, :, 1:] = 0
+    elif case == "clusters":     # tile-aligned tight clusters at mixed separations: the regime where tile bounds decide most skips
+        cen = g.normal(0, 1, (2, N // 32, 1, C)) * g.choice([0.05, 0.3, 2.0], (2, N // 32, 1, 1))
+        x = (cen + 0.02 * g.normal(0, 1, (2, N // 32, 32, C))).reshape(2, N, C).astype(np.float32)
+    elif case == "shells":       # every point at (almost) the same distance from every other: thresholds and bounds nearly touch
+        x = g.normal(0, 1, (2, N, C))
+        x = (x / np.linalg.norm(x, axis=-1, keepdims=True) * (1.0 + 1e-4 * g.normal(0, 1, (2, N, 1)))).astype(np.float32)
     oidx, _ = orc.knn_np(x, 20)
     got = ops.knn_pm(torch.from_numpy(x.reshape(-1, C)).to(cuda), 2, N, 20, impl=impl).cpu().numpy()
     assert (got == oidx).all(), f"{(got != oidx).any(-1).sum()} rows differ"

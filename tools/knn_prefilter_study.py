@@ -1,7 +1,7 @@
 """Would a cheap low-precision distance tile (one bf16 MFMA product, 1/16 of the exact tile's matrix cycles) prove most of the
 visited-but-useless candidate tiles of the feature-space kNN irrelevant?  Per (query tile W, candidate tile T) of the bench
 model's F0 features: 'needed' = T holds a candidate that beats some query's final k-th best; 'bound' = the centroid / radius
-bound the kernel uses cannot exclude T; 'pre' = neither can the bf16 tile with a rigorous error bound (|q||c| 2^-7).
+bound the kernel uses cannot exclude T; 'pre' = neither can the bf16 tile with a rigorous error bound (7.9e-3 |q||c|).
 python tools/knn_prefilter_study.py"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "lpd-net-pytorch_amd")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -46,10 +46,10 @@ for center in (False, True):
         dot_b = fb @ fb.t()
         n2 = (fc * fc).sum(1)
         pd_b = 2 * dot_b - n2[:, None] - n2[None]
-        eps = 2.0 * nrm[:, None] * nrm[None] * 2.0 ** -7.9
+        eps = 2.0 * nrm[:, None] * nrm[None] * 7.9e-3           # (1 + u)^2 - 1 with u = 2^-8, + accumulation
         pre = ((pd_b + eps) >= thr[:, None]).view(nt, 32, nt, 32).any(3).any(1)
         # two-product variant: q exact to 16 bits (hi + lo) against bf16 candidates: error only from the candidate side
-        eps2 = 2.0 * nrm[:, None] * nrm[None] * 2.0 ** -8.9
+        eps2 = 2.0 * nrm[:, None] * nrm[None] * 3.95e-3
         pd_2 = 2 * (fc @ fb.t()) - n2[:, None] - n2[None]
         pre2 = ((pd_2 + eps2) >= thr[:, None]).view(nt, 32, nt, 32).any(3).any(1)
         tot["needed"] += needed.float().sum(1).mean().item(); tot["bound"] += bound.float().sum(1).mean().item()
