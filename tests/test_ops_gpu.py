@@ -94,7 +94,7 @@ def test_knn_many_small_clouds(cuda):
 
 
 @pytest.mark.parametrize("impl", [0, 4])
-@pytest.mark.parametrize("case", ["offset", "huge", "tiny", "identical", "line", "clusters", "shells"])
+@pytest.mark.parametrize("case", ["offset", "huge", "tiny", "identical", "line", "clusters", "shells", "halfulp"])
 @pytest.mark.parametrize("C", [3, 64])
 def test_knn_ill_conditioned_clouds(cuda, case, impl, C):
     """Inputs on which the fp32 pd evaluation is badly conditioned or fully degenerate: a cloud far from the origin
@@ -124,6 +124,12 @@ def test_knn_ill_conditioned_clouds(cuda, case, impl, C):
     elif case == "shells":       # every point at (almost) the same distance from every other: thresholds and bounds nearly touch
         x = g.normal(0, 1, (2, N, C))
         x = (x / np.linalg.norm(x, axis=-1, keepdims=True) * (1.0 + 1e-4 * g.normal(0, 1, (2, N, 1)))).astype(np.float32)
+    elif case == "halfulp":      # every coordinate just below a bf16 rounding tie (maximal rounding error, all in one direction),
+        # in tile-aligned clusters that differ only in bits bf16 does not keep
+        base = g.choice([0.25, 0.5, 1.0, 2.0], (2, N // 32, 1, C)) * (1.0 + g.integers(0, 128, (2, N // 32, 1, C)) / 128.0)
+        bits = base.astype(np.float32).view(np.uint32) | np.uint32(0x7F00)            # low mantissa 0x7Fxx: rounds DOWN by ~u/2 ... u
+        x = (bits + g.integers(0, 0x100, (2, N // 32, 32, C)).astype(np.uint32)).view(np.float32).reshape(2, N, C)
+        x = (x * g.choice([-1.0, 1.0], (2, 1, 1, C)).reshape(2, 1, C)).astype(np.float32)
     oidx, _ = orc.knn_np(x, 20)
     got = ops.knn_pm(torch.from_numpy(x.reshape(-1, C)).to(cuda), 2, N, 20, impl=impl).cpu().numpy()
     assert (got == oidx).all(), f"{(got != oidx).any(-1).sum()} rows differ"
