@@ -392,6 +392,67 @@ __global__ void knn_prep_pm_kernel(const float* __restrict__ xpm, int ld, float*
         }
 }
 
+// The same for exactly 64 channels with FOUR lanes per point (lane j: channels 16 j .. 16 j + 15): a row is read as one
+// contiguous 256 bytes per four lanes and the packed image written in 128-byte runs (one thread per point read 16 strided
+// float4 and ran at 2 TB/s: 31 us at 32 x 4096 points); the partial sums of the four 16-channel blocks are combined in the
+// order knn_sumsq_kernel uses, so xx is bit-identical.  When the best-first kernel will want the bf16 image of the operands
+// (xb != nullptr: tabulated low-precision bounds, whole tiles only), the lane writes its k-step of it from the same registers:
+// lane j's eight packed values of half h ARE fragment (tile, k-step j) of lane (point, h).
+typedef __bf16 knn_prep_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void knn_prep_pm4_kernel(const float* __restrict__ xpm, int ld, float* __restrict__ xx, float* __restrict__ xp,
+                                                           __bf16* __restrict__ xb, long long M, int N, int nt)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long m = t >> 2;
+    const int j = (int)(t & 3);
+    const bool live = m < M;
+    const float* row = xpm + (live ? m : M - 1) * ld + 16 * j;
+    float v[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 q = *reinterpret_cast<const float4*>(row + 4 * g);
+        v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+    }
+    float acc = __fmul_rn(v[0], v[0]);
+#pragma unroll
+    for (int c = 1; c < 16; ++c) acc = __fadd_rn(acc, __fmul_rn(v[c], v[c]));
+    const int lane0 = (threadIdx.x & 63) & ~3;
+    float total = __shfl(acc, lane0, 64);
+    total = __fadd_rn(total, __shfl(acc, lane0 + 1, 64));
+    total = __fadd_rn(total, __shfl(acc, lane0 + 2, 64));
+    total = __fadd_rn(total, __shfl(acc, lane0 + 3, 64));
+    if (!live) return;
+    if (j == 0) xx[m] = total;
+    float* dst = xp + m * 64 + 8 * j;
+    const long long b = m / N;
+    const int pt = (int)(m - b * N);
+    __bf16* fb = xb ? xb + ((((size_t)b * nt + (pt >> 5)) * 5 + j) * 64 + (pt & 31)) * 8 : nullptr;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        *reinterpret_cast<float4*>(dst + h * 32) = make_float4(v[h], v[2 + h], v[4 + h], v[6 + h]);
+        *reinterpret_cast<float4*>(dst + h * 32 + 4) = make_float4(v[8 + h], v[10 + h], v[12 + h], v[14 + h]);
+        if (fb) {
+            knn_prep_bf16x8 e;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) e[i] = (__bf16)v[2 * i + h];
+            *reinterpret_cast<knn_prep_bf16x8*>(fb + h * 32 * 8) = e;
+        }
+    }
+    if (fb && j < 2) {     // fifth k-step: (hi, lo) of -xx / 2 in half 0, zeros in half 1
+        knn_prep_bf16x8 e;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = (__bf16)0.0f;
+        if (j == 0) {
+            const float w = -0.5f * total;
+            const __bf16 hi = (__bf16)w;
+            e[0] = hi;
+            e[1] = (__bf16)(w - (float)hi);
+        }
+        __bf16* f4 = xb + ((((size_t)b * nt + (pt >> 5)) * 5 + 4) * 64 + (pt & 31) + 32 * j) * 8;
+        *reinterpret_cast<knn_prep_bf16x8*>(f4) = e;
+    }
+}
+
 // operand column of point j (clamped to N-1: padded candidates are neutralised through xx = NaN)
 template <int CP>
 __device__ __forceinline__ void knn3_ld_ops(const float* __restrict__ xpb, int N, int j, int h, float (&a)[CP])
@@ -1566,8 +1627,23 @@ inline size_t knn7_extra_floats(int B, int N, int CP)
     return n;
 }
 
+// the low-precision bound pass (LPD_KNN_PRE=0: centroid / radius bounds) and where its bf16 operand image lives in the workspace
+inline bool knn7_tight()
+{
+    static const bool tight = !(getenv("LPD_KNN_PRE") && atoi(getenv("LPD_KNN_PRE")) == 0);
+    return tight;
+}
+inline __bf16* knn7_xb_of(const float* xx, int B, int N)      // 64 channels (CP = 32), one wave per workgroup
+{
+    const int nt = (N + 31) / 32;
+    const float* txmax = xx + (size_t)B * N * (1 + 64) + (size_t)B * nt * (64 + 2);
+    const int32_t* order = reinterpret_cast<const int32_t*>(txmax + (size_t)B * nt + 4) + (size_t)B * nt;
+    const uintptr_t a0 = (reinterpret_cast<uintptr_t>(order + (size_t)nt * B + 4) + 15) & ~(uintptr_t)15;
+    return reinterpret_cast<__bf16*>(a0);
+}
+
 template <int CP, int KMAX, bool ONFLY>
-int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg = 0)
+int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg = 0, bool xb_ready = false)
 {
     using L = Knn7Cfg<CP, KMAX, ONFLY>;
     static_assert(L::WAVE >= L::MERGE, "merge region must fit the wave's LDS region");
@@ -1588,12 +1664,10 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
     const int nitems = bpc * B;
     uint16_t* ubq = nullptr;
     if constexpr (CP == 32 && !ONFLY) {
-        static const bool tight = !(getenv("LPD_KNN_PRE") && atoi(getenv("LPD_KNN_PRE")) == 0);
-        if (tight) {
-            const uintptr_t a0 = (reinterpret_cast<uintptr_t>(order + nitems + 4) + 15) & ~(uintptr_t)15;
-            __bf16* xb = reinterpret_cast<__bf16*>(a0);
+        if (knn7_tight()) {
+            __bf16* xb = knn7_xb_of(xx, B, N);
             ubq = reinterpret_cast<uint16_t*>(xb + (size_t)B * nt * 32 * KNN7_XB);
-            hipLaunchKernelGGL(knn7_bf16_kernel, dim3((nt * 64 + 255) / 256, B), dim3(256), 0, stream, (const float*)xp, xx, xb, N, nt);
+            if (!xb_ready) hipLaunchKernelGGL(knn7_bf16_kernel, dim3((nt * 64 + 255) / 256, B), dim3(256), 0, stream, (const float*)xp, xx, xb, N, nt);
             hipLaunchKernelGGL(knn7_bound_kernel, dim3((nt + 4 * KNN7_BQT - 1) / (4 * KNN7_BQT), B), dim3(256), 0, stream, (const __bf16*)xb, xx,
                                (const float*)txmax, ubq, N, nt, C);
             LPD_CHECK_LAUNCH("lpd_knn(low-precision bounds)");
@@ -1620,11 +1694,11 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
 // larger clouds and neighbourhoods (BASELINE configs[4]: N = 16384, k = 64)
 constexpr int KNN7_MAXN = 65536;
 inline bool knn7_applies(int C, int N, int k) { return C <= 64 && k <= 64 && N <= KNN7_MAXN; }
-inline int knn7_dispatch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg)
+inline int knn7_dispatch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg, bool xb_ready = false)
 {
     const bool small = k <= 20 && N <= KNN7_MAXT * 32;
     if (C <= 4) return k <= 20 ? knn7_launch<2, 20, true>(x, xx, idx, B, C, N, k, stream, dbg) : knn7_launch<2, 64, true>(x, xx, idx, B, C, N, k, stream, dbg);
-    if (small) return knn7_launch<32, 20, false>(x, xx, idx, B, C, N, k, stream, dbg);
+    if (small) return knn7_launch<32, 20, false>(x, xx, idx, B, C, N, k, stream, dbg, xb_ready);
     return k <= 20 ? knn7_launch<32, 20, true>(x, xx, idx, B, C, N, k, stream, dbg) : knn7_launch<32, 64, true>(x, xx, idx, B, C, N, k, stream, dbg);
 }
 
@@ -1736,11 +1810,17 @@ extern "C" int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k,
     LPD_CHECK_ARG(C <= 4 || ((uintptr_t)x_pm & 15) == 0, "lpd_knn_pm: x_pm must be 16-byte aligned");
     const long long M = (long long)B * N;
     float* xp = ws + M;
+    const bool best_first = ((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && knn7_applies(C, N, k);
+    bool xb_ready = false;
     if (C <= 4) hipLaunchKernelGGL(knn_prep_pm_kernel<2>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);
-    else hipLaunchKernelGGL(knn_prep_pm_kernel<32>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);
+    else if (C == 64 && ld % 4 == 0) {
+        // four lanes per point; the bf16 operand image of the low-precision bound pass in the same pass when that pass will run
+        xb_ready = best_first && knn7_tight() && k <= 20 && N <= KNN7_MAXT * 32 && N % 32 == 0;
+        hipLaunchKernelGGL(knn_prep_pm4_kernel, dim3((unsigned)((4 * M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp,
+                           xb_ready ? knn7_xb_of(ws, B, N) : (__bf16*)nullptr, M, N, (N + 31) / 32);
+    } else hipLaunchKernelGGL(knn_prep_pm_kernel<32>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);
     LPD_CHECK_LAUNCH("lpd_knn_pm(prep)");
-    if (((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && knn7_applies(C, N, k))
-        return knn7_dispatch(nullptr, ws, idx, B, C, N, k, stream, impl == 5);
+    if (best_first) return knn7_dispatch(nullptr, ws, idx, B, C, N, k, stream, impl == 5, xb_ready);
     if (C <= 4) return knn3_dispatch_k<2>(nullptr, ws, idx, B, C, N, k, stream);
     return knn3_dispatch_k<32>(nullptr, ws, idx, B, C, N, k, stream);
 }
