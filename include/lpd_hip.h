@@ -58,6 +58,22 @@ int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* ws,
 long long lpd_knn_workspace_floats(int B, int C, int N, int k);
 /* The same on point-major rows x_pm [B*N][ld] (the pipeline's activation layout; C <= 64, k <= 64): no transposes. */
 int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k, int32_t* idx, float* ws, int impl, void* stream);
+/* impl | LPD_KNN_PM_PREPARED: the operands of the 64-channel cloud are in ws already (lpd_lpdnet_front wrote them); x_pm may be
+ * NULL.  lpd_knn_pm_layout: where lpd_knn_pm keeps them -- squared norms xx [B*N], packed operand image xp [B*N][2][32], and the
+ * bf16 image xb of the low-precision bound pass (NULL when that pass will not run on these sizes). */
+#define LPD_KNN_PM_PREPARED 256
+int lpd_knn_pm_layout(int B, int C, int N, int k, float* ws, float** xx, float** xp, void** xb);
+
+/*
+ * The layers in front of the feature-space kNN of LPD-Net in one launch (util/lpdnet_model.py:231-232, no T-Nets):
+ *   F0 = act(BN2(conv2_lpd(act(BN1(conv1_lpd(xyz))))))   xyz [B*N][ldx] (3 coordinates used), W1 [64][3], W2 [64][64] ([out][in]),
+ *   s / b = folded eval-mode BatchNorm scale / shift, act none / ReLU / LeakyReLU; exact fp32 (fma chains, f32-input MFMA).
+ * F0 [B*N][64] row-major.  knn_ws != NULL (a lpd_knn_workspace_floats(B, 64, N, k) workspace): the kNN operands of F0 are
+ * written there too, and lpd_knn_pm(NULL, 64, B, 64, N, k, idx, knn_ws, LPD_KNN_PM_PREPARED, stream) builds the graph.
+ * N % 128 == 0.
+ */
+int lpd_lpdnet_front(const float* xyz, int ldx, const float* W1, const float* s1, const float* b1, const float* W2, const float* s2,
+                     const float* b2, int act, float slope, float* F0, int B, int N, int k, float* knn_ws, void* stream);
 
 /*
  * Dense fp32 GEMM with fused epilogue:  C = act((A.B + bias) * scale + shift), per output column.

@@ -1798,24 +1798,45 @@ extern "C" int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
     return LPD_ERR_UNSUPPORTED;
 }
 
+namespace {
+// does lpd_knn_pm(impl) run the low-precision bound pass on these sizes (and so want the bf16 operand image)?
+inline bool knn_pm_wants_xb(int C, int N, int k, int impl)
+{
+    const bool best_first = ((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && knn7_applies(C, N, k);
+    return best_first && C == 64 && knn7_tight() && k <= 20 && N <= KNN7_MAXT * 32 && N % 32 == 0;
+}
+}  // namespace
+
+extern "C" int lpd_knn_pm_layout(int B, int C, int N, int k, float* ws, float** xx, float** xp, void** xb)
+{
+    LPD_CHECK_ARG(ws && xx && xp && xb && B > 0 && N > 0 && C > 0 && C <= 64, "lpd_knn_pm_layout: bad arguments");
+    *xx = ws;
+    *xp = ws + (size_t)B * N;
+    *xb = (C == 64 && knn_pm_wants_xb(C, N, k, 0)) ? (void*)knn7_xb_of(ws, B, N) : nullptr;
+    return LPD_OK;
+}
+
 // Point-major entry: x_pm [B*N][ld] rows (C <= 64 channels used).  Same results as lpd_knn on the transposed input; skips
 // the channel-major round trip (transpose + pack) that the pipeline would otherwise pay for each graph.
 extern "C" int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k, int32_t* idx, float* ws, int impl, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    LPD_CHECK_ARG(x_pm && idx && ws, "lpd_knn_pm: null pointer");
+    LPD_CHECK_ARG((x_pm || (impl & LPD_KNN_PM_PREPARED)) && idx && ws, "lpd_knn_pm: null pointer");
     LPD_CHECK_ARG(B > 0 && C > 0 && N > 0 && ld >= C, "lpd_knn_pm: bad dims B=%d C=%d N=%d ld=%d", B, C, N, ld);
     LPD_CHECK_ARG(k > 0 && k <= N, "lpd_knn_pm: need 0 < k <= N (k=%d N=%d)", k, N);
     LPD_CHECK_ARG(C <= 64 && k <= 64, "lpd_knn_pm: built for C <= 64, k <= 64 (got C=%d k=%d); use lpd_knn on the channel-major tensor", C, k);
-    LPD_CHECK_ARG(C <= 4 || ((uintptr_t)x_pm & 15) == 0, "lpd_knn_pm: x_pm must be 16-byte aligned");
+    LPD_CHECK_ARG(C <= 4 || (impl & LPD_KNN_PM_PREPARED) || ((uintptr_t)x_pm & 15) == 0, "lpd_knn_pm: x_pm must be 16-byte aligned");
     const long long M = (long long)B * N;
     float* xp = ws + M;
+    const bool prepped = (impl & LPD_KNN_PM_PREPARED) != 0;     // the operands are in ws already (lpd_lpdnet_front)
+    impl &= ~LPD_KNN_PM_PREPARED;
     const bool best_first = ((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && knn7_applies(C, N, k);
-    bool xb_ready = false;
-    if (C <= 4) hipLaunchKernelGGL(knn_prep_pm_kernel<2>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);
-    else if (C == 64 && ld % 4 == 0) {
-        // four lanes per point; the bf16 operand image of the low-precision bound pass in the same pass when that pass will run
-        xb_ready = best_first && knn7_tight() && k <= 20 && N <= KNN7_MAXT * 32 && N % 32 == 0;
+    // the bf16 operand image of the low-precision bound pass is written with the operands when that pass will run
+    const bool xb_ready = knn_pm_wants_xb(C, N, k, impl) && (prepped || ld % 4 == 0);
+    LPD_CHECK_ARG(!prepped || C == 64, "lpd_knn_pm: prepared operands are a 64-channel affair (C=%d)", C);
+    if (prepped) { /* nothing to do */ }
+    else if (C <= 4) hipLaunchKernelGGL(knn_prep_pm_kernel<2>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);
+    else if (C == 64 && ld % 4 == 0) {      // four lanes per point
         hipLaunchKernelGGL(knn_prep_pm4_kernel, dim3((unsigned)((4 * M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp,
                            xb_ready ? knn7_xb_of(ws, B, N) : (__bf16*)nullptr, M, N, (N + 31) / 32);
     } else hipLaunchKernelGGL(knn_prep_pm_kernel<32>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);

@@ -167,6 +167,7 @@ def _knn_rows(rows, B, N, C, k):
 # cloud-panel [B, C/8, N, 8] buffers for x1|x2|x3 and the SN1 projections (LPD_PANELS=0: row-major everywhere)
 PANEL_LAYOUT = __import__("os").environ.get("LPD_PANELS", "1") != "0"
 SIDE_STREAM = __import__("os").environ.get("LPD_SIDE_STREAM", "1") != "0"   # xyz kNN on a second HIP stream (eval path)
+FUSED_FRONT = __import__("os").environ.get("LPD_FUSED_FRONT", "1") != "0"   # conv1 + conv2 + kNN operands in one launch (no T-Nets)
 _SIDE = {}
 _SIDE_LOCK = __import__("threading").Lock()      # nn.DataParallel calls forward from one host thread per device
 
@@ -242,17 +243,24 @@ def lpdnet_features_eval(net, x, reorder=True):
             idx_x = _knn_rows(xyz, B, N, 3, k)
             i16_x = ops.pack_idx16(idx_x)
         side_job = (side, idx_x, i16_x)
-    with ops.exact_gemm():      # everything in front of the feature-space kNN is exact fp32
-        if net.t3d:
-            trans = transform_net_eval(net.t_net3d, xyz, B, N)
-            p = _aligned_input(ops.apply_transform(xyz, trans, N), p, mfea)
+    knn_ws = None
+    if FUSED_FRONT and not (mfea or net.t3d or net.tfea) and N % 128 == 0 and k <= 64:
+        # conv1 -> conv2 and the kNN operands of their output in one launch (lpd_lpdnet_front), exact fp32
         s, b = bn_affine(net.bn1_lpd)
-        f = ops.linear(p, _w2d(net.conv1_lpd), scale=s, shift=b, act=act, slope=slope)
-        s, b = bn_affine(net.bn2_lpd)
-        f = ops.linear(f, _w2d(net.conv2_lpd), scale=s, shift=b, act=act, slope=slope)      # F0 [M,64]
-        if net.tfea:
-            tf = transform_net_eval(net.t_net_fea, f, B, N)
-            f = ops.apply_transform(f, tf, N)
+        s2_, b2_ = bn_affine(net.bn2_lpd)
+        f, knn_ws = ops.lpdnet_front(xyz, _w2d(net.conv1_lpd), s, b, _w2d(net.conv2_lpd), s2_, b2_, B, N, k, act=act, slope=slope)
+    else:
+        with ops.exact_gemm():      # everything in front of the feature-space kNN is exact fp32
+            if net.t3d:
+                trans = transform_net_eval(net.t_net3d, xyz, B, N)
+                p = _aligned_input(ops.apply_transform(xyz, trans, N), p, mfea)
+            s, b = bn_affine(net.bn1_lpd)
+            f = ops.linear(p, _w2d(net.conv1_lpd), scale=s, shift=b, act=act, slope=slope)
+            s, b = bn_affine(net.bn2_lpd)
+            f = ops.linear(f, _w2d(net.conv2_lpd), scale=s, shift=b, act=act, slope=slope)      # F0 [M,64]
+            if net.tfea:
+                tf = transform_net_eval(net.t_net_fea, f, B, N)
+                f = ops.apply_transform(f, tf, N)
     s1, b1 = bn_affine(net.convDG1[1])
     s2, b2 = bn_affine(net.convDG2[1])
     s3, b3 = bn_affine(net.convSN1[1])
@@ -267,7 +275,7 @@ def lpdnet_features_eval(net, x, reorder=True):
         with torch.cuda.stream(side):
             pq = ops.linear(f, wdg1)                                                      # [M,256] = [P | Q]
     # dynamic graph in feature space
-    idx_f = _knn_rows(f, B, N, 64, k)
+    idx_f = ops.knn_prepared(knn_ws, B, N, k) if knn_ws is not None else _knn_rows(f, B, N, 64, k)
     if pq is None:
         pq = ops.linear(f, wdg1)                                                          # [M,256] = [P | Q]
     resident = _kagg_cloud_resident(idx_f, N, M, act)

@@ -95,6 +95,37 @@ def knn(x_cm, k, impl=None):
     return idx
 
 
+def lpdnet_front(xyz, W1, s1, b1, W2, s2, b2, B, N, k, act=ACT_NONE, slope=0.01):
+    """F0 = act(BN2(conv2(act(BN1(conv1(xyz)))))) [B*N, 64] of the LPD-Net trunk in one launch, exact fp32, together with the kNN
+    operands of F0 (lpd_lpdnet_front).  Returns (F0, ws): pass ws to knn_prepared."""
+    _req(xyz, "xyz")
+    ldx = _rows(xyz, "xyz")
+    M = xyz.shape[0]
+    if M != B * N or N % 128:
+        raise ValueError("lpdnet_front: rows != B*N or N % 128 != 0")
+    W1 = W1.reshape(64, 3).contiguous()
+    W2 = W2.reshape(64, 64).contiguous()
+    f0 = torch.empty((M, 64), dtype=torch.float32, device=xyz.device)
+    ws = torch.empty((knn_workspace_floats(B, 64, N),), dtype=torch.float32, device=xyz.device)
+    lib = _lib.load()
+    _call("lpdnet_front", lib.lpd_lpdnet_front, _ptr(xyz), ldx, _ptr(W1), _ptr(_vec(s1, "s1", 64)), _ptr(_vec(b1, "b1", 64)), _ptr(W2),
+          _ptr(_vec(s2, "s2", 64)), _ptr(_vec(b2, "b2", 64)), act, float(slope), _ptr(f0), B, N, k, _ptr(ws), _stream())
+    return f0, ws
+
+
+KNN_PM_PREPARED = 256
+
+
+def knn_prepared(ws, B, N, k, impl=None):
+    """kNN graph from the operands lpdnet_front left in ws (64 channels)."""
+    if impl is None:
+        impl = KNN_IMPL
+    idx = torch.empty((B, N, k), dtype=torch.int32, device=ws.device)
+    lib = _lib.load()
+    _call(f"knn[C=64,k={k}]", lib.lpd_knn_pm, None, 64, B, 64, N, k, _ptr(idx), _ptr(ws), impl | KNN_PM_PREPARED, _stream())
+    return idx
+
+
 def knn_pm(x_pm, B, N, k, impl=None):
     """kNN on point-major rows x_pm [B*N, C] (C <= 64, k <= 32): same indices as knn() on the transposed tensor, without
     the transpose + pack round trip."""

@@ -539,6 +539,35 @@ def test_gemm_weight_fragment_path(cuda, M, N, K, bk):
     assert any(k.startswith("gemmx3w") for k in prof), list(prof)
 
 
+@pytest.mark.parametrize("B,N,k,act", [(3, 1024, 20, 2), (2, 4096, 20, 1), (1, 5120, 20, 2), (2, 256, 64, 0)])
+def test_lpdnet_front_fused(cuda, B, N, k, act):
+    """lpd_lpdnet_front (conv1 -> conv2 + the kNN operands of their output in one launch) against the separate exact-fp32 layers:
+    F0 to fp32 rounding (the summation order of conv2 differs), and the graph lpd_knn_pm builds from the prepared operands is
+    EXACTLY the graph of the fused kernel's own F0 (prepared and unprepared entries agree bit for bit)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5 + N)
+    xyz = (torch.rand(B * N, 3, generator=g) * 2 - 1).to(cuda)
+    W1 = torch.randn(64, 3, generator=g).to(cuda)
+    W2 = (torch.randn(64, 64, generator=g) / 8).to(cuda)
+    s1, b1, s2, b2 = (torch.randn(64, generator=g).to(cuda) for _ in range(4))
+    f0, ws = ops.lpdnet_front(xyz, W1, s1, b1, W2, s2, b2, B, N, k, act=act, slope=0.2)
+    with ops.exact_gemm():
+        f1 = ops.linear(xyz, W1, scale=s1, shift=b1, act=act, slope=0.2)
+        ref = ops.linear(f1, W2, scale=s2, shift=b2, act=act, slope=0.2)
+    want = xyz.double() @ W1.double().t() * s1.double() + b1.double()
+    want = want if act == 0 else torch.where(want > 0, want, want * (0.0 if act == 1 else 0.2))
+    want = want @ W2.double().t() * s2.double() + b2.double()
+    want = want if act == 0 else torch.where(want > 0, want, want * (0.0 if act == 1 else 0.2))
+    assert _rel(f0, want) < 2e-6 and _rel(ref, want) < 2e-6
+    idx_prepared = ops.knn_prepared(ws, B, N, k)
+    idx_plain = ops.knn_pm(f0, B, N, k)
+    assert torch.equal(idx_prepared, idx_plain)
+    oidx, _ = orc.knn_np(f0.view(B, N, 64).cpu().numpy(), k)
+    rows_ok = (idx_prepared.cpu().numpy() == oidx).all(-1)
+    ties = orc.knn_tie_rows(f0.view(B, N, 64).cpu().numpy(), k)
+    assert rows_ok[~ties].all()
+
+
 @pytest.mark.parametrize("K,N,act", [(128, 512, 2), (64, 128, 1), (128, 160, 0)])
 def test_gemm_x3t_panels(cuda, K, N, act):
     """lpd_gemm_x3t (short reduction, cloud panels in and out, computed transposed: the SN1 projection): fp32-grade against a
