@@ -59,10 +59,13 @@ long long lpd_knn_workspace_floats(int B, int C, int N, int k);
 /* The same on point-major rows x_pm [B*N][ld] (the pipeline's activation layout; C <= 64, k <= 64): no transposes. */
 int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k, int32_t* idx, float* ws, int impl, void* stream);
 /* impl | LPD_KNN_PM_PREPARED: the operands of the 64-channel cloud are in ws already (lpd_lpdnet_front wrote them); x_pm may be
- * NULL.  lpd_knn_pm_layout: where lpd_knn_pm keeps them -- squared norms xx [B*N], packed operand image xp [B*N][2][32], and the
- * bf16 image xb of the low-precision bound pass (NULL when that pass will not run on these sizes). */
+ * NULL.  lpd_knn_pm_layout: where lpd_knn_pm keeps them -- squared norms xx [B*N], packed operand image xp [B*N][2][32], the
+ * bf16 image xb of the low-precision bound pass (NULL when that pass will not run on these sizes) and the statistics of the
+ * 32-point tiles of the best-first search (centroids [B*nt][2 cp] in packed operand order, then |c|^2, radius and max |x|^2,
+ * [B*nt] each; nt = ceil(N / 32), cp = 2 for C <= 4 else 32; NULL when the best-first search will not run).  "Prepared" means
+ * all of these. */
 #define LPD_KNN_PM_PREPARED 256
-int lpd_knn_pm_layout(int B, int C, int N, int k, float* ws, float** xx, float** xp, void** xb);
+int lpd_knn_pm_layout(int B, int C, int N, int k, float* ws, float** xx, float** xp, void** xb, float** tiles);
 
 /*
  * The layers in front of the feature-space kNN of LPD-Net in one launch (util/lpdnet_model.py:231-232, no T-Nets):

@@ -28,6 +28,7 @@ struct FrontArgs {
     float* xx;         // [M] or null: no kNN operands
     float* xp;         // [M][2][32]
     __bf16* xb;        // fragment-major bf16 image or null
+    float* tiles;      // tile statistics of the best-first kNN ([B*nt][64] centroids, then |c|^2, radius, max |x|^2: [B*nt] each) or null
     long long M;
     int N, nt;
 };
@@ -168,6 +169,45 @@ __global__ __launch_bounds__(256) void lpdnet_front_kernel(FrontArgs g)
             __bf16* f4 = g.xb + ((((size_t)b * g.nt + (pt >> 5)) * 5 + 4) * 64 + (pt & 31) + 32 * j) * 8;
             *reinterpret_cast<fr_bf16x8*>(f4) = e;
         }
+        if (j == 0) xs[p] = total;
+    }
+    if (!g.tiles) return;
+    __syncthreads();
+
+    // ---- tile statistics of the best-first kNN (knn7_tile_stats_kernel, same arithmetic): wave w = tile w of the block ----
+    {
+        const long long nbt = (g.M / g.N) * g.nt;                   // tiles in all clouds
+        const long long t = (m0 >> 5) + wave;                       // N % 128 == 0: tile index over all clouds = point / 32
+        const int pc = (lane & 31) * 2 + (lane >> 5);               // packed column `lane` is channel 2 s + h
+        const float* tile = Fs + wave * 32 * FR_LDF;
+        float sum = 0.f;
+        for (int i = 0; i < 32; ++i) sum += tile[i * FR_LDF + pc];
+        const float cm = sum / 32.0f;
+        g.tiles[t * 64 + lane] = cm;
+        float* cen = Bs + wave * 64;                                // (the W2 image is not needed any more: every wave passed the
+        cen[lane] = cm;                                             //  barrier behind the MFMAs) broadcast reads instead of 64 shuffles
+        float d2 = 0.f, nx = 0.f;
+        const int pr = lane & 31;                                   // both half-waves walk the same 32 points (max is idempotent)
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) {
+            const float d = tile[pr * FR_LDF + (c & 31) * 2 + (c >> 5)] - cen[c];
+            d2 = fmaf(d, d, d2);
+        }
+        nx = xs[wave * 32 + pr];
+        const bool bad = __any(!(fabsf(nx) <= 3.0e38f));
+        float cn = fmaf(cm, cm, 0.f);
+#pragma unroll
+        for (int mm = 32; mm >= 1; mm >>= 1) {
+            d2 = fmaxf(d2, __shfl_xor(d2, mm, 64));
+            nx = fmaxf(nx, __shfl_xor(nx, mm, 64));
+            cn += __shfl_xor(cn, mm, 64);
+        }
+        if (lane == 0) {
+            float* cnorm = g.tiles + nbt * 64;
+            cnorm[t] = cn;
+            cnorm[nbt + t] = sqrtf(d2) * 1.0001f + 1e-30f;          // radius
+            cnorm[2 * nbt + t] = bad ? INFINITY : nx;              // max |x|^2
+        }
     }
 }
 
@@ -182,11 +222,11 @@ extern "C" int lpd_lpdnet_front(const float* xyz, int ldx, const float* W1, cons
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_lpdnet_front: act=%d unsupported (none/ReLU/LeakyReLU)", act);
     LPD_CHECK_ARG(act != 2 || (slope >= 0.0f && slope <= 1.0f), "lpd_lpdnet_front: LeakyReLU slope %g outside [0, 1]", (double)slope);
     LPD_CHECK_ARG((((uintptr_t)W2 | (uintptr_t)F0) & 15) == 0, "lpd_lpdnet_front: W2 and F0 must be 16-byte aligned");
-    FrontArgs g{xyz, ldx, W1, s1, b1, W2, s2, b2, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), F0, nullptr, nullptr, nullptr,
+    FrontArgs g{xyz, ldx, W1, s1, b1, W2, s2, b2, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), F0, nullptr, nullptr, nullptr, nullptr,
                 (long long)B * N, N, (N + 31) / 32};
     if (knn_ws) {
         void* xb = nullptr;
-        const int rc = lpd_knn_pm_layout(B, 64, N, k, knn_ws, &g.xx, &g.xp, &xb);
+        const int rc = lpd_knn_pm_layout(B, 64, N, k, knn_ws, &g.xx, &g.xp, &xb, &g.tiles);
         if (rc != LPD_OK) return rc;
         g.xb = reinterpret_cast<__bf16*>(xb);
     }

@@ -1643,7 +1643,8 @@ inline __bf16* knn7_xb_of(const float* xx, int B, int N)      // 64 channels (CP
 }
 
 template <int CP, int KMAX, bool ONFLY>
-int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg = 0, bool xb_ready = false)
+int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg = 0, bool xb_ready = false,
+                bool stats_ready = false)
 {
     using L = Knn7Cfg<CP, KMAX, ONFLY>;
     static_assert(L::WAVE >= L::MERGE, "merge region must fit the wave's LDS region");
@@ -1654,7 +1655,8 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
     float* rad = cnorm + (size_t)B * nt;
     float* txmax = rad + (size_t)B * nt;
     if (x) hipLaunchKernelGGL(knn_pack_kernel<CP>, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xp, C, N);
-    hipLaunchKernelGGL(knn7_tile_stats_kernel<CP>, dim3(nt, B), dim3(64), 0, stream, (const float*)xp, xx, cenp, cnorm, rad, txmax, N, nt);
+    if (!stats_ready)
+        hipLaunchKernelGGL(knn7_tile_stats_kernel<CP>, dim3(nt, B), dim3(64), 0, stream, (const float*)xp, xx, cenp, cnorm, rad, txmax, N, nt);
     LPD_CHECK_LAUNCH("lpd_knn(tile pre-pass)");
     constexpr int WAVES = 1;
     const int bpc = (N + WAVES * 32 - 1) / (WAVES * 32);
@@ -1694,12 +1696,14 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
 // larger clouds and neighbourhoods (BASELINE configs[4]: N = 16384, k = 64)
 constexpr int KNN7_MAXN = 65536;
 inline bool knn7_applies(int C, int N, int k) { return C <= 64 && k <= 64 && N <= KNN7_MAXN; }
-inline int knn7_dispatch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg, bool xb_ready = false)
+inline int knn7_dispatch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg, bool xb_ready = false,
+                         bool stats_ready = false)
 {
     const bool small = k <= 20 && N <= KNN7_MAXT * 32;
     if (C <= 4) return k <= 20 ? knn7_launch<2, 20, true>(x, xx, idx, B, C, N, k, stream, dbg) : knn7_launch<2, 64, true>(x, xx, idx, B, C, N, k, stream, dbg);
-    if (small) return knn7_launch<32, 20, false>(x, xx, idx, B, C, N, k, stream, dbg, xb_ready);
-    return k <= 20 ? knn7_launch<32, 20, true>(x, xx, idx, B, C, N, k, stream, dbg) : knn7_launch<32, 64, true>(x, xx, idx, B, C, N, k, stream, dbg);
+    if (small) return knn7_launch<32, 20, false>(x, xx, idx, B, C, N, k, stream, dbg, xb_ready, stats_ready);
+    return k <= 20 ? knn7_launch<32, 20, true>(x, xx, idx, B, C, N, k, stream, dbg, false, stats_ready)
+                   : knn7_launch<32, 64, true>(x, xx, idx, B, C, N, k, stream, dbg, false, stats_ready);
 }
 
 template <int CP>
@@ -1807,12 +1811,14 @@ inline bool knn_pm_wants_xb(int C, int N, int k, int impl)
 }
 }  // namespace
 
-extern "C" int lpd_knn_pm_layout(int B, int C, int N, int k, float* ws, float** xx, float** xp, void** xb)
+extern "C" int lpd_knn_pm_layout(int B, int C, int N, int k, float* ws, float** xx, float** xp, void** xb, float** tiles)
 {
-    LPD_CHECK_ARG(ws && xx && xp && xb && B > 0 && N > 0 && C > 0 && C <= 64, "lpd_knn_pm_layout: bad arguments");
+    LPD_CHECK_ARG(ws && xx && xp && xb && tiles && B > 0 && N > 0 && C > 0 && C <= 64, "lpd_knn_pm_layout: bad arguments");
+    const int cp = C <= 4 ? 2 : 32;
     *xx = ws;
     *xp = ws + (size_t)B * N;
     *xb = (C == 64 && knn_pm_wants_xb(C, N, k, 0)) ? (void*)knn7_xb_of(ws, B, N) : nullptr;
+    *tiles = (KNN7_DEFAULT && knn7_applies(C, N, k)) ? *xp + (size_t)B * N * 2 * cp : nullptr;
     return LPD_OK;
 }
 
@@ -1841,7 +1847,7 @@ extern "C" int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k,
                            xb_ready ? knn7_xb_of(ws, B, N) : (__bf16*)nullptr, M, N, (N + 31) / 32);
     } else hipLaunchKernelGGL(knn_prep_pm_kernel<32>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, x_pm, ld, ws, xp, C, M);
     LPD_CHECK_LAUNCH("lpd_knn_pm(prep)");
-    if (best_first) return knn7_dispatch(nullptr, ws, idx, B, C, N, k, stream, impl == 5, xb_ready);
+    if (best_first) return knn7_dispatch(nullptr, ws, idx, B, C, N, k, stream, impl == 5, xb_ready, prepped);
     if (C <= 4) return knn3_dispatch_k<2>(nullptr, ws, idx, B, C, N, k, stream);
     return knn3_dispatch_k<32>(nullptr, ws, idx, B, C, N, k, stream);
 }

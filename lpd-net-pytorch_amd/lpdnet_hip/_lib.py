@@ -41,7 +41,7 @@ SIGNATURES = {
     "lpd_f64_to_f32": [_c_p, _c_p, _c_ll, _c_p],
     "lpd_best_pos_bwd": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p],
     "lpd_hard_negatives": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p],
-    "lpd_knn_pm_layout": [_c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
+    "lpd_knn_pm_layout": [_c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_lpdnet_front": [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p],
     "lpd_knn_pm": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_int, _c_p],
     "lpd_knn_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
