@@ -415,10 +415,10 @@ def pointnet_features_eval(net, x):
 # NetVLAD head
 # ------------------------------------------------------------------------------------------------
 def _head_splits(K):
-    """split-K factor for the [B, K] x [K, out] hidden projection: one 256-deep slice of K per workgroup, up to 256 of them
+    """split-K factor for the [B, K] x [K, out] hidden projection: one 128-deep slice of K per workgroup, up to 512 of them
     (lpd_gemm's few-row split-K kernel streams one weight column per thread)."""
     s = 1
-    while s < 256 and K // (s * 2) >= 256:
+    while s < 512 and K // (s * 2) >= 128:
         s *= 2
     return s
 
