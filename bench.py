@@ -407,6 +407,7 @@ def main():
                                    f"N={args.points}, k={args.k}, eval_batch_size={args.batch} clouds/step/GPU",
                        "clouds_per_step_per_gpu": args.batch, "num_points": args.points,
                        "parallelism": f"shard-by-cloud x{world} (one process per GPU, no data-path collective)",
+                       "hip_streams": engine.side_stream_report(dev),
                        "arithmetic": ("fp32 tensors; kNN distances and every layer in front of the feature-space kNN exact fp32; large dense "
                                       "products as 3-product split-bf16 MFMA with fp32 accumulation (DESIGN.md 3.2)"
                                       if ops.GEMM_BF16X3 else "fp32 tensors, every product on the f32-input MFMA / fp32 FMA")},

@@ -166,7 +166,54 @@ def _knn_rows(rows, B, N, C, k):
 
 # cloud-panel [B, C/8, N, 8] buffers for x1|x2|x3 and the SN1 projections (LPD_PANELS=0: row-major everywhere)
 PANEL_LAYOUT = __import__("os").environ.get("LPD_PANELS", "1") != "0"
-SIDE_STREAM = __import__("os").environ.get("LPD_SIDE_STREAM", "1") != "0"   # xyz kNN on a second HIP stream (eval path)
+# xyz kNN (and the DG1 stage's projection and K-agg) on a second HIP stream in the eval path: True / False, or "auto" (default):
+# decided per device from timed forwards.  On most MI355X boxes of the pool the second stream takes 3 % off the step; on some it
+# ADDS 10-20 % and makes the step time erratic (2.40 / 2.67 ms against 2.23 on one stream, same binaries, same inputs), so
+# neither setting is right everywhere.  auto: the first eval forward on a device runs with the second stream (warm-up), the next
+# four alternate the two modes between device synchronisations, and the faster sum wins for the rest of the process.
+_side_env = __import__("os").environ.get("LPD_SIDE_STREAM", "auto")
+SIDE_STREAM = "auto" if _side_env == "auto" else (_side_env != "0")
+_SIDE_AUTO = {}      # device key -> {"calls": int, "t": [two-stream ms, one-stream ms], "choice": bool or None}
+
+
+def _side_mode(device):
+    """(use the second stream for this forward?, timing slot or None).  Explicit settings pass through."""
+    if SIDE_STREAM != "auto":
+        return bool(SIDE_STREAM), None
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    with _SIDE_LOCK:
+        st = _SIDE_AUTO.setdefault(key, {"calls": 0, "t": [0.0, 0.0], "choice": None})
+        if st["choice"] is not None:
+            return st["choice"], None
+        n = st["calls"]
+        st["calls"] = n + 1
+    if n == 0:
+        return True, None                    # warm-up: allocator, fragment caches, the stream itself
+    slot = (n - 1) & 1                       # calls 1..4: two, one, two, one
+    return slot == 0, (key, slot, n)
+
+
+def side_stream_report(device):
+    """what the eval forward does on this device: 'two streams' / 'one stream', with the calibration times when auto decided"""
+    if SIDE_STREAM != "auto":
+        return "two streams (set)" if SIDE_STREAM else "one stream (set)"
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _SIDE_AUTO.get(key)
+    if not st or st["choice"] is None:
+        return "auto (not calibrated yet)"
+    return "%s (auto: trunk %.2f ms with the second stream, %.2f ms without, two forwards each)" % (
+        "two streams" if st["choice"] else "one stream", st["t"][0] / 2, st["t"][1] / 2)
+
+
+def _side_timed(token, t_ms):
+    key, slot, n = token
+    with _SIDE_LOCK:
+        st = _SIDE_AUTO[key]
+        st["t"][slot] += t_ms
+        if n >= 4 and st["choice"] is None:
+            # where the second stream helps it helps by ~3 % of the step, where it hurts by 10-20 %: two timed forwards each
+            # cannot resolve the former, so the second stream stays on unless it is clearly (> 5 %) slower
+            st["choice"] = st["t"][0] <= 1.05 * st["t"][1]
 FUSED_FRONT = __import__("os").environ.get("LPD_FUSED_FRONT", "1") != "0"   # conv1 + conv2 + kNN operands in one launch (no T-Nets)
 _SIDE = {}
 _SIDE_LOCK = __import__("threading").Lock()      # nn.DataParallel calls forward from one host thread per device
@@ -224,6 +271,22 @@ def lpdnet_features_eval(net, x, reorder=True):
     mfea = getattr(net, "use_mFea", False)
     x = _check_input(x, 8) if mfea else reorder_points(_check_input(x), reorder)
     B, N = x.shape[0], x.shape[2]
+    act = ops.ACT_RELU if net.use_relu else ops.ACT_LEAKY
+    side_ok = PANEL_LAYOUT and N % 128 == 0 and _resident_shape(net.k, N, B * N, act)
+    use_side, timing = _side_mode(x.device) if side_ok else (False, None)
+    if timing is not None:                   # calibration forward: timed between device synchronisations
+        torch.cuda.synchronize(x.device)
+        t_cal = __import__("time").perf_counter()
+        try:
+            return _lpdnet_features_eval_body(net, x, mfea, use_side)
+        finally:
+            torch.cuda.synchronize(x.device)
+            _side_timed(timing, (__import__("time").perf_counter() - t_cal) * 1e3)
+    return _lpdnet_features_eval_body(net, x, mfea, use_side and side_ok)
+
+
+def _lpdnet_features_eval_body(net, x, mfea, use_side):
+    B, N = x.shape[0], x.shape[2]
     M = B * N
     k = net.k
     act, slope = (ops.ACT_RELU, 0.0) if net.use_relu else (ops.ACT_LEAKY, LEAKY_SLOPE)
@@ -234,7 +297,7 @@ def lpdnet_features_eval(net, x, reorder=True):
         xyz = x.view(M, 3)
         p = xyz
     side_job = None
-    if SIDE_STREAM and PANEL_LAYOUT and N % 128 == 0 and _resident_shape(k, N, M, act):
+    if use_side:
         # The static graph in Cartesian space depends on the input alone: its kNN (wave-slot-bound, two waves per SIMD) runs
         # on a second HIP stream next to the per-point layers and the feature-space kNN and is joined in front of the SN1 K-agg.
         main, side = torch.cuda.current_stream(), _side_stream(x.device)
