@@ -38,7 +38,16 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """torch's current stream on the current device as a raw pointer.  torch.cuda.current_stream() builds a Stream object
+    through three layers of Python (10 us a call, a quarter of the host time of an eval forward: tools/host_profile.py); the raw
+    accessor is what torch's own code generators use."""
+    if _raw_stream is not None and _cur_device is not None:
+        return ctypes.c_void_p(_raw_stream(_cur_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
