@@ -987,6 +987,7 @@ __device__ __forceinline__ void knn_merge_halves_bitonic(float (&v)[64], int (&i
 // is visited.  Image xb: per (point, k-half) 32 channels in packed operand order + 8 extras (hi, lo, 0 ...; zero in the
 // second half) = the lane's five 16-byte MFMA operands, stored fragment-major ([tile][k-step][lane][8]).
 constexpr int KNN7_XB = 80;   // bf16 per point: 2 halves x 40
+constexpr int KNN7_PRE_MAXT = 512;   // the low-precision pass runs for clouds of up to 512 tiles (N <= 16384: 16.8 MB of bounds per cloud)
 typedef __bf16 knn_bf16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void knn7_bf16_kernel(const float* __restrict__ xp, const float* __restrict__ xx, __bf16* __restrict__ xb,
@@ -1034,7 +1035,6 @@ __global__ __launch_bounds__(256, 2) void knn7_bound_kernel(const __bf16* __rest
     const int h = lane >> 5, col = lane & 31;
     const int b = blockIdx.y;
     const int W0 = (blockIdx.x * 4 + wave) * QT;
-    if (W0 >= nt) return;
     const __bf16* xbb = xb + ((size_t)b * nt * 5 * 64 + lane) * 8;
     const float* txb = txmax + (size_t)b * nt;
     float smax = 0.f;
@@ -1069,10 +1069,12 @@ __global__ __launch_bounds__(256, 2) void knn7_bound_kernel(const __bf16* __rest
 #pragma unroll
         for (int s = 0; s < 5; ++s) c[s] = *reinterpret_cast<const knn_bf16x8*>(xbb + ((size_t)T * 5 + s) * 512);
     };
-    const float tx_lo = txb[min(lane, nt - 1)], tx_hi = txb[min(64 + lane, nt - 1)];      // nt <= 128
+    __shared__ float stx[KNN7_PRE_MAXT];                 // xx_max of every tile (a global load per tile would be a dependent round trip)
+    for (int t = tid; t < nt; t += 256) stx[t] = txb[t];
+    __syncthreads();
+    if (W0 >= nt) return;
     auto one_tile = [&](int T, const knn_bf16x8 (&c)[5]) {
-        // xx_max of the tile out of the lanes' registers (a load here would be a dependent round trip per tile)
-        const float tx = __builtin_amdgcn_readlane(T < 64 ? tx_lo : tx_hi, T & 63);
+        const float tx = stx[T];
         const float ncT = sqrtf(tx) * 1.0001f;
         const float cT = 2.0f * (tx * 7.62939453125e-6f + E0);
 #pragma unroll
@@ -1372,6 +1374,11 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
                 const float lb = fmaxf(dq - radb[T], 0.0f);
                 ub = -(lb * lb) * 0.99999f + E0;                                  // upper bound of every computed pd in tile T
             } else if constexpr (ONFLY) {   // this half-lane's CP channels, the other half by shuffle
+                if (ubq) {      // ... unless the low-precision pass tabulated the bounds (too large for LDS here: read where tested)
+                    ub = __uint_as_float((uint32_t)ubq[(((size_t)b * nt + W) * nt + T) * 32 + col] << 16);
+                    if (__any(ub >= thrv)) return T;
+                    continue;
+                }
                 const float* ct = cenb + (size_t)T * (2 * CP) + h * CP;
                 float part = 0.0f;
 #pragma unroll
@@ -1622,7 +1629,7 @@ inline size_t knn7_extra_floats(int B, int N, int CP)
 {
     const size_t nt = (size_t)(N + 31) / 32;
     size_t n = (size_t)B * nt * (2 * CP + 3 + 2) + 16;   // + predicted tile counts and launch order (int32 each)
-    if (CP == 32 && N <= KNN7_MAXT * 32)                 // low-precision pass: bf16 image of the operands + the bound table
+    if (CP == 32 && nt <= (size_t)KNN7_PRE_MAXT)         // low-precision pass: bf16 image of the operands + the bound table
         n += (size_t)B * nt * 32 * (KNN7_XB / 2) + (size_t)B * nt * nt * 16 + 16;
     return n;
 }
@@ -1665,8 +1672,8 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
     int32_t* order = pred + (size_t)B * nt;
     const int nitems = bpc * B;
     uint16_t* ubq = nullptr;
-    if constexpr (CP == 32 && !ONFLY) {
-        if (knn7_tight()) {
+    if constexpr (CP == 32) {
+        if (knn7_tight() && nt <= KNN7_PRE_MAXT) {
             __bf16* xb = knn7_xb_of(xx, B, N);
             ubq = reinterpret_cast<uint16_t*>(xb + (size_t)B * nt * 32 * KNN7_XB);
             if (!xb_ready) hipLaunchKernelGGL(knn7_bf16_kernel, dim3((nt * 64 + 255) / 256, B), dim3(256), 0, stream, (const float*)xp, xx, xb, N, nt);
@@ -1702,8 +1709,8 @@ inline int knn7_dispatch(const float* x, const float* xx, int32_t* idx, int B, i
     const bool small = k <= 20 && N <= KNN7_MAXT * 32;
     if (C <= 4) return k <= 20 ? knn7_launch<2, 20, true>(x, xx, idx, B, C, N, k, stream, dbg) : knn7_launch<2, 64, true>(x, xx, idx, B, C, N, k, stream, dbg);
     if (small) return knn7_launch<32, 20, false>(x, xx, idx, B, C, N, k, stream, dbg, xb_ready, stats_ready);
-    return k <= 20 ? knn7_launch<32, 20, true>(x, xx, idx, B, C, N, k, stream, dbg, false, stats_ready)
-                   : knn7_launch<32, 64, true>(x, xx, idx, B, C, N, k, stream, dbg, false, stats_ready);
+    return k <= 20 ? knn7_launch<32, 20, true>(x, xx, idx, B, C, N, k, stream, dbg, xb_ready, stats_ready)
+                   : knn7_launch<32, 64, true>(x, xx, idx, B, C, N, k, stream, dbg, xb_ready, stats_ready);
 }
 
 template <int CP>
@@ -1807,7 +1814,7 @@ namespace {
 inline bool knn_pm_wants_xb(int C, int N, int k, int impl)
 {
     const bool best_first = ((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && knn7_applies(C, N, k);
-    return best_first && C == 64 && knn7_tight() && k <= 20 && N <= KNN7_MAXT * 32 && N % 32 == 0;
+    return best_first && C == 64 && knn7_tight() && N <= KNN7_PRE_MAXT * 32 && N % 32 == 0;
 }
 }  // namespace
 
