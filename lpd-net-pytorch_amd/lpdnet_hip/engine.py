@@ -199,8 +199,10 @@ def side_stream_report(device):
         return "two streams (set)" if SIDE_STREAM else "one stream (set)"
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     st = _SIDE_AUTO.get(key)
-    if not st or st["choice"] is None:
-        return "auto (not calibrated yet)"
+    if not st:
+        return "one stream (the second stream serves the cloud-resident shapes only: k = 20, N <= 4096, N % 128 == 0)"
+    if st["choice"] is None:
+        return "auto (calibrating: %d of 5 forwards seen)" % st["calls"]
     return "%s (auto: trunk %.2f ms with the second stream, %.2f ms without, two forwards each)" % (
         "two streams" if st["choice"] else "one stream", st["t"][0] / 2, st["t"][1] / 2)
 
