@@ -185,6 +185,8 @@ def _side_mode(device):
         st = _SIDE_AUTO.setdefault(key, {"calls": 0, "t": [0.0, 0.0], "choice": None})
         if st["choice"] is not None:
             return st["choice"], None
+        if torch.cuda.is_current_stream_capturing():      # a graph capture cannot be timed (no synchronisation inside): one stream
+            return False, None
         n = st["calls"]
         st["calls"] = n + 1
     if n == 0:
