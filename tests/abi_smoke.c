@@ -7,7 +7,8 @@
  * (gcc, links liblpd_hip.so + libamdhip64), run on the GPU box by tests/test_abi_gpu.py.
  *
  *   abi_smoke            -> runs lpd_version, lpd_knn_workspace_floats, lpd_gemm (plain and
- *                           cloud-panel A/C), lpd_gemm_bf16x3, lpd_knn on the device, checks the
+ *                           cloud-panel A/C), lpd_gemm_bf16x3, lpd_knn, lpd_lpdnet_front +
+ *                           lpd_knn_pm(PREPARED) on the device, checks the
  *                           results against host loops, prints "abi_smoke OK", exit 0
  *   abi_smoke --symbols  -> no GPU call: only lpd_version / workspace sizes (CPU-side check)
  */
@@ -177,6 +178,62 @@ int main(int argc, char** argv)
     }
     printf("lpd_knn C=3 N=%d k=%d: %d rows checked, %d wrong\n", KN, KK, checked, bad);
     if (bad || checked < KN / 2) return 7;
+
+    /* ---- lpd_lpdnet_front + lpd_knn_pm(LPD_KNN_PM_PREPARED): conv1 -> conv2 on 256 points against host loops, and the graph
+     *      built from the operands the front kernel left in the workspace against lpd_knn_pm on the same features ---- */
+    {
+        enum { FN = 256, FK = 8 };
+        float *hxyz = malloc(sizeof(float) * FN * 3), *hW1 = malloc(sizeof(float) * 64 * 3), *hW2 = malloc(sizeof(float) * 64 * 64);
+        float hs[4][64], *hF = malloc(sizeof(float) * FN * 64);
+        double* rF = malloc(sizeof(double) * FN * 64);
+        for (int i = 0; i < FN * 3; ++i) hxyz[i] = frand(&seed);
+        for (int i = 0; i < 64 * 3; ++i) hW1[i] = frand(&seed);
+        for (int i = 0; i < 64 * 64; ++i) hW2[i] = 0.125f * frand(&seed);
+        for (int v = 0; v < 4; ++v)
+            for (int i = 0; i < 64; ++i) hs[v][i] = (v & 1) ? 0.1f * frand(&seed) : 1.0f + 0.5f * frand(&seed);
+        for (int m = 0; m < FN; ++m) {
+            double f1[64];
+            for (int c = 0; c < 64; ++c) {
+                double v = 0;
+                for (int k = 0; k < 3; ++k) v += (double)hxyz[m * 3 + k] * hW1[c * 3 + k];
+                v = v * hs[0][c] + hs[1][c];
+                f1[c] = v > 0 ? v : 0.2 * v;
+            }
+            for (int n = 0; n < 64; ++n) {
+                double v = 0;
+                for (int c = 0; c < 64; ++c) v += f1[c] * hW2[n * 64 + c];
+                v = v * hs[2][n] + hs[3][n];
+                rF[m * 64 + n] = v > 0 ? v : 0.2 * v;
+            }
+        }
+        float *dxyz, *dW1, *dW2, *dsb, *dF, *dkws, *dkws2;
+        int32_t *di1, *di2, *hi1 = malloc(sizeof(int32_t) * FN * FK), *hi2 = malloc(sizeof(int32_t) * FN * FK);
+        long long kws = lpd_knn_workspace_floats(1, 64, FN, FK);
+        CHECK_HIP(hipMalloc((void**)&dxyz, sizeof(float) * FN * 3));
+        CHECK_HIP(hipMalloc((void**)&dW1, sizeof(float) * 64 * 3));
+        CHECK_HIP(hipMalloc((void**)&dW2, sizeof(float) * 64 * 64));
+        CHECK_HIP(hipMalloc((void**)&dsb, sizeof(float) * 4 * 64));
+        CHECK_HIP(hipMalloc((void**)&dF, sizeof(float) * FN * 64));
+        CHECK_HIP(hipMalloc((void**)&dkws, sizeof(float) * kws));
+        CHECK_HIP(hipMalloc((void**)&dkws2, sizeof(float) * kws));
+        CHECK_HIP(hipMalloc((void**)&di1, sizeof(int32_t) * FN * FK));
+        CHECK_HIP(hipMalloc((void**)&di2, sizeof(int32_t) * FN * FK));
+        CHECK_HIP(hipMemcpy(dxyz, hxyz, sizeof(float) * FN * 3, hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(dW1, hW1, sizeof(float) * 64 * 3, hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(dW2, hW2, sizeof(float) * 64 * 64, hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(dsb, hs, sizeof(float) * 4 * 64, hipMemcpyHostToDevice));
+        CHECK_LPD(lpd_lpdnet_front(dxyz, 3, dW1, dsb, dsb + 64, dW2, dsb + 128, dsb + 192, LPD_ACT_LEAKY, 0.2f, dF, 1, FN, FK, dkws, st));
+        CHECK_LPD(lpd_knn_pm(NULL, 64, 1, 64, FN, FK, di1, dkws, LPD_KNN_PM_PREPARED, st));
+        CHECK_LPD(lpd_knn_pm(dF, 64, 1, 64, FN, FK, di2, dkws2, 0, st));
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(hF, dF, sizeof(float) * FN * 64, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(hi1, di1, sizeof(int32_t) * FN * FK, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(hi2, di2, sizeof(int32_t) * FN * FK, hipMemcpyDeviceToHost));
+        double ef = max_rel(hF, rF, FN * 64);
+        int diff = memcmp(hi1, hi2, sizeof(int32_t) * FN * FK) != 0;
+        printf("lpd_lpdnet_front rel err %.2e; prepared kNN graph %s lpd_knn_pm's\n", ef, diff ? "DIFFERS from" : "==");
+        if (!(ef < 5e-6) || diff) return 9;
+    }
 
     /* ---- error convention: a bad argument returns LPD_ERR_ARG with a message, no exception, no abort ---- */
     int rc = lpd_knn(dx, 1, 3, KN, KN + 1, didx, dws, 0, st);
