@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-train", action="store_true", help="skip the secondary quadruplet train-step measurement")
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--no-train-bf16", action="store_true", help="skip the bf16-storage train-step measurement (configs[2] as stated)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary eval records (configs[1] at 128 clouds/step, configs[4]: N=16384, k=64, 64 clouds/step)")
     return ap.parse_args()
 
 
@@ -103,17 +105,15 @@ def cpu_baseline(model, points, seconds_target=20.0):
     # ---- C restatement, one cloud per core ----
     native = orc.build_c_oracle_native(os.path.join(tempfile.gettempdir(), f"liblpd_oracle_native_{os.getpid()}.so"))
     lib = ctypes.CDLL(native)
-    nC = max(1, min(avail, 256))
+    nC = max(1, min(avail, 128))      # 128 clouds: one run takes ~7 s on the pool's 256-core hosts, so warm-up + 3 timed runs fit the budget
     xc = torch.rand((nC, 1, points, 3), generator=g) * 2 - 1
-    t0 = time.time()
     dc, used = orc.forward_lpdnet_c(sd, xc, k=model.emb_nn.k, threads=nC, lib=lib)      # warm-up (page faults, weights into cache)
-    first = time.time() - t0
     times = []
-    for _ in range(3 if first < seconds_target / 3 else 1):
+    for _ in range(3):                # always a median of 3
         t0 = time.time()
         orc.forward_lpdnet_c(sd, xc, k=model.emb_nn.k, threads=nC, lib=lib)
         times.append(time.time() - t0)
-    tc = sorted(times)[len(times) // 2]
+    tc = sorted(times)[1]
     # ---- torch-CPU oracle (cross-check and the reference descriptors for the parity figure) ----
     Bs = 4
     x = xc[:Bs].clone()
@@ -141,7 +141,55 @@ def cpu_baseline(model, points, seconds_target=20.0):
                       f"gcc -O3 -march=native, OpenMP: one cloud per thread, {used} threads of {avail} host cores), median of {len(times)} after a warm-up run",
             "torch_cpu_cross_check": {"value": round(Bs / t, 3), "unit": "descriptors/s", "cores": threads,
                                       "sample": f"torch-CPU oracle (ATen), {Bs} clouds, median of 3 at the fastest of the tried thread counts"},
-            "c_vs_torch_oracle_norm_rel": float(f"{agree:.3e}")}, x, ref
+            "c_vs_torch_oracle_norm_rel": float(f"{agree:.3e}")}, x, ref, threads
+
+
+def cpu_train_baseline(points, threads, seconds_target=25.0):
+    """the quadruplet train step (forward in train mode, lazy quadruplet loss, backward, Adam) of the
+    reference path on this box's host cores = the torch-CPU oracle (ATen + autograd, the reference's own formulation) at the
+    thread count the eval cross-check found fastest.  B = 6 clouds (bq=1, P=2, Ng=2; BASELINE.md's 0.175 step/s row), median of
+    3 after a warm-up step; then ONE step at bq=1, P=2, Ng=18 (B = 22, half of configs[2]'s batch) if the budget allows, so that
+    the per-cloud scaling is on record (B = 44 needs ~35 GB and ~45 s per step in this formulation)."""
+    from oracle import lpd_oracle as orc
+    torch.set_num_threads(threads)
+    sd0 = orc.synthetic_state("lpdnet", num_points=points)
+    names = [k for k, v in sd0.items() if v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var"))]
+
+    def run(bq, P, Ng, reps):
+        B = bq * (1 + P + Ng + 1)
+        g = torch.Generator().manual_seed(4242)
+        x = torch.rand((B, 1, points, 3), generator=g) * 2 - 1
+        sd = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd0.items()}
+        opt = torch.optim.Adam([sd[k] for k in names], lr=1e-5)
+        ts = []
+        for it in range(reps + 1):
+            t0 = time.time()
+            opt.zero_grad(set_to_none=True)
+            d = orc.pointnetvlad_forward(sd, x, featnet="lpdnet", train=True, new_stats={})
+            q, p, n, o = torch.split(d.view(bq, -1, 256), [1, P, Ng, 1], dim=1)
+            loss = orc.quadruplet_loss(q, p, n, o, 0.5, 0.2, use_min=True, lazy=True, ignore_zero_loss=False)
+            loss.backward()
+            opt.step()
+            if it:
+                ts.append(time.time() - t0)
+            elif reps > 1 and time.time() - t0 > seconds_target / 3:
+                reps = 1
+        return B, sorted(ts)[len(ts) // 2], len(ts)
+    t_all = time.time()
+    B, t6, n6 = run(1, 2, 2, 3)
+    rec = {"value": round(1.0 / t6, 4), "unit": "steps/s", "cores": threads, "kind": "port", "clouds_per_step": B,
+           "clouds_per_s": round(B / t6, 3),
+           "sample": f"torch-CPU oracle (ATen + autograd: the reference's formulation), quadruplet train step bq=1 P=2 Ng=2 -> {B} clouds "
+                     f"x {points} pts, forward + lazy quadruplet loss + backward + Adam, {threads} threads, median of {n6} after a warm-up step"}
+    try:
+        free_gb = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2**30
+    except (ValueError, OSError):
+        free_gb = 0.0
+    if time.time() - t_all < seconds_target * 0.6 and free_gb > 48 and 22.0 / B * t6 * 2 < seconds_target:
+        B2, t22, _ = run(1, 2, 18, 1)
+        rec["half_cfg2_batch"] = {"clouds_per_step": B2, "seconds_per_step": round(t22, 3), "clouds_per_s": round(B2 / t22, 3),
+                                  "sample": "one timed step after a warm-up step, bq=1 P=2 Ng=18"}
+    return rec
 
 
 def _time_steps(step, first, n, dist, dev):
@@ -240,6 +288,48 @@ def train_bench(dev, dist, world, rank, points, steps, warmup=2, storage="f32"):
             "dtype": storage, "losses": losses, "peak_hbm_gib": round(peak, 2), "exchange": comm}
 
 
+def secondary_eval(dev, points, k, batch, steps, warmup=2):
+    """One more eval-forward measurement on rank 0's GPU (world 1 only), reported INSIDE the JSON line next to the headline
+    workload: same model family, random-init weights, clouds resident in HBM; the K-agg launches of the SN1 stage are bracketed
+    by HIP events inside the timed region, like the headline's."""
+    from lpdnet_hip import ops
+    from util.PointNetVlad import PointNetVlad
+    torch.manual_seed(1234)
+    model = PointNetVlad(num_points=points, featnet="lpdnet", emb_dims=1024, output_dim=256)
+    model.emb_nn.k = k
+    model = model.to(dev).eval()
+    gen = torch.Generator().manual_seed(4321)
+    clouds = [(torch.rand((batch, 1, points, 3), generator=gen) * 2 - 1).to(dev) for _ in range(2)]
+    with torch.no_grad():
+        for i in range(warmup + 1):
+            model(clouds[i % 2])
+        torch.cuda.synchronize()
+        ops.PROFILE, ops.PROFILE_ONLY = {}, ("edge_gather_max",)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            model(clouds[i % 2])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    kern = kernel_table(ops.PROFILE)
+    ops.PROFILE, ops.PROFILE_ONLY = None, None
+    rec = {"metric": "global descriptors/sec", "value": round(batch * steps / el, 2), "unit": "descriptors/s",
+           "ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "warmup": warmup + 1,
+           "config": {"num_points": points, "k": k, "clouds_per_step": batch}}
+    key = next((k_ for k_ in kern if k_.startswith("edge_gather_max") and k_.endswith("[C=256]")), None)
+    if key is not None:
+        t_s = kern[key]["avg_us"] * 1e-6
+        pts = batch * points
+        alg = (KAGG_ROW_BYTES + 4 * k) * pts
+        alg_direct = (128 * 4 + 256 * 4 + 4 * k) * pts
+        rec["roofline"] = {"kernel": f"{ops.KAGG_KERNEL_NAMES.get(key.split('[')[0], key)}, SN1 stage, C=256, k={k}", "bound": "hbm",
+                           "achieved": round(alg / t_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(alg / t_s / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_us": kern[key]["avg_us"],
+                           "algorithmic_bytes_per_launch": alg, "frac_direct_form": round(alg_direct / t_s / 1e9 / HBM_PEAK_GBS, 4)}
+    del model, clouds
+    torch.cuda.empty_cache()
+    return rec
+
+
 def kernel_table(prof):
     kern = {}
     for name, evs in prof.items():
@@ -300,9 +390,13 @@ def main():
 
     # Settling phase, before the W warm-up steps of the contract: a box that has been idle runs its first ~second of kernels
     # below its steady clocks (first process on a fresh box: 3.0-3.2 ms per step for a whole 20-step region, 2.1 ms in the
-    # process that follows), and the eval forward times its first five calls to choose one or two HIP streams (engine._side_mode).
+    # process that follows), and engine.calibrate times the forward with and without the second HIP stream (interleaved, medians).
     t_settle = time.perf_counter()
     n_settle = 0
+    for _ in range(4):                                  # allocator, fragment caches, clocks
+        step(n_settle)
+        n_settle += 1
+    engine.calibrate(model, clouds[0])                  # one or two HIP streams on this device: measured here, never inside a forward
     while n_settle < 6 or time.perf_counter() - t_settle < args.settle_seconds:
         step(n_settle)
         n_settle += 1
@@ -338,14 +432,13 @@ def main():
     torch.cuda.synchronize()
     prof_all = ops.PROFILE
     prof_all.update({k_: v for k_, v in prof.items()})      # K-agg entries: the timed region's own measurements
-    side_was = engine.SIDE_STREAM
-    engine.SIDE_STREAM = False
+    engine._SIDE_FORCE.mode = False
     ops.PROFILE = {}
     for i in range(min(args.steps, 5) + 1):
         step(i)
     torch.cuda.synchronize()
     prof_serial = ops.PROFILE
-    engine.SIDE_STREAM = side_was
+    engine._SIDE_FORCE.mode = None
     ops.PROFILE = None
     per_rank = [round(args.batch * args.steps / my_elapsed, 1)]
     if dist is not None:
@@ -373,7 +466,7 @@ def main():
         alg = (KAGG_ROW_BYTES + 4 * args.k) * pts
         alg_direct = (128 * 4 + 256 * 4 + 4 * args.k) * pts      # SURVEY 8d direct form: x2 row in, indices, x3 row out
         ach = alg / t_s / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "kagg_pmc.json")
         if os.path.exists(pmc):          # PMC passes are kept per workload: {"runs": [{batch, points, k, bench_key, hbm_bytes_per_launch}]}
             try:
@@ -382,10 +475,12 @@ def main():
                     if (r.get("batch", 32), r.get("points", 4096), r.get("k", 20)) == (args.batch, args.points, args.k) \
                             and r.get("bench_key") == key:
                         traffic = r.get("hbm_bytes_per_launch")
+                        traffic_source = ("profiles/kagg_pmc.json (rocprofv3 --pmc passes of an EARLIER run of this command on the same "
+                                          "workload, FETCH_SIZE doubled per MI355X_MICROARCH.md; not measured in this run): " + str(r.get("source")))
             except Exception:
                 traffic = None
         roof = {"kernel": f"{kname}, SN1 stage, C=256, k={args.k}", "bound": "hbm", "achieved": round(ach, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_us": kern[key]["avg_us"],
                 "numerator": "split form: P row + Q row + out row + int32 indices per point (the rows this kernel reads and "
                              "writes once; P and Q exist because the SN1 convolution is split, DESIGN.md 3.3)",
@@ -398,6 +493,12 @@ def main():
             roof["stage"] = {"kernels": [pk, key], "us": round(t_stage * 1e6, 1),
                              "frac_direct_form": round(alg_direct / t_stage / 1e9 / HBM_PEAK_GBS, 4)}
 
+    secondary = None
+    if world == 1 and not args.no_secondary and (args.points, args.k, args.batch) == (4096, 20, 32):
+        # configs[1] "run both" batch sizes (evaluate.py:101-102 multiplies eval_batch_size by 1+P+Ng), and the
+        # stress configuration configs[4] with its K-agg roofline, so that neither is builder-run only
+        secondary = {"configs[1] at 128 clouds/step": secondary_eval(dev, 4096, 20, 128, 10),
+                     "configs[4] stress (N=16384, k=64, 64 clouds/step)": secondary_eval(dev, 16384, 64, 64, 5)}
     train = None
     if not args.no_train:
         del out
@@ -428,15 +529,22 @@ def main():
             "descriptors_per_s_per_rank": per_rank,
             "roofline": roof, "kernels": kern, "kernels_one_stream": kern1, "train": train,
         }
+        if secondary is not None:
+            line["secondary"] = secondary
         if train is not None and train_bf16 is not None:
             line["train_bf16"] = train_bf16
         if world == 1 and not args.no_cpu_baseline:
-            base, xs, ref = cpu_baseline(model, args.points)
+            base, xs, ref, best_threads = cpu_baseline(model, args.points)
             with torch.no_grad():
                 got = model(xs.to(dev)).cpu()
             rel = ((got - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)).max().item()
             line["cpu_baseline"] = base
             line["parity_norm_rel_vs_oracle"] = float(f"{rel:.3e}")
+            if train is not None:
+                tb = cpu_train_baseline(args.points, best_threads)
+                train["cpu_baseline"] = tb
+                if train_bf16 is not None:
+                    train_bf16["cpu_baseline"] = tb
         line_out.write(json.dumps(line) + "\n")
         line_out.flush()
     if dist is not None:

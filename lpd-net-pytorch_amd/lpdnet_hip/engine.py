@@ -166,65 +166,93 @@ def _knn_rows(rows, B, N, C, k):
 
 # cloud-panel [B, C/8, N, 8] buffers for x1|x2|x3 and the SN1 projections (LPD_PANELS=0: row-major everywhere)
 PANEL_LAYOUT = __import__("os").environ.get("LPD_PANELS", "1") != "0"
-# xyz kNN (and the DG1 stage's projection and K-agg) on a second HIP stream in the eval path: True / False, or "auto" (default):
-# decided per device from timed forwards.  On most MI355X boxes of the pool the second stream takes 3 % off the step; on some it
-# ADDS 10-20 % and makes the step time erratic (2.40 / 2.67 ms against 2.23 on one stream, same binaries, same inputs), so
-# neither setting is right everywhere.  auto: the first eval forward on a device runs with the second stream (warm-up), the next
-# four alternate the two modes between device synchronisations, and the faster sum wins for the rest of the process.
+# xyz kNN (and the DG1 stage's projection and K-agg) on a second HIP stream in the eval path.  LPD_SIDE_STREAM=1 / 0 force it on /
+# off; the default "auto" runs on ONE stream until `calibrate(model, x)` has measured both modes on this device (bench.py and
+# harness.get_latent_vectors call it; a bare `model(x)` never synchronises or times anything).  On most MI355X boxes of the pool
+# the second stream takes 3 % off the step; on some it ADDS 10-20 % and makes the step time erratic (2.40 / 2.67 ms against 2.23 on
+# one stream, same binaries, same inputs), so neither setting is right everywhere.
 _side_env = __import__("os").environ.get("LPD_SIDE_STREAM", "auto")
 SIDE_STREAM = "auto" if _side_env == "auto" else (_side_env != "0")
-_SIDE_AUTO = {}      # device key -> {"calls": int, "t": [two-stream ms, one-stream ms], "choice": bool or None}
+_SIDE_AUTO = {}      # device key -> {"choice": bool, "ms": (two-stream median, one-stream median), "n": samples per mode, "shape": (B, N)}
+CALIBRATE_SAMPLES = 7
+CALIBRATE_MIN_GAIN = 0.01      # the second stream must win by more than 1 % of the median forward to be switched on
+
+
+def _dev_key(device):
+    return (device.type, device.index if device.index is not None else torch.cuda.current_device())
+
+
+_SIDE_FORCE = __import__("threading").local()      # calibrate()'s per-thread override (DataParallel: one host thread per device)
 
 
 def _side_mode(device):
-    """(use the second stream for this forward?, timing slot or None).  Explicit settings pass through."""
+    """use the second stream for this forward?  Explicit settings pass through; auto = the calibrated choice, one stream before."""
+    forced = getattr(_SIDE_FORCE, "mode", None)
+    if forced is not None:
+        return forced
     if SIDE_STREAM != "auto":
-        return bool(SIDE_STREAM), None
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        return bool(SIDE_STREAM)
+    st = _SIDE_AUTO.get(_dev_key(device))
+    return bool(st and st["choice"]) and not torch.cuda.is_current_stream_capturing()
+
+
+def calibrate(model, x, samples=None, force=False):
+    """Measure the eval forward `model(x)` with and without the second HIP stream on x's device and keep the faster mode for the
+    rest of the process (LPD_SIDE_STREAM=auto only; returns the report string).  `samples` forwards per mode, interleaved
+    (two, one, two, one, ...) after two warm-up forwards per mode, each timed with HIP events on the caller's current stream (the
+    second stream is joined into it before the forward returns, so the pair of events brackets both); medians decide.  Nothing
+    but the caller's stream is synchronised.  Call it once per device with a batch of the shape the job runs."""
+    if SIDE_STREAM != "auto" or not x.is_cuda:
+        return side_stream_report(x.device)
+    key = _dev_key(x.device)
     with _SIDE_LOCK:
-        st = _SIDE_AUTO.setdefault(key, {"calls": 0, "t": [0.0, 0.0], "choice": None})
-        if st["choice"] is not None:
-            return st["choice"], None
-        if torch.cuda.is_current_stream_capturing():      # a graph capture cannot be timed (no synchronisation inside): one stream
-            return False, None
-        n = st["calls"]
-        st["calls"] = n + 1
-    if n == 0:
-        return True, None                    # warm-up: allocator, fragment caches, the stream itself
-    slot = (n - 1) & 1                       # calls 1..4: two, one, two, one
-    return slot == 0, (key, slot, n)
+        if key in _SIDE_AUTO and not force:
+            return side_stream_report(x.device)
+    n = int(samples or CALIBRATE_SAMPLES)
+    times = ([], [])
+    was_training = model.training
+    model.eval()
+    stream = torch.cuda.current_stream(x.device)
+    try:
+        with torch.no_grad():
+            for it in range(2 * (n + 2)):
+                slot = it & 1                                   # 0: two streams, 1: one stream
+                _SIDE_FORCE.mode = (slot == 0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                model(x)
+                e1.record(stream)
+                e1.synchronize()
+                if it >= 4:
+                    times[slot].append(e0.elapsed_time(e1))
+    finally:
+        _SIDE_FORCE.mode = None
+        model.train(was_training)
+    med = tuple(sorted(t)[len(t) // 2] for t in times)
+    with _SIDE_LOCK:
+        _SIDE_AUTO[key] = {"choice": med[0] < (1.0 - CALIBRATE_MIN_GAIN) * med[1], "ms": med, "n": n,
+                           "shape": (int(x.shape[0]), int(x.shape[2]))}
+    return side_stream_report(x.device)
 
 
 def side_stream_report(device):
-    """what the eval forward does on this device: 'two streams' / 'one stream', with the calibration times when auto decided"""
+    """what the eval forward does on this device: 'two streams' / 'one stream', with the calibration medians when auto decided"""
     if SIDE_STREAM != "auto":
         return "two streams (set)" if SIDE_STREAM else "one stream (set)"
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    st = _SIDE_AUTO.get(key)
+    st = _SIDE_AUTO.get(_dev_key(device))
     if not st:
-        return "one stream (the second stream serves the cloud-resident shapes only: k = 20, N <= 4096, N % 128 == 0)"
-    if st["choice"] is None:
-        return "auto (calibrating: %d of 5 forwards seen)" % st["calls"]
-    return "%s (auto: trunk %.2f ms with the second stream, %.2f ms without, two forwards each)" % (
-        "two streams" if st["choice"] else "one stream", st["t"][0] / 2, st["t"][1] / 2)
+        return "one stream (not calibrated: engine.calibrate(model, x) measures the second stream)"
+    return "%s (calibrated at B=%d, N=%d: forward %.3f ms with the second stream, %.3f ms without; medians of %d interleaved forwards each)" % (
+        "two streams" if st["choice"] else "one stream", st["shape"][0], st["shape"][1], st["ms"][0], st["ms"][1], st["n"])
 
 
-def _side_timed(token, t_ms):
-    key, slot, n = token
-    with _SIDE_LOCK:
-        st = _SIDE_AUTO[key]
-        st["t"][slot] += t_ms
-        if n >= 4 and st["choice"] is None:
-            # where the second stream helps it helps by ~3 % of the step, where it hurts by 10-20 %: two timed forwards each
-            # cannot resolve the former, so the second stream stays on unless it is clearly (> 5 %) slower
-            st["choice"] = st["t"][0] <= 1.05 * st["t"][1]
 FUSED_FRONT = __import__("os").environ.get("LPD_FUSED_FRONT", "1") != "0"   # conv1 + conv2 + kNN operands in one launch (no T-Nets)
 _SIDE = {}
 _SIDE_LOCK = __import__("threading").Lock()      # nn.DataParallel calls forward from one host thread per device
 
 
 def _side_stream(device):
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    key = _dev_key(device)
     with _SIDE_LOCK:
         st = _SIDE.get(key)
         if st is None:
@@ -277,16 +305,7 @@ def lpdnet_features_eval(net, x, reorder=True):
     B, N = x.shape[0], x.shape[2]
     act = ops.ACT_RELU if net.use_relu else ops.ACT_LEAKY
     side_ok = PANEL_LAYOUT and N % 128 == 0 and _resident_shape(net.k, N, B * N, act)
-    use_side, timing = _side_mode(x.device) if side_ok else (False, None)
-    if timing is not None:                   # calibration forward: timed between device synchronisations
-        torch.cuda.synchronize(x.device)
-        t_cal = __import__("time").perf_counter()
-        try:
-            return _lpdnet_features_eval_body(net, x, mfea, use_side)
-        finally:
-            torch.cuda.synchronize(x.device)
-            _side_timed(timing, (__import__("time").perf_counter() - t_cal) * 1e3)
-    return _lpdnet_features_eval_body(net, x, mfea, use_side and side_ok)
+    return _lpdnet_features_eval_body(net, x, mfea, side_ok and _side_mode(x.device))
 
 
 def _lpdnet_features_eval_body(net, x, mfea, use_side):

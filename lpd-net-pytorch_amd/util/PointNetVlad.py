@@ -198,4 +198,6 @@ class PointNetVlad(nn.Module):
     def forward(self, x):
         trunk = self.emb_nn if self.emb_nn is not None else self.point_net
         feat, B, N = trunk._features(x)          # point-major: no [B,E,N,1] round trip between trunk and head
+        if engine.DEBUG_AUX is not None:         # test hook: the trunk's output rows [B*N, E] (stage-probe fixtures)
+            engine.DEBUG_AUX["feat"] = feat
         return self.net_vlad._pool(feat, B, N)

@@ -81,3 +81,54 @@ def cloud(seed: int, B: int, N: int, C: int = 3) -> np.ndarray:
     for b in range(B):
         out[b] = uniform(f"cloud/{seed}/{b}", N * C).astype(np.float32).reshape(N, C)
     return out
+
+
+def scene_cloud(seed: int, B: int, N: int) -> np.ndarray:
+    """[B, N, 3] fp32 structured clouds: every cloud is a DIFFERENT arrangement of a noisy ground patch, 2-5 vertical wall segments
+    and 2-4 compact blobs inside [-1, 1)^3 (a crude stand-in for the Oxford submaps the reference trains on: zero-centred,
+    ground-removed street scenes), function of (seed, b, n) only.  Unlike `cloud` (44 draws of the SAME uniform distribution, whose
+    descriptors are nearly equal, so that the head's train-mode BatchNorms over the batch rows divide by a vanishing variance and
+    amplify rounding and kNN near-ties a hundredfold), the clouds of a batch differ from one another the way real submaps do."""
+    out = np.empty((B, N, 3), dtype=np.float32)
+    for b in range(B):
+        par = uniform(f"scene/{seed}/{b}/par", 64)
+        u = uniform(f"scene/{seed}/{b}/pts", N * 3).reshape(N, 3)
+        walls = 2 + int((par[0] + 1.0) * 2.0) % 4                 # 2..5
+        blobs = 2 + int((par[1] + 1.0) * 1.5) % 3                 # 2..4
+        ground_frac = 0.25 + 0.15 * par[2]                        # 0.10 .. 0.40 of the points
+        n_ground = int(ground_frac * N)
+        n_blob = int((0.10 + 0.05 * par[3]) * N)
+        pts = np.empty((N, 3), dtype=np.float64)
+        # ground: a tilted patch with 2 cm-scale roughness
+        gx, gy = par[4] * 0.2, par[5] * 0.2
+        pts[:n_ground, 0] = u[:n_ground, 0] * 0.95
+        pts[:n_ground, 1] = u[:n_ground, 1] * 0.95
+        pts[:n_ground, 2] = -0.6 + 0.3 * par[6] + gx * pts[:n_ground, 0] + gy * pts[:n_ground, 1] + 0.02 * u[:n_ground, 2]
+        # blobs
+        lo = n_ground
+        for j in range(blobs):
+            hi = lo + n_blob // blobs if j < blobs - 1 else n_ground + n_blob
+            c = par[8 + 3 * j: 11 + 3 * j] * np.array([0.8, 0.8, 0.4])
+            r = 0.05 + 0.10 * (par[20 + j] + 1.0) * 0.5
+            pts[lo:hi] = c + r * u[lo:hi]
+            lo = hi
+        # walls: vertical rectangles of random position, heading, length and height, 1 cm thick
+        n_wall = N - lo
+        for j in range(walls):
+            hi = lo + n_wall // walls if j < walls - 1 else N
+            cx, cy = par[24 + 2 * j] * 0.7, par[25 + 2 * j] * 0.7
+            t = par[34 + j]                                        # heading by the rational parametrisation of the circle:
+            ct, st = (1.0 - t * t) / (1.0 + t * t), 2.0 * t / (1.0 + t * t)   # + - * / only, bit-identical on every host
+            half_len = 0.15 + 0.25 * (par[40 + j] + 1.0) * 0.5
+            height = 0.3 + 0.5 * (par[46 + j] + 1.0) * 0.5
+            s = u[lo:hi, 0] * half_len
+            pts[lo:hi, 0] = cx + s * ct - 0.01 * u[lo:hi, 1] * st
+            pts[lo:hi, 1] = cy + s * st + 0.01 * u[lo:hi, 1] * ct
+            pts[lo:hi, 2] = -0.5 + (u[lo:hi, 2] + 1.0) * 0.5 * height
+            lo = hi
+        pts -= 0.5 * (pts.min(axis=0, keepdims=True) + pts.max(axis=0, keepdims=True))     # centre of the bounding box (exact ops)
+        pts /= np.abs(pts).max() * 1.0001
+        # a fixed pseudo-random permutation so that no stage sees the elements in blocks
+        order = np.argsort(uniform(f"scene/{seed}/{b}/perm", N), kind="stable")
+        out[b] = pts[order].astype(np.float32)
+    return out

@@ -66,6 +66,58 @@ def test_eval_descriptors_vs_reference_golden(cuda, golden_dir, tag, featnet, kw
         idx_f = aux["idx_feat"].cpu().numpy()
         agree = (idx_f == g["idx_feat"].astype(np.int32)).all(-1).mean()
         assert agree >= 0.995, f"feature-space kNN rows equal to the reference: {agree:.4f}"    # measured 0.999
+        # the reference's F0 (input of the feature-space kNN, [B,64,N]): exact-fp32 layers, 16 probes + checksums
+        _check_stage("F0", aux["F0"], g, B, N, probe_tol=2e-6, sum_tol=1e-6, frac=1.0)
+    # the trunk's output [B,E,N,1] as the reference holds it: 16 probes + checksums
+    _check_stage("feat", aux["feat"], g, B, N, probe_tol=2e-4, sum_tol=2e-4, frac=0.9)
+
+
+def _check_stage(name, rows, g, B, N, *, probe_tol, sum_tol, frac):
+    """rows [B*N, C] point-major (caller's point order) against a fixture's `<name>_probe` values at flat positions `<name>_pos`
+    of the reference's channel-major [B,C,N] tensor, and its (sum, abs-sum) checksums.  `frac` of the probes must sit within
+    probe_tol * max|probe| (a feature-space kNN near-tie that falls the other way moves single entries behind it)."""
+    rows = rows.detach().double().cpu().view(B, N, -1)
+    C = rows.shape[2]
+    pos = g[name + "_pos"].astype(np.int64)
+    b, c, n = pos // (C * N), (pos // N) % C, pos % N
+    got = rows[torch.from_numpy(b), torch.from_numpy(n), torch.from_numpy(c)].numpy()
+    want = g[name + "_probe"].astype(np.float64)
+    scale = np.abs(want).max()
+    ok = np.abs(got - want) <= probe_tol * scale
+    assert ok.mean() >= frac, f"{name}: {ok.sum()} of {ok.size} probes within {probe_tol:g} (worst {np.abs(got - want).max() / scale:.2e})"
+    sums = g[name + "_sum"]
+    assert abs(rows.sum().item() - sums[0]) <= sum_tol * sums[1], (name, rows.sum().item(), sums[0])
+    assert abs(rows.abs().sum().item() - sums[1]) <= sum_tol * sums[1], (name, rows.abs().sum().item(), sums[1])
+
+
+@pytest.mark.parametrize("tag,train", [("eval_lpdnet_stages_b2_n4096", False), ("train_lpdnet_stages_bq1_p2_n2_n1024", True)])
+def test_stage_tensors_vs_reference_taps(cuda, golden_dir, tag, train):
+    """SURVEY 8c stage fixtures: F0 / x1 / x2 / x3 / feat of the REFERENCE, tapped by forward hooks on its own sub-modules
+    (tests/golden/make_golden_r3.py), 512 probes + checksums each, eval mode (N = 4096) and train mode (batch statistics,
+    N = 1024).  An error that cancels in the descriptor is localised to its stage here.  x1..feat sit behind the feature-space
+    kNN, where ~0.1 % of the rows pick a different near-tied neighbour than the reference (it inherits conv rounding, as the
+    oracle does): 98 % of the probes must agree to 2e-4 of the stage's range, the checksums to 5e-4."""
+    from lpdnet_hip import engine
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    B, N = int(g["B"]), int(g["N"])
+    m, _ = _model("lpdnet", N, cuda)
+    m.train(train)
+    x = torch.from_numpy(synth.cloud(int(g["seed"]), B, N)).unsqueeze(1).to(cuda)
+    engine.DEBUG_AUX = {}
+    engine.MORTON_ORDER = False
+    try:
+        with torch.no_grad():
+            desc = m(x)
+        aux = engine.DEBUG_AUX
+    finally:
+        engine.DEBUG_AUX = None
+        engine.MORTON_ORDER = True
+    assert _norm_rel(desc, torch.from_numpy(g["desc"])) < DESC_TOL
+    _check_stage("F0", aux["F0"], g, B, N, probe_tol=2e-6 if not train else 2e-5, sum_tol=2e-6 if not train else 2e-5, frac=1.0)
+    cat = aux["cat"]
+    for name, lo, hi in (("x1", 0, 128), ("x2", 128, 256), ("x3", 256, 512)):
+        _check_stage(name, cat[:, lo:hi].contiguous(), g, B, N, probe_tol=2e-4, sum_tol=5e-4, frac=0.98)
+    _check_stage("feat", aux["feat"], g, B, N, probe_tol=2e-4, sum_tol=5e-4, frac=0.98)
 
 
 @pytest.mark.parametrize("tag", ["eval_lpdnet_k64_b2_n2048", "eval_lpdnet_k64_b1_n16384"])

@@ -1,9 +1,12 @@
-"""The data-parallel training wrapper on the REAL model with a REAL process group on the GPU box (world size 1: the
-collectives are issued over RCCL and must leave the gradients of the single-process step unchanged).  -m gpu only.
-The N > 1 arithmetic is covered by the gloo world-2 tests in tests/test_parallel_cpu.py; the N-rank launch by
+"""The data-parallel training wrapper on the REAL model with a REAL process group on the GPU box: world size 1 over RCCL (the
+collectives are issued and must leave the gradients of the single-process step unchanged) and world size 2 over gloo with both
+ranks on the box's one GPU (each rank its own tuples: reduced gradients = mean of the two single-process gradients).  -m gpu only.
+The toy-model arithmetic is covered by the gloo world-2 tests in tests/test_parallel_cpu.py; the N-rank launch by
 `python bench.py --gpus N` (the launcher test there)."""
 import os
 import socket
+import subprocess
+import sys
 
 import pytest
 import torch
@@ -62,3 +65,52 @@ def test_grad_allreduce_on_pointnetvlad_over_rccl_world1(cuda):
         # difference can re-route a gradient entry to another arg-max edge (tests/test_train_gpu.py header), so the trunk
         # gets the trunk tolerance and the head (in front of every max) the tight one
         assert err < (1e-4 if n.startswith("net_vlad.") else 1e-2), (n, err)
+
+
+def test_grad_allreduce_world2_real_model_one_gpu(cuda, tmp_path):
+    """configs[3]'s exchange on the real model with more than one rank: two processes (gloo; both on cuda:0 -- the box has one GPU),
+    each with its OWN tuples, run the real PointNetVlad forward / backward (custom autograd.Functions, `hidden1_weights` reduced
+    from its post-accumulate hook while the trunk's backward still runs, the 3.3 MB bucket at the engine callback) under
+    GradAllReduce.  Reduced gradients must equal the mean of the two single-process gradients (head 1e-4; trunk 1e-2: behind the
+    max over k a last-bit difference re-routes single gradient entries, tests/test_train_gpu.py header), both replicas must hold
+    rank 0's weights, and hidden1_weights must be the first gradient to become ready."""
+    from util.PointNetVlad import PointNetVlad
+    import _world2_worker as w2
+    N, bq, P, Ng = 1024, 1, 2, 2
+    B = bq * (1 + P + Ng + 1)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_world2_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(tmp_path), str(N), str(bq), str(P), str(Ng)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    r = [torch.load(os.path.join(tmp_path, f"rank{i}.pt")) for i in range(2)]
+    sd = orc.synthetic_state("lpdnet", num_points=N)
+    singles = []
+    for rank in range(2):
+        m = PointNetVlad(num_points=N, featnet="lpdnet")
+        m.load_state_dict(sd, strict=True)
+        m = m.to(cuda).train()
+        _step(m, w2.tuples_of_rank(rank, B, N).to(cuda), bq, P, Ng)
+        singles.append({n: p.grad.detach().cpu() for n, p in m.named_parameters()})
+    assert torch.equal(r[0]["w_probe"], r[1]["w_probe"]) and torch.equal(r[0]["w_probe"], sd["emb_nn.conv3_lpd.weight"][:4, :4].view(4, 4))
+    worst = {}
+    for n in singles[0]:
+        assert torch.equal(r[0]["grads"][n], r[1]["grads"][n]), n            # one reduced gradient on both ranks
+        want = 0.5 * (singles[0][n] + singles[1][n])
+        if want.norm().item() < 1e-9:
+            continue
+        err = (r[0]["grads"][n] - want).norm().item() / max(want.norm().item(), 1e-20)
+        worst[n] = err
+        assert err < (1e-4 if n.startswith("net_vlad.") else 1e-2), (n, err)
+        # ... and it is NOT rank 0's own gradient (the ranks really had different tuples)
+    assert (singles[0]["net_vlad.hidden1_weights"] - singles[1]["net_vlad.hidden1_weights"]).norm() > 0.1 * singles[0]["net_vlad.hidden1_weights"].norm()
+    for rr in r:
+        assert rr["stats"]["steps"] == 2 and rr["stats"]["big_reduced"] == 2
+        assert rr["stats"]["bucket_elems"] == 17605184 - 65536 * 256
+        assert rr["first_grad"] == "net_vlad.hidden1_weights" or rr["first_grad"].startswith("net_vlad."), rr["first_grad"]
+    print("world-2 reduced-vs-mean rel-L2: head max %.2e, trunk max %.2e" % (
+        max(v for k, v in worst.items() if k.startswith("net_vlad.")), max(v for k, v in worst.items() if not k.startswith("net_vlad."))))

@@ -447,3 +447,117 @@ def test_use_mfea_trunks_eval_and_train(cuda, cls, t3d):
             assert ((a - b).norm() / b.norm()).item() < 2e-2, name
     with pytest.raises(ValueError):
         net.eval()(x8[..., :3].to(cuda))
+
+
+# ---- BASELINE configs[2] at its stated size: batch_num_queries 2, positives 2, negatives 18 -> B = 44 clouds of 4096 points ----
+def _cfg2_report(tag, **kv):
+    if os.environ.get("LPD_TEST_VERBOSE"):
+        print("cfg2", tag, {k: (float(f"{v:.3e}") if isinstance(v, float) else v) for k, v in kv.items()})
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_train_step0_cfg2_full_size_vs_reference(cuda, golden_dir, storage):
+    """Step 0 of the REFERENCE's training loop at the size configs[2] states (train_pointnetvlad.py:202-217, config.py:15-17;
+    fixture: tests/golden/make_golden_r3.py, structured clouds `synth.scene_cloud`), in both storage modes of the HIP path.
+
+    Yardstick for the descriptors: the fixture also holds the reference's OWN fp64 forward (`desc64`).  Two evaluations of this
+    step differ through a handful of feature-space kNN near-ties and the head's BatchNorms over the 44 batch rows whatever the
+    precision: the reference's fp32 run sits 3.3e-4 (max over the 44 descriptors, norm-relative) / 7.3e-5 (median) from its fp64
+    run, the fp32 oracle 6.8e-4 / 5.1e-5.  The fp32-storage path must be as close to fp64 as those are (max <= 1e-3, median
+    <= 1.5e-4); gradients against the reference's fp32 autograd at the gates of the small fixtures (1e-2 per tensor)."""
+    from lpdnet_hip import autograd
+    g = np.load(os.path.join(golden_dir, "train_lpdnet_bq2_p2_n18_n4096.npz"))
+    bq, P, Ng, N = [int(v) for v in g["dims"]]
+    B = bq * (1 + P + Ng + 1)
+    assert (B, N) == (44, 4096)
+    m, _ = _train_model(N, cuda, "lpdnet")
+    x = torch.from_numpy(synth.scene_cloud(int(g["seed"]), B, N)).unsqueeze(1).to(cuda)
+    prev = autograd.set_train_storage(storage)
+    try:
+        out, loss = _step(m, x, bq, P, Ng)
+    finally:
+        autograd.set_train_storage(prev)
+    d64 = torch.from_numpy(g["desc64"])
+
+    def nr(a):
+        return ((a.double() - d64).abs().amax(dim=1) / d64.abs().amax(dim=1))
+    e_ref, e_gpu = nr(torch.from_numpy(g["desc"])), nr(out.detach().cpu())
+    q, p, n, o = torch.split(d64.view(bq, -1, 256), [1, P, Ng, 1], dim=1)
+    loss64 = orc.quadruplet_loss(q, p, n, o, 0.5, 0.2, use_min=True, lazy=True, ignore_zero_loss=False).item()
+    loss_err = abs(loss.item() - loss64) / abs(loss64)
+    ref_loss_err = abs(float(g["loss"]) - loss64) / abs(loss64)
+    params = dict(m.named_parameters())
+    errs, l2errs = {}, {}
+    for key in g.files:
+        if key.startswith("grad/"):
+            name = key[5:]
+            errs[name] = float(np.linalg.norm(params[name].grad.cpu().numpy() - g[key]) / np.linalg.norm(g[key]))
+        elif key.startswith("gsum/"):
+            name = key[5:]
+            l2errs[name] = abs(params[name].grad.double().pow(2).sum().sqrt().item() - g[key][2]) / g[key][2]
+    perr = {}
+    for key in g.files:
+        if key.startswith("gprobe/"):
+            name = key[7:]
+            got = params[name].grad.detach().cpu().reshape(-1)[torch.from_numpy(g["gpos/" + name])].numpy()
+            perr[name] = float(np.linalg.norm(got - g[key]) / max(np.linalg.norm(g[key]), 1e-30))
+    berr = 0.0
+    for key in g.files:
+        if key.startswith("buf/"):
+            buf = dict(m.named_buffers())[key[4:]].cpu().numpy()
+            berr = max(berr, float(np.abs(buf - g[key]).max() / (np.abs(g[key]).max() + 1e-6)))
+    _cfg2_report(storage, desc_max=e_gpu.max().item(), desc_median=e_gpu.median().item(), ref_max=e_ref.max().item(),
+                 ref_median=e_ref.median().item(), loss=loss.item(), loss64=loss64, loss_err=loss_err, ref_loss_err=ref_loss_err,
+                 grad_max=max(errs.values()), grad_median=float(np.median(list(errs.values()))), l2_max=max(l2errs.values()),
+                 probe_max=max(perr.values()), running_stats=berr,
+                 worst=sorted(((round(e, 5), n_) for n_, e in errs.items()), reverse=True)[:4])
+    desc_max, desc_med, loss_tol, g_tol, g_med = CFG2_GATES[storage]
+    assert e_gpu.max().item() < desc_max and e_gpu.median().item() < desc_med, (e_gpu.max().item(), e_gpu.median().item())
+    assert loss_err < loss_tol, (loss.item(), loss64)
+    assert max(errs.values()) < g_tol and float(np.median(list(errs.values()))) < g_med, errs
+    assert max(l2errs.values()) < g_tol, l2errs
+    assert berr < (2e-4 if storage == "f32" else 2e-2), berr
+    for name, b in m.named_buffers():
+        if name.endswith("num_batches_tracked"):
+            assert int(b) == 1
+
+
+# storage -> (descriptor max, descriptor median [norm-relative to the reference's fp64 forward], loss, gradient max, gradient median)
+CFG2_GATES = {"f32": (1e-3, 1.5e-4, 2e-3, 1e-2, 2.5e-3),
+              "bf16": (BF16_DESC_TOL, BF16_DESC_TOL, BF16_LOSS_TOL, BF16_GRAD_TOL, BF16_GRAD_MEDIAN)}
+
+
+def test_bf16_storage_converges_like_fp32(cuda):
+    """30 Adam steps on a FIXED set of 8 tuples (bq = 2 -> four batches, cycled), fp32 storage against bf16 storage from the same
+    initial weights: both losses must fall, and the bf16 run must end within 10 % of the fp32 run (mean loss over the last cycle
+    of four batches)."""
+    from lpdnet_hip import autograd
+    N, bq, P, Ng, steps = 1024, 2, 2, 2, 32
+    per = 1 + P + Ng + 1
+    tuples = torch.from_numpy(synth.scene_cloud(51, 8 * per, N)).view(4, bq * per, 1, N, 3).to(cuda)
+    curves = {}
+    for storage in ("f32", "bf16"):
+        m, _ = _train_model(N, cuda, "lpdnet")
+        opt = torch.optim.Adam(m.parameters(), lr=CONVERGENCE_LR)
+        prev = autograd.set_train_storage(storage)
+        try:
+            losses = []
+            for it in range(steps):
+                opt.zero_grad(set_to_none=True)
+                _, loss = _step(m, tuples[it % 4], bq, P, Ng)
+                opt.step()
+                losses.append(loss.item())
+        finally:
+            autograd.set_train_storage(prev)
+        curves[storage] = losses
+    first = {s: float(np.mean(c[:4])) for s, c in curves.items()}
+    last = {s: float(np.mean(c[-4:])) for s, c in curves.items()}
+    if os.environ.get("LPD_TEST_VERBOSE"):
+        print("convergence", {s: [round(v, 3) for v in c] for s, c in curves.items()}, first, last)
+    for s in curves:
+        assert np.isfinite(curves[s]).all()
+        assert last[s] < 0.7 * first[s], (s, first[s], last[s])
+    assert abs(last["bf16"] - last["f32"]) < 0.10 * max(last["f32"], 0.05 * first["f32"]), (last, first)
+
+
+CONVERGENCE_LR = 1e-4
