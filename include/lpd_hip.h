@@ -143,6 +143,11 @@ int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, 
  * multiple of 128 points, act none / ReLU / LeakyReLU.  frags: lpd_gemm_prep_b(W [N][K], b_kmajor = 0).
  */
 int lpd_gemm_x3t_applies(int M, int N, int K, int act, long long a_cloud, long long c_cloud, int panel_n);
+/* lpd_gemm_x3t with A given as SPLIT bf16 planes (a_hi: hi plane [cloud][K/8][panel_ld][8], a_cloud elements between clouds; the lo
+ * plane a_lo elements behind it) */
+int lpd_gemm_x3ts(const void* a_hi, long long a_lo, const void* frags, float* C, int M, int N, int K, const float* bias,
+                  const float* scale, const float* shift, int act, float slope, long long a_cloud, long long c_cloud, int panel_n,
+                  int panel_ld, void* stream);
 int lpd_gemm_x3t(const float* A, const void* frags, float* C, int M, int N, int K, const float* bias, const float* scale,
                  const float* shift, int act, float slope, long long a_cloud, long long c_cloud, int panel_n, int panel_ld,
                  void* stream);
@@ -171,6 +176,12 @@ int lpd_edge_gather_max(const float* P, int ldp, const float* Q, int ldq, const 
 int lpd_edge_gather_max16(const float* P, int ldp, const float* Q, int ldq, const uint16_t* idx16, float* out, int ldo,
                           const float* scale, const float* shift, int M, int N, int C, int k, int act, float slope, long long p_cloud,
                           long long q_cloud, long long o_cloud, int panel_ld, void* stream);
+/* The same with SPLIT output for lpd_gemm_p8 / lpd_gemm_x3ts: out_hi = hi plane of a pair of bf16 cloud-panel planes
+ * [cloud][C/8][panel_ld][8] (hi = bf16(x), lo = bf16(x - hi); o_cloud bf16 elements between clouds), the lo plane o_lo elements
+ * behind it.  Same bytes as the fp32 row; the two lanes of a point exchange halves (DPP) so that each still stores 16 bytes. */
+int lpd_edge_gather_max16s(const float* P, int ldp, const float* Q, int ldq, const uint16_t* idx16, void* out_hi, long long o_lo,
+                           const float* scale, const float* shift, int M, int N, int C, int k, int act, float slope, long long p_cloud,
+                           long long q_cloud, long long o_cloud, int panel_ld, void* stream);
 
 /* int32 kNN indices [M][k] (local to the cloud, < 65536) -> the uint16 copy lpd_edge_gather_max16 reads:
  * blocked by 32 points, index quad i of point m at ((m/32)*5 + i)*32 + m%32 (uint2 units); idx16 holds
@@ -205,6 +216,10 @@ int lpd_edge_mlp(const float* P, int ldp, const float* Q, int ldq, const int32_t
 /* Same contract on the bf16 MFMA (split-bf16, three products per term, fp32 accumulate: see lpd_gemm_bf16x3). */
 int lpd_edge_mlp_bf16x3(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
                  const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo, int M,
+                 int N, int CM, int CO, int k, int act, float slope, long long out_cloud, int panel_ld, void* stream);
+/* ... with SPLIT output (see lpd_edge_gather_max16s): out_hi / out_lo planes of bf16 cloud panels, out_cloud elements between clouds */
+int lpd_edge_mlp_bf16x3s(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
+                 const float* b1, const float* W2, const float* s2, const float* b2, void* out_hi, long long out_lo, int M,
                  int N, int CM, int CO, int k, int act, float slope, long long out_cloud, int panel_ld, void* stream);
 
 /* Per-point linear layer with K <= 8 inputs (+bias, affine, activation): the 3 -> 64 first layers
@@ -455,6 +470,24 @@ int lpd_gemm_tn_bf16(const uint16_t* A, const uint16_t* B, float* dW, float* ws,
 long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB, int batch);
 int lpd_gemm_tn(const float* A, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
                 int batch, long long sA, long long sB, void* stream);
+
+/*
+ * conv3_lpd of the eval path (util/lpdnet_model.py:262: 512 -> emb_dims per point, + bn3 + activation) on PRE-SPLIT operands:
+ *   C[m][n] = act(scale[n] * sum_k A[m][k] W[n][k] + shift[n]),   A = a_hi + a_lo,  three bf16 MFMA products per term (fp32-grade)
+ * a_hi / a_lo: bf16 cloud panels [cloud][K/8][a_panel_ld][8] (hi = bf16(x), lo = bf16(x - hi); written by the producers of
+ * [x1 | x2 | x3] or by lpd_split_panels), a_cloud bf16 elements apart; frags: lpd_gemm_prep_b(W [N][K], b_kmajor = 0);
+ * C: row-major [M][ldc] (c_cloud = 0) or fp32 cloud panels [cloud][N/8][c_panel_ld][8], c_cloud floats apart.
+ * 256 x 256 block tiles, LDS-DMA ring, persistent workgroups (csrc/lpd_gemm_p8.hip).  lpd_gemm_p8_applies: N % 256 == 0,
+ * K % 32 == 0, clouds of a multiple of 256 points.  act none / ReLU / LeakyReLU.  impl: 0 (= 5) or 5 / 6 staging units in flight.
+ */
+int lpd_gemm_p8_applies(int M, int N, int K, int panel_n);
+int lpd_gemm_p8(const void* a_hi, const void* a_lo, long long a_cloud, int a_panel_ld, const void* frags, float* C, int ldc,
+                long long c_cloud, int c_panel_ld, int M, int N, int K, int panel_n, const float* scale, const float* shift,
+                int act, float slope, int impl, void* stream);
+/* fp32 cloud panels [clouds][panels][s_panel_ld][8] (s_cloud floats apart) -> the two bf16 planes hi / lo of the same layout
+ * ([clouds][panels][d_panel_ld][8], d_cloud elements apart); n rows per panel are converted. */
+int lpd_split_panels(const float* src, long long s_cloud, int s_panel_ld, void* hi, void* lo, long long d_cloud, int d_panel_ld,
+                     int clouds, int panels, int n, void* stream);
 
 #ifdef __cplusplus
 }

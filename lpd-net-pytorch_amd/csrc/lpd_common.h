@@ -66,3 +66,36 @@ __device__ __forceinline__ int lpd_xcd_remap(int bid, int nblocks)
     int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + slot;
 }
+
+// ---- split-bf16 activation planes (what lpd_gemm_p8 / lpd_gemm_x3t read): x = hi + lo, hi = bf16(x), lo = bf16(x - hi) ----
+typedef __bf16 lpd_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float lpd_f32x2 __attribute__((ext_vector_type(2)));
+
+// two floats -> packed hi pair and packed lo pair (element 0 in the low half of the dword)
+__device__ __forceinline__ void lpd_split2(float x0, float x1, unsigned& hi, unsigned& lo)
+{
+    const lpd_bf16x2 h2 = __builtin_convertvector((lpd_f32x2){x0, x1}, lpd_bf16x2);
+    hi = __builtin_bit_cast(unsigned, h2);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    const lpd_bf16x2 l2 = __builtin_convertvector((lpd_f32x2){r0, r1}, lpd_bf16x2);
+    lo = __builtin_bit_cast(unsigned, l2);
+}
+
+// the value of lane (id ^ 1) (DPP quad_perm [1,0,3,2]: no LDS traffic)
+__device__ __forceinline__ unsigned lpd_lane_xor1(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+}
+
+// Two adjacent lanes (even: channels c..c+3, odd: c+4..c+7 of one point) hold a float4 each; afterwards the EVEN lane holds the 8
+// hi values and the ODD lane the 8 lo values of the point's 8 channels as one 16-byte word: each lane stores 16 bytes into "its"
+// plane (even -> hi plane, odd -> lo plane) at the point's row.
+__device__ __forceinline__ uint4 lpd_split8_pair(const float4& r, int odd)
+{
+    unsigned h0, l0, h1, l1;
+    lpd_split2(r.x, r.y, h0, l0);
+    lpd_split2(r.z, r.w, h1, l1);
+    const unsigned s0 = odd ? h0 : l0, s1 = odd ? h1 : l1;       // what the partner needs
+    const unsigned r0 = lpd_lane_xor1(s0), r1 = lpd_lane_xor1(s1);
+    return odd ? make_uint4(r0, r1, l0, l1) : make_uint4(h0, h1, r0, r1);
+}

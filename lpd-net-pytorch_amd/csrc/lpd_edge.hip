@@ -49,7 +49,22 @@ struct GatherArgs {
     // [cloud][C/8][N][8]: slice N * 8 with a row stride of 8, cloud = floats between clouds in that buffer.
     long long p_slice, q_slice, o_slice;
     long long p_cloud, q_cloud, o_cloud;
+    // split output (cloud-resident form, cloud-panel out only): `out` is the hi plane of a bf16 pair of planes, the lo plane o_lo
+    // elements behind it (o_slice / o_cloud count bf16 elements); 0 = fp32 output
+    long long o_lo;
 };
+
+// one point's result of the cloud-resident kernels: fp32 float4 into the row, or (SPLIT) the pair-exchanged hi / lo word
+template <bool SPLIT>
+__device__ __forceinline__ void kagg_store(float* outc, unsigned row_off, const float4& r, int cl, long long o_lo)
+{
+    if constexpr (!SPLIT) *reinterpret_cast<float4*>(outc + row_off) = r;
+    else {
+        // outc = hi plane + cloud + slice (bf16 elements, no lane part); row_off = row * 8
+        __bf16* p = reinterpret_cast<__bf16*>(outc) + (cl ? o_lo : 0) + row_off;
+        *reinterpret_cast<uint4*>(p) = lpd_split8_pair(r, cl);
+    }
+}
 
 // LPP = lanes per point = C / 4 (16, 32 or 64)
 template <int LPP>
@@ -141,7 +156,7 @@ struct CloudOps {
     unsigned m;     // global row of the point (32-bit element offsets: the host checks M * ld * 4 < 2^32)
 };
 
-template <bool HAS_Q>
+template <bool HAS_Q, bool SPLIT = false>
 __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArgs g, const uint16_t* __restrict__ idx16,
                                                                        int nslices, float ns)
 {
@@ -165,7 +180,8 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArg
     const int passes = (N + GROUPS - 1) / GROUPS;
     const uint2* idx2 = reinterpret_cast<const uint2*>(idx16);
     const float* Qc = g.Q + b * g.q_cloud + sl * g.q_slice + cl * 4;      // row n of the cloud at + n * ld
-    float* outc = g.out + b * g.o_cloud + sl * g.o_slice + cl * 4;
+    float* outc = SPLIT ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(g.out) + b * g.o_cloud + sl * g.o_slice)
+                        : g.out + b * g.o_cloud + sl * g.o_slice + cl * 4;
     const unsigned ldq = g.ldq, ldo = g.ldo;
 
     // A pass past the end of the cloud re-reads (and later re-stores, with identical values) the last point:
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArg
         r.y = fmaxf(r.y, 0.f) + ns * fminf(r.y, 0.f);
         r.z = fmaxf(r.z, 0.f) + ns * fminf(r.z, 0.f);
         r.w = fmaxf(r.w, 0.f) + ns * fminf(r.w, 0.f);
-        *reinterpret_cast<float4*>(outc + (o.m - row0) * ldo) = r;
+        kagg_store<SPLIT>(outc, (o.m - row0) * ldo, r, cl, g.o_lo);
     };
     for (int ps = 0; ps < passes; ps += 3) {
         load(Co, ps + 2);
@@ -246,7 +262,7 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArg
 // fill 80; without Q / out traffic 79; with no global memory traffic at all 55).  During its last item a workgroup
 // keeps issuing the loads with a row stride of 0 (one 32-byte piece, no traffic): a branch around them would make the
 // compiler's in-order vmcnt accounting wait for them early.
-template <bool HAS_Q>
+template <bool HAS_Q, bool SPLIT = false>
 __global__ __launch_bounds__(1024) void edge_gather_max_cloud16p_kernel(GatherArgs g, const uint16_t* __restrict__ idx16,
                                                                         int nslices, float ns, int nwork, int per)
 {
@@ -280,7 +296,8 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16p_kernel(GatherAr
         const int col = sl * 8 + cl * 4;
         const unsigned row0 = (unsigned)b * N;
         const float* Qc = g.Q + b * g.q_cloud + sl * g.q_slice + cl * 4;
-        float* outc = g.out + b * g.o_cloud + sl * g.o_slice + cl * 4;
+        float* outc = SPLIT ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(g.out) + b * g.o_cloud + sl * g.o_slice)
+                            : g.out + b * g.o_cloud + sl * g.o_slice + cl * 4;
         const float* Pn = p_slice_ptr(min(w + 1, w_end - 1));
         const unsigned ldpn = w + 1 < w_end ? (unsigned)g.ldp : 0u;   // last item: every lane re-reads one row piece (no traffic)
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -330,7 +347,7 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16p_kernel(GatherAr
             r.y = fmaxf(r.y, 0.f) + ns * fminf(r.y, 0.f);
             r.z = fmaxf(r.z, 0.f) + ns * fminf(r.z, 0.f);
             r.w = fmaxf(r.w, 0.f) + ns * fminf(r.w, 0.f);
-            *reinterpret_cast<float4*>(outc + (o.m - row0) * ldo) = r;
+            kagg_store<SPLIT>(outc, (o.m - row0) * ldo, r, cl, g.o_lo);
         };
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {
@@ -378,6 +395,8 @@ struct EdgeMlpArgs {
     float slope;
     long long out_cloud;  // 0: out row-major [M][ldo]; else cloud-panel [cloud][.][panel_ld][8] with this many floats between clouds
     int panel_ld;         // rows allotted to one panel (>= N)
+    long long out_lo;     // != 0 (split-bf16 kernel, cloud-panel out): `out` is the hi plane of a pair of bf16 planes, the lo plane
+                          // out_lo elements behind it; out_cloud counts bf16 elements
 };
 
 // m = m0 + (row inside the block); a block's 64 points lie in one cloud when the output is in cloud-panel form
@@ -752,7 +771,20 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + (ptile + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m >= g.M) continue;
-            *edge_mlp_out(g, m0, (size_t)m, n) = lpd_act_pl(sc2 * (sgn * zmax[i][r]) + sh2, ns);
+            const float v = lpd_act_pl(sc2 * (sgn * zmax[i][r]) + sh2, ns);
+            if (!g.out_lo) { *edge_mlp_out(g, m0, (size_t)m, n) = v; continue; }      // uniform
+            // split planes: this lane holds channel n of point m; the even lane of a pair stores (hi_n, hi_n+1) into the hi plane,
+            // the odd lane (lo_n-1, lo_n) into the lo plane -- one 4-byte store per lane, as in the fp32 form
+            const __bf16 hb = (__bf16)v;
+            const __bf16 lb = (__bf16)(v - (float)hb);
+            const unsigned hu = __builtin_bit_cast(unsigned short, hb), lu = __builtin_bit_cast(unsigned short, lb);
+            const int odd = n & 1;
+            const unsigned got = lpd_lane_xor1(odd ? hu : lu);
+            const unsigned word = odd ? (got | (lu << 16)) : (hu | (got << 16));
+            const size_t b = (size_t)(m0 / g.N);
+            __bf16* dst = reinterpret_cast<__bf16*>(g.out) + (odd ? g.out_lo : 0) + b * g.out_cloud +
+                          ((size_t)(n >> 3) * g.panel_ld + ((size_t)m - b * g.N)) * 8 + ((n & 7) & ~1);
+            *reinterpret_cast<unsigned*>(dst) = word;
         }
 }
 
@@ -783,7 +815,7 @@ extern "C" int lpd_edge_gather_max(const float* P, int ldp, const float* Q, int 
     LPD_CHECK_ARG(ldp % 4 == 0 && ldo % 4 == 0 && (!Q || ldq % 4 == 0), "lpd_edge_gather_max: leading dims must be multiples of 4");
     LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)out | (uintptr_t)Q | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0,
                   "lpd_edge_gather_max: pointers must be 16-byte aligned");
-    GatherArgs g{P, Q, idx, out, scale, shift, M, N, C, k, ldp, ldq, ldo, act, slope, 0, 0, 0, 0, 0, 0};
+    GatherArgs g{P, Q, idx, out, scale, shift, M, N, C, k, ldp, ldq, ldo, act, slope, 0, 0, 0, 0, 0, 0, 0};
     const int lpp = C / 4;
     const int nwork = (M + (64 / lpp) - 1) / (64 / lpp);
     int blocks = (nwork + 3) / 4;
@@ -798,10 +830,12 @@ extern "C" int lpd_edge_gather_max(const float* P, int ldp, const float* Q, int 
 
 static int edge_mlp_entry(bool x3, const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
                           const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo,
-                          int M, int N, int CM, int CO, int k, int act, float slope, long long out_cloud, int panel_ld, void* stream_)
+                          int M, int N, int CM, int CO, int k, int act, float slope, long long out_cloud, int panel_ld, void* stream_,
+                          long long out_lo = 0)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(P && idx && s1 && b1 && W2 && s2 && b2 && out, "lpd_edge_mlp: null pointer");
+    LPD_CHECK_ARG(!out_lo || (x3 && out_cloud && out_lo % 8 == 0), "lpd_edge_mlp: split output needs the bf16x3 kernel and cloud-panel planes");
     LPD_CHECK_ARG(M > 0 && N > 0 && k > 0 && M % N == 0, "lpd_edge_mlp: bad dims M=%d N=%d k=%d", M, N, k);
     LPD_CHECK_ARG(k <= 128, "lpd_edge_mlp: k=%d > 128 unsupported", k);
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_mlp: act=%d unsupported (none/ReLU/LeakyReLU)", act);
@@ -810,7 +844,7 @@ static int edge_mlp_entry(bool x3, const float* P, int ldp, const float* Q, int 
     LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)Q | (uintptr_t)s1 | (uintptr_t)b1 | (uintptr_t)W2) & 15) == 0,
                   "lpd_edge_mlp: pointers must be 16-byte aligned");
     LPD_CHECK_ARG(!out_cloud || (N % EM_PTS == 0 && panel_ld >= N), "lpd_edge_mlp: cloud-panel out needs N %% 64 == 0 and panel_ld >= N");
-    EdgeMlpArgs g{P, Q, idx, s1, b1, W2, s2, b2, out, M, N, k, ldp, ldq, ldo, act, slope, out_cloud, panel_ld};
+    EdgeMlpArgs g{P, Q, idx, s1, b1, W2, s2, b2, out, M, N, k, ldp, ldq, ldo, act, slope, out_cloud, panel_ld, out_lo};
     if (CM == 128 && CO == 128) return x3 ? edge_mlp_x3_launch<128, 128>(g, stream) : edge_mlp_launch<128, 128>(g, stream);
     if (CM == 64 && CO == 64) return x3 ? edge_mlp_x3_launch<64, 64>(g, stream) : edge_mlp_launch<64, 64>(g, stream);
     lpd_set_error("lpd_edge_mlp: (CM=%d, CO=%d) unsupported; built for (128,128) and (64,64)", CM, CO);
@@ -829,9 +863,10 @@ extern "C" int lpd_pack_idx16(const int32_t* idx, uint16_t* idx16, long long M, 
     return LPD_OK;
 }
 
-extern "C" int lpd_edge_gather_max16(const float* P, int ldp, const float* Q, int ldq, const uint16_t* idx16, float* out,
-                                     int ldo, const float* scale, const float* shift, int M, int N, int C, int k, int act,
-                                     float slope, long long p_cloud, long long q_cloud, long long o_cloud, int panel_ld, void* stream_)
+static int edge_gather_max16_impl(const float* P, int ldp, const float* Q, int ldq, const uint16_t* idx16, float* out,
+                                  int ldo, const float* scale, const float* shift, int M, int N, int C, int k, int act,
+                                  float slope, long long p_cloud, long long q_cloud, long long o_cloud, int panel_ld, long long o_lo,
+                                  void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(P && idx16 && out, "lpd_edge_gather_max16: null pointer");
@@ -852,7 +887,7 @@ extern "C" int lpd_edge_gather_max16(const float* P, int ldp, const float* Q, in
     const long long ps = (long long)panel_ld * 8;
     GatherArgs g{P, Q, nullptr, out, scale, shift, M, N, C, k, p_cloud ? 8 : ldp, q_cloud ? 8 : ldq, o_cloud ? 8 : ldo, act, slope,
                  p_cloud ? ps : 8, q_cloud ? ps : 8, o_cloud ? ps : 8,
-                 p_cloud ? p_cloud : (long long)N * ldp, q_cloud ? q_cloud : (long long)N * ldq, o_cloud ? o_cloud : (long long)N * ldo};
+                 p_cloud ? p_cloud : (long long)N * ldp, q_cloud ? q_cloud : (long long)N * ldq, o_cloud ? o_cloud : (long long)N * ldo, o_lo};
     const int nslices = C / 8;
     const size_t lds = (size_t)KAGG_IMG1 + (size_t)N * 16;
     const float ns = act == 0 ? 1.0f : (act == 1 ? 0.0f : slope);
@@ -860,30 +895,45 @@ extern "C" int lpd_edge_gather_max16(const float* P, int ldp, const float* Q, in
     static const int persist = getenv("LPD_KAGG_PERSIST") ? atoi(getenv("LPD_KAGG_PERSIST")) : -1;
     const int nwork = (M / N) * nslices;
     const int per_auto = (nwork + 255) / 256;
-    if (persist != 0 && N > 3584 && N <= 4096 && (persist > 0 ? persist : per_auto) >= 3) {   // eight passes of 512 points; with two items
-                                                                                              // per CU the dynamic launch is faster (C = 128: 61 vs 72 us)
-        const int per = persist > 0 ? persist : per_auto;
-        const int grid = (nwork + per - 1) / per;
-        if (Q) {
-            auto kern = edge_gather_max_cloud16p_kernel<true>;
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, stream, g, idx16, nslices, ns, nwork, per);
-        } else {
-            auto kern = edge_gather_max_cloud16p_kernel<false>;
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, stream, g, idx16, nslices, ns, nwork, per);
-        }
-    } else if (Q) {
-        auto kern = edge_gather_max_cloud16_kernel<true>;
+    const bool persistent = persist != 0 && N > 3584 && N <= 4096 && (persist > 0 ? persist : per_auto) >= 3;   // eight passes of 512
+                                              // points; with two items per CU the dynamic launch is faster (C = 128: 61 vs 72 us)
+    const int per = persist > 0 ? persist : per_auto;
+    auto launch_p = [&](auto kern) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((nwork + per - 1) / per), dim3(1024), lds, stream, g, idx16, nslices, ns, nwork, per);
+    };
+    auto launch_d = [&](auto kern) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3((M / N) * nslices), dim3(1024), lds, stream, g, idx16, nslices, ns);
+    };
+    if (persistent) {
+        if (o_lo) { if (Q) launch_p(edge_gather_max_cloud16p_kernel<true, true>); else launch_p(edge_gather_max_cloud16p_kernel<false, true>); }
+        else { if (Q) launch_p(edge_gather_max_cloud16p_kernel<true, false>); else launch_p(edge_gather_max_cloud16p_kernel<false, false>); }
     } else {
-        auto kern = edge_gather_max_cloud16_kernel<false>;
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3((M / N) * nslices), dim3(1024), lds, stream, g, idx16, nslices, ns);
+        if (o_lo) { if (Q) launch_d(edge_gather_max_cloud16_kernel<true, true>); else launch_d(edge_gather_max_cloud16_kernel<false, true>); }
+        else { if (Q) launch_d(edge_gather_max_cloud16_kernel<true, false>); else launch_d(edge_gather_max_cloud16_kernel<false, false>); }
     }
     LPD_CHECK_LAUNCH("lpd_edge_gather_max16");
     return LPD_OK;
+}
+
+extern "C" int lpd_edge_gather_max16(const float* P, int ldp, const float* Q, int ldq, const uint16_t* idx16, float* out,
+                                     int ldo, const float* scale, const float* shift, int M, int N, int C, int k, int act,
+                                     float slope, long long p_cloud, long long q_cloud, long long o_cloud, int panel_ld, void* stream_)
+{
+    return edge_gather_max16_impl(P, ldp, Q, ldq, idx16, out, ldo, scale, shift, M, N, C, k, act, slope, p_cloud, q_cloud, o_cloud,
+                                  panel_ld, 0, stream_);
+}
+
+// the same with SPLIT output: out_hi = hi plane of a pair of bf16 cloud-panel planes [cloud][C/8][panel_ld][8] (o_cloud elements
+// between clouds), the lo plane o_lo elements behind it (hi = bf16(x), lo = bf16(x - hi): what lpd_gemm_p8 / lpd_gemm_x3t read)
+extern "C" int lpd_edge_gather_max16s(const float* P, int ldp, const float* Q, int ldq, const uint16_t* idx16, void* out_hi,
+                                      long long o_lo, const float* scale, const float* shift, int M, int N, int C, int k, int act,
+                                      float slope, long long p_cloud, long long q_cloud, long long o_cloud, int panel_ld, void* stream_)
+{
+    LPD_CHECK_ARG(o_cloud != 0 && o_lo != 0 && (o_lo % 8) == 0, "lpd_edge_gather_max16s: split output needs cloud panels and a lo-plane offset");
+    return edge_gather_max16_impl(P, ldp, Q, ldq, idx16, reinterpret_cast<float*>(out_hi), 8, scale, shift, M, N, C, k, act, slope,
+                                  p_cloud, q_cloud, o_cloud, panel_ld, o_lo, stream_);
 }
 
 extern "C" int lpd_edge_mlp(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
@@ -898,4 +948,15 @@ extern "C" int lpd_edge_mlp_bf16x3(const float* P, int ldp, const float* Q, int 
                                    int M, int N, int CM, int CO, int k, int act, float slope, long long out_cloud, int panel_ld, void* stream)
 {
     return edge_mlp_entry(true, P, ldp, Q, ldq, idx, s1, b1, W2, s2, b2, out, ldo, M, N, CM, CO, k, act, slope, out_cloud, panel_ld, stream);
+}
+
+// lpd_edge_mlp_bf16x3 with SPLIT output: out_hi = hi plane of a pair of bf16 cloud-panel planes (out_cloud elements between clouds),
+// the lo plane out_lo elements behind it
+extern "C" int lpd_edge_mlp_bf16x3s(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
+                                    const float* b1, const float* W2, const float* s2, const float* b2, void* out_hi, long long out_lo,
+                                    int M, int N, int CM, int CO, int k, int act, float slope, long long out_cloud, int panel_ld, void* stream)
+{
+    LPD_CHECK_ARG(out_lo != 0 && out_cloud != 0, "lpd_edge_mlp_bf16x3s: split output needs cloud panels and a lo-plane offset");
+    return edge_mlp_entry(true, P, ldp, Q, ldq, idx, s1, b1, W2, s2, b2, reinterpret_cast<float*>(out_hi), 8, M, N, CM, CO, k, act, slope,
+                          out_cloud, panel_ld, stream, out_lo);
 }

@@ -58,6 +58,7 @@ struct X3tArgs {
     float ns;                      // negative-side slope of the piecewise-linear activation (1 none, 0 ReLU, slope LeakyReLU)
     long long a_cloud, c_cloud;    // floats between clouds
     int panel_n, panel_ld;
+    long long a_lo;                // != 0: A is the hi plane of a pair of split bf16 planes (a_cloud in elements), lo plane a_lo behind
 };
 
 constexpr int XT_THREADS = 256;    // 128 rows per workgroup (a panel cloud is a multiple of 128 rows)
@@ -105,7 +106,21 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
     for (int s = 0; s < KS; ++s) load_w(wave, s);
 
     // ---- the 128 rows, split once: thread -> (row tid / 2, float4 half tid % 2) of every panel ----
-    {
+    if (g.a_lo) {                 // pre-split planes (the producer wrote hi / lo): straight copies
+        const int row = tid >> 1, half = tid & 1;
+        const __bf16* src = reinterpret_cast<const __bf16*>(g.A) + (long long)cloud * g.a_cloud + (long long)(mc0 + row) * 8 + half * 4;
+        uint2 vh[K / 8], vl[K / 8];
+#pragma unroll
+        for (int p = 0; p < K / 8; ++p) {
+            vh[p] = *reinterpret_cast<const uint2*>(src + (long long)p * g.panel_ld * 8);
+            vl[p] = *reinterpret_cast<const uint2*>(src + g.a_lo + (long long)p * g.panel_ld * 8);
+        }
+#pragma unroll
+        for (int p = 0; p < K / 8; ++p) {
+            *reinterpret_cast<uint2*>(img + row * LDK + p * 8 + half * 4) = vh[p];
+            *reinterpret_cast<uint2*>(img + IMG + row * LDK + p * 8 + half * 4) = vl[p];
+        }
+    } else {
         const int row = tid >> 1, half = tid & 1;
         const float* src = A + (long long)(mc0 + row) * 8 + half * 4;
         float4 v[K / 8];
@@ -198,9 +213,9 @@ extern "C" int lpd_gemm_x3t_applies(int M, int N, int K, int act, long long a_cl
            panel_n > 0 && panel_n % 128 == 0 && M % panel_n == 0 && act >= 0 && act <= 2;
 }
 
-extern "C" int lpd_gemm_x3t(const float* A, const void* frags, float* C, int M, int N, int K, const float* bias, const float* scale,
-                            const float* shift, int act, float slope, long long a_cloud, long long c_cloud, int panel_n, int panel_ld,
-                            void* stream_)
+static int gemm_x3t_impl(const float* A, const void* frags, float* C, int M, int N, int K, const float* bias, const float* scale,
+                         const float* shift, int act, float slope, long long a_cloud, long long c_cloud, int panel_n, int panel_ld,
+                         long long a_lo, void* stream_)
 {
     LPD_CHECK_ARG(A && frags && C, "lpd_gemm_x3t: null pointer");
     LPD_CHECK_ARG(lpd_gemm_x3t_applies(M, N, K, act, a_cloud, c_cloud, panel_n),
@@ -214,10 +229,28 @@ extern "C" int lpd_gemm_x3t(const float* A, const void* frags, float* C, int M, 
                   "lpd_gemm_x3t: pointers must be 16-byte aligned");
     const int KS = K / 16, NT = N / 32;
     const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
-    X3tArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, bias, scale, shift, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), a_cloud, c_cloud, panel_n, panel_ld};
+    X3tArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, bias, scale, shift, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), a_cloud, c_cloud, panel_n, panel_ld, a_lo};
     hipStream_t stream = (hipStream_t)stream_;
     if (KS == 8) x3t_launch<8>(g, stream);
     else x3t_launch<4>(g, stream);
     LPD_CHECK_LAUNCH("lpd_gemm_x3t");
     return LPD_OK;
+}
+
+extern "C" int lpd_gemm_x3t(const float* A, const void* frags, float* C, int M, int N, int K, const float* bias, const float* scale,
+                            const float* shift, int act, float slope, long long a_cloud, long long c_cloud, int panel_n, int panel_ld,
+                            void* stream_)
+{
+    return gemm_x3t_impl(A, frags, C, M, N, K, bias, scale, shift, act, slope, a_cloud, c_cloud, panel_n, panel_ld, 0, stream_);
+}
+
+// the same product with A given as SPLIT bf16 planes (a_hi: hi plane [cloud][K/8][panel_ld][8], a_cloud elements between clouds; the lo
+// plane a_lo elements behind it): the x2 block as the fused edge MLP writes it for conv3 (lpd_edge_mlp_bf16x3s)
+extern "C" int lpd_gemm_x3ts(const void* a_hi, long long a_lo, const void* frags, float* C, int M, int N, int K, const float* bias,
+                             const float* scale, const float* shift, int act, float slope, long long a_cloud, long long c_cloud,
+                             int panel_n, int panel_ld, void* stream_)
+{
+    LPD_CHECK_ARG(a_lo != 0 && a_lo % 8 == 0, "lpd_gemm_x3ts: lo-plane offset");
+    return gemm_x3t_impl(reinterpret_cast<const float*>(a_hi), frags, C, M, N, K, bias, scale, shift, act, slope, a_cloud, c_cloud, panel_n,
+                         panel_ld, a_lo, stream_);
 }

@@ -37,6 +37,10 @@ SIGNATURES = {
     "lpd_gemm_x3t": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_ll, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_x3w": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int,
                      _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_p],
+    "lpd_gemm_p8_applies": [_c_int, _c_int, _c_int, _c_int],
+    "lpd_gemm_p8": [_c_p, _c_p, _c_ll, _c_int, _c_p, _c_p, _c_int, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p,
+                    _c_int, _c_f, _c_int, _c_p],
+    "lpd_split_panels": [_c_p, _c_ll, _c_int, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_p],
     "lpd_retrieval_topk": [_c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_f64_to_f32": [_c_p, _c_p, _c_ll, _c_p],
     "lpd_best_pos_bwd": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p],
@@ -49,6 +53,11 @@ SIGNATURES = {
                             _c_int, _c_int, _c_f, _c_p],
     "lpd_edge_gather_max16": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int,
                               _c_int, _c_int, _c_f, _c_ll, _c_ll, _c_ll, _c_int, _c_p],
+    "lpd_edge_gather_max16s": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_ll, _c_p, _c_p, _c_int, _c_int, _c_int,
+                               _c_int, _c_int, _c_f, _c_ll, _c_ll, _c_ll, _c_int, _c_p],
+    "lpd_edge_mlp_bf16x3s": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int,
+                             _c_int, _c_int, _c_int, _c_int, _c_f, _c_ll, _c_int, _c_p],
+    "lpd_gemm_x3ts": [_c_p, _c_ll, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_ll, _c_ll, _c_int, _c_int, _c_p],
     "lpd_pack_idx16": [_c_p, _c_p, ctypes.c_longlong, _c_int, _c_p],
     "lpd_pack_idx16w": [_c_p, _c_p, ctypes.c_longlong, _c_int, _c_p],
     "lpd_edge_gather_maxw": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int,

@@ -22,6 +22,8 @@ DEBUG_AUX = None
 # gathers cache-local).  Tests switch it off to compare intermediate index tensors in the caller's order.
 MORTON_ORDER = True
 MORTON_MAX_POINTS = 16384
+# PointNetVlad.forward (eval) runs batches of more than EVAL_CHUNK x 4096 points as slices of that many points (0: never slice)
+EVAL_CHUNK = int(__import__("os").environ.get("LPD_EVAL_CHUNK", "32"))
 
 
 def reorder_points(x, reorder=True):
@@ -272,6 +274,7 @@ def _kagg_cloud_resident(idx, N, M, act):
 
 
 KAGG_WINDOW = __import__("os").environ.get("LPD_KAGG_WINDOW", "1") != "0"
+CONV3_P8 = __import__("os").environ.get("LPD_P8", "1") != "0"      # conv3 on lpd_gemm_p8 with split-bf16 [x1 | x2 | x3] planes (0: lpd_gemm_x3w)
 
 
 def _kagg_windowed(idx, N, act):
@@ -373,7 +376,16 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side):
         # streams one 8-channel slice of a whole cloud per workgroup, which in this layout is ONE contiguous 32*N-byte run
         # (row-major: N pieces of 32 bytes, ~4x slower through L1/L2), while a GEMM block's 128 rows x K still sit inside one
         # cloud's contiguous block; the GEMMs read / write the panels directly.
-        cat = ops.panels_empty(B, N, 512, x.device)
+        # conv3 on the LDS-DMA ring kernel (lpd_gemm_p8) reads its operand as two bf16 planes (hi + lo), so the producers of
+        # x1 / x2 / x3 write those planes instead of fp32 panels (same bytes) and the SN1 projection reads the x2 planes
+        split = (CONV3_P8 and resident and ops.GEMM_BF16X3 and ops._EXACT.depth == 0 and N % 256 == 0
+                 and net.conv3_lpd.weight.shape[0] % 256 == 0)
+        if split:
+            cat = ops.split_panels_empty(B, N, 512, x.device)
+            x1v, x2v, x3v = cat[:, :, 0:16], cat[:, :, 16:32], cat[:, :, 32:64]
+        else:
+            cat = ops.panels_empty(B, N, 512, x.device)
+            x1v, x2v, x3v = cat[:, 0:16], cat[:, 16:32], cat[:, 32:64]
         if side_job is not None:
             # the DG1-stage K-agg (HBM-bound) runs on the second stream next to the fused edge MLP (MFMA / VALU-bound); both
             # read pq and the feature-space graph and write different panels of `cat`
@@ -384,11 +396,14 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side):
             for t in (idx_f, cat):
                 t.record_stream(side)
             with torch.cuda.stream(side):
-                kagg_p(pq[:, :128], pq[:, 128:], pack(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
+                kagg_p(pq[:, :128], pq[:, 128:], pack(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=x1v)
         else:
-            kagg_p(pq[:, :128], pq[:, 128:], pack(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:16])
-        ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope, out=cat[:, 16:32])
-        pq3 = ops.gemm(cat[:, 16:32], split_edge_weight(net.convSN1, "cat_nc"), b_kmajor=False, a_panels=True, out_panels=True)
+            kagg_p(pq[:, :128], pq[:, 128:], pack(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=x1v)
+        ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope, out=x2v)
+        if split:
+            pq3 = ops.gemm_x3t_split(x2v, split_edge_weight(net.convSN1, "cat_nc"))
+        else:
+            pq3 = ops.gemm(x2v, split_edge_weight(net.convSN1, "cat_nc"), b_kmajor=False, a_panels=True, out_panels=True)
         if side_job is not None:
             side, idx_x, i16_x = side_job
             main = torch.cuda.current_stream()
@@ -398,10 +413,13 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side):
         else:
             idx_x = _knn_rows(xyz, B, N, 3, k)      # static graph in Cartesian space (raw xyz even when t3d, :226,255)
             i16_x = pack(idx_x)
-        kagg_p(pq3[:, 0:32], pq3[:, 32:64], i16_x, N, scale=s3, shift=b3, act=act, slope=slope, out=cat[:, 32:64])
+        kagg_p(pq3[:, 0:32], pq3[:, 32:64], i16_x, N, scale=s3, shift=b3, act=act, slope=slope, out=x3v)
         if DEBUG_AUX is not None:
-            DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=ops.panels_to_rows(cat))
-        feat = ops.gemm(cat, _w2d(net.conv3_lpd), b_kmajor=False, a_panels=True, scale=sc, shift=bc, act=act, slope=slope)
+            DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=ops.split_to_rows(cat) if split else ops.panels_to_rows(cat))
+        if split:
+            feat = ops.gemm_p8(cat, _w2d(net.conv3_lpd), scale=sc, shift=bc, act=act, slope=slope)
+        else:
+            feat = ops.gemm(cat, _w2d(net.conv3_lpd), b_kmajor=False, a_panels=True, scale=sc, shift=bc, act=act, slope=slope)
         return feat, B, N
     if side_job is not None:
         torch.cuda.current_stream().wait_stream(side_job[0])

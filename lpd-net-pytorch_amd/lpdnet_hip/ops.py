@@ -346,6 +346,87 @@ def rows_to_panels(X, B):
     return out
 
 
+def split_panels_empty(B, N, C, device):
+    """Uninitialised SPLIT cloud-panel buffer: the two bf16 planes (hi = bf16(x), lo = bf16(x - hi)) of a [B, C/8, N, 8] activation
+    tensor, as one tensor [2, B, C/8, N(+pad), 8] (the [:, :, :, :N] view is returned): what lpd_gemm_p8 reads."""
+    return torch.empty((2, B, C // 8, N + PANEL_PAD_ROWS, 8), dtype=torch.bfloat16, device=device)[:, :, :, :N]
+
+
+def split_panels(P, out=None):
+    """fp32 cloud panels [B, C/8, N, 8] -> split bf16 planes [2, B, C/8, N, 8] (lpd_split_panels)."""
+    if not _is_panels(P):
+        raise ValueError("split_panels: expected a cloud-panel [B, C/8, N, 8] tensor")
+    Bc, Pn, N, _ = P.shape
+    if out is None:
+        out = split_panels_empty(Bc, N, Pn * 8, P.device)
+    lib = _lib.load()
+    _call("split_panels", lib.lpd_split_panels, _ptr(P), P.stride(0), P.stride(1) // 8, _ptr(out[0]), _ptr(out[1]), out.stride(1),
+          out.stride(2) // 8, Bc, Pn, N, _stream())
+    return out
+
+
+def _is_split(t):
+    """a (panel-range view of a) split cloud-panel buffer: [2, B, P, N, 8] bf16"""
+    return (t is not None and t.dim() == 5 and t.dtype == torch.bfloat16 and t.shape[0] == 2 and t.shape[4] == 8 and t.stride(4) == 1
+            and t.stride(3) == 8 and t.stride(2) % 8 == 0 and t.stride(2) >= t.shape[3] * 8)
+
+
+def split_to_rows(S):
+    """split cloud panels [2, B, C/8, N, 8] -> row-major fp32 [B*N, C] (hi + lo; diagnostics / tests)."""
+    x = S[0].float() + S[1].float()
+    Bc, Pn, N, _ = x.shape
+    return x.permute(0, 2, 1, 3).reshape(Bc * N, Pn * 8).contiguous()
+
+
+P8_IMPL = int(os.environ.get("LPD_P8_IMPL", "0"))
+
+
+def gemm_x3t_split(S, W, *, out=None):
+    """S [2, B, K/8, N, 8] split planes x W [Nout, K] -> fp32 cloud panels [B, Nout/8, N, 8] (the bare product: the neighbour / centre
+    projections of the split SN1 edge convolution from the x2 block as the fused edge MLP writes it for conv3)."""
+    _req(W, "W")
+    if not _is_split(S):
+        raise ValueError("gemm_x3t_split: expected split cloud panels [2, B, K/8, N, 8] (bf16)")
+    _, Bc, Pn, Np, _ = S.shape
+    M, K, N = Bc * Np, Pn * 8, W.shape[0]
+    if out is None:
+        out = panels_empty(Bc, Np, N, S.device)
+    lib = _lib.load()
+    if (W.shape[1] != K or not _is_panels(out) or out.shape[1] * 8 != N or out.shape[2] != Np or out.stride(1) != S.stride(2)
+            or not lib.lpd_gemm_x3t_applies(M, N, K, 0, S.stride(1), out.stride(0), Np)):
+        raise ValueError(f"gemm_x3t_split: shape not built (M={M}, N={N}, K={K}, points per cloud {Np})")
+    frags = _weight_frags(W, False, N, K)
+    _call(f"gemmx3t[{M}x{N}x{K}]", lib.lpd_gemm_x3ts, _ptr(S[0]), S.stride(0), _ptr(frags), _ptr(out), M, N, K, None, None, None, 0, 0.0,
+          S.stride(1), out.stride(0), Np, out.stride(1) // 8, _stream())
+    return out
+
+
+def gemm_p8(S, W, *, scale=None, shift=None, act=ACT_NONE, slope=0.01, out=None, out_panels=False):
+    """act(scale * (A W^T) + shift) for split cloud-panel activations S [2, B, K/8, N, 8] (split_panels / the producers' split
+    epilogues) and a weight W [Nout, K] (torch conv layout): lpd_gemm_p8.  out: row-major [B*N, Nout] or fp32 cloud panels."""
+    _req(W, "W")
+    two, Bc, Pn, Np, _ = S.shape
+    if two != 2 or S.dtype != torch.bfloat16 or S.stride(4) != 1 or S.stride(3) != 8:
+        raise ValueError("gemm_p8: expected split cloud panels [2, B, K/8, N, 8] (bf16)")
+    M, K, N = Bc * Np, Pn * 8, W.shape[0]
+    lib = _lib.load()
+    if W.shape[1] != K or not lib.lpd_gemm_p8_applies(M, N, K, Np):
+        raise ValueError(f"gemm_p8: shape not built (M={M}, N={N}, K={K}, points per cloud {Np})")
+    if out is None:
+        out = panels_empty(Bc, Np, N, S.device) if out_panels else torch.empty((M, N), dtype=torch.float32, device=S.device)
+    if out_panels:
+        if not _is_panels(out) or out.shape[1] * 8 != N or out.shape[2] != Np:
+            raise ValueError("gemm_p8: out_panels expects a cloud-panel [B, Nout/8, N, 8] tensor")
+        ldc, c_cloud, c_ld = 8, out.stride(0), out.stride(1) // 8
+    else:
+        ldc, c_cloud, c_ld = _rows(out, "out"), 0, 0
+    scale, shift = _vec(scale, "scale", N), _vec(shift, "shift", N)
+    frags = _weight_frags(W, False, N, K)
+    _call(f"gemm_p8[{M}x{N}x{K}]", lib.lpd_gemm_p8, _ptr(S[0]), _ptr(S[1]), S.stride(1), S.stride(2) // 8, _ptr(frags), _ptr(out), ldc,
+          c_cloud, c_ld, M, N, K, Np, _ptr(scale), _ptr(shift), act, float(slope), P8_IMPL, _stream())
+    return out
+
+
 def _is_panels(t):
     """a (view of a) cloud-panel buffer: [B, P, N, 8] with strides (anything, panel_ld * 8 >= N * 8, 8, 1)"""
     return (t is not None and t.dim() == 4 and t.shape[3] == 8 and t.stride(3) == 1 and t.stride(2) == 8
@@ -521,6 +602,18 @@ def edge_gather_max16(P, Q, idx16, N, *, scale=None, shift=None, act=ACT_NONE, s
         raise ValueError("edge_gather_max16: idx16 must come from pack_idx16 of this graph")
     if out is None:
         out = torch.empty((M, C), dtype=torch.float32, device=P.device)
+    if _is_split(out):           # split bf16 planes for lpd_gemm_p8 (same bytes as the fp32 panels)
+        if out.shape[2] * 8 != C or out.shape[3] != N or out.shape[1] * N != M or not (pan_p and (Q is None or pan_q)):
+            raise ValueError("edge_gather_max16: split out must be a [2, B, C/8, N, 8] view and P / Q cloud panels")
+        if out.stride(2) // 8 != _panel_ld(P, Q):
+            raise ValueError("edge_gather_max16: split out and P / Q must share the panel stride")
+        _req(P, "P"); _req(Q, "Q")
+        scale, shift = _vec(scale, "scale", C), _vec(shift, "shift", C)
+        lib = _lib.load()
+        _call(f"edge_gather_max16[C={C}]", lib.lpd_edge_gather_max16s, _ptr(P), 8, _ptr(Q), 0 if Q is None else 8, _ptr(idx16), _ptr(out[0]),
+              out.stride(0), _ptr(scale), _ptr(shift), M, N, C, k, act, float(slope), P.stride(0), Q.stride(0) if Q is not None else 0,
+              out.stride(1), out.stride(2) // 8, _stream())
+        return out
     pan_o = out.dim() == 4
     for t, pan, name in ((P, pan_p, "P"), (Q, pan_q, "Q"), (out, pan_o, "out")):
         _req(t, name)
@@ -560,6 +653,18 @@ def edge_gather_maxw(P, Q, idx16, N, *, scale=None, shift=None, act=ACT_NONE, sl
         raise ValueError("edge_gather_maxw: idx16 must come from pack_idx16w of this graph")
     if out is None:
         out = torch.empty((M, C), dtype=torch.float32, device=P.device)
+    if _is_split(out):           # split bf16 planes for lpd_gemm_p8 (same bytes as the fp32 panels)
+        if out.shape[2] * 8 != C or out.shape[3] != N or out.shape[1] * N != M or not (pan_p and (Q is None or pan_q)):
+            raise ValueError("edge_gather_max16: split out must be a [2, B, C/8, N, 8] view and P / Q cloud panels")
+        if out.stride(2) // 8 != _panel_ld(P, Q):
+            raise ValueError("edge_gather_max16: split out and P / Q must share the panel stride")
+        _req(P, "P"); _req(Q, "Q")
+        scale, shift = _vec(scale, "scale", C), _vec(shift, "shift", C)
+        lib = _lib.load()
+        _call(f"edge_gather_max16[C={C}]", lib.lpd_edge_gather_max16s, _ptr(P), 8, _ptr(Q), 0 if Q is None else 8, _ptr(idx16), _ptr(out[0]),
+              out.stride(0), _ptr(scale), _ptr(shift), M, N, C, k, act, float(slope), P.stride(0), Q.stride(0) if Q is not None else 0,
+              out.stride(1), out.stride(2) // 8, _stream())
+        return out
     pan_o = out.dim() == 4
     for t, pan, name in ((P, pan_p, "P"), (Q, pan_q, "Q"), (out, pan_o, "out")):
         _req(t, name)
@@ -597,6 +702,17 @@ def _edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, act, slope, out, exact):
     if out is None:
         out = torch.empty((M, CO), dtype=torch.float32, device=P.device)
     out_cloud = 0
+    if _is_split(out):
+        if out.shape[2] * 8 != CO or out.shape[1] * out.shape[3] != M or out.shape[3] != N:
+            raise ValueError("edge_mlp: split out must be a [2, B, CO/8, N, 8] view")
+        if not (GEMM_BF16X3 and not exact and _EXACT.depth == 0):
+            raise ValueError("edge_mlp: split output is written by the split-bf16 kernel only")
+        s1, b1 = _vec(s1, "s1", CM), _vec(b1, "b1", CM)
+        s2, b2 = _vec(s2, "s2", CO), _vec(b2, "b2", CO)
+        lib = _lib.load()
+        _call(f"edge_mlpx3[{CM}->{CO}]", lib.lpd_edge_mlp_bf16x3s, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(s1), _ptr(b1), _ptr(W2), _ptr(s2),
+              _ptr(b2), _ptr(out[0]), out.stride(0), M, N, CM, CO, k, act, float(slope), out.stride(1), out.stride(2) // 8, _stream())
+        return out
     if out.dim() == 4:
         if not _is_panels(out) or out.shape[1] * 8 != CO or out.shape[0] * out.shape[2] != M or out.shape[2] != N:
             raise ValueError("edge_mlp: cloud-panel out must be a [B, CO/8, N, 8] view")

@@ -876,3 +876,106 @@ def test_gemm_tn_weight_gradient_kernel(cuda, M, KA, KB):
         got3 = ops.gemm_tn(A3, B3)
         assert got3.shape == (nb, KA, KB)
         assert _rel(got3, torch.einsum("bma,bmc->bac", A3.double(), B3.double())) < 2e-5
+
+
+# ------------------------------------------------------------------ split-bf16 planes + lpd_gemm_p8 (conv3 of the eval path)
+def _split_ref(x):
+    """hi = bf16(x), lo = bf16(x - hi) as torch computes them (round to nearest even)"""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+@pytest.mark.parametrize("Bc,Np,K,N,act,panels", [(2, 256, 512, 1024, 2, False), (3, 512, 64, 256, 1, True), (1, 768, 512, 512, 0, True),
+                                                  (9, 256, 96, 256, 2, False), (32, 256, 512, 1024, 2, True)])
+def test_gemm_p8_split_panels(cuda, Bc, Np, K, N, act, panels):
+    """lpd_gemm_p8 (256 x 256 tiles, LDS-DMA ring, persistent workgroups; pre-split bf16 cloud-panel A, prepared weight fragments)
+    against a float64 product: fp32-grade (three products per term), every epilogue term, row-major and cloud-panel C, tile counts
+    below / at / above one tile per workgroup, K from 2 to 16 ring K-tiles; 10 repeated launches are bit-identical (a race in the
+    DMA ring shows up as run-to-run differences); lpd_split_panels reproduces torch's hi / lo rounding bit for bit."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(7 + Bc + Np + K + N)
+    M = Bc * Np
+    X = (torch.randn(M, K, generator=g) * 2.0).to(cuda)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    sc, sh = torch.randn(N, generator=g).to(cuda), torch.randn(N, generator=g).to(cuda)
+    S = ops.split_panels(ops.rows_to_panels(X, Bc))
+    hi, lo = _split_ref(X)
+    to_rows = lambda P: P.permute(0, 2, 1, 3).reshape(M, K)
+    assert torch.equal(to_rows(S[0]), hi) and torch.equal(to_rows(S[1]), lo)
+    ref = (X.double() @ W.double().t()) * sc.double() + sh.double()
+    ref = ref if act == 0 else torch.where(ref > 0, ref, ref * (0.0 if act == 1 else 0.05))
+    for impl in (5, 6):
+        ops.P8_IMPL = impl
+        try:
+            if panels:
+                wide = ops.panels_empty(Bc, Np, N + 64, cuda)
+                wide.fill_(-7.0)
+                out = ops.gemm_p8(S, W, scale=sc, shift=sh, act=act, slope=0.05, out=wide[:, 4:4 + N // 8], out_panels=True)
+                rows = ops.panels_to_rows(out)
+                assert bool((wide[:, :4] == -7.0).all()) and bool((wide[:, 4 + N // 8:] == -7.0).all())
+            else:
+                buf = torch.full((M, N + 8), -7.0, device=cuda)
+                rows = ops.gemm_p8(S, W, scale=sc, shift=sh, act=act, slope=0.05, out=buf[:, 4:4 + N])
+                assert bool((buf[:, :4] == -7.0).all()) and bool((buf[:, 4 + N:] == -7.0).all())
+            assert _rel(rows, ref) < 2e-5
+            first = rows.clone()
+            for _ in range(10):
+                again = ops.gemm_p8(S, W, scale=sc, shift=sh, act=act, slope=0.05, out_panels=panels)
+                assert torch.equal(ops.panels_to_rows(again) if panels else again, first)
+        finally:
+            ops.P8_IMPL = 0
+    bare = ops.gemm_p8(S, W)
+    assert _rel(bare, X.double() @ W.double().t()) < 2e-5
+    with pytest.raises(ValueError):
+        ops.gemm_p8(S[:, :, :, :Np - 128], W)            # clouds must be multiples of 256 points
+
+
+@pytest.mark.parametrize("C,N,B,hasq", [(256, 4096, 2, True), (128, 1024, 3, True), (64, 512, 2, False), (256, 3800, 1, True)])
+def test_kagg_split_output_is_the_split_of_the_fp32_output(cuda, C, N, B, hasq):
+    """lpd_edge_gather_max16s: the hi / lo planes the cloud-resident K-agg writes for conv3 are bit for bit bf16(x) and
+    bf16(x - bf16(x)) of the fp32 result of lpd_edge_gather_max16 (persistent and one-item-per-workgroup forms), written into a
+    panel sub-range of a wider pair of planes with untouched neighbours."""
+    ops = _ops()
+    P, Q, idx, scale, shift = _edge_inputs(B, N, C, 20, C + N + 3)
+    Pp, Qp = ops.rows_to_panels(P.to(cuda), B), ops.rows_to_panels(Q.to(cuda), B)
+    idx16 = ops.pack_idx16(idx.to(cuda))
+    q = Qp if hasq else None
+    want = ops.panels_to_rows(ops.edge_gather_max16(Pp, q, idx16, N, scale=scale.to(cuda), shift=shift.to(cuda), act=ops.ACT_LEAKY,
+                                                    slope=0.01, out=ops.panels_empty(B, N, C, cuda)))
+    wide = ops.split_panels_empty(B, N, C + 128, cuda)
+    wide.fill_(3.0)
+    got = ops.edge_gather_max16(Pp, q, idx16, N, scale=scale.to(cuda), shift=shift.to(cuda), act=ops.ACT_LEAKY, slope=0.01,
+                                out=wide[:, :, 8:8 + C // 8])
+    hi, lo = _split_ref(want)
+    to_rows = lambda Pn: Pn.permute(0, 2, 1, 3).reshape(B * N, C)
+    assert torch.equal(to_rows(got[0]), hi) and torch.equal(to_rows(got[1]), lo)
+    assert bool((wide[:, :, :8] == 3.0).all()) and bool((wide[:, :, 8 + C // 8:] == 3.0).all())
+    assert _rel(ops.split_to_rows(got), want) < 2e-5
+
+
+@pytest.mark.parametrize("CM,N,B", [(128, 512, 2), (64, 256, 3)])
+def test_edge_mlp_split_output_and_x3t_on_split_planes(cuda, CM, N, B):
+    """lpd_edge_mlp_bf16x3s writes the x2 block as hi / lo planes (bit for bit the split of its fp32 output), and lpd_gemm_x3ts
+    multiplies those planes: bit-identical to lpd_gemm_x3t on the fp32 panels (the same LDS images, the same products)."""
+    ops = _ops()
+    k = 20
+    P, Q, idx, s1, b1 = _edge_inputs(B, N, CM, k, CM + N)
+    g = torch.Generator().manual_seed(5)
+    W2 = (torch.randn(CM, CM, generator=g) / CM ** 0.5).to(cuda)
+    s2, b2 = torch.randn(CM, generator=g).to(cuda), torch.randn(CM, generator=g).to(cuda)
+    args = (P.to(cuda), Q.to(cuda), idx.to(cuda), N, s1.to(cuda), b1.to(cuda), W2, s2, b2)
+    want_p = ops.edge_mlp(*args, act=ops.ACT_LEAKY, slope=0.01, out=ops.panels_empty(B, N, CM, cuda))
+    want = ops.panels_to_rows(want_p)
+    wide = ops.split_panels_empty(B, N, CM + 64, cuda)
+    wide.fill_(3.0)
+    got = ops.edge_mlp(*args, act=ops.ACT_LEAKY, slope=0.01, out=wide[:, :, 4:4 + CM // 8])
+    hi, lo = _split_ref(want)
+    to_rows = lambda Pn: Pn.permute(0, 2, 1, 3).reshape(B * N, CM)
+    assert torch.equal(to_rows(got[0]), hi) and torch.equal(to_rows(got[1]), lo)
+    assert bool((wide[:, :, :4] == 3.0).all()) and bool((wide[:, :, 4 + CM // 8:] == 3.0).all())
+    if N % 128 == 0:
+        Wp = (torch.randn(2 * CM, CM, generator=g) / CM ** 0.5).to(cuda)
+        a = ops.gemm(want_p, Wp, b_kmajor=False, a_panels=True, out_panels=True)
+        b = ops.gemm_x3t_split(got, Wp)
+        assert torch.equal(a, b)

@@ -96,7 +96,7 @@ def test_grad_allreduce_world2_real_model_one_gpu(cuda, tmp_path):
         m = m.to(cuda).train()
         _step(m, w2.tuples_of_rank(rank, B, N).to(cuda), bq, P, Ng)
         singles.append({n: p.grad.detach().cpu() for n, p in m.named_parameters()})
-    assert torch.equal(r[0]["w_probe"], r[1]["w_probe"]) and torch.equal(r[0]["w_probe"], sd["emb_nn.conv3_lpd.weight"][:4, :4].view(4, 4))
+    assert torch.equal(r[0]["w_probe"], r[1]["w_probe"]) and torch.equal(r[0]["w_probe"].view(4, 4), sd["emb_nn.conv3_lpd.weight"][:4, :4].view(4, 4))
     worst = {}
     for n in singles[0]:
         assert torch.equal(r[0]["grads"][n], r[1]["grads"][n]), n            # one reduced gradient on both ranks

@@ -523,14 +523,22 @@ def test_train_step0_cfg2_full_size_vs_reference(cuda, golden_dir, storage):
 
 
 # storage -> (descriptor max, descriptor median [norm-relative to the reference's fp64 forward], loss, gradient max, gradient median)
-CFG2_GATES = {"f32": (1e-3, 1.5e-4, 2e-3, 1e-2, 2.5e-3),
-              "bf16": (BF16_DESC_TOL, BF16_DESC_TOL, BF16_LOSS_TOL, BF16_GRAD_TOL, BF16_GRAD_MEDIAN)}
+# Measured on MI355X (round 3): fp32 storage 2.3e-4 / 2.8e-5 (closer to fp64 than the reference's own fp32 run: 3.2e-4 / 7.3e-5),
+# loss 2e-6, gradients vs the reference's fp32 autograd 1.7e-3 max / 7.7e-4 median, running statistics 5e-5;
+# bf16 storage 2.7e-3 / 1.4e-3, loss 4.9e-4, gradients 3.2e-2 max / 9.2e-3 median -- 5-10x tighter than on the B = 6 / B = 16
+# fixtures (test_train_bf16_storage_vs_oracle: 1.8e-2, 1.5 %, 7-12 %), as expected when the head's BatchNorms run over 44 rows
+# instead of 6, and that is what the gates below state.
+CFG2_GATES = {"f32": (1e-3, 1.5e-4, 5e-4, 1e-2, 2.5e-3),
+              "bf16": (1e-2, 5e-3, 5e-3, 0.1, 0.03)}
 
 
 def test_bf16_storage_converges_like_fp32(cuda):
-    """30 Adam steps on a FIXED set of 8 tuples (bq = 2 -> four batches, cycled), fp32 storage against bf16 storage from the same
+    """32 Adam steps on a FIXED set of 8 tuples (bq = 2 -> four batches, cycled), fp32 storage against bf16 storage from the same
     initial weights: both losses must fall, and the bf16 run must end within 10 % of the fp32 run (mean loss over the last cycle
-    of four batches)."""
+    of four batches).  The margins are 40 / 20 instead of the reference's 0.5 / 0.2 so that the hinges stay active over the whole
+    run: with 0.5 / 0.2 these tuples are separated after ONE update (measured: losses 10.0, 0, 0, 21.8, then exactly 0 in both
+    modes), which compares nothing."""
+    import loss.pointnetvlad_loss as L
     from lpdnet_hip import autograd
     N, bq, P, Ng, steps = 1024, 2, 2, 2, 32
     per = 1 + P + Ng + 1
@@ -544,7 +552,9 @@ def test_bf16_storage_converges_like_fp32(cuda):
             losses = []
             for it in range(steps):
                 opt.zero_grad(set_to_none=True)
-                _, loss = _step(m, tuples[it % 4], bq, P, Ng)
+                q, p, n, o = torch.split(m(tuples[it % 4]).view(bq, -1, 256), [1, P, Ng, 1], dim=1)
+                loss = L.quadruplet_loss(q, p, n, o, 40.0, 20.0, use_min=True, lazy=True, ignore_zero_loss=False)
+                loss.backward()
                 opt.step()
                 losses.append(loss.item())
         finally:
