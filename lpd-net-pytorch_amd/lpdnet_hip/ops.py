@@ -603,16 +603,19 @@ def edge_gather_max16(P, Q, idx16, N, *, scale=None, shift=None, act=ACT_NONE, s
     if out is None:
         out = torch.empty((M, C), dtype=torch.float32, device=P.device)
     if _is_split(out):           # split bf16 planes for lpd_gemm_p8 (same bytes as the fp32 panels)
-        if out.shape[2] * 8 != C or out.shape[3] != N or out.shape[1] * N != M or not (pan_p and (Q is None or pan_q)):
-            raise ValueError("edge_gather_max16: split out must be a [2, B, C/8, N, 8] view and P / Q cloud panels")
-        if out.stride(2) // 8 != _panel_ld(P, Q):
-            raise ValueError("edge_gather_max16: split out and P / Q must share the panel stride")
-        _req(P, "P"); _req(Q, "Q")
+        if out.shape[2] * 8 != C or out.shape[3] != N or out.shape[1] * N != M:
+            raise ValueError("edge_gather_max16: split out must be a [2, B, C/8, N, 8] view")
+        for t, pan, name in ((P, pan_p, "P"), (Q, pan_q, "Q")):
+            _req(t, name)
+            if t is not None and pan and (not _is_panels(t) or t.shape[1] * 8 != C or t.shape[2] != N or t.shape[0] * N != M
+                                          or t.stride(1) != out.stride(2)):
+                raise ValueError(f"edge_gather_max16: cloud-panel {name} must be a [B, C/8, N, 8] view with the panel stride of out")
         scale, shift = _vec(scale, "scale", C), _vec(shift, "shift", C)
         lib = _lib.load()
-        _call(f"edge_gather_max16[C={C}]", lib.lpd_edge_gather_max16s, _ptr(P), 8, _ptr(Q), 0 if Q is None else 8, _ptr(idx16), _ptr(out[0]),
-              out.stride(0), _ptr(scale), _ptr(shift), M, N, C, k, act, float(slope), P.stride(0), Q.stride(0) if Q is not None else 0,
-              out.stride(1), out.stride(2) // 8, _stream())
+        _call(f"edge_gather_max16[C={C}]", lib.lpd_edge_gather_max16s, _ptr(P), 8 if pan_p else _rows(P, "P"), _ptr(Q),
+              0 if Q is None else (8 if pan_q else _rows(Q, "Q")), _ptr(idx16), _ptr(out[0]), out.stride(0), _ptr(scale), _ptr(shift),
+              M, N, C, k, act, float(slope), P.stride(0) if pan_p else 0, Q.stride(0) if pan_q else 0, out.stride(1),
+              out.stride(2) // 8, _stream())
         return out
     pan_o = out.dim() == 4
     for t, pan, name in ((P, pan_p, "P"), (Q, pan_q, "Q"), (out, pan_o, "out")):
@@ -654,16 +657,19 @@ def edge_gather_maxw(P, Q, idx16, N, *, scale=None, shift=None, act=ACT_NONE, sl
     if out is None:
         out = torch.empty((M, C), dtype=torch.float32, device=P.device)
     if _is_split(out):           # split bf16 planes for lpd_gemm_p8 (same bytes as the fp32 panels)
-        if out.shape[2] * 8 != C or out.shape[3] != N or out.shape[1] * N != M or not (pan_p and (Q is None or pan_q)):
-            raise ValueError("edge_gather_max16: split out must be a [2, B, C/8, N, 8] view and P / Q cloud panels")
-        if out.stride(2) // 8 != _panel_ld(P, Q):
-            raise ValueError("edge_gather_max16: split out and P / Q must share the panel stride")
-        _req(P, "P"); _req(Q, "Q")
+        if out.shape[2] * 8 != C or out.shape[3] != N or out.shape[1] * N != M:
+            raise ValueError("edge_gather_max16: split out must be a [2, B, C/8, N, 8] view")
+        for t, pan, name in ((P, pan_p, "P"), (Q, pan_q, "Q")):
+            _req(t, name)
+            if t is not None and pan and (not _is_panels(t) or t.shape[1] * 8 != C or t.shape[2] != N or t.shape[0] * N != M
+                                          or t.stride(1) != out.stride(2)):
+                raise ValueError(f"edge_gather_max16: cloud-panel {name} must be a [B, C/8, N, 8] view with the panel stride of out")
         scale, shift = _vec(scale, "scale", C), _vec(shift, "shift", C)
         lib = _lib.load()
-        _call(f"edge_gather_max16[C={C}]", lib.lpd_edge_gather_max16s, _ptr(P), 8, _ptr(Q), 0 if Q is None else 8, _ptr(idx16), _ptr(out[0]),
-              out.stride(0), _ptr(scale), _ptr(shift), M, N, C, k, act, float(slope), P.stride(0), Q.stride(0) if Q is not None else 0,
-              out.stride(1), out.stride(2) // 8, _stream())
+        _call(f"edge_gather_max16[C={C}]", lib.lpd_edge_gather_max16s, _ptr(P), 8 if pan_p else _rows(P, "P"), _ptr(Q),
+              0 if Q is None else (8 if pan_q else _rows(Q, "Q")), _ptr(idx16), _ptr(out[0]), out.stride(0), _ptr(scale), _ptr(shift),
+              M, N, C, k, act, float(slope), P.stride(0) if pan_p else 0, Q.stride(0) if pan_q else 0, out.stride(1),
+              out.stride(2) // 8, _stream())
         return out
     pan_o = out.dim() == 4
     for t, pan, name in ((P, pan_p, "P"), (Q, pan_q, "Q"), (out, pan_o, "out")):

@@ -517,3 +517,30 @@ def test_second_backward_raises_a_clear_error(cuda):
     loss.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="second time"):
         loss.backward()
+
+
+@pytest.mark.parametrize("env", [{"LPD_GEMM_FP32": "1"}, {"LPD_SIDE_STREAM": "0"}, {"LPD_SIDE_STREAM": "1"}, {"LPD_P8": "0"},
+                                 {"LPD_PANELS": "0"}, {"LPD_FUSED_FRONT": "0"}, {"LPD_KNN_PRE": "0"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_documented_switches_are_live(cuda, env):
+    """The environment switches README.md documents are read at import, so each one is exercised in a fresh interpreter: the
+    smoke forward (LPD-Net eval, B = 6, N = 512 and the N = 4096 golden case) must hold the 1e-4 descriptor bar under every one."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import numpy as np, torch\n"
+            "import __graft_entry__ as g\n"
+            "g.smoke()\n"
+            "from oracle import lpd_oracle as orc, synth\n"
+            "from util.PointNetVlad import PointNetVlad\n"
+            "gold = np.load(%r)\n"
+            "m = PointNetVlad(num_points=4096, featnet='lpdnet'); m.load_state_dict(orc.synthetic_state('lpdnet', num_points=4096)); m = m.cuda().eval()\n"
+            "x = torch.from_numpy(synth.cloud(int(gold['seed']), 2, 4096)).unsqueeze(1).cuda()\n"
+            "with torch.no_grad(): d = m(x).cpu()\n"
+            "ref = torch.from_numpy(gold['desc'])\n"
+            "rel = ((d - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)).max().item()\n"
+            "print('golden rel', rel); assert rel < 1e-4, rel\n") % (root, os.path.join(root, "lpd-net-pytorch_amd"),
+                                                                      os.path.join(root, "tests", "golden", "eval_lpdnet_b2_n4096.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "golden rel" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

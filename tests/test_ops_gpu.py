@@ -952,9 +952,14 @@ def test_kagg_split_output_is_the_split_of_the_fp32_output(cuda, C, N, B, hasq):
     assert torch.equal(to_rows(got[0]), hi) and torch.equal(to_rows(got[1]), lo)
     assert bool((wide[:, :, :8] == 3.0).all()) and bool((wide[:, :, 8 + C // 8:] == 3.0).all())
     assert _rel(ops.split_to_rows(got), want) < 2e-5
+    # row-major P | Q (the DG1 stage: halves of one projection output) into split planes
+    PQ = torch.cat([P, Q], dim=1).to(cuda)
+    got2 = ops.edge_gather_max16(PQ[:, :C], PQ[:, C:] if hasq else None, idx16, N, scale=scale.to(cuda), shift=shift.to(cuda),
+                                 act=ops.ACT_LEAKY, slope=0.01, out=ops.split_panels_empty(B, N, C, cuda))
+    assert torch.equal(to_rows(got2[0]), hi) and torch.equal(to_rows(got2[1]), lo)
 
 
-@pytest.mark.parametrize("CM,N,B", [(128, 512, 2), (64, 256, 3)])
+@pytest.mark.parametrize("CM,N,B", [(128, 512, 2), (64, 256, 4)])
 def test_edge_mlp_split_output_and_x3t_on_split_planes(cuda, CM, N, B):
     """lpd_edge_mlp_bf16x3s writes the x2 block as hi / lo planes (bit for bit the split of its fp32 output), and lpd_gemm_x3ts
     multiplies those planes: bit-identical to lpd_gemm_x3t on the fp32 panels (the same LDS images, the same products)."""
