@@ -473,17 +473,30 @@ int lpd_gemm_tn(const float* A, long long lda, const float* B, long long ldb, fl
 
 /*
  * conv3_lpd of the eval path (util/lpdnet_model.py:262: 512 -> emb_dims per point, + bn3 + activation) on PRE-SPLIT operands:
- *   C[m][n] = act(scale[n] * sum_k A[m][k] W[n][k] + shift[n]),   A = a_hi + a_lo,  three bf16 MFMA products per term (fp32-grade)
+ *   C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]),   A = a_hi + a_lo,  three bf16 MFMA products per term (fp32-grade); an
+ *   eval-mode BatchNorm rides as W = diag(scale) W_conv, bias = shift
  * a_hi / a_lo: bf16 cloud panels [cloud][K/8][a_panel_ld][8] (hi = bf16(x), lo = bf16(x - hi); written by the producers of
  * [x1 | x2 | x3] or by lpd_split_panels), a_cloud bf16 elements apart; frags: lpd_gemm_prep_b(W [N][K], b_kmajor = 0);
  * C: row-major [M][ldc] (c_cloud = 0) or fp32 cloud panels [cloud][N/8][c_panel_ld][8], c_cloud floats apart.
  * 256 x 256 block tiles, LDS-DMA ring, persistent workgroups (csrc/lpd_gemm_p8.hip).  lpd_gemm_p8_applies: N % 256 == 0,
- * K % 32 == 0, clouds of a multiple of 256 points.  act none / ReLU / LeakyReLU.  impl: 0 (= 5) or 5 / 6 staging units in flight.
+ * K % 32 == 0, K >= 64, clouds of a multiple of 256 points.  act none / ReLU / LeakyReLU (0 <= slope <= 1).  impl: 0 (= 6) or
+ * 5 / 6 staging units in flight.
  */
 int lpd_gemm_p8_applies(int M, int N, int K, int panel_n);
 int lpd_gemm_p8(const void* a_hi, const void* a_lo, long long a_cloud, int a_panel_ld, const void* frags, float* C, int ldc,
-                long long c_cloud, int c_panel_ld, int M, int N, int K, int panel_n, const float* scale, const float* shift,
+                long long c_cloud, int c_panel_ld, int M, int N, int K, int panel_n, const float* bias,
                 int act, float slope, int impl, void* stream);
+/* lpd_gemm_p8 + the NetVLAD assignment product (util/PointNetVlad.py:48, x . cluster_weights) of its own output in the same launch:
+ * besides C, parts[j][m][0..64) = C[m][256 j .. 256 j + 255] . W2[256 j .. 256 j + 255][0..64) for the N / 256 column blocks j
+ * (part_stride floats between the planes); lpd_softmax_affine_parts sums the planes.  w2_frags: lpd_gemm_prep_b(W2 [N][64], ldb,
+ * b_kmajor = 1, 64, N). */
+int lpd_gemm_p8_fused(const void* a_hi, const void* a_lo, long long a_cloud, int a_panel_ld, const void* frags, float* C, int ldc,
+                      long long c_cloud, int c_panel_ld, int M, int N, int K, int panel_n, const float* bias, int act, float slope,
+                      const void* w2_frags, float* parts, long long part_stride, void* stream);
+/* softmax(scale * (sum of `parts` planes of in, part_stride floats apart) + shift) over 64 columns, with the per-group column sums
+ * of lpd_softmax_affine (group_rows % 64 == 0); parts in {1, 2, 4, 8} */
+int lpd_softmax_affine_parts(const float* in, int parts, long long part_stride, float* out, int rows, const float* scale,
+                             const float* shift, int group_rows, float* colsum, int colsum_ld, void* stream);
 /* fp32 cloud panels [clouds][panels][s_panel_ld][8] (s_cloud floats apart) -> the two bf16 planes hi / lo of the same layout
  * ([clouds][panels][d_panel_ld][8], d_cloud elements apart); n rows per panel are converted. */
 int lpd_split_panels(const float* src, long long s_cloud, int s_panel_ld, void* hi, void* lo, long long d_cloud, int d_panel_ld,

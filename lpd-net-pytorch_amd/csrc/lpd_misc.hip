@@ -113,9 +113,12 @@ __global__ __launch_bounds__(256) void softmax_affine_colsum_kernel(const float*
 
 // 64 columns: sixteen lanes per row (float4 each), four rows per wave-instruction -- 1 KiB loads / stores and four
 // shuffle steps per reduction instead of 256-byte accesses and six (36 -> 2x faster at 131072 rows).
+// parts > 1: the input is the SUM of `parts` planes, part_stride floats apart (the per-column-block partial products of
+// lpd_gemm_p8_fused)
+template <int PARTS = 1>
 __global__ __launch_bounds__(256) void softmax_affine_colsum64_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
                                                                       const float* scale, const float* shift, int group_rows,
-                                                                      float* __restrict__ colsum, int colsum_ld)
+                                                                      float* __restrict__ colsum, int colsum_ld, long long part_stride = 0)
 {
     const int lane = threadIdx.x & 63;
     const int q = lane & 15, sub = lane >> 4;                  // column quad, row inside the group of four
@@ -126,7 +129,12 @@ __global__ __launch_bounds__(256) void softmax_affine_colsum64_kernel(const floa
 #pragma unroll
     for (int r = 0; r < SM_RPW; r += 4) {
         const long long row = row0 + r + sub;
-        float4 v = *reinterpret_cast<const float4*>(in + row * 64 + 4 * q);
+        float4 pv[PARTS];
+#pragma unroll
+        for (int pz = 0; pz < PARTS; ++pz) pv[pz] = *reinterpret_cast<const float4*>(in + pz * part_stride + row * 64 + 4 * q);   // all in flight
+        float4 v = pv[0];
+#pragma unroll
+        for (int pz = 1; pz < PARTS; ++pz) { v.x += pv[pz].x; v.y += pv[pz].y; v.z += pv[pz].z; v.w += pv[pz].w; }
         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
         float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
 #pragma unroll
@@ -437,8 +445,8 @@ extern "C" int lpd_softmax_affine(const float* in, float* out, int rows, int nco
                       "lpd_softmax_affine: column sums need group_rows %% %d == 0 and rows %% group_rows == 0", SM_RPW);
         const int waves = rows / SM_RPW;
         if (ncols == 64 && group_rows % (4 * SM_RPW) == 0 && ((((uintptr_t)in | (uintptr_t)out | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0))
-            hipLaunchKernelGGL(softmax_affine_colsum64_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, in, out, rows, scale, shift,
-                               group_rows, colsum, colsum_ld);
+            hipLaunchKernelGGL(softmax_affine_colsum64_kernel<1>, dim3((waves + 3) / 4), dim3(256), 0, stream, in, out, rows, scale, shift,
+                               group_rows, colsum, colsum_ld, 0);
         else
             hipLaunchKernelGGL(softmax_affine_colsum_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, in, out, rows, ncols, scale, shift,
                                group_rows, colsum, colsum_ld);
@@ -446,6 +454,31 @@ extern "C" int lpd_softmax_affine(const float* in, float* out, int rows, int nco
         hipLaunchKernelGGL(softmax_affine_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, out, rows, ncols, scale, shift);
     }
     LPD_CHECK_LAUNCH("lpd_softmax_affine");
+    return LPD_OK;
+}
+
+// softmax(scale * (sum of `parts` planes) + shift) over 64 columns + per-group column sums: the consumer of lpd_gemm_p8_fused's
+// partial assignment products.  rows % group_rows == 0, group_rows % 64 == 0.
+extern "C" int lpd_softmax_affine_parts(const float* in, int parts, long long part_stride, float* out, int rows, const float* scale,
+                                        const float* shift, int group_rows, float* colsum, int colsum_ld, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(in && out && colsum, "lpd_softmax_affine_parts: null pointer");
+    LPD_CHECK_ARG((parts == 1 || parts == 2 || parts == 4 || parts == 8) && part_stride >= (long long)rows * 64 && part_stride % 4 == 0,
+                  "lpd_softmax_affine_parts: parts in {1, 2, 4, 8}");
+    LPD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "lpd_softmax_affine_parts: scale and shift must be given together");
+    LPD_CHECK_ARG(rows > 0 && group_rows > 0 && group_rows % (4 * SM_RPW) == 0 && rows % group_rows == 0 && colsum_ld >= 64,
+                  "lpd_softmax_affine_parts: rows %% group_rows == 0, group_rows %% %d == 0", 4 * SM_RPW);
+    LPD_CHECK_ARG((((uintptr_t)in | (uintptr_t)out | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0, "lpd_softmax_affine_parts: alignment");
+    const int waves = rows / SM_RPW;
+    const dim3 grid((waves + 3) / 4), block(256);
+    switch (parts) {
+        case 1: hipLaunchKernelGGL(softmax_affine_colsum64_kernel<1>, grid, block, 0, stream, in, out, rows, scale, shift, group_rows, colsum, colsum_ld, part_stride); break;
+        case 2: hipLaunchKernelGGL(softmax_affine_colsum64_kernel<2>, grid, block, 0, stream, in, out, rows, scale, shift, group_rows, colsum, colsum_ld, part_stride); break;
+        case 4: hipLaunchKernelGGL(softmax_affine_colsum64_kernel<4>, grid, block, 0, stream, in, out, rows, scale, shift, group_rows, colsum, colsum_ld, part_stride); break;
+        default: hipLaunchKernelGGL(softmax_affine_colsum64_kernel<8>, grid, block, 0, stream, in, out, rows, scale, shift, group_rows, colsum, colsum_ld, part_stride); break;
+    }
+    LPD_CHECK_LAUNCH("lpd_softmax_affine_parts");
     return LPD_OK;
 }
 

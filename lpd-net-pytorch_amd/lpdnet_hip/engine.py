@@ -102,6 +102,16 @@ def split_edge_weight(seq, mode):
     return _cached(seq, "split_" + mode, (conv.weight,), build)
 
 
+def conv3_folded(net):
+    """conv3_lpd's weight with the eval-mode bn3 scale folded in (lpd_gemm_p8 adds a bias only): one tensor object per version of
+    its sources, so that its MFMA fragments are cached like a parameter's."""
+    bn, conv = net.bn3_lpd, net.conv3_lpd
+    src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    if bn.num_batches_tracked is not None:
+        src = src + (bn.num_batches_tracked,)
+    return _cached(net, "conv3_folded", src, lambda: (_w2d(conv) * bn_affine(bn)[0].unsqueeze(1)).contiguous())
+
+
 def _need_eval(module, what):
     if module.training:
         raise NotImplementedError(
@@ -301,17 +311,23 @@ def split_mfea(x):
     return rows[:, :3].contiguous(), rows
 
 
-def lpdnet_features_eval(net, x, reorder=True):
-    """util/lpdnet_model.py:211-268 (LPDNet.forward), eval mode."""
+FUSE_ASSIGN = __import__("os").environ.get("LPD_FUSE_ASSIGN", "1") != "0"    # conv3 + the NetVLAD assignment product in one launch
+
+
+def lpdnet_features_eval(net, x, reorder=True, assign=None):
+    """util/lpdnet_model.py:211-268 (LPDNet.forward), eval mode.  assign: the NetVLADLoupe that will pool the result -- where conv3
+    runs on lpd_gemm_p8, its assignment product x . cluster_weights (PointNetVlad.py:48) is computed in the same launch and the
+    partial planes are returned as a fourth value (None otherwise) for netvlad_eval(logit_parts=...)."""
     mfea = getattr(net, "use_mFea", False)
     x = _check_input(x, 8) if mfea else reorder_points(_check_input(x), reorder)
     B, N = x.shape[0], x.shape[2]
     act = ops.ACT_RELU if net.use_relu else ops.ACT_LEAKY
     side_ok = PANEL_LAYOUT and N % 128 == 0 and _resident_shape(net.k, N, B * N, act)
-    return _lpdnet_features_eval_body(net, x, mfea, side_ok and _side_mode(x.device))
+    out = _lpdnet_features_eval_body(net, x, mfea, side_ok and _side_mode(x.device), assign)
+    return out if assign is not None else out[:3]
 
 
-def _lpdnet_features_eval_body(net, x, mfea, use_side):
+def _lpdnet_features_eval_body(net, x, mfea, use_side, assign=None):
     B, N = x.shape[0], x.shape[2]
     M = B * N
     k = net.k
@@ -416,11 +432,16 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side):
         kagg_p(pq3[:, 0:32], pq3[:, 32:64], i16_x, N, scale=s3, shift=b3, act=act, slope=slope, out=x3v)
         if DEBUG_AUX is not None:
             DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=ops.split_to_rows(cat) if split else ops.panels_to_rows(cat))
+        parts = None
         if split:
-            feat = ops.gemm_p8(cat, _w2d(net.conv3_lpd), scale=sc, shift=bc, act=act, slope=slope)
+            if (FUSE_ASSIGN and assign is not None and assign.cluster_size == 64 and N % 64 == 0
+                    and assign.feature_size == net.conv3_lpd.weight.shape[0] and net.conv3_lpd.weight.shape[0] // 256 in (1, 2, 4, 8)):
+                feat, parts = ops.gemm_p8(cat, conv3_folded(net), shift=bc, act=act, slope=slope, assign_w=assign.cluster_weights)
+            else:
+                feat = ops.gemm_p8(cat, conv3_folded(net), shift=bc, act=act, slope=slope)
         else:
             feat = ops.gemm(cat, _w2d(net.conv3_lpd), b_kmajor=False, a_panels=True, scale=sc, shift=bc, act=act, slope=slope)
-        return feat, B, N
+        return feat, B, N, parts
     if side_job is not None:
         torch.cuda.current_stream().wait_stream(side_job[0])
         pq.record_stream(torch.cuda.current_stream())
@@ -439,7 +460,7 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side):
     kagg(pq[:, :256], pq[:, 256:], idx_x, N, scale=s3, shift=b3, act=act, slope=slope, out=cat[:, 256:512])
     if DEBUG_AUX is not None:
         DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=cat)
-    return ops.linear(cat, _w2d(net.conv3_lpd), scale=sc, shift=bc, act=act, slope=slope), B, N
+    return ops.linear(cat, _w2d(net.conv3_lpd), scale=sc, shift=bc, act=act, slope=slope), B, N, None
 
 
 def _aligned_input(xyz_t, p_all, mfea):
@@ -537,8 +558,9 @@ def _pool_splits(B, N, E):
     return s
 
 
-def netvlad_eval(vlad, feat, B, N):
-    """util/PointNetVlad.py:45-83 + GatingContext :103-115, eval mode.  feat [B*N, E] point-major."""
+def netvlad_eval(vlad, feat, B, N, logit_parts=None):
+    """util/PointNetVlad.py:45-83 + GatingContext :103-115, eval mode.  feat [B*N, E] point-major.  logit_parts: the partial
+    assignment products [E/256, B*N, 64] lpd_gemm_p8_fused left next to feat (their sum = feat . cluster_weights)."""
     if N != vlad.max_samples:
         raise ValueError(f"NetVLADLoupe was built for max_samples={vlad.max_samples}, got N={N}")
     E, K = vlad.feature_size, vlad.cluster_size
@@ -547,12 +569,15 @@ def netvlad_eval(vlad, feat, B, N):
     else:
         s = _cached(vlad, "ones", (vlad.cluster_biases,), lambda: torch.ones_like(vlad.cluster_biases))
         b = vlad.cluster_biases
-    a = ops.gemm(feat, vlad.cluster_weights, b_kmajor=True)
     ws = None
-    if N % 16 == 0:      # a_sum (:63) falls out of the softmax pass
-        a, ws = ops.softmax_affine(a, s, b, out=a, colsum_rows=N)
+    if logit_parts is not None:          # the assignment product came with conv3: sum the column blocks' planes inside the softmax pass
+        a, ws = ops.softmax_affine_parts(logit_parts, s, b, colsum_rows=N)
     else:
-        a = ops.softmax_affine(a, s, b, out=a)
+        a = ops.gemm(feat, vlad.cluster_weights, b_kmajor=True)
+        if N % 16 == 0:      # a_sum (:63) falls out of the softmax pass
+            a, ws = ops.softmax_affine(a, s, b, out=a, colsum_rows=N)
+        else:
+            a = ops.softmax_affine(a, s, b, out=a)
     vraw = ops.pool_tn(feat.view(B, N, E), a.view(B, N, K))                                                              # [B,E,K]
     if vraw is None:
         vraw = ops.gemm(feat.view(B, N, E), a.view(B, N, K), a_kmajor=True, b_kmajor=True, splits=_pool_splits(B, N, E))

@@ -401,29 +401,49 @@ def gemm_x3t_split(S, W, *, out=None):
     return out
 
 
-def gemm_p8(S, W, *, scale=None, shift=None, act=ACT_NONE, slope=0.01, out=None, out_panels=False):
+def gemm_p8(S, W, *, scale=None, shift=None, act=ACT_NONE, slope=0.01, out=None, out_panels=False, assign_w=None):
     """act(scale * (A W^T) + shift) for split cloud-panel activations S [2, B, K/8, N, 8] (split_panels / the producers' split
-    epilogues) and a weight W [Nout, K] (torch conv layout): lpd_gemm_p8.  out: row-major [B*N, Nout] or fp32 cloud panels."""
+    epilogues) and a weight W [Nout, K] (torch conv layout): lpd_gemm_p8.  out: row-major [B*N, Nout] or fp32 cloud panels.
+    The kernel adds a bias only: `scale` is folded into W here (per call -- callers with a fixed scale pass the folded weight,
+    engine.conv3_folded, whose fragments are cached).
+    assign_w [Nout, 64] (NetVLAD cluster_weights): also returns parts [Nout/256, B*N, 64], the per-column-block partial products
+    out[:, 256 j : 256 j + 256] @ assign_w[256 j : 256 j + 256] computed in the same launch -> (out, parts)."""
     _req(W, "W")
-    two, Bc, Pn, Np, _ = S.shape
-    if two != 2 or S.dtype != torch.bfloat16 or S.stride(4) != 1 or S.stride(3) != 8:
+    if not _is_split(S):
         raise ValueError("gemm_p8: expected split cloud panels [2, B, K/8, N, 8] (bf16)")
+    _, Bc, Pn, Np, _ = S.shape
     M, K, N = Bc * Np, Pn * 8, W.shape[0]
     lib = _lib.load()
-    if W.shape[1] != K or not lib.lpd_gemm_p8_applies(M, N, K, Np):
+    if W.dim() != 2 or W.shape[1] != K or not lib.lpd_gemm_p8_applies(M, N, K, Np):
         raise ValueError(f"gemm_p8: shape not built (M={M}, N={N}, K={K}, points per cloud {Np})")
     if out is None:
         out = panels_empty(Bc, Np, N, S.device) if out_panels else torch.empty((M, N), dtype=torch.float32, device=S.device)
     if out_panels:
-        if not _is_panels(out) or out.shape[1] * 8 != N or out.shape[2] != Np:
+        if not _is_panels(out) or out.shape[1] * 8 != N or out.shape[2] != Np or out.shape[0] != Bc:
             raise ValueError("gemm_p8: out_panels expects a cloud-panel [B, Nout/8, N, 8] tensor")
         ldc, c_cloud, c_ld = 8, out.stride(0), out.stride(1) // 8
     else:
+        _req(out, "out")
+        if out.shape[0] != M or out.shape[1] != N:
+            raise ValueError("gemm_p8: out has the wrong shape")
         ldc, c_cloud, c_ld = _rows(out, "out"), 0, 0
     scale, shift = _vec(scale, "scale", N), _vec(shift, "shift", N)
+    if scale is not None:
+        W = (W * scale.unsqueeze(1)).contiguous()
+    if act == ACT_LEAKY and not 0.0 <= slope <= 1.0:
+        raise ValueError("gemm_p8: LeakyReLU slope outside [0, 1]")
     frags = _weight_frags(W, False, N, K)
+    if assign_w is not None:
+        _req(assign_w, "assign_w")
+        if assign_w.dim() != 2 or tuple(assign_w.shape) != (N, 64) or assign_w.stride(1) != 1:
+            raise ValueError(f"gemm_p8: assign_w must be [{N}, 64] with unit column stride")
+        frags2 = _weight_frags(assign_w, True, 64, N)
+        parts = torch.empty((N // 256, M, 64), dtype=torch.float32, device=S.device)
+        _call(f"gemm_p8+assign[{M}x{N}x{K}]", lib.lpd_gemm_p8_fused, _ptr(S[0]), _ptr(S[1]), S.stride(1), S.stride(2) // 8, _ptr(frags),
+              _ptr(out), ldc, c_cloud, c_ld, M, N, K, Np, _ptr(shift), act, float(slope), _ptr(frags2), _ptr(parts), parts.stride(0), _stream())
+        return out, parts
     _call(f"gemm_p8[{M}x{N}x{K}]", lib.lpd_gemm_p8, _ptr(S[0]), _ptr(S[1]), S.stride(1), S.stride(2) // 8, _ptr(frags), _ptr(out), ldc,
-          c_cloud, c_ld, M, N, K, Np, _ptr(scale), _ptr(shift), act, float(slope), P8_IMPL, _stream())
+          c_cloud, c_ld, M, N, K, Np, _ptr(shift), act, float(slope), P8_IMPL, _stream())
     return out
 
 
@@ -768,6 +788,24 @@ def softmax_affine(x, scale=None, shift=None, out=None, colsum_rows=None):
     ws = torch.zeros((rows // colsum_rows, 2 * n), dtype=torch.float32, device=x.device)
     _call("softmax_affine", lib.lpd_softmax_affine, _ptr(x), _ptr(out), rows, n, _ptr(scale), _ptr(shift), colsum_rows, _ptr(ws), 2 * n,
           _stream())
+    return out, ws
+
+
+def softmax_affine_parts(parts, scale=None, shift=None, colsum_rows=None):
+    """softmax(scale * sum_j parts[j] + shift) over the 64 columns (parts [P, rows, 64]: the partial assignment products of
+    gemm_p8(..., assign_w=...)), with the per-cloud column sums like softmax_affine(colsum_rows=N) -> (out [rows, 64], ws)."""
+    _req(parts, "parts")
+    if parts.dim() != 3 or parts.shape[2] != 64 or not parts[0].is_contiguous():
+        raise ValueError("softmax_affine_parts: expected [P, rows, 64]")
+    P, rows, n = parts.shape
+    if colsum_rows is None or colsum_rows % 64 or rows % colsum_rows:
+        raise ValueError("softmax_affine_parts: colsum_rows must be a multiple of 64 that divides the row count")
+    out = torch.empty((rows, n), dtype=torch.float32, device=parts.device)
+    scale, shift = _vec(scale, "scale", n), _vec(shift, "shift", n)
+    ws = torch.zeros((rows // colsum_rows, 2 * n), dtype=torch.float32, device=parts.device)
+    lib = _lib.load()
+    _call("softmax_affine", lib.lpd_softmax_affine_parts, _ptr(parts), P, parts.stride(0), _ptr(out), rows, _ptr(scale), _ptr(shift),
+          colsum_rows, _ptr(ws), 2 * n, _stream())
     return out, ws
 
 

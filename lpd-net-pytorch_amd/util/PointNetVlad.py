@@ -204,6 +204,12 @@ class PointNetVlad(nn.Module):
             # tuned for (measured: 128 clouds in one piece 12.2 ms = 10.5 k descriptors/s, as 4 x 32 the 32-cloud rate)
             per = max(1, engine.EVAL_CHUNK * 4096 // x.shape[2])
             return torch.cat([self.forward(x[i:i + per]) for i in range(0, x.shape[0], per)], dim=0)
+        if not self.training and isinstance(trunk, LPDNet):
+            # eval: conv3 and the NetVLAD assignment product share a launch where that is built (engine.lpdnet_features_eval)
+            feat, B, N, parts = engine.lpdnet_features_eval(trunk, x, assign=self.net_vlad)
+            if engine.DEBUG_AUX is not None:
+                engine.DEBUG_AUX["feat"] = feat
+            return engine.netvlad_eval(self.net_vlad, feat, B, N, logit_parts=parts)
         feat, B, N = trunk._features(x)          # point-major: no [B,E,N,1] round trip between trunk and head
         if engine.DEBUG_AUX is not None:         # test hook: the trunk's output rows [B*N, E] (stage-probe fixtures)
             engine.DEBUG_AUX["feat"] = feat

@@ -984,3 +984,34 @@ def test_edge_mlp_split_output_and_x3t_on_split_planes(cuda, CM, N, B):
         a = ops.gemm(want_p, Wp, b_kmajor=False, a_panels=True, out_panels=True)
         b = ops.gemm_x3t_split(got, Wp)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("Bc,Np,K,N,panels", [(2, 256, 512, 1024, False), (5, 512, 128, 256, True), (32, 256, 512, 1024, False)])
+def test_gemm_p8_fused_assignment_product(cuda, Bc, Np, K, N, panels):
+    """lpd_gemm_p8_fused: conv3 and the NetVLAD assignment product of its output in one launch.  C is bit-identical to the plain
+    kernel's; every partial plane parts[j] = C[:, 256 j : 256 j + 256] @ W2[256 j : 256 j + 256] to fp32 grade against float64;
+    repeated launches are bit-identical; lpd_softmax_affine_parts = softmax of the affine of the summed planes + per-cloud sums."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11 + Bc + Np + K + N)
+    M = Bc * Np
+    X = (torch.randn(M, K, generator=g) * 2.0).to(cuda)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    W2 = torch.nn.Parameter((torch.randn(N, 64, generator=g) / N ** 0.5).to(cuda))
+    sh = torch.randn(N, generator=g).to(cuda)
+    S = ops.split_panels(ops.rows_to_panels(X, Bc))
+    plain = ops.gemm_p8(S, W, shift=sh, act=ops.ACT_LEAKY, slope=0.01, out_panels=panels)
+    out, parts = ops.gemm_p8(S, W, shift=sh, act=ops.ACT_LEAKY, slope=0.01, out_panels=panels, assign_w=W2.data)
+    assert torch.equal(out, plain)
+    rows = (ops.panels_to_rows(out) if panels else out).double()
+    assert parts.shape == (N // 256, M, 64)
+    for j in range(N // 256):
+        ref = rows[:, 256 * j:256 * j + 256] @ W2.data[256 * j:256 * j + 256].double()
+        assert _rel(parts[j], ref) < 2e-5, j
+    for _ in range(5):
+        o2, p2 = ops.gemm_p8(S, W, shift=sh, act=ops.ACT_LEAKY, slope=0.01, out_panels=panels, assign_w=W2.data)
+        assert torch.equal(o2, out) and torch.equal(p2, parts)
+    sc, b = (0.5 + torch.rand(64, generator=g)).to(cuda), torch.randn(64, generator=g).to(cuda)
+    a, ws = ops.softmax_affine_parts(parts, sc, b, colsum_rows=Np)
+    want = torch.softmax(parts.double().sum(0) * sc.double() + b.double(), dim=1)
+    assert _rel(a, want) < 1e-5
+    assert _rel(ws[:, :64], want.view(Bc, Np, 64).sum(1)) < 1e-5 and bool((ws[:, 64:] == 0).all())

@@ -50,6 +50,10 @@ for impl in (5, 6):
     ops.P8_IMPL = impl
     print("impl", impl, "p8 rows   median/min us", timeit(lambda: ops.gemm_p8(S, W, scale=sc, shift=sh, act=ops.ACT_LEAKY, out=outr)))
     print("impl", impl, "p8 panels median/min us", timeit(lambda: ops.gemm_p8(S, W, scale=sc, shift=sh, act=ops.ACT_LEAKY, out=outp, out_panels=True)))
+for impl, name in ((8, "no LDS-DMA in the loop"), (16, "no MFMAs (6 units ahead)"), (16 + 5, "no MFMAs (5 units ahead)"), (24, "neither (reads + barriers + stores)"), (32, "full, nt loads")):
+    ops.P8_IMPL = impl
+    print("timing-only:", name, timeit(lambda: ops.gemm_p8(S, W, shift=sh, act=ops.ACT_LEAKY, out=outr)))
+ops.P8_IMPL = 0
 print("x3w (current conv3)    median/min us", timeit(lambda: ops.gemm(P, W, b_kmajor=False, a_panels=True, scale=sc, shift=sh, act=ops.ACT_LEAKY, out=outr)))
 print("split_panels           median/min us", timeit(lambda: ops.split_panels(P, out=S)))
 # repeatability / race screen: 30 runs must be bit-identical
