@@ -135,6 +135,12 @@ int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, 
                  const float* scale, const float* shift, int act, float slope, int accumulate,
                  long long a_cloud, long long c_cloud, int panel_n, int panel_ld, int impl, void* stream);
 
+/* The bare product C = A W^T (+ bias) of a TRAIN-mode layer with its BatchNorm statistics from the epilogue: stat_sum / stat_sumsq
+ * [N] fp64 (zeroed by the call) = column sums / sums of squares of C over the M rows (fp32 over a block's 128 rows, fp64 atomics),
+ * i.e. lpd_colstats without the second pass over C. */
+int lpd_gemm_x3w_stats(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
+                       double* stat_sum, double* stat_sumsq, int impl, void* stream);
+
 /*
  * The same product for a SHORT reduction with cloud-panel A and C (the neighbour / centre projection of the split SN1 edge
  * convolution, util/lpdnet_model.py:257: K = 128 -> N = 512), computed transposed: the prepared weight fragments are the MFMA's

@@ -569,6 +569,8 @@ struct X3wArgs {
     int panel_n, panel_ld;
     int rotate;                   // start the reduction of row tile t at chunk 5 t mod chunks (see the kernel)
     int prods;                    // 3 = split-bf16 (fp32-grade), 1 = a_hi b_hi only (bf16-storage training mode)
+    double* stat_sum;             // train-mode BatchNorm statistics of the RAW product (+ bias), accumulated in the epilogue:
+    double* stat_sumsq;           // column sums / sums of squares over the M rows (fp32 over a block's 128 rows, fp64 atomics); or null
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -773,6 +775,24 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
                 if (g.accumulate) v += *dst;
                 *dst = v;
             }
+        if (g.stat_sum) {        // uniform.  This lane: column n, up to 16 RT rows; its partner (lane ^ 32) the other rows of the tiles
+            float su = 0.f, sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (rt0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = m < g.M ? acc[i][j][r] + bi : 0.f;
+                    su += v;
+                    sq += v * v;
+                }
+            su += __shfl_xor(su, 32, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (h == 0) {
+                atomicAdd(g.stat_sum + n, (double)su);
+                atomicAdd(g.stat_sumsq + n, (double)sq);
+            }
+        }
     }
 }
 
@@ -1103,9 +1123,10 @@ static void x3w_wide_launch(const X3wArgs& g, int NT, hipStream_t stream)
     x3w_wide_launch_kc<WN, PANELS, 32>(g, NT, stream);
 }
 
-extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
-                            const float* scale, const float* shift, int act, float slope, int accumulate,
-                            long long a_cloud, long long c_cloud, int panel_n, int panel_ld, int impl, void* stream_)
+static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
+                         const float* scale, const float* shift, int act, float slope, int accumulate,
+                         long long a_cloud, long long c_cloud, int panel_n, int panel_ld, int impl, double* stat_sum, double* stat_sumsq,
+                         void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     const bool a_panels = a_cloud != 0, c_panels = c_cloud != 0;
@@ -1123,7 +1144,11 @@ extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C
     const int KS = (K + 15) / 16, NT = (N + 31) / 32;
     const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
     X3wArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, K, KS, lda, ldc, bias, scale, shift, act, slope, accumulate,
-              a_cloud, c_cloud, panel_n, panel_ld, 0, prods};
+              a_cloud, c_cloud, panel_n, panel_ld, 0, prods, stat_sum, stat_sumsq};
+    if (stat_sum) {
+        (void)hipMemsetAsync(stat_sum, 0, sizeof(double) * N, stream);
+        (void)hipMemsetAsync(stat_sumsq, 0, sizeof(double) * N, stream);
+    }
     {   // (it matters for a row-major A with a power-of-two row stride; applied to every layout so that the summation
         //  order -- and with it every bit of the result -- does not depend on the layout of A)
         static const int rot = getenv("LPD_X3W_ROTATE") ? atoi(getenv("LPD_X3W_ROTATE")) : 1;
@@ -1149,4 +1174,23 @@ extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C
     }
     LPD_CHECK_LAUNCH("lpd_gemm_x3w");
     return LPD_OK;
+}
+
+extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
+                            const float* scale, const float* shift, int act, float slope, int accumulate,
+                            long long a_cloud, long long c_cloud, int panel_n, int panel_ld, int impl, void* stream_)
+{
+    return gemm_x3w_impl(A, lda, frags, C, ldc, M, N, K, bias, scale, shift, act, slope, accumulate, a_cloud, c_cloud, panel_n, panel_ld, impl,
+                         nullptr, nullptr, stream_);
+}
+
+// The bare product C = A W^T (+ bias) of a TRAIN-mode layer together with the statistics its BatchNorm needs: stat_sum[n] /
+// stat_sumsq[n] (fp64, zeroed here) receive the column sums / sums of squares of C over the M rows from the kernel's epilogue
+// (fp32 over a block's 128 rows, then fp64 atomics) -- what lpd_colstats computes with a second pass over C
+// (util/lpdnet_model.py:262: conv3_lpd + bn3_lpd over all B*N points; :251 convDG2 over all B*N*k edges).
+extern "C" int lpd_gemm_x3w_stats(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
+                                  double* stat_sum, double* stat_sumsq, int impl, void* stream_)
+{
+    LPD_CHECK_ARG(stat_sum && stat_sumsq, "lpd_gemm_x3w_stats: null statistics");
+    return gemm_x3w_impl(A, lda, frags, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 0.0f, 0, 0, 0, 0, 0, impl, stat_sum, stat_sumsq, stream_);
 }

@@ -171,8 +171,7 @@ class _PointLayer:
 
     @staticmethod
     def fwd(x, w2d, bn, act, slope):
-        y = ops.linear(x, w2d)
-        st = ops.bn_train_stats(y, bn)
+        y, st = ops.linear_bn_stats(x, w2d, bn)       # the statistics ride in the GEMM's epilogue where that kernel is built
         z = ops.affine_act(y, st.scale, st.shift, act, slope)
         return y, st, z
 
@@ -387,7 +386,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         if TRAIN_STORAGE == "bf16":      # bf16 mode: the dense products behind the kNN take bf16 operands (one MFMA product)
             with ops.bf16_gemm():
                 return _LPDNetTrainFn._forward(ctx, net, x, *params)
-        with ops.train_forward_gemm():
+        with ops.train_forward_gemm(x.shape[0]):
             return _LPDNetTrainFn._forward(ctx, net, x, *params)
 
     @staticmethod
@@ -422,8 +421,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
             u1, stg1 = ops.edge_build(pq1[:, :128], pq1[:, 128:], idx_f, N, bn=net.convDG1[1])   # [E,128] raw + its BN statistics
             arg1 = ops.group_max(u1, k, stg1.scale, stg1.shift, act, slope, cat[:, 0:128])            # x1
             y1e = ops.affine_act(u1, stg1.scale, stg1.shift, act, slope)        # [E,128] post-activation edges
-            z = ops.linear(y1e, w2d(net.convDG2[0]))                            # [E,128] raw
-            stg2 = ops.bn_train_stats(z, net.convDG2[1])
+            z, stg2 = ops.linear_bn_stats(y1e, w2d(net.convDG2[0]), net.convDG2[1])   # [E,128] raw + its statistics (GEMM epilogue)
             arg2 = ops.group_max(z, k, stg2.scale, stg2.shift, act, slope, cat[:, 128:256])           # x2
         # SN1 on the xyz graph, split form: statistics, max and arg-max from one gather pass, no [E,256] tensor
         idx_x = engine._knn_rows(x.view(B * N, 3), B, N, 3, k)
@@ -547,7 +545,7 @@ class _LPDNetOrignTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, x, *params):
-        with ops.train_forward_gemm():
+        with ops.train_forward_gemm(x.shape[0]):
             return _LPDNetOrignTrainFn._forward(ctx, net, x, *params)
 
     @staticmethod
@@ -663,7 +661,7 @@ class _PointNetTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, x, *params):
-        with ops.train_forward_gemm():
+        with ops.train_forward_gemm(x.shape[0]):
             return _PointNetTrainFn._forward(ctx, net, x, *params)
 
     @staticmethod
@@ -813,7 +811,7 @@ class _NetVLADTrainFn(torch.autograd.Function):
         if ctx.bf16:      # the big per-point products (assignment, pooling) take bf16 operands; the B-row head products stay
             with ops.bf16_gemm():      # on the exact / split path by their shapes (ops.gemm's policy: skinny outputs)
                 return _NetVLADTrainFn._forward(ctx, vlad, B, N, feat, *params)
-        with ops.train_forward_gemm():
+        with ops.train_forward_gemm(B):
             return _NetVLADTrainFn._forward(ctx, vlad, B, N, feat, *params)
 
     @staticmethod

@@ -1015,3 +1015,34 @@ def test_gemm_p8_fused_assignment_product(cuda, Bc, Np, K, N, panels):
     want = torch.softmax(parts.double().sum(0) * sc.double() + b.double(), dim=1)
     assert _rel(a, want) < 1e-5
     assert _rel(ws[:, :64], want.view(Bc, Np, 64).sum(1)) < 1e-5 and bool((ws[:, 64:] == 0).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1024, 512), (5000, 128, 128), (2048 + 77, 256, 256)])
+def test_gemm_epilogue_batchnorm_statistics(cuda, M, N, K):
+    """lpd_gemm_x3w_stats: the train-mode BatchNorm statistics of a layer from its GEMM's epilogue equal those of the separate
+    pass (lpd_colstats) over the same output -- scale / shift / mean / invstd to 1e-6, running statistics updated once -- for
+    row counts that are not multiples of the 128-row blocks, and the product itself is the plain kernel's, bit for bit."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    X = (torch.randn(M, K, generator=g) * 1.5 + 0.3).to(cuda)
+    W = torch.nn.Parameter((torch.randn(N, K, generator=g) / K ** 0.5).to(cuda))
+    bn1, bn2 = torch.nn.BatchNorm1d(N).to(cuda), torch.nn.BatchNorm1d(N).to(cuda)
+    with torch.no_grad():
+        for bn in (bn1, bn2):
+            bn.weight.copy_(torch.linspace(0.5, 1.5, N))
+            bn.bias.copy_(torch.linspace(-0.2, 0.2, N))
+    prof = ops.PROFILE = {}
+    try:
+        y, st = ops.linear_bn_stats(X, W.data, bn1)
+    finally:
+        ops.PROFILE = None
+    assert any(k.startswith("gemmx3w+stats") for k in prof) and "colstats" not in prof, list(prof)
+    y2 = ops.linear(X, W.data)
+    st2 = ops.bn_train_stats(y2, bn2)
+    assert torch.equal(y, y2) or _rel(y, y2) < 1e-6
+    for a, b in ((st.scale, st2.scale), (st.shift, st2.shift), (st.mean, st2.mean), (st.invstd, st2.invstd),
+                 (bn1.running_mean, bn2.running_mean), (bn1.running_var, bn2.running_var)):
+        assert _rel(a, b) < 2e-6
+    ref = X.double() @ W.data.double().t()
+    assert _rel(st.mean, ref.mean(0)) < 1e-5 and _rel(st.invstd, 1.0 / torch.sqrt(ref.var(0, unbiased=False) + 1e-5)) < 1e-5
+    assert int(bn1.num_batches_tracked) == 1
