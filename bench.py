@@ -59,11 +59,18 @@ def parse():
 
 def launch_ranks(args):
     """--gpus N > 1 without RANK: start the N ranks as a CHILD process tree (never exec / re-use a process that has touched
-    the GPU; this parent makes no HIP call -- torch.cuda.device_count() does not initialise the runtime on this image)."""
+    the GPU; this parent makes no HIP call at all: the GPUs are counted from the kfd topology in sysfs)."""
     import socket
     import subprocess
-    n_vis = torch.cuda.device_count()
-    if n_vis < args.gpus:
+    # count GPUs without the HIP runtime: the kfd topology lists one node per agent, GPUs are the ones with SIMDs
+    n_vis = None
+    try:
+        top = "/sys/class/kfd/kfd/topology/nodes"
+        n_vis = sum(1 for d in os.listdir(top)
+                    if any(ln.split()[0] == "simd_count" and int(ln.split()[1]) > 0 for ln in open(os.path.join(top, d, "properties"))))
+    except (OSError, ValueError, IndexError):
+        n_vis = None          # no topology (container without sysfs): let the ranks report what they see
+    if n_vis is not None and n_vis < args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible on this node")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -318,9 +325,11 @@ def secondary_eval(dev, points, k, batch, steps, warmup=2):
     key = next((k_ for k_ in kern if k_.startswith("edge_gather_max") and k_.endswith("[C=256]")), None)
     if key is not None:
         t_s = kern[key]["avg_us"] * 1e-6
-        pts = batch * points
+        per_step = max(1, round(kern[key]["launches"] / steps))      # a large batch runs as slices (engine.EVAL_CHUNK): one launch per slice
+        pts = batch * points // per_step
         alg = (KAGG_ROW_BYTES + 4 * k) * pts
         alg_direct = (128 * 4 + 256 * 4 + 4 * k) * pts
+        rec["config"]["clouds_per_launch"] = batch // per_step
         rec["roofline"] = {"kernel": f"{ops.KAGG_KERNEL_NAMES.get(key.split('[')[0], key)}, SN1 stage, C=256, k={k}", "bound": "hbm",
                            "achieved": round(alg / t_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(alg / t_s / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_us": kern[key]["avg_us"],
@@ -472,8 +481,8 @@ def main():
             try:
                 rec = json.load(open(pmc))
                 for r in rec.get("runs", [rec]):
-                    if (r.get("batch", 32), r.get("points", 4096), r.get("k", 20)) == (args.batch, args.points, args.k) \
-                            and r.get("bench_key") == key:
+                    if traffic is None and (r.get("batch", 32), r.get("points", 4096), r.get("k", 20)) == (args.batch, args.points, args.k) \
+                            and r.get("bench_key") == key:      # the newest matching record comes first
                         traffic = r.get("hbm_bytes_per_launch")
                         traffic_source = ("profiles/kagg_pmc.json (rocprofv3 --pmc passes of an EARLIER run of this command on the same "
                                           "workload, FETCH_SIZE doubled per MI355X_MICROARCH.md; not measured in this run): " + str(r.get("source")))

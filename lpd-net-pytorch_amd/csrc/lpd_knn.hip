@@ -1625,11 +1625,13 @@ int knn3_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
 }
 
 // workspace behind [xx | xp]: centroids, |c|^2, radii, max |x|^2 per 32-point tile
+inline bool knn7_tight();
 inline size_t knn7_extra_floats(int B, int N, int CP)
 {
     const size_t nt = (size_t)(N + 31) / 32;
     size_t n = (size_t)B * nt * (2 * CP + 3 + 2) + 16;   // + predicted tile counts and launch order (int32 each)
-    if (CP == 32 && nt <= (size_t)KNN7_PRE_MAXT)         // low-precision pass: bf16 image of the operands + the bound table
+    if (CP == 32 && nt <= (size_t)KNN7_PRE_MAXT && knn7_tight())   // low-precision pass: bf16 image of the operands + the bound table
+                                                                    // (B nt^2 16 floats: 1.07 GB at B = 64, N = 16384 -- not reserved when the pass is off)
         n += (size_t)B * nt * 32 * (KNN7_XB / 2) + (size_t)B * nt * nt * 16 + 16;
     return n;
 }

@@ -139,14 +139,30 @@ def save_checkpoint(path, model, optimizer, epoch, total_iterations, recall):
                 "optimizer": optimizer.state_dict(), "recall": float(recall)}, path)
 
 
-def load_pretrained(model, path, optimizer=None, map_location="cpu"):
+def load_pretrained(model, path, optimizer=None, map_location="cpu", trust_checkpoint=True):
     """train_pointnetvlad.py:64-77: a path ending in '7' (.t7) holds a bare state_dict (loaded with strict=False), anything
-    else the .ckpt dictionary (strict=True, optimizer state restored).  -> (starting_epoch, total_iterations)."""
+    else the .ckpt dictionary (strict=True, optimizer state restored).  -> (starting_epoch, total_iterations).
+
+    The file is first read with torch's weights-only unpickler (tensors, containers and the numpy scalar types the reference's
+    checkpoints hold: `recall` is a numpy.float64, train_pointnetvlad.py:172-199).  Only if that refuses the file AND
+    trust_checkpoint is set (the default: the reference's own torch.load executes whatever the pickle says) it is read with the
+    full unpickler; pass trust_checkpoint=False for files of unknown origin."""
     target = _unwrap(model)
-    # weights_only=False: the reference's .ckpt stores `recall` as numpy.float64 (np.mean, train_pointnetvlad.py:172-199) and
-    # the optimizer state as a plain pickle; torch >= 2.6 refuses those under the weights-only default.  Like the
-    # reference's own torch.load, this trusts the file: load checkpoints from sources you trust.
-    blob = torch.load(path, map_location=map_location, weights_only=False)
+    try:
+        allow = [np.dtype, np.float64, np.float32, np.int64]
+        for name in ("scalar", "_reconstruct"):
+            for mod in (getattr(np, "_core", None), getattr(np, "core", None)):
+                fn = getattr(getattr(mod, "multiarray", None), name, None) if mod is not None else None
+                if fn is not None:
+                    allow.append(fn)
+                    break
+        allow += [type(np.dtype(t)) for t in ("float64", "float32", "int64")]
+        with torch.serialization.safe_globals(allow):
+            blob = torch.load(path, map_location=map_location, weights_only=True)
+    except Exception:      # noqa: BLE001 -- anything the restricted unpickler does not accept
+        if not trust_checkpoint:
+            raise
+        blob = torch.load(path, map_location=map_location, weights_only=False)
     if str(path)[-1] == "7":
         target.load_state_dict(_strip_module_prefix(blob), strict=False)
         return 0, 0
