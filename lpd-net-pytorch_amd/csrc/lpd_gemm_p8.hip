@@ -293,7 +293,7 @@ __global__ __launch_bounds__(P8_THREADS, 2) void gemm_p8_kernel(P8Args g)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- matrix segment: 2 column tiles x 2 k-steps x 3 products ----
-                __builtin_amdgcn_s_setprio(1);
+                if constexpr ((DBG & 16) != 0) __builtin_amdgcn_s_setprio(1);      // measured: 423 us without, 440 with
                 f32x16& c0 = acc[2 * P];
                 f32x16& c1 = acc[2 * P + 1];
                 if constexpr ((DBG & 2) != 0) {
@@ -311,8 +311,22 @@ __global__ __launch_bounds__(P8_THREADS, 2) void gemm_p8_kernel(P8Args g)
                 c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl11, ah1, c1, 0, 0, 0);
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh01, ah1, c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh11, ah1, c1, 0, 0, 0);
+                if constexpr ((DBG & 4) != 0) {       // timing only: the same 12 MFMAs once more (what a 24-MFMA phase would cost per barrier pair)
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh00, al0, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh10, al0, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl00, ah0, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl10, ah0, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh00, ah0, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh10, ah0, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh01, al1, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh11, al1, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl01, ah1, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl11, ah1, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh01, ah1, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh11, ah1, c1, 0, 0, 0);
                 }
-                __builtin_amdgcn_s_setprio(0);
+                }
+                if constexpr ((DBG & 16) != 0) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
             };
@@ -343,7 +357,6 @@ __global__ __launch_bounds__(P8_THREADS, 2) void gemm_p8_kernel(P8Args g)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { z0[r] = 0.0f; z1[r] = 0.0f; }
                 }
-                __builtin_amdgcn_s_setprio(1);
                 auto step = [&](auto Ic, p8_bf16x8 (&w)[4], p8_bf16x8 (&wn)[4]) {
                     constexpr int I = decltype(Ic)::value;
                     constexpr int T = 2 * P + (I >> 1), Q = 4 * (I & 1);       // accumulator tile, first register of the 16-channel group / 2
@@ -395,7 +408,6 @@ __global__ __launch_bounds__(P8_THREADS, 2) void gemm_p8_kernel(P8Args g)
                 step(P8Int<1>{}, wb, wa);
                 step(P8Int<2>{}, wa, wb);
                 step(P8Int<3>{}, wb, wa);
-                __builtin_amdgcn_s_setprio(0);
                 {   // the two column tiles start the next tile from its bias
                     const int n0 = bias_n0(seq + 1);
                     init_tile(2 * P, n0);
@@ -434,6 +446,13 @@ extern "C" int lpd_gemm_p8_applies(int M, int N, int K, int panel_n)
     return (M > 0 && N > 0 && K >= 64 && N % 256 == 0 && K % 32 == 0 && panel_n > 0 && panel_n % 256 == 0 && M % panel_n == 0) ? 1 : 0;
 }
 
+// Pricing runs on this kernel (tools/p8_bench.py, B = 32: 131072 x 1024 x 512, one box): full 430 us; without LDS-DMA in the loop 362;
+// without MFMAs 315; with neither -- LDS reads, barriers, stores -- 238; every phase's 12 MFMAs issued twice 645 (1.5x for 2x the
+// matrix work); without s_setprio around the MFMAs 423 (kept off); nt (aux = 2) loads 487.  A second generation with TWO phases of 24
+// MFMAs per K-tile (4 LDS-DMA pieces and 16 - 20 fragment reads per load segment, 10-slot ring in all 160 KiB of LDS, 252 - 256 registers)
+// was built on the strength of the 645 us figure and measured 438 us (fused form 520 against 444): the load segment grows with the
+// phase -- its LDS-DMA issue (~70 cycles a piece) and fragment reads are what fills the ~270 cycles a barrier interval costs beside
+// its MFMAs -- so the ratio does not move; it was removed again.
 static int gemm_p8_impl(const void* a_hi, const void* a_lo, long long a_cloud, int a_panel_ld, const void* frags, float* C, int ldc,
                         long long c_cloud, int c_panel_ld, int M, int N, int K, int panel_n, const float* bias, int act, float slope,
                         const void* w2_frags, float* parts, long long part_stride, int impl, void* stream_)
@@ -476,6 +495,8 @@ static int gemm_p8_impl(const void* a_hi, const void* a_lo, long long a_cloud, i
     if (w2_frags) {
         if (c_cloud != 0) launch(gemm_p8_kernel<6, true, 0, true>); else launch(gemm_p8_kernel<6, false, 0, true>);
     }
+    else if ((impl & 127) == 96) launch(gemm_p8_kernel<6, false, 16>);
+    else if (impl & 64) launch(gemm_p8_kernel<6, false, 4>);
     else if ((impl & 24) == 24) launch(gemm_p8_kernel<6, false, 3>);      // timing-only variants (tools/p8_bench.py): results are garbage
     else if (impl & 32) launch(gemm_p8_kernel<6, false, 8>);
     else if ((impl & 24) == 8) launch(gemm_p8_kernel<6, false, 1>);

@@ -46,11 +46,14 @@ def timeit(fn, n=20):
 
 outr = torch.empty((B * N, NO), device=dev)
 outp = ops.panels_empty(B, N, NO, dev)
-for impl in (5, 6):
+W2 = torch.nn.Parameter((torch.randn((NO, 64), generator=g) * 0.03).to(dev))
+for impl in (0, 5, 6):
     ops.P8_IMPL = impl
+    if impl == 0:
+        print("fused assignment: rows median/min us", timeit(lambda: ops.gemm_p8(S, W, shift=sh, act=ops.ACT_LEAKY, out=outr, assign_w=W2.data)))
     print("impl", impl, "p8 rows   median/min us", timeit(lambda: ops.gemm_p8(S, W, scale=sc, shift=sh, act=ops.ACT_LEAKY, out=outr)))
     print("impl", impl, "p8 panels median/min us", timeit(lambda: ops.gemm_p8(S, W, scale=sc, shift=sh, act=ops.ACT_LEAKY, out=outp, out_panels=True)))
-for impl, name in ((8, "no LDS-DMA in the loop"), (16, "no MFMAs (6 units ahead)"), (16 + 5, "no MFMAs (5 units ahead)"), (24, "neither (reads + barriers + stores)"), (32, "full, nt loads")):
+for impl, name in ((8, "no LDS-DMA in the loop"), (16, "no MFMAs (6 units ahead)"), (16 + 5, "no MFMAs (5 units ahead)"), (24, "neither (reads + barriers + stores)"), (32, "full, nt loads"), (64, "full, every phase's 12 MFMAs issued twice"), (96, "full, WITH s_setprio around the MFMAs")):
     ops.P8_IMPL = impl
     print("timing-only:", name, timeit(lambda: ops.gemm_p8(S, W, shift=sh, act=ops.ACT_LEAKY, out=outr)))
 ops.P8_IMPL = 0
