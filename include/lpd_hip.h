@@ -449,6 +449,9 @@ int lpd_edge_split_bwd(const float* dOut, long long ldo, const float* usel, cons
 int lpd_edge_build_bf16(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, uint16_t* U, long long M,
                         int N, int C, int k, double* sum, double* sumsq, void* stream);
 /* one pass over U: Y = act(scale U + shift) (bf16, the dense consumer's input) and out[i] = act(scale sel_t U + shift), arg[i] */
+/* fp32 storage form of the same pass: Y [M*k][C] = act(scale * U + shift), out [M][ldo] = max over the k rows of a point, arg the slot */
+int lpd_edge_act_max(const float* U, int k, const float* scale, const float* shift, int act, float slope, float* Y, float* out,
+                     long long ldo, uint8_t* arg, long long M, int C, void* stream);
 int lpd_edge_act_max_bf16(const uint16_t* U, int k, const float* scale, const float* shift, int act, float slope, uint16_t* Y,
                           float* out, long long ldo, uint8_t* arg, long long M, int C, void* stream);
 /* one pass over the raw conv output Z: batch statistics (sum, sumsq) and the raw selected value sel[i] = sel_t Z[(i,t)] with its

@@ -326,6 +326,50 @@ __global__ __launch_bounds__(256) void edge_act_max_bf16_kernel(const uint16_t* 
     }
 }
 
+// The same pass for fp32 edge tensors (fp32 storage mode: replaces lpd_group_max + lpd_affine_act, two reads of U, by one)
+__global__ __launch_bounds__(256) void edge_act_max_f32_kernel(const float* __restrict__ U, int k, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int act, float slope,
+                                                               float* __restrict__ Y, float* __restrict__ out, long long ldo,
+                                                               uint8_t* __restrict__ arg, long long M, int C)
+{
+    const int LQ = C >> 2;
+    const int RG = 256 / LQ;
+    const int q = threadIdx.x % LQ, rg = threadIdx.x / LQ;
+    const float ns = lpd_neg_slope(act, slope);
+    float sc[4], sh[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { sc[c] = scale[q * 4 + c]; sh[c] = shift[q * 4 + c]; }
+    for (long long i = (long long)blockIdx.x * RG + rg; i < M; i += (long long)gridDim.x * RG) {
+        float mx[4], mn[4];
+        int amx[4] = {0, 0, 0, 0}, amn[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { mx[c] = -INFINITY; mn[c] = INFINITY; }
+        for (int t = 0; t < k; ++t) {
+            const long long off = (i * k + t) * C + q * 4;
+            const float4 v4 = *reinterpret_cast<const float4*>(U + off);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            float y[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (v[c] > mx[c]) { mx[c] = v[c]; amx[c] = t; }
+                if (v[c] < mn[c]) { mn[c] = v[c]; amn[c] = t; }
+                y[c] = lpd_act_pl(sc[c] * v[c] + sh[c], ns);
+            }
+            *reinterpret_cast<float4*>(Y + off) = make_float4(y[0], y[1], y[2], y[3]);
+        }
+        float o[4];
+        uint8_t a[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool usemax = sc[c] >= 0.0f;
+            o[c] = lpd_act_pl(sc[c] * (usemax ? mx[c] : mn[c]) + sh[c], ns);
+            a[c] = (uint8_t)(usemax ? amx[c] : amn[c]);
+        }
+        *reinterpret_cast<float4*>(out + i * ldo + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uchar4*>(arg + i * C + q * 4) = make_uchar4(a[0], a[1], a[2], a[3]);
+    }
+}
+
 // One pass over Z (bf16, raw conv output): batch statistics of Z (fp64) and the raw selected value per point
 // sel[i] = sel_t Z[(i,t)] (max where gamma >= 0, min where gamma < 0) with its slot; the BatchNorm + activation of the
 // selected values is an [M, C] pass afterwards (the sign of the scale is the sign of gamma).
@@ -899,6 +943,22 @@ extern "C" int lpd_edge_act_max_bf16(const uint16_t* U, int k, const float* scal
     hipLaunchKernelGGL(edge_act_max_bf16_kernel, dim3(grid_for(M, rg, 8192)), dim3(256), 0, stream, U, k, scale, shift, act, slope, Y, out,
                        ldo, arg, M, C);
     LPD_CHECK_LAUNCH("lpd_edge_act_max_bf16");
+    return LPD_OK;
+}
+
+// fp32 storage: Y [M*k][C] = act(scale * U + shift), out [M][ldo] = its max over the k rows of a point, arg [M][C] the slot -- one pass
+// over U (util/lpdnet_model.py:249-250: convDG1's BatchNorm + activation and x1 = max over k)
+extern "C" int lpd_edge_act_max(const float* U, int k, const float* scale, const float* shift, int act, float slope, float* Y, float* out,
+                                long long ldo, uint8_t* arg, long long M, int C, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(U && scale && shift && Y && out && arg, "lpd_edge_act_max: null pointer");
+    LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && k <= 255 && ldo % 4 == 0, "lpd_edge_act_max: bad dims");
+    LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_act_max: activation %d unsupported", act);
+    const int rg = 256 / (C / 4);
+    hipLaunchKernelGGL(edge_act_max_f32_kernel, dim3(grid_for(M, rg, 8192)), dim3(256), 0, stream, U, k, scale, shift, act, slope, Y, out,
+                       ldo, arg, M, C);
+    LPD_CHECK_LAUNCH("lpd_edge_act_max");
     return LPD_OK;
 }
 

@@ -103,6 +103,7 @@ SIGNATURES = {
     "lpd_edge_split_bwd": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_ll,
                            _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_p],
     "lpd_edge_build_bf16": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p],
+    "lpd_edge_act_max": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p],
     "lpd_edge_act_max_bf16": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p],
     "lpd_group_sel_stats_bf16": [_c_p, _c_int, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p, _c_p, _c_p],
     "lpd_edge_bn_bwd_bf16": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int,

@@ -419,8 +419,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
             del zsel
         else:
             u1, stg1 = ops.edge_build(pq1[:, :128], pq1[:, 128:], idx_f, N, bn=net.convDG1[1])   # [E,128] raw + its BN statistics
-            arg1 = ops.group_max(u1, k, stg1.scale, stg1.shift, act, slope, cat[:, 0:128])            # x1
-            y1e = ops.affine_act(u1, stg1.scale, stg1.shift, act, slope)        # [E,128] post-activation edges
+            y1e, arg1 = ops.edge_act_max(u1, k, stg1, act, slope, out=cat[:, 0:128])                  # post-activation edges + x1, one pass over u1
             z, stg2 = ops.linear_bn_stats(y1e, w2d(net.convDG2[0]), net.convDG2[1])   # [E,128] raw + its statistics (GEMM epilogue)
             arg2 = ops.group_max(z, k, stg2.scale, stg2.shift, act, slope, cat[:, 128:256])           # x2
         # SN1 on the xyz graph, split form: statistics, max and arg-max from one gather pass, no [E,256] tensor

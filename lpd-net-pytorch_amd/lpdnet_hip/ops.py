@@ -1176,6 +1176,22 @@ def edge_build_bf16(P, Q, idx, N, bn):
     return U, _bn_finalize(sums, M * k, C, bn)
 
 
+def edge_act_max(U, k, st, act, slope, out):
+    """One pass over U (fp32 [M*k, C]): -> (Y = act(BN(U)) [M*k, C], arg uint8 [M, C]); out [M, C] receives max_k of the same values
+    (what group_max + affine_act compute with two reads of U)."""
+    _req(U, "U")
+    ldo = _rows(out, "out")
+    M, C = out.shape
+    if U.shape != (M * k, C) or not U.is_contiguous():
+        raise ValueError("edge_act_max: shape mismatch")
+    Y = torch.empty_like(U)
+    arg = torch.empty((M, C), dtype=torch.uint8, device=U.device)
+    lib = _lib.load()
+    _call(f"edge_act_max[C={C}]", lib.lpd_edge_act_max, _ptr(U), k, _ptr(st.scale), _ptr(st.shift), act, float(slope), _ptr(Y),
+          _ptr(out), ldo, _ptr(arg), M, C, _stream())
+    return Y, arg
+
+
 def edge_act_max_bf16(U, k, st, act, slope, out):
     """One pass over U (bf16): -> (Y = act(BN(U)) bf16 [M*k, C], arg uint8 [M, C]); out [M, C] receives max_k of the same values."""
     _bf16_rows(U, "U")
