@@ -57,20 +57,24 @@ def parse():
     return ap.parse_args()
 
 
+def visible_gpus():
+    """GPUs of this node counted WITHOUT the HIP runtime (the launcher must not initialise it): the kfd topology in sysfs lists one
+    node per agent, GPUs are the ones with SIMDs.  None when the topology is not visible (the ranks then report what they see)."""
+    try:
+        top = "/sys/class/kfd/kfd/topology/nodes"
+        return sum(1 for d in os.listdir(top)
+                   if any(ln.split()[0] == "simd_count" and int(ln.split()[1]) > 0 for ln in open(os.path.join(top, d, "properties"))))
+    except (OSError, ValueError, IndexError):
+        return None
+
+
 def launch_ranks(args):
     """--gpus N > 1 without RANK: start the N ranks as a CHILD process tree (never exec / re-use a process that has touched
     the GPU; this parent makes no HIP call at all: the GPUs are counted from the kfd topology in sysfs)."""
     import socket
     import subprocess
-    # count GPUs without the HIP runtime: the kfd topology lists one node per agent, GPUs are the ones with SIMDs
-    n_vis = None
-    try:
-        top = "/sys/class/kfd/kfd/topology/nodes"
-        n_vis = sum(1 for d in os.listdir(top)
-                    if any(ln.split()[0] == "simd_count" and int(ln.split()[1]) > 0 for ln in open(os.path.join(top, d, "properties"))))
-    except (OSError, ValueError, IndexError):
-        n_vis = None          # no topology (container without sysfs): let the ranks report what they see
-    if n_vis is not None and n_vis < args.gpus:
+    n_vis = visible_gpus()
+    if n_vis and n_vis < args.gpus:      # 0 / None: the topology is hidden (container): the ranks report what they see
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible on this node")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))

@@ -159,7 +159,7 @@ def test_bench_launcher_builds_the_torchrun_command(monkeypatch):
         seen["cmd"], seen["env"] = cmd, env
         return R()
     monkeypatch.setattr(subprocess, "run", fake_run)
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 8)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
     monkeypatch.delenv("RANK", raising=False)
     args = bench.parse()
@@ -168,6 +168,6 @@ def test_bench_launcher_builds_the_torchrun_command(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
     assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 1)
     with pytest.raises(SystemExit):
         bench.launch_ranks(args)
