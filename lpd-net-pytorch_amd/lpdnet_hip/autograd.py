@@ -923,3 +923,76 @@ def netvlad_train(vlad, feat, B, N):
         raise ValueError(f"NetVLADLoupe was built for max_samples={vlad.max_samples}, got N={N}")
     params = _named(vlad, _NetVLADTrainFn.param_names(vlad))
     return _NetVLADTrainFn.apply(vlad, B, N, feat, *params)
+
+
+# ------------------------------------------------------------------------------------------------
+# standalone train-mode forwards of the sub-modules the trunks normally drive from the inside
+# (TranformNet lpdnet_model.py:295-313, STN3d PointNetVlad.py:152-179, GatingContext PointNetVlad.py:103-115)
+# ------------------------------------------------------------------------------------------------
+class _TNetTrainFn(torch.autograd.Function):
+    """rows [B*N, kd] point-major -> [B, kd, kd]; the layers, BatchNorm statistics and backward of _TNet"""
+
+    @staticmethod
+    def forward(ctx, net, use_bn, B, N, rows, *params):
+        t, S = _TNet.fwd(net, rows, B, N, use_bn)
+        ctx.net, ctx.use_bn, ctx.dims, ctx.saved = net, use_bn, (B, N), S
+        ctx.need_dh = rows.requires_grad
+        return t
+
+    @staticmethod
+    def backward(ctx, dt):
+        B, N = ctx.dims
+        dh, grads = _TNet.bwd(ctx.net, dt.contiguous(), _saved(ctx), B, N, ctx.use_bn, need_dh=ctx.need_dh)
+        ctx.saved = None
+        return (None, None, None, None, dh) + tuple(grads)
+
+
+def tnet_train(net, rows, B, N, use_bn=True):
+    params = _named(net, _TNet.param_names(net, use_bn))
+    return _TNetTrainFn.apply(net, use_bn, B, N, rows, *params)
+
+
+class _GatingTrainFn(torch.autograd.Function):
+    """out = x * sigmoid(BN_train(x Wg)) (or sigmoid(x Wg + bias)); rows padded to a multiple of 32 like the head's"""
+
+    @staticmethod
+    def forward(ctx, gc, x, *params):
+        B, O = x.shape
+        Bp = (B + 31) // 32 * 32
+        h = torch.zeros((Bp, O), dtype=torch.float32, device=x.device)
+        h[:B] = x
+        with ops.exact_gemm():
+            g0 = ops.gemm(h, gc.gating_weights, b_kmajor=True)
+        if gc.add_batch_norm:
+            stg = ops.bn_train_stats(g0, gc.bn1, rows=B)
+            gates = ops.affine_act(g0, stg.scale, stg.shift, ops.ACT_SIGMOID, rows=B)
+        else:
+            stg = None
+            g0 = ops.affine_act(g0, torch.ones_like(gc.gating_biases), gc.gating_biases, ops.ACT_NONE, out=g0, rows=B)
+            gates = ops.affine_act(g0, None, None, ops.ACT_SIGMOID, rows=B)
+        ctx.gc, ctx.dims, ctx.saved = gc, (B, O, Bp), dict(h=h, g0=g0, stg=stg, gates=gates)
+        return ops.mul(h[:B], gates[:B])
+
+    @staticmethod
+    def backward(ctx, dout):
+        gc, S = ctx.gc, _saved(ctx)
+        B, O, Bp = ctx.dims
+        dout = dout.contiguous()
+        h, gates = S["h"], S["gates"]
+        dgates = torch.zeros((Bp, O), dtype=torch.float32, device=dout.device)
+        dh = torch.zeros((Bp, O), dtype=torch.float32, device=dout.device)
+        dgates[:B] = ops.mul(dout, h[:B])
+        dh[:B] = ops.mul(dout, gates[:B])
+        dg0, dgam, dbet = ops.bn_act_bwd(dgates, S["g0"], S["stg"], ops.ACT_SIGMOID, out=dgates, rows=B)
+        with ops.exact_gemm():
+            dwg = ops.gemm(h, dg0, a_kmajor=True, b_kmajor=True)
+            ops.gemm(dg0, gc.gating_weights, b_kmajor=False, out=dh, accumulate=True)
+        ctx.saved = None
+        tail = (dwg, dgam, dbet) if gc.add_batch_norm else (dwg, dbet)
+        return (None, dh[:B].clone()) + tail
+
+
+def gating_train(gc, x):
+    names = ["gating_weights"] + (["bn1.weight", "bn1.bias"] if gc.add_batch_norm else ["gating_biases"])
+    return _GatingTrainFn.apply(gc, x.float().contiguous(), *_named(gc, names))
+

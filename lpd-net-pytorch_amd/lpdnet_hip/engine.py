@@ -112,12 +112,6 @@ def conv3_folded(net):
     return _cached(net, "conv3_folded", src, lambda: (_w2d(conv) * bn_affine(bn)[0].unsqueeze(1)).contiguous())
 
 
-def _need_eval(module, what):
-    if module.training:
-        raise NotImplementedError(
-            f"{what}: training-mode forward goes through lpdnet_hip.autograd; call .eval() for inference")
-
-
 def _check_input(x, dims=3):
     if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 1 or x.shape[3] != dims:
         raise ValueError(f"expected input [B,1,N,{dims}], got {tuple(x.shape) if isinstance(x, torch.Tensor) else type(x)}")

@@ -31,7 +31,9 @@ class GatingContext(nn.Module):
             self.bn1 = None
 
     def forward(self, x):
-        engine._need_eval(self, "GatingContext")
+        if self.training:           # standalone train-mode forward (batch statistics over the rows, autograd): PointNetVlad.py:103-115
+            from lpdnet_hip import autograd
+            return autograd.gating_train(self, x)
         return engine.gating_eval(self, x.float().contiguous())
 
 
@@ -113,8 +115,18 @@ class STN3d(nn.Module):
             self.bn5 = nn.BatchNorm1d(256)
 
     def forward(self, x):
-        engine._need_eval(self, "STN3d")
         B = x.shape[0]
+        if self.training:           # standalone train-mode forward (batch statistics, autograd): reference PointNetVlad.py:152-179
+            from lpdnet_hip import autograd
+            if self.k == 3:
+                N = x.shape[2]
+                rows = x.float().reshape(B * N, 3)
+            else:
+                N = x.shape[2]
+                rows = x.float().reshape(B, self.k, N).transpose(1, 2).reshape(B * N, self.k)
+            if N != self.num_points:
+                raise ValueError(f"STN3d was built for num_points={self.num_points}, got N={N}")
+            return autograd.tnet_train(self, rows.contiguous(), B, N, use_bn=self.use_bn)
         if self.k == 3:
             N = x.shape[2]
             rows = x.float().contiguous().view(B * N, 3)

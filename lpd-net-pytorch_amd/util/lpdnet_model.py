@@ -90,10 +90,13 @@ class TranformNet(nn.Module):
         self.k = k
 
     def forward(self, x):
-        engine._need_eval(self, "TranformNet")
         if x.dim() != 3 or x.shape[1] != self.k:
             raise ValueError(f"TranformNet(k={self.k}): expected [B,{self.k},N], got {tuple(x.shape)}")
         B, N = x.shape[0], x.shape[2]
+        if self.training:           # standalone train-mode forward (batch statistics, autograd): reference lpdnet_model.py:295-313
+            from lpdnet_hip import autograd
+            rows = x.float().transpose(1, 2).reshape(B * N, self.k)      # [B,k,N] -> point-major rows (torch op: carries the gradient)
+            return autograd.tnet_train(self, rows.contiguous(), B, N, use_bn=True)
         rows = ops.transpose(x.float().contiguous()).view(B * N, self.k)
         return engine.transform_net_eval(self, rows, B, N)
 

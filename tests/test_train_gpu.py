@@ -575,3 +575,62 @@ def test_bf16_storage_converges_like_fp32(cuda):
 
 
 CONVERGENCE_LR = 1e-4
+
+
+def test_standalone_train_mode_forwards_of_the_submodules(cuda):
+    """TranformNet, STN3d (with and without BatchNorm, k = 3 and k = 64) and GatingContext (with and without BatchNorm) called
+    on their own in train mode -- what the reference's modules do when used outside PointNetVlad (lpdnet_model.py:295-313,
+    PointNetVlad.py:103-115,152-179): batch statistics, running-stat update, gradients to the input and every parameter,
+    against the fp64 oracle."""
+    from util.lpdnet_model import TranformNet
+    from util.PointNetVlad import STN3d, GatingContext
+    dt = torch.float64
+    g = torch.Generator().manual_seed(5)
+
+    def run(mod, pre, x, ofn, names):
+        mod = mod.to(cuda).train()
+        with torch.no_grad():
+            for p in mod.parameters():
+                p.copy_((torch.rand(p.shape, generator=g) - 0.5) * (0.4 if p.dim() > 1 else 1.0) + (0.8 if p.dim() == 1 else 0.0))
+        sd = {pre + k: (v.detach().cpu().to(dt).requires_grad_(True) if v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var"))
+                        else v.detach().cpu().to(dt) if v.dtype == torch.float32 else v.detach().cpu().clone()) for k, v in mod.state_dict().items()}
+        xg = x.to(cuda).requires_grad_(True)
+        xo = x.to(dt).requires_grad_(True)
+        got = mod(xg)
+        new_stats = {}
+        want = ofn(sd, xo, new_stats)
+        assert got.shape == want.shape
+        assert _desc_rel(got.reshape(got.shape[0], -1), want.reshape(want.shape[0], -1)) < 2e-4
+        w = torch.randn(want.shape, generator=g)
+        (got * w.to(cuda)).sum().backward()
+        (want * w.to(dt)).sum().backward()
+        assert ((xg.grad.cpu().double() - xo.grad).norm() / xo.grad.norm()).item() < 5e-3
+        for n in names:
+            a, b = dict(mod.named_parameters())[n].grad.cpu().double(), sd[pre + n].grad
+            assert ((a - b).norm() / b.norm()).item() < 5e-3, n
+        for n, b in mod.named_buffers():
+            if n.endswith("running_mean"):
+                assert torch.allclose(b.cpu().double(), new_stats[pre + n], rtol=1e-4, atol=1e-5), n
+            if n.endswith("num_batches_tracked"):
+                assert int(b) == 1
+
+    B, N = 8, 256
+    x3 = torch.randn(B, 3, N, generator=g)
+    run(TranformNet(3), "t.", x3, lambda sd, x, ns: orc.transform_net(sd, "t.", x, True, ns), ["conv1.weight", "conv3.weight", "bn3.weight", "fc2.weight", "fc3.bias"])
+    x64 = torch.randn(B, 64, N, generator=g)
+    run(TranformNet(64), "t.", x64, lambda sd, x, ns: orc.transform_net(sd, "t.", x, True, ns), ["conv1.weight", "bn5.bias", "fc3.weight"])
+    xs = torch.randn(B, 1, N, 3, generator=g)
+    run(STN3d(num_points=N, k=3, use_bn=True), "s.", xs, lambda sd, x, ns: orc.stn3d(sd, "s.", x, 3, True, ns, True), ["conv1.weight", "bn4.weight", "fc3.weight"])
+    run(STN3d(num_points=N, k=3, use_bn=False), "s.", xs, lambda sd, x, ns: orc.stn3d(sd, "s.", x, 3, True, ns, False), ["conv2.weight", "fc1.bias", "fc3.weight"])
+    xf = torch.randn(B, 64, N, 1, generator=g)
+    run(STN3d(num_points=N, k=64, use_bn=True), "s.", xf, lambda sd, x, ns: orc.stn3d(sd, "s.", x, 64, True, ns, True), ["conv1.weight", "bn1.bias", "fc3.bias"])
+
+    def gating_oracle(bn):
+        def f(sd, x, ns):
+            gts = torch.matmul(x, sd["g.gating_weights"])
+            gts = orc._bn(sd, "g.bn1", gts, True, ns) if bn else gts + sd["g.gating_biases"]
+            return x * torch.sigmoid(gts)
+        return f
+    xh = torch.randn(12, 256, generator=g)
+    run(GatingContext(256, add_batch_norm=True), "g.", xh, gating_oracle(True), ["gating_weights", "bn1.weight", "bn1.bias"])
+    run(GatingContext(256, add_batch_norm=False), "g.", xh, gating_oracle(False), ["gating_weights", "gating_biases"])
