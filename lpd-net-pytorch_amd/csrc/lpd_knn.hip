@@ -492,11 +492,17 @@ __device__ __forceinline__ void knn3_ld_xx(const float* __restrict__ xxb, int N,
 // One tile: pd of 32 candidates x 32 queries on the MFMA; operand registers are refilled with the NEXT tile's
 // values four at a time right after the MFMAs that consumed them have issued.
 //   pd = ((-xx_j) - (-2 dot)) - xx_i ;  (-xx_j) - (-2 dot) == fma(2, dot, -xx_j) bit for bit (2*dot is exact).
-template <int CP>
+// ALWAYS (clouds of whole 32-point tiles, N % 32 == 0): the refills are UNCONDITIONAL and the squared norms one vector load each -- no
+// branch inside the tile.  With `if (have_next)` around the refills the compiler resolves the vmcnt state at every join by waiting
+// for vmcnt(0) -- in the middle of the tile's MFMA sequence and again in front of the norm loads: two L2 round trips per visited
+// tile, the ~3 k cycles of 'advance' per tile that no re-coding of the walk could remove.  Callers pass a valid
+// tile (any) when there is no next one; its values are never used.
+template <int CP, bool ALWAYS = false>
 __device__ __forceinline__ void knn3_tile(float (&a)[CP], float4 (&x4)[4], const float (&qreg)[CP], float xq,
                                           const float* __restrict__ xpb, const float* __restrict__ xxb, int N, int j_next,
                                           bool have_next, int col, int h, bool vec_ok, float (&pd)[16])
 {
+    if constexpr (ALWAYS) have_next = true;
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const float* row = xpb + ((size_t)min(j_next + col, N - 1) * 2 + h) * CP;
     if constexpr (CP % 4 == 0) {
@@ -524,7 +530,10 @@ __device__ __forceinline__ void knn3_tile(float (&a)[CP], float4 (&x4)[4], const
         const float xxj = (r & 3) == 0 ? xv.x : (r & 3) == 1 ? xv.y : (r & 3) == 2 ? xv.z : xv.w;
         pd[r] = __fsub_rn(__fmaf_rn(2.0f, acc[r], -xxj), xq);
     }
-    if (have_next) knn3_ld_xx(xxb, N, j_next, h, vec_ok, x4);
+    if constexpr (ALWAYS) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) x4[g] = *reinterpret_cast<const float4*>(xxb + j_next + 8 * g + 4 * h);
+    } else if (have_next) knn3_ld_xx(xxb, N, j_next, h, vec_ok, x4);
 }
 
 template <int CP, int KMAX>
@@ -1262,7 +1271,7 @@ __device__ __forceinline__ void knn7_insert(float (&v)[KMAX], int (&id)[KMAX], f
 // WAVES: waves per workgroup.  A workgroup's LDS and wave slots stay taken until its slowest wave is done and the tile
 // counts of neighbouring waves differ (C = 64: mean 51, p90 69, max 89 tiles): single-wave workgroups at C = 64
 // (638 -> 607 us), four waves at C = 3 (shorter waves; the larger groups launch faster: 278 vs 287 us).
-template <int CP, int KMAX, int WAVES, bool ONFLY>
+template <int CP, int KMAX, int WAVES, bool ONFLY, bool FULLT = false>
 __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SIMD)) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
                                                              const float* __restrict__ cenp, const float* __restrict__ cnorm,
                                                              const float* __restrict__ rad, const float* __restrict__ txmax,
@@ -1271,6 +1280,7 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
                                                              const uint16_t* __restrict__ ubq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem7[];
+    if constexpr (FULLT) dbg = 0;      // diagnostics (statistics, phase clocks) live in the branchy variant only: they cost ~17 registers
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too
@@ -1359,12 +1369,12 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
     // visiting order: outwards along the Z-curve, W, W+1, W-1, W+2, ... (the visited tiles always form an interval around
     // W, which is what makes the one-compare insertion exact)
     int spos = 0;
-    auto find_next = [&]() -> int {   // next tile in order that some query of the wave can still gain from; -1 at the end
+    auto find_next_walk = [&]() -> int {   // next tile in order that some query of the wave can still gain from; -1 at the end
         while (spos < 2 * nt) {
             const int T = (spos & 1) ? W + ((spos + 1) >> 1) : W - (spos >> 1);
             ++spos;
             if (T < 0 || T >= nt) continue;
-            if constexpr ((CP == 32) && !ONFLY) ++stat_fn;
+            if constexpr ((CP == 32) && !ONFLY && !FULLT) ++stat_fn;
             float ub;
             if constexpr (CP == 2) {   // centroid in operand order (c0, c2 | c1, 0), like the query's own row
                 const float4 cen = *reinterpret_cast<const float4*>(cenb + (size_t)T * 4);
@@ -1396,12 +1406,54 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
         }
         return -1;
     };
+    // Large clouds with tabulated bounds (ONFLY && ubq): one dependent 2-byte global read per TESTED tile -- 512 of them per wave at
+    // N = 16384, an L2 round trip each -- was the walk's cost.  The bounds of eight consecutive walk positions are now requested
+    // together (eight independent loads, packed two per register) and tested as a bit mask against the current threshold: one round
+    // trip per eight tiles.  The bounds do not depend on the threshold, so testing a cached bound later is the same test.
+    uint32_t ubp[4] = {0, 0, 0, 0};
+    uint32_t cvalid = 0;               // bit j: cached position j is a tile of the cloud (the first threshold is -inf: a sentinel bound would pass)
+    int cbase = -8;                    // walk position of the first cached bound (a multiple of 8); spos in [cbase, cbase + 8) is cached
+    auto walk_tile = [&](int pos) -> int { return (pos & 1) ? W + ((pos + 1) >> 1) : W - (pos >> 1); };
+    auto find_next_tab = [&]() -> int {
+        while (spos < 2 * nt) {
+            if (spos >= cbase + 8) {
+                cbase = spos & ~7;
+                cvalid = 0;
+                uint32_t raw[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int T = walk_tile(cbase + j);
+                    const bool ok = T >= 0 && T < nt;                                   // uniform
+                    cvalid |= (ok ? 1u : 0u) << j;
+                    raw[j] = (uint32_t)ubq[(((size_t)b * nt + W) * nt + (ok ? T : W)) * 32 + col];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ubp[j] = raw[2 * j] | (raw[2 * j + 1] << 16);
+            }
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float ub = __uint_as_float((j & 1) ? (ubp[j >> 1] & 0xffff0000u) : (ubp[j >> 1] << 16));
+                m |= (__any(ub >= thrv) ? 1u : 0u) << j;
+            }
+            m &= cvalid & ~((1u << (spos - cbase)) - 1u);          // tiles of the cloud, not yet consumed
+            if (m == 0) { spos = cbase + 8; continue; }
+            const int j = __builtin_ctz(m);
+            spos = cbase + j + 1;
+            return walk_tile(cbase + j);
+        }
+        return -1;
+    };
+    auto find_next = [&]() -> int {
+        if constexpr (ONFLY && CP == 32) { if (ubq) return find_next_tab(); }
+        return find_next_walk();
+    };
     auto drain = [&]() {
         int nmax = cnt;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, __shfl_xor(nmax, m, 64));
         nmax = __builtin_amdgcn_readfirstlane(nmax);
-        stat_it += nmax; stat_adm += cnt; ++stat_drains;
+        if constexpr (!FULLT) { stat_it += nmax; stat_adm += cnt; ++stat_drains; }
         for (int e = 0; e < nmax; ++e) {
             const float2 ent = myq[(e < cnt ? e : 0) * 64];
             const float pv = (e < cnt && ent.x >= lv[KMAX - 1]) ? ent.x : -INFINITY;   // -inf: no-op insert (branch-free)
@@ -1426,7 +1478,7 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
     };
 
     long long tm_adv = 0, tm_tile = 0, tm_sel = 0, tm_drain = 0, tm0 = 0, tm_start = 0;   // dbg: cycles per phase (s_memtime)
-    constexpr bool TIMERS = (CP == 32) && !ONFLY;     // (the phase clocks cost the xyz kernel registers it does not have: 128 at four waves per SIMD)
+    constexpr bool TIMERS = (CP == 32) && !ONFLY && !FULLT;     // (the phase clocks cost the xyz kernel registers it does not have: 128 at four waves per SIMD)
     auto tick = [&]() -> long long { return (TIMERS && dbg) ? (long long)__builtin_readcyclecounter() : 0; };
     tm_start = tick();
     // Operands two tiles ahead (TWO register sets, 64 channels with short lists only: 226 registers): a tile's operands are
@@ -1452,10 +1504,10 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
     }
     // one tile: `cur` sits in (aa, xx4), which the product refills with the operands of the tile TWO_AHEAD ? nxt2 : nxt
     auto visit = [&](auto& aa, float4 (&xx4)[4]) {
-        ++stat_tiles;
+        if constexpr (!FULLT) ++stat_tiles;
         tm0 = tick();
         const int pf = TWO_AHEAD ? nxt2 : nxt;
-        knn3_tile<CP>(aa, xx4, qreg, xq, xpb, xxb, N, (pf >= 0 ? pf : 0) * 32, pf >= 0, col, h, vec_ok, pd);
+        knn3_tile<CP, FULLT>(aa, xx4, qreg, xq, xpb, xxb, N, (pf >= 0 ? pf : 0) * 32, pf >= 0, col, h, vec_ok, pd);
         float mx = fmaxf(fmaxf(fmaxf(pd[0], pd[1]), fmaxf(pd[2], pd[3])), fmaxf(fmaxf(pd[4], pd[5]), fmaxf(pd[6], pd[7])));
         mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(pd[8], pd[9]), fmaxf(pd[10], pd[11])), fmaxf(fmaxf(pd[12], pd[13]), fmaxf(pd[14], pd[15]))));
         if (TIMERS && dbg) { const long long t = tick(); tm_tile += t - tm0; tm0 = t; }
@@ -1498,10 +1550,10 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
         }
     } else {
         while (cur >= 0) {
-            ++stat_tiles;
+            if constexpr (!FULLT) ++stat_tiles;
             tm0 = tick();
             const int pf = nxt;
-            knn3_tile<CP>(a, x4, qreg, xq, xpb, xxb, N, (pf >= 0 ? pf : 0) * 32, pf >= 0, col, h, vec_ok, pd);
+            knn3_tile<CP, FULLT>(a, x4, qreg, xq, xpb, xxb, N, (pf >= 0 ? pf : 0) * 32, pf >= 0, col, h, vec_ok, pd);
             float mx = fmaxf(fmaxf(fmaxf(pd[0], pd[1]), fmaxf(pd[2], pd[3])), fmaxf(fmaxf(pd[4], pd[5]), fmaxf(pd[6], pd[7])));
             mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(pd[8], pd[9]), fmaxf(pd[10], pd[11])), fmaxf(fmaxf(pd[12], pd[13]), fmaxf(pd[14], pd[15]))));
             if (TIMERS && dbg) { const long long t = tick(); tm_tile += t - tm0; tm0 = t; }
@@ -1691,11 +1743,15 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
     }
     {
         size_t lds = (size_t)WAVES * L::WAVE;
-        auto kern = knn7_kernel<CP, KMAX, WAVES, ONFLY>;
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(WAVES * 64), lds, stream, (const float*)xp, xx, (const float*)cenp,
-                           (const float*)cnorm, (const float*)rad, (const float*)txmax, idx, (const int32_t*)(lpt ? order : nullptr),
-                           N, k, nt, C, bpc, dbg, (const uint16_t*)ubq);
+        static const bool branchy = getenv("LPD_KNN_FULLT") && atoi(getenv("LPD_KNN_FULLT")) == 0;     // 0: the branchy tile body for every N
+        auto go = [&](auto kern) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(WAVES * 64), lds, stream, (const float*)xp, xx, (const float*)cenp,
+                               (const float*)cnorm, (const float*)rad, (const float*)txmax, idx, (const int32_t*)(lpt ? order : nullptr),
+                               N, k, nt, C, bpc, dbg, (const uint16_t*)ubq);
+        };
+        if (N % 32 == 0 && !branchy && !dbg) go(knn7_kernel<CP, KMAX, WAVES, ONFLY, true>);      // whole tiles: branch-free tile body
+        else go(knn7_kernel<CP, KMAX, WAVES, ONFLY, false>);
         LPD_CHECK_LAUNCH("lpd_knn(best-first)");
     }
     return LPD_OK;
@@ -1789,8 +1845,8 @@ extern "C" int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
     LPD_CHECK_ARG(B <= 65535, "lpd_knn: B=%d exceeds grid.y", B);
     hipLaunchKernelGGL(knn_sumsq_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xx_ws, C, N);
     LPD_CHECK_LAUNCH("lpd_knn(sumsq)");
-    if (((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && knn7_applies(C, N, k))   // best-first (5: statistics)
-        return knn7_dispatch(x, xx_ws, idx, B, C, N, k, stream, impl == 5);
+    if (((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6 || impl == 7 || impl == 8)) && knn7_applies(C, N, k))   // best-first (5: statistics)
+        return knn7_dispatch(x, xx_ws, idx, B, C, N, k, stream, impl == 5 ? 1 : (impl == 7 ? 256 : (impl == 8 ? 512 : 0)));   // 7 / 8: timing experiments
     if (impl == 0 || impl == 4) {   // ascending scan (larger clouds, k > 20; impl 4: forced, for A/B timing)
         if (C <= 4) return knn3_dispatch_k<2>(x, xx_ws, idx, B, C, N, k, stream);
         if (C <= 64) return knn3_dispatch_k<32>(x, xx_ws, idx, B, C, N, k, stream);
