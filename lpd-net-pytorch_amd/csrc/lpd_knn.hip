@@ -1845,8 +1845,8 @@ extern "C" int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
     LPD_CHECK_ARG(B <= 65535, "lpd_knn: B=%d exceeds grid.y", B);
     hipLaunchKernelGGL(knn_sumsq_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xx_ws, C, N);
     LPD_CHECK_LAUNCH("lpd_knn(sumsq)");
-    if (((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6 || impl == 7 || impl == 8)) && knn7_applies(C, N, k))   // best-first (5: statistics)
-        return knn7_dispatch(x, xx_ws, idx, B, C, N, k, stream, impl == 5 ? 1 : (impl == 7 ? 256 : (impl == 8 ? 512 : 0)));   // 7 / 8: timing experiments
+    if (((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && knn7_applies(C, N, k))   // best-first (5: statistics)
+        return knn7_dispatch(x, xx_ws, idx, B, C, N, k, stream, impl == 5);
     if (impl == 0 || impl == 4) {   // ascending scan (larger clouds, k > 20; impl 4: forced, for A/B timing)
         if (C <= 4) return knn3_dispatch_k<2>(x, xx_ws, idx, B, C, N, k, stream);
         if (C <= 64) return knn3_dispatch_k<32>(x, xx_ws, idx, B, C, N, k, stream);
