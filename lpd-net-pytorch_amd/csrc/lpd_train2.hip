@@ -645,15 +645,16 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint16_t* __res
     // patch of this thread: matrix (A for tid < KA, B for the next KB threads), channel group c8, row group rg
     const bool isA = tid < KA;
     const int pt = isA ? tid : tid - KA;
-    const int ncg = (isA ? KA : KB) / 8;
-    const int c8 = pt % ncg, rg = pt / ncg;                       // rg in 0..7 (KA, KB multiples of 64: ncg * 8 = K patches)
+    const int rg = pt & 7, c8 = pt >> 3;                          // row group 0..7, channel group 0..K/8-1
     const bool active = tid < KA + KB;
     const uint16_t* src = (isA ? A : B) + c8 * 8;
     const int ldsrc = isA ? KA : KB;
-    // column blocks (8 rows of m = 16 bytes) are XOR-swizzled with the channel group: a wave's sixteen lanes with consecutive
-    // c8 write rows 8 * 144 bytes apart, i.e. onto only two of the sixteen 16-byte bank groups (8-way conflicts on every
-    // ds_write_b128: 8 of the 15 k cycles per chunk); the readers apply the same swizzle
-    uint16_t* dst = (isA ? at : bt) + (c8 * 8) * LDT + ((rg ^ (c8 >> 1)) & 7) * 8;
+    // LDS banking (MI355X_MICROARCH.md, LDS): a ds_write_b128 is served in groups of 8 consecutive lanes over 32 banks -- the eight
+    // lanes of a group hold the eight ROW groups of one channel group, i.e. 128 contiguous bytes of a transposed row; the
+    // ds_read_b128 of the MFMA operands (16-lane groups over 64 banks, channel stride 144 B = 36 dwords: slot 9 * col mod 16) is
+    // conflict-free on the plain image too.  (Rounds 1-2 put consecutive CHANNEL groups into a lane group and XOR-swizzled the
+    // column blocks: 2-way on every write AND every read, SQ_LDS_BANK_CONFLICT = as many cycles as the conflict-free accesses.)
+    uint16_t* dst = (isA ? at : bt) + (c8 * 8) * LDT + rg * 8;
     uint4 pr[8];
     auto load_patch = [&](long long m0) {
 #pragma unroll
@@ -698,8 +699,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint16_t* __res
 #pragma unroll
                 for (int s = 0; s < CH / 16; ++s) {
                     const int ca = ta * 32 + col, cb = tb * 32 + col;
-                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(at + ca * LDT + (((s * 2 + h) ^ (ca >> 4)) & 7) * 8);
-                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bt + cb * LDT + (((s * 2 + h) ^ (cb >> 4)) & 7) * 8);
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(at + ca * LDT + (s * 2 + h) * 8);
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bt + cb * LDT + (s * 2 + h) * 8);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
                 }
             }
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint16_t* __res
 // ahead), converts it to packed bf16 hi / lo pairs, transposes both in registers (v_perm_b32) and writes sixteen 16-byte
 // channel pieces into four [channel][row] LDS images.
 template <int KBT>
-__global__ __launch_bounds__(256) void gemm_tn_x3_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B,
+__global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B,
                                                          long long ldb, float* __restrict__ slabs, long long M, int KA, int KB,
                                                          long long rows_per_split, int nsplit, long long sA, long long sB)
 {
@@ -756,12 +757,11 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(const float* __restrict
     const long long m_end = min(M, m_begin + rows_per_split);
     const bool isA = tid < 128;
     const int pt = isA ? tid : tid - 128;
-    const int ncg = (isA ? 128 : KBT) / 8;
-    const int c8 = pt % ncg, rg = pt / ncg;
+    const int rg = pt & 7, c8 = pt >> 3;       // a lane group of 8 = the 8 row groups of one channel group (see gemm_tn_bf16_kernel)
     const bool active = isA || pt < KBT;       // KBT = 64: threads 192.. have no patch
     const float* src = isA ? A + a0 + c8 * 8 : B + b0 + c8 * 8;
     const long long ldsrc = isA ? lda : ldb;
-    const int swz = ((rg ^ (c8 >> 1)) & 7) * 8;      // XOR-swizzled column block (see gemm_tn_bf16_kernel)
+    const int swz = rg * 8;
     uint16_t* dhi = (isA ? ah : bh) + (c8 * 8) * LDT + swz;
     uint16_t* dlo = (isA ? al : bl) + (c8 * 8) * LDT + swz;
     float4 pr[16];
@@ -776,31 +776,30 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(const float* __restrict
     };
     auto store_patch = [&]() {
         if (!active) return;
-        uint32_t wh[8][4], wl[8][4];           // row i, channel pair p: packed bf16 (channel 2p | channel 2p+1 << 16)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float v[8] = {pr[2 * i].x, pr[2 * i].y, pr[2 * i].z, pr[2 * i].w, pr[2 * i + 1].x, pr[2 * i + 1].y, pr[2 * i + 1].z, pr[2 * i + 1].w};
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const uint32_t hp = pack_bf16(v[2 * p], v[2 * p + 1]);
-                const float r0 = v[2 * p] - __uint_as_float(hp << 16), r1 = v[2 * p + 1] - __uint_as_float(hp & 0xffff0000u);
-                wh[i][p] = hp;
-                wl[i][p] = pack_bf16(r0, r1);
-            }
-        }
+        // one channel pair at a time (its eight rows converted, transposed, written): 16 temporaries live instead of 64 -- with all
+        // four pairs converted first the <128> kernel needed 264 registers, i.e. ONE block per CU
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
+            uint32_t wh[8], wl[8];             // row i: packed bf16 (channel 2p | channel 2p+1 << 16)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 q = pr[2 * i + (p >> 1)];
+                const float v0 = (p & 1) ? q.z : q.x, v1 = (p & 1) ? q.w : q.y;
+                const uint32_t hp = pack_bf16(v0, v1);
+                wh[i] = hp;
+                wl[i] = pack_bf16(v0 - __uint_as_float(hp << 16), v1 - __uint_as_float(hp & 0xffff0000u));
+            }
             uint4 lo, hi;
-            lo.x = __builtin_amdgcn_perm(wh[1][p], wh[0][p], 0x05040100u); hi.x = __builtin_amdgcn_perm(wh[1][p], wh[0][p], 0x07060302u);
-            lo.y = __builtin_amdgcn_perm(wh[3][p], wh[2][p], 0x05040100u); hi.y = __builtin_amdgcn_perm(wh[3][p], wh[2][p], 0x07060302u);
-            lo.z = __builtin_amdgcn_perm(wh[5][p], wh[4][p], 0x05040100u); hi.z = __builtin_amdgcn_perm(wh[5][p], wh[4][p], 0x07060302u);
-            lo.w = __builtin_amdgcn_perm(wh[7][p], wh[6][p], 0x05040100u); hi.w = __builtin_amdgcn_perm(wh[7][p], wh[6][p], 0x07060302u);
+            lo.x = __builtin_amdgcn_perm(wh[1], wh[0], 0x05040100u); hi.x = __builtin_amdgcn_perm(wh[1], wh[0], 0x07060302u);
+            lo.y = __builtin_amdgcn_perm(wh[3], wh[2], 0x05040100u); hi.y = __builtin_amdgcn_perm(wh[3], wh[2], 0x07060302u);
+            lo.z = __builtin_amdgcn_perm(wh[5], wh[4], 0x05040100u); hi.z = __builtin_amdgcn_perm(wh[5], wh[4], 0x07060302u);
+            lo.w = __builtin_amdgcn_perm(wh[7], wh[6], 0x05040100u); hi.w = __builtin_amdgcn_perm(wh[7], wh[6], 0x07060302u);
             *reinterpret_cast<uint4*>(dhi + (2 * p) * LDT) = lo;
             *reinterpret_cast<uint4*>(dhi + (2 * p + 1) * LDT) = hi;
-            lo.x = __builtin_amdgcn_perm(wl[1][p], wl[0][p], 0x05040100u); hi.x = __builtin_amdgcn_perm(wl[1][p], wl[0][p], 0x07060302u);
-            lo.y = __builtin_amdgcn_perm(wl[3][p], wl[2][p], 0x05040100u); hi.y = __builtin_amdgcn_perm(wl[3][p], wl[2][p], 0x07060302u);
-            lo.z = __builtin_amdgcn_perm(wl[5][p], wl[4][p], 0x05040100u); hi.z = __builtin_amdgcn_perm(wl[5][p], wl[4][p], 0x07060302u);
-            lo.w = __builtin_amdgcn_perm(wl[7][p], wl[6][p], 0x05040100u); hi.w = __builtin_amdgcn_perm(wl[7][p], wl[6][p], 0x07060302u);
+            lo.x = __builtin_amdgcn_perm(wl[1], wl[0], 0x05040100u); hi.x = __builtin_amdgcn_perm(wl[1], wl[0], 0x07060302u);
+            lo.y = __builtin_amdgcn_perm(wl[3], wl[2], 0x05040100u); hi.y = __builtin_amdgcn_perm(wl[3], wl[2], 0x07060302u);
+            lo.z = __builtin_amdgcn_perm(wl[5], wl[4], 0x05040100u); hi.z = __builtin_amdgcn_perm(wl[5], wl[4], 0x07060302u);
+            lo.w = __builtin_amdgcn_perm(wl[7], wl[6], 0x05040100u); hi.w = __builtin_amdgcn_perm(wl[7], wl[6], 0x07060302u);
             *reinterpret_cast<uint4*>(dlo + (2 * p) * LDT) = lo;
             *reinterpret_cast<uint4*>(dlo + (2 * p + 1) * LDT) = hi;
         }
@@ -819,13 +818,13 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(const float* __restrict
 #pragma unroll
         for (int s = 0; s < CH / 16; ++s) {
             const int ca = wave * 32 + col;
-            const int oa = ca * LDT + (((s * 2 + h) ^ (ca >> 4)) & 7) * 8;
+            const int oa = ca * LDT + (s * 2 + h) * 8;
             const bf16x8 avh = *reinterpret_cast<const bf16x8*>(ah + oa);
             const bf16x8 avl = *reinterpret_cast<const bf16x8*>(al + oa);
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
                 const int cb = j * 32 + col;
-                const int ob = cb * LDT + (((s * 2 + h) ^ (cb >> 4)) & 7) * 8;
+                const int ob = cb * LDT + (s * 2 + h) * 8;
                 const bf16x8 bvh = *reinterpret_cast<const bf16x8*>(bh + ob);
                 const bf16x8 bvl = *reinterpret_cast<const bf16x8*>(bl + ob);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl, bvh, acc[j], 0, 0, 0);
@@ -842,6 +841,144 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(const float* __restrict
             const int arow = a0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             slab[(size_t)arow * KB + b0 + j * 32 + col] = acc[j][r];
         }
+}
+
+// The wide weight gradient (conv3: dW3 = dZ^T X, 1024 x 512 over 180 224 rows) on 256 x 256 output tiles.  gemm_tn_x3_kernel
+// above runs that shape at 26 % of the matrix peak: its 128 x 128 tiles move 5.9 GB through L2 for 1.1 GB of operands, a chunk's
+// conversion (305 vector instructions per wave) and its 48 MFMAs alternate between two barriers, and the loads of the next chunk
+// have only the MFMA phase to land in (PMC: 45 % of the wave cycles issue-stalled, 24 % parked).  Here: 512 threads, a wave owns
+// 64 x 128 of the tile (2 x 4 accumulator tiles), 32-row chunks in TWO halves of the same [channel][row] images (channel rows
+// of 144 bytes: 64 rows + 16 bytes of padding -- the operand reads are conflict-free on 36-dword strides, and a store group
+// of 8 lanes = 4 row groups x 2 channel quads 576 bytes apart covers 128 contiguous bytes of banks), ONE barrier per chunk:
+// while the MFMAs of chunk n read one half, the same waves convert chunk n+1 (requested a whole iteration earlier) and write
+// it to the other half, and request chunk n+2.  All loads are unconditional (M % 32 == 0, ranges of whole chunks).
+__global__ __launch_bounds__(512, 2) void gemm_tn_x3_256_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B,
+                                                                long long ldb, float* __restrict__ slabs, int KA, int KB,
+                                                                long long rows_per_split, long long M)
+{
+    constexpr int LDB = 144;                       // bytes per channel row of an image
+    extern __shared__ __attribute__((aligned(16))) unsigned char tn3_lds[];
+    unsigned char* const img_hi = tn3_lds;                  // [512 channels: A 0..255, B 256..511][144]
+    unsigned char* const img_lo = tn3_lds + 512 * LDB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int ntile_a = KA / 256, ntile_b = KB / 256;
+    const int lin = lpd_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = lin % (ntile_a * ntile_b), split = lin / (ntile_a * ntile_b);
+    const int a0 = (tile % ntile_a) * 256, b0 = (tile / ntile_a) * 256;
+    const long long m_begin = (long long)split * rows_per_split;
+    const long long m_end = min(M, m_begin + rows_per_split);
+    const int nchunk = (int)((m_end - m_begin) / 32);
+    // this thread's patch: 8 rows (row group rg) x 4 channels (quad); waves 0..3 stage A, waves 4..7 stage B
+    const int rg = tid & 3, quad = tid >> 2;
+    const bool isA = quad < 64;
+    const float* src = isA ? A + a0 + quad * 4 : B + b0 + (quad - 64) * 4;
+    const long long ldsrc = isA ? lda : ldb;
+    src += (m_begin + rg * 8) * ldsrc;
+    const long long chunk_step = 32 * ldsrc;
+    const int wr_off = (quad * 4) * LDB + rg * 16;             // + 64 * half + channel * 144
+    const int wa = wave & 3, wb = wave >> 2;                  // wave's tiles: A channels 64 wa .. +63, B channels 128 wb .. +127
+    const int rd_a = (wa * 64 + col) * LDB + h * 16;          // + 64 * half + 32 * kstep + 32 * 144 * tile
+    const int rd_b = (256 + wb * 128 + col) * LDB + h * 16;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 r0[8], r1[8];
+    auto load = [&](float4 (&r)[8], int chunk) {
+        const float* p = src + (long long)chunk * chunk_step;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = *reinterpret_cast<const float4*>(p + i * ldsrc);
+    };
+    // conversion of a patch in eight pieces (channel pair p = piece / 4: rows 0..3, rows 4..7, the two hi stores, the two lo stores)
+    uint32_t wh[8], wl[8];
+    auto conv_piece = [&](const float4 (&r)[8], int half, int piece) {
+        const int p = piece >> 2, sub = piece & 3;
+        if (sub < 2) {
+#pragma unroll
+            for (int i = 4 * sub; i < 4 * sub + 4; ++i) {
+                const float v0 = p ? r[i].z : r[i].x, v1 = p ? r[i].w : r[i].y;
+                const uint32_t hp = pack_bf16(v0, v1);
+                wh[i] = hp;
+                wl[i] = pack_bf16(v0 - __uint_as_float(hp << 16), v1 - __uint_as_float(hp & 0xffff0000u));
+            }
+        } else {
+            const uint32_t* w = sub == 2 ? wh : wl;
+            uint4 e, o;                            // even / odd channel of the pair: rows 0..7 as four dwords
+            e.x = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u); o.x = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
+            e.y = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u); o.y = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+            e.z = __builtin_amdgcn_perm(w[5], w[4], 0x05040100u); o.z = __builtin_amdgcn_perm(w[5], w[4], 0x07060302u);
+            e.w = __builtin_amdgcn_perm(w[7], w[6], 0x05040100u); o.w = __builtin_amdgcn_perm(w[7], w[6], 0x07060302u);
+            unsigned char* img = sub == 2 ? img_hi : img_lo;
+            const int off = wr_off + half * 64 + (2 * p) * LDB;
+            *reinterpret_cast<uint4*>(img + off) = e;
+            *reinterpret_cast<uint4*>(img + off + LDB) = o;
+        }
+    };
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+    auto read_a = [&](int half, int ks) {
+        const int oa = rd_a + half * 64 + ks * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const bf16x8*>(img_hi + oa + i * 32 * LDB);
+            al[i] = *reinterpret_cast<const bf16x8*>(img_lo + oa + i * 32 * LDB);
+        }
+    };
+    auto read_b = [&](int slot, int half, int ks, int j) {
+        const int ob = rd_b + half * 64 + ks * 32 + j * 32 * LDB;
+        bh[slot] = *reinterpret_cast<const bf16x8*>(img_hi + ob);
+        bl[slot] = *reinterpret_cast<const bf16x8*>(img_lo + ob);
+    };
+    // one chunk: eight blocks of [operand reads of the NEXT block | 6 MFMAs | one piece of the next chunk's conversion].  (Pinning
+    // the blocks with sched_barrier(0), or leaving the conversion in one lump between the two k-steps, times the same: 725..730 us
+    // for dW3 against 993 us for the 128-wide kernel on the same box; PMC: no LDS conflicts, MFMA-busy 0.37..0.40.)
+    auto chunk = [&](int n, const float4 (&cur)[8], float4 (&nxt)[8]) {
+        const int half = n & 1;
+        load(nxt, n + 2 < nchunk ? n + 2 : nchunk - 1);        // unconditional: the last chunks are re-read and dropped
+        read_a(half, 0);
+        read_b(0, half, 0, 0);
+#pragma unroll
+        for (int step = 0; step < 8; ++step) {
+            const int j = step & 3, sl = step & 1;
+            if (step < 7) read_b(sl ^ 1, half, (step + 1) >> 2, (step + 1) & 3);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[sl], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[sl], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[sl], acc[i][j], 0, 0, 0);
+            }
+            if (step == 3) read_a(half, 1);
+            conv_piece(cur, half ^ 1, step);       // on the last chunk: a re-read chunk into the half nobody reads again
+        }
+        __syncthreads();
+    };
+
+    if (nchunk > 0) {          // (a split past the end of the rows writes a zero slab)
+        load(r0, 0);
+#pragma unroll
+        for (int piece = 0; piece < 8; ++piece) conv_piece(r0, 0, piece);
+        load(r0, nchunk > 1 ? 1 : 0);
+        __syncthreads();
+        for (int n = 0; n < nchunk; n += 2) {
+            chunk(n, r0, r1);
+            if (n + 1 < nchunk) chunk(n + 1, r1, r0);
+        }
+    }
+    float* slab = slabs + (size_t)split * KA * KB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int arow = a0 + wa * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                slab[(size_t)arow * KB + b0 + wb * 128 + j * 32 + col] = acc[i][j][r];
+            }
 }
 
 __global__ void gemm_tn_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int n, int nslabs)
@@ -1057,8 +1194,21 @@ extern "C" int lpd_gemm_tn_bf16(const uint16_t* A, const uint16_t* B, float* dW,
     return LPD_OK;
 }
 
+// the 256 x 256-tile kernel: wide products over whole 32-row chunks (LPD_TN256=0 keeps the 128-wide kernel)
+static bool gemm_tn_256(long long M, int KA, int KB, int batch)
+{
+    static const bool on = [] { const char* e = getenv("LPD_TN256"); return !(e && e[0] == '0'); }();
+    return on && batch == 1 && KA % 256 == 0 && KB % 256 == 0 && M % 32 == 0 && M >= 8192;
+}
+
 static long long gemm_tn_splits(long long M, int KA, int KB, int batch)
 {
+    if (gemm_tn_256(M, KA, KB, batch)) {
+        const long long tiles = (long long)(KA / 256) * (KB / 256);
+        long long splits = 1;
+        while (tiles * splits * 2 <= 256 && M / (splits * 2) >= 1024) splits *= 2;
+        return splits;
+    }
     long long tiles = (long long)(KA / 128) * ((KB + 127) / 128) * batch;
     long long splits = 1;
     while (tiles * splits * 2 <= 1024 && M / (splits * 2) >= 1024) splits *= 2;
@@ -1082,6 +1232,17 @@ extern "C" int lpd_gemm_tn(const float* A, long long lda, const float* B, long l
     const long long splits = gemm_tn_splits(M, KA, KB, batch);
     long long rps = (M + splits - 1) / splits;
     rps = (rps + 63) / 64 * 64;
+    if (gemm_tn_256(M, KA, KB, batch)) {
+        const long long blocks = (long long)(KA / 256) * (KB / 256) * splits;
+        constexpr int lds = 2 * 512 * 144;
+        (void)hipFuncSetAttribute((const void*)gemm_tn_x3_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(gemm_tn_x3_256_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, A, lda, B, ldb, ws, KA, KB, rps, M);
+        LPD_CHECK_LAUNCH("lpd_gemm_tn(256)");
+        const int n = KA * KB;
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, stream, (const float*)ws, dW, n, (int)splits);
+        LPD_CHECK_LAUNCH("lpd_gemm_tn(reduce)");
+        return LPD_OK;
+    }
     const int kbt = KB % 128 == 0 ? 128 : 64;
     const long long blocks = (long long)(KA / 128) * (KB / kbt) * splits * batch;
     LPD_CHECK_ARG(blocks < (1ll << 31), "lpd_gemm_tn: too many blocks");
