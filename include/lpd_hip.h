@@ -357,6 +357,9 @@ int lpd_edge_build(const float* P, long long ldp, const float* Q, long long ldq,
  * BatchNorm + activation, lpdnet_model.py:250,252,258); arg[i][c] = selected t (uint8). */
 int lpd_group_max(const float* X, long long ldx, int k, const float* scale, const float* shift, int act, float slope,
                   float* out, long long ldo, uint8_t* arg, long long M, int C, void* stream);
+/* The same, also keeping the RAW selected values xsel[i][c] = X[(i,arg[i][c])][c] ([M][ldsel]) for lpd_edge_bn_bwd_sel. */
+int lpd_group_max_sel(const float* X, long long ldx, int k, const float* scale, const float* shift, int act, float slope,
+                      float* out, long long ldo, uint8_t* arg, float* xsel, long long ldsel, long long M, int C, void* stream);
 
 /* Backward of lpd_group_max w.r.t. the post-activation edge values: dX[(i,arg[i][c])][c] (+)= dOut[i][c];
  * accumulate = 0 writes all k rows (zeros elsewhere). */
@@ -371,6 +374,11 @@ int lpd_edge_bn_bwd(const float* dOut, long long ldo, const uint8_t* arg, const 
                     float* dQ, long long ldq, int k, long long M, int C, const float* scale, const float* shift,
                     const float* mean, const float* invstd, int act, float slope, double* dbeta, double* dgamma,
                     void* stream);
+/* The arg-max-only form (no dense gradient, no dQ) with the raw selected values Xsel [M][ldsel] the forward kept
+ * (lpd_group_max_sel): the dbeta / dgamma reduction is an [M][C] pass instead of a gather from the edge tensor. */
+int lpd_edge_bn_bwd_sel(const float* dOut, long long ldo, const uint8_t* arg, const float* X, const float* Xsel, long long ldsel,
+                        float* dX, int k, long long M, int C, const float* scale, const float* shift, const float* mean,
+                        const float* invstd, int act, float slope, double* dbeta, double* dgamma, void* stream);
 
 /* dQ[i] = sum_t dU[(i,t)]  (gradient of the centre term). */
 int lpd_group_sum(const float* dU, int k, float* dQ, long long ldq, long long M, int C, void* stream);
@@ -462,6 +470,10 @@ int lpd_group_sel_stats_bf16(const uint16_t* Z, int k, const float* gamma, float
 int lpd_edge_bn_bwd_bf16(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* dDense, const uint16_t* X, uint16_t* dX,
                          float* dQ, long long ldq, int k, long long M, int C, const float* scale, const float* shift,
                          const float* mean, const float* invstd, int act, float slope, double* dbeta, double* dgamma, void* stream);
+/* arg-max-only form with the raw selected values of lpd_group_sel_stats_bf16 (cf. lpd_edge_bn_bwd_sel) */
+int lpd_edge_bn_bwd_bf16_sel(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* X, const float* Xsel, long long ldsel,
+                             uint16_t* dX, int k, long long M, int C, const float* scale, const float* shift, const float* mean,
+                             const float* invstd, int act, float slope, double* dbeta, double* dgamma, void* stream);
 /* lpd_gather_sum_rows with a bf16 edge-gradient tensor (fp32 sums) */
 int lpd_gather_sum_rows_bf16(const uint16_t* dU, const int32_t* rowptr, const int32_t* edges, float* dP, long long ldp, long long M,
                              int C, int accumulate, void* stream);

@@ -271,7 +271,8 @@ __global__ __launch_bounds__(256) void edge_build_kernel(const float* __restrict
 // out[i][c] = act(scale[c] * sel_t X[(i,t)][c] + shift[c]), arg[i][c] = the selected t
 __global__ void group_max_kernel(const float* __restrict__ X, long long ldx, int k, const float* __restrict__ scale,
                                  const float* __restrict__ shift, int act, float slope, float* __restrict__ out,
-                                 long long ldo, uint8_t* __restrict__ arg, long long M, int C)
+                                 long long ldo, uint8_t* __restrict__ arg, float* __restrict__ xsel, long long ldsel, long long M,
+                                 int C)
 {
     const int Q = C >> 2;
     const long long total = M * Q;
@@ -291,18 +292,20 @@ __global__ void group_max_kernel(const float* __restrict__ X, long long ldx, int
                 if (v[c] < mn[c]) { mn[c] = v[c]; amn[c] = t; }
             }
         }
-        float o[4];
+        float o[4], xs[4];
         uint8_t a[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int ch = q * 4 + c;
             const float sc = scale[ch], sh = shift[ch];
             const bool usemax = sc >= 0.0f;
-            o[c] = lpd_act(sc * (usemax ? mx[c] : mn[c]) + sh, act, slope);
+            xs[c] = usemax ? mx[c] : mn[c];
+            o[c] = lpd_act(sc * xs[c] + sh, act, slope);
             a[c] = (uint8_t)(usemax ? amx[c] : amn[c]);
         }
         *reinterpret_cast<float4*>(out + i * ldo + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
         *reinterpret_cast<uchar4*>(arg + i * C + q * 4) = make_uchar4(a[0], a[1], a[2], a[3]);
+        if (xsel) *reinterpret_cast<float4*>(xsel + i * ldsel + q * 4) = make_float4(xs[0], xs[1], xs[2], xs[3]);
     }
 }
 
@@ -343,7 +346,9 @@ __global__ void group_max_bwd_kernel(const float* __restrict__ dOut, long long l
 __global__ __launch_bounds__(256) void edge_bn_bwd_reduce_kernel(const float* __restrict__ dOut, long long ldo,
                                                                  const uint8_t* __restrict__ arg,
                                                                  const float* __restrict__ dDense,   // [E][C] or null
-                                                                 const float* __restrict__ X, int k, long long M, int C,
+                                                                 const float* __restrict__ X,
+                                                                 const float* __restrict__ Xsel,     // [M][ldsel] X at arg, or null
+                                                                 long long ldsel, int k, long long M, int C,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                  int act, float slope, double* __restrict__ dbeta,
@@ -379,9 +384,14 @@ __global__ __launch_bounds__(256) void edge_bn_bwd_reduce_kernel(const float* __
                 }
             }
         } else {
+            float xs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (Xsel) {                      // the selected values kept by the forward: no gather from the edge tensor
+                const float4 x4 = *reinterpret_cast<const float4*>(Xsel + i * ldsel + q * 4);
+                xs[0] = x4.x; xs[1] = x4.y; xs[2] = x4.z; xs[3] = x4.w;
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {   // only the arg-max edge carries gradient
-                const float x = X[(i * k + a[c]) * C + q * 4 + c];
+                const float x = Xsel ? xs[c] : X[(i * k + a[c]) * C + q * 4 + c];
                 const float dpre = g[c] * act_grad(sc[c] * x + sh[c], act, slope);
                 sb[c] += dpre;
                 sg[c] += (double)dpre * ((x - mu[c]) * is[c]);
@@ -864,16 +874,31 @@ extern "C" int lpd_edge_build(const float* P, long long ldp, const float* Q, lon
     return LPD_OK;
 }
 
+static int group_max_impl(const float* X, long long ldx, int k, const float* scale, const float* shift, int act, float slope, float* out,
+                          long long ldo, uint8_t* arg, float* xsel, long long ldsel, long long M, int C, void* stream)
+{
+    LPD_CHECK_ARG(X && scale && shift && out && arg && M > 0 && k > 0 && k <= 255, "lpd_group_max: bad arguments");
+    LPD_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (!xsel || ldsel % 4 == 0),
+                  "lpd_group_max: C and leading dims must be multiples of 4");
+    LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_group_max: act=%d unsupported (none/ReLU/LeakyReLU)", act);
+    hipLaunchKernelGGL(group_max_kernel, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, ST(stream), X, ldx, k, scale, shift,
+                       act, slope, out, ldo, arg, xsel, ldsel, M, C);
+    LPD_CHECK_LAUNCH("lpd_group_max");
+    return LPD_OK;
+}
+
 extern "C" int lpd_group_max(const float* X, long long ldx, int k, const float* scale, const float* shift, int act,
                              float slope, float* out, long long ldo, uint8_t* arg, long long M, int C, void* stream)
 {
-    LPD_CHECK_ARG(X && scale && shift && out && arg && M > 0 && k > 0 && k <= 255, "lpd_group_max: bad arguments");
-    LPD_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "lpd_group_max: C and leading dims must be multiples of 4");
-    LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_group_max: act=%d unsupported (none/ReLU/LeakyReLU)", act);
-    hipLaunchKernelGGL(group_max_kernel, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, ST(stream), X, ldx, k, scale, shift,
-                       act, slope, out, ldo, arg, M, C);
-    LPD_CHECK_LAUNCH("lpd_group_max");
-    return LPD_OK;
+    return group_max_impl(X, ldx, k, scale, shift, act, slope, out, ldo, arg, nullptr, 0, M, C, stream);
+}
+
+extern "C" int lpd_group_max_sel(const float* X, long long ldx, int k, const float* scale, const float* shift, int act,
+                                 float slope, float* out, long long ldo, uint8_t* arg, float* xsel, long long ldsel, long long M,
+                                 int C, void* stream)
+{
+    LPD_CHECK_ARG(xsel, "lpd_group_max_sel: xsel is null");
+    return group_max_impl(X, ldx, k, scale, shift, act, slope, out, ldo, arg, xsel, ldsel, M, C, stream);
 }
 
 extern "C" int lpd_group_max_bwd(const float* dOut, long long ldo, const uint8_t* arg, int k, float* dX, long long M, int C,
@@ -886,24 +911,44 @@ extern "C" int lpd_group_max_bwd(const float* dOut, long long ldo, const uint8_t
     return LPD_OK;
 }
 
-extern "C" int lpd_edge_bn_bwd(const float* dOut, long long ldo, const uint8_t* arg, const float* dDense, const float* X,
-                               float* dX, float* dQ, long long ldq, int k, long long M, int C, const float* scale,
-                               const float* shift, const float* mean, const float* invstd, int act, float slope,
-                               double* dbeta, double* dgamma, void* stream)
+static int edge_bn_bwd_impl(const float* dOut, long long ldo, const uint8_t* arg, const float* dDense, const float* X,
+                            const float* Xsel, long long ldsel, float* dX, float* dQ, long long ldq, int k, long long M, int C,
+                            const float* scale, const float* shift, const float* mean, const float* invstd, int act, float slope,
+                            double* dbeta, double* dgamma, void* stream)
 {
     LPD_CHECK_ARG(dOut && arg && X && dX && scale && shift && mean && invstd && dbeta && dgamma && M > 0 && k > 0 && k <= 255,
                   "lpd_edge_bn_bwd: bad arguments");
-    LPD_CHECK_ARG(cols_ok(C) && ldo % 4 == 0 && (!dQ || ldq % 4 == 0), "lpd_edge_bn_bwd: C=%d / leading dims unsupported", C);
+    LPD_CHECK_ARG(cols_ok(C) && ldo % 4 == 0 && (!dQ || ldq % 4 == 0) && (!Xsel || ldsel % 4 == 0),
+                  "lpd_edge_bn_bwd: C=%d / leading dims unsupported", C);
     (void)hipMemsetAsync(dbeta, 0, sizeof(double) * C, ST(stream));
     (void)hipMemsetAsync(dgamma, 0, sizeof(double) * C, ST(stream));
     const int RG = 256 / (C / 4);
-    hipLaunchKernelGGL(edge_bn_bwd_reduce_kernel, dim3(grid_for(M, RG * 2)), dim3(256), 0, ST(stream), dOut, ldo, arg, dDense, X, k,
-                       M, C, scale, shift, mean, invstd, act, slope, dbeta, dgamma);
+    hipLaunchKernelGGL(edge_bn_bwd_reduce_kernel, dim3(grid_for(M, RG * 2)), dim3(256), 0, ST(stream), dOut, ldo, arg, dDense, X, Xsel,
+                       ldsel, k, M, C, scale, shift, mean, invstd, act, slope, dbeta, dgamma);
     LPD_CHECK_LAUNCH("lpd_edge_bn_bwd(reduce)");
     hipLaunchKernelGGL(edge_bn_bwd_apply_kernel, dim3(grid_for(M, RG)), dim3(256), 0, ST(stream), dOut, ldo, arg, dDense, X, dX, dQ,
                        ldq, k, M, C, scale, shift, mean, invstd, dbeta, dgamma, (double)M * k, act, slope);
     LPD_CHECK_LAUNCH("lpd_edge_bn_bwd(apply)");
     return LPD_OK;
+}
+
+extern "C" int lpd_edge_bn_bwd(const float* dOut, long long ldo, const uint8_t* arg, const float* dDense, const float* X,
+                               float* dX, float* dQ, long long ldq, int k, long long M, int C, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, int act, float slope,
+                               double* dbeta, double* dgamma, void* stream)
+{
+    return edge_bn_bwd_impl(dOut, ldo, arg, dDense, X, nullptr, 0, dX, dQ, ldq, k, M, C, scale, shift, mean, invstd, act, slope, dbeta,
+                            dgamma, stream);
+}
+
+extern "C" int lpd_edge_bn_bwd_sel(const float* dOut, long long ldo, const uint8_t* arg, const float* X, const float* Xsel,
+                                   long long ldsel, float* dX, int k, long long M, int C, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, int act, float slope, double* dbeta, double* dgamma,
+                                   void* stream)
+{
+    LPD_CHECK_ARG(Xsel, "lpd_edge_bn_bwd_sel: Xsel is null");
+    return edge_bn_bwd_impl(dOut, ldo, arg, nullptr, X, Xsel, ldsel, dX, nullptr, 0, k, M, C, scale, shift, mean, invstd, act, slope,
+                            dbeta, dgamma, stream);
 }
 
 extern "C" int lpd_group_sum(const float* dU, int k, float* dQ, long long ldq, long long M, int C, void* stream)

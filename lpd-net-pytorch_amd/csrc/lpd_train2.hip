@@ -414,7 +414,8 @@ __global__ __launch_bounds__(256) void group_sel_stats_bf16_kernel(const uint16_
 // fused backward of out[i] = max_t act(BN(X[(i,t)])) (+ optional dense gradient) on bf16 tensors (cf. lpd_edge_bn_bwd)
 __global__ __launch_bounds__(256) void edge_bn_bwd_reduce_bf16_kernel(const float* __restrict__ dOut, long long ldo,
                                                                       const uint8_t* __restrict__ arg, const uint16_t* __restrict__ dDense,
-                                                                      const uint16_t* __restrict__ X, int k, long long M, int C,
+                                                                      const uint16_t* __restrict__ X, const float* __restrict__ Xsel,
+                                                                      long long ldsel, int k, long long M, int C,
                                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                       int act, float slope, double* __restrict__ dbeta,
@@ -448,9 +449,14 @@ __global__ __launch_bounds__(256) void edge_bn_bwd_reduce_bf16_kernel(const floa
                 }
             }
         } else {
+            float xs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (Xsel) {                      // the selected values kept by the forward (lpd_group_sel_stats_bf16): no gather
+                const float4 x4 = *reinterpret_cast<const float4*>(Xsel + i * ldsel + q * 4);
+                xs[0] = x4.x; xs[1] = x4.y; xs[2] = x4.z; xs[3] = x4.w;
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float x = bf2f(X[(i * k + a[c]) * C + q * 4 + c]);
+                const float x = Xsel ? xs[c] : bf2f(X[(i * k + a[c]) * C + q * 4 + c]);
                 const float dpre = g[c] * act_grad2(sc[c] * x + sh[c], act, slope);
                 sb[c] += dpre;
                 sg[c] += (double)dpre * ((x - mu[c]) * is[c]);
@@ -1114,26 +1120,46 @@ extern "C" int lpd_group_sel_stats_bf16(const uint16_t* Z, int k, const float* g
     return LPD_OK;
 }
 
-extern "C" int lpd_edge_bn_bwd_bf16(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* dDense, const uint16_t* X,
-                                    uint16_t* dX, float* dQ, long long ldq, int k, long long M, int C, const float* scale,
-                                    const float* shift, const float* mean, const float* invstd, int act, float slope, double* dbeta,
-                                    double* dgamma, void* stream_)
+static int edge_bn_bwd_bf16_impl(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* dDense, const uint16_t* X,
+                                 const float* Xsel, long long ldsel, uint16_t* dX, float* dQ, long long ldq, int k, long long M, int C,
+                                 const float* scale, const float* shift, const float* mean, const float* invstd, int act, float slope,
+                                 double* dbeta, double* dgamma, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(dOut && arg && X && dX && scale && shift && mean && invstd && dbeta && dgamma, "lpd_edge_bn_bwd_bf16: null pointer");
-    LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && k <= 255 && ldo % 4 == 0 && ldq % 4 == 0, "lpd_edge_bn_bwd_bf16: bad dims");
+    LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && k <= 255 && ldo % 4 == 0 && ldq % 4 == 0 && ldsel % 4 == 0,
+                  "lpd_edge_bn_bwd_bf16: bad dims");
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_bn_bwd_bf16: activation %d unsupported", act);
     (void)hipMemsetAsync(dbeta, 0, sizeof(double) * C, stream);
     (void)hipMemsetAsync(dgamma, 0, sizeof(double) * C, stream);
     const int rg = 256 / (C / 4);
-    hipLaunchKernelGGL(edge_bn_bwd_reduce_bf16_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, dOut, ldo, arg, dDense, X, k, M,
-                       C, scale, shift, mean, invstd, act, slope, dbeta, dgamma);
+    hipLaunchKernelGGL(edge_bn_bwd_reduce_bf16_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, dOut, ldo, arg, dDense, X, Xsel,
+                       ldsel, k, M, C, scale, shift, mean, invstd, act, slope, dbeta, dgamma);
     LPD_CHECK_LAUNCH("lpd_edge_bn_bwd_bf16(reduce)");
     hipLaunchKernelGGL(edge_bn_bwd_apply_bf16_kernel, dim3(grid_for(M, rg, 8192)), dim3(256), 0, stream, dOut, ldo, arg, dDense, X, dX, dQ,
                        ldq, k, M, C, scale, shift, mean, invstd, (const double*)dbeta, (const double*)dgamma, (double)M * (double)k, act,
                        slope);
     LPD_CHECK_LAUNCH("lpd_edge_bn_bwd_bf16(apply)");
     return LPD_OK;
+}
+
+extern "C" int lpd_edge_bn_bwd_bf16(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* dDense, const uint16_t* X,
+                                    uint16_t* dX, float* dQ, long long ldq, int k, long long M, int C, const float* scale,
+                                    const float* shift, const float* mean, const float* invstd, int act, float slope, double* dbeta,
+                                    double* dgamma, void* stream)
+{
+    return edge_bn_bwd_bf16_impl(dOut, ldo, arg, dDense, X, nullptr, 0, dX, dQ, ldq, k, M, C, scale, shift, mean, invstd, act, slope, dbeta,
+                                 dgamma, stream);
+}
+
+extern "C" int lpd_edge_bn_bwd_bf16_sel(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* X, const float* Xsel,
+                                        long long ldsel, uint16_t* dX, int k, long long M, int C, const float* scale, const float* shift,
+                                        const float* mean, const float* invstd, int act, float slope, double* dbeta, double* dgamma,
+                                        void* stream)
+{
+    LPD_CHECK_ARG(Xsel, "lpd_edge_bn_bwd_bf16_sel: Xsel is null");
+    return edge_bn_bwd_bf16_impl(dOut, ldo, arg, nullptr, X, Xsel, ldsel, dX, nullptr, 0, k, M, C, scale, shift, mean, invstd, act, slope,
+                                 dbeta, dgamma, stream);
 }
 
 extern "C" int lpd_gather_sum_rows_bf16(const uint16_t* dU, const int32_t* rowptr, const int32_t* edges, float* dP, long long ldp,

@@ -86,6 +86,11 @@ SIGNATURES = {
                        _c_p, _c_p, _c_p],
     "lpd_edge_build": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p],
     "lpd_group_max": [_c_p, _c_ll, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p],
+    "lpd_group_max_sel": [_c_p, _c_ll, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_ll, _c_int, _c_p],
+    "lpd_edge_bn_bwd_sel": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f,
+                            _c_p, _c_p, _c_p],
+    "lpd_edge_bn_bwd_bf16_sel": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f,
+                                 _c_p, _c_p, _c_p],
     "lpd_group_max_bwd": [_c_p, _c_ll, _c_p, _c_int, _c_p, _c_ll, _c_int, _c_int, _c_p],
     "lpd_edge_bn_bwd": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int,
                         _c_f, _c_p, _c_p, _c_p],

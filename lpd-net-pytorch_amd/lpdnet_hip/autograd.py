@@ -416,12 +416,11 @@ class _LPDNetTrainFn(torch.autograd.Function):
             z = ops.gemm_bf16s(y1e, w2d(net.convDG2[0]))                        # [E,128] raw, bf16 MFMA
             zsel, arg2, stg2 = ops.group_sel_stats_bf16(z, k, net.convDG2[1])   # statistics of z + the raw selected values
             ops.affine_act(zsel, stg2.scale, stg2.shift, act, slope, out=cat[:, 128:256])             # x2
-            del zsel
         else:
             u1, stg1 = ops.edge_build(pq1[:, :128], pq1[:, 128:], idx_f, N, bn=net.convDG1[1])   # [E,128] raw + its BN statistics
             y1e, arg1 = ops.edge_act_max(u1, k, stg1, act, slope, out=cat[:, 0:128])                  # post-activation edges + x1, one pass over u1
             z, stg2 = ops.linear_bn_stats(y1e, w2d(net.convDG2[0]), net.convDG2[1])   # [E,128] raw + its statistics (GEMM epilogue)
-            arg2 = ops.group_max(z, k, stg2.scale, stg2.shift, act, slope, cat[:, 128:256])           # x2
+            arg2, zsel = ops.group_max(z, k, stg2.scale, stg2.shift, act, slope, cat[:, 128:256], keep_sel=True)   # x2
         # SN1 on the xyz graph, split form: statistics, max and arg-max from one gather pass, no [E,256] tensor
         idx_x = engine._knn_rows(x.view(B * N, 3), B, N, 3, k)
         wcat3 = engine.split_edge_weight(net.convSN1, "cat_nc")
@@ -431,7 +430,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         y3, st3, feat = _PointLayer.fwd(cat, w2d(net.conv3_lpd), net.bn3_lpd, act, slope)
         ctx.net, ctx.dims, ctx.actslope, ctx.bf16 = net, (B, N, M, k), (act, slope), bf16
         ctx.saved = dict(front=front, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1,
-                         u1=u1, stg1=stg1, arg1=arg1, y1e=y1e, z=z, stg2=stg2, arg2=arg2, wcat3=wcat3, pq3=pq3, s3=s3, usel3=usel3,
+                         u1=u1, stg1=stg1, arg1=arg1, y1e=y1e, z=z, zsel=zsel, stg2=stg2, arg2=arg2, wcat3=wcat3, pq3=pq3, s3=s3, usel3=usel3,
                          stg3=stg3, arg3=arg3, cat=cat, y3=y3, st3=st3)
         if engine.DEBUG_AUX is not None:
             engine.DEBUG_AUX.update(F0=f0, idx_feat=idx_f, idx_xyz=idx_x, cat=cat, argsel=dict(x1=arg1, x2=arg2, x3=arg3))
@@ -466,7 +465,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         dpq1 = torch.empty((M, 256), dtype=torch.float32, device=dfeat.device)
         if ctx.bf16:
             # DG2: x2 = groupmax(act(BN(Z))), Z = Y1e W2^T  (bf16 edge tensors, bf16 MFMA products)
-            dz, dgs2, dbs2 = ops.edge_bn_bwd_bf16(dcat[:, 128:256], S["arg2"], k, S["z"], S["stg2"], act, slope)
+            dz, dgs2, dbs2 = ops.edge_bn_bwd_bf16(dcat[:, 128:256], S["arg2"], k, S["z"], S["stg2"], act, slope, xsel=S["zsel"])
             dw2 = ops.gemm_tn_bf16(dz, S["y1e"])                                # [Co,Ci] = dZ^T Y1e
             dy1e = ops.gemm_bf16s(dz, w2d(net.convDG2[0]), b_kmajor=True)       # [E,128] = dZ W2
             del dz
@@ -475,7 +474,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
             ops.gather_sum_rows_bf16(du1, ops.GraphT(S["idx_f"], N), dpq1[:, :128])
         else:
             # DG2: x2 = groupmax(act(BN(Z))), Z = Y1e W2^T
-            dz, dgs2, dbs2 = ops.edge_bn_bwd(dcat[:, 128:256], S["arg2"], k, S["z"], S["stg2"], act, slope)
+            dz, dgs2, dbs2 = ops.edge_bn_bwd(dcat[:, 128:256], S["arg2"], k, S["z"], S["stg2"], act, slope, xsel=S["zsel"])
             dw2 = _dweight(dz, S["y1e"])
             dy1e = ops.gemm(dz, w2d(net.convDG2[0]), b_kmajor=True)             # [E,128]
             del dz
@@ -516,14 +515,14 @@ class _EdgeChain:
         ya = ops.affine_act(u, st_a.scale, st_a.shift, act, slope)               # [E,c]
         z = ops.linear(ya, w_b)                                                   # [E,co] raw
         st_b = ops.bn_train_stats(z, bn_b)
-        arg = ops.group_max(z, k, st_b.scale, st_b.shift, act, slope, out)
-        return dict(u=u, st_a=st_a, ya=ya, z=z, st_b=st_b, arg=arg)
+        arg, zsel = ops.group_max(z, k, st_b.scale, st_b.shift, act, slope, out, keep_sel=True)
+        return dict(u=u, st_a=st_a, ya=ya, z=z, zsel=zsel, st_b=st_b, arg=arg)
 
     @staticmethod
     def bwd(dout, S, w_b, idx, N, k, c, has_q, act, slope):
         """returns (dPQ [M, c or 2c], dW_b, dgamma_b, dbeta_b, dgamma_a, dbeta_a)"""
         M = dout.shape[0]
-        dz, dg_b, db_b = ops.edge_bn_bwd(dout, S["arg"], k, S["z"], S["st_b"], act, slope)
+        dz, dg_b, db_b = ops.edge_bn_bwd(dout, S["arg"], k, S["z"], S["st_b"], act, slope, xsel=S["zsel"])
         dw_b = _dweight(dz, S["ya"])
         dya = ops.gemm(dz, w_b, b_kmajor=True)
         del dz

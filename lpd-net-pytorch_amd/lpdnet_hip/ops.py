@@ -1028,13 +1028,20 @@ def edge_build(P, Q, idx, N, bn=None):
     return U, _bn_finalize(sums, M * k, C, bn)
 
 
-def group_max(X, k, scale, shift, act, slope, out):
+def group_max(X, k, scale, shift, act, slope, out, keep_sel=False):
+    """out [M,C] = act(scale * sel_t X[(i,t)] + shift), -> arg [M,C] uint8; keep_sel: -> (arg, xsel [M,C]) with the raw selected values
+    (what edge_bn_bwd(..., xsel=) reads instead of gathering them from X again)."""
     ldx, ldo = _rows(X, "X"), _rows(out, "out")
     M, C = out.shape
     if X.shape[0] != M * k or X.shape[1] != C:
         raise ValueError("group_max: shape mismatch")
     arg = torch.empty((M, C), dtype=torch.uint8, device=X.device)
     lib = _lib.load()
+    if keep_sel:
+        xsel = torch.empty((M, C), dtype=torch.float32, device=X.device)
+        _call(f"group_max[C={C}]", lib.lpd_group_max_sel, _ptr(X), ldx, k, _ptr(scale), _ptr(shift), act, float(slope), _ptr(out), ldo,
+              _ptr(arg), _ptr(xsel), C, M, C, _stream())
+        return arg, xsel
     _call(f"group_max[C={C}]", lib.lpd_group_max, _ptr(X), ldx, k, _ptr(scale), _ptr(shift), act, float(slope), _ptr(out), ldo,
           _ptr(arg), M, C, _stream())
     return arg
@@ -1052,16 +1059,26 @@ def group_max_bwd(dOut, arg, k, dX=None, accumulate=False):
     return dX
 
 
-def edge_bn_bwd(dOut, arg, k, X, st, act, slope, dense=None, dQ=None):
+def edge_bn_bwd(dOut, arg, k, X, st, act, slope, dense=None, dQ=None, xsel=None):
     """Fused backward through max-over-k + activation + train-mode BatchNorm on a materialised edge tensor X [M*k, C].
     dOut [M, C] (view allowed): gradient of the group-max output; dense [M*k, C]: optional dense gradient on the
-    post-activation edges (overwritten with the result).  Returns (dX [M*k, C], dgamma, dbeta); fills dQ if given."""
+    post-activation edges (overwritten with the result).  Returns (dX [M*k, C], dgamma, dbeta); fills dQ if given.
+    xsel [M, C] (arg-max-only form): the raw selected values the forward kept (group_max(keep_sel=True)) -- same result."""
     ldo = _rows(dOut, "dOut")
     M, C = arg.shape
     dX = dense if dense is not None else torch.empty((M * k, C), dtype=torch.float32, device=X.device)
     ldq = _rows(dQ, "dQ") if dQ is not None else 0
     red = torch.empty((2, C), dtype=torch.float64, device=X.device)
     lib = _lib.load()
+    if xsel is not None:
+        if dense is not None or dQ is not None:
+            raise ValueError("edge_bn_bwd: xsel belongs to the arg-max-only form (no dense gradient, no dQ)")
+        _req(xsel, "xsel")
+        _call(f"edge_bn_bwd[C={C}]", lib.lpd_edge_bn_bwd_sel, _ptr(dOut), ldo, _ptr(arg), _ptr(X), _ptr(xsel), _rows(xsel, "xsel"),
+              _ptr(dX), k, M, C, _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(red[0]),
+              _ptr(red[1]), _stream())
+        redf = red.float()
+        return dX, redf[1], redf[0]
     _call(f"edge_bn_bwd[C={C}]", lib.lpd_edge_bn_bwd, _ptr(dOut), ldo, _ptr(arg), _ptr(dense), _ptr(X), _ptr(dX), _ptr(dQ), ldq, k,
           M, C, _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(red[0]), _ptr(red[1]),
           _stream())
@@ -1221,8 +1238,9 @@ def group_sel_stats_bf16(Z, k, bn):
     return sel, arg, _bn_finalize(sums, M * k, C, bn)
 
 
-def edge_bn_bwd_bf16(dOut, arg, k, X, st, act, slope, dense=None, dQ=None):
-    """edge_bn_bwd on bf16 tensors: -> (dX bf16 [M*k, C] (aliases `dense` when given), dgamma, dbeta)."""
+def edge_bn_bwd_bf16(dOut, arg, k, X, st, act, slope, dense=None, dQ=None, xsel=None):
+    """edge_bn_bwd on bf16 tensors: -> (dX bf16 [M*k, C] (aliases `dense` when given), dgamma, dbeta).  xsel [M, C] fp32: the raw
+    selected values of group_sel_stats_bf16 (arg-max-only form)."""
     ldo = _rows(dOut, "dOut")
     M, C = arg.shape
     _bf16_rows(X, "X", C)
@@ -1232,6 +1250,15 @@ def edge_bn_bwd_bf16(dOut, arg, k, X, st, act, slope, dense=None, dQ=None):
     ldq = _rows(dQ, "dQ") if dQ is not None else 0
     red = torch.empty((2, C), dtype=torch.float64, device=X.device)
     lib = _lib.load()
+    if xsel is not None:
+        if dense is not None or dQ is not None:
+            raise ValueError("edge_bn_bwd_bf16: xsel belongs to the arg-max-only form (no dense gradient, no dQ)")
+        _req(xsel, "xsel")
+        _call(f"edge_bn_bwd_bf16[C={C}]", lib.lpd_edge_bn_bwd_bf16_sel, _ptr(dOut), ldo, _ptr(arg), _ptr(X), _ptr(xsel),
+              _rows(xsel, "xsel"), _ptr(dX), k, M, C, _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope),
+              _ptr(red[0]), _ptr(red[1]), _stream())
+        redf = red.float()
+        return dX, redf[1], redf[0]
     _call(f"edge_bn_bwd_bf16[C={C}]", lib.lpd_edge_bn_bwd_bf16, _ptr(dOut), ldo, _ptr(arg), _ptr(dense), _ptr(X), _ptr(dX), _ptr(dQ), ldq,
           k, M, C, _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(red[0]), _ptr(red[1]),
           _stream())

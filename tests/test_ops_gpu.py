@@ -787,9 +787,16 @@ def test_bf16_storage_edge_kernels(cuda):
     dX32, dg32, db32 = ops.edge_bn_bwd(dOut, arg16, k, Ur, st32, act, slope, dense=dense.float(), dQ=dQ32)
     assert _rel(dg16, dg32) < 1e-5 and _rel(db16, db32) < 1e-5 and _rel(dQ16, dQ32) < 1e-5
     assert torch.equal(dX16, dX32.to(torch.bfloat16))
-    dX16b, _, _ = ops.edge_bn_bwd_bf16(dOut, argz, k, Z16, stz, act, slope)                    # sparse form (no dense gradient)
-    dX32b, _, _ = ops.edge_bn_bwd(dOut, argz, k, Z16.float(), stz, act, slope)
+    dX16b, dg16b, db16b = ops.edge_bn_bwd_bf16(dOut, argz, k, Z16, stz, act, slope)            # sparse form (no dense gradient)
+    dX32b, dg32b, db32b = ops.edge_bn_bwd(dOut, argz, k, Z16.float(), stz, act, slope)
     assert torch.equal(dX16b, dX32b.to(torch.bfloat16))
+    # the same with the raw selected values the forward kept (no gather from the edge tensor): bit-identical
+    dX16c, dg16c, db16c = ops.edge_bn_bwd_bf16(dOut, argz, k, Z16, stz, act, slope, xsel=sel)
+    assert torch.equal(dX16c, dX16b) and torch.equal(dg16c, dg16b) and torch.equal(db16c, db16b)
+    argzc, selc = ops.group_max(Z16.float(), k, stz.scale, stz.shift, act, slope, torch.empty(M, C, device=cuda), keep_sel=True)
+    assert torch.equal(argzc, argz) and torch.equal(selc, sel)
+    dX32c, dg32c, db32c = ops.edge_bn_bwd(dOut, argz, k, Z16.float(), stz, act, slope, xsel=selc)
+    assert torch.equal(dX32c, dX32b) and torch.equal(dg32c, dg32b) and torch.equal(db32c, db32b)
     gt = ops.GraphT(idx, N)
     a = torch.empty(M, C, device=cuda)
     b = torch.empty(M, C, device=cuda)
