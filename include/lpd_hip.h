@@ -474,6 +474,25 @@ int lpd_edge_bn_bwd_bf16(const float* dOut, long long ldo, const uint8_t* arg, c
 int lpd_edge_bn_bwd_bf16_sel(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* X, const float* Xsel, long long ldsel,
                              uint16_t* dX, int k, long long M, int C, const float* scale, const float* shift, const float* mean,
                              const float* invstd, int act, float slope, double* dbeta, double* dgamma, void* stream);
+/* Backward of x2 = max_k act(BN_train(Z)), Z = Y1e W2^T (lpdnet_model.py:251-252) on bf16 edge tensors WITHOUT the [M*k][128] gradient
+ * dZ (csrc/lpd_train3.hip).  (1) dpre16 [M][C] = bf16(dOut * act'(scale Xsel + shift)) and the fp64 sums dbeta = sum dpre,
+ * dgamma = sum dpre xhat, from the raw selected values Xsel [M][ldsel] of lpd_group_sel_stats_bf16. */
+int lpd_bn_sel_bwd_reduce(const float* dOut, long long ldo, const float* Xsel, long long ldsel, long long M, int C, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, int act, float slope, uint16_t* dpre16,
+                          double* dbeta, double* dgamma, void* stream);
+/* (2) dW2 [128][128] = dZ^T Y1e from ONE pass over Y1e [M*k][128] bf16: S = D^T Y1e (D: dpre16 at the arg-max slots), the Gram matrix
+ * Y1e^T Y1e and the column sums, then dW2[c] = s_c (S[c] - m1_c s - m2_c invstd_c (W2[c] G - mu_c s)) in fp64.  W2 [128][ldw]: the
+ * convolution weight; dbeta / dgamma: the sums of (1); ws: lpd_edge_dw_sel_bf16_ws_bytes(M * k) bytes, 16-byte aligned.
+ * Requires (M * k) % 128 == 0, 8 <= k <= 255. */
+long long lpd_edge_dw_sel_bf16_ws_bytes(long long E);
+int lpd_edge_dw_sel_bf16(const uint16_t* Y, const uint8_t* arg, const uint16_t* dpre16, int k, long long M, const float* W2, long long ldw,
+                         const float* scale, const float* mean, const float* invstd, const double* dbeta, const double* dgamma, float* dW2,
+                         void* ws, void* stream);
+/* (3) dY [M*k][128] (bf16) = dZ W2 with dZ = s (delta dpre - m1 - xhat m2) generated from Z [M*k][128] (bf16), arg [M][128] and dpre16
+ * while the operand is loaded.  16 <= k <= 255. */
+int lpd_gemm_bf16s_bnbwd(const uint16_t* Z, const uint8_t* arg, const uint16_t* dpre16, int k, long long M, const float* W2, int ldw,
+                         const float* scale, const float* mean, const float* invstd, const double* dbeta, const double* dgamma, uint16_t* dY,
+                         void* stream);
 /* lpd_gather_sum_rows with a bf16 edge-gradient tensor (fp32 sums) */
 int lpd_gather_sum_rows_bf16(const uint16_t* dU, const int32_t* rowptr, const int32_t* edges, float* dP, long long ldp, long long M,
                              int C, int accumulate, void* stream);

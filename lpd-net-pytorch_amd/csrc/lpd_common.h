@@ -56,6 +56,28 @@ __device__ __forceinline__ float lpd_act_any(float v, int act, float slope)
     return lpd_act_pl(v, lpd_neg_slope(act, slope));
 }
 
+// ---- column statistics across blocks -------------------------------------------------------------------------------------
+// Every statistics / reduction kernel of the training path ends with each block adding its 2 x C fp64 partial sums to the
+// SAME 2 x C doubles.  Device-scope fp64 atomics on one 128-byte line are served one after the other: 4096 blocks x 256 addresses
+// in 16 lines = 330 us of drain behind an [M, C] pass that takes 60 us (tools/train_profile.py, bn_sel_bwd_reduce: 375 us).
+// The blocks therefore add into one of 32 REPLICAS (blockIdx % 32: thirty-two times the lines, 1/32 of the queue on each), and a
+// small second launch (lpd_stat_finish) sums the replicas into the caller's 2 x C doubles and clears them.  (A ticket instead
+// of the second launch -- the block that draws the last one sums the replicas -- costs more than it saves: 4096 returning
+// atomics on ONE address behind a __threadfence took 620 us.)  The replicas live in a per-(device, stream) scratch buffer the
+// library allocates on first use: launches on one stream are ordered, so they share it.
+#define LPD_STAT_REPLICAS 32
+#define LPD_STAT_CMAX 1024
+struct LpdStatWs {
+    double* rep;             // [LPD_STAT_REPLICAS][2][LPD_STAT_CMAX], all zero between (statistics kernel, lpd_stat_finish) pairs
+    double* sum() const { return rep; }                      // what the kernels take in place of the caller's sum / sumsq pointers
+    double* sumsq() const { return rep + LPD_STAT_CMAX; }
+};
+LpdStatWs lpd_stat_ws(hipStream_t stream);      // lpd_abi.hip; rep == nullptr if the allocation failed
+// o0[c] = sum over the replicas of column c (c < ncols <= LPD_STAT_CMAX), o1 likewise; clears the replicas
+int lpd_stat_finish(LpdStatWs ws, double* o0, double* o1, int ncols, hipStream_t stream);
+// offset of this block's replica, to be added to the column index of both pointers
+__device__ __forceinline__ size_t lpd_stat_rofs() { return (size_t)(blockIdx.x % LPD_STAT_REPLICAS) * 2 * LPD_STAT_CMAX; }
+
 // Blocks b and b+8 share an XCD (round-robin dispatch, MI355X_MICROARCH.md "Workgroup dispatch").
 // Map a linear block id so that each XCD owns a contiguous range of work items; bijective for any n.
 __device__ __forceinline__ int lpd_xcd_remap(int bid, int nblocks)

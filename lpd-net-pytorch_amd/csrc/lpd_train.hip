@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
             for (int e = 0; e < 8; ++e) red[q][e] += red[g * Q + q][e];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            atomicAdd(&sum[q * 4 + e], red[q][e]);
-            atomicAdd(&sumsq[q * 4 + e], red[q][4 + e]);
+            atomicAdd(&sum[lpd_stat_rofs() + q * 4 + e], red[q][e]);
+            atomicAdd(&sumsq[lpd_stat_rofs() + q * 4 + e], red[q][4 + e]);
         }
     }
 }
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
             for (int e = 0; e < 8; ++e) red[q][e] += red[g * Q + q][e];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            atomicAdd(&dbeta[q * 4 + e], red[q][e]);
-            atomicAdd(&dgamma[q * 4 + e], red[q][4 + e]);
+            atomicAdd(&dbeta[lpd_stat_rofs() + q * 4 + e], red[q][e]);
+            atomicAdd(&dgamma[lpd_stat_rofs() + q * 4 + e], red[q][4 + e]);
         }
     }
 }
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(256) void edge_build_kernel(const float* __restrict
                 for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[g * LPP + threadIdx.x][e];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                atomicAdd(&sum[threadIdx.x * 4 + e], red[threadIdx.x][e]);
-                atomicAdd(&sumsq[threadIdx.x * 4 + e], red[threadIdx.x][4 + e]);
+                atomicAdd(&sum[lpd_stat_rofs() + threadIdx.x * 4 + e], red[threadIdx.x][e]);
+                atomicAdd(&sumsq[lpd_stat_rofs() + threadIdx.x * 4 + e], red[threadIdx.x][4 + e]);
             }
         }
     }
@@ -407,8 +407,8 @@ __global__ __launch_bounds__(256) void edge_bn_bwd_reduce_kernel(const float* __
             for (int e = 0; e < 8; ++e) red[q][e] += red[g2 * Q + q][e];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            atomicAdd(&dbeta[q * 4 + e], red[q][e]);
-            atomicAdd(&dgamma[q * 4 + e], red[q][4 + e]);
+            atomicAdd(&dbeta[lpd_stat_rofs() + q * 4 + e], red[q][e]);
+            atomicAdd(&dgamma[lpd_stat_rofs() + q * 4 + e], red[q][4 + e]);
         }
     }
 }
@@ -795,18 +795,18 @@ extern "C" int lpd_colstats(const float* X, long long ld, long long R, int C, do
 {
     LPD_CHECK_ARG(X && sum && sumsq && R > 0, "lpd_colstats: bad arguments");
     LPD_CHECK_ARG(C >= 4 && C % 4 == 0 && ld % 4 == 0, "lpd_colstats: C=%d and ld must be multiples of 4", C);
-    (void)hipMemsetAsync(sum, 0, sizeof(double) * C, ST(stream));
-    (void)hipMemsetAsync(sumsq, 0, sizeof(double) * C, ST(stream));
+    const LpdStatWs ws = lpd_stat_ws(ST(stream));
+    LPD_CHECK_ARG(ws.rep, "lpd_colstats: no memory for the statistics scratch");
     // the kernel takes a column panel of 4*2^n <= 1024 columns; other widths (k*k = 12, 4096 of the T-Nets) go panel by panel
     for (int c0 = 0; c0 < C;) {
         int w = 1024;
         while (w > C - c0) w >>= 1;
         const int RG = 256 / (w / 4);
-        hipLaunchKernelGGL(colstats_kernel, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream), X + c0, ld, R, w, sum + c0,
-                           sumsq + c0);
+        hipLaunchKernelGGL(colstats_kernel, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream), X + c0, ld, R, w, ws.sum(), ws.sumsq());
+        LPD_CHECK_LAUNCH("lpd_colstats");
+        if (int rc = lpd_stat_finish(ws, sum + c0, sumsq + c0, w, ST(stream))) return rc;
         c0 += w;
     }
-    LPD_CHECK_LAUNCH("lpd_colstats");
     return LPD_OK;
 }
 
@@ -842,12 +842,13 @@ extern "C" int lpd_bn_act_bwd(const float* dY, long long lddy, const float* X, l
     LPD_CHECK_ARG(dY && X && dX && dbeta && dgamma && R > 0, "lpd_bn_act_bwd: bad arguments");
     LPD_CHECK_ARG(cols_ok(C) && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0, "lpd_bn_act_bwd: C=%d / leading dims unsupported", C);
     LPD_CHECK_ARG(!has_bn || (scale && shift && mean && invstd), "lpd_bn_act_bwd: BatchNorm form needs scale/shift/mean/invstd");
-    (void)hipMemsetAsync(dbeta, 0, sizeof(double) * C, ST(stream));
-    (void)hipMemsetAsync(dgamma, 0, sizeof(double) * C, ST(stream));
+    const LpdStatWs ws = lpd_stat_ws(ST(stream));
+    LPD_CHECK_ARG(ws.rep, "lpd_bn_act_bwd: no memory for the statistics scratch");
     const int RG = 256 / (C / 4);
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream), dY, lddy, X, ldx, R, C,
-                       scale, shift, has_bn ? mean : nullptr, has_bn ? invstd : nullptr, act, slope, dbeta, dgamma);
+                       scale, shift, has_bn ? mean : nullptr, has_bn ? invstd : nullptr, act, slope, ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_bn_act_bwd(reduce)");
+    if (int rc = lpd_stat_finish(ws, dbeta, dgamma, C, ST(stream))) return rc;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(R * (C / 4), 256 * 4)), dim3(256), 0, ST(stream), dY, lddy, X,
                        ldx, dX, lddx, R, C, scale, shift, mean, invstd, dbeta, dgamma, (double)R, act, slope, has_bn);
     LPD_CHECK_LAUNCH("lpd_bn_act_bwd(apply)");
@@ -858,9 +859,14 @@ extern "C" int lpd_edge_build(const float* P, long long ldp, const float* Q, lon
                               long long M, int N, int C, int k, double* sum, double* sumsq, void* stream)
 {
     LPD_CHECK_ARG((sum == nullptr) == (sumsq == nullptr), "lpd_edge_build: sum and sumsq come in pairs");
+    LpdStatWs ws = {nullptr};
+    double* usum = sum;
+    double* usumsq = sumsq;
     if (sum) {
-        (void)hipMemsetAsync(sum, 0, sizeof(double) * C, ST(stream));
-        (void)hipMemsetAsync(sumsq, 0, sizeof(double) * C, ST(stream));
+        ws = lpd_stat_ws(ST(stream));
+        LPD_CHECK_ARG(ws.rep, "lpd_edge_build: no memory for the statistics scratch");
+        sum = ws.sum();
+        sumsq = ws.sumsq();
     }
     LPD_CHECK_ARG(P && idx && U && M > 0 && N > 0 && k > 0 && M % N == 0, "lpd_edge_build: bad arguments");
     LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_build: C=%d unsupported (64/128/256)", C);
@@ -871,6 +877,7 @@ extern "C" int lpd_edge_build(const float* P, long long ldp, const float* Q, lon
     else if (lpp == 32) hipLaunchKernelGGL(edge_build_kernel<32>, dim3(g), dim3(256), 0, ST(stream), P, ldp, Q, ldq, idx, U, M, N, k, sum, sumsq);
     else hipLaunchKernelGGL(edge_build_kernel<16>, dim3(g), dim3(256), 0, ST(stream), P, ldp, Q, ldq, idx, U, M, N, k, sum, sumsq);
     LPD_CHECK_LAUNCH("lpd_edge_build");
+    if (usum) return lpd_stat_finish(ws, usum, usumsq, C, ST(stream));
     return LPD_OK;
 }
 
@@ -920,12 +927,13 @@ static int edge_bn_bwd_impl(const float* dOut, long long ldo, const uint8_t* arg
                   "lpd_edge_bn_bwd: bad arguments");
     LPD_CHECK_ARG(cols_ok(C) && ldo % 4 == 0 && (!dQ || ldq % 4 == 0) && (!Xsel || ldsel % 4 == 0),
                   "lpd_edge_bn_bwd: C=%d / leading dims unsupported", C);
-    (void)hipMemsetAsync(dbeta, 0, sizeof(double) * C, ST(stream));
-    (void)hipMemsetAsync(dgamma, 0, sizeof(double) * C, ST(stream));
+    const LpdStatWs ws = lpd_stat_ws(ST(stream));
+    LPD_CHECK_ARG(ws.rep, "lpd_edge_bn_bwd: no memory for the statistics scratch");
     const int RG = 256 / (C / 4);
     hipLaunchKernelGGL(edge_bn_bwd_reduce_kernel, dim3(grid_for(M, RG * 2)), dim3(256), 0, ST(stream), dOut, ldo, arg, dDense, X, Xsel,
-                       ldsel, k, M, C, scale, shift, mean, invstd, act, slope, dbeta, dgamma);
+                       ldsel, k, M, C, scale, shift, mean, invstd, act, slope, ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_edge_bn_bwd(reduce)");
+    if (int rc = lpd_stat_finish(ws, dbeta, dgamma, C, ST(stream))) return rc;
     hipLaunchKernelGGL(edge_bn_bwd_apply_kernel, dim3(grid_for(M, RG)), dim3(256), 0, ST(stream), dOut, ldo, arg, dDense, X, dX, dQ,
                        ldq, k, M, C, scale, shift, mean, invstd, dbeta, dgamma, (double)M * k, act, slope);
     LPD_CHECK_LAUNCH("lpd_edge_bn_bwd(apply)");

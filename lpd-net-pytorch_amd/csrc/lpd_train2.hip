@@ -67,8 +67,8 @@ __device__ __forceinline__ void reduce_quads(double (&red)[NT][8], const double 
             for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[g * LQ + threadIdx.x][e];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            atomicAdd(&o0[threadIdx.x * 4 + e], red[threadIdx.x][e]);
-            atomicAdd(&o1[threadIdx.x * 4 + e], red[threadIdx.x][4 + e]);
+            atomicAdd(&o0[lpd_stat_rofs() + threadIdx.x * 4 + e], red[threadIdx.x][e]);
+            atomicAdd(&o1[lpd_stat_rofs() + threadIdx.x * 4 + e], red[threadIdx.x][4 + e]);
         }
     }
 }
@@ -1017,15 +1017,15 @@ extern "C" int lpd_edge_split_fwd(const float* P, long long ldp, const float* Q,
     LPD_CHECK_ARG(P && Q && idx && gamma && S && usel && arg && sum && sumsq, "lpd_edge_split_fwd: null pointer");
     LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_split_fwd: C=%d unsupported", C);
     LPD_CHECK_ARG(M > 0 && N > 0 && k > 0 && k <= 255 && M % N == 0 && ldp % 4 == 0 && ldq % 4 == 0, "lpd_edge_split_fwd: bad dims");
-    (void)hipMemsetAsync(sum, 0, sizeof(double) * C, stream);
-    (void)hipMemsetAsync(sumsq, 0, sizeof(double) * C, stream);
+    const LpdStatWs ws = lpd_stat_ws(stream);
+    LPD_CHECK_ARG(ws.rep, "lpd_edge_split_fwd: no memory for the statistics scratch");
     const int lpp = C / 4;
     const int grid = grid_for(M, 4 * (64 / lpp) * 4, 2048);
-    if (C == 64) hipLaunchKernelGGL(edge_split_fwd_kernel<16>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, gamma, S, usel, arg, M, N, k, sum, sumsq);
-    else if (C == 128) hipLaunchKernelGGL(edge_split_fwd_kernel<32>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, gamma, S, usel, arg, M, N, k, sum, sumsq);
-    else hipLaunchKernelGGL(edge_split_fwd_kernel<64>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, gamma, S, usel, arg, M, N, k, sum, sumsq);
+    if (C == 64) hipLaunchKernelGGL(edge_split_fwd_kernel<16>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, gamma, S, usel, arg, M, N, k, ws.sum(), ws.sumsq());
+    else if (C == 128) hipLaunchKernelGGL(edge_split_fwd_kernel<32>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, gamma, S, usel, arg, M, N, k, ws.sum(), ws.sumsq());
+    else hipLaunchKernelGGL(edge_split_fwd_kernel<64>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, gamma, S, usel, arg, M, N, k, ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_edge_split_fwd");
-    return LPD_OK;
+    return lpd_stat_finish(ws, sum, sumsq, C, stream);
 }
 
 extern "C" int lpd_edge_split_bwd(const float* dOut, long long ldo, const float* usel, const uint8_t* arg, const float* S,
@@ -1040,12 +1040,13 @@ extern "C" int lpd_edge_split_bwd(const float* dOut, long long ldo, const float*
     LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_split_bwd: C=%d unsupported", C);
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_split_bwd: activation %d unsupported", act);
     LPD_CHECK_ARG(ldo % 4 == 0 && ldp % 4 == 0 && ldq % 4 == 0 && lddp % 4 == 0 && lddq % 4 == 0, "lpd_edge_split_bwd: leading dims % 4");
-    (void)hipMemsetAsync(dbeta, 0, sizeof(double) * C, stream);
-    (void)hipMemsetAsync(dgamma, 0, sizeof(double) * C, stream);
+    const LpdStatWs ws = lpd_stat_ws(stream);
+    LPD_CHECK_ARG(ws.rep, "lpd_edge_split_bwd: no memory for the statistics scratch");
     const int rg = 256 / (C / 4);
     hipLaunchKernelGGL(edge_split_bwd_reduce_kernel, dim3(grid_for(M, rg * 8, 2048)), dim3(256), 0, stream, dOut, ldo, usel, G, M, C,
-                       scale, shift, mean, invstd, act, slope, dbeta, dgamma);
+                       scale, shift, mean, invstd, act, slope, ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_edge_split_bwd(reduce)");
+    if (int rc = lpd_stat_finish(ws, dbeta, dgamma, C, stream)) return rc;
     const int lpr = C / 4;
     const int grid = grid_for(M, 4 * (64 / lpr) * 2, 8192);
     if (C == 64) hipLaunchKernelGGL(edge_split_bwd_apply_kernel<16>, dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
@@ -1062,9 +1063,14 @@ extern "C" int lpd_edge_build_bf16(const float* P, long long ldp, const float* Q
     LPD_CHECK_ARG(P && idx && U, "lpd_edge_build_bf16: null pointer");
     LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_build_bf16: C=%d unsupported", C);
     LPD_CHECK_ARG((sum == nullptr) == (sumsq == nullptr), "lpd_edge_build_bf16: sum and sumsq come together");
+    LpdStatWs ws = {nullptr};
+    double* usum = sum;
+    double* usumsq = sumsq;
     if (sum) {
-        (void)hipMemsetAsync(sum, 0, sizeof(double) * C, stream);
-        (void)hipMemsetAsync(sumsq, 0, sizeof(double) * C, stream);
+        ws = lpd_stat_ws(stream);
+        LPD_CHECK_ARG(ws.rep, "lpd_edge_build_bf16: no memory for the statistics scratch");
+        sum = ws.sum();
+        sumsq = ws.sumsq();
     }
     const int lpp = C / 4;
     const int grid = grid_for(M, 4 * (64 / lpp) * 4, 2048);
@@ -1072,6 +1078,7 @@ extern "C" int lpd_edge_build_bf16(const float* P, long long ldp, const float* Q
     else if (C == 128) hipLaunchKernelGGL(edge_build_bf16_kernel<32>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, U, M, N, k, sum, sumsq);
     else hipLaunchKernelGGL(edge_build_bf16_kernel<64>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, U, M, N, k, sum, sumsq);
     LPD_CHECK_LAUNCH("lpd_edge_build_bf16");
+    if (usum) return lpd_stat_finish(ws, usum, usumsq, C, stream);
     return LPD_OK;
 }
 
@@ -1111,13 +1118,13 @@ extern "C" int lpd_group_sel_stats_bf16(const uint16_t* Z, int k, const float* g
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(Z && gamma && sel && arg && sum && sumsq, "lpd_group_sel_stats_bf16: null pointer");
     LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && k <= 255 && lds % 4 == 0, "lpd_group_sel_stats_bf16: bad dims");
-    (void)hipMemsetAsync(sum, 0, sizeof(double) * C, stream);
-    (void)hipMemsetAsync(sumsq, 0, sizeof(double) * C, stream);
+    const LpdStatWs ws = lpd_stat_ws(stream);
+    LPD_CHECK_ARG(ws.rep, "lpd_group_sel_stats_bf16: no memory for the statistics scratch");
     const int rg = 256 / (C / 4);
     hipLaunchKernelGGL(group_sel_stats_bf16_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, Z, k, gamma, sel, lds, arg, M, C,
-                       sum, sumsq);
+                       ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_group_sel_stats_bf16");
-    return LPD_OK;
+    return lpd_stat_finish(ws, sum, sumsq, C, stream);
 }
 
 static int edge_bn_bwd_bf16_impl(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* dDense, const uint16_t* X,
@@ -1130,12 +1137,13 @@ static int edge_bn_bwd_bf16_impl(const float* dOut, long long ldo, const uint8_t
     LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && k <= 255 && ldo % 4 == 0 && ldq % 4 == 0 && ldsel % 4 == 0,
                   "lpd_edge_bn_bwd_bf16: bad dims");
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_bn_bwd_bf16: activation %d unsupported", act);
-    (void)hipMemsetAsync(dbeta, 0, sizeof(double) * C, stream);
-    (void)hipMemsetAsync(dgamma, 0, sizeof(double) * C, stream);
+    const LpdStatWs ws = lpd_stat_ws(stream);
+    LPD_CHECK_ARG(ws.rep, "lpd_edge_bn_bwd_bf16: no memory for the statistics scratch");
     const int rg = 256 / (C / 4);
     hipLaunchKernelGGL(edge_bn_bwd_reduce_bf16_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, dOut, ldo, arg, dDense, X, Xsel,
-                       ldsel, k, M, C, scale, shift, mean, invstd, act, slope, dbeta, dgamma);
+                       ldsel, k, M, C, scale, shift, mean, invstd, act, slope, ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_edge_bn_bwd_bf16(reduce)");
+    if (int rc = lpd_stat_finish(ws, dbeta, dgamma, C, stream)) return rc;
     hipLaunchKernelGGL(edge_bn_bwd_apply_bf16_kernel, dim3(grid_for(M, rg, 8192)), dim3(256), 0, stream, dOut, ldo, arg, dDense, X, dX, dQ,
                        ldq, k, M, C, scale, shift, mean, invstd, (const double*)dbeta, (const double*)dgamma, (double)M * (double)k, act,
                        slope);

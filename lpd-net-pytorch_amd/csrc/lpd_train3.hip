@@ -1,0 +1,469 @@
+// lpd_train3.hip -- backward of the DG2 stage (x2 = max_k act(BN_train(convDG2(y1e))), util/lpdnet_model.py:251-252) on bf16 edge
+// tensors WITHOUT the [E, 128] gradient tensor dZ.
+//
+// With dpre_i[c] = dx2_i[c] * act'(pre) living on the arg-max edge of (point i, channel c) only, m1 = mean(dpre), m2 = mean(dpre xhat)
+// over all E = M k edges and xhat = (z - mu) invstd, the BatchNorm backward is
+//     dZ[(i,t)][c] = s_c (delta_{t,arg_ic} dpre_i[c] - m1_c - xhat[(i,t)][c] m2_c)                                   (dense: E x 128).
+// lpd_train2.hip wrote dZ (bf16, 0.92 GB at B = 44), read it for dW2 = dZ^T Y1e and again for dY1e = dZ W2: 467 + 699 + 558 us.
+// Here:
+//   (1) lpd_bn_sel_bwd_reduce: an [M, C] pass over (dx2, the selected raw values kept by the forward): dpre (bf16), sum dpre, sum dpre xhat.
+//   (2) lpd_edge_dw_sel_bf16: ONE pass over Y1e computes S = D^T Y1e (D = the arg-max matrix delta dpre, built from [M, C] data while
+//       staging), the Gram matrix G = Y1e^T Y1e and the column sums s = 1^T Y1e; then, because z = Y1e W2^T,
+//           dW2[c][:] = s_c (S[c][:] - m1_c s - m2_c invstd_c (W2[c][:] G - mu_c s))                     (lpd_dw2_finish, fp64).
+//   (3) lpd_gemm_bf16s_bnbwd: dY1e = dZ W2 with dZ generated in the A-operand loader from z (bf16), (arg, dpre) of the row's point and
+//       two constants per channel: A = z a1 + a0 + delta dpre, the factor s_c folded into the staged weight rows.
+#include "lpd_common.h"
+#include <math.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b)   // RNE (v_cvt_pk_bf16_f32)
+{
+    const bf16x2v h = __builtin_convertvector((f32x2v){a, b}, bf16x2v);
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+inline int grid_for(long long items, int per_block, int cap = 4096)
+{
+    long long g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+// ------------------------------------------------------------------------------------------ (1)
+// dpre16[i][c] = bf16(dOut[i][c] * act'(scale x + shift)), dbeta += dpre, dgamma += dpre xhat (fp32 values, fp64 sums; the same
+// arithmetic and loop order as edge_bn_bwd_reduce_bf16_kernel's arg-max branch)
+__global__ __launch_bounds__(256) void bn_sel_bwd_reduce_kernel(const float* __restrict__ dOut, long long ldo, const float* __restrict__ Xsel,
+                                                                long long ldsel, long long M, int C, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, float ns, uint16_t* __restrict__ dpre16,
+                                                                double* __restrict__ dbeta, double* __restrict__ dgamma)
+{
+    __shared__ double red[256][8];
+    const int LQ = C >> 2;
+    const int RG = 256 / LQ;
+    const int q = threadIdx.x % LQ, rg = threadIdx.x / LQ;
+    float sc[4], sh[4], mu[4], is[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { sc[c] = scale[q * 4 + c]; sh[c] = shift[q * 4 + c]; mu[c] = mean[q * 4 + c]; is[c] = invstd[q * 4 + c]; }
+    double sb[4] = {0, 0, 0, 0}, sg[4] = {0, 0, 0, 0};
+    for (long long i = (long long)blockIdx.x * RG + rg; i < M; i += (long long)gridDim.x * RG) {
+        const float4 g4 = *reinterpret_cast<const float4*>(dOut + i * ldo + q * 4);
+        const float4 x4 = *reinterpret_cast<const float4*>(Xsel + i * ldsel + q * 4);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+        float dp[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            dp[c] = g[c] * (sc[c] * x[c] + sh[c] > 0.0f ? 1.0f : ns);
+            sb[c] += dp[c];
+            sg[c] += (double)dp[c] * ((x[c] - mu[c]) * is[c]);
+        }
+        *reinterpret_cast<uint2*>(dpre16 + i * C + q * 4) = make_uint2(pack_bf16(dp[0], dp[1]), pack_bf16(dp[2], dp[3]));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = sb[e]; red[threadIdx.x][4 + e] = sg[e]; }
+    __syncthreads();
+    if ((int)threadIdx.x < LQ) {
+        for (int g2 = 1; g2 < RG; ++g2)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[g2 * LQ + threadIdx.x][e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&dbeta[lpd_stat_rofs() + threadIdx.x * 4 + e], red[threadIdx.x][e]);
+            atomicAdd(&dgamma[lpd_stat_rofs() + threadIdx.x * 4 + e], red[threadIdx.x][4 + e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ (2)
+// slab[block] = [ S = D^T Y (128 x 128) | G = Y^T Y (128 x 128) | s = column sums of Y (128) ] over the block's rows of Y [E][128] bf16.
+// 512 threads, 128-row chunks in the two halves of [channel][row] LDS images (channel rows of 528 bytes: 2 x 128 rows + 16 bytes
+// of padding -- operand reads on 132-dword strides and store groups of 8 consecutive row groups are conflict-free, cf.
+// gemm_tn_bf16_kernel), one barrier per chunk: waves 0..3 stage Y patches (8 rows x 8 channels, register transpose), waves 4..7
+// build the D patches from (arg, dpre) of the one or two points their 8 rows belong to; the loads of chunk n+2 are requested at
+// the top of chunk n.  Wave (wa, wb) owns output row tiles wa (of S) and 4 + wa (of G), column tiles 2 wb, 2 wb + 1.
+// (First version: 256 threads, 64-row chunks, 8 accumulator tiles per wave: 34 spilled registers, loads one chunk ahead, 518 us.)
+__global__ __launch_bounds__(512, 2) void edge_dw_sel_bf16_kernel(const uint16_t* __restrict__ Y, const uint8_t* __restrict__ arg,
+                                                                  const uint16_t* __restrict__ dpre16, int k, long long E, long long Mp,
+                                                                  long long rows_per_block, float* __restrict__ slabs)
+{
+    constexpr int LDB = 528;                       // bytes per channel row of an image
+    extern __shared__ __attribute__((aligned(16))) unsigned char dw_lds[];
+    unsigned char* const img_d = dw_lds;
+    unsigned char* const img_y = dw_lds + 128 * LDB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const long long m_begin = (long long)blockIdx.x * rows_per_block;
+    const long long m_end = min(E, m_begin + rows_per_block);
+    const int nchunk = m_end > m_begin ? (int)((m_end - m_begin) / 128) : 0;     // whole chunks: E % 128 == 0 (host check)
+    const bool isY = __builtin_amdgcn_readfirstlane(tid) < 256;      // wave-uniform: waves 0..3 stage Y; waves 4..7 build D
+    const int wv = wave & 3;
+    const int rg = (lane & 7) + 8 * (wv >> 1), c8 = (lane >> 3) + 8 * (wv & 1);   // row group (8 rows) 0..15, channel group (8 channels) 0..15
+    unsigned char* const img = isY ? img_y : img_d;
+    const int wr_off = (c8 * 8) * LDB + rg * 16;   // + 256 * half + channel * LDB
+    const int wa = wave & 3, wb = wave >> 2;
+    const int rd_a = (wa * 32 + col) * LDB + h * 16;             // + 256 * half + 32 * kstep   (D image and Y image)
+    const int rd_b = (wb * 64 + col) * LDB + h * 16;             // + 32 * LDB * j
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // raw registers of a chunk: Y threads 8 row pieces; D threads (dpre, dpre, arg | arg) of two points in r[0..2], the first row's slot in ta
+    struct Raw { uint4 r[8]; int ta; };
+    Raw r0, r1;
+    auto load = [&](Raw& R, int chunk) {
+        const long long row0 = m_begin + (long long)chunk * 128 + rg * 8;
+        if (isY) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) R.r[i] = *reinterpret_cast<const uint4*>(Y + (row0 + i) * 128 + c8 * 8);
+        } else {
+            const long long ia = row0 / k;
+            const long long ib = ia + 1 < Mp ? ia + 1 : Mp - 1;
+            R.ta = (int)(row0 - ia * k);
+            const uint2 aa = *reinterpret_cast<const uint2*>(arg + ia * 128 + c8 * 8);
+            const uint2 ab = *reinterpret_cast<const uint2*>(arg + ib * 128 + c8 * 8);
+            R.r[0] = *reinterpret_cast<const uint4*>(dpre16 + ia * 128 + c8 * 8);
+            R.r[1] = *reinterpret_cast<const uint4*>(dpre16 + ib * 128 + c8 * 8);
+            R.r[2] = make_uint4(aa.x, aa.y, ab.x, ab.y);
+        }
+    };
+    auto transpose_store = [&](const uint32_t (&w)[8][4], int half) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {              // channel pair (2p, 2p+1) of the group: rows 0..7 as four dwords each
+            uint4 e, o;
+            e.x = __builtin_amdgcn_perm(w[1][p], w[0][p], 0x05040100u); o.x = __builtin_amdgcn_perm(w[1][p], w[0][p], 0x07060302u);
+            e.y = __builtin_amdgcn_perm(w[3][p], w[2][p], 0x05040100u); o.y = __builtin_amdgcn_perm(w[3][p], w[2][p], 0x07060302u);
+            e.z = __builtin_amdgcn_perm(w[5][p], w[4][p], 0x05040100u); o.z = __builtin_amdgcn_perm(w[5][p], w[4][p], 0x07060302u);
+            e.w = __builtin_amdgcn_perm(w[7][p], w[6][p], 0x05040100u); o.w = __builtin_amdgcn_perm(w[7][p], w[6][p], 0x07060302u);
+            const int off = wr_off + half * 256 + (2 * p) * LDB;
+            *reinterpret_cast<uint4*>(img + off) = e;
+            *reinterpret_cast<uint4*>(img + off + LDB) = o;
+        }
+    };
+    auto convert_store = [&](const Raw& R, int half) {
+        uint32_t w[8][4];
+        if (isY) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                w[i][0] = R.r[i].x; w[i][1] = R.r[i].y; w[i][2] = R.r[i].z; w[i][3] = R.r[i].w;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {      // column sums of the staged rows (fp32 per thread, fp64 across blocks)
+                    cs[2 * d] += __uint_as_float(w[i][d] << 16);
+                    cs[2 * d + 1] += __uint_as_float(w[i][d] & 0xffff0000u);
+                }
+            }
+        } else {
+            const uint32_t dpa[4] = {R.r[0].x, R.r[0].y, R.r[0].z, R.r[0].w}, dpb[4] = {R.r[1].x, R.r[1].y, R.r[1].z, R.r[1].w};
+            const uint32_t aa[2] = {R.r[2].x, R.r[2].y}, ab[2] = {R.r[2].z, R.r[2].w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int tt = R.ta + i;
+                const bool second = tt >= k;
+                const uint32_t t = (uint32_t)(second ? tt - k : tt);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {      // channels 2d, 2d + 1
+                    const uint32_t a2 = ((second ? ab[d >> 1] : aa[d >> 1]) >> (16 * (d & 1))) & 0xffffu;
+                    const uint32_t dp = second ? dpb[d] : dpa[d];
+                    const uint32_t mask = ((a2 & 0xffu) == t ? 0xffffu : 0u) | ((a2 >> 8) == t ? 0xffff0000u : 0u);
+                    w[i][d] = dp & mask;
+                }
+            }
+        }
+        transpose_store(w, half);
+    };
+    auto mma = [&](int half, int ks0) {            // four of the chunk's eight k-steps
+#pragma unroll
+        for (int ks = ks0; ks < ks0 + 4; ++ks) {
+            const int o = half * 256 + ks * 32;
+            const bf16x8 ad = *reinterpret_cast<const bf16x8*>(img_d + rd_a + o);
+            const bf16x8 ay = *reinterpret_cast<const bf16x8*>(img_y + rd_a + o);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(img_y + rd_b + o + j * 32 * LDB);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, b, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay, b, acc[1][j], 0, 0, 0);
+            }
+        }
+    };
+    auto chunk = [&](int n, const Raw& cur, Raw& nxt) {
+        load(nxt, n + 2 < nchunk ? n + 2 : nchunk - 1);        // unconditional: the last chunks are re-read and dropped
+        mma(n & 1, 0);
+        if (n + 1 < nchunk) convert_store(cur, (n + 1) & 1);
+        mma(n & 1, 4);
+        __syncthreads();
+    };
+    if (nchunk > 0) {
+        load(r0, 0);
+        convert_store(r0, 0);
+        load(r0, nchunk > 1 ? 1 : 0);
+        __syncthreads();
+        for (int n = 0; n < nchunk; n += 2) {
+            chunk(n, r0, r1);
+            if (n + 1 < nchunk) chunk(n + 1, r1, r0);
+        }
+    }
+    float* slab = slabs + (size_t)blockIdx.x * (256 * 128 + 128);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int arow = i * 128 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                slab[(size_t)arow * 128 + wb * 64 + j * 32 + col] = acc[i][j][r];
+            }
+    // column sums: the 16 row-group threads of a channel group, summed in a fixed order through LDS (the images are free now)
+    float* tmp = reinterpret_cast<float*>(img_d);
+    if (isY)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tmp[(c8 * 16 + rg) * 8 + e] = cs[e];
+    __syncthreads();
+    if (tid < 128) {
+        const int g8 = tid >> 3, e = tid & 7;
+        float t = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += tmp[(g8 * 16 + r) * 8 + e];
+        slab[256 * 128 + tid] = t;
+    }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, double* __restrict__ out, int n, int nslabs)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nslabs; ++b) s += slabs[(size_t)b * n + e];
+    out[e] = s;
+}
+
+// dW2[c][n] = s_c (S[c][n] - m1_c s[n] - m2_c invstd_c (sum_m W2[c][m] G[m][n] - mu_c s[n]))      one block per c, one thread per n
+__global__ __launch_bounds__(128) void dw2_finish_kernel(const double* __restrict__ R, const float* __restrict__ W2, long long ldw,
+                                                         const float* __restrict__ scale, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const double* __restrict__ dbeta,
+                                                         const double* __restrict__ dgamma, double count, float* __restrict__ dW2)
+{
+    const int c = blockIdx.x, n = threadIdx.x;
+    const double* S = R;
+    const double* G = R + 128 * 128;
+    const double* s = R + 2 * 128 * 128;
+    double zy = 0.0;
+    for (int m = 0; m < 128; ++m) zy += (double)W2[(size_t)c * ldw + m] * G[m * 128 + n];
+    const double m1 = dbeta[c] / count, m2 = dgamma[c] / count;
+    dW2[c * 128 + n] = (float)((double)scale[c] * (S[c * 128 + n] - m1 * s[n] - m2 * (double)invstd[c] * (zy - (double)mean[c] * s[n])));
+}
+
+// ------------------------------------------------------------------------------------------ (3)
+// dY[e][n] (bf16) = sum_c dZ[e][c] W2[c][n], dZ[e][c] = s_c (delta dpre - m1_c - xhat m2_c) generated in the loader:
+// A[e][c] = z[e][c] a1_c + a0_c + (arg[i][c] == t ? dpre[i][c] : 0), a1 = -invstd m2, a0 = mu invstd m2 - m1, e = (i, t);
+// staged weight rows s_c W2[c][:] (hi + lo).  Structure of gemm_bf16s_kernel (one wave: 32 rows x all 128 columns, transposed
+// MFMA tile, contraction index permuted k = h 64 + 8 s + e).  A tile's 32 rows belong to at most three points (k >= 16): their
+// arg / dpre rows (128 + 256 bytes each) go through a wave-private LDS buffer, requested one tile ahead and BEFORE the next
+// tile's z rows (vmcnt counts in order: the wait for them leaves the z rows in flight); as per-lane registers the two
+// would be 48 more registers per tile in flight (first version: 333 spilled registers).
+__global__ __launch_bounds__(256, 2) void gemm_bf16s_bnbwd_kernel(const uint16_t* __restrict__ Z, const uint8_t* __restrict__ arg,
+                                                                   const uint16_t* __restrict__ dpre16, int k, const float* __restrict__ W2,
+                                                                   int ldw, const float* __restrict__ scale, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, const double* __restrict__ dbeta,
+                                                                   const double* __restrict__ dgamma, double count,
+                                                                   uint16_t* __restrict__ Cout, long long E, long long Mp)
+{
+    constexpr int K = 128, N = 128, KS = K / 16, NT = N / 32, LDW = K + 8;
+    constexpr int PB = 384;                         // bytes of one point in the side buffer: dpre (256) | arg (128)
+    extern __shared__ __attribute__((aligned(16))) __bf16 wimg3[];   // hi image, lo image (2 * N * LDW bf16), float2 consts [K], side buffers
+    __bf16* whi = wimg3;
+    __bf16* wlo = wimg3 + N * LDW;
+    float2* cst = reinterpret_cast<float2*>(wimg3 + 2 * N * LDW);
+    unsigned char* side = reinterpret_cast<unsigned char*>(cst + K) + (threadIdx.x >> 6) * (2 * 3 * PB);   // this wave's two buffers
+    const int tid = threadIdx.x;
+    for (int e = tid; e < N * K; e += 256) {       // W(n, kk) = s_kk W2[kk][n]
+        const int n = e % N, kk = e / N;
+        const float w = W2[(size_t)kk * ldw + n] * scale[kk];
+        const __bf16 hi = (__bf16)w;
+        const __bf16 lo = (__bf16)(w - (float)hi);
+        whi[n * LDW + kk] = hi;
+        wlo[n * LDW + kk] = lo;
+    }
+    if (tid < K) {
+        const float m1 = (float)(dbeta[tid] / count), m2 = (float)(dgamma[tid] / count);
+        cst[tid] = make_float2(-invstd[tid] * m2, mean[tid] * invstd[tid] * m2 - m1);
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const long long ntile = (E + 31) / 32;
+    const long long stride = (long long)gridDim.x * 4;
+    long long tile = (long long)blockIdx.x * 4 + wave;
+    uint4 zc[KS], zn[KS], sd, sa;
+    // side data of a tile: lane L stages dpre piece (point L / 16, 16 bytes L % 16) and arg piece (point (L & 31) / 8, 16 bytes L % 8)
+    const int sd_p = (lane >> 4) < 3 ? (lane >> 4) : 2, sd_q = lane & 15;
+    const int sa_p = ((lane & 31) >> 3) < 3 ? ((lane & 31) >> 3) : 2, sa_q = lane & 7;
+    auto load_side = [&](long long tl) {
+        const long long i0 = (tl * 32 < E ? tl * 32 : E - 1) / k;
+        const long long pd = i0 + sd_p < Mp ? i0 + sd_p : Mp - 1, pa = i0 + sa_p < Mp ? i0 + sa_p : Mp - 1;
+        sd = *reinterpret_cast<const uint4*>(dpre16 + pd * K + sd_q * 8);
+        sa = *reinterpret_cast<const uint4*>(arg + pa * K + sa_q * 16);
+    };
+    auto store_side = [&](int buf) {
+        unsigned char* b = side + buf * (3 * PB);
+        if (lane < 48) *reinterpret_cast<uint4*>(b + sd_p * PB + sd_q * 16) = sd;
+        if (lane < 24) *reinterpret_cast<uint4*>(b + sa_p * PB + 256 + sa_q * 16) = sa;
+    };
+    auto load_z = [&](long long tl, uint4 (&z)[KS]) {
+        const long long row = tl * 32 + col;
+        const uint16_t* zp = Z + (row < E ? row : E - 1) * K + h * (K / 2);
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) z[s2] = *reinterpret_cast<const uint4*>(zp + s2 * 8);
+    };
+    int buf = 0;
+    if (tile < ntile) {
+        load_side(tile);
+        load_z(tile, zc);
+        store_side(0);
+    }
+    for (; tile < ntile; tile += stride, buf ^= 1) {
+        const long long row = tile * 32 + col;
+        const long long rr = row < E ? row : E - 1;
+        const long long i0 = (tile * 32 < E ? tile * 32 : E - 1) / k;
+        const long long ip = rr / k;
+        const uint32_t t = (uint32_t)(rr - ip * k);
+        const unsigned char* sb = side + buf * (3 * PB) + (int)(ip - i0) * PB + h * 128;     // this lane's point: dpre half, arg half at + 256 - h * 64
+        const long long tn = tile + stride < ntile ? tile + stride : tile;
+        load_side(tn);                              // first (see above), then the z rows of the next tile
+        load_z(tn, zn);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+            const uint32_t zw[4] = {zc[s2].x, zc[s2].y, zc[s2].z, zc[s2].w};
+            const uint4 d4 = *reinterpret_cast<const uint4*>(sb + s2 * 16);
+            const uint2 a2v = *reinterpret_cast<const uint2*>(sb + 256 - h * 64 + s2 * 8);
+            const uint32_t dw[4] = {d4.x, d4.y, d4.z, d4.w};
+            const uint32_t aw[2] = {a2v.x, a2v.y};
+            uint32_t op[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {          // channels h 64 + 8 s2 + 2 d, + 1
+                const float4 c2 = *reinterpret_cast<const float4*>(&cst[h * (K / 2) + s2 * 8 + 2 * d]);   // (a1, a0) of both channels
+                const uint32_t a2 = (aw[d >> 1] >> (16 * (d & 1))) & 0xffffu;
+                const float v0 = fmaf(__uint_as_float(zw[d] << 16), c2.x, c2.y) + ((a2 & 0xffu) == t ? __uint_as_float(dw[d] << 16) : 0.0f);
+                const float v1 = fmaf(__uint_as_float(zw[d] & 0xffff0000u), c2.z, c2.w) +
+                                 ((a2 >> 8) == t ? __uint_as_float(dw[d] & 0xffff0000u) : 0.0f);
+                op[d] = pack_bf16(v0, v1);
+            }
+            const bf16x8 av = __builtin_bit_cast(bf16x8, make_uint4(op[0], op[1], op[2], op[3]));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int off = (j * 32 + col) * LDW + h * (K / 2) + s2 * 8;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(whi + off);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wlo + off);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, av, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, av, acc[j], 0, 0, 0);
+            }
+        }
+        store_side(buf ^ 1);                        // the next tile's side data (this wave's own buffer: no barrier)
+        if (row < E) {
+            uint16_t* cp = Cout + row * N;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {   // accumulator rows 8g + 4h + {0..3} = output channels j*32 + 8g + 4h + ...
+                    const uint2 pk = make_uint2(pack_bf16(acc[j][4 * g], acc[j][4 * g + 1]), pack_bf16(acc[j][4 * g + 2], acc[j][4 * g + 3]));
+                    *reinterpret_cast<uint2*>(cp + j * 32 + 8 * g + 4 * h) = pk;
+                }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) zc[s2] = zn[s2];
+    }
+}
+
+}  // namespace
+
+extern "C" int lpd_bn_sel_bwd_reduce(const float* dOut, long long ldo, const float* Xsel, long long ldsel, long long M, int C,
+                                     const float* scale, const float* shift, const float* mean, const float* invstd, int act, float slope,
+                                     uint16_t* dpre16, double* dbeta, double* dgamma, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(dOut && Xsel && scale && shift && mean && invstd && dpre16 && dbeta && dgamma && M > 0, "lpd_bn_sel_bwd_reduce: null pointer");
+    LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && ldo % 4 == 0 && ldsel % 4 == 0, "lpd_bn_sel_bwd_reduce: bad dims");
+    LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_bn_sel_bwd_reduce: activation %d unsupported", act);
+    const LpdStatWs ws = lpd_stat_ws(stream);
+    LPD_CHECK_ARG(ws.rep, "lpd_bn_sel_bwd_reduce: no memory for the statistics scratch");
+    const int rg = 256 / (C / 4);
+    hipLaunchKernelGGL(bn_sel_bwd_reduce_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, dOut, ldo, Xsel, ldsel, M, C, scale,
+                       shift, mean, invstd, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), dpre16, ws.sum(), ws.sumsq());
+    LPD_CHECK_LAUNCH("lpd_bn_sel_bwd_reduce");
+    return lpd_stat_finish(ws, dbeta, dgamma, C, stream);
+}
+
+static long long edge_dw_sel_blocks(long long E)
+{
+    long long b = E / 4096;
+    return b > 256 ? 256 : (b < 1 ? 1 : b);       // one 512-thread block per CU
+}
+
+extern "C" long long lpd_edge_dw_sel_bf16_ws_bytes(long long E)
+{
+    return edge_dw_sel_blocks(E) * (256 * 128 + 128) * (long long)sizeof(float) + (256 * 128 + 128) * (long long)sizeof(double);
+}
+
+extern "C" int lpd_edge_dw_sel_bf16(const uint16_t* Y, const uint8_t* arg, const uint16_t* dpre16, int k, long long M, const float* W2,
+                                    long long ldw, const float* scale, const float* mean, const float* invstd, const double* dbeta,
+                                    const double* dgamma, float* dW2, void* ws, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(Y && arg && dpre16 && W2 && scale && mean && invstd && dbeta && dgamma && dW2 && ws && M > 0, "lpd_edge_dw_sel_bf16: null pointer");
+    LPD_CHECK_ARG(k >= 8 && k <= 255 && ldw >= 128, "lpd_edge_dw_sel_bf16: 8 <= k <= 255 and ldw >= 128 required");
+    LPD_CHECK_ARG((M * k) % 128 == 0, "lpd_edge_dw_sel_bf16: M * k must be a multiple of 128 (got %lld)", M * k);
+    LPD_CHECK_ARG((((uintptr_t)Y | (uintptr_t)dpre16 | (uintptr_t)arg | (uintptr_t)ws) & 15) == 0, "lpd_edge_dw_sel_bf16: pointers must be 16-byte aligned");
+    const long long E = M * k;
+    const long long blocks = edge_dw_sel_blocks(E);
+    long long rpb = (E + blocks - 1) / blocks;
+    rpb = (rpb + 127) / 128 * 128;
+    constexpr int n = 256 * 128 + 128;
+    constexpr int lds = 2 * 128 * 528;
+    double* red = reinterpret_cast<double*>(ws);
+    float* slabs = reinterpret_cast<float*>(red + n);
+    (void)hipFuncSetAttribute((const void*)edge_dw_sel_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(edge_dw_sel_bf16_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, Y, arg, dpre16, k, E, M, rpb, slabs);
+    LPD_CHECK_LAUNCH("lpd_edge_dw_sel_bf16");
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)slabs, red, n, (int)blocks);
+    LPD_CHECK_LAUNCH("lpd_edge_dw_sel_bf16(reduce)");
+    hipLaunchKernelGGL(dw2_finish_kernel, dim3(128), dim3(128), 0, stream, (const double*)red, W2, ldw, scale, mean, invstd, dbeta, dgamma,
+                       (double)M * (double)k, dW2);
+    LPD_CHECK_LAUNCH("lpd_edge_dw_sel_bf16(finish)");
+    return LPD_OK;
+}
+
+extern "C" int lpd_gemm_bf16s_bnbwd(const uint16_t* Z, const uint8_t* arg, const uint16_t* dpre16, int k, long long M, const float* W2, int ldw,
+                                    const float* scale, const float* mean, const float* invstd, const double* dbeta, const double* dgamma,
+                                    uint16_t* dY, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(Z && arg && dpre16 && W2 && scale && mean && invstd && dbeta && dgamma && dY && M > 0, "lpd_gemm_bf16s_bnbwd: null pointer");
+    LPD_CHECK_ARG(k >= 16 && k <= 255 && ldw >= 128, "lpd_gemm_bf16s_bnbwd: 16 <= k <= 255 and ldw >= 128 required");
+    LPD_CHECK_ARG((((uintptr_t)Z | (uintptr_t)dpre16 | (uintptr_t)arg | (uintptr_t)dY) & 15) == 0, "lpd_gemm_bf16s_bnbwd: pointers must be 16-byte aligned");
+    const long long E = M * k;
+    constexpr int lds = 2 * 128 * (128 + 8) * 2 + 128 * 8 + 4 * 2 * 3 * 384;
+    (void)hipFuncSetAttribute((const void*)gemm_bf16s_bnbwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const long long tiles = (E + 31) / 32;
+    long long blocks = (tiles + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(gemm_bf16s_bnbwd_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, Z, arg, dpre16, k, W2, ldw, scale, mean, invstd,
+                       dbeta, dgamma, (double)M * (double)k, dY, E, M);
+    LPD_CHECK_LAUNCH("lpd_gemm_bf16s_bnbwd");
+    return LPD_OK;
+}

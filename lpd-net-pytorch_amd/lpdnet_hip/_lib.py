@@ -113,9 +113,13 @@ SIGNATURES = {
     "lpd_group_sel_stats_bf16": [_c_p, _c_int, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p, _c_p, _c_p],
     "lpd_edge_bn_bwd_bf16": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int,
                              _c_f, _c_p, _c_p, _c_p],
+    "lpd_bn_sel_bwd_reduce": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p],
+    "lpd_edge_dw_sel_bf16": [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
+    "lpd_gemm_bf16s_bnbwd": [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_gather_sum_rows_bf16": [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_bf16s": [_c_p, _c_p, _c_int, _c_int, _c_p, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_tn_bf16_ws_floats": [_c_ll, _c_int, _c_int],
+    "lpd_edge_dw_sel_bf16_ws_bytes": [_c_ll],
     "lpd_gemm_tn_bf16": [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_tn_ws_floats": [_c_ll, _c_int, _c_int, _c_int],
     "lpd_gemm_tn": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_p],
@@ -123,7 +127,8 @@ SIGNATURES = {
                         _c_int, _c_f, _c_f, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
 }
 _RESTYPES = {"lpd_last_error": ctypes.c_char_p, "lpd_knn_workspace_floats": ctypes.c_longlong,
-             "lpd_gemm_prep_b_bytes": ctypes.c_longlong, "lpd_gemm_tn_bf16_ws_floats": ctypes.c_longlong, "lpd_gemm_tn_ws_floats": ctypes.c_longlong}
+             "lpd_gemm_prep_b_bytes": ctypes.c_longlong, "lpd_gemm_tn_bf16_ws_floats": ctypes.c_longlong, "lpd_gemm_tn_ws_floats": ctypes.c_longlong,
+             "lpd_edge_dw_sel_bf16_ws_bytes": ctypes.c_longlong}
 
 _lib = None
 

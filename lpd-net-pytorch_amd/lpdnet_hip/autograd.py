@@ -465,10 +465,19 @@ class _LPDNetTrainFn(torch.autograd.Function):
         dpq1 = torch.empty((M, 256), dtype=torch.float32, device=dfeat.device)
         if ctx.bf16:
             # DG2: x2 = groupmax(act(BN(Z))), Z = Y1e W2^T  (bf16 edge tensors, bf16 MFMA products)
-            dz, dgs2, dbs2 = ops.edge_bn_bwd_bf16(dcat[:, 128:256], S["arg2"], k, S["z"], S["stg2"], act, slope, xsel=S["zsel"])
-            dw2 = ops.gemm_tn_bf16(dz, S["y1e"])                                # [Co,Ci] = dZ^T Y1e
-            dy1e = ops.gemm_bf16s(dz, w2d(net.convDG2[0]), b_kmajor=True)       # [E,128] = dZ W2
-            del dz
+            w2 = w2d(net.convDG2[0])
+            if ops.dg2_bwd_fused_applies(M, k, w2.shape[0]) and w2.shape[1] == 128:
+                # no dZ tensor: dW2 from one pass over Y1e (arg-max product + Gram matrix), dY1e = dZ W2 with dZ built in the loader
+                dpre16, red2 = ops.bn_sel_bwd_reduce(dcat[:, 128:256], S["zsel"], S["stg2"], act, slope)
+                dw2 = ops.edge_dw_sel_bf16(S["y1e"], S["arg2"], dpre16, k, w2, S["stg2"], red2)
+                dy1e = ops.gemm_bf16s_bnbwd(S["z"], S["arg2"], dpre16, k, w2, S["stg2"], red2)
+                redf = red2.float()
+                dgs2, dbs2 = redf[1], redf[0]
+            else:
+                dz, dgs2, dbs2 = ops.edge_bn_bwd_bf16(dcat[:, 128:256], S["arg2"], k, S["z"], S["stg2"], act, slope, xsel=S["zsel"])
+                dw2 = ops.gemm_tn_bf16(dz, S["y1e"])                            # [Co,Ci] = dZ^T Y1e
+                dy1e = ops.gemm_bf16s(dz, w2, b_kmajor=True)                    # [E,128] = dZ W2
+                del dz
             du1, dgs1, dbs1 = ops.edge_bn_bwd_bf16(dcat[:, 0:128], S["arg1"], k, S["u1"], S["stg1"], act, slope, dense=dy1e,
                                                    dQ=dpq1[:, 128:])
             ops.gather_sum_rows_bf16(du1, ops.GraphT(S["idx_f"], N), dpq1[:, :128])

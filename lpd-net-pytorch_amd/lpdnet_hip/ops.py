@@ -1266,6 +1266,50 @@ def edge_bn_bwd_bf16(dOut, arg, k, X, st, act, slope, dense=None, dQ=None, xsel=
     return dX, redf[1], redf[0]
 
 
+def dg2_bwd_fused_applies(M, k, C):
+    """The DG2 backward without the dZ tensor (csrc/lpd_train3.hip) covers 128 channels, 16 <= k <= 255, whole 128-row chunks."""
+    return DG2_BWD_FUSED and C == 128 and 16 <= k <= 255 and (M * k) % 128 == 0
+
+
+def bn_sel_bwd_reduce(dOut, xsel, st, act, slope):
+    """Arg-max-only BatchNorm backward, reduction part: -> (dpre16 [M, C] bf16 = dOut * act'(pre), red fp64 [2, C] = (sum dpre,
+    sum dpre xhat)); xsel: the raw selected values of the forward."""
+    ldo = _rows(dOut, "dOut")
+    _req(xsel, "xsel")
+    M, C = xsel.shape
+    dpre16 = torch.empty((M, C), dtype=torch.bfloat16, device=xsel.device)
+    red = torch.empty((2, C), dtype=torch.float64, device=xsel.device)
+    lib = _lib.load()
+    _call(f"bn_sel_bwd_reduce[C={C}]", lib.lpd_bn_sel_bwd_reduce, _ptr(dOut), ldo, _ptr(xsel), _rows(xsel, "xsel"), M, C, _ptr(st.scale),
+          _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(dpre16), _ptr(red[0]), _ptr(red[1]), _stream())
+    return dpre16, red
+
+
+def edge_dw_sel_bf16(Y, arg, dpre16, k, W2, st, red):
+    """dW2 [128, 128] = dZ^T Y of the DG2 stage from one pass over Y [M*k, 128] bf16 (no dZ tensor): see lpd_edge_dw_sel_bf16."""
+    _bf16_rows(Y, "Y", 128), _bf16_rows(dpre16, "dpre16", 128)
+    _req(W2, "W2")
+    M = arg.shape[0]
+    lib = _lib.load()
+    ws = torch.empty((int(lib.lpd_edge_dw_sel_bf16_ws_bytes(M * k)),), dtype=torch.uint8, device=Y.device)
+    dW2 = torch.empty((128, 128), dtype=torch.float32, device=Y.device)
+    _call(f"edge_dw_sel_bf16[{M * k}]", lib.lpd_edge_dw_sel_bf16, _ptr(Y), _ptr(arg), _ptr(dpre16), k, M, _ptr(W2), W2.stride(0),
+          _ptr(st.scale), _ptr(st.mean), _ptr(st.invstd), _ptr(red[0]), _ptr(red[1]), _ptr(dW2), _ptr(ws), _stream())
+    return dW2
+
+
+def gemm_bf16s_bnbwd(Z, arg, dpre16, k, W2, st, red):
+    """dY [M*k, 128] bf16 = dZ W2 with dZ (BatchNorm backward of the arg-max gradient) generated in the operand loader."""
+    _bf16_rows(Z, "Z", 128), _bf16_rows(dpre16, "dpre16", 128)
+    _req(W2, "W2")
+    M = arg.shape[0]
+    dY = torch.empty((M * k, 128), dtype=torch.bfloat16, device=Z.device)
+    lib = _lib.load()
+    _call(f"gemm_bf16s_bnbwd[{M * k}x128x128]", lib.lpd_gemm_bf16s_bnbwd, _ptr(Z), _ptr(arg), _ptr(dpre16), k, M, _ptr(W2), W2.stride(0),
+          _ptr(st.scale), _ptr(st.mean), _ptr(st.invstd), _ptr(red[0]), _ptr(red[1]), _ptr(dY), _stream())
+    return dY
+
+
 def gather_sum_rows_bf16(dU, graph, dP, accumulate=False):
     ldp = _rows(dP, "dP")
     M, C = dP.shape
@@ -1307,6 +1351,7 @@ def gemm_tn_bf16(A, B):
     return dW
 
 
+DG2_BWD_FUSED = os.environ.get("LPD_DG2_BWD_FUSED", "1") != "0"    # bf16 storage: DG2 backward without the dZ tensor (lpd_train3.hip)
 GEMM_TN = os.environ.get("LPD_GEMM_TN", "1") != "0"      # weight gradients on the register-transposing kernel (lpd_gemm_tn)
 
 

@@ -797,6 +797,31 @@ def test_bf16_storage_edge_kernels(cuda):
     assert torch.equal(argzc, argz) and torch.equal(selc, sel)
     dX32c, dg32c, db32c = ops.edge_bn_bwd(dOut, argz, k, Z16.float(), stz, act, slope, xsel=selc)
     assert torch.equal(dX32c, dX32b) and torch.equal(dg32c, dg32b) and torch.equal(db32c, db32b)
+    # DG2 backward without the dZ tensor (csrc/lpd_train3.hip): dW = dZ^T Y from one pass over Y (arg-max product + Gram matrix),
+    # dY = dZ W with dZ generated in the operand loader -- against fp64 on the same stored tensors, and against the dZ path
+    assert ops.dg2_bwd_fused_applies(M, k, C)
+    dpre16, red = ops.bn_sel_bwd_reduce(dOut, sel, stz, act, slope)
+    assert torch.equal(red[0].float(), db16b) and torch.equal(red[1].float(), dg16b)
+    z64, y64 = Z16.double(), Y16.double()
+    pre = stz.scale.double() * sel.double() + stz.shift.double()
+    dpre = dOut.double() * torch.where(pre > 0, 1.0, slope)
+    assert torch.equal(dpre16, dpre.float().to(torch.bfloat16))
+    D = torch.zeros(M, k, C, dtype=torch.float64, device=cuda)
+    D.scatter_(1, argz.long().view(M, 1, C), dpre16.double().view(M, 1, C))            # the kernels use the bf16 dpre
+    m1, m2 = red[0] / (M * k), red[1] / (M * k)
+    xhat = (z64 - stz.mean.double()) * stz.invstd.double()
+    dZ = stz.scale.double() * (D.view(M * k, C) - m1 - xhat * m2)
+    dW_new = ops.edge_dw_sel_bf16(Y16, argz, dpre16, k, W, stz, red)
+    dW_old = ops.gemm_tn_bf16(dX16b, Y16)
+    dW_ref = dZ.t() @ y64
+    # the Gram form sums the UNROUNDED z = Y W^T where the dZ path holds z rounded to bf16 and dZ rounded to bf16
+    dW_ref_u = (stz.scale.double() * (D.view(M * k, C) - m1 - ((y64 @ W.double().t()) - stz.mean.double()) * stz.invstd.double() * m2)).t() @ y64
+    assert _rel(dW_new, dW_ref_u) < 2e-5, _rel(dW_new, dW_ref_u)
+    assert _rel(dW_new, dW_ref) < 3e-4 and _rel(dW_old, dW_ref) < 8e-3, (_rel(dW_new, dW_ref), _rel(dW_old, dW_ref))   # measured 7e-5 / 3.9e-3
+    dY_new = ops.gemm_bf16s_bnbwd(Z16, argz, dpre16, k, W, stz, red)
+    dY_old = ops.gemm_bf16s(dX16b, W, b_kmajor=True)
+    dY_ref = dZ @ W.double()
+    assert _rel(dY_new.double(), dY_ref) < 6e-3 and _rel(dY_old.double(), dY_ref) < 8e-3, (_rel(dY_new.double(), dY_ref), _rel(dY_old.double(), dY_ref))
     gt = ops.GraphT(idx, N)
     a = torch.empty(M, C, device=cuda)
     b = torch.empty(M, C, device=cuda)
