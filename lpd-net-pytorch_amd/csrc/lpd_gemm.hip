@@ -788,9 +788,10 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
                 }
             su += __shfl_xor(su, 32, 64);
             sq += __shfl_xor(sq, 32, 64);
-            if (h == 0) {
-                atomicAdd(g.stat_sum + n, (double)su);
-                atomicAdd(g.stat_sumsq + n, (double)sq);
+            if (h == 0) {        // into the replica of this row block (lpd_common.h, column statistics across blocks)
+                const size_t rofs = (size_t)((m0 >> 7) % LPD_STAT_REPLICAS) * 2 * LPD_STAT_CMAX;
+                atomicAdd(g.stat_sum + rofs + n, (double)su);
+                atomicAdd(g.stat_sumsq + rofs + n, (double)sq);
             }
         }
     }
@@ -1143,12 +1144,14 @@ static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, i
     LPD_CHECK_ARG(impl == 0 || impl == 2 || impl == 3, "lpd_gemm_x3w: impl=%d", impl);
     const int KS = (K + 15) / 16, NT = (N + 31) / 32;
     const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
-    X3wArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, K, KS, lda, ldc, bias, scale, shift, act, slope, accumulate,
-              a_cloud, c_cloud, panel_n, panel_ld, 0, prods, stat_sum, stat_sumsq};
+    LpdStatWs sws = {nullptr};
     if (stat_sum) {
-        (void)hipMemsetAsync(stat_sum, 0, sizeof(double) * N, stream);
-        (void)hipMemsetAsync(stat_sumsq, 0, sizeof(double) * N, stream);
+        LPD_CHECK_ARG(N <= LPD_STAT_CMAX, "lpd_gemm_x3w_stats: N=%d exceeds %d columns", N, LPD_STAT_CMAX);
+        sws = lpd_stat_ws(stream);
+        LPD_CHECK_ARG(sws.rep, "lpd_gemm_x3w_stats: no memory for the statistics scratch");
     }
+    X3wArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, K, KS, lda, ldc, bias, scale, shift, act, slope, accumulate,
+              a_cloud, c_cloud, panel_n, panel_ld, 0, prods, stat_sum ? sws.sum() : nullptr, stat_sum ? sws.sumsq() : nullptr};
     {   // (it matters for a row-major A with a power-of-two row stride; applied to every layout so that the summation
         //  order -- and with it every bit of the result -- does not depend on the layout of A)
         static const int rot = getenv("LPD_X3W_ROTATE") ? atoi(getenv("LPD_X3W_ROTATE")) : 1;
@@ -1173,6 +1176,7 @@ static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, i
         }
     }
     LPD_CHECK_LAUNCH("lpd_gemm_x3w");
+    if (stat_sum) return lpd_stat_finish(sws, stat_sum, stat_sumsq, N, stream);
     return LPD_OK;
 }
 
