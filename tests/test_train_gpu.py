@@ -634,3 +634,17 @@ def test_standalone_train_mode_forwards_of_the_submodules(cuda):
     xh = torch.randn(12, 256, generator=g)
     run(GatingContext(256, add_batch_norm=True), "g.", xh, gating_oracle(True), ["gating_weights", "bn1.weight", "bn1.bias"])
     run(GatingContext(256, add_batch_norm=False), "g.", xh, gating_oracle(False), ["gating_weights", "gating_biases"])
+
+
+@pytest.mark.parametrize("env", [{"LPD_DG2_BWD_FUSED": "0"}, {"LPD_TN256": "0"}, {"LPD_GEMM_STATS": "0"}, {"LPD_GEMM_TN": "0"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_training_switches_are_live(env):
+    """The training-path switches README.md documents are read at import (or at the first launch): the bf16-storage oracle
+    comparison and the reference's train step 0 run in a fresh interpreter under each of them."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_train_gpu.py"), "-k",
+           "test_train_bf16_storage_vs_oracle or (test_train_step0_vs_reference_golden and lpdnet_bq1)"]
+    r = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
