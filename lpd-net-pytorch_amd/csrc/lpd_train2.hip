@@ -171,7 +171,10 @@ __global__ __launch_bounds__(256) void edge_split_bwd_reduce_kernel(const float*
     reduce_quads<256>(red, sb, sg, LQ, dbeta, dgamma);
 }
 
-// one (part of a) wave per point j: dQ_j (own row) and dP_j (over the incoming edges of the transposed graph)
+// one (part of a) wave per point j: dQ_j (own row) and dP_j (over the incoming edges of the transposed graph).
+// (Tried in round 3 and dropped: the dP slice of a (cloud, 8 channels) accumulated in LDS over the FORWARD graph with ds_add_f32 --
+// 923 M lane-adds at B = 44 took 5.3 ms, i.e. ~0.36 lane-adds per clock and CU: LDS float atomics are no bulk accumulator.  The
+// forward on an LDS-resident P slice, without the eval K-agg kernel's operand pipeline and persistent blocks: 513 against 559 us.)
 template <int LPR>
 __global__ __launch_bounds__(256) void edge_split_bwd_apply_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ edges,
                                                                    const float* __restrict__ G, const uint8_t* __restrict__ arg,
@@ -205,7 +208,31 @@ __global__ __launch_bounds__(256) void edge_split_bwd_apply_kernel(const int32_t
         if (j >= M) continue;
         const int beg = rowptr[j], end = rowptr[j + 1];
         float A[4] = {0, 0, 0, 0}, R[4] = {0, 0, 0, 0};
-        for (int p = beg; p < end; ++p) {
+        int p = beg;
+        for (; p + 3 < end; p += 4) {          // four incoming edges at a time: twelve independent row loads in flight (1104 -> 930 us)
+            unsigned ii[4], tt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned e = (unsigned)edges[p + u];
+                ii[u] = e / ku;
+                tt[u] = e - ii[u] * ku;
+            }
+            float4 q4[4], g4[4];
+            uchar4 a4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                q4[u] = *reinterpret_cast<const float4*>(Q + (long long)ii[u] * ldq + cl * 4);
+                g4[u] = *reinterpret_cast<const float4*>(G + (long long)ii[u] * C + cl * 4);
+                a4[u] = *reinterpret_cast<const uchar4*>(arg + (long long)ii[u] * C + cl * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {      // same order of additions as the one-edge loop
+                R[0] += q4[u].x; R[1] += q4[u].y; R[2] += q4[u].z; R[3] += q4[u].w;
+                A[0] += a4[u].x == tt[u] ? g4[u].x : 0.f; A[1] += a4[u].y == tt[u] ? g4[u].y : 0.f;
+                A[2] += a4[u].z == tt[u] ? g4[u].z : 0.f; A[3] += a4[u].w == tt[u] ? g4[u].w : 0.f;
+            }
+        }
+        for (; p < end; ++p) {
             const unsigned e = (unsigned)edges[p];
             const unsigned i = e / ku, t = e - i * ku;
             const float4 q4 = *reinterpret_cast<const float4*>(Q + (long long)i * ldq + cl * 4);
