@@ -131,6 +131,8 @@ int lpd_gemm_bf16x1(const float* A, const float* B, float* C, int M, int N, int 
  */
 long long lpd_gemm_prep_b_bytes(int N, int K);
 int lpd_gemm_prep_b(const float* B, int ldb, int b_kmajor, int N, int K, void* frags, void* stream);
+/* `batch` matrices sB floats apart -> `batch` fragment sets lpd_gemm_prep_b_bytes(N, K) bytes apart (lpd_gemm_x3t_rows, batched) */
+int lpd_gemm_prep_b_batch(const float* B, int ldb, int b_kmajor, int N, int K, int batch, long long sB, void* frags, void* stream);
 int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
                  const float* scale, const float* shift, int act, float slope, int accumulate,
                  long long a_cloud, long long c_cloud, int panel_n, int panel_ld, int impl, void* stream);
@@ -154,6 +156,14 @@ int lpd_gemm_x3t_applies(int M, int N, int K, int act, long long a_cloud, long l
 int lpd_gemm_x3ts(const void* a_hi, long long a_lo, const void* frags, float* C, int M, int N, int K, const float* bias,
                   const float* scale, const float* shift, int act, float slope, long long a_cloud, long long c_cloud, int panel_n,
                   int panel_ld, void* stream);
+/* The transposed short-reduction product on ROW-MAJOR fp32 operands: C [M][ldc] = act((A [M][lda] . W^T + bias) * scale + shift) with the
+ * fragments of lpd_gemm_prep_b; K = 64 or 128, N % 32 == 0, M % 128 == 0.  batch > 1: independent problems with their own A, C
+ * (strides sA, sC in floats) and fragment sets (frag_bytes apart). */
+int lpd_gemm_x3t_rows_applies(int M, int N, int K, int act, long long lda, long long ldc);
+int lpd_gemm_x3t_rows(const float* A, long long lda, const void* frags, float* C, long long ldc, int M, int N, int K, const float* bias,
+                      const float* scale, const float* shift, int act, float slope, int batch, long long sA, long long sC,
+                      long long frag_bytes, void* stream);
+
 int lpd_gemm_x3t(const float* A, const void* frags, float* C, int M, int N, int K, const float* bias, const float* scale,
                  const float* shift, int act, float slope, long long a_cloud, long long c_cloud, int panel_n, int panel_ld,
                  void* stream);

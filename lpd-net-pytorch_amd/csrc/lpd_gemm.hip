@@ -530,10 +530,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16x3_kernel(GemmArgs g)
 // ---------------------------------------------------------------------------------------------
 // fragment order: frag[((nt * KS + ks) * 64 + lane) * 8 + j] = B[k = 16 ks + 8 (lane >> 5) + j][n = 32 nt + (lane & 31)]
 __global__ void gemm_prep_b_kernel(const float* __restrict__ B, int ldb, int b_kmajor, int N, int K, int KS,
-                                   __bf16* __restrict__ fhi, __bf16* __restrict__ flo, long long total)
+                                   __bf16* __restrict__ fhi, __bf16* __restrict__ flo, long long total, long long sB = 0)
 {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (nt, ks, lane)
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (nt, ks, lane); blockIdx.y: matrix of a batch
     if (t >= total) return;
+    B += (long long)blockIdx.y * sB;
+    fhi += (long long)blockIdx.y * total * 16;      // a matrix's fragment set: hi array, then lo array
+    flo += (long long)blockIdx.y * total * 16;
     const int lane = (int)(t & 63);
     const long long f = t >> 6;
     const int ks = (int)(f % KS), nt = (int)(f / KS);
@@ -1094,6 +1097,21 @@ extern "C" int lpd_gemm_prep_b(const float* B, int ldb, int b_kmajor, int N, int
     hipLaunchKernelGGL(gemm_prep_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, ldb, b_kmajor, N,
                        K, KS, fhi, flo, total);
     LPD_CHECK_LAUNCH("lpd_gemm_prep_b");
+    return LPD_OK;
+}
+
+// `batch` matrices sB floats apart -> `batch` fragment sets, lpd_gemm_prep_b_bytes(N, K) bytes apart (lpd_gemm_x3t_rows, batched)
+extern "C" int lpd_gemm_prep_b_batch(const float* B, int ldb, int b_kmajor, int N, int K, int batch, long long sB, void* frags, void* stream)
+{
+    LPD_CHECK_ARG(B && frags && N > 0 && K > 0 && batch >= 1 && batch <= 65535, "lpd_gemm_prep_b_batch: bad arguments");
+    LPD_CHECK_ARG(((uintptr_t)frags & 15) == 0, "lpd_gemm_prep_b_batch: frags must be 16-byte aligned");
+    const int KS = (K + 15) / 16, NT = (N + 31) / 32;
+    const long long total = (long long)NT * KS * 64;
+    __bf16* fhi = reinterpret_cast<__bf16*>(frags);
+    __bf16* flo = fhi + total * 8;
+    hipLaunchKernelGGL(gemm_prep_b_kernel, dim3((unsigned)((total + 255) / 256), batch), dim3(256), 0, (hipStream_t)stream, B, ldb, b_kmajor,
+                       N, K, KS, fhi, flo, total, sB);
+    LPD_CHECK_LAUNCH("lpd_gemm_prep_b_batch");
     return LPD_OK;
 }
 

@@ -59,6 +59,8 @@ struct X3tArgs {
     long long a_cloud, c_cloud;    // floats between clouds
     int panel_n, panel_ld;
     long long a_lo;                // != 0: A is the hi plane of a pair of split bf16 planes (a_cloud in elements), lo plane a_lo behind
+    long long lda, ldc;            // ROWS form: A [M][lda], C [M][ldc] row-major fp32 (no panels)
+    long long sA, sC, sF;          // ROWS form, batched over blockIdx.y: floats between the problems' A / C, bf16 elements between their fragments
 };
 
 constexpr int XT_THREADS = 256;    // 128 rows per workgroup (a panel cloud is a multiple of 128 rows)
@@ -75,26 +77,27 @@ __device__ __forceinline__ void xt_split4(const float4& a, uint2& hi, uint2& lo)
     lo = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
 }
 
-template <int KS>
+template <int KS, bool ROWS>
 __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
 {
     constexpr int K = KS * 16, LDK = K + 8, IMG = 128 * LDK;
-    extern __shared__ __attribute__((aligned(16))) __bf16 img[];     // [hi | lo][128 rows][LDK]
+    extern __shared__ __attribute__((aligned(16))) __bf16 img[];     // [hi | lo][128 rows][LDK] (+ ROWS: a [32][36] fp32 staging tile per wave)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const int col = lane & 31;
     const int m0 = lpd_xcd_remap(blockIdx.x, gridDim.x) * 128;
-    const int cloud = m0 / g.panel_n;
-    const int mc0 = m0 - cloud * g.panel_n;             // first row of the workgroup inside its cloud
-    const float* A = g.A + (long long)cloud * g.a_cloud;
-    float* C = g.C + (long long)cloud * g.c_cloud + (long long)(mc0 + col) * 8 + 4 * h;
+    const int cloud = ROWS ? 0 : m0 / g.panel_n;
+    const int mc0 = ROWS ? m0 : m0 - cloud * g.panel_n;  // first row of the workgroup inside its cloud (ROWS: in the matrix)
+    const float* A = ROWS ? g.A + (long long)blockIdx.y * g.sA : g.A + (long long)cloud * g.a_cloud;
+    float* C = ROWS ? g.C + (long long)blockIdx.y * g.sC + (long long)(mc0 + col) * g.ldc + 4 * h
+                    : g.C + (long long)cloud * g.c_cloud + (long long)(mc0 + col) * 8 + 4 * h;
 
     // ---- weight fragments of this wave's first tile: fragment (tile nt, k-step s) = 1 KiB at ((nt * KS + s) * 64 + lane) * 8 ----
     const int NT = g.N >> 5;
-    const __bf16* fh = g.fhi + (long long)lane * 8;
-    const __bf16* fl = g.flo + (long long)lane * 8;
+    const __bf16* fh = g.fhi + (ROWS ? (long long)blockIdx.y * g.sF : 0) + (long long)lane * 8;
+    const __bf16* fl = g.flo + (ROWS ? (long long)blockIdx.y * g.sF : 0) + (long long)lane * 8;
     xt_bf16x8 w_hi[KS], w_lo[KS];
     auto load_w = [&](int nt, int s) {       // one register set: step s of the NEXT tile is requested right behind the MFMAs of step s
         nt = nt < NT ? nt : NT - 1;           // past the end: any valid tile (never multiplied)
@@ -106,7 +109,21 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
     for (int s = 0; s < KS; ++s) load_w(wave, s);
 
     // ---- the 128 rows, split once: thread -> (row tid / 2, float4 half tid % 2) of every panel ----
-    if (g.a_lo) {                 // pre-split planes (the producer wrote hi / lo): straight copies
+    if constexpr (ROWS) {         // row-major A: a wave's lanes along the row (K / 4 float4 per row), 256 / (K / 4) rows per pass
+        constexpr int Q4 = K / 4, RPP = XT_THREADS / Q4;
+        const int c4 = tid % Q4, r0 = tid / Q4;
+        const float* src = A + (long long)(mc0 + r0) * g.lda + c4 * 4;
+        float4 v[128 / RPP];
+#pragma unroll
+        for (int p = 0; p < 128 / RPP; ++p) v[p] = *reinterpret_cast<const float4*>(src + (long long)p * RPP * g.lda);
+#pragma unroll
+        for (int p = 0; p < 128 / RPP; ++p) {
+            uint2 hh, ll;
+            xt_split4(v[p], hh, ll);
+            *reinterpret_cast<uint2*>(img + (p * RPP + r0) * LDK + c4 * 4) = hh;
+            *reinterpret_cast<uint2*>(img + IMG + (p * RPP + r0) * LDK + c4 * 4) = ll;
+        }
+    } else if (g.a_lo) {          // pre-split planes (the producer wrote hi / lo): straight copies
         const int row = tid >> 1, half = tid & 1;
         const __bf16* src = reinterpret_cast<const __bf16*>(g.A) + (long long)cloud * g.a_cloud + (long long)(mc0 + row) * 8 + half * 4;
         uint2 vh[K / 8], vl[K / 8];
@@ -138,6 +155,18 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
 
     const __bf16* dh = img + col * LDK + h * 8;
     const bool plain = !g.bias && !g.scale && g.ns == 1.0f;
+    // ROWS: a row of a 32 x 32 result tile sits in two lanes, four columns at a time -- stored directly, an instruction writes 32-byte
+    // pieces of 32 rows (180224 x 512 x 128: 217 us, 1.7 TB/s of writes).  The tile goes through a wave-private LDS tile instead and
+    // leaves as 8 whole 128-byte rows per instruction.
+    float* const st = reinterpret_cast<float*>(img + 2 * IMG) + wave * (32 * 36);
+    float* const stw = st + col * 36 + 4 * h;                 // this lane's columns 8 q + 4 h .. + 3 of row col
+    const float* const str = st + (lane >> 3) * 36 + (lane & 7) * 4;
+    float* const Crow = ROWS ? g.C + (long long)blockIdx.y * g.sC + (long long)(mc0 + (lane >> 3)) * g.ldc + (lane & 7) * 4 : nullptr;
+    auto rows_out = [&](int nt, int i) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            *reinterpret_cast<float4*>(Crow + (long long)(i * 32 + p * 8) * g.ldc + nt * 32) = *reinterpret_cast<const float4*>(str + p * 8 * 36);
+    };
     for (int nt = wave; nt < NT; nt += 4) {
         // (the operand fetches do not depend on the tile: left visible, the compiler hoists all of them out of this loop -- 256
         //  registers of data fragments, spilled)
@@ -168,6 +197,16 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
         }
         // ---- epilogue: registers 4 q .. 4 q + 3 of row tile i are columns 32 nt + 8 q + 4 h + {0..3} of row 32 i + col ----
         if (plain) {                              // uniform: the bare product (the edge projections)
+            if constexpr (ROWS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(stw + q * 8) = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
+                    rows_out(nt, i);
+                }
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float* dst = C + (long long)(nt * 4 + q) * g.panel_ld * 8;
@@ -190,19 +229,29 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
                 v.x = (v.x + bi.x) * sc.x + sh.x; v.y = (v.y + bi.y) * sc.y + sh.y;
                 v.z = (v.z + bi.z) * sc.z + sh.z; v.w = (v.w + bi.w) * sc.w + sh.w;
                 v.x = lpd_act_pl(v.x, g.ns); v.y = lpd_act_pl(v.y, g.ns); v.z = lpd_act_pl(v.z, g.ns); v.w = lpd_act_pl(v.w, g.ns);
-                *reinterpret_cast<float4*>(dst + i * 32 * 8) = v;
+                if constexpr (ROWS) acc[i][4 * q] = v.x, acc[i][4 * q + 1] = v.y, acc[i][4 * q + 2] = v.z, acc[i][4 * q + 3] = v.w;
+                else *reinterpret_cast<float4*>(dst + i * 32 * 8) = v;
+            }
+        }
+        if constexpr (ROWS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(stw + q * 8) = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
+                rows_out(nt, i);
             }
         }
     }
 }
 
-template <int KS>
-void x3t_launch(const X3tArgs& g, hipStream_t stream)
+template <int KS, bool ROWS = false>
+void x3t_launch(const X3tArgs& g, hipStream_t stream, int batch = 1)
 {
-    const size_t lds = (size_t)2 * 128 * (KS * 16 + 8) * sizeof(__bf16);
-    auto kern = gemm_x3t_kernel<KS>;
+    const size_t lds = (size_t)2 * 128 * (KS * 16 + 8) * sizeof(__bf16) + (ROWS ? 4 * 32 * 36 * sizeof(float) : 0);
+    auto kern = gemm_x3t_kernel<KS, ROWS>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(g.M / 128), dim3(XT_THREADS), lds, stream, g);
+    hipLaunchKernelGGL(kern, dim3(g.M / 128, batch), dim3(XT_THREADS), lds, stream, g);
 }
 
 }  // namespace
@@ -229,7 +278,8 @@ static int gemm_x3t_impl(const float* A, const void* frags, float* C, int M, int
                   "lpd_gemm_x3t: pointers must be 16-byte aligned");
     const int KS = K / 16, NT = N / 32;
     const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
-    X3tArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, bias, scale, shift, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), a_cloud, c_cloud, panel_n, panel_ld, a_lo};
+    X3tArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, bias, scale, shift, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), a_cloud, c_cloud, panel_n, panel_ld, a_lo,
+              0, 0, 0, 0, 0};
     hipStream_t stream = (hipStream_t)stream_;
     if (KS == 8) x3t_launch<8>(g, stream);
     else x3t_launch<4>(g, stream);
@@ -253,4 +303,37 @@ extern "C" int lpd_gemm_x3ts(const void* a_hi, long long a_lo, const void* frags
     LPD_CHECK_ARG(a_lo != 0 && a_lo % 8 == 0, "lpd_gemm_x3ts: lo-plane offset");
     return gemm_x3t_impl(reinterpret_cast<const float*>(a_hi), frags, C, M, N, K, bias, scale, shift, act, slope, a_cloud, c_cloud, panel_n,
                          panel_ld, a_lo, stream_);
+}
+
+// The same transposed product on ROW-MAJOR fp32 operands (no panels): C [M][ldc] = act((A [M][lda] . W^T + bias) * scale + shift), K = 64
+// or 128, N % 32 == 0, M % 128 == 0; `batch` problems with their own A, C and fragments (strides sA, sC in floats; frag_bytes between the
+// fragment sets as lpd_gemm_prep_b wrote them).  The generic 128 x 128 block kernel spends a short reduction in barriers, re-splitting
+// and 4-byte stores: SN1 projection of the training step (180224 x 512 x 128) 211 us there.
+extern "C" int lpd_gemm_x3t_rows_applies(int M, int N, int K, int act, long long lda, long long ldc)
+{
+    return (K == 64 || K == 128) && N > 0 && N % 32 == 0 && M > 0 && M % 128 == 0 && act >= 0 && act <= 2 && lda % 4 == 0 && ldc % 4 == 0 &&
+           lda >= K && ldc >= N;
+}
+
+extern "C" int lpd_gemm_x3t_rows(const float* A, long long lda, const void* frags, float* C, long long ldc, int M, int N, int K, const float* bias,
+                                 const float* scale, const float* shift, int act, float slope, int batch, long long sA, long long sC,
+                                 long long frag_bytes, void* stream_)
+{
+    LPD_CHECK_ARG(A && frags && C && batch >= 1 && batch <= 65535, "lpd_gemm_x3t_rows: bad arguments");
+    LPD_CHECK_ARG(lpd_gemm_x3t_rows_applies(M, N, K, act, lda, ldc),
+                  "lpd_gemm_x3t_rows: K in {64, 128}, N %% 32 == 0, M %% 128 == 0, act none / ReLU / LeakyReLU (M=%d N=%d K=%d act=%d)", M, N, K, act);
+    LPD_CHECK_ARG(act != 2 || (slope >= 0.0f && slope <= 1.0f), "lpd_gemm_x3t_rows: LeakyReLU slope %g outside [0, 1]", (double)slope);
+    LPD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "lpd_gemm_x3t_rows: scale and shift must be given together");
+    LPD_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)frags & 15) == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)bias & 15) == 0 &&
+                      ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0 && sA % 4 == 0 && sC % 4 == 0 && frag_bytes % 16 == 0,
+                  "lpd_gemm_x3t_rows: pointers / strides must be 16-byte aligned");
+    const int KS = K / 16, NT = N / 32;
+    const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
+    X3tArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, bias, scale, shift, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), 0, 0, 0, 0, 0,
+              lda, ldc, sA, sC, frag_bytes / 2};
+    hipStream_t stream = (hipStream_t)stream_;
+    if (KS == 8) x3t_launch<8, true>(g, stream, batch);
+    else x3t_launch<4, true>(g, stream, batch);
+    LPD_CHECK_LAUNCH("lpd_gemm_x3t_rows");
+    return LPD_OK;
 }

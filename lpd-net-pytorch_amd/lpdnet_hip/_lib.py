@@ -33,7 +33,11 @@ SIGNATURES = {
                  _c_ll, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_ll, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_prep_b_bytes": [_c_int, _c_int],
     "lpd_gemm_prep_b": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p],
+    "lpd_gemm_prep_b_batch": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_p, _c_p],
     "lpd_gemm_x3t_applies": [_c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_int],
+    "lpd_gemm_x3t_rows_applies": [_c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll],
+    "lpd_gemm_x3t_rows": [_c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_ll, _c_ll, _c_ll,
+                          _c_p],
     "lpd_gemm_x3t": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_ll, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_x3w": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int,
                      _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_p],

@@ -239,6 +239,7 @@ _FRAG_LOCK = __import__("threading").Lock()     # nn.DataParallel-style callers:
 X3W_FORWARD = os.environ.get("LPD_X3W_FWD", "1") != "0"    # forward layers with K >= 256 on the prepared-fragment kernel
 X3W_IMPL = int(os.environ.get("LPD_X3W_IMPL", "0"))         # lpd_gemm_x3w impl (0 = by shape); benchmarking only
 X3T_PANELS = os.environ.get("LPD_X3T", "1") != "0"          # short-reduction panel-to-panel products on lpd_gemm_x3t
+X3T_ROWS = os.environ.get("LPD_X3T_ROWS", "1") != "0"       # ... and row-major ones (K = 64 / 128) on lpd_gemm_x3t_rows
 
 
 def _weight_frags(B2, b_kmajor, N, K):
@@ -311,6 +312,20 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
     # fragments of B prepared once, B never staged through LDS (lpd_gemm_x3w).  Measured (tools/x3w_bench.py, M = 131072):
     # conv3 512 -> 1024 660 -> 505 us, dX 1024 -> 512 433 us; at K <= 128 the generic kernel is as fast or faster
     # (SN1 projection 142 vs 149 us, DG1 projection 52 vs 58 us), and k-major weights transpose in registers there.
+    # a short reduction (K = 64 / 128) over many rows: the transposed product lpd_gemm_x3t_rows (data rows as the MFMA's B operand, one
+    # barrier, float4 stores) -- the 128 x 128 block kernel spends it in barriers and 4-byte stores (SN1 projection of the training step 211 us)
+    if (GEMM_BF16X3 and X3T_ROWS and not exact and _EXACT.depth == 0 and _FAST.depth == 0 and not a_kmajor and splits == 1
+            and not accumulate and nb * M >= 16384 and nb <= 65535 and lib.lpd_gemm_x3t_rows_applies(M, N, K, act, lda, ldc)
+            and A.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and sA % 4 == 0 and sC % 4 == 0):
+        if batched:      # per-problem weights (the NetVLAD backward's [a | dA0] . [dVraw_b | Wc]^T): their fragments, every call
+            fb = int(lib.lpd_gemm_prep_b_bytes(N, K))
+            frags = torch.empty((nb * fb,), dtype=torch.uint8, device=A.device)
+            _call("gemm_prep_b", lib.lpd_gemm_prep_b_batch, _ptr(B), ldb, int(bool(b_kmajor)), N, K, nb, sB, _ptr(frags), _stream())
+        else:
+            fb, frags = 0, _weight_frags(B, b_kmajor, N, K)
+        _call(f"gemmx3t[{M}x{N}x{K}]" + (f"x{nb}" if batched else ""), lib.lpd_gemm_x3t_rows, _ptr(A), lda, _ptr(frags), _ptr(out), ldc, M, N, K,
+              _ptr(bias), _ptr(scale), _ptr(shift), act, float(slope), nb, sA, sC, fb, _stream())
+        return out
     if (GEMM_BF16X3 and not exact and _EXACT.depth == 0 and not a_kmajor and not batched and splits == 1
             and M >= 1024 and N >= 64 and N * K <= (1 << 22)
             and ((b_kmajor and K >= 128) or (X3W_FORWARD and K >= 256))):
