@@ -444,6 +444,12 @@ int lpd_vlad_finalize_bwd(const float* dOut, const float* v, const float* inv_c,
 int lpd_edge_split_fwd(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, const float* gamma,
                        float* S, float* usel, uint8_t* arg, long long M, int N, int C, int k, double* sum, double* sumsq,
                        void* stream);
+/* The same on cloud-resident slices (the organisation of lpd_edge_gather_max16: a block holds an 8-channel slice of a whole cloud in
+ * LDS and gathers the k neighbour pieces from there): idx16 from lpd_pack_idx16; k = 20, N <= 4096, C % 8 == 0.  S, usel, arg are
+ * bit-identical to lpd_edge_split_fwd, the statistics equal up to the order of the fp64 additions. */
+int lpd_edge_split_fwd16_applies(int N, int C, int k);
+int lpd_edge_split_fwd16(const float* P, long long ldp, const float* Q, long long ldq, const uint16_t* idx16, const float* gamma, float* S,
+                         float* usel, uint8_t* arg, long long M, int N, int C, int k, double* sum, double* sumsq, void* stream);
 
 /*
  * Backward of the split-form stage: dOut [M][ldo] = gradient of x3.  G [M][C] (scratch, receives dpre = dOut * act'),

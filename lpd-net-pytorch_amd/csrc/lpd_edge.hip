@@ -255,6 +255,141 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArg
     }
 }
 
+// The TRAINING forward of the split-form stage (lpd_train2.hip (1): S = sum_t P_nbr, the selected raw value + its slot, and the
+// closed-form BatchNorm statistics) on the same cloud-resident organisation: what edge_split_fwd_kernel gathers as 1-KiB rows through
+// L2 (3.7 GB at B = 44, C = 256: 559 us) comes from the LDS-resident slice here.  Row-major P / Q ([M][ld], slice = 8 columns).
+struct SplitFwdArgs {
+    const float* P;
+    const float* Q;
+    const float* gamma;      // [C]: the sign of the BatchNorm scale (selection = max where gamma >= 0, min otherwise)
+    float* S;                // [M][C]
+    float* usel;             // [M][C]
+    uint8_t* arg;            // [M][C]
+    double* sum;             // statistics replicas (lpd_common.h): column c of this block's replica at + c
+    double* sumsq;
+    int N, C;
+    int ldp, ldq;
+};
+
+template <int THREADS>     // 1024: the sums / arg-max bookkeeping does not fit 128 registers (102 spilled, 844 us); 512
+__global__ __launch_bounds__(THREADS) void edge_split_fwd_cloud16_kernel(SplitFwdArgs g, const uint16_t* __restrict__ idx16, int nslices)
+{
+    extern __shared__ float4 win[];   // two images [N][16 B]: channels 0-3 at byte 0, channels 4-7 at byte KAGG_IMG1
+    constexpr int GROUPS = THREADS / 2, KQ = 5;
+    const int tid = threadIdx.x;
+    const int cl = tid & 1;
+    const int grp = tid >> 1;
+    const unsigned lbase = cl * KAGG_IMG1;
+    const char* winb = reinterpret_cast<const char*>(win);
+    const int w = lpd_xcd_remap(blockIdx.x, gridDim.x);
+    const int sl = w % nslices;
+    const int b = w / nslices;
+    const int col = sl * 8 + cl * 4;
+    const unsigned row0 = (unsigned)b * g.N;
+    const int N = g.N, C = g.C;
+    const int passes = (N + GROUPS - 1) / GROUPS;
+    const uint2* idx2 = reinterpret_cast<const uint2*>(idx16);
+    const float* Qc = g.Q + (size_t)row0 * g.ldq + col;
+    const unsigned ldq = g.ldq;
+    auto load = [&](CloudOps& o, int ps) {
+        o.m = row0 + min(ps * GROUPS + grp, N - 1);
+        const uint2* ip = idx2 + ((o.m >> 5) * (KQ * 32) + (o.m & 31));
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) o.ix[i] = ip[i * 32];
+        o.q = *reinterpret_cast<const float4*>(Qc + (o.m - row0) * ldq);
+    };
+    const float4 gm = *reinterpret_cast<const float4*>(g.gamma + col);
+    const float4 sg = make_float4(gm.x >= 0.f ? 1.f : -1.f, gm.y >= 0.f ? 1.f : -1.f, gm.z >= 0.f ? 1.f : -1.f, gm.w >= 0.f ? 1.f : -1.f);
+    const float* Pc = g.P + (size_t)row0 * g.ldp + col;
+    {   // the cloud's slice of P, sign-adjusted (one running max serves both selections): every row piece requested before the first store
+        constexpr int NP = 4096 / GROUPS;
+        float4 pr[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) pr[i] = *reinterpret_cast<const float4*>(Pc + (size_t)min(grp + i * GROUPS, N - 1) * g.ldp);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int r = grp + i * GROUPS;
+            float4 p = pr[i];
+            p.x *= sg.x; p.y *= sg.y; p.z *= sg.z; p.w *= sg.w;
+            if (r < N) *reinterpret_cast<float4*>(const_cast<char*>(winb) + lbase + r * 16) = p;
+        }
+    }
+    CloudOps A, Bo, Co;
+    load(A, 0);
+    load(Bo, 1);
+    __syncthreads();
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    const float kf = 4.0f * KQ;
+    auto process = [&](const CloudOps& o, bool valid) {
+        float sp[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned ab[4] = {0, 0, 0, 0};
+        auto edge = [&](unsigned off, unsigned t) {
+            const float4 a = *reinterpret_cast<const float4*>(winb + (off + lbase));
+            const float p[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                sp[c] += p[c];
+                sq[c] = fmaf(p[c], p[c], sq[c]);
+                const bool take = p[c] > best[c];          // first extremum of the sign-adjusted values, like torch.max / torch.min
+                best[c] = take ? p[c] : best[c];
+                ab[c] = take ? t : ab[c];
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) {
+            edge(o.ix[i].x & 0xffffu, 4 * i);
+            edge(o.ix[i].x >> 16, 4 * i + 1);
+            edge(o.ix[i].y & 0xffffu, 4 * i + 2);
+            edge(o.ix[i].y >> 16, 4 * i + 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float sgn[4] = {sg.x, sg.y, sg.z, sg.w}, q[4] = {o.q.x, o.q.y, o.q.z, o.q.w};
+        float S4[4], U4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            S4[c] = sgn[c] * sp[c];                       // exact: the sign flips commute with the rounding of the sums
+            U4[c] = sgn[c] * best[c] + q[c];
+        }
+        const size_t off = (size_t)o.m * C + col;
+        *reinterpret_cast<float4*>(g.S + off) = make_float4(S4[0], S4[1], S4[2], S4[3]);
+        *reinterpret_cast<float4*>(g.usel + off) = make_float4(U4[0], U4[1], U4[2], U4[3]);
+        *reinterpret_cast<uint32_t*>(g.arg + off) = ab[0] | (ab[1] << 8) | (ab[2] << 16) | (ab[3] << 24);
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s[c] += (double)S4[c] + (double)kf * q[c];
+                ss[c] += (double)sq[c] + 2.0 * (double)q[c] * S4[c] + (double)kf * q[c] * q[c];
+            }
+        }
+    };
+    for (int ps = 0; ps < passes; ps += 3) {     // (a pass past the end of the cloud re-stores the last point with identical values)
+        load(Co, ps + 2);
+        process(A, ps * GROUPS + grp < N);
+        load(A, ps + 3);
+        if (ps + 1 < passes) process(Bo, (ps + 1) * GROUPS + grp < N);
+        load(Bo, ps + 4);
+        if (ps + 2 < passes) process(Co, (ps + 2) * GROUPS + grp < N);
+    }
+    // 8 sums per lane -> per (wave, cl) by shuffles over the 32 lanes of a parity -> per block through LDS -> the block's replica
+    __syncthreads();                              // every gather is done: the images are free
+    double* red = reinterpret_cast<double*>(win);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int o2 = 32; o2 > 1; o2 >>= 1) { s[c] += __shfl_xor(s[c], o2, 64); ss[c] += __shfl_xor(ss[c], o2, 64); }
+    if ((tid & 62) == 0)                          // lanes 0 and 1 of each wave
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { red[((tid >> 6) * 2 + cl) * 8 + c] = s[c]; red[((tid >> 6) * 2 + cl) * 8 + 4 + c] = ss[c]; }
+    __syncthreads();
+    if (tid < 16) {                               // tid = which * 8 + channel of the slice
+        const int which = tid >> 3, ch = tid & 7;
+        double t = 0.0;
+        for (int wv = 0; wv < THREADS / 64; ++wv) t += red[(wv * 2 + (ch >> 2)) * 8 + which * 4 + (ch & 3)];
+        atomicAdd((which ? g.sumsq : g.sum) + lpd_stat_rofs() + sl * 8 + ch, t);
+    }
+}
+
 // Persistent form for 8-pass clouds (3584 < N <= 4096, the benchmark shape): a workgroup walks `per` consecutive
 // (cloud, slice) items and requests the NEXT item's P rows while it works through the current one -- one float4 per
 // thread and pass, parked in registers until the gathers of the current slice are done, then stored to LDS.  With one
@@ -959,4 +1094,35 @@ extern "C" int lpd_edge_mlp_bf16x3s(const float* P, int ldp, const float* Q, int
     LPD_CHECK_ARG(out_lo != 0 && out_cloud != 0, "lpd_edge_mlp_bf16x3s: split output needs cloud panels and a lo-plane offset");
     return edge_mlp_entry(true, P, ldp, Q, ldq, idx, s1, b1, W2, s2, b2, reinterpret_cast<float*>(out_hi), 8, M, N, CM, CO, k, act, slope,
                           out_cloud, panel_ld, stream, out_lo);
+}
+
+// Training forward of the split-form edge stage on cloud-resident slices (see edge_split_fwd_cloud16_kernel): same results as
+// lpd_edge_split_fwd (S, usel, arg bit-identical; the statistics up to the order of the fp64 additions).  idx16 from lpd_pack_idx16;
+// k = 20, N <= 4096, C % 8 == 0, row-major P / Q.
+extern "C" int lpd_edge_split_fwd16_applies(int N, int C, int k)
+{
+    static const bool on = [] { const char* e = getenv("LPD_SPLIT_LDS"); return !(e && e[0] == '0'); }();
+    return on && k == 20 && N >= 32 && N <= 4096 && C > 0 && C % 8 == 0 && C <= LPD_STAT_CMAX;
+}
+
+extern "C" int lpd_edge_split_fwd16(const float* P, long long ldp, const float* Q, long long ldq, const uint16_t* idx16, const float* gamma,
+                                    float* S, float* usel, uint8_t* arg, long long M, int N, int C, int k, double* sum, double* sumsq,
+                                    void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(P && Q && idx16 && gamma && S && usel && arg && sum && sumsq, "lpd_edge_split_fwd16: null pointer");
+    LPD_CHECK_ARG(M > 0 && N > 0 && M % N == 0 && lpd_edge_split_fwd16_applies(N, C, k), "lpd_edge_split_fwd16: N=%d C=%d k=%d unsupported", N, C, k);
+    LPD_CHECK_ARG(ldp % 4 == 0 && ldq % 4 == 0 && ldp < (1ll << 31) && ldq < (1ll << 31), "lpd_edge_split_fwd16: leading dims");
+    LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)Q | (uintptr_t)S | (uintptr_t)usel | (uintptr_t)arg | (uintptr_t)gamma | (uintptr_t)idx16) & 15) == 0,
+                  "lpd_edge_split_fwd16: pointers must be 16-byte aligned");
+    LPD_CHECK_ARG((unsigned long long)M * (unsigned long long)C * 4ull < (1ull << 34), "lpd_edge_split_fwd16: tensor too large");
+    const LpdStatWs ws = lpd_stat_ws(stream);
+    LPD_CHECK_ARG(ws.rep, "lpd_edge_split_fwd16: no memory for the statistics scratch");
+    SplitFwdArgs g{P, Q, gamma, S, usel, arg, ws.sum(), ws.sumsq(), N, C, (int)ldp, (int)ldq};
+    const int nslices = C / 8;
+    const size_t lds = (size_t)KAGG_IMG1 + (size_t)N * 16;
+    (void)hipFuncSetAttribute((const void*)edge_split_fwd_cloud16_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(edge_split_fwd_cloud16_kernel<512>, dim3((unsigned)((M / N) * nslices)), dim3(512), lds, stream, g, idx16, nslices);
+    LPD_CHECK_LAUNCH("lpd_edge_split_fwd16");
+    return lpd_stat_finish(ws, sum, sumsq, C, stream);
 }

@@ -1174,6 +1174,12 @@ def edge_split_fwd(P, Q, idx, N, bn):
     arg = torch.empty((M, C), dtype=torch.uint8, device=dev)
     sums = torch.empty((2, C), dtype=torch.float64, device=dev)
     lib = _lib.load()
+    if (lib.lpd_edge_split_fwd16_applies(N, C, k) and P.data_ptr() % 16 == 0 and Q.data_ptr() % 16 == 0
+            and bn.weight.data_ptr() % 16 == 0):
+        # cloud-resident slices (the eval K-agg kernel's organisation): the k neighbour rows come from LDS, not through L2
+        _call(f"edge_split_fwd[C={C}]", lib.lpd_edge_split_fwd16, _ptr(P), ldp, _ptr(Q), ldq, _ptr(pack_idx16(idx)), _ptr(bn.weight),
+              _ptr(S), _ptr(usel), _ptr(arg), M, N, C, k, _ptr(sums[0]), _ptr(sums[1]), _stream())
+        return S, usel, arg, _bn_finalize(sums, M * k, C, bn)
     _call(f"edge_split_fwd[C={C}]", lib.lpd_edge_split_fwd, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(bn.weight), _ptr(S), _ptr(usel),
           _ptr(arg), M, N, C, k, _ptr(sums[0]), _ptr(sums[1]), _stream())
     return S, usel, arg, _bn_finalize(sums, M * k, C, bn)

@@ -697,7 +697,7 @@ def _bn_for(C, seed):
     return bn
 
 
-@pytest.mark.parametrize("C,N,k,B", [(256, 512, 20, 2), (128, 300, 20, 3), (64, 128, 7, 2), (256, 256, 64, 1)])
+@pytest.mark.parametrize("C,N,k,B", [(256, 512, 20, 2), (128, 300, 20, 3), (64, 128, 7, 2), (256, 256, 64, 1), (256, 4096, 20, 2), (64, 1000, 20, 1)])
 def test_split_form_edge_stage_equals_the_materialised_one(cuda, C, N, k, B):
     """lpd_edge_split_fwd / _bwd (no [M*k, C] edge tensor; closed-form BatchNorm sums, one pass over the transposed graph)
     against the materialised formulation edge_build -> group_max -> edge_bn_bwd -> gather_sum_rows: outputs, arg-max,
@@ -718,8 +718,21 @@ def test_split_form_edge_stage_equals_the_materialised_one(cuda, C, N, k, B):
     dU, dg_a, db_a = ops.edge_bn_bwd(dOut, arg_a, k, U, st_a, act, slope, dQ=dQ_a)
     dP_a = torch.empty(M, C, device=cuda)
     ops.gather_sum_rows(dU, ops.GraphT(idx, N), dP_a)
-    # split form
+    # split form (k = 20, N <= 4096: on cloud-resident slices; the wave-per-point kernel must give the same S / usel / arg bit for bit)
     S, usel, arg_b, st_b = ops.edge_split_fwd(P, Q, idx, N, bn_b)
+    if k == 20:
+        import ctypes
+        from lpdnet_hip import _lib
+        lib = _lib.load()
+        assert lib.lpd_edge_split_fwd16_applies(N, C, k)
+        S0, u0, a0 = torch.empty_like(S), torch.empty_like(usel), torch.empty_like(arg_b)
+        sums0 = torch.empty(2, C, dtype=torch.float64, device=cuda)
+        idc = idx.reshape(-1, k).contiguous()
+        rc = lib.lpd_edge_split_fwd(P.data_ptr(), P.stride(0), Q.data_ptr(), Q.stride(0), idc.data_ptr(), bn_b.weight.data_ptr(), S0.data_ptr(),
+                                    u0.data_ptr(), a0.data_ptr(), M, N, C, k, sums0[0].data_ptr(), sums0[1].data_ptr(),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        assert torch.equal(S0, S) and torch.equal(u0, usel) and torch.equal(a0, arg_b)
     out_b = ops.affine_act(usel, st_b.scale, st_b.shift, act, slope)
     buf = torch.zeros(M, 2 * C + 8, device=cuda)
     dg_b, db_b = ops.edge_split_bwd(dOut, usel, arg_b, S, P, Q, ops.GraphT(idx, N), st_b, act, slope, k, dP=buf[:, 4:4 + C],
