@@ -174,7 +174,11 @@ __global__ __launch_bounds__(256) void edge_split_bwd_reduce_kernel(const float*
 // one (part of a) wave per point j: dQ_j (own row) and dP_j (over the incoming edges of the transposed graph).
 // (Tried in round 3 and dropped: the dP slice of a (cloud, 8 channels) accumulated in LDS over the FORWARD graph with ds_add_f32 --
 // 923 M lane-adds at B = 44 took 5.3 ms, i.e. ~0.36 lane-adds per clock and CU: LDS float atomics are no bulk accumulator.  The
-// forward on an LDS-resident P slice, without the eval K-agg kernel's operand pipeline and persistent blocks: 513 against 559 us.)
+// forward on an LDS-resident P slice, without the eval K-agg kernel's operand pipeline and persistent blocks: 513 against 559 us --
+// the forward now runs on the eval kernel's organisation, lpd_edge.hip edge_split_fwd_cloud16_kernel: 352 us.  Also tried for this
+// backward: a block holding the 4-channel slices of Q, dpre and arg of a whole cloud in LDS and walking a degree-sorted, slot-major
+// transposed graph (built by LDS atomics + a counting sort in 56 us; heavy rows by a scan kernel): correct, but 8.3 GB of random
+// 16 / 16 / 4-byte LDS reads plus the scattered slice fills cost 762 us against 930 here.)
 template <int LPR>
 __global__ __launch_bounds__(256) void edge_split_bwd_apply_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ edges,
                                                                    const float* __restrict__ G, const uint8_t* __restrict__ arg,
