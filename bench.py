@@ -23,6 +23,7 @@ oracle (torch-CPU restatement of the reference path) timed on this box's host co
 sample; it is a reported baseline, not the optimisation target.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -45,6 +46,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--settle-seconds", type=float, default=1.0,
                     help="untimed forwards in front of the warm-up steps until the device has been busy this long (clock ramp of an idle box)")
+    ap.add_argument("--settle-max-seconds", type=float, default=12.0,
+                    help="... and at most this long, until two consecutive windows of 64 forwards agree within 1.5 %%")
     ap.add_argument("--batch", type=int, default=32, help="clouds per step per GPU (eval_batch_size)")
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--k", type=int, default=20, help="neighbours per point (reference hard-codes 20; configs[4] uses 64)")
@@ -207,12 +210,25 @@ def _time_steps(step, first, n, dist, dev):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    # (the caller has switched the cyclic garbage collector off in front of its warm-up steps: a full collection of this process's
+    #  heap was caught stalling ONE timed step's enqueue for 82 ms -- gpu_ms 78 of that step, per_step below -- in one run of five;
+    #  collecting HERE would leave the GPU idle for tens of ms right in front of the timed region, which costs its clocks:
+    #  1.92 ms per eval step in a 20-step region against 1.83 in a 200-step one)
     t0 = time.perf_counter()
-    out = [step(first + i) for i in range(n)]
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    host = []
+    out = []
+    evs[0].record()
+    for i in range(n):
+        th = time.perf_counter()
+        out.append(step(first + i))
+        host.append(round(1e3 * (time.perf_counter() - th), 2))
+        evs[i + 1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     el = time.perf_counter() - t0
+    _time_steps.last = {"gpu_ms": [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(n)], "host_enqueue_ms": host}
     if dist is not None:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -220,9 +236,11 @@ def _time_steps(step, first, n, dist, dev):
     return el, out
 
 
-def train_bench(dev, dist, world, rank, points, steps, warmup=2, storage="f32"):
+def train_bench(dev, dist, world, rank, points, steps, warmup=4, storage="f32"):
     """Secondary metric of BASELINE.json: quadruplet train-steps/s (configs[2]: bq=2, P=2, Ng=18 -> 44 clouds/rank,
-    lazy quadruplet loss, Adam), data-parallel across ranks with the RCCL gradient all-reduce (configs[3])."""
+    lazy quadruplet loss, Adam), data-parallel across ranks with the RCCL gradient all-reduce (configs[3]).
+    Four untimed steps first: the leg starts from an emptied allocator cache (12 GiB of blocks to re-create), and with two
+    warm-up steps about one run in five still met device allocations inside its five timed steps (22 ms instead of 15.6)."""
     from util.PointNetVlad import PointNetVlad
     import loss.pointnetvlad_loss as L
     from lpdnet_hip import autograd
@@ -254,10 +272,14 @@ def train_bench(dev, dist, world, rank, points, steps, warmup=2, storage="f32"):
     prev_storage = autograd.set_train_storage(storage)
     try:
         step = make_step(net)
+        gc.collect()
+        gc.disable()                                    # until the timed steps are over (see _time_steps)
         for i in range(warmup):
             step(i)
         torch.cuda.reset_peak_memory_stats(dev)
         el, losses = _time_steps(step, warmup, steps, dist, dev)
+        gc.enable()
+        per_step = getattr(_time_steps, "last", None)       # stream-event time and host enqueue time of every timed step
         losses = [round(float(l.item()), 4) for l in losses]
         peak = torch.cuda.max_memory_allocated(dev) / 2**30
         comm = None
@@ -296,7 +318,7 @@ def train_bench(dev, dist, world, rank, points, steps, warmup=2, storage="f32"):
             "tuples_per_s": round(bq * world * steps / el, 3), "ms_per_step": round(1e3 * el / steps, 2), "steps": steps,
             "config": f"BASELINE configs[{2 if world == 1 else 3}]: bq={bq} P={P} Ng={Ng} -> {B} clouds/rank, N={points}, lazy quadruplet, "
                       f"Adam, {storage} storage; x{world} ranks data-parallel (per-rank BN, gradient all-reduce)",
-            "dtype": storage, "losses": losses, "peak_hbm_gib": round(peak, 2), "exchange": comm}
+            "dtype": storage, "losses": losses, "peak_hbm_gib": round(peak, 2), "exchange": comm, "per_step": per_step}
 
 
 def secondary_eval(dev, points, k, batch, steps, warmup=2):
@@ -312,6 +334,8 @@ def secondary_eval(dev, points, k, batch, steps, warmup=2):
     gen = torch.Generator().manual_seed(4321)
     clouds = [(torch.rand((batch, 1, points, 3), generator=gen) * 2 - 1).to(dev) for _ in range(2)]
     with torch.no_grad():
+        gc.collect()
+        gc.disable()                                    # until the timed steps are over (see _time_steps)
         for i in range(warmup + 1):
             model(clouds[i % 2])
         torch.cuda.synchronize()
@@ -321,6 +345,7 @@ def secondary_eval(dev, points, k, batch, steps, warmup=2):
             model(clouds[i % 2])
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        gc.enable()
     kern = kernel_table(ops.PROFILE)
     ops.PROFILE, ops.PROFILE_ONLY = None, None
     rec = {"metric": "global descriptors/sec", "value": round(batch * steps / el, 2), "unit": "descriptors/s",
@@ -416,6 +441,24 @@ def main():
         if n_settle % 8 == 0:
             torch.cuda.synchronize()
     torch.cuda.synchronize()
+    # ... and until the step time has stopped moving: windows of 64 forwards, two in a row within 1.5 % of each other, at most
+    # --settle-max-seconds in all (a fresh box has been seen at 2.0 ms/step in its first process's timed region, 1.83 in the next)
+    prev = None
+    while time.perf_counter() - t_settle < args.settle_max_seconds:
+        tw = time.perf_counter()
+        for _ in range(64):
+            step(n_settle)
+            n_settle += 1
+        torch.cuda.synchronize()
+        cur = (time.perf_counter() - tw) / 64
+        if prev is not None and abs(cur - prev) <= 0.015 * prev:
+            break
+        prev = cur
+    settle_s = time.perf_counter() - t_settle
+    gc.collect()
+    gc.disable()                                        # until the timed steps are over (see _time_steps)
+    for i in range(8):                                  # the collection left the GPU idle: a few forwards in front of the W warm-up steps
+        step(i)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -432,6 +475,7 @@ def main():
         out = step(i)
     torch.cuda.synchronize()
     my_elapsed = time.perf_counter() - t0
+    gc.enable()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -535,7 +579,7 @@ def main():
                        "clouds_per_step_per_gpu": args.batch, "num_points": args.points,
                        "parallelism": f"shard-by-cloud x{world} (one process per GPU, no data-path collective)",
                        "hip_streams": engine.side_stream_report(dev),
-                       "settle": f"{n_settle} untimed forwards ({args.settle_seconds:g} s) before the warm-up steps",
+                       "settle": f"{n_settle} untimed forwards ({settle_s:.1f} s: until two windows of 64 agree within 1.5 %) before the warm-up steps",
                        "arithmetic": ("fp32 tensors; kNN distances and every layer in front of the feature-space kNN exact fp32; large dense "
                                       "products as 3-product split-bf16 MFMA with fp32 accumulation (DESIGN.md 3.2)"
                                       if ops.GEMM_BF16X3 else "fp32 tensors, every product on the f32-input MFMA / fp32 FMA")},
