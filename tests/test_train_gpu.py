@@ -636,12 +636,13 @@ def test_standalone_train_mode_forwards_of_the_submodules(cuda):
     run(GatingContext(256, add_batch_norm=False), "g.", xh, gating_oracle(False), ["gating_weights", "gating_biases"])
 
 
-@pytest.mark.parametrize("env", [{"LPD_DG2_BWD_FUSED": "0"}, {"LPD_TN256": "0"}, {"LPD_GEMM_STATS": "0"}, {"LPD_GEMM_TN": "0"},
-                                 {"LPD_SPLIT_LDS": "0"}, {"LPD_X3T_ROWS": "0"}],
+@pytest.mark.parametrize("env", [{"LPD_DG2_BWD_FUSED": "0", "LPD_TN256": "0", "LPD_GEMM_STATS": "0", "LPD_SPLIT_LDS": "0", "LPD_X3T_ROWS": "0"},
+                                 {"LPD_GEMM_TN": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_training_switches_are_live(env):
     """The training-path switches README.md documents are read at import (or at the first launch): the bf16-storage oracle
-    comparison and the reference's train step 0 run in a fresh interpreter under each of them."""
+    comparison and the reference's train step 0 run in a fresh interpreter with the round-3 kernels switched off together (the paths
+    they replaced stay tested), and with the register-transposing weight-gradient kernels off."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
