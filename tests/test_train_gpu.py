@@ -529,7 +529,7 @@ def test_train_step0_cfg2_full_size_vs_reference(cuda, golden_dir, storage):
 # fixtures (test_train_bf16_storage_vs_oracle: 1.8e-2, 1.5 %, 7-12 %), as expected when the head's BatchNorms run over 44 rows
 # instead of 6, and that is what the gates below state.
 CFG2_GATES = {"f32": (1e-3, 1.5e-4, 5e-4, 5e-3, 2e-3),
-              "bf16": (1e-2, 5e-3, 5e-3, 0.1, 0.03)}
+              "bf16": (6e-3, 3e-3, 2e-3, 0.07, 0.02)}     # about twice the measured values above (unchanged by the round-3 kernels)
 
 
 def test_bf16_storage_converges_like_fp32(cuda):
