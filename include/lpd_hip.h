@@ -509,6 +509,17 @@ int lpd_edge_dw_sel_bf16(const uint16_t* Y, const uint8_t* arg, const uint16_t* 
 int lpd_gemm_bf16s_bnbwd(const uint16_t* Z, const uint8_t* arg, const uint16_t* dpre16, int k, long long M, const float* W2, int ldw,
                          const float* scale, const float* mean, const float* invstd, const double* dbeta, const double* dgamma, uint16_t* dY,
                          void* stream);
+/* The three steps above for fp32 STORAGE (fp32 Y1e / Z / dY, fp32 dpre; split-bf16 products): (M * k) % 64 == 0, 16 <= k <= 255; the
+ * workspace of lpd_edge_dw_sel_f32 is lpd_edge_dw_sel_bf16_ws_bytes(M * k) bytes. */
+int lpd_bn_sel_bwd_reduce_f32(const float* dOut, long long ldo, const float* Xsel, long long ldsel, long long M, int C, const float* scale,
+                              const float* shift, const float* mean, const float* invstd, int act, float slope, float* dpre, double* dbeta,
+                              double* dgamma, void* stream);
+int lpd_edge_dw_sel_f32(const float* Y, const uint8_t* arg, const float* dpre, int k, long long M, const float* W2, long long ldw,
+                        const float* scale, const float* mean, const float* invstd, const double* dbeta, const double* dgamma, float* dW2,
+                        void* ws, void* stream);
+int lpd_gemm_f32s_bnbwd(const float* Z, const uint8_t* arg, const float* dpre, int k, long long M, const float* W2, int ldw,
+                        const float* scale, const float* mean, const float* invstd, const double* dbeta, const double* dgamma, float* dY,
+                        void* stream);
 /* lpd_gather_sum_rows with a bf16 edge-gradient tensor (fp32 sums) */
 int lpd_gather_sum_rows_bf16(const uint16_t* dU, const int32_t* rowptr, const int32_t* edges, float* dP, long long ldp, long long M,
                              int C, int accumulate, void* stream);

@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void bn_sel_bwd_reduce_kernel(const float* __r
                                                                 long long ldsel, long long M, int C, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, float ns, uint16_t* __restrict__ dpre16,
-                                                                double* __restrict__ dbeta, double* __restrict__ dgamma)
+                                                                float* __restrict__ dpre32, double* __restrict__ dbeta,
+                                                                double* __restrict__ dgamma)
 {
     __shared__ double red[256][8];
     const int LQ = C >> 2;
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(256) void bn_sel_bwd_reduce_kernel(const float* __r
             sb[c] += dp[c];
             sg[c] += (double)dp[c] * ((x[c] - mu[c]) * is[c]);
         }
-        *reinterpret_cast<uint2*>(dpre16 + i * C + q * 4) = make_uint2(pack_bf16(dp[0], dp[1]), pack_bf16(dp[2], dp[3]));
+        if (dpre16) *reinterpret_cast<uint2*>(dpre16 + i * C + q * 4) = make_uint2(pack_bf16(dp[0], dp[1]), pack_bf16(dp[2], dp[3]));
+        if (dpre32) *reinterpret_cast<float4*>(dpre32 + i * C + q * 4) = make_float4(dp[0], dp[1], dp[2], dp[3]);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = sb[e]; red[threadIdx.x][4 + e] = sg[e]; }
@@ -390,23 +392,333 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_bnbwd_kernel(const uint16_t
     }
 }
 
+// ------------------------------------------------------------------------------------------ fp32 storage: the same two kernels
+// (2f) slab[block] = [ S = D^T Y | G = Y^T Y | column sums of Y ] for fp32 Y [E][128] and fp32 dpre [M][128], split-bf16 products (three
+// per term).  512 threads, 64-row chunks in the two halves of FOUR images (D hi / lo, Y hi / lo: [channel][2 x 64 rows] bf16, 272-byte
+// channel rows); a staging thread owns an 8-row x 4-channel patch (waves 0..3: Y, waves 4..7: D), loads two chunks ahead.
+__global__ __launch_bounds__(512, 2) void edge_dw_sel_f32_kernel(const float* __restrict__ Y, const uint8_t* __restrict__ arg,
+                                                                 const float* __restrict__ dpre, int k, long long E, long long Mp,
+                                                                 long long rows_per_block, float* __restrict__ slabs)
+{
+    constexpr int LDB = 272, IMG = 128 * LDB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dwf_lds[];      // D hi | D lo | Y hi | Y lo
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const long long m_begin = (long long)blockIdx.x * rows_per_block;
+    const long long m_end = min(E, m_begin + rows_per_block);
+    const int nchunk = m_end > m_begin ? (int)((m_end - m_begin) / 64) : 0;      // whole chunks: E % 64 == 0 (host check)
+    const bool isY = __builtin_amdgcn_readfirstlane(tid) < 256;
+    const int pt = tid & 255;
+    const int rg = pt & 7, c4 = pt >> 3;           // row group (8 rows) 0..7, channel quad 0..31
+    unsigned char* const img_hi = dwf_lds + (isY ? 2 * IMG : 0);
+    unsigned char* const img_lo = img_hi + IMG;
+    const int wr_off = (c4 * 4) * LDB + rg * 16;   // + 128 * half + channel * LDB
+    const int wa = wave & 3, wb = wave >> 2;
+    const int rd_a = (wa * 32 + col) * LDB + h * 16;             // + 128 * half + 32 * kstep
+    const int rd_b = (wb * 64 + col) * LDB + h * 16;             // + 32 * LDB * j
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    struct Raw { float4 r[8]; };     // Y: 8 row pieces; D: dpre of two points in r[0], r[1]; r[2] = (arg quad a, arg quad b, first slot) as bits
+    Raw r0, r1;
+    auto load = [&](Raw& R, int chunk) {
+        const long long row0 = m_begin + (long long)chunk * 64 + rg * 8;
+        if (isY) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) R.r[i] = *reinterpret_cast<const float4*>(Y + (row0 + i) * 128 + c4 * 4);
+        } else {
+            const long long ia = row0 / k;
+            const long long ib = ia + 1 < Mp ? ia + 1 : Mp - 1;
+            const uint32_t aa = *reinterpret_cast<const uint32_t*>(arg + ia * 128 + c4 * 4);
+            const uint32_t ab = *reinterpret_cast<const uint32_t*>(arg + ib * 128 + c4 * 4);
+            R.r[0] = *reinterpret_cast<const float4*>(dpre + ia * 128 + c4 * 4);
+            R.r[1] = *reinterpret_cast<const float4*>(dpre + ib * 128 + c4 * 4);
+            R.r[2] = make_float4(__uint_as_float(aa), __uint_as_float(ab), __int_as_float((int)(row0 - ia * k)), 0.0f);
+        }
+    };
+    auto convert_store = [&](const Raw& R, int half) {
+        float v[8][4];
+        if (isY) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i][0] = R.r[i].x; v[i][1] = R.r[i].y; v[i][2] = R.r[i].z; v[i][3] = R.r[i].w;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cs[c] += v[i][c];
+            }
+        } else {
+            const float da[4] = {R.r[0].x, R.r[0].y, R.r[0].z, R.r[0].w}, db[4] = {R.r[1].x, R.r[1].y, R.r[1].z, R.r[1].w};
+            const uint32_t aa = __float_as_uint(R.r[2].x), ab = __float_as_uint(R.r[2].y);
+            const int ta = __float_as_int(R.r[2].z);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int tt = ta + i;
+                const bool second = tt >= k;
+                const uint32_t t = (uint32_t)(second ? tt - k : tt);
+                const uint32_t a = second ? ab : aa;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[i][c] = ((a >> (8 * c)) & 0xffu) == t ? (second ? db[c] : da[c]) : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {              // channel pair (2p, 2p+1) of the quad
+            uint32_t wh[8], wl[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v0 = v[i][2 * p], v1 = v[i][2 * p + 1];
+                const uint32_t hp = pack_bf16(v0, v1);
+                wh[i] = hp;
+                wl[i] = pack_bf16(v0 - __uint_as_float(hp << 16), v1 - __uint_as_float(hp & 0xffff0000u));
+            }
+            uint4 e, o;
+            e.x = __builtin_amdgcn_perm(wh[1], wh[0], 0x05040100u); o.x = __builtin_amdgcn_perm(wh[1], wh[0], 0x07060302u);
+            e.y = __builtin_amdgcn_perm(wh[3], wh[2], 0x05040100u); o.y = __builtin_amdgcn_perm(wh[3], wh[2], 0x07060302u);
+            e.z = __builtin_amdgcn_perm(wh[5], wh[4], 0x05040100u); o.z = __builtin_amdgcn_perm(wh[5], wh[4], 0x07060302u);
+            e.w = __builtin_amdgcn_perm(wh[7], wh[6], 0x05040100u); o.w = __builtin_amdgcn_perm(wh[7], wh[6], 0x07060302u);
+            const int off = wr_off + half * 128 + (2 * p) * LDB;
+            *reinterpret_cast<uint4*>(img_hi + off) = e;
+            *reinterpret_cast<uint4*>(img_hi + off + LDB) = o;
+            e.x = __builtin_amdgcn_perm(wl[1], wl[0], 0x05040100u); o.x = __builtin_amdgcn_perm(wl[1], wl[0], 0x07060302u);
+            e.y = __builtin_amdgcn_perm(wl[3], wl[2], 0x05040100u); o.y = __builtin_amdgcn_perm(wl[3], wl[2], 0x07060302u);
+            e.z = __builtin_amdgcn_perm(wl[5], wl[4], 0x05040100u); o.z = __builtin_amdgcn_perm(wl[5], wl[4], 0x07060302u);
+            e.w = __builtin_amdgcn_perm(wl[7], wl[6], 0x05040100u); o.w = __builtin_amdgcn_perm(wl[7], wl[6], 0x07060302u);
+            *reinterpret_cast<uint4*>(img_lo + off) = e;
+            *reinterpret_cast<uint4*>(img_lo + off + LDB) = o;
+        }
+    };
+    const unsigned char* const dh = dwf_lds, * const dl = dwf_lds + IMG, * const yh = dwf_lds + 2 * IMG, * const yl = dwf_lds + 3 * IMG;
+    auto mma = [&](int half, int ks0) {            // two of the chunk's four k-steps
+#pragma unroll
+        for (int ks = ks0; ks < ks0 + 2; ++ks) {
+            const int o = half * 128 + ks * 32;
+            const bf16x8 adh = *reinterpret_cast<const bf16x8*>(dh + rd_a + o), adl = *reinterpret_cast<const bf16x8*>(dl + rd_a + o);
+            const bf16x8 ayh = *reinterpret_cast<const bf16x8*>(yh + rd_a + o), ayl = *reinterpret_cast<const bf16x8*>(yl + rd_a + o);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(yh + rd_b + o + j * 32 * LDB);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(yl + rd_b + o + j * 32 * LDB);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(adl, bh, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ayl, bh, acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(adh, bl, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ayh, bl, acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(adh, bh, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ayh, bh, acc[1][j], 0, 0, 0);
+            }
+        }
+    };
+    auto chunk = [&](int n, const Raw& cur, Raw& nxt) {
+        load(nxt, n + 2 < nchunk ? n + 2 : nchunk - 1);        // unconditional: the last chunks are re-read and dropped
+        mma(n & 1, 0);
+        if (n + 1 < nchunk) convert_store(cur, (n + 1) & 1);
+        mma(n & 1, 2);
+        __syncthreads();
+    };
+    if (nchunk > 0) {
+        load(r0, 0);
+        convert_store(r0, 0);
+        load(r0, nchunk > 1 ? 1 : 0);
+        __syncthreads();
+        for (int n = 0; n < nchunk; n += 2) {
+            chunk(n, r0, r1);
+            if (n + 1 < nchunk) chunk(n + 1, r1, r0);
+        }
+    }
+    float* slab = slabs + (size_t)blockIdx.x * (256 * 128 + 128);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int arow = i * 128 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                slab[(size_t)arow * 128 + wb * 64 + j * 32 + col] = acc[i][j][r];
+            }
+    float* tmp = reinterpret_cast<float*>(dwf_lds);      // column sums: the 8 row-group threads of a channel quad, in a fixed order
+    if (isY)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tmp[(c4 * 8 + rg) * 4 + e] = cs[e];
+    __syncthreads();
+    if (tid < 128) {
+        const int q4 = tid >> 2, e = tid & 3;
+        float t = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += tmp[(q4 * 8 + r) * 4 + e];
+        slab[256 * 128 + tid] = t;
+    }
+}
+
+// (3f) dY [E][128] (fp32) = dZ W2 with dZ generated in the loader from fp32 z: A = z a1 + a0 + delta dpre, split hi + lo, three products
+// with the staged weight rows s_c W2[c][:] (hi + lo).  512 threads share the weight images; a wave owns 32 rows and all 128 columns
+// (transposed tile); the result leaves through a wave-private LDS tile as whole 128-byte rows (cf. lpd_gemm_x3t_rows).
+__global__ __launch_bounds__(512, 2) void gemm_f32s_bnbwd_kernel(const float* __restrict__ Z, const uint8_t* __restrict__ arg,
+                                                                 const float* __restrict__ dpre, int k, const float* __restrict__ W2, int ldw,
+                                                                 const float* __restrict__ scale, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const double* __restrict__ dbeta,
+                                                                 const double* __restrict__ dgamma, double count, float* __restrict__ Cout,
+                                                                 long long E, long long Mp)
+{
+    constexpr int K = 128, N = 128, KS = K / 16, NT = N / 32, LDW = K + 8;
+    constexpr int PB = 640;                         // bytes of one point in the side buffer: dpre (512) | arg (128)
+    extern __shared__ __attribute__((aligned(16))) __bf16 wimg4[];   // hi, lo images | float2 consts [K] | per wave: side buffers, staging tile
+    __bf16* whi = wimg4;
+    __bf16* wlo = wimg4 + N * LDW;
+    float2* cst = reinterpret_cast<float2*>(wimg4 + 2 * N * LDW);
+    unsigned char* wbase = reinterpret_cast<unsigned char*>(cst + K) + (threadIdx.x >> 6) * (2 * 3 * PB + 32 * 36 * 4);
+    unsigned char* side = wbase;
+    float* st = reinterpret_cast<float*>(wbase + 2 * 3 * PB);
+    const int tid = threadIdx.x;
+    for (int e = tid; e < N * K; e += 512) {       // W(n, kk) = s_kk W2[kk][n]
+        const int n = e % N, kk = e / N;
+        const float w = W2[(size_t)kk * ldw + n] * scale[kk];
+        const __bf16 hi = (__bf16)w;
+        const __bf16 lo = (__bf16)(w - (float)hi);
+        whi[n * LDW + kk] = hi;
+        wlo[n * LDW + kk] = lo;
+    }
+    if (tid < K) {
+        const float m1 = (float)(dbeta[tid] / count), m2 = (float)(dgamma[tid] / count);
+        cst[tid] = make_float2(-invstd[tid] * m2, mean[tid] * invstd[tid] * m2 - m1);
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const long long ntile = (E + 31) / 32;
+    const long long stride = (long long)gridDim.x * 8;
+    long long tile = (long long)blockIdx.x * 8 + wave;
+    float4 zc[16], zn[16], sd[2], sa;
+    // side data of a tile: lanes 0..47 stage dpre (point L / 16, 32 bytes L % 16), lanes 0..23 arg (point L / 8, 16 bytes L % 8)
+    const int sd_p = (lane >> 4) < 3 ? (lane >> 4) : 2, sd_q = lane & 15;
+    const int sa_p = ((lane & 31) >> 3) < 3 ? ((lane & 31) >> 3) : 2, sa_q = lane & 7;
+    auto load_side = [&](long long tl) {
+        const long long i0 = (tl * 32 < E ? tl * 32 : E - 1) / k;
+        const long long pd = i0 + sd_p < Mp ? i0 + sd_p : Mp - 1, pa = i0 + sa_p < Mp ? i0 + sa_p : Mp - 1;
+        sd[0] = *reinterpret_cast<const float4*>(dpre + pd * K + sd_q * 8);
+        sd[1] = *reinterpret_cast<const float4*>(dpre + pd * K + sd_q * 8 + 4);
+        sa = *reinterpret_cast<const float4*>(arg + pa * K + sa_q * 16);
+    };
+    auto store_side = [&](int buf) {
+        unsigned char* b = side + buf * (3 * PB);
+        if (lane < 48) {
+            *reinterpret_cast<float4*>(b + sd_p * PB + sd_q * 32) = sd[0];
+            *reinterpret_cast<float4*>(b + sd_p * PB + sd_q * 32 + 16) = sd[1];
+        }
+        if (lane < 24) *reinterpret_cast<float4*>(b + sa_p * PB + 512 + sa_q * 16) = sa;
+    };
+    auto load_z = [&](long long tl, float4 (&z)[16]) {
+        const long long row = tl * 32 + col;
+        const float* zp = Z + (row < E ? row : E - 1) * K + h * (K / 2);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) z[u] = *reinterpret_cast<const float4*>(zp + u * 4);
+    };
+    int buf = 0;
+    if (tile < ntile) {
+        load_side(tile);
+        load_z(tile, zc);
+        store_side(0);
+    }
+    float* const stw = st + col * 36 + 4 * h;
+    const float* const str = st + (lane >> 3) * 36 + (lane & 7) * 4;
+    for (; tile < ntile; tile += stride, buf ^= 1) {
+        const long long row = tile * 32 + col;
+        const long long rr = row < E ? row : E - 1;
+        const long long i0 = (tile * 32 < E ? tile * 32 : E - 1) / k;
+        const long long ip = rr / k;
+        const uint32_t t = (uint32_t)(rr - ip * k);
+        const unsigned char* sb = side + buf * (3 * PB) + (int)(ip - i0) * PB;     // this lane's point: dpre [128] fp32, arg [128] at + 512
+        const long long tn = tile + stride < ntile ? tile + stride : tile;
+        load_side(tn);                              // first, then the z rows of the next tile (in-order vmcnt, see gemm_bf16s_bnbwd_kernel)
+        load_z(tn, zn);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {           // channels h 64 + 8 s2 .. + 7
+            const float zv[8] = {zc[2 * s2].x, zc[2 * s2].y, zc[2 * s2].z, zc[2 * s2].w, zc[2 * s2 + 1].x, zc[2 * s2 + 1].y, zc[2 * s2 + 1].z, zc[2 * s2 + 1].w};
+            const int c0 = h * (K / 2) + s2 * 8;
+            const float4 d0 = *reinterpret_cast<const float4*>(sb + c0 * 4), d1 = *reinterpret_cast<const float4*>(sb + c0 * 4 + 16);
+            const uint2 a2 = *reinterpret_cast<const uint2*>(sb + 512 + c0);
+            const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            uint32_t oh[4], ol[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const float4 c2 = *reinterpret_cast<const float4*>(&cst[c0 + 2 * d]);       // (a1, a0) of channels 2d, 2d + 1
+                const uint32_t ab = ((d < 2 ? a2.x : a2.y) >> (16 * (d & 1))) & 0xffffu;
+                const float v0 = fmaf(zv[2 * d], c2.x, c2.y) + ((ab & 0xffu) == t ? dv[2 * d] : 0.0f);
+                const float v1 = fmaf(zv[2 * d + 1], c2.z, c2.w) + ((ab >> 8) == t ? dv[2 * d + 1] : 0.0f);
+                const uint32_t hp = pack_bf16(v0, v1);
+                oh[d] = hp;
+                ol[d] = pack_bf16(v0 - __uint_as_float(hp << 16), v1 - __uint_as_float(hp & 0xffff0000u));
+            }
+            const bf16x8 avh = __builtin_bit_cast(bf16x8, make_uint4(oh[0], oh[1], oh[2], oh[3]));
+            const bf16x8 avl = __builtin_bit_cast(bf16x8, make_uint4(ol[0], ol[1], ol[2], ol[3]));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int off = (j * 32 + col) * LDW + c0;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(whi + off);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wlo + off);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, avh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, avl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, avh, acc[j], 0, 0, 0);
+            }
+        }
+        store_side(buf ^ 1);                        // the next tile's side data (this wave's own buffer: no barrier)
+        // rows of the tile through the wave's LDS tile: lane (row col, h) holds columns 32 j + 8 g + 4 h .. + 3
+        const long long r0w = tile * 32 + (lane >> 3);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(stw + g * 8) = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const long long rw = r0w + p * 8;
+                const float4 v = *reinterpret_cast<const float4*>(str + p * 8 * 36);
+                if (rw < E) *reinterpret_cast<float4*>(Cout + rw * N + j * 32 + (lane & 7) * 4) = v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) zc[u] = zn[u];
+    }
+}
+
 }  // namespace
 
-extern "C" int lpd_bn_sel_bwd_reduce(const float* dOut, long long ldo, const float* Xsel, long long ldsel, long long M, int C,
-                                     const float* scale, const float* shift, const float* mean, const float* invstd, int act, float slope,
-                                     uint16_t* dpre16, double* dbeta, double* dgamma, void* stream_)
+static int bn_sel_bwd_reduce_impl(const float* dOut, long long ldo, const float* Xsel, long long ldsel, long long M, int C, const float* scale,
+                                  const float* shift, const float* mean, const float* invstd, int act, float slope, uint16_t* dpre16,
+                                  float* dpre32, double* dbeta, double* dgamma, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    LPD_CHECK_ARG(dOut && Xsel && scale && shift && mean && invstd && dpre16 && dbeta && dgamma && M > 0, "lpd_bn_sel_bwd_reduce: null pointer");
+    LPD_CHECK_ARG(dOut && Xsel && scale && shift && mean && invstd && (dpre16 || dpre32) && dbeta && dgamma && M > 0, "lpd_bn_sel_bwd_reduce: null pointer");
     LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && ldo % 4 == 0 && ldsel % 4 == 0, "lpd_bn_sel_bwd_reduce: bad dims");
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_bn_sel_bwd_reduce: activation %d unsupported", act);
     const LpdStatWs ws = lpd_stat_ws(stream);
     LPD_CHECK_ARG(ws.rep, "lpd_bn_sel_bwd_reduce: no memory for the statistics scratch");
     const int rg = 256 / (C / 4);
     hipLaunchKernelGGL(bn_sel_bwd_reduce_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, dOut, ldo, Xsel, ldsel, M, C, scale,
-                       shift, mean, invstd, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), dpre16, ws.sum(), ws.sumsq());
+                       shift, mean, invstd, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), dpre16, dpre32, ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_bn_sel_bwd_reduce");
     return lpd_stat_finish(ws, dbeta, dgamma, C, stream);
+}
+
+extern "C" int lpd_bn_sel_bwd_reduce(const float* dOut, long long ldo, const float* Xsel, long long ldsel, long long M, int C,
+                                     const float* scale, const float* shift, const float* mean, const float* invstd, int act, float slope,
+                                     uint16_t* dpre16, double* dbeta, double* dgamma, void* stream)
+{
+    return bn_sel_bwd_reduce_impl(dOut, ldo, Xsel, ldsel, M, C, scale, shift, mean, invstd, act, slope, dpre16, nullptr, dbeta, dgamma, stream);
+}
+
+extern "C" int lpd_bn_sel_bwd_reduce_f32(const float* dOut, long long ldo, const float* Xsel, long long ldsel, long long M, int C,
+                                         const float* scale, const float* shift, const float* mean, const float* invstd, int act, float slope,
+                                         float* dpre, double* dbeta, double* dgamma, void* stream)
+{
+    return bn_sel_bwd_reduce_impl(dOut, ldo, Xsel, ldsel, M, C, scale, shift, mean, invstd, act, slope, nullptr, dpre, dbeta, dgamma, stream);
 }
 
 static long long edge_dw_sel_blocks(long long E)
@@ -465,5 +777,54 @@ extern "C" int lpd_gemm_bf16s_bnbwd(const uint16_t* Z, const uint8_t* arg, const
     hipLaunchKernelGGL(gemm_bf16s_bnbwd_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, Z, arg, dpre16, k, W2, ldw, scale, mean, invstd,
                        dbeta, dgamma, (double)M * (double)k, dY, E, M);
     LPD_CHECK_LAUNCH("lpd_gemm_bf16s_bnbwd");
+    return LPD_OK;
+}
+
+// fp32 storage: the same two steps on fp32 tensors (split-bf16 products).  (M * k) % 64 == 0, 16 <= k <= 255.
+extern "C" int lpd_edge_dw_sel_f32(const float* Y, const uint8_t* arg, const float* dpre, int k, long long M, const float* W2, long long ldw,
+                                   const float* scale, const float* mean, const float* invstd, const double* dbeta, const double* dgamma,
+                                   float* dW2, void* ws, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(Y && arg && dpre && W2 && scale && mean && invstd && dbeta && dgamma && dW2 && ws && M > 0, "lpd_edge_dw_sel_f32: null pointer");
+    LPD_CHECK_ARG(k >= 8 && k <= 255 && ldw >= 128, "lpd_edge_dw_sel_f32: 8 <= k <= 255 and ldw >= 128 required");
+    LPD_CHECK_ARG((M * k) % 64 == 0, "lpd_edge_dw_sel_f32: M * k must be a multiple of 64 (got %lld)", M * k);
+    LPD_CHECK_ARG((((uintptr_t)Y | (uintptr_t)dpre | (uintptr_t)arg | (uintptr_t)ws) & 15) == 0, "lpd_edge_dw_sel_f32: pointers must be 16-byte aligned");
+    const long long E = M * k;
+    const long long blocks = edge_dw_sel_blocks(E);
+    long long rpb = (E + blocks - 1) / blocks;
+    rpb = (rpb + 63) / 64 * 64;
+    constexpr int n = 256 * 128 + 128;
+    constexpr int lds = 4 * 128 * 272;
+    double* red = reinterpret_cast<double*>(ws);
+    float* slabs = reinterpret_cast<float*>(red + n);
+    (void)hipFuncSetAttribute((const void*)edge_dw_sel_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(edge_dw_sel_f32_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, Y, arg, dpre, k, E, M, rpb, slabs);
+    LPD_CHECK_LAUNCH("lpd_edge_dw_sel_f32");
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)slabs, red, n, (int)blocks);
+    LPD_CHECK_LAUNCH("lpd_edge_dw_sel_f32(reduce)");
+    hipLaunchKernelGGL(dw2_finish_kernel, dim3(128), dim3(128), 0, stream, (const double*)red, W2, ldw, scale, mean, invstd, dbeta, dgamma,
+                       (double)M * (double)k, dW2);
+    LPD_CHECK_LAUNCH("lpd_edge_dw_sel_f32(finish)");
+    return LPD_OK;
+}
+
+extern "C" int lpd_gemm_f32s_bnbwd(const float* Z, const uint8_t* arg, const float* dpre, int k, long long M, const float* W2, int ldw,
+                                   const float* scale, const float* mean, const float* invstd, const double* dbeta, const double* dgamma,
+                                   float* dY, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(Z && arg && dpre && W2 && scale && mean && invstd && dbeta && dgamma && dY && M > 0, "lpd_gemm_f32s_bnbwd: null pointer");
+    LPD_CHECK_ARG(k >= 16 && k <= 255 && ldw >= 128, "lpd_gemm_f32s_bnbwd: 16 <= k <= 255 and ldw >= 128 required");
+    LPD_CHECK_ARG((((uintptr_t)Z | (uintptr_t)dpre | (uintptr_t)arg | (uintptr_t)dY) & 15) == 0, "lpd_gemm_f32s_bnbwd: pointers must be 16-byte aligned");
+    const long long E = M * k;
+    constexpr int lds = 2 * 128 * (128 + 8) * 2 + 128 * 8 + 8 * (2 * 3 * 640 + 32 * 36 * 4);
+    (void)hipFuncSetAttribute((const void*)gemm_f32s_bnbwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const long long tiles = (E + 31) / 32;
+    long long blocks = (tiles + 7) / 8;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(gemm_f32s_bnbwd_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, Z, arg, dpre, k, W2, ldw, scale, mean, invstd,
+                       dbeta, dgamma, (double)M * (double)k, dY, E, M);
+    LPD_CHECK_LAUNCH("lpd_gemm_f32s_bnbwd");
     return LPD_OK;
 }

@@ -122,6 +122,9 @@ SIGNATURES = {
     "lpd_bn_sel_bwd_reduce": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_dw_sel_bf16": [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_gemm_bf16s_bnbwd": [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
+    "lpd_bn_sel_bwd_reduce_f32": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p],
+    "lpd_edge_dw_sel_f32": [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
+    "lpd_gemm_f32s_bnbwd": [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_gather_sum_rows_bf16": [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_bf16s": [_c_p, _c_p, _c_int, _c_int, _c_p, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_tn_bf16_ws_floats": [_c_ll, _c_int, _c_int],

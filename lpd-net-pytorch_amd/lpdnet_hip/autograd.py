@@ -483,10 +483,20 @@ class _LPDNetTrainFn(torch.autograd.Function):
             ops.gather_sum_rows_bf16(du1, ops.GraphT(S["idx_f"], N), dpq1[:, :128])
         else:
             # DG2: x2 = groupmax(act(BN(Z))), Z = Y1e W2^T
-            dz, dgs2, dbs2 = ops.edge_bn_bwd(dcat[:, 128:256], S["arg2"], k, S["z"], S["stg2"], act, slope, xsel=S["zsel"])
-            dw2 = _dweight(dz, S["y1e"])
-            dy1e = ops.gemm(dz, w2d(net.convDG2[0]), b_kmajor=True)             # [E,128]
-            del dz
+            w2 = w2d(net.convDG2[0])
+            if (ops.dg2_bwd_fused_applies(M, k, w2.shape[0]) and w2.shape[1] == 128 and ops.GEMM_BF16X3 and ops._EXACT.depth == 0
+                    and S["z"].is_contiguous() and S["y1e"].is_contiguous()):
+                # no dZ tensor (as in the bf16 mode, on fp32 tensors with split-bf16 products)
+                dpre2, red2 = ops.bn_sel_bwd_reduce(dcat[:, 128:256], S["zsel"], S["stg2"], act, slope, dtype=torch.float32)
+                dw2 = ops.edge_dw_sel_f32(S["y1e"], S["arg2"], dpre2, k, w2, S["stg2"], red2)
+                dy1e = ops.gemm_f32s_bnbwd(S["z"], S["arg2"], dpre2, k, w2, S["stg2"], red2)
+                redf = red2.float()
+                dgs2, dbs2 = redf[1], redf[0]
+            else:
+                dz, dgs2, dbs2 = ops.edge_bn_bwd(dcat[:, 128:256], S["arg2"], k, S["z"], S["stg2"], act, slope, xsel=S["zsel"])
+                dw2 = _dweight(dz, S["y1e"])
+                dy1e = ops.gemm(dz, w2, b_kmajor=True)                          # [E,128]
+                del dz
             # DG1: y1e = act(BN(U1)); consumers: DG2 (dense) and x1 = groupmax (sparse)
             du1, dgs1, dbs1 = ops.edge_bn_bwd(dcat[:, 0:128], S["arg1"], k, S["u1"], S["stg1"], act, slope, dense=dy1e,
                                               dQ=dpq1[:, 128:])

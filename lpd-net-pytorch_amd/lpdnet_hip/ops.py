@@ -1292,18 +1292,46 @@ def dg2_bwd_fused_applies(M, k, C):
     return DG2_BWD_FUSED and C == 128 and 16 <= k <= 255 and (M * k) % 128 == 0
 
 
-def bn_sel_bwd_reduce(dOut, xsel, st, act, slope):
-    """Arg-max-only BatchNorm backward, reduction part: -> (dpre16 [M, C] bf16 = dOut * act'(pre), red fp64 [2, C] = (sum dpre,
-    sum dpre xhat)); xsel: the raw selected values of the forward."""
+def bn_sel_bwd_reduce(dOut, xsel, st, act, slope, dtype=torch.bfloat16):
+    """Arg-max-only BatchNorm backward, reduction part: -> (dpre [M, C] (bf16, or fp32 for the fp32 storage mode) = dOut * act'(pre),
+    red fp64 [2, C] = (sum dpre, sum dpre xhat)); xsel: the raw selected values of the forward."""
     ldo = _rows(dOut, "dOut")
     _req(xsel, "xsel")
     M, C = xsel.shape
-    dpre16 = torch.empty((M, C), dtype=torch.bfloat16, device=xsel.device)
+    dpre = torch.empty((M, C), dtype=dtype, device=xsel.device)
     red = torch.empty((2, C), dtype=torch.float64, device=xsel.device)
     lib = _lib.load()
-    _call(f"bn_sel_bwd_reduce[C={C}]", lib.lpd_bn_sel_bwd_reduce, _ptr(dOut), ldo, _ptr(xsel), _rows(xsel, "xsel"), M, C, _ptr(st.scale),
-          _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(dpre16), _ptr(red[0]), _ptr(red[1]), _stream())
-    return dpre16, red
+    _call(f"bn_sel_bwd_reduce[C={C}]", lib.lpd_bn_sel_bwd_reduce if dtype == torch.bfloat16 else lib.lpd_bn_sel_bwd_reduce_f32, _ptr(dOut),
+          ldo, _ptr(xsel), _rows(xsel, "xsel"), M, C, _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope),
+          _ptr(dpre), _ptr(red[0]), _ptr(red[1]), _stream())
+    return dpre, red
+
+
+def edge_dw_sel_f32(Y, arg, dpre, k, W2, st, red):
+    """edge_dw_sel_bf16 for the fp32 storage mode: Y [M*k, 128] fp32, dpre [M, 128] fp32 (split-bf16 products)."""
+    _req(Y, "Y"), _req(dpre, "dpre"), _req(W2, "W2")
+    if Y.shape[1] != 128 or not Y.is_contiguous() or not dpre.is_contiguous():
+        raise ValueError("edge_dw_sel_f32: contiguous [*, 128] tensors expected")
+    M = arg.shape[0]
+    lib = _lib.load()
+    ws = torch.empty((int(lib.lpd_edge_dw_sel_bf16_ws_bytes(M * k)),), dtype=torch.uint8, device=Y.device)
+    dW2 = torch.empty((128, 128), dtype=torch.float32, device=Y.device)
+    _call(f"edge_dw_sel_f32[{M * k}]", lib.lpd_edge_dw_sel_f32, _ptr(Y), _ptr(arg), _ptr(dpre), k, M, _ptr(W2), W2.stride(0), _ptr(st.scale),
+          _ptr(st.mean), _ptr(st.invstd), _ptr(red[0]), _ptr(red[1]), _ptr(dW2), _ptr(ws), _stream())
+    return dW2
+
+
+def gemm_f32s_bnbwd(Z, arg, dpre, k, W2, st, red):
+    """gemm_bf16s_bnbwd for the fp32 storage mode: dY [M*k, 128] fp32 = dZ W2, dZ generated from fp32 Z in the operand loader."""
+    _req(Z, "Z"), _req(dpre, "dpre"), _req(W2, "W2")
+    if Z.shape[1] != 128 or not Z.is_contiguous() or not dpre.is_contiguous():
+        raise ValueError("gemm_f32s_bnbwd: contiguous [*, 128] tensors expected")
+    M = arg.shape[0]
+    dY = torch.empty((M * k, 128), dtype=torch.float32, device=Z.device)
+    lib = _lib.load()
+    _call(f"gemm_f32s_bnbwd[{M * k}x128x128]", lib.lpd_gemm_f32s_bnbwd, _ptr(Z), _ptr(arg), _ptr(dpre), k, M, _ptr(W2), W2.stride(0),
+          _ptr(st.scale), _ptr(st.mean), _ptr(st.invstd), _ptr(red[0]), _ptr(red[1]), _ptr(dY), _stream())
+    return dY
 
 
 def edge_dw_sel_bf16(Y, arg, dpre16, k, W2, st, red):

@@ -1093,3 +1093,37 @@ def test_gemm_epilogue_batchnorm_statistics(cuda, M, N, K):
     ref = X.double() @ W.data.double().t()
     assert _rel(st.mean, ref.mean(0)) < 1e-5 and _rel(st.invstd, 1.0 / torch.sqrt(ref.var(0, unbiased=False) + 1e-5)) < 1e-5
     assert int(bn1.num_batches_tracked) == 1
+
+
+def test_dg2_backward_without_dz_fp32_storage(cuda):
+    """fp32 storage: dW2 from one pass over Y1e (arg-max product + Gram matrix + column sums, split-bf16 products) and dY1e = dZ W2 with dZ
+    generated in the operand loader (csrc/lpd_train3.hip (2f), (3f)) against fp64 and against the materialised dZ path."""
+    ops = _ops()
+    C, N, k, B = 128, 320, 20, 2
+    M = B * N
+    g = torch.Generator().manual_seed(11)
+    Y = torch.relu(torch.randn(M * k, C, generator=g)).to(cuda) + 0.05
+    W = (torch.randn(C, C, generator=g) / C ** 0.5).to(cuda)
+    Z = (Y.double() @ W.double().t()).float().contiguous()
+    act, slope = ops.ACT_LEAKY, 0.01
+    bn = _bn_for(C, 6).to(cuda).train()
+    st = ops.bn_train_stats(Z, bn)
+    out = torch.empty(M, C, device=cuda)
+    arg, sel = ops.group_max(Z, k, st.scale, st.shift, act, slope, out, keep_sel=True)
+    dOut = torch.randn(M, C, generator=g).to(cuda)
+    assert ops.dg2_bwd_fused_applies(M, k, C)
+    dpre, red = ops.bn_sel_bwd_reduce(dOut, sel, st, act, slope, dtype=torch.float32)
+    dZ_old, dg_old, db_old = ops.edge_bn_bwd(dOut, arg, k, Z, st, act, slope, xsel=sel)
+    assert torch.equal(red[0].float(), db_old) and torch.equal(red[1].float(), dg_old)
+    pre = st.scale.double() * sel.double() + st.shift.double()
+    dpre64 = dOut.double() * torch.where(pre > 0, 1.0, slope)
+    assert _rel(dpre, dpre64) < 1e-6
+    D = torch.zeros(M, k, C, dtype=torch.float64, device=cuda)
+    D.scatter_(1, arg.long().view(M, 1, C), dpre64.view(M, 1, C))
+    m1, m2 = red[0] / (M * k), red[1] / (M * k)
+    dZ = st.scale.double() * (D.view(M * k, C) - m1 - (Z.double() - st.mean.double()) * st.invstd.double() * m2)
+    assert _rel(dZ_old, dZ) < 1e-5
+    dW_new = ops.edge_dw_sel_f32(Y, arg, dpre, k, W, st, red)
+    assert _rel(dW_new, dZ.t() @ Y.double()) < 3e-5, _rel(dW_new, dZ.t() @ Y.double())
+    dY_new = ops.gemm_f32s_bnbwd(Z, arg, dpre, k, W, st, red)
+    assert _rel(dY_new, dZ @ W.double()) < 2e-5, _rel(dY_new, dZ @ W.double())
