@@ -1127,3 +1127,30 @@ def test_dg2_backward_without_dz_fp32_storage(cuda):
     assert _rel(dW_new, dZ.t() @ Y.double()) < 3e-5, _rel(dW_new, dZ.t() @ Y.double())
     dY_new = ops.gemm_f32s_bnbwd(Z, arg, dpre, k, W, st, red)
     assert _rel(dY_new, dZ @ W.double()) < 2e-5, _rel(dY_new, dZ @ W.double())
+
+
+@pytest.mark.parametrize("M,N,K,bk,nb", [(16384, 256, 64, False, 1), (32768, 96, 128, True, 1), (4096, 1024, 128, False, 5), (2048, 64, 64, False, 9)])
+def test_gemm_x3t_rows_short_reductions(cuda, M, N, K, bk, nb):
+    """lpd_gemm_x3t_rows (transposed MFMA on row-major operands, result tiles through a wave-private LDS tile, per-problem weight fragments
+    when batched): ops.gemm routes K in {64, 128} products over >= 16384 rows to it -- against fp64 and against the block kernel, with bias,
+    BatchNorm affine, LeakyReLU and a strided A."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    shape_a = (nb, M, K + 8) if nb > 1 else (M, K + 8)
+    A = torch.randn(shape_a, generator=g).to(cuda)[..., 4:4 + K]
+    Wt = (torch.randn(((nb,) if nb > 1 else ()) + ((K, N) if bk else (N, K)), generator=g) / K ** 0.5).to(cuda)
+    bias, scale, shift = torch.randn(N, generator=g).to(cuda), (torch.rand(N, generator=g) + 0.5).to(cuda), torch.randn(N, generator=g).to(cuda)
+    kw = dict(a_kmajor=False, b_kmajor=bk) if nb > 1 else dict(b_kmajor=bk, bias=bias, scale=scale, shift=shift, act=ops.ACT_LEAKY, slope=0.2)
+    assert ops.X3T_ROWS
+    got = ops.gemm(A.contiguous() if nb > 1 else A, Wt, **kw)
+    Wd = Wt.double() if bk else Wt.double().transpose(-1, -2)
+    ref = A.double() @ Wd
+    if nb == 1:
+        ref = torch.nn.functional.leaky_relu((ref + bias.double()) * scale.double() + shift.double(), 0.2)
+    assert _rel(got, ref) < 2e-5, _rel(got, ref)
+    ops.X3T_ROWS = False
+    try:
+        old = ops.gemm(A.contiguous() if nb > 1 else A, Wt, **kw)
+    finally:
+        ops.X3T_ROWS = True
+    assert _rel(got, old) < 2e-5
