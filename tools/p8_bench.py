@@ -53,7 +53,7 @@ for impl in (0, 5, 6):
         print("fused assignment: rows median/min us", timeit(lambda: ops.gemm_p8(S, W, shift=sh, act=ops.ACT_LEAKY, out=outr, assign_w=W2.data)))
     print("impl", impl, "p8 rows   median/min us", timeit(lambda: ops.gemm_p8(S, W, scale=sc, shift=sh, act=ops.ACT_LEAKY, out=outr)))
     print("impl", impl, "p8 panels median/min us", timeit(lambda: ops.gemm_p8(S, W, scale=sc, shift=sh, act=ops.ACT_LEAKY, out=outp, out_panels=True)))
-for impl, name in ((8, "no LDS-DMA in the loop"), (16, "no MFMAs (6 units ahead)"), (16 + 5, "no MFMAs (5 units ahead)"), (24, "neither (reads + barriers + stores)"), (32, "full, nt loads"), (64, "full, every phase's 12 MFMAs issued twice"), (96, "full, WITH s_setprio around the MFMAs")):
+for impl, name in ((8, "no LDS-DMA in the loop"), (16, "no MFMAs (6 units ahead)"), (16 + 5, "no MFMAs (5 units ahead)"), (24, "neither (reads + barriers + stores)"), (32, "full, nt loads"), (64, "full, every phase's 12 MFMAs issued twice"), (96, "full, WITH s_setprio around the MFMAs"), (128, "full, NO output stores")):
     ops.P8_IMPL = impl
     print("timing-only:", name, timeit(lambda: ops.gemm_p8(S, W, shift=sh, act=ops.ACT_LEAKY, out=outr)))
 ops.P8_IMPL = 0
