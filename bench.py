@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--no-train", action="store_true", help="skip the secondary quadruplet train-step measurement")
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--no-train-bf16", action="store_true", help="skip the bf16-storage train-step measurement (configs[2] as stated)")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="nccl = RCCL, one GPU per rank (the measurement).  gloo = DRY RUN of the multi-rank path on however many GPUs are "
+                         "visible (ranks share them: RCCL refuses two ranks on one device): launcher, exchange block and per-rank "
+                         "reporting execute, the line is marked dry_run and its timings mean nothing")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary eval records (configs[1] at 128 clouds/step, configs[4]: N=16384, k=64, 64 clouds/step)")
     return ap.parse_args()
@@ -77,7 +81,7 @@ def launch_ranks(args):
     import socket
     import subprocess
     n_vis = visible_gpus()
-    if n_vis and n_vis < args.gpus:      # 0 / None: the topology is hidden (container): the ranks report what they see
+    if n_vis and n_vis < args.gpus and args.dist_backend == "nccl":      # 0 / None: the topology is hidden (container): the ranks report what they see
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible on this node")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -119,7 +123,7 @@ def cpu_baseline(model, points, seconds_target=20.0):
     # ---- C restatement, one cloud per core ----
     native = orc.build_c_oracle_native(os.path.join(tempfile.gettempdir(), f"liblpd_oracle_native_{os.getpid()}.so"))
     lib = ctypes.CDLL(native)
-    nC = max(1, min(avail, 128))      # 128 clouds: one run takes ~7 s on the pool's 256-core hosts, so warm-up + 3 timed runs fit the budget
+    nC = max(1, min(avail, 256))      # one cloud per hardware thread of the host (the baseline stays the best CPU figure)
     xc = torch.rand((nC, 1, points, 3), generator=g) * 2 - 1
     dc, used = orc.forward_lpdnet_c(sd, xc, k=model.emb_nn.k, threads=nC, lib=lib)      # warm-up (page faults, weights into cache)
     times = []
@@ -128,6 +132,16 @@ def cpu_baseline(model, points, seconds_target=20.0):
         orc.forward_lpdnet_c(sd, xc, k=model.emb_nn.k, threads=nC, lib=lib)
         times.append(time.time() - t0)
     tc = sorted(times)[1]
+    # ... and one timed run on half as many threads (one per physical core of an SMT host): the better rate is the value
+    alt = None
+    if nC >= 64:
+        nH = nC // 2
+        t0 = time.time()
+        orc.forward_lpdnet_c(sd, xc[:nH], k=model.emb_nn.k, threads=nH, lib=lib)
+        th = time.time() - t0
+        alt = {"threads": nH, "clouds": nH, "value": round(nH / th, 3), "sample": "one timed run"}
+        if nH / th > nC / tc:
+            alt, nC, tc, used, times = {"threads": nC, "clouds": nC, "value": round(nC / tc, 3), "sample": "median of 3"}, nH, th, nH, [th]
     # ---- torch-CPU oracle (cross-check and the reference descriptors for the parity figure) ----
     Bs = 4
     x = xc[:Bs].clone()
@@ -155,6 +169,7 @@ def cpu_baseline(model, points, seconds_target=20.0):
                       f"gcc -O3 -march=native, OpenMP: one cloud per thread, {used} threads of {avail} host cores), median of {len(times)} after a warm-up run",
             "torch_cpu_cross_check": {"value": round(Bs / t, 3), "unit": "descriptors/s", "cores": threads,
                                       "sample": f"torch-CPU oracle (ATen), {Bs} clouds, median of 3 at the fastest of the tried thread counts"},
+            "other_thread_count": alt,
             "c_vs_torch_oracle_norm_rel": float(f"{agree:.3e}")}, x, ref, threads
 
 
@@ -230,13 +245,18 @@ def _time_steps(step, first, n, dist, dev):
     el = time.perf_counter() - t0
     _time_steps.last = {"gpu_ms": [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(n)], "host_enqueue_ms": host}
     if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        el = _dist_max(dist, dev, el)
     return el, out
 
 
-def train_bench(dev, dist, world, rank, points, steps, warmup=4, storage="f32"):
+def _dist_max(dist, dev, value):
+    """max over the ranks of a host scalar (gloo has no GPU all_gather / barrier: CPU tensors there)"""
+    t = torch.tensor([value], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def train_bench(dev, dist, world, rank, points, steps, warmup=4, storage="f32", tuple_shape=(2, 2, 18), label=None):
     """Secondary metric of BASELINE.json: quadruplet train-steps/s (configs[2]: bq=2, P=2, Ng=18 -> 44 clouds/rank,
     lazy quadruplet loss, Adam), data-parallel across ranks with the RCCL gradient all-reduce (configs[3]).
     Four untimed steps first: the leg starts from an emptied allocator cache (12 GiB of blocks to re-create), and with two
@@ -244,7 +264,7 @@ def train_bench(dev, dist, world, rank, points, steps, warmup=4, storage="f32"):
     from util.PointNetVlad import PointNetVlad
     import loss.pointnetvlad_loss as L
     from lpdnet_hip import autograd
-    bq, P, Ng = 2, 2, 18
+    bq, P, Ng = tuple_shape
     B = bq * (1 + P + Ng + 1)
     torch.manual_seed(1234)
     model = PointNetVlad(num_points=points, featnet="lpdnet", emb_dims=1024, output_dim=256).to(dev).train()
@@ -303,20 +323,19 @@ def train_bench(dev, dist, world, rank, points, steps, warmup=4, storage="f32"):
             e1.record()
             torch.cuda.synchronize()
             ar_ms = e0.elapsed_time(e1) / reps
-            t = torch.tensor([ar_ms], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ar_max = _dist_max(dist, dev, ar_ms)
             nbytes = 4 * (big.numel() + small.numel())
-            comm = {"allreduce_ms_per_step_isolated": round(float(t.item()), 3), "gradient_bytes": nbytes,
-                    "allreduce_busbw_GBps": round(2 * (world - 1) / world * nbytes / (float(t.item()) * 1e-3) / 1e9, 1),
+            comm = {"allreduce_ms_per_step_isolated": round(ar_max, 3), "gradient_bytes": nbytes,
+                    "allreduce_busbw_GBps": round(2 * (world - 1) / world * nbytes / (ar_max * 1e-3) / 1e9, 1),
                     "ms_per_step_without_exchange": round(1e3 * el0 / steps, 2),
                     "allreduce_exposed_ms_per_step": round(1e3 * (el - el0) / steps, 3),
-                    "backend": "nccl (RCCL)", "buckets": "hidden1_weights (67 MB) from its post-accumulate hook, overlapped "
+                    "backend": "nccl (RCCL)" if dist.get_backend() == "nccl" else dist.get_backend() + " (dry run: not a measurement)", "buckets": "hidden1_weights (67 MB) from its post-accumulate hook, overlapped "
                     "with the trunk's backward; the other 3.3 MB flattened into one bucket at the end of backward"}
     finally:
         autograd.set_train_storage(prev_storage)
     return {"metric": "quadruplet train-steps/sec", "value": round(steps / el, 3), "unit": "steps/s",
             "tuples_per_s": round(bq * world * steps / el, 3), "ms_per_step": round(1e3 * el / steps, 2), "steps": steps,
-            "config": f"BASELINE configs[{2 if world == 1 else 3}]: bq={bq} P={P} Ng={Ng} -> {B} clouds/rank, N={points}, lazy quadruplet, "
+            "config": (label or f"BASELINE configs[{2 if world == 1 else 3}]") + f": bq={bq} P={P} Ng={Ng} -> {B} clouds/rank, N={points}, lazy quadruplet, "
                       f"Adam, {storage} storage; x{world} ranks data-parallel (per-rank BN, gradient all-reduce)",
             "dtype": storage, "losses": losses, "peak_hbm_gib": round(peak, 2), "exchange": comm, "per_step": per_step}
 
@@ -392,6 +411,9 @@ def main():
     sys.stdout.flush()
     line_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+    dry_run = args.dist_backend != "nccl"
+    if dry_run:                               # ranks share the visible GPUs (one on a gpurun box)
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -400,7 +422,10 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dry_run:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from lpdnet_hip import engine, ops
     from util.PointNetVlad import PointNetVlad
@@ -499,10 +524,8 @@ def main():
     ops.PROFILE = None
     per_rank = [round(args.batch * args.steps / my_elapsed, 1)]
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        mine = torch.tensor([my_elapsed], device=dev, dtype=torch.float64)
+        elapsed = _dist_max(dist, dev, elapsed)
+        mine = torch.tensor([my_elapsed], device="cpu" if dry_run else dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [round(args.batch * args.steps / float(x.item()), 1) for x in allr]
@@ -527,13 +550,25 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "kagg_pmc.json")
         if os.path.exists(pmc):          # PMC passes are kept per workload: {"runs": [{batch, points, k, bench_key, hbm_bytes_per_launch}]}
             try:
+                import hashlib
+                h = hashlib.sha256()
+                for f_ in ("lpd_edge.hip", "lpd_edge_win.hip"):      # where the K-agg kernels live (tools/kagg_pmc.py stamps the same hash)
+                    h.update(open(os.path.join(ROOT, "lpd-net-pytorch_amd", "csrc", f_), "rb").read())
+                sha = h.hexdigest()
                 rec = json.load(open(pmc))
                 for r in rec.get("runs", [rec]):
-                    if traffic is None and (r.get("batch", 32), r.get("points", 4096), r.get("k", 20)) == (args.batch, args.points, args.k) \
+                    if (r.get("batch", 32), r.get("points", 4096), r.get("k", 20)) == (args.batch, args.points, args.k) \
                             and r.get("bench_key") == key:      # the newest matching record comes first
-                        traffic = r.get("hbm_bytes_per_launch")
-                        traffic_source = ("profiles/kagg_pmc.json (rocprofv3 --pmc passes of an EARLIER run of this command on the same "
-                                          "workload, FETCH_SIZE doubled per MI355X_MICROARCH.md; not measured in this run): " + str(r.get("source")))
+                        if r.get("kernel_source_sha256") == sha:
+                            traffic = r.get("hbm_bytes_per_launch")
+                            traffic_source = ("profiles/kagg_pmc.json: rocprofv3 --pmc passes (tools/kagg_pmc.py) over this command on this "
+                                              "workload with THIS kernel source (sha256 of csrc/lpd_edge*.hip matches); FETCH_SIZE doubled per "
+                                              "MI355X_MICROARCH.md; not collected inside this run: " + str(r.get("source")))
+                        else:
+                            traffic_source = ("none: the newest PMC record in profiles/kagg_pmc.json was taken with a different kernel source "
+                                              "(hash mismatch) -- re-run tools/kagg_pmc.py; its figure was "
+                                              + str(r.get("hbm_bytes_per_launch")) + " B per launch")
+                        break
             except Exception:
                 traffic = None
         roof = {"kernel": f"{kname}, SN1 stage, C=256, k={args.k}", "bound": "hbm", "achieved": round(ach, 1),
@@ -556,6 +591,12 @@ def main():
         # stress configuration configs[4] with its K-agg roofline, so that neither is builder-run only
         secondary = {"configs[1] at 128 clouds/step": secondary_eval(dev, 4096, 20, 128, 10),
                      "configs[4] stress (N=16384, k=64, 64 clouds/step)": secondary_eval(dev, 16384, 64, 64, 5)}
+        # the reference's OWN operating points (util/data.py:117-133 embeds one cloud at a time, util/initPara.py:32-43 gives an eval
+        # batch of 6 x (1 + 1 + 2) = 24 and a train batch of bq=2, P=1, Ng=2 -> 10 clouds): small batches, where launch counts and
+        # the 256-workgroup persistent kernels matter more than bandwidth
+        secondary["reference operating points (eval, N=4096, k=20)"] = {
+            f"{b} clouds/step": {kk: vv for kk, vv in secondary_eval(dev, 4096, 20, b, 30, warmup=5).items() if kk in ("value", "unit", "ms_per_step", "steps")}
+            for b in (1, 6, 10, 24)}
     train = None
     if not args.no_train:
         del out
@@ -566,11 +607,20 @@ def main():
         if not args.no_train_bf16 and "bf16" in _ag.TRAIN_STORAGES:
             torch.cuda.empty_cache()
             train_bf16 = train_bench(dev, dist, world, rank, args.points, args.train_steps, storage="bf16")
+        if world == 1 and not args.no_secondary and secondary is not None:
+            torch.cuda.empty_cache()       # the reference's default train batch (initPara.py:32-43): bq=2, P=1, Ng=2 -> 10 clouds
+            secondary["reference default train batch (bq=2, P=1, Ng=2 -> 10 clouds)"] = {
+                st: {kk: vv for kk, vv in train_bench(dev, None, 1, 0, args.points, args.train_steps, storage=st, tuple_shape=(2, 1, 2),
+                                                      label="reference defaults (util/initPara.py:32-43)").items()
+                     if kk in ("value", "unit", "ms_per_step", "steps", "config", "losses", "peak_hbm_gib")}
+                for st in ("f32", "bf16")}
 
     if rank == 0:
         line = {
             "metric": "global descriptors/sec (4096-pt clouds)", "value": round(value, 2), "unit": "descriptors/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            **({"dry_run": f"--dist-backend {args.dist_backend}: {world} ranks on {torch.cuda.device_count()} GPU(s); exercises the launcher, the "
+                           "exchange block and the per-rank reporting -- NOT a measurement"} if dry_run else {}),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (U[-1,1)^3 clouds resident in HBM, seed 1234+rank; random-init weights, randomised BN statistics)",
             "config": {"workload": ("BASELINE configs[1]" if (args.points, args.k) == (4096, 20) else "BASELINE configs[4] (stress)") +

@@ -10,7 +10,10 @@
  *
  * Conventions
  *   - plain C: device pointers, ints, floats; no torch types, no exceptions.
- *   - the caller owns every buffer (inputs, outputs, workspaces); nothing here allocates.
+ *   - the caller owns every buffer (inputs, outputs, workspaces); nothing here allocates.  Entry points that reduce over
+ *     workgroups (BatchNorm statistics and their backward sums) take `double* stat_ws`: lpd_stat_ws_bytes() bytes of device
+ *     memory, zero-filled ONCE by the caller; every call that returns LPD_OK leaves it all-zero again, so one workspace serves
+ *     all calls on one stream (two streams that run concurrently need two).  After an LPD_ERR_LAUNCH return re-zero it.
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = default
  *     stream); nothing synchronises.
  *   - return 0 on success, <0 on error (LPD_ERR_*); lpd_last_error() gives the text
@@ -41,6 +44,8 @@ extern "C" {
 
 int lpd_version(void);
 const char* lpd_last_error(void);
+/* size of the `stat_ws` workspace (see Conventions): 32 replicas x 2 x 1024 doubles = 512 KiB */
+long long lpd_stat_ws_bytes(void);
 
 /*
  * kNN graph construction.  Replaces util/lpdnet_model.py:317-326 `knn(x, k)`.
@@ -141,7 +146,7 @@ int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, 
  * [N] fp64 (zeroed by the call) = column sums / sums of squares of C over the M rows (fp32 over a block's 128 rows, fp64 atomics),
  * i.e. lpd_colstats without the second pass over C. */
 int lpd_gemm_x3w_stats(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
-                       double* stat_sum, double* stat_sumsq, int impl, void* stream);
+                       double* stat_sum, double* stat_sumsq, int impl, double* stat_ws, void* stream);
 
 /*
  * The same product for a SHORT reduction with cloud-panel A and C (the neighbour / centre projection of the split SN1 edge
@@ -337,7 +342,7 @@ int lpd_morton_sort(const float* xyz, float* out, int32_t* perm, int B, int N, v
 
 /* Column sums and sums of squares over R rows of X [R][ld] (BatchNorm batch statistics,
  * nn.BatchNorm1d/2d in train mode).  C and ld multiples of 4. */
-int lpd_colstats(const float* X, long long ld, long long R, int C, double* sum, double* sumsq, void* stream);
+int lpd_colstats(const float* X, long long ld, long long R, int C, double* sum, double* sumsq, double* stat_ws, void* stream);
 
 /* From the sums: mean, biased variance -> scale = gamma/sqrt(var+eps), shift = beta - mean*scale, mean, invstd;
  * updates running_mean / running_var in place (momentum, unbiased variance) when given. */
@@ -354,14 +359,14 @@ int lpd_affine_act(const float* X, long long ldx, float* Y, long long ldy, long 
  * X is the raw pre-BatchNorm tensor.  In-place (dX == dY) allowed. */
 int lpd_bn_act_bwd(const float* dY, long long lddy, const float* X, long long ldx, float* dX, long long lddx, long long R,
                    int C, const float* scale, const float* shift, const float* mean, const float* invstd, int act,
-                   float slope, int has_bn, double* dbeta, double* dgamma, void* stream);
+                   float slope, int has_bn, double* dbeta, double* dgamma, double* stat_ws, void* stream);
 
 /* Materialised edge tensor (training only): U[(i,t)] = P[nbr(i,t)] + Q[i], rows i*k+t, [M*k][C]
  * (the split form of util/lpdnet_model.py:350-357 + the 1x1 conv).  C in {64,128,256}.
  * sum / sumsq ([C] doubles, both or neither): the BatchNorm statistics of U, accumulated while the rows are written
  * (what lpd_colstats would compute in a second pass over U). */
 int lpd_edge_build(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, float* U, long long M,
-                   int N, int C, int k, double* sum, double* sumsq, void* stream);
+                   int N, int C, int k, double* sum, double* sumsq, double* stat_ws, void* stream);
 
 /* out[i][c] = act(scale[c] * sel_t X[(i,t)][c] + shift[c]) over k consecutive rows (x.max(dim=-1) after
  * BatchNorm + activation, lpdnet_model.py:250,252,258); arg[i][c] = selected t (uint8). */
@@ -383,12 +388,12 @@ int lpd_group_max_bwd(const float* dOut, long long ldo, const uint8_t* arg, int 
 int lpd_edge_bn_bwd(const float* dOut, long long ldo, const uint8_t* arg, const float* dDense, const float* X, float* dX,
                     float* dQ, long long ldq, int k, long long M, int C, const float* scale, const float* shift,
                     const float* mean, const float* invstd, int act, float slope, double* dbeta, double* dgamma,
-                    void* stream);
+                    double* stat_ws, void* stream);
 /* The arg-max-only form (no dense gradient, no dQ) with the raw selected values Xsel [M][ldsel] the forward kept
  * (lpd_group_max_sel): the dbeta / dgamma reduction is an [M][C] pass instead of a gather from the edge tensor. */
 int lpd_edge_bn_bwd_sel(const float* dOut, long long ldo, const uint8_t* arg, const float* X, const float* Xsel, long long ldsel,
                         float* dX, int k, long long M, int C, const float* scale, const float* shift, const float* mean,
-                        const float* invstd, int act, float slope, double* dbeta, double* dgamma, void* stream);
+                        const float* invstd, int act, float slope, double* dbeta, double* dgamma, double* stat_ws, void* stream);
 
 /* dQ[i] = sum_t dU[(i,t)]  (gradient of the centre term). */
 int lpd_group_sum(const float* dU, int k, float* dQ, long long ldq, long long M, int C, void* stream);
@@ -443,13 +448,13 @@ int lpd_vlad_finalize_bwd(const float* dOut, const float* v, const float* inv_c,
  */
 int lpd_edge_split_fwd(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, const float* gamma,
                        float* S, float* usel, uint8_t* arg, long long M, int N, int C, int k, double* sum, double* sumsq,
-                       void* stream);
+                       double* stat_ws, void* stream);
 /* The same on cloud-resident slices (the organisation of lpd_edge_gather_max16: a block holds an 8-channel slice of a whole cloud in
  * LDS and gathers the k neighbour pieces from there): idx16 from lpd_pack_idx16; k = 20, N <= 4096, C % 8 == 0.  S, usel, arg are
  * bit-identical to lpd_edge_split_fwd, the statistics equal up to the order of the fp64 additions. */
 int lpd_edge_split_fwd16_applies(int N, int C, int k);
 int lpd_edge_split_fwd16(const float* P, long long ldp, const float* Q, long long ldq, const uint16_t* idx16, const float* gamma, float* S,
-                         float* usel, uint8_t* arg, long long M, int N, int C, int k, double* sum, double* sumsq, void* stream);
+                         float* usel, uint8_t* arg, long long M, int N, int C, int k, double* sum, double* sumsq, double* stat_ws, void* stream);
 
 /*
  * Backward of the split-form stage: dOut [M][ldo] = gradient of x3.  G [M][C] (scratch, receives dpre = dOut * act'),
@@ -462,7 +467,7 @@ int lpd_edge_split_bwd(const float* dOut, long long ldo, const float* usel, cons
                        long long ldp, const float* Q, long long ldq, const int32_t* rowptr, const int32_t* edges, float* G,
                        float* dP, long long lddp, float* dQ, long long lddq, long long M, int C, int k, const float* scale,
                        const float* shift, const float* mean, const float* invstd, int act, float slope, double* dbeta,
-                       double* dgamma, void* stream);
+                       double* dgamma, double* stat_ws, void* stream);
 
 /*
  * bf16 STORAGE of the per-edge tensors that must exist (BASELINE.json configs[2]: the DG1 -> DG2 chain, where convDG2
@@ -471,7 +476,7 @@ int lpd_edge_split_bwd(const float* dOut, long long ldo, const float* usel, cons
  */
 /* lpd_edge_build with a bf16 result; the statistics are those of the stored (rounded) values */
 int lpd_edge_build_bf16(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, uint16_t* U, long long M,
-                        int N, int C, int k, double* sum, double* sumsq, void* stream);
+                        int N, int C, int k, double* sum, double* sumsq, double* stat_ws, void* stream);
 /* one pass over U: Y = act(scale U + shift) (bf16, the dense consumer's input) and out[i] = act(scale sel_t U + shift), arg[i] */
 /* fp32 storage form of the same pass: Y [M*k][C] = act(scale * U + shift), out [M][ldo] = max over the k rows of a point, arg the slot */
 int lpd_edge_act_max(const float* U, int k, const float* scale, const float* shift, int act, float slope, float* Y, float* out,
@@ -481,21 +486,21 @@ int lpd_edge_act_max_bf16(const uint16_t* U, int k, const float* scale, const fl
 /* one pass over the raw conv output Z: batch statistics (sum, sumsq) and the raw selected value sel[i] = sel_t Z[(i,t)] with its
  * slot (max where gamma >= 0, else min); BatchNorm + activation of sel is an [M][C] lpd_affine_act afterwards */
 int lpd_group_sel_stats_bf16(const uint16_t* Z, int k, const float* gamma, float* sel, long long lds, uint8_t* arg, long long M, int C,
-                             double* sum, double* sumsq, void* stream);
+                             double* sum, double* sumsq, double* stat_ws, void* stream);
 /* lpd_edge_bn_bwd on bf16 tensors (dDense optional; dX may alias dDense) */
 int lpd_edge_bn_bwd_bf16(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* dDense, const uint16_t* X, uint16_t* dX,
                          float* dQ, long long ldq, int k, long long M, int C, const float* scale, const float* shift,
-                         const float* mean, const float* invstd, int act, float slope, double* dbeta, double* dgamma, void* stream);
+                         const float* mean, const float* invstd, int act, float slope, double* dbeta, double* dgamma, double* stat_ws, void* stream);
 /* arg-max-only form with the raw selected values of lpd_group_sel_stats_bf16 (cf. lpd_edge_bn_bwd_sel) */
 int lpd_edge_bn_bwd_bf16_sel(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* X, const float* Xsel, long long ldsel,
                              uint16_t* dX, int k, long long M, int C, const float* scale, const float* shift, const float* mean,
-                             const float* invstd, int act, float slope, double* dbeta, double* dgamma, void* stream);
+                             const float* invstd, int act, float slope, double* dbeta, double* dgamma, double* stat_ws, void* stream);
 /* Backward of x2 = max_k act(BN_train(Z)), Z = Y1e W2^T (lpdnet_model.py:251-252) on bf16 edge tensors WITHOUT the [M*k][128] gradient
  * dZ (csrc/lpd_train3.hip).  (1) dpre16 [M][C] = bf16(dOut * act'(scale Xsel + shift)) and the fp64 sums dbeta = sum dpre,
  * dgamma = sum dpre xhat, from the raw selected values Xsel [M][ldsel] of lpd_group_sel_stats_bf16. */
 int lpd_bn_sel_bwd_reduce(const float* dOut, long long ldo, const float* Xsel, long long ldsel, long long M, int C, const float* scale,
                           const float* shift, const float* mean, const float* invstd, int act, float slope, uint16_t* dpre16,
-                          double* dbeta, double* dgamma, void* stream);
+                          double* dbeta, double* dgamma, double* stat_ws, void* stream);
 /* (2) dW2 [128][128] = dZ^T Y1e from ONE pass over Y1e [M*k][128] bf16: S = D^T Y1e (D: dpre16 at the arg-max slots), the Gram matrix
  * Y1e^T Y1e and the column sums, then dW2[c] = s_c (S[c] - m1_c s - m2_c invstd_c (W2[c] G - mu_c s)) in fp64.  W2 [128][ldw]: the
  * convolution weight; dbeta / dgamma: the sums of (1); ws: lpd_edge_dw_sel_bf16_ws_bytes(M * k) bytes, 16-byte aligned.
@@ -513,7 +518,7 @@ int lpd_gemm_bf16s_bnbwd(const uint16_t* Z, const uint8_t* arg, const uint16_t* 
  * workspace of lpd_edge_dw_sel_f32 is lpd_edge_dw_sel_bf16_ws_bytes(M * k) bytes. */
 int lpd_bn_sel_bwd_reduce_f32(const float* dOut, long long ldo, const float* Xsel, long long ldsel, long long M, int C, const float* scale,
                               const float* shift, const float* mean, const float* invstd, int act, float slope, float* dpre, double* dbeta,
-                              double* dgamma, void* stream);
+                              double* dgamma, double* stat_ws, void* stream);
 int lpd_edge_dw_sel_f32(const float* Y, const uint8_t* arg, const float* dpre, int k, long long M, const float* W2, long long ldw,
                         const float* scale, const float* mean, const float* invstd, const double* dbeta, const double* dgamma, float* dW2,
                         void* ws, void* stream);

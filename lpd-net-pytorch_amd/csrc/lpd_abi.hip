@@ -15,32 +15,8 @@ void lpd_set_error(const char* fmt, ...)
 extern "C" const char* lpd_last_error(void) { return g_lpd_err; }
 extern "C" int lpd_version(void) { return 100; }  // 0.1.0
 
-// ---- scratch of the cross-block column statistics (lpd_common.h): one per (device, stream), never freed ----
-#include <map>
-#include <mutex>
-#include <utility>
-
-LpdStatWs lpd_stat_ws(hipStream_t stream)
-{
-    static std::mutex mu;
-    static std::map<std::pair<int, void*>, LpdStatWs> table;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(mu);
-    const auto key = std::make_pair(dev, (void*)stream);
-    auto it = table.find(key);
-    if (it != table.end()) return it->second;
-    LpdStatWs ws = {nullptr};
-    const size_t bytes = sizeof(double) * LPD_STAT_REPLICAS * 2 * LPD_STAT_CMAX;
-    void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {   // hipMemset: synchronous, once per stream
-        (void)hipGetLastError();
-        return ws;
-    }
-    ws.rep = reinterpret_cast<double*>(p);
-    table[key] = ws;
-    return ws;
-}
+// ---- workspace of the cross-block column statistics (lpd_common.h): owned by the caller ----
+extern "C" long long lpd_stat_ws_bytes(void) { return (long long)sizeof(double) * LPD_STAT_REPLICAS * 2 * LPD_STAT_CMAX; }
 
 namespace {
 __global__ void stat_gather_kernel(double* __restrict__ rep, double* __restrict__ o0, double* __restrict__ o1, int ncols)

@@ -63,8 +63,9 @@ __device__ __forceinline__ float lpd_act_any(float v, int act, float slope)
 // The blocks therefore add into one of 32 REPLICAS (blockIdx % 32: thirty-two times the lines, 1/32 of the queue on each), and a
 // small second launch (lpd_stat_finish) sums the replicas into the caller's 2 x C doubles and clears them.  (A ticket instead
 // of the second launch -- the block that draws the last one sums the replicas -- costs more than it saves: 4096 returning
-// atomics on ONE address behind a __threadfence took 620 us.)  The replicas live in a per-(device, stream) scratch buffer the
-// library allocates on first use: launches on one stream are ordered, so they share it.
+// atomics on ONE address behind a __threadfence took 620 us.)  The replicas live in a CALLER-OWNED workspace (the `stat_ws` argument of every entry point
+// that reduces over blocks: lpd_stat_ws_bytes() bytes, zero-filled once by the caller, left all-zero by every call that returns
+// LPD_OK; one workspace per stream -- launches on one stream are ordered, so they share it).  The library allocates nothing.
 #define LPD_STAT_REPLICAS 32
 #define LPD_STAT_CMAX 1024
 struct LpdStatWs {
@@ -72,7 +73,7 @@ struct LpdStatWs {
     double* sum() const { return rep; }                      // what the kernels take in place of the caller's sum / sumsq pointers
     double* sumsq() const { return rep + LPD_STAT_CMAX; }
 };
-LpdStatWs lpd_stat_ws(hipStream_t stream);      // lpd_abi.hip; rep == nullptr if the allocation failed
+inline LpdStatWs lpd_stat_arg(double* stat_ws) { return LpdStatWs{stat_ws}; }      // the caller's workspace (may be null: checked by the entry points)
 // o0[c] = sum over the replicas of column c (c < ncols <= LPD_STAT_CMAX), o1 likewise; clears the replicas
 int lpd_stat_finish(LpdStatWs ws, double* o0, double* o1, int ncols, hipStream_t stream);
 // offset of this block's replica, to be added to the column index of both pointers

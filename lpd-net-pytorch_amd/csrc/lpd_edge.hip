@@ -1107,7 +1107,7 @@ extern "C" int lpd_edge_split_fwd16_applies(int N, int C, int k)
 
 extern "C" int lpd_edge_split_fwd16(const float* P, long long ldp, const float* Q, long long ldq, const uint16_t* idx16, const float* gamma,
                                     float* S, float* usel, uint8_t* arg, long long M, int N, int C, int k, double* sum, double* sumsq,
-                                    void* stream_)
+                                    double* stat_ws, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(P && Q && idx16 && gamma && S && usel && arg && sum && sumsq, "lpd_edge_split_fwd16: null pointer");
@@ -1116,8 +1116,8 @@ extern "C" int lpd_edge_split_fwd16(const float* P, long long ldp, const float* 
     LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)Q | (uintptr_t)S | (uintptr_t)usel | (uintptr_t)arg | (uintptr_t)gamma | (uintptr_t)idx16) & 15) == 0,
                   "lpd_edge_split_fwd16: pointers must be 16-byte aligned");
     LPD_CHECK_ARG((unsigned long long)M * (unsigned long long)C * 4ull < (1ull << 34), "lpd_edge_split_fwd16: tensor too large");
-    const LpdStatWs ws = lpd_stat_ws(stream);
-    LPD_CHECK_ARG(ws.rep, "lpd_edge_split_fwd16: no memory for the statistics scratch");
+    const LpdStatWs ws = lpd_stat_arg(stat_ws);
+    LPD_CHECK_ARG(ws.rep, "lpd_edge_split_fwd16: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     SplitFwdArgs g{P, Q, gamma, S, usel, arg, ws.sum(), ws.sumsq(), N, C, (int)ldp, (int)ldq};
     const int nslices = C / 8;
     const size_t lds = (size_t)KAGG_IMG1 + (size_t)N * 16;

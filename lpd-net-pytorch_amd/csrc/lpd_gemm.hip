@@ -1145,7 +1145,7 @@ static void x3w_wide_launch(const X3wArgs& g, int NT, hipStream_t stream)
 static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
                          const float* scale, const float* shift, int act, float slope, int accumulate,
                          long long a_cloud, long long c_cloud, int panel_n, int panel_ld, int impl, double* stat_sum, double* stat_sumsq,
-                         void* stream_)
+                         double* stat_ws, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     const bool a_panels = a_cloud != 0, c_panels = c_cloud != 0;
@@ -1165,8 +1165,8 @@ static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, i
     LpdStatWs sws = {nullptr};
     if (stat_sum) {
         LPD_CHECK_ARG(N <= LPD_STAT_CMAX, "lpd_gemm_x3w_stats: N=%d exceeds %d columns", N, LPD_STAT_CMAX);
-        sws = lpd_stat_ws(stream);
-        LPD_CHECK_ARG(sws.rep, "lpd_gemm_x3w_stats: no memory for the statistics scratch");
+        sws = lpd_stat_arg(stat_ws);
+        LPD_CHECK_ARG(sws.rep, "lpd_gemm_x3w_stats: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     }
     X3wArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, K, KS, lda, ldc, bias, scale, shift, act, slope, accumulate,
               a_cloud, c_cloud, panel_n, panel_ld, 0, prods, stat_sum ? sws.sum() : nullptr, stat_sum ? sws.sumsq() : nullptr};
@@ -1203,7 +1203,7 @@ extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C
                             long long a_cloud, long long c_cloud, int panel_n, int panel_ld, int impl, void* stream_)
 {
     return gemm_x3w_impl(A, lda, frags, C, ldc, M, N, K, bias, scale, shift, act, slope, accumulate, a_cloud, c_cloud, panel_n, panel_ld, impl,
-                         nullptr, nullptr, stream_);
+                         nullptr, nullptr, nullptr, stream_);
 }
 
 // The bare product C = A W^T (+ bias) of a TRAIN-mode layer together with the statistics its BatchNorm needs: stat_sum[n] /
@@ -1211,8 +1211,8 @@ extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C
 // (fp32 over a block's 128 rows, then fp64 atomics) -- what lpd_colstats computes with a second pass over C
 // (util/lpdnet_model.py:262: conv3_lpd + bn3_lpd over all B*N points; :251 convDG2 over all B*N*k edges).
 extern "C" int lpd_gemm_x3w_stats(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
-                                  double* stat_sum, double* stat_sumsq, int impl, void* stream_)
+                                  double* stat_sum, double* stat_sumsq, int impl, double* stat_ws, void* stream_)
 {
     LPD_CHECK_ARG(stat_sum && stat_sumsq, "lpd_gemm_x3w_stats: null statistics");
-    return gemm_x3w_impl(A, lda, frags, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 0.0f, 0, 0, 0, 0, 0, impl, stat_sum, stat_sumsq, stream_);
+    return gemm_x3w_impl(A, lda, frags, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 0.0f, 0, 0, 0, 0, 0, impl, stat_sum, stat_sumsq, stat_ws, stream_);
 }

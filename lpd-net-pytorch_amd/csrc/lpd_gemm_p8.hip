@@ -495,17 +495,27 @@ static int gemm_p8_impl(const void* a_hi, const void* a_lo, long long a_cloud, i
         hipLaunchKernelGGL(kern, dim3(grid), dim3(P8_THREADS), P8_LDS_BYTES, stream, g);
     };
     const bool d5 = (impl & 7) == 5;
+#ifdef LPD_P8_BENCH
+    // timing-only variants (tools/p8_bench.py builds its own library with -DLPD_P8_BENCH): their RESULTS ARE GARBAGE, so the product
+    // library does not contain them
+    if (!w2_frags && (impl & ~7)) {
+        if (impl & 128) launch(gemm_p8_kernel<6, false, 32>);
+        else if ((impl & 127) == 96) launch(gemm_p8_kernel<6, false, 16>);
+        else if (impl & 64) launch(gemm_p8_kernel<6, false, 4>);
+        else if ((impl & 24) == 24) launch(gemm_p8_kernel<6, false, 3>);
+        else if (impl & 32) launch(gemm_p8_kernel<6, false, 8>);
+        else if ((impl & 24) == 8) launch(gemm_p8_kernel<6, false, 1>);
+        else if ((impl & 16) && d5) launch(gemm_p8_kernel<5, false, 2>);
+        else launch(gemm_p8_kernel<6, false, 2>);
+        LPD_CHECK_LAUNCH("lpd_gemm_p8");
+        return LPD_OK;
+    }
+#else
+    LPD_CHECK_ARG(impl == 0 || impl == 5 || impl == 6, "lpd_gemm_p8: impl %d is not built (0 / 6 = six units of lookahead, 5 = five)", impl);
+#endif
     if (w2_frags) {
         if (c_cloud != 0) launch(gemm_p8_kernel<6, true, 0, true>); else launch(gemm_p8_kernel<6, false, 0, true>);
     }
-    else if (impl & 128) launch(gemm_p8_kernel<6, false, 32>);
-    else if ((impl & 127) == 96) launch(gemm_p8_kernel<6, false, 16>);
-    else if (impl & 64) launch(gemm_p8_kernel<6, false, 4>);
-    else if ((impl & 24) == 24) launch(gemm_p8_kernel<6, false, 3>);      // timing-only variants (tools/p8_bench.py): results are garbage
-    else if (impl & 32) launch(gemm_p8_kernel<6, false, 8>);
-    else if ((impl & 24) == 8) launch(gemm_p8_kernel<6, false, 1>);
-    else if ((impl & 16) && d5) launch(gemm_p8_kernel<5, false, 2>);
-    else if (impl & 16) launch(gemm_p8_kernel<6, false, 2>);
     else if (c_cloud != 0) { if (d5) launch(gemm_p8_kernel<5, true>); else launch(gemm_p8_kernel<6, true>); }
     else { if (d5) launch(gemm_p8_kernel<5, false>); else launch(gemm_p8_kernel<6, false>); }
     LPD_CHECK_LAUNCH("lpd_gemm_p8");

@@ -975,12 +975,12 @@ inline bool cols_ok(int C) { return C >= 4 && C % 4 == 0 && (C / 4) <= 256 && 25
 
 #define ST(s) ((hipStream_t)(s))
 
-extern "C" int lpd_colstats(const float* X, long long ld, long long R, int C, double* sum, double* sumsq, void* stream)
+extern "C" int lpd_colstats(const float* X, long long ld, long long R, int C, double* sum, double* sumsq, double* stat_ws, void* stream)
 {
     LPD_CHECK_ARG(X && sum && sumsq && R > 0, "lpd_colstats: bad arguments");
     LPD_CHECK_ARG(C >= 4 && C % 4 == 0 && ld % 4 == 0, "lpd_colstats: C=%d and ld must be multiples of 4", C);
-    const LpdStatWs ws = lpd_stat_ws(ST(stream));
-    LPD_CHECK_ARG(ws.rep, "lpd_colstats: no memory for the statistics scratch");
+    const LpdStatWs ws = lpd_stat_arg(stat_ws);
+    LPD_CHECK_ARG(ws.rep, "lpd_colstats: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     // the kernel takes a column panel of 4*2^n <= 1024 columns; other widths (k*k = 12, 4096 of the T-Nets) go panel by panel
     for (int c0 = 0; c0 < C;) {
         int w = 1024;
@@ -1021,13 +1021,13 @@ extern "C" int lpd_affine_act(const float* X, long long ldx, float* Y, long long
 extern "C" int lpd_bn_act_bwd(const float* dY, long long lddy, const float* X, long long ldx, float* dX, long long lddx,
                               long long R, int C, const float* scale, const float* shift, const float* mean,
                               const float* invstd, int act, float slope, int has_bn, double* dbeta, double* dgamma,
-                              void* stream)
+                              double* stat_ws, void* stream)
 {
     LPD_CHECK_ARG(dY && X && dX && dbeta && dgamma && R > 0, "lpd_bn_act_bwd: bad arguments");
     LPD_CHECK_ARG(cols_ok(C) && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0, "lpd_bn_act_bwd: C=%d / leading dims unsupported", C);
     LPD_CHECK_ARG(!has_bn || (scale && shift && mean && invstd), "lpd_bn_act_bwd: BatchNorm form needs scale/shift/mean/invstd");
-    const LpdStatWs ws = lpd_stat_ws(ST(stream));
-    LPD_CHECK_ARG(ws.rep, "lpd_bn_act_bwd: no memory for the statistics scratch");
+    const LpdStatWs ws = lpd_stat_arg(stat_ws);
+    LPD_CHECK_ARG(ws.rep, "lpd_bn_act_bwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     const int RG = 256 / (C / 4);
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream), dY, lddy, X, ldx, R, C,
                        scale, shift, has_bn ? mean : nullptr, has_bn ? invstd : nullptr, act, slope, ws.sum(), ws.sumsq());
@@ -1040,15 +1040,15 @@ extern "C" int lpd_bn_act_bwd(const float* dY, long long lddy, const float* X, l
 }
 
 extern "C" int lpd_edge_build(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, float* U,
-                              long long M, int N, int C, int k, double* sum, double* sumsq, void* stream)
+                              long long M, int N, int C, int k, double* sum, double* sumsq, double* stat_ws, void* stream)
 {
     LPD_CHECK_ARG((sum == nullptr) == (sumsq == nullptr), "lpd_edge_build: sum and sumsq come in pairs");
     LpdStatWs ws = {nullptr};
     double* usum = sum;
     double* usumsq = sumsq;
     if (sum) {
-        ws = lpd_stat_ws(ST(stream));
-        LPD_CHECK_ARG(ws.rep, "lpd_edge_build: no memory for the statistics scratch");
+        ws = lpd_stat_arg(stat_ws);
+        LPD_CHECK_ARG(ws.rep, "lpd_edge_build: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
         sum = ws.sum();
         sumsq = ws.sumsq();
     }
@@ -1105,14 +1105,14 @@ extern "C" int lpd_group_max_bwd(const float* dOut, long long ldo, const uint8_t
 static int edge_bn_bwd_impl(const float* dOut, long long ldo, const uint8_t* arg, const float* dDense, const float* X,
                             const float* Xsel, long long ldsel, float* dX, float* dQ, long long ldq, int k, long long M, int C,
                             const float* scale, const float* shift, const float* mean, const float* invstd, int act, float slope,
-                            double* dbeta, double* dgamma, void* stream)
+                            double* dbeta, double* dgamma, double* stat_ws, void* stream)
 {
     LPD_CHECK_ARG(dOut && arg && X && dX && scale && shift && mean && invstd && dbeta && dgamma && M > 0 && k > 0 && k <= 255,
                   "lpd_edge_bn_bwd: bad arguments");
     LPD_CHECK_ARG(cols_ok(C) && ldo % 4 == 0 && (!dQ || ldq % 4 == 0) && (!Xsel || ldsel % 4 == 0),
                   "lpd_edge_bn_bwd: C=%d / leading dims unsupported", C);
-    const LpdStatWs ws = lpd_stat_ws(ST(stream));
-    LPD_CHECK_ARG(ws.rep, "lpd_edge_bn_bwd: no memory for the statistics scratch");
+    const LpdStatWs ws = lpd_stat_arg(stat_ws);
+    LPD_CHECK_ARG(ws.rep, "lpd_edge_bn_bwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     const int RG = 256 / (C / 4);
     hipLaunchKernelGGL(edge_bn_bwd_reduce_kernel, dim3(grid_for(M, RG * 2)), dim3(256), 0, ST(stream), dOut, ldo, arg, dDense, X, Xsel,
                        ldsel, k, M, C, scale, shift, mean, invstd, act, slope, ws.sum(), ws.sumsq());
@@ -1127,20 +1127,20 @@ static int edge_bn_bwd_impl(const float* dOut, long long ldo, const uint8_t* arg
 extern "C" int lpd_edge_bn_bwd(const float* dOut, long long ldo, const uint8_t* arg, const float* dDense, const float* X,
                                float* dX, float* dQ, long long ldq, int k, long long M, int C, const float* scale,
                                const float* shift, const float* mean, const float* invstd, int act, float slope,
-                               double* dbeta, double* dgamma, void* stream)
+                               double* dbeta, double* dgamma, double* stat_ws, void* stream)
 {
     return edge_bn_bwd_impl(dOut, ldo, arg, dDense, X, nullptr, 0, dX, dQ, ldq, k, M, C, scale, shift, mean, invstd, act, slope, dbeta,
-                            dgamma, stream);
+                            dgamma, stat_ws, stream);
 }
 
 extern "C" int lpd_edge_bn_bwd_sel(const float* dOut, long long ldo, const uint8_t* arg, const float* X, const float* Xsel,
                                    long long ldsel, float* dX, int k, long long M, int C, const float* scale, const float* shift,
                                    const float* mean, const float* invstd, int act, float slope, double* dbeta, double* dgamma,
-                                   void* stream)
+                                   double* stat_ws, void* stream)
 {
     LPD_CHECK_ARG(Xsel, "lpd_edge_bn_bwd_sel: Xsel is null");
     return edge_bn_bwd_impl(dOut, ldo, arg, nullptr, X, Xsel, ldsel, dX, nullptr, 0, k, M, C, scale, shift, mean, invstd, act, slope,
-                            dbeta, dgamma, stream);
+                            dbeta, dgamma, stat_ws, stream);
 }
 
 extern "C" int lpd_group_sum(const float* dU, int k, float* dQ, long long ldq, long long M, int C, void* stream)

@@ -1046,14 +1046,14 @@ inline int grid_for(long long items, int per_block, int cap = 4096)
 // ------------------------------------------------------------------------------------------------
 extern "C" int lpd_edge_split_fwd(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx,
                                   const float* gamma, float* S, float* usel, uint8_t* arg, long long M, int N, int C, int k,
-                                  double* sum, double* sumsq, void* stream_)
+                                  double* sum, double* sumsq, double* stat_ws, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(P && Q && idx && gamma && S && usel && arg && sum && sumsq, "lpd_edge_split_fwd: null pointer");
     LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_split_fwd: C=%d unsupported", C);
     LPD_CHECK_ARG(M > 0 && N > 0 && k > 0 && k <= 255 && M % N == 0 && ldp % 4 == 0 && ldq % 4 == 0, "lpd_edge_split_fwd: bad dims");
-    const LpdStatWs ws = lpd_stat_ws(stream);
-    LPD_CHECK_ARG(ws.rep, "lpd_edge_split_fwd: no memory for the statistics scratch");
+    const LpdStatWs ws = lpd_stat_arg(stat_ws);
+    LPD_CHECK_ARG(ws.rep, "lpd_edge_split_fwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     const int lpp = C / 4;
     const int grid = grid_for(M, 4 * (64 / lpp) * 4, 2048);
     if (C == 64) hipLaunchKernelGGL(edge_split_fwd_kernel<16>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, gamma, S, usel, arg, M, N, k, ws.sum(), ws.sumsq());
@@ -1067,7 +1067,7 @@ extern "C" int lpd_edge_split_bwd(const float* dOut, long long ldo, const float*
                                   const float* P, long long ldp, const float* Q, long long ldq, const int32_t* rowptr,
                                   const int32_t* edges, float* G, float* dP, long long lddp, float* dQ, long long lddq, long long M,
                                   int C, int k, const float* scale, const float* shift, const float* mean, const float* invstd,
-                                  int act, float slope, double* dbeta, double* dgamma, void* stream_)
+                                  int act, float slope, double* dbeta, double* dgamma, double* stat_ws, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(dOut && usel && arg && S && P && Q && rowptr && edges && G && dP && dQ && dbeta && dgamma,
@@ -1075,8 +1075,8 @@ extern "C" int lpd_edge_split_bwd(const float* dOut, long long ldo, const float*
     LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_split_bwd: C=%d unsupported", C);
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_split_bwd: activation %d unsupported", act);
     LPD_CHECK_ARG(ldo % 4 == 0 && ldp % 4 == 0 && ldq % 4 == 0 && lddp % 4 == 0 && lddq % 4 == 0, "lpd_edge_split_bwd: leading dims % 4");
-    const LpdStatWs ws = lpd_stat_ws(stream);
-    LPD_CHECK_ARG(ws.rep, "lpd_edge_split_bwd: no memory for the statistics scratch");
+    const LpdStatWs ws = lpd_stat_arg(stat_ws);
+    LPD_CHECK_ARG(ws.rep, "lpd_edge_split_bwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     const int rg = 256 / (C / 4);
     hipLaunchKernelGGL(edge_split_bwd_reduce_kernel, dim3(grid_for(M, rg * 8, 2048)), dim3(256), 0, stream, dOut, ldo, usel, G, M, C,
                        scale, shift, mean, invstd, act, slope, ws.sum(), ws.sumsq());
@@ -1092,7 +1092,7 @@ extern "C" int lpd_edge_split_bwd(const float* dOut, long long ldo, const float*
 }
 
 extern "C" int lpd_edge_build_bf16(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, uint16_t* U,
-                                   long long M, int N, int C, int k, double* sum, double* sumsq, void* stream_)
+                                   long long M, int N, int C, int k, double* sum, double* sumsq, double* stat_ws, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(P && idx && U, "lpd_edge_build_bf16: null pointer");
@@ -1102,8 +1102,8 @@ extern "C" int lpd_edge_build_bf16(const float* P, long long ldp, const float* Q
     double* usum = sum;
     double* usumsq = sumsq;
     if (sum) {
-        ws = lpd_stat_ws(stream);
-        LPD_CHECK_ARG(ws.rep, "lpd_edge_build_bf16: no memory for the statistics scratch");
+        ws = lpd_stat_arg(stat_ws);
+        LPD_CHECK_ARG(ws.rep, "lpd_edge_build_bf16: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
         sum = ws.sum();
         sumsq = ws.sumsq();
     }
@@ -1148,13 +1148,13 @@ extern "C" int lpd_edge_act_max(const float* U, int k, const float* scale, const
 }
 
 extern "C" int lpd_group_sel_stats_bf16(const uint16_t* Z, int k, const float* gamma, float* sel, long long lds, uint8_t* arg,
-                                        long long M, int C, double* sum, double* sumsq, void* stream_)
+                                        long long M, int C, double* sum, double* sumsq, double* stat_ws, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(Z && gamma && sel && arg && sum && sumsq, "lpd_group_sel_stats_bf16: null pointer");
     LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && k <= 255 && lds % 4 == 0, "lpd_group_sel_stats_bf16: bad dims");
-    const LpdStatWs ws = lpd_stat_ws(stream);
-    LPD_CHECK_ARG(ws.rep, "lpd_group_sel_stats_bf16: no memory for the statistics scratch");
+    const LpdStatWs ws = lpd_stat_arg(stat_ws);
+    LPD_CHECK_ARG(ws.rep, "lpd_group_sel_stats_bf16: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     const int rg = 256 / (C / 4);
     hipLaunchKernelGGL(group_sel_stats_bf16_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, Z, k, gamma, sel, lds, arg, M, C,
                        ws.sum(), ws.sumsq());
@@ -1165,15 +1165,15 @@ extern "C" int lpd_group_sel_stats_bf16(const uint16_t* Z, int k, const float* g
 static int edge_bn_bwd_bf16_impl(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* dDense, const uint16_t* X,
                                  const float* Xsel, long long ldsel, uint16_t* dX, float* dQ, long long ldq, int k, long long M, int C,
                                  const float* scale, const float* shift, const float* mean, const float* invstd, int act, float slope,
-                                 double* dbeta, double* dgamma, void* stream_)
+                                 double* dbeta, double* dgamma, double* stat_ws, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(dOut && arg && X && dX && scale && shift && mean && invstd && dbeta && dgamma, "lpd_edge_bn_bwd_bf16: null pointer");
     LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && k <= 255 && ldo % 4 == 0 && ldq % 4 == 0 && ldsel % 4 == 0,
                   "lpd_edge_bn_bwd_bf16: bad dims");
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_bn_bwd_bf16: activation %d unsupported", act);
-    const LpdStatWs ws = lpd_stat_ws(stream);
-    LPD_CHECK_ARG(ws.rep, "lpd_edge_bn_bwd_bf16: no memory for the statistics scratch");
+    const LpdStatWs ws = lpd_stat_arg(stat_ws);
+    LPD_CHECK_ARG(ws.rep, "lpd_edge_bn_bwd_bf16: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     const int rg = 256 / (C / 4);
     hipLaunchKernelGGL(edge_bn_bwd_reduce_bf16_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, dOut, ldo, arg, dDense, X, Xsel,
                        ldsel, k, M, C, scale, shift, mean, invstd, act, slope, ws.sum(), ws.sumsq());
@@ -1189,20 +1189,20 @@ static int edge_bn_bwd_bf16_impl(const float* dOut, long long ldo, const uint8_t
 extern "C" int lpd_edge_bn_bwd_bf16(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* dDense, const uint16_t* X,
                                     uint16_t* dX, float* dQ, long long ldq, int k, long long M, int C, const float* scale,
                                     const float* shift, const float* mean, const float* invstd, int act, float slope, double* dbeta,
-                                    double* dgamma, void* stream)
+                                    double* dgamma, double* stat_ws, void* stream)
 {
     return edge_bn_bwd_bf16_impl(dOut, ldo, arg, dDense, X, nullptr, 0, dX, dQ, ldq, k, M, C, scale, shift, mean, invstd, act, slope, dbeta,
-                                 dgamma, stream);
+                                 dgamma, stat_ws, stream);
 }
 
 extern "C" int lpd_edge_bn_bwd_bf16_sel(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* X, const float* Xsel,
                                         long long ldsel, uint16_t* dX, int k, long long M, int C, const float* scale, const float* shift,
                                         const float* mean, const float* invstd, int act, float slope, double* dbeta, double* dgamma,
-                                        void* stream)
+                                        double* stat_ws, void* stream)
 {
     LPD_CHECK_ARG(Xsel, "lpd_edge_bn_bwd_bf16_sel: Xsel is null");
     return edge_bn_bwd_bf16_impl(dOut, ldo, arg, nullptr, X, Xsel, ldsel, dX, nullptr, 0, k, M, C, scale, shift, mean, invstd, act, slope,
-                                 dbeta, dgamma, stream);
+                                 dbeta, dgamma, stat_ws, stream);
 }
 
 extern "C" int lpd_gather_sum_rows_bf16(const uint16_t* dU, const int32_t* rowptr, const int32_t* edges, float* dP, long long ldp,

@@ -692,14 +692,14 @@ __global__ __launch_bounds__(512, 2) void gemm_f32s_bnbwd_kernel(const float* __
 
 static int bn_sel_bwd_reduce_impl(const float* dOut, long long ldo, const float* Xsel, long long ldsel, long long M, int C, const float* scale,
                                   const float* shift, const float* mean, const float* invstd, int act, float slope, uint16_t* dpre16,
-                                  float* dpre32, double* dbeta, double* dgamma, void* stream_)
+                                  float* dpre32, double* dbeta, double* dgamma, double* stat_ws, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(dOut && Xsel && scale && shift && mean && invstd && (dpre16 || dpre32) && dbeta && dgamma && M > 0, "lpd_bn_sel_bwd_reduce: null pointer");
     LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && ldo % 4 == 0 && ldsel % 4 == 0, "lpd_bn_sel_bwd_reduce: bad dims");
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_bn_sel_bwd_reduce: activation %d unsupported", act);
-    const LpdStatWs ws = lpd_stat_ws(stream);
-    LPD_CHECK_ARG(ws.rep, "lpd_bn_sel_bwd_reduce: no memory for the statistics scratch");
+    const LpdStatWs ws = lpd_stat_arg(stat_ws);
+    LPD_CHECK_ARG(ws.rep, "lpd_bn_sel_bwd_reduce: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     const int rg = 256 / (C / 4);
     hipLaunchKernelGGL(bn_sel_bwd_reduce_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, dOut, ldo, Xsel, ldsel, M, C, scale,
                        shift, mean, invstd, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), dpre16, dpre32, ws.sum(), ws.sumsq());
@@ -709,16 +709,16 @@ static int bn_sel_bwd_reduce_impl(const float* dOut, long long ldo, const float*
 
 extern "C" int lpd_bn_sel_bwd_reduce(const float* dOut, long long ldo, const float* Xsel, long long ldsel, long long M, int C,
                                      const float* scale, const float* shift, const float* mean, const float* invstd, int act, float slope,
-                                     uint16_t* dpre16, double* dbeta, double* dgamma, void* stream)
+                                     uint16_t* dpre16, double* dbeta, double* dgamma, double* stat_ws, void* stream)
 {
-    return bn_sel_bwd_reduce_impl(dOut, ldo, Xsel, ldsel, M, C, scale, shift, mean, invstd, act, slope, dpre16, nullptr, dbeta, dgamma, stream);
+    return bn_sel_bwd_reduce_impl(dOut, ldo, Xsel, ldsel, M, C, scale, shift, mean, invstd, act, slope, dpre16, nullptr, dbeta, dgamma, stat_ws, stream);
 }
 
 extern "C" int lpd_bn_sel_bwd_reduce_f32(const float* dOut, long long ldo, const float* Xsel, long long ldsel, long long M, int C,
                                          const float* scale, const float* shift, const float* mean, const float* invstd, int act, float slope,
-                                         float* dpre, double* dbeta, double* dgamma, void* stream)
+                                         float* dpre, double* dbeta, double* dgamma, double* stat_ws, void* stream)
 {
-    return bn_sel_bwd_reduce_impl(dOut, ldo, Xsel, ldsel, M, C, scale, shift, mean, invstd, act, slope, nullptr, dpre, dbeta, dgamma, stream);
+    return bn_sel_bwd_reduce_impl(dOut, ldo, Xsel, ldsel, M, C, scale, shift, mean, invstd, act, slope, nullptr, dpre, dbeta, dgamma, stat_ws, stream);
 }
 
 static long long edge_dw_sel_blocks(long long E)

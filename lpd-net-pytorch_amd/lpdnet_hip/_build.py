@@ -21,6 +21,9 @@ ABI_SMOKE_BIN = os.path.join(REPO, "tests", "abi_smoke")
 # (HIP's __fmul_rn/__fadd_rn are plain operators and DO get contracted otherwise); explicit fmaf /
 # MFMA are unaffected.
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wno-unused-value"]
+# measurement builds only (e.g. LPD_EXTRA_FLAGS=-DLPD_P8_BENCH for tools/p8_bench.py's timing-only conv3 variants); part of the
+# content hash, so switching it rebuilds
+FLAGS += os.environ.get("LPD_EXTRA_FLAGS", "").split()
 
 
 def _hipcc():

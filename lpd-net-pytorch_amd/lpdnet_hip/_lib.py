@@ -24,6 +24,7 @@ _c_p = ctypes.c_void_p
 SIGNATURES = {
     "lpd_version": [],
     "lpd_last_error": [],
+    "lpd_stat_ws_bytes": [],
     "lpd_knn": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_int, _c_p],
     "lpd_gemm": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                  _c_ll, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_ll, _c_ll, _c_int, _c_int, _c_p],
@@ -48,7 +49,7 @@ SIGNATURES = {
                           _c_int, _c_f, _c_p, _c_p, _c_ll, _c_p],
     "lpd_softmax_affine_parts": [_c_p, _c_int, _c_ll, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_int, _c_p],
     "lpd_split_panels": [_c_p, _c_ll, _c_int, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_p],
-    "lpd_gemm_x3w_stats": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_p],
+    "lpd_gemm_x3w_stats": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_p, _c_p],
     "lpd_retrieval_topk": [_c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_f64_to_f32": [_c_p, _c_p, _c_ll, _c_p],
     "lpd_best_pos_bwd": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p],
@@ -83,21 +84,21 @@ SIGNATURES = {
     "lpd_mul": [_c_p, _c_p, _c_p, _c_ll, _c_p],
     "lpd_gating": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "lpd_morton_sort": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p],
-    "lpd_colstats": [_c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p],
+    "lpd_colstats": [_c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_bn_finalize": [_c_p, _c_p, ctypes.c_double, _c_int, _c_p, _c_p, _c_p, _c_p, _c_f, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_affine_act": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p],
     "lpd_bn_act_bwd": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int,
-                       _c_p, _c_p, _c_p],
-    "lpd_edge_build": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p],
+                       _c_p, _c_p, _c_p, _c_p],
+    "lpd_edge_build": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_group_max": [_c_p, _c_ll, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p],
     "lpd_group_max_sel": [_c_p, _c_ll, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_ll, _c_int, _c_p],
     "lpd_edge_bn_bwd_sel": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f,
-                            _c_p, _c_p, _c_p],
+                            _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_bn_bwd_bf16_sel": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f,
-                                 _c_p, _c_p, _c_p],
+                                 _c_p, _c_p, _c_p, _c_p],
     "lpd_group_max_bwd": [_c_p, _c_ll, _c_p, _c_int, _c_p, _c_ll, _c_int, _c_int, _c_p],
     "lpd_edge_bn_bwd": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int,
-                        _c_f, _c_p, _c_p, _c_p],
+                        _c_f, _c_p, _c_p, _c_p, _c_p],
     "lpd_group_sum": [_c_p, _c_int, _c_p, _c_ll, _c_ll, _c_int, _c_p],
     "lpd_scatter_add_rows": [_c_p, _c_p, _c_p, _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_p],
     "lpd_graph_transpose": [_c_p, _c_ll, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
@@ -108,21 +109,21 @@ SIGNATURES = {
     "lpd_cloud_outer": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_int, _c_int, _c_int, _c_p],
     "lpd_softmax_bwd": [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_p],
     "lpd_vlad_finalize_bwd": [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
-    "lpd_edge_split_fwd": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p],
+    "lpd_edge_split_fwd": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_split_bwd": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_ll,
-                           _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_p],
+                           _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_split_fwd16_applies": [_c_int, _c_int, _c_int],
-    "lpd_edge_split_fwd16": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p],
-    "lpd_edge_build_bf16": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p],
+    "lpd_edge_split_fwd16": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
+    "lpd_edge_build_bf16": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_act_max": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p],
     "lpd_edge_act_max_bf16": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p],
-    "lpd_group_sel_stats_bf16": [_c_p, _c_int, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p, _c_p, _c_p],
+    "lpd_group_sel_stats_bf16": [_c_p, _c_int, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_bn_bwd_bf16": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int,
-                             _c_f, _c_p, _c_p, _c_p],
-    "lpd_bn_sel_bwd_reduce": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p],
+                             _c_f, _c_p, _c_p, _c_p, _c_p],
+    "lpd_bn_sel_bwd_reduce": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_dw_sel_bf16": [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_gemm_bf16s_bnbwd": [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
-    "lpd_bn_sel_bwd_reduce_f32": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p],
+    "lpd_bn_sel_bwd_reduce_f32": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_dw_sel_f32": [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_gemm_f32s_bnbwd": [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_gather_sum_rows_bf16": [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_ll, _c_int, _c_int, _c_p],
@@ -135,7 +136,7 @@ SIGNATURES = {
     "lpd_metric_loss": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_int, _c_int, _c_int,
                         _c_int, _c_f, _c_f, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
 }
-_RESTYPES = {"lpd_last_error": ctypes.c_char_p, "lpd_knn_workspace_floats": ctypes.c_longlong,
+_RESTYPES = {"lpd_last_error": ctypes.c_char_p, "lpd_stat_ws_bytes": ctypes.c_longlong, "lpd_knn_workspace_floats": ctypes.c_longlong,
              "lpd_gemm_prep_b_bytes": ctypes.c_longlong, "lpd_gemm_tn_bf16_ws_floats": ctypes.c_longlong, "lpd_gemm_tn_ws_floats": ctypes.c_longlong,
              "lpd_edge_dw_sel_bf16_ws_bytes": ctypes.c_longlong}
 

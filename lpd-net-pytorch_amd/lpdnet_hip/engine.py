@@ -15,12 +15,26 @@ from . import ops
 
 LEAKY_SLOPE = 0.01
 
-# test hook: when set to a dict, the trunks drop intermediate tensors into it (idx_feat, idx_xyz, F0, cat)
-DEBUG_AUX = None
+class _PerThread(__import__("threading").local):
+    """Settings a caller may flip around ONE forward.  Per host thread: nn.DataParallel-style callers run one forward per device
+    thread (train_pointnetvlad.py:80), and a test hook set by one of them must not leak into the others.  Read and written as
+    module attributes (`engine.DEBUG_AUX = {}`, `engine.MORTON_ORDER = False`): the module's class maps them onto this object."""
+    # test hook: when set to a dict, the trunks drop intermediate tensors into it (idx_feat, idx_xyz, F0, cat)
+    DEBUG_AUX = None
+    # Z-order the points of each cloud once per forward (descriptor is order-invariant; makes the neighbour
+    # gathers cache-local).  Tests switch it off to compare intermediate index tensors in the caller's order.
+    MORTON_ORDER = True
 
-# Z-order the points of each cloud once per forward (descriptor is order-invariant; makes the neighbour
-# gathers cache-local).  Tests switch it off to compare intermediate index tensors in the caller's order.
-MORTON_ORDER = True
+
+_TLS = _PerThread()
+
+
+class _EngineModule(__import__("types").ModuleType):
+    DEBUG_AUX = property(lambda self: _TLS.DEBUG_AUX, lambda self, v: setattr(_TLS, "DEBUG_AUX", v))
+    MORTON_ORDER = property(lambda self: _TLS.MORTON_ORDER, lambda self, v: setattr(_TLS, "MORTON_ORDER", v))
+
+
+__import__("sys").modules[__name__].__class__ = _EngineModule
 MORTON_MAX_POINTS = 16384
 # PointNetVlad.forward (eval) runs batches of more than EVAL_CHUNK x 4096 points as slices of that many points (0: never slice)
 EVAL_CHUNK = int(__import__("os").environ.get("LPD_EVAL_CHUNK", "32"))
@@ -29,7 +43,7 @@ EVAL_CHUNK = int(__import__("os").environ.get("LPD_EVAL_CHUNK", "32"))
 def reorder_points(x, reorder=True):
     """x [B,1,N,3] -> Z-ordered copy (or x itself when disabled / too large).  reorder=False: the caller needs the per-point
     output in ITS point order (the public LPDNet.forward / LPDNetOrign.forward); PointNetVlad's descriptor is order-invariant."""
-    if reorder and MORTON_ORDER and 64 <= x.shape[2] <= MORTON_MAX_POINTS:
+    if reorder and _TLS.MORTON_ORDER and 64 <= x.shape[2] <= MORTON_MAX_POINTS:
         return ops.morton_sort(x)
     return x
 
@@ -51,12 +65,15 @@ def _cached(module, key, tensors, build):
     c = _cache_of(module)
     hit = c.get(key)
     if hit is not None and hit[0] == sig:
+        if hit[2] is not None:      # built on another stream (a second host thread on the same module)?
+            ops.consumer_sync(hit[2], *(hit[1] if isinstance(hit[1], tuple) else (hit[1],)))
         return hit[1]
     with torch.no_grad():
         val = build()
     if isinstance(val, torch.Tensor):
         val._lpd_stable = True      # one object per version of its sources: ops._weight_frags may cache its MFMA fragments
-    c[key] = (sig, val)
+    cuda = any(t.is_cuda for t in tensors)
+    c[key] = (sig, val, ops.producer_mark() if cuda else None)
     return val
 
 
@@ -424,8 +441,8 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side, assign=None):
             idx_x = _knn_rows(xyz, B, N, 3, k)      # static graph in Cartesian space (raw xyz even when t3d, :226,255)
             i16_x = pack(idx_x)
         kagg_p(pq3[:, 0:32], pq3[:, 32:64], i16_x, N, scale=s3, shift=b3, act=act, slope=slope, out=x3v)
-        if DEBUG_AUX is not None:
-            DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=ops.split_to_rows(cat) if split else ops.panels_to_rows(cat))
+        if _TLS.DEBUG_AUX is not None:
+            _TLS.DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=ops.split_to_rows(cat) if split else ops.panels_to_rows(cat))
         parts = None
         if split:
             if (FUSE_ASSIGN and assign is not None and assign.cluster_size == 64 and N % 64 == 0
@@ -452,8 +469,8 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side, assign=None):
         idx_x = _knn_rows(x.view(B * N, 3), B, N, 3, k)
     pq = ops.linear(cat[:, 128:256], split_edge_weight(net.convSN1, "cat_nc"))          # [M,512]
     kagg(pq[:, :256], pq[:, 256:], idx_x, N, scale=s3, shift=b3, act=act, slope=slope, out=cat[:, 256:512])
-    if DEBUG_AUX is not None:
-        DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=cat)
+    if _TLS.DEBUG_AUX is not None:
+        _TLS.DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x, cat=cat)
     return ops.linear(cat, _w2d(net.conv3_lpd), scale=sc, shift=bc, act=act, slope=slope), B, N, None
 
 
@@ -499,8 +516,8 @@ def lpdnet_origin_features_eval(net, x, reorder=True):
     s1, b1 = bn_affine(net.convSN1[1])
     s2, b2 = bn_affine(net.convSN2[1])
     h = ops.edge_mlp(pn, None, idx_x, N, s1, b1, _w2d(net.convSN2[0]), s2, b2, act=act, slope=slope)
-    if DEBUG_AUX is not None:
-        DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x)
+    if _TLS.DEBUG_AUX is not None:
+        _TLS.DEBUG_AUX.update(F0=f, idx_feat=idx_f, idx_xyz=idx_x)
     h = seq(seq(seq(h, net.conv3_lpd), net.conv4_lpd), net.conv5_lpd)
     return h, B, N
 

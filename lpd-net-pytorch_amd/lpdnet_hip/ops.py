@@ -11,18 +11,30 @@ from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 
-# When set to a dict, every C-ABI call is bracketed by HIP events recorded on the launch stream
-# (torch's current stream): {label: [(start_event, end_event), ...]}.  Used by bench.py.
-PROFILE = None
+class _PerThread(__import__("threading").local):
+    """Measurement hooks, per host thread (a profile opened by one thread must not collect another thread's launches); read and
+    written as module attributes (`ops.PROFILE = {}`): the module's class maps them onto this object."""
+    # When set to a dict, every C-ABI call is bracketed by HIP events recorded on the launch stream
+    # (torch's current stream): {label: [(start_event, end_event), ...]}.  Used by bench.py.
+    PROFILE = None
+    PROFILE_ONLY = None   # tuple of label prefixes: only those calls get events (90 event pairs per eval step cost 1.6 ms of host
+                          # time -- more than the GPU needs for the step -- so a timed region brackets only what it reports)
 
 
-PROFILE_ONLY = None   # tuple of label prefixes: only those calls get events (90 event pairs per eval step cost 1.6 ms of host
-                      # time -- more than the GPU needs for the step -- so a timed region brackets only what it reports)
+_TLS = _PerThread()
+
+
+class _OpsModule(__import__("types").ModuleType):
+    PROFILE = property(lambda self: _TLS.PROFILE, lambda self, v: setattr(_TLS, "PROFILE", v))
+    PROFILE_ONLY = property(lambda self: _TLS.PROFILE_ONLY, lambda self, v: setattr(_TLS, "PROFILE_ONLY", v))
+
+
+__import__("sys").modules[__name__].__class__ = _OpsModule
 
 
 def _call(label, fn, *args):
-    prof = PROFILE
-    if prof is None or (PROFILE_ONLY is not None and not label.startswith(PROFILE_ONLY)):
+    prof, only = _TLS.PROFILE, _TLS.PROFILE_ONLY
+    if prof is None or (only is not None and not label.startswith(only)):
         _lib.check(fn(*args), fn.__name__)
         return
     a = torch.cuda.Event(enable_timing=True)
@@ -49,6 +61,27 @@ def _stream():
     if _raw_stream is not None and _cur_device is not None:
         return ctypes.c_void_p(_raw_stream(_cur_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_STAT_WS = {}
+_STAT_LOCK = __import__("threading").Lock()
+
+
+def _stat_ws():
+    """The `stat_ws` argument of the C-ABI's cross-workgroup reductions (include/lpd_hip.h, Conventions): a zero-filled
+    lpd_stat_ws_bytes() buffer per (device, stream), owned here (torch's allocator), kept all-zero by the library between calls.
+    Keyed by the raw stream handle: calls on one stream are ordered and share it; a recycled handle finds an all-zero buffer."""
+    dev = _cur_device() if _cur_device is not None else torch.cuda.current_device()
+    raw = _raw_stream(dev) if _raw_stream is not None else torch.cuda.current_stream().cuda_stream
+    t = _STAT_WS.get((dev, raw))
+    if t is None:
+        n = int(_lib.load().lpd_stat_ws_bytes()) // 8
+        t = torch.zeros(n, dtype=torch.float64, device=torch.device("cuda", dev))      # memset on the current stream: ordered
+        if torch.cuda.is_current_stream_capturing():
+            return ctypes.c_void_p(t.data_ptr())      # graph-private memory: not cached beyond the capture (the memset is a graph node)
+        with _STAT_LOCK:
+            t = _STAT_WS.setdefault((dev, raw), t)
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def _req(t, name, dtype=torch.float32):
@@ -255,16 +288,37 @@ def _weight_frags(B2, b_kmajor, N, K):
         with _FRAG_LOCK:
             hit = _FRAG_CACHE.get(key)
         if hit is not None:
+            consumer_sync(hit[2], hit[0])
             return hit[0]
     lib = _lib.load()
     frags = torch.empty((int(lib.lpd_gemm_prep_b_bytes(N, K)),), dtype=torch.uint8, device=B2.device)
     _call("gemm_prep_b", lib.lpd_gemm_prep_b, _ptr(B2), B2.stride(0), int(bool(b_kmajor)), N, K, _ptr(frags), _stream())
     if cacheable:
+        mark = producer_mark()
         with _FRAG_LOCK:
             if len(_FRAG_CACHE) > 256:
                 _FRAG_CACHE.clear()
-            _FRAG_CACHE[key] = (frags, base)     # the reference keeps the parameter's storage from being recycled under the key
+            _FRAG_CACHE[key] = (frags, base, mark)     # the reference keeps the parameter's storage from being recycled under the key
     return frags
+
+
+def producer_mark():
+    """(raw stream, event) behind the launches that filled a cache entry: a later hit from ANOTHER stream (a second host thread
+    running the same module on its own stream) must not read the entry before those launches are done."""
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    ev = torch.cuda.Event()
+    ev.record()
+    return (_stream().value, ev)
+
+
+def consumer_sync(mark, *tensors):
+    if mark is not None and mark[0] != _stream().value:
+        cur = torch.cuda.current_stream()
+        cur.wait_event(mark[1])
+        for t in tensors:
+            if isinstance(t, torch.Tensor):
+                t.record_stream(cur)
 
 
 def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=None, act=ACT_NONE, slope=0.01,
@@ -701,21 +755,11 @@ def edge_gather_maxw(P, Q, idx16, N, *, scale=None, shift=None, act=ACT_NONE, sl
         raise ValueError("edge_gather_maxw: idx16 must come from pack_idx16w of this graph")
     if out is None:
         out = torch.empty((M, C), dtype=torch.float32, device=P.device)
-    if _is_split(out):           # split bf16 planes for lpd_gemm_p8 (same bytes as the fp32 panels)
-        if out.shape[2] * 8 != C or out.shape[3] != N or out.shape[1] * N != M:
-            raise ValueError("edge_gather_max16: split out must be a [2, B, C/8, N, 8] view")
-        for t, pan, name in ((P, pan_p, "P"), (Q, pan_q, "Q")):
-            _req(t, name)
-            if t is not None and pan and (not _is_panels(t) or t.shape[1] * 8 != C or t.shape[2] != N or t.shape[0] * N != M
-                                          or t.stride(1) != out.stride(2)):
-                raise ValueError(f"edge_gather_max16: cloud-panel {name} must be a [B, C/8, N, 8] view with the panel stride of out")
-        scale, shift = _vec(scale, "scale", C), _vec(shift, "shift", C)
-        lib = _lib.load()
-        _call(f"edge_gather_max16[C={C}]", lib.lpd_edge_gather_max16s, _ptr(P), 8 if pan_p else _rows(P, "P"), _ptr(Q),
-              0 if Q is None else (8 if pan_q else _rows(Q, "Q")), _ptr(idx16), _ptr(out[0]), out.stride(0), _ptr(scale), _ptr(shift),
-              M, N, C, k, act, float(slope), P.stride(0) if pan_p else 0, Q.stride(0) if pan_q else 0, out.stride(1),
-              out.stride(2) // 8, _stream())
-        return out
+    if _is_split(out):
+        # the split-plane epilogue exists in the cloud-resident kernel only, which reads pack_idx16's byte offsets; idx16 here holds
+        # pack_idx16w's raw indices (same tensor type and shape): refuse instead of computing with the wrong encoding
+        raise ValueError("edge_gather_maxw: split bf16 output planes are not built for the windowed kernel "
+                         "(use edge_gather_max16 with pack_idx16 for N <= 4096, k = 20, or an fp32 output)")
     pan_o = out.dim() == 4
     for t, pan, name in ((P, pan_p, "P"), (Q, pan_q, "Q"), (out, pan_o, "out")):
         _req(t, name)
@@ -932,7 +976,7 @@ def bn_train_stats(X, bn, rows=None):
     dev = X.device
     sums = torch.empty((2, C), dtype=torch.float64, device=dev)
     lib = _lib.load()
-    _call("colstats", lib.lpd_colstats, _ptr(X), ld, R, C, _ptr(sums[0]), _ptr(sums[1]), _stream())
+    _call("colstats", lib.lpd_colstats, _ptr(X), ld, R, C, _ptr(sums[0]), _ptr(sums[1]), _stat_ws(), _stream())
     return _bn_finalize(sums, R, C, bn)
 
 
@@ -956,7 +1000,7 @@ def linear_bn_stats(x, w, bn, bias=None):
         sums = torch.empty((2, N), dtype=torch.float64, device=x.device)
         lib = _lib.load()
         _call(f"gemmx3w+stats[{M}x{N}x{K}]", lib.lpd_gemm_x3w_stats, _ptr(x), ldx, _ptr(frags), _ptr(y), N, M, N, K, _ptr(bias), _ptr(sums[0]),
-              _ptr(sums[1]), X3W_IMPL, _stream())
+              _ptr(sums[1]), X3W_IMPL, _stat_ws(), _stream())
         return y, _bn_finalize(sums, M, N, bn)
     y = linear(x, w, bias=bias)
     return y, bn_train_stats(y, bn)
@@ -989,7 +1033,7 @@ def colsum(X, rows=None):
     C = X.shape[1]
     sums = torch.empty((2, C), dtype=torch.float64, device=X.device)
     lib = _lib.load()
-    _call("colstats", lib.lpd_colstats, _ptr(X), ld, R, C, _ptr(sums[0]), _ptr(sums[1]), _stream())
+    _call("colstats", lib.lpd_colstats, _ptr(X), ld, R, C, _ptr(sums[0]), _ptr(sums[1]), _stat_ws(), _stream())
     return sums[0].float()
 
 
@@ -1020,7 +1064,7 @@ def bn_act_bwd(dY, X, st, act=ACT_NONE, slope=0.01, out=None, rows=None):
     has_bn = st is not None
     _call("bn_act_bwd", lib.lpd_bn_act_bwd, _ptr(dY), lddy, _ptr(X), ldx, _ptr(out), lddx, R, C,
           _ptr(st.scale) if has_bn else None, _ptr(st.shift) if has_bn else None, _ptr(st.mean) if has_bn else None,
-          _ptr(st.invstd) if has_bn else None, act, float(slope), int(has_bn), _ptr(red[0]), _ptr(red[1]), _stream())
+          _ptr(st.invstd) if has_bn else None, act, float(slope), int(has_bn), _ptr(red[0]), _ptr(red[1]), _stat_ws(), _stream())
     redf = red.float()
     return out, redf[1], redf[0]
 
@@ -1037,7 +1081,7 @@ def edge_build(P, Q, idx, N, bn=None):
     sums = torch.empty((2, C), dtype=torch.float64, device=P.device) if bn is not None else None
     lib = _lib.load()
     _call(f"edge_build[C={C}]", lib.lpd_edge_build, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(U), M, N, C, k,
-          _ptr(sums[0]) if bn is not None else None, _ptr(sums[1]) if bn is not None else None, _stream())
+          _ptr(sums[0]) if bn is not None else None, _ptr(sums[1]) if bn is not None else None, _stat_ws(), _stream())
     if bn is None:
         return U
     return U, _bn_finalize(sums, M * k, C, bn)
@@ -1091,12 +1135,12 @@ def edge_bn_bwd(dOut, arg, k, X, st, act, slope, dense=None, dQ=None, xsel=None)
         _req(xsel, "xsel")
         _call(f"edge_bn_bwd[C={C}]", lib.lpd_edge_bn_bwd_sel, _ptr(dOut), ldo, _ptr(arg), _ptr(X), _ptr(xsel), _rows(xsel, "xsel"),
               _ptr(dX), k, M, C, _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(red[0]),
-              _ptr(red[1]), _stream())
+              _ptr(red[1]), _stat_ws(), _stream())
         redf = red.float()
         return dX, redf[1], redf[0]
     _call(f"edge_bn_bwd[C={C}]", lib.lpd_edge_bn_bwd, _ptr(dOut), ldo, _ptr(arg), _ptr(dense), _ptr(X), _ptr(dX), _ptr(dQ), ldq, k,
           M, C, _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(red[0]), _ptr(red[1]),
-          _stream())
+          _stat_ws(), _stream())
     redf = red.float()
     return dX, redf[1], redf[0]
 
@@ -1178,10 +1222,10 @@ def edge_split_fwd(P, Q, idx, N, bn):
             and bn.weight.data_ptr() % 16 == 0):
         # cloud-resident slices (the eval K-agg kernel's organisation): the k neighbour rows come from LDS, not through L2
         _call(f"edge_split_fwd[C={C}]", lib.lpd_edge_split_fwd16, _ptr(P), ldp, _ptr(Q), ldq, _ptr(pack_idx16(idx)), _ptr(bn.weight),
-              _ptr(S), _ptr(usel), _ptr(arg), M, N, C, k, _ptr(sums[0]), _ptr(sums[1]), _stream())
+              _ptr(S), _ptr(usel), _ptr(arg), M, N, C, k, _ptr(sums[0]), _ptr(sums[1]), _stat_ws(), _stream())
         return S, usel, arg, _bn_finalize(sums, M * k, C, bn)
     _call(f"edge_split_fwd[C={C}]", lib.lpd_edge_split_fwd, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(bn.weight), _ptr(S), _ptr(usel),
-          _ptr(arg), M, N, C, k, _ptr(sums[0]), _ptr(sums[1]), _stream())
+          _ptr(arg), M, N, C, k, _ptr(sums[0]), _ptr(sums[1]), _stat_ws(), _stream())
     return S, usel, arg, _bn_finalize(sums, M * k, C, bn)
 
 
@@ -1194,7 +1238,7 @@ def edge_split_bwd(dOut, usel, arg, S, P, Q, graph, st, act, slope, k, dP, dQ):
     lib = _lib.load()
     _call(f"edge_split_bwd[C={C}]", lib.lpd_edge_split_bwd, _ptr(dOut), ldo, _ptr(usel), _ptr(arg), _ptr(S), _ptr(P), ldp, _ptr(Q), ldq,
           _ptr(graph.rowptr), _ptr(graph.edges), _ptr(G), _ptr(dP), lddp, _ptr(dQ), lddq, M, C, k, _ptr(st.scale), _ptr(st.shift),
-          _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(red[0]), _ptr(red[1]), _stream())
+          _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(red[0]), _ptr(red[1]), _stat_ws(), _stream())
     redf = red.float()
     return redf[1], redf[0]
 
@@ -1210,7 +1254,7 @@ def edge_build_bf16(P, Q, idx, N, bn):
     sums = torch.empty((2, C), dtype=torch.float64, device=P.device)
     lib = _lib.load()
     _call(f"edge_build_bf16[C={C}]", lib.lpd_edge_build_bf16, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(U), M, N, C, k, _ptr(sums[0]),
-          _ptr(sums[1]), _stream())
+          _ptr(sums[1]), _stat_ws(), _stream())
     return U, _bn_finalize(sums, M * k, C, bn)
 
 
@@ -1255,7 +1299,7 @@ def group_sel_stats_bf16(Z, k, bn):
     sums = torch.empty((2, C), dtype=torch.float64, device=Z.device)
     lib = _lib.load()
     _call(f"group_sel_stats_bf16[C={C}]", lib.lpd_group_sel_stats_bf16, _ptr(Z), k, _ptr(bn.weight), _ptr(sel), C, _ptr(arg), M, C,
-          _ptr(sums[0]), _ptr(sums[1]), _stream())
+          _ptr(sums[0]), _ptr(sums[1]), _stat_ws(), _stream())
     return sel, arg, _bn_finalize(sums, M * k, C, bn)
 
 
@@ -1277,12 +1321,12 @@ def edge_bn_bwd_bf16(dOut, arg, k, X, st, act, slope, dense=None, dQ=None, xsel=
         _req(xsel, "xsel")
         _call(f"edge_bn_bwd_bf16[C={C}]", lib.lpd_edge_bn_bwd_bf16_sel, _ptr(dOut), ldo, _ptr(arg), _ptr(X), _ptr(xsel),
               _rows(xsel, "xsel"), _ptr(dX), k, M, C, _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope),
-              _ptr(red[0]), _ptr(red[1]), _stream())
+              _ptr(red[0]), _ptr(red[1]), _stat_ws(), _stream())
         redf = red.float()
         return dX, redf[1], redf[0]
     _call(f"edge_bn_bwd_bf16[C={C}]", lib.lpd_edge_bn_bwd_bf16, _ptr(dOut), ldo, _ptr(arg), _ptr(dense), _ptr(X), _ptr(dX), _ptr(dQ), ldq,
           k, M, C, _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(red[0]), _ptr(red[1]),
-          _stream())
+          _stat_ws(), _stream())
     redf = red.float()
     return dX, redf[1], redf[0]
 
@@ -1303,7 +1347,7 @@ def bn_sel_bwd_reduce(dOut, xsel, st, act, slope, dtype=torch.bfloat16):
     lib = _lib.load()
     _call(f"bn_sel_bwd_reduce[C={C}]", lib.lpd_bn_sel_bwd_reduce if dtype == torch.bfloat16 else lib.lpd_bn_sel_bwd_reduce_f32, _ptr(dOut),
           ldo, _ptr(xsel), _rows(xsel, "xsel"), M, C, _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope),
-          _ptr(dpre), _ptr(red[0]), _ptr(red[1]), _stream())
+          _ptr(dpre), _ptr(red[0]), _ptr(red[1]), _stat_ws(), _stream())
     return dpre, red
 
 

@@ -209,14 +209,17 @@ class PointNetVlad(nn.Module):
 
     def forward(self, x):
         trunk = self.emb_nn if self.emb_nn is not None else self.point_net
-        if (not self.training and engine.EVAL_CHUNK and isinstance(x, torch.Tensor) and x.dim() == 4
+        # the eval fast paths below need EVERY part in eval mode: after model.eval(); model.net_vlad.train() (or emb_nn.train()) each
+        # sub-module dispatches on its own flag, as the reference's nn.Modules do
+        all_eval = not (self.training or trunk.training or self.net_vlad.training)
+        if (all_eval and engine.EVAL_CHUNK and isinstance(x, torch.Tensor) and x.dim() == 4
                 and x.shape[2] <= 4096 and x.shape[0] * x.shape[2] > engine.EVAL_CHUNK * 4096):
             # eval-mode clouds are independent: large batches (evaluate.py:101-102 sends eval_batch_size * (1 + P + Ng) clouds) run
             # as slices whose [B*N, 1024] feature map stays inside the 256 MiB Infinity Cache + L2 working set the kernels are
             # tuned for (measured: 128 clouds in one piece 12.2 ms = 10.5 k descriptors/s, as 4 x 32 the 32-cloud rate)
             per = max(1, engine.EVAL_CHUNK * 4096 // x.shape[2])
             return torch.cat([self.forward(x[i:i + per]) for i in range(0, x.shape[0], per)], dim=0)
-        if not self.training and isinstance(trunk, LPDNet):
+        if all_eval and isinstance(trunk, LPDNet):
             # eval: conv3 and the NetVLAD assignment product share a launch where that is built (engine.lpdnet_features_eval)
             feat, B, N, parts = engine.lpdnet_features_eval(trunk, x, assign=self.net_vlad)
             if engine.DEBUG_AUX is not None:

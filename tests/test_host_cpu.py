@@ -124,7 +124,10 @@ def test_checkpoint_interop_with_the_reference_format(tmp_path):
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     sd0 = {k: v.clone() for k, v in m.state_dict().items()}
     ck = tmp_path / "3-model.ckpt"
-    harness.save_checkpoint(ck, torch.nn.DataParallel(m) if False else m, opt, epoch=3, total_iterations=1234, recall=81.5)
+    harness.save_checkpoint(ck, m, opt, epoch=3, total_iterations=1234, recall=81.5)
+    # ... and from an nn.DataParallel wrapper, whose `.module` the reference unwraps before saving (train_pointnetvlad.py:174-177)
+    harness.save_checkpoint(tmp_path / "wrapped.ckpt", torch.nn.DataParallel(m), opt, epoch=3, total_iterations=1234, recall=81.5)
+    assert list(torch.load(tmp_path / "wrapped.ckpt")["state_dict"]) == list(sd0)
     blob = torch.load(ck)
     assert set(blob) == {"epoch", "iter", "state_dict", "optimizer", "recall"} and blob["iter"] == 1234
     assert list(blob["state_dict"]) == list(sd0)

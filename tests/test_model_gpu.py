@@ -544,3 +544,178 @@ def test_documented_switches_are_live(cuda, env):
                                                                       os.path.join(root, "tests", "golden", "eval_lpdnet_b2_n4096.npz"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "golden rel" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------ the batch sizes that are BENCHED (missing 3)
+def _host_threads(n):
+    try:
+        return max(1, min(n, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(n, os.cpu_count() or 1))
+
+
+@pytest.mark.parametrize("B,N,k", [(32, 4096, 20), (8, 16384, 64)], ids=["cfg2_b32_n4096_k20", "cfg5_b8_n16384_k64"])
+def test_eval_benched_batches_vs_c_oracle(cuda, B, N, k):
+    """configs[1] at its benched batch (32 clouds: 256 persistent workgroups x 4 items, lpd_gemm_p8 on 32 clouds, the bound tables
+    of 32 clouds) and configs[4]'s shape at 8 clouds (windowed K-agg, tabulated bounds, 64-entry lists) against the plain-C
+    restatement of the whole reference path (oracle/lpd_forward.c, pinned to the reference's golden descriptors by
+    tests/test_oracle_golden.py): every descriptor within 1e-4, norm-relative."""
+    m, sd = _model("lpdnet", N, cuda)
+    m.emb_nn.k = k
+    x = torch.from_numpy(synth.cloud(1000 + B, B, N)).unsqueeze(1)
+    want, _ = orc.forward_lpdnet_c(sd, x, k=k, threads=_host_threads(B))
+    with torch.no_grad():
+        got = m(x.to(cuda))
+    assert got.shape == (B, 256)
+    assert _norm_rel(got, torch.from_numpy(want)) < DESC_TOL
+
+
+def test_eval_128_clouds_in_slices_equals_4x32_and_one_piece(cuda):
+    """evaluate.py:101-102 sends eval_batch_size * (1 + P + Ng) clouds; PointNetVlad.forward (eval) runs 128 x 4096 points as four
+    slices of engine.EVAL_CHUNK clouds.  The sliced forward = the four 32-cloud forwards (same launches: 1e-6, float atomics in
+    the NetVLAD column sums), the one-piece forward (EVAL_CHUNK = 0: other grid sizes, a 2 GiB feature map) agrees to 1e-5, and
+    8 of the 128 descriptors are held against the C oracle."""
+    from lpdnet_hip import engine
+    N, B = 4096, 128
+    m, sd = _model("lpdnet", N, cuda)
+    x = torch.from_numpy(synth.cloud(2100, B, N)).unsqueeze(1).to(cuda)
+    assert engine.EVAL_CHUNK == 32
+    with torch.no_grad():
+        sliced = m(x)
+        quarters = torch.cat([m(x[i:i + 32]) for i in range(0, B, 32)])
+        prev, engine.EVAL_CHUNK = engine.EVAL_CHUNK, 0
+        try:
+            whole = m(x)
+        finally:
+            engine.EVAL_CHUNK = prev
+    assert _norm_rel(sliced, quarters) < 1e-6
+    assert _norm_rel(whole, quarters) < 1e-5
+    pick = torch.arange(5, B, 16)
+    want, _ = orc.forward_lpdnet_c(sd, x[pick].cpu(), k=20, threads=_host_threads(len(pick)))
+    assert _norm_rel(sliced[pick], torch.from_numpy(want)) < DESC_TOL
+
+
+# ------------------------------------------------------------------ N4 on the GPU: checkpoint round trip of a TRAINED model
+def test_checkpoint_round_trip_of_a_trained_model(cuda, tmp_path):
+    """train_pointnetvlad.py:64-77,172-199 around the HIP model: two Adam steps, save_checkpoint from an nn.DataParallel wrapper
+    (the reference saves `model.module.state_dict()`), load_pretrained into a fresh model + optimizer -> identical eval
+    descriptors and an IDENTICAL third step (loss, updated weights, running statistics); the `module.`-prefixed .ckpt and the
+    bare .t7 forms load to the same weights."""
+    from lpdnet_hip import harness
+    from util.PointNetVlad import PointNetVlad
+    N, bq, P, Ng = 256, 2, 1, 2
+    per = 1 + P + Ng + 1
+    m, _ = _model("lpdnet", N, cuda)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    tup = [torch.from_numpy(synth.scene_cloud(70 + i, bq * per, N)).view(bq, per, N, 3) for i in range(3)]
+    for i in range(2):
+        harness.train_step(m, opt, tup[i][:, :1], tup[i][:, 1:1 + P], tup[i][:, 1 + P:1 + P + Ng], tup[i][:, -1:], margin_1=40.0, margin_2=20.0)
+    wrapped = torch.nn.DataParallel(m, device_ids=[cuda.index or 0])
+    ck = tmp_path / "2-model.ckpt"
+    harness.save_checkpoint(ck, wrapped, opt, epoch=2, total_iterations=2, recall=55.0)
+    blob = torch.load(ck, map_location="cpu")
+    assert list(blob["state_dict"]) == list(m.state_dict()) and not any(k.startswith("module.") for k in blob["state_dict"])
+    m2 = PointNetVlad(num_points=N, featnet="lpdnet").to(cuda)
+    opt2 = torch.optim.Adam(m2.parameters(), lr=1e-4)
+    assert harness.load_pretrained(m2, ck, opt2, map_location=cuda) == (3, 2)
+    xe = torch.from_numpy(synth.cloud(81, 5, N)).unsqueeze(1).to(cuda)
+    m.eval(), m2.eval()
+    with torch.no_grad():
+        assert _norm_rel(m2(xe), m(xe)) < 1e-6
+    losses = []
+    for mod, o in ((m, opt), (m2, opt2)):
+        t = tup[2]
+        losses.append(harness.train_step(mod, o, t[:, :1], t[:, 1:1 + P], t[:, 1 + P:1 + P + Ng], t[:, -1:], margin_1=40.0, margin_2=20.0).item())
+    assert losses[0] > 0 and abs(losses[0] - losses[1]) <= 1e-6 * abs(losses[0]), losses
+    sa, sb = m.state_dict(), m2.state_dict()
+    for key in sa:
+        a, b = sa[key].double(), sb[key].double()
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item()), key     # float atomics in a few reductions: not bitwise
+    # the two other file forms the reference reads (script.py:62-81; a path ending in "7" = bare state_dict, strict=False)
+    pref = dict(blob, state_dict={"module." + k: v for k, v in blob["state_dict"].items()})
+    torch.save(pref, tmp_path / "dp.ckpt")
+    torch.save(blob["state_dict"], tmp_path / "weights.t7")
+    for name in ("dp.ckpt", "weights.t7"):
+        m3 = PointNetVlad(num_points=N, featnet="lpdnet").to(cuda)
+        harness.load_pretrained(torch.nn.DataParallel(m3, device_ids=[cuda.index or 0]), tmp_path / name, map_location=cuda)
+        assert all(torch.equal(m3.state_dict()[k].cpu(), v) for k, v in blob["state_dict"].items()), name
+
+
+# ------------------------------------------------------------------ re-entrancy: two host threads on two streams
+def test_two_host_threads_on_two_streams(cuda):
+    """train_pointnetvlad.py:80 (nn.DataParallel) calls forward from one host thread per replica.  Two threads, each on its own
+    HIP stream, run concurrently: (A) eval forwards of ONE shared model from both threads with cold caches (folded BatchNorm
+    affines, weight fragments: filled by whichever thread comes first, read by the other across streams), (B) an eval forward in
+    one thread next to a train-mode forward + backward of another model in the other.  Results = the serial ones; a debug hook
+    set by one thread is invisible to the other."""
+    import threading
+    from lpdnet_hip import engine
+    N = 512
+    xs = [torch.from_numpy(synth.cloud(90 + i, 4, N)).unsqueeze(1).to(cuda) for i in range(2)]
+    xt = torch.from_numpy(synth.scene_cloud(95, 6, N)).unsqueeze(1).to(cuda)
+    m_ser, _ = _model("lpdnet", N, cuda)
+    mt_ser, _ = _model("lpdnet", N, cuda)
+    with torch.no_grad():
+        want = [m_ser(x) for x in xs]
+    mt_ser.train()
+    out = mt_ser(xt)
+    out.square().sum().backward()
+    want_train = (out.detach().clone(), {n: p.grad.clone() for n, p in mt_ser.named_parameters()})
+    torch.cuda.synchronize()
+
+    def run(fns):
+        res, errs = [None] * len(fns), []
+        barrier = threading.Barrier(len(fns))
+
+        def work(i):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream(device=cuda)):
+                    barrier.wait()
+                    res[i] = fns[i]()
+                    torch.cuda.current_stream().synchronize()
+            except Exception as exc:      # noqa: BLE001
+                errs.append(exc)
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(len(fns))]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+        return res
+    # (A) one shared model, cold caches, both threads in eval mode
+    for rep in range(3):
+        m_sh, _ = _model("lpdnet", N, cuda)
+        torch.cuda.synchronize()
+
+        def ev(i, m=m_sh):
+            with torch.no_grad():
+                return m(xs[i])
+        got = run([lambda: ev(0), lambda: ev(1)])
+        for g_, w_ in zip(got, want):
+            assert _norm_rel(g_, w_) < 1e-6
+    # (B) eval in one thread, train forward + backward of another model in the other; the eval thread sets a debug hook
+    m_ev, _ = _model("lpdnet", N, cuda)
+    mt, _ = _model("lpdnet", N, cuda)
+    mt.train()
+    seen = {}
+
+    def eval_side():
+        engine.DEBUG_AUX = {}
+        try:
+            with torch.no_grad():
+                r = [m_ev(xs[0]) for _ in range(3)][-1]
+            seen["eval_keys"] = sorted(engine.DEBUG_AUX)
+        finally:
+            engine.DEBUG_AUX = None
+        return r
+
+    def train_side():
+        seen["train_thread_hook"] = engine.DEBUG_AUX
+        o = mt(xt)
+        o.square().sum().backward()
+        return o.detach()
+    got_e, got_t = run([eval_side, train_side])
+    assert seen["train_thread_hook"] is None and "idx_feat" in seen["eval_keys"] and engine.DEBUG_AUX is None
+    assert _norm_rel(got_e, want[0]) < 1e-6
+    assert _norm_rel(got_t, want_train[0]) < 1e-5
+    for n, p in mt.named_parameters():
+        a, b = p.grad.double(), want_train[1][n].double()
+        assert ((a - b).norm() / b.norm().clamp_min(1e-30)).item() < 1e-4, n

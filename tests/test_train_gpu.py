@@ -464,7 +464,9 @@ def test_train_step0_cfg2_full_size_vs_reference(cuda, golden_dir, storage):
     step differ through a handful of feature-space kNN near-ties and the head's BatchNorms over the 44 batch rows whatever the
     precision: the reference's fp32 run sits 3.3e-4 (max over the 44 descriptors, norm-relative) / 7.3e-5 (median) from its fp64
     run, the fp32 oracle 6.8e-4 / 5.1e-5.  The fp32-storage path must be as close to fp64 as those are (max <= 1e-3, median
-    <= 1.5e-4); gradients against the reference's fp32 autograd at the gates of the small fixtures (1e-2 per tensor)."""
+    <= 1.5e-4), and -- the direct figure -- as close to the reference's fp32 descriptors as the reference's two precisions are to
+    each other (same gates; printed as `vs_ref32_*`); gradients against the reference's fp32 autograd at CFG2_GATES (fp32 storage:
+    5e-3 per tensor, median 2e-3; measured 1.7e-3 / 8e-4)."""
     from lpdnet_hip import autograd
     g = np.load(os.path.join(golden_dir, "train_lpdnet_bq2_p2_n18_n4096.npz"))
     bq, P, Ng, N = [int(v) for v in g["dims"]]
@@ -482,6 +484,8 @@ def test_train_step0_cfg2_full_size_vs_reference(cuda, golden_dir, storage):
     def nr(a):
         return ((a.double() - d64).abs().amax(dim=1) / d64.abs().amax(dim=1))
     e_ref, e_gpu = nr(torch.from_numpy(g["desc"])), nr(out.detach().cpu())
+    d32 = torch.from_numpy(g["desc"]).double()             # the reference's own fp32 run: GPU fp32 vs reference fp32, directly
+    e_32 = (out.detach().cpu().double() - d32).abs().amax(dim=1) / d32.abs().amax(dim=1)
     q, p, n, o = torch.split(d64.view(bq, -1, 256), [1, P, Ng, 1], dim=1)
     loss64 = orc.quadruplet_loss(q, p, n, o, 0.5, 0.2, use_min=True, lazy=True, ignore_zero_loss=False).item()
     loss_err = abs(loss.item() - loss64) / abs(loss64)
@@ -506,13 +510,15 @@ def test_train_step0_cfg2_full_size_vs_reference(cuda, golden_dir, storage):
         if key.startswith("buf/"):
             buf = dict(m.named_buffers())[key[4:]].cpu().numpy()
             berr = max(berr, float(np.abs(buf - g[key]).max() / (np.abs(g[key]).max() + 1e-6)))
-    _cfg2_report(storage, desc_max=e_gpu.max().item(), desc_median=e_gpu.median().item(), ref_max=e_ref.max().item(),
+    _cfg2_report(storage, vs_ref32_max=e_32.max().item(), vs_ref32_median=e_32.median().item(),
+                 desc_max=e_gpu.max().item(), desc_median=e_gpu.median().item(), ref_max=e_ref.max().item(),
                  ref_median=e_ref.median().item(), loss=loss.item(), loss64=loss64, loss_err=loss_err, ref_loss_err=ref_loss_err,
                  grad_max=max(errs.values()), grad_median=float(np.median(list(errs.values()))), l2_max=max(l2errs.values()),
                  probe_max=max(perr.values()), running_stats=berr,
                  worst=sorted(((round(e, 5), n_) for n_, e in errs.items()), reverse=True)[:4])
     desc_max, desc_med, loss_tol, g_tol, g_med = CFG2_GATES[storage]
     assert e_gpu.max().item() < desc_max and e_gpu.median().item() < desc_med, (e_gpu.max().item(), e_gpu.median().item())
+    assert e_32.max().item() < desc_max and e_32.median().item() < desc_med, ("vs reference fp32", e_32.max().item(), e_32.median().item())
     assert loss_err < loss_tol, (loss.item(), loss64)
     assert max(errs.values()) < g_tol and float(np.median(list(errs.values()))) < g_med, errs
     assert max(l2errs.values()) < g_tol, l2errs

@@ -55,7 +55,11 @@ for impl in (0, 5, 6):
     print("impl", impl, "p8 panels median/min us", timeit(lambda: ops.gemm_p8(S, W, scale=sc, shift=sh, act=ops.ACT_LEAKY, out=outp, out_panels=True)))
 for impl, name in ((8, "no LDS-DMA in the loop"), (16, "no MFMAs (6 units ahead)"), (16 + 5, "no MFMAs (5 units ahead)"), (24, "neither (reads + barriers + stores)"), (32, "full, nt loads"), (64, "full, every phase's 12 MFMAs issued twice"), (96, "full, WITH s_setprio around the MFMAs"), (128, "full, NO output stores")):
     ops.P8_IMPL = impl
-    print("timing-only:", name, timeit(lambda: ops.gemm_p8(S, W, shift=sh, act=ops.ACT_LEAKY, out=outr)))
+    try:
+        print("timing-only:", name, timeit(lambda: ops.gemm_p8(S, W, shift=sh, act=ops.ACT_LEAKY, out=outr)))
+    except Exception as exc:      # the product library rejects them: rebuild with LPD_EXTRA_FLAGS=-DLPD_P8_BENCH python -m lpdnet_hip._build
+        print("timing-only variants are not in this build (LPD_EXTRA_FLAGS=-DLPD_P8_BENCH):", str(exc).splitlines()[0])
+        break
 ops.P8_IMPL = 0
 print("x3w (current conv3)    median/min us", timeit(lambda: ops.gemm(P, W, b_kmajor=False, a_panels=True, scale=sc, shift=sh, act=ops.ACT_LEAKY, out=outr)))
 print("split_panels           median/min us", timeit(lambda: ops.split_panels(P, out=S)))
