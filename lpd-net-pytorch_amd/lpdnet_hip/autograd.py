@@ -12,6 +12,36 @@ from .ops import _ptr, _req, _stream
 
 
 # ------------------------------------------------------------------------------------------------
+# The measurement / test hooks (ops.PROFILE, ops.PROFILE_ONLY, engine.DEBUG_AUX) are per host thread, and autograd runs a CUDA
+# node's backward on ITS OWN worker thread: every Function remembers the hooks of the thread that ran its forward and its backward
+# runs under them, so that a profile or a debug dict opened around `loss.backward()` sees the backward's launches -- and nobody else's.
+# ------------------------------------------------------------------------------------------------
+def _hooked_forward(fn):
+    def forward(ctx, *args):
+        from . import engine
+        ctx._lpd_hooks = (ops._TLS.PROFILE, ops._TLS.PROFILE_ONLY, engine._TLS.DEBUG_AUX)
+        return fn(ctx, *args)
+    forward.__doc__ = fn.__doc__
+    return forward
+
+
+def _hooked_backward(fn):
+    def backward(ctx, *grads):
+        from . import engine
+        hooks = getattr(ctx, "_lpd_hooks", None)
+        if hooks is None or hooks == (None, None, None):
+            return fn(ctx, *grads)
+        prev = (ops._TLS.PROFILE, ops._TLS.PROFILE_ONLY, engine._TLS.DEBUG_AUX)
+        ops._TLS.PROFILE, ops._TLS.PROFILE_ONLY, engine._TLS.DEBUG_AUX = hooks
+        try:
+            return fn(ctx, *grads)
+        finally:
+            ops._TLS.PROFILE, ops._TLS.PROFILE_ONLY, engine._TLS.DEBUG_AUX = prev
+    backward.__doc__ = fn.__doc__
+    return backward
+
+
+# ------------------------------------------------------------------------------------------------
 # losses (loss/pointnetvlad_loss.py)
 # ------------------------------------------------------------------------------------------------
 def _rows3(t, name):
@@ -25,6 +55,7 @@ def _rows3(t, name):
 
 class _MetricLoss(torch.autograd.Function):
     @staticmethod
+    @_hooked_forward
     def forward(ctx, q, pos, neg, other, m1, m2, use_min, lazy, ignore_zero, quad):
         q, pos, neg = _rows3(q, "q_vec"), _rows3(pos, "pos_vecs"), _rows3(neg, "neg_vecs")
         if quad:
@@ -51,6 +82,7 @@ class _MetricLoss(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @_hooked_backward
     def backward(ctx, g):
         gq, gpos, gneg, gother = ctx.saved_tensors
         return (g * gq, g * gpos, g * gneg, (g * gother) if ctx.quad else None, None, None, None, None, None, None)
@@ -64,12 +96,14 @@ class _BestPos(torch.autograd.Function):
     """(min_pos, max_pos) of loss/pointnetvlad_loss.py:6-12 with their gradients: d min_pos / dq = -2 (pos_argmin - q), etc."""
 
     @staticmethod
+    @_hooked_forward
     def forward(ctx, query, pos_vecs):
         mn, mx = _best_pos_values(query, pos_vecs)
         ctx.save_for_backward(query, pos_vecs)
         return mn, mx
 
     @staticmethod
+    @_hooked_backward
     def backward(ctx, gmin, gmax):
         query, pos = ctx.saved_tensors
         q, p = _rows3(query, "query"), _rows3(pos, "pos_vecs")
@@ -382,6 +416,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
               "bn3_lpd.weight", "bn3_lpd.bias")
 
     @staticmethod
+    @_hooked_forward
     def forward(ctx, net, x, *params):
         if TRAIN_STORAGE == "bf16":      # bf16 mode: the dense products behind the kNN take bf16 operands (one MFMA product)
             with ops.bf16_gemm():
@@ -437,6 +472,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         return feat
 
     @staticmethod
+    @_hooked_backward
     def backward(ctx, dfeat):
         if ctx.bf16:
             with ops.bf16_gemm():
@@ -561,6 +597,7 @@ class _LPDNetOrignTrainFn(torch.autograd.Function):
                    for leaf in ("0.weight", "1.weight", "1.bias"))
 
     @staticmethod
+    @_hooked_forward
     def forward(ctx, net, x, *params):
         with ops.train_forward_gemm(x.shape[0]):
             return _LPDNetOrignTrainFn._forward(ctx, net, x, *params)
@@ -602,6 +639,7 @@ class _LPDNetOrignTrainFn(torch.autograd.Function):
         return feat
 
     @staticmethod
+    @_hooked_backward
     def backward(ctx, dfeat):
         from . import engine
         net, S = ctx.net, _saved(ctx)
@@ -677,6 +715,7 @@ class _PointNetTrainFn(torch.autograd.Function):
         return names
 
     @staticmethod
+    @_hooked_forward
     def forward(ctx, net, x, *params):
         with ops.train_forward_gemm(x.shape[0]):
             return _PointNetTrainFn._forward(ctx, net, x, *params)
@@ -702,6 +741,7 @@ class _PointNetTrainFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_hooked_backward
     def backward(ctx, dfeat):
         net, S = ctx.net, _saved(ctx)
         B, N = ctx.dims
@@ -742,11 +782,13 @@ class _ToPointMajor(torch.autograd.Function):
     inside PointNetVlad the trunk hands its rows over directly)."""
 
     @staticmethod
+    @_hooked_forward
     def forward(ctx, x3):
         ctx.shape = x3.shape
         return ops.transpose(x3).view(x3.shape[0] * x3.shape[2], x3.shape[1])
 
     @staticmethod
+    @_hooked_backward
     def backward(ctx, d):
         B, E, N = ctx.shape
         return ops.transpose(d.contiguous().view(B, N, E))
@@ -756,11 +798,13 @@ class _ToChannelMajor(torch.autograd.Function):
     """[B*N, E] point-major rows -> the reference's [B, E, N, 1] with a gradient (the public trunk forwards in train mode)"""
 
     @staticmethod
+    @_hooked_forward
     def forward(ctx, feat, B, N):
         ctx.dims = (B, N, feat.shape[1])
         return ops.transpose(feat.view(B, N, feat.shape[1])).unsqueeze(-1)
 
     @staticmethod
+    @_hooked_backward
     def backward(ctx, d):
         B, N, E = ctx.dims
         return ops.transpose(d.reshape(B, E, N).contiguous()).view(B * N, E), None, None
@@ -786,12 +830,14 @@ class _CloudMaxFn(torch.autograd.Function):
     """per-cloud max over the N points of point-major rows [B*N, C] -> [B, C] (MaxPool2d((num_points,1)), PointNetVlad.py:235)"""
 
     @staticmethod
+    @_hooked_forward
     def forward(ctx, feat, B, N):
         out, arg = ops.colmax_arg(feat, B, N)
         ctx.arg, ctx.N = arg, N
         return out
 
     @staticmethod
+    @_hooked_backward
     def backward(ctx, dout):
         return ops.colmax_bwd(dout.contiguous(), ctx.arg, ctx.N), None, None
 
@@ -823,6 +869,7 @@ class _NetVLADTrainFn(torch.autograd.Function):
         return names
 
     @staticmethod
+    @_hooked_forward
     def forward(ctx, vlad, B, N, feat, *params):
         ctx.bf16 = TRAIN_STORAGE == "bf16"
         if ctx.bf16:      # the big per-point products (assignment, pooling) take bf16 operands; the B-row head products stay
@@ -873,6 +920,7 @@ class _NetVLADTrainFn(torch.autograd.Function):
         return ops.mul(h[:B], gates[:B])
 
     @staticmethod
+    @_hooked_backward
     def backward(ctx, dout):
         if ctx.bf16:
             with ops.bf16_gemm():
@@ -951,6 +999,7 @@ class _TNetTrainFn(torch.autograd.Function):
     """rows [B*N, kd] point-major -> [B, kd, kd]; the layers, BatchNorm statistics and backward of _TNet"""
 
     @staticmethod
+    @_hooked_forward
     def forward(ctx, net, use_bn, B, N, rows, *params):
         t, S = _TNet.fwd(net, rows, B, N, use_bn)
         ctx.net, ctx.use_bn, ctx.dims, ctx.saved = net, use_bn, (B, N), S
@@ -958,6 +1007,7 @@ class _TNetTrainFn(torch.autograd.Function):
         return t
 
     @staticmethod
+    @_hooked_backward
     def backward(ctx, dt):
         B, N = ctx.dims
         dh, grads = _TNet.bwd(ctx.net, dt.contiguous(), _saved(ctx), B, N, ctx.use_bn, need_dh=ctx.need_dh)
@@ -974,6 +1024,7 @@ class _GatingTrainFn(torch.autograd.Function):
     """out = x * sigmoid(BN_train(x Wg)) (or sigmoid(x Wg + bias)); rows padded to a multiple of 32 like the head's"""
 
     @staticmethod
+    @_hooked_forward
     def forward(ctx, gc, x, *params):
         B, O = x.shape
         Bp = (B + 31) // 32 * 32
@@ -992,6 +1043,7 @@ class _GatingTrainFn(torch.autograd.Function):
         return ops.mul(h[:B], gates[:B])
 
     @staticmethod
+    @_hooked_backward
     def backward(ctx, dout):
         gc, S = ctx.gc, _saved(ctx)
         B, O, Bp = ctx.dims
