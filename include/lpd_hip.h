@@ -387,9 +387,13 @@ int lpd_group_max_bwd(const float* dOut, long long ldo, const uint8_t* arg, int 
  * dQ[i] = sum_t dX[(i,t)] (optional, the centre-term gradient) and the fp64 reductions dbeta/dgamma [C]. */
 int lpd_edge_bn_bwd(const float* dOut, long long ldo, const uint8_t* arg, const float* dDense, const float* X, float* dX,
                     float* dQ, long long ldq, int k, long long M, int C, const float* scale, const float* shift,
-                    const float* mean, const float* invstd, int act, float slope, double* dbeta, double* dgamma,
+                    const float* mean, const float* invstd, int act, float slope, float inv_ns, double* dbeta, double* dgamma,
                     double* stat_ws, void* stream);
-/* The arg-max-only form (no dense gradient, no dQ) with the raw selected values Xsel [M][ldsel] the forward kept
+/* inv_ns (lpd_edge_bn_bwd, lpd_edge_bn_bwd_bf16): 0 = X holds the raw pre-BatchNorm values.  > 0 (dense form, act none / LeakyReLU with
+ * negative slope 1 / inv_ns): X holds the POST-activation values Y = act(BN(U)) -- what lpd_edge_mlp_train stores instead of U -- and
+ * the pre-activation is recovered as y (y > 0) or y * inv_ns; `mean` then carries the BatchNorm bias beta and `invstd` 1 / gamma
+ * (xhat = (pre - beta) / gamma), `scale` stays gamma * invstd.
+ * The arg-max-only form (no dense gradient, no dQ) with the raw selected values Xsel [M][ldsel] the forward kept
  * (lpd_group_max_sel): the dbeta / dgamma reduction is an [M][C] pass instead of a gather from the edge tensor. */
 int lpd_edge_bn_bwd_sel(const float* dOut, long long ldo, const uint8_t* arg, const float* X, const float* Xsel, long long ldsel,
                         float* dX, int k, long long M, int C, const float* scale, const float* shift, const float* mean,
@@ -449,6 +453,19 @@ int lpd_vlad_finalize_bwd(const float* dOut, const float* v, const float* inv_c,
 int lpd_edge_split_fwd(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, const float* gamma,
                        float* S, float* usel, uint8_t* arg, long long M, int N, int C, int k, double* sum, double* sumsq,
                        double* stat_ws, void* stream);
+/*
+ * Train-mode DG1 -> DG2 stage in ONE launch (util/lpdnet_model.py:249-252 under batch statistics), replacing
+ * lpd_edge_build + lpd_edge_act_max + the [E,128] x [128,128] product + lpd_group_max / lpd_group_sel_stats_bf16:
+ *   Y1e[(i,t)][:] = act(s1 (P[nbr(i,t)] + Q[i]) + b1)   (s1 / b1 = BatchNorm1 scale / shift of THIS batch: lpd_edge_split_fwd gives the
+ *                   statistics of U = P[nbr] + Q without writing U, and x1 = max_t Y1e with its arg-max through act(s1 usel + b1))
+ *   Z = Y1e W2^T (raw), sum / sumsq = its column statistics (fp64, zeroed here), zsel[i][c] = max_t Z (gamma2[c] >= 0) or min_t Z,
+ *   arg2[i][c] = the first slot t that attains it.
+ * bf16 != 0: Y1e and Z are bf16 tensors (bf16 storage mode) and the product takes the rounded Y1e (two MFMA products with the split
+ * weight); else fp32 tensors and three split-bf16 products.  128 -> 128 channels, M % 64 == 0, N % 64 == 0, k <= 255.
+ */
+int lpd_edge_mlp_train(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1, const float* b1,
+                       const float* W2, const float* gamma2, void* Y1e, void* Z, int bf16, float* zsel, int ldsel, uint8_t* arg2,
+                       double* sum, double* sumsq, int M, int N, int k, int act, float slope, double* stat_ws, void* stream);
 /* The same on cloud-resident slices (the organisation of lpd_edge_gather_max16: a block holds an 8-channel slice of a whole cloud in
  * LDS and gathers the k neighbour pieces from there): idx16 from lpd_pack_idx16; k = 20, N <= 4096, C % 8 == 0.  S, usel, arg are
  * bit-identical to lpd_edge_split_fwd, the statistics equal up to the order of the fp64 additions. */
@@ -490,7 +507,8 @@ int lpd_group_sel_stats_bf16(const uint16_t* Z, int k, const float* gamma, float
 /* lpd_edge_bn_bwd on bf16 tensors (dDense optional; dX may alias dDense) */
 int lpd_edge_bn_bwd_bf16(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* dDense, const uint16_t* X, uint16_t* dX,
                          float* dQ, long long ldq, int k, long long M, int C, const float* scale, const float* shift,
-                         const float* mean, const float* invstd, int act, float slope, double* dbeta, double* dgamma, double* stat_ws, void* stream);
+                         const float* mean, const float* invstd, int act, float slope, float inv_ns, double* dbeta, double* dgamma,
+                         double* stat_ws, void* stream);
 /* arg-max-only form with the raw selected values of lpd_group_sel_stats_bf16 (cf. lpd_edge_bn_bwd_sel) */
 int lpd_edge_bn_bwd_bf16_sel(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* X, const float* Xsel, long long ldsel,
                              uint16_t* dX, int k, long long M, int C, const float* scale, const float* shift, const float* mean,

@@ -923,6 +923,207 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// TRAIN-mode DG1 -> DG2 stage in one launch (util/lpdnet_model.py:249-252 with batch statistics): the organisation of
+// edge_mlp_x3_kernel<128, 128> with the tensors the backward pass needs written on the way --
+//   Y1e[(i,t)][c] = act(s1 (P[nbr(i,t)] + Q[i]) + b1)          (s1, b1: BatchNorm1 scale / shift of THIS batch, from the split-form
+//                                                               statistics pass lpd_edge_split_fwd: the raw edge tensor U is never written)
+//   Z = Y1e W2^T (raw)                                          stored from the accumulators, row (i, t)
+//   sum Z, sum Z^2 per channel (fp32 per lane over the block's 64 x k rows, fp64 across blocks through the replicas)
+//   zsel[i][c] = sel_t Z[(i,t)][c], arg2[i][c] = first t that attains it (sel = max where gamma2[c] >= 0, min otherwise: the
+//   selection needs the SIGN of the BatchNorm2 scale only, which is known before the statistics)
+// BF16 = bf16 storage (autograd.set_train_storage("bf16")): Y1e and Z are stored as bf16, the product takes the ROUNDED Y1e as its
+// operand (a_hi only) against the split weight (two MFMA products, as lpd_gemm_bf16s); fp32 storage: three split-bf16 products.
+// x1 = max_t Y1e and its arg-max come from the statistics pass (the activation is monotone), not from here: the running maximum
+// of 64 points x 128 channels would not fit the register budget of two workgroups per CU.
+// ------------------------------------------------------------------------------------------
+struct EdgeMlpTrainArgs {
+    const float* P; const float* Q; const int32_t* idx;
+    const float* s1; const float* b1; const float* W2; const float* gamma2;
+    void* Y; void* Z;            // [M k][128] bf16 or fp32
+    float* zsel; uint8_t* arg2;  // [M][ldsel], [M][128]
+    double* sum; double* sumsq;  // replicas (lpd_common.h)
+    int M, N, k, ldp, ldq, ldsel, act;
+    float slope;
+};
+
+typedef unsigned em_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned em_u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool BF16>
+__global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_kernel(EdgeMlpTrainArgs g)
+{
+    constexpr int CM = 128;
+    using Cfg = EdgeMlpX3Cfg<CM, CM>;
+    constexpr int LDK = Cfg::LDK, IMG = Cfg::IMG, KS = Cfg::KS, PASSES = Cfg::PASSES, NIMG = BF16 ? 1 : 2;
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];   // [2 buffers][hi (| lo)][64][LDK], then idx
+    int* idxs = reinterpret_cast<int*>(smem16 + 2 * NIMG * IMG);      // [EM_PTS][k]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    const int m0 = lpd_xcd_remap(blockIdx.x, gridDim.x) * EM_PTS;    // M % 64 == 0 (host check)
+    const int n = wave * 32 + col;                                   // this lane's output channel
+    const float sgn = g.gamma2[n] >= 0.f ? 1.0f : -1.0f;
+    em_bf16x8 b_hi[KS], b_lo[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const float4 w0 = *reinterpret_cast<const float4*>(g.W2 + (size_t)n * CM + s * 16 + h * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(g.W2 + (size_t)n * CM + s * 16 + h * 8 + 4);
+        em_bf16x4 h0, l0, h1, l1;
+        em_split4(sgn * w0.x, sgn * w0.y, sgn * w0.z, sgn * w0.w, h0, l0);
+        em_split4(sgn * w1.x, sgn * w1.y, sgn * w1.z, sgn * w1.w, h1, l1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b_hi[s][e] = h0[e]; b_hi[s][4 + e] = h1[e]; b_lo[s][e] = l0[e]; b_lo[s][4 + e] = l1[e]; }
+    }
+    for (int f = tid; f < EM_PTS * g.k; f += EM_THREADS) {
+        const int p = f / g.k, t = f - p * g.k;
+        const int m = m0 + p;
+        idxs[f] = (m / g.N) * g.N + g.idx[(size_t)m * g.k + t];
+    }
+    const int c4 = tid % Cfg::F4_PER_ROW, prow = tid / Cfg::F4_PER_ROW;
+    const float4 s1 = *reinterpret_cast<const float4*>(g.s1 + c4 * 4);
+    const float4 b1 = *reinterpret_cast<const float4*>(g.b1 + c4 * 4);
+    const float ns = lpd_neg_slope(g.act, g.slope);
+    const float pinf = em_opaque_inf();
+    const em_f32x2 s1a = {s1.x, s1.y}, s1b = {s1.z, s1.w}, ns2 = {ns, ns};
+    float4 qc[PASSES];
+#pragma unroll
+    for (int e = 0; e < PASSES; ++e) {
+        const int m = m0 + prow + Cfg::ROWS_PER_PASS * e;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.Q) q = *reinterpret_cast<const float4*>(g.Q + (size_t)m * g.ldq + c4 * 4);
+        qc[e] = make_float4(s1.x * q.x + b1.x, s1.y * q.y + b1.y, s1.z * q.z + b1.z, s1.w * q.w + b1.w);
+    }
+    __syncthreads();
+
+    float4 pg[PASSES];
+    auto gather = [&](int t) {
+#pragma unroll
+        for (int e = 0; e < PASSES; ++e) {
+            const int row = idxs[(prow + Cfg::ROWS_PER_PASS * e) * g.k + t];
+            pg[e] = *reinterpret_cast<const float4*>(g.P + (size_t)row * g.ldp + c4 * 4);
+        }
+    };
+    constexpr int ES = BF16 ? 2 : 4;                                       // bytes per stored element
+    // The block's slabs of Y1e and Z (64 k rows) as buffer resources: a store is (resource, this thread's constant 32-bit offset,
+    // scalar offset of the row) -- with flat pointers the compiler kept a 64-bit address register per store of the unrolled
+    // epilogue (85-100 spilled registers)
+    const unsigned slab = (unsigned)EM_PTS * (unsigned)g.k * (CM * ES);
+    const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<unsigned char*>(g.Y) + (size_t)m0 * g.k * (CM * ES), 0, slab, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zres = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<unsigned char*>(g.Z) + (size_t)m0 * g.k * (CM * ES), 0, slab, 0x00020000);
+    const unsigned rowb = (unsigned)g.k * (CM * ES);                       // bytes between consecutive POINTS' rows of one slot
+    const unsigned yoff = ((unsigned)prow * (unsigned)g.k * CM + c4 * 4) * ES;       // M k 128 ES < 2^32 (host check)
+    const unsigned zoff = ((unsigned)(4 * h) * (unsigned)g.k * CM + (BF16 ? (n & ~1) : n)) * ES;
+    // slot t's tile into LDS buffer `buf` AND its rows (i, t) into Y1e: 32 threads (c4) cover one 256- / 512-byte row
+    auto build = [&](int buf, int t) {
+        __bf16* hi_img = smem16 + buf * NIMG * IMG;
+#pragma unroll
+        for (int e = 0; e < PASSES; ++e) {
+            const int p = prow + Cfg::ROWS_PER_PASS * e;
+            const em_f32x2 ya = __builtin_elementwise_fma(s1a, (em_f32x2){pg[e].x, pg[e].y}, (em_f32x2){qc[e].x, qc[e].y});
+            const em_f32x2 yb = __builtin_elementwise_fma(s1b, (em_f32x2){pg[e].z, pg[e].w}, (em_f32x2){qc[e].z, qc[e].w});
+            const em_f32x2 na = ns2 * ya, nb = ns2 * yb;
+            const float y0 = em_vmax(ya[0], na[0], pinf), y1 = em_vmax(ya[1], na[1], pinf), y2 = em_vmax(yb[0], nb[0], pinf),
+                        y3 = em_vmax(yb[1], nb[1], pinf);
+            // uniform base (scalar registers) + this thread's constant 32-bit offset: no 64-bit address register per store
+            const unsigned ysoff = (unsigned)(Cfg::ROWS_PER_PASS * e) * rowb + (unsigned)t * (CM * ES);      // uniform
+            uint2 hh, ll;
+            em_split4_packed(y0, y1, y2, y3, hh, ll);
+            *reinterpret_cast<uint2*>(hi_img + p * LDK + c4 * 4) = hh;
+            if constexpr (BF16) {
+                __builtin_amdgcn_raw_buffer_store_b64((em_u32x2){hh.x, hh.y}, yres, yoff, ysoff, 0);
+            } else {
+                *reinterpret_cast<uint2*>(hi_img + IMG + p * LDK + c4 * 4) = ll;
+                __builtin_amdgcn_raw_buffer_store_b128((em_u32x4){__float_as_uint(y0), __float_as_uint(y1), __float_as_uint(y2), __float_as_uint(y3)},
+                                                       yres, yoff, ysoff, 0);
+            }
+        }
+    };
+
+    f32x16 zmax[2];
+    uint32_t arg2w[2][4];        // byte (r & 3) of word r >> 2: slot of the running extremum of accumulator element r
+    float ssum = 0.0f, ssq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zmax[i][r] = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) arg2w[i][w] = 0u;
+    }
+    gather(0);
+    build(0, 0);
+    __syncthreads();
+
+    for (int t = 0; t < g.k; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < g.k) gather(t + 1);
+        const __bf16* ah = smem16 + buf * NIMG * IMG + col * LDK + h * 8;
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const em_bf16x8 a_hi = *reinterpret_cast<const em_bf16x8*>(ah + i * 32 * LDK + s * 16);
+                if constexpr (!BF16) {
+                    const em_bf16x8 a_lo = *reinterpret_cast<const em_bf16x8*>(ah + IMG + i * 32 * LDK + s * 16);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi[s], acc[i], 0, 0, 0);
+                }
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo[s], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi[s], acc[i], 0, 0, 0);
+            }
+        }
+        // acc = sgn * Z tile: rows = points (i, r -> i * 32 + (r & 3) + 8 (r >> 2) + 4 h), column = this lane's channel n
+        const uint32_t tb = (uint32_t)t;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][r];
+                const unsigned zsoff = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rowb + (unsigned)t * (CM * ES);      // uniform
+                const float z = sgn * v;
+                if constexpr (BF16) {
+                    // the stored value is the rounded one; statistics and selection are taken of the fp32 value (as lpd_gemm_bf16s +
+                    // lpd_group_sel_stats_bf16 take them of the stored one: the difference is the 2^-9 the storage mode states)
+                    const __bf16 zb = (__bf16)z;
+                    const unsigned mine = __builtin_bit_cast(unsigned short, zb);
+                    const unsigned other = lpd_lane_xor1(mine);
+                    if (!(col & 1)) __builtin_amdgcn_raw_buffer_store_b32(mine | (other << 16), zres, zoff, zsoff, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z), zres, zoff, zsoff, 0);
+                }
+                ssum += v;
+                ssq = fmaf(v, v, ssq);
+                const bool gt = v > zmax[i][r];
+                zmax[i][r] = em_vmax(zmax[i][r], v, pinf);
+                const uint32_t sh8 = 8u * (r & 3);
+                const uint32_t cand = (arg2w[i][r >> 2] & ~(0xffu << sh8)) | (tb << sh8);
+                arg2w[i][r >> 2] = gt ? cand : arg2w[i][r >> 2];
+            }
+        if (t + 1 < g.k) build(buf ^ 1, t + 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            g.zsel[(size_t)m * g.ldsel + n] = sgn * zmax[i][r];
+            g.arg2[(size_t)m * CM + n] = (uint8_t)((arg2w[i][r >> 2] >> (8 * (r & 3))) & 0xffu);
+        }
+    // column statistics of Z: the two half-waves hold disjoint rows of the same channel
+    ssum += __shfl_xor(ssum, 32);
+    ssq += __shfl_xor(ssq, 32);
+    if (h == 0) {
+        atomicAdd(&g.sum[lpd_stat_rofs() + n], (double)(sgn * ssum));
+        atomicAdd(&g.sumsq[lpd_stat_rofs() + n], (double)ssq);
+    }
+}
+
 template <int CM, int CO>
 int edge_mlp_x3_launch(const EdgeMlpArgs& g, hipStream_t stream)
 {
@@ -1094,6 +1295,38 @@ extern "C" int lpd_edge_mlp_bf16x3s(const float* P, int ldp, const float* Q, int
     LPD_CHECK_ARG(out_lo != 0 && out_cloud != 0, "lpd_edge_mlp_bf16x3s: split output needs cloud panels and a lo-plane offset");
     return edge_mlp_entry(true, P, ldp, Q, ldq, idx, s1, b1, W2, s2, b2, reinterpret_cast<float*>(out_hi), 8, M, N, CM, CO, k, act, slope,
                           out_cloud, panel_ld, stream, out_lo);
+}
+
+// Train-mode DG1 -> DG2 stage in one launch (edge_mlp_train_kernel): Y1e, Z (raw), the statistics of Z, the selected raw values and
+// their slots.  bf16 != 0: Y1e / Z are bf16 tensors.  M % 64 == 0, N % 64 == 0, 128 -> 128 channels, k <= 255.
+extern "C" int lpd_edge_mlp_train(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1, const float* b1,
+                                  const float* W2, const float* gamma2, void* Y1e, void* Z, int bf16, float* zsel, int ldsel,
+                                  uint8_t* arg2, double* sum, double* sumsq, int M, int N, int k, int act, float slope, double* stat_ws,
+                                  void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(P && idx && s1 && b1 && W2 && gamma2 && Y1e && Z && zsel && arg2 && sum && sumsq, "lpd_edge_mlp_train: null pointer");
+    LPD_CHECK_ARG(M > 0 && N > 0 && M % N == 0 && M % EM_PTS == 0 && N % EM_PTS == 0 && k > 0 && k <= 255,
+                  "lpd_edge_mlp_train: M=%d N=%d k=%d unsupported (multiples of 64, k <= 255)", M, N, k);
+    LPD_CHECK_ARG(act >= 0 && act <= 2 && (act != 2 || (slope >= 0.0f && slope <= 1.0f)), "lpd_edge_mlp_train: activation unsupported");
+    LPD_CHECK_ARG((unsigned long long)64 * k * 128 * 4 < (1ull << 31), "lpd_edge_mlp_train: k too large");
+    LPD_CHECK_ARG(ldp % 4 == 0 && (!Q || ldq % 4 == 0), "lpd_edge_mlp_train: leading dims must be multiples of 4");
+    LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)Q | (uintptr_t)s1 | (uintptr_t)b1 | (uintptr_t)W2 | (uintptr_t)Y1e | (uintptr_t)Z) & 15) == 0,
+                  "lpd_edge_mlp_train: pointers must be 16-byte aligned");
+    const LpdStatWs ws = lpd_stat_arg(stat_ws);
+    LPD_CHECK_ARG(ws.rep, "lpd_edge_mlp_train: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
+    EdgeMlpTrainArgs g{P, Q, idx, s1, b1, W2, gamma2, Y1e, Z, zsel, arg2, ws.sum(), ws.sumsq(), M, N, k, ldp, ldq, ldsel, act, slope};
+    using Cfg = EdgeMlpX3Cfg<128, 128>;
+    const size_t lds = (size_t)(bf16 ? 2 : 4) * Cfg::IMG * sizeof(__bf16) + (size_t)EM_PTS * k * sizeof(int);
+    if (bf16) {
+        (void)hipFuncSetAttribute((const void*)edge_mlp_train_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(edge_mlp_train_kernel<true>, dim3(M / EM_PTS), dim3(EM_THREADS), lds, stream, g);
+    } else {
+        (void)hipFuncSetAttribute((const void*)edge_mlp_train_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(edge_mlp_train_kernel<false>, dim3(M / EM_PTS), dim3(EM_THREADS), lds, stream, g);
+    }
+    LPD_CHECK_LAUNCH("lpd_edge_mlp_train");
+    return lpd_stat_finish(ws, sum, sumsq, 128, stream);
 }
 
 // Training forward of the split-form edge stage on cloud-resident slices (see edge_split_fwd_cloud16_kernel): same results as

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void edge_bn_bwd_reduce_kernel(const float* __
                                                                  long long ldsel, int k, long long M, int C,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                 int act, float slope, double* __restrict__ dbeta,
+                                                                 int act, float slope, float inv_ns, double* __restrict__ dbeta,
                                                                  double* __restrict__ dgamma)
 {
     __shared__ double red[256][8];
@@ -378,9 +378,13 @@ __global__ __launch_bounds__(256) void edge_bn_bwd_reduce_kernel(const float* __
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float gy = d[c] + (a[c] == t ? g[c] : 0.0f);
-                    const float dpre = gy * act_grad(sc[c] * x[c] + sh[c], act, slope);
+                    // inv_ns > 0: X holds the POST-activation value y = act(pre) (LeakyReLU / identity, negative slope ns = 1 / inv_ns):
+                    // pre = y or y / ns, xhat = (pre - beta) / gamma with `mean` = beta and `invstd` = 1 / gamma passed by the host
+                    const float pre = inv_ns > 0.0f ? (x[c] > 0.0f ? x[c] : x[c] * inv_ns) : sc[c] * x[c] + sh[c];
+                    const float xh = ((inv_ns > 0.0f ? pre : x[c]) - mu[c]) * is[c];
+                    const float dpre = gy * act_grad(pre, act, slope);
                     sb[c] += dpre;
-                    sg[c] += (double)dpre * ((x[c] - mu[c]) * is[c]);
+                    sg[c] += (double)dpre * xh;
                 }
             }
         } else {
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(256) void edge_bn_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, const double* __restrict__ dbeta,
                                                                 const double* __restrict__ dgamma, double count, int act,
-                                                                float slope)
+                                                                float slope, float inv_ns)
 {
     const int Q = C >> 2;
     const int RG = 256 / Q;
@@ -453,8 +457,10 @@ __global__ __launch_bounds__(256) void edge_bn_bwd_apply_kernel(const float* __r
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float gy = d[c] + (a[c] == t ? g[c] : 0.0f);
-                const float dpre = gy * act_grad(sc[c] * x[c] + sh[c], act, slope);
-                o[c] = sc[c] * (dpre - mb[c] - (x[c] - mu[c]) * is[c] * mg[c]);
+                const float pre = inv_ns > 0.0f ? (x[c] > 0.0f ? x[c] : x[c] * inv_ns) : sc[c] * x[c] + sh[c];      // see the reduce kernel
+                const float xh = ((inv_ns > 0.0f ? pre : x[c]) - mu[c]) * is[c];
+                const float dpre = gy * act_grad(pre, act, slope);
+                o[c] = sc[c] * (dpre - mb[c] - xh * mg[c]);
                 sum[c] += o[c];
             }
             *reinterpret_cast<float4*>(dX + off) = make_float4(o[0], o[1], o[2], o[3]);
@@ -1105,8 +1111,10 @@ extern "C" int lpd_group_max_bwd(const float* dOut, long long ldo, const uint8_t
 static int edge_bn_bwd_impl(const float* dOut, long long ldo, const uint8_t* arg, const float* dDense, const float* X,
                             const float* Xsel, long long ldsel, float* dX, float* dQ, long long ldq, int k, long long M, int C,
                             const float* scale, const float* shift, const float* mean, const float* invstd, int act, float slope,
-                            double* dbeta, double* dgamma, double* stat_ws, void* stream)
+                            float inv_ns, double* dbeta, double* dgamma, double* stat_ws, void* stream)
 {
+    LPD_CHECK_ARG(inv_ns == 0.0f || (dDense && (act == 0 || act == 2) && inv_ns >= 1.0f),
+                  "lpd_edge_bn_bwd: post-activation X needs the dense form and an invertible activation (none / LeakyReLU)");
     LPD_CHECK_ARG(dOut && arg && X && dX && scale && shift && mean && invstd && dbeta && dgamma && M > 0 && k > 0 && k <= 255,
                   "lpd_edge_bn_bwd: bad arguments");
     LPD_CHECK_ARG(cols_ok(C) && ldo % 4 == 0 && (!dQ || ldq % 4 == 0) && (!Xsel || ldsel % 4 == 0),
@@ -1115,11 +1123,11 @@ static int edge_bn_bwd_impl(const float* dOut, long long ldo, const uint8_t* arg
     LPD_CHECK_ARG(ws.rep, "lpd_edge_bn_bwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     const int RG = 256 / (C / 4);
     hipLaunchKernelGGL(edge_bn_bwd_reduce_kernel, dim3(grid_for(M, RG * 2)), dim3(256), 0, ST(stream), dOut, ldo, arg, dDense, X, Xsel,
-                       ldsel, k, M, C, scale, shift, mean, invstd, act, slope, ws.sum(), ws.sumsq());
+                       ldsel, k, M, C, scale, shift, mean, invstd, act, slope, inv_ns, ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_edge_bn_bwd(reduce)");
     if (int rc = lpd_stat_finish(ws, dbeta, dgamma, C, ST(stream))) return rc;
     hipLaunchKernelGGL(edge_bn_bwd_apply_kernel, dim3(grid_for(M, RG)), dim3(256), 0, ST(stream), dOut, ldo, arg, dDense, X, dX, dQ,
-                       ldq, k, M, C, scale, shift, mean, invstd, dbeta, dgamma, (double)M * k, act, slope);
+                       ldq, k, M, C, scale, shift, mean, invstd, dbeta, dgamma, (double)M * k, act, slope, inv_ns);
     LPD_CHECK_LAUNCH("lpd_edge_bn_bwd(apply)");
     return LPD_OK;
 }
@@ -1127,10 +1135,10 @@ static int edge_bn_bwd_impl(const float* dOut, long long ldo, const uint8_t* arg
 extern "C" int lpd_edge_bn_bwd(const float* dOut, long long ldo, const uint8_t* arg, const float* dDense, const float* X,
                                float* dX, float* dQ, long long ldq, int k, long long M, int C, const float* scale,
                                const float* shift, const float* mean, const float* invstd, int act, float slope,
-                               double* dbeta, double* dgamma, double* stat_ws, void* stream)
+                               float inv_ns, double* dbeta, double* dgamma, double* stat_ws, void* stream)
 {
-    return edge_bn_bwd_impl(dOut, ldo, arg, dDense, X, nullptr, 0, dX, dQ, ldq, k, M, C, scale, shift, mean, invstd, act, slope, dbeta,
-                            dgamma, stat_ws, stream);
+    return edge_bn_bwd_impl(dOut, ldo, arg, dDense, X, nullptr, 0, dX, dQ, ldq, k, M, C, scale, shift, mean, invstd, act, slope, inv_ns,
+                            dbeta, dgamma, stat_ws, stream);
 }
 
 extern "C" int lpd_edge_bn_bwd_sel(const float* dOut, long long ldo, const uint8_t* arg, const float* X, const float* Xsel,
@@ -1140,7 +1148,7 @@ extern "C" int lpd_edge_bn_bwd_sel(const float* dOut, long long ldo, const uint8
 {
     LPD_CHECK_ARG(Xsel, "lpd_edge_bn_bwd_sel: Xsel is null");
     return edge_bn_bwd_impl(dOut, ldo, arg, nullptr, X, Xsel, ldsel, dX, nullptr, 0, k, M, C, scale, shift, mean, invstd, act, slope,
-                            dbeta, dgamma, stat_ws, stream);
+                            0.0f, dbeta, dgamma, stat_ws, stream);
 }
 
 extern "C" int lpd_group_sum(const float* dU, int k, float* dQ, long long ldq, long long M, int C, void* stream)

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void edge_bn_bwd_reduce_bf16_kernel(const floa
                                                                       long long ldsel, int k, long long M, int C,
                                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                      int act, float slope, double* __restrict__ dbeta,
+                                                                      int act, float slope, float inv_ns, double* __restrict__ dbeta,
                                                                       double* __restrict__ dgamma)
 {
     __shared__ double red[256][8];
@@ -474,9 +474,13 @@ __global__ __launch_bounds__(256) void edge_bn_bwd_reduce_bf16_kernel(const floa
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float gy = d[c] + (a[c] == t ? g[c] : 0.0f);
-                    const float dpre = gy * act_grad2(sc[c] * x[c] + sh[c], act, slope);
+                    // inv_ns > 0: X holds the POST-activation value y = act(pre) (LeakyReLU / identity, negative slope ns = 1 / inv_ns):
+                    // pre = y or y / ns, xhat = (pre - beta) / gamma with `mean` = beta and `invstd` = 1 / gamma passed by the host
+                    const float pre = inv_ns > 0.0f ? (x[c] > 0.0f ? x[c] : x[c] * inv_ns) : sc[c] * x[c] + sh[c];
+                    const float xh = ((inv_ns > 0.0f ? pre : x[c]) - mu[c]) * is[c];
+                    const float dpre = gy * act_grad2(pre, act, slope);
                     sb[c] += dpre;
-                    sg[c] += (double)dpre * ((x[c] - mu[c]) * is[c]);
+                    sg[c] += (double)dpre * xh;
                 }
             }
         } else {
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256) void edge_bn_bwd_apply_bf16_kernel(const float
                                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                      const double* __restrict__ dbeta, const double* __restrict__ dgamma,
-                                                                     double count, int act, float slope)
+                                                                     double count, int act, float slope, float inv_ns)
 {
     const int LQ = C >> 2;
     const int RG = 256 / LQ;
@@ -536,8 +540,10 @@ __global__ __launch_bounds__(256) void edge_bn_bwd_apply_bf16_kernel(const float
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float gy = d[c] + (a[c] == t ? g[c] : 0.0f);
-                const float dpre = gy * act_grad2(sc[c] * x[c] + sh[c], act, slope);
-                o[c] = sc[c] * (dpre - mb[c] - (x[c] - mu[c]) * is[c] * mg[c]);
+                const float pre = inv_ns > 0.0f ? (x[c] > 0.0f ? x[c] : x[c] * inv_ns) : sc[c] * x[c] + sh[c];      // see the reduce kernel
+                const float xh = ((inv_ns > 0.0f ? pre : x[c]) - mu[c]) * is[c];
+                const float dpre = gy * act_grad2(pre, act, slope);
+                o[c] = sc[c] * (dpre - mb[c] - xh * mg[c]);
                 sum[c] += o[c];      // the centre-term gradient sums the fp32 values, not the rounded ones
             }
             st4_bf16(dX + off, make_float4(o[0], o[1], o[2], o[3]));
@@ -1165,9 +1171,11 @@ extern "C" int lpd_group_sel_stats_bf16(const uint16_t* Z, int k, const float* g
 static int edge_bn_bwd_bf16_impl(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* dDense, const uint16_t* X,
                                  const float* Xsel, long long ldsel, uint16_t* dX, float* dQ, long long ldq, int k, long long M, int C,
                                  const float* scale, const float* shift, const float* mean, const float* invstd, int act, float slope,
-                                 double* dbeta, double* dgamma, double* stat_ws, void* stream_)
+                                 float inv_ns, double* dbeta, double* dgamma, double* stat_ws, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(inv_ns == 0.0f || (dDense && (act == 0 || act == 2) && inv_ns >= 1.0f),
+                  "lpd_edge_bn_bwd_bf16: post-activation X needs the dense form and an invertible activation (none / LeakyReLU)");
     LPD_CHECK_ARG(dOut && arg && X && dX && scale && shift && mean && invstd && dbeta && dgamma, "lpd_edge_bn_bwd_bf16: null pointer");
     LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && k <= 255 && ldo % 4 == 0 && ldq % 4 == 0 && ldsel % 4 == 0,
                   "lpd_edge_bn_bwd_bf16: bad dims");
@@ -1176,23 +1184,23 @@ static int edge_bn_bwd_bf16_impl(const float* dOut, long long ldo, const uint8_t
     LPD_CHECK_ARG(ws.rep, "lpd_edge_bn_bwd_bf16: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     const int rg = 256 / (C / 4);
     hipLaunchKernelGGL(edge_bn_bwd_reduce_bf16_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, dOut, ldo, arg, dDense, X, Xsel,
-                       ldsel, k, M, C, scale, shift, mean, invstd, act, slope, ws.sum(), ws.sumsq());
+                       ldsel, k, M, C, scale, shift, mean, invstd, act, slope, inv_ns, ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_edge_bn_bwd_bf16(reduce)");
     if (int rc = lpd_stat_finish(ws, dbeta, dgamma, C, stream)) return rc;
     hipLaunchKernelGGL(edge_bn_bwd_apply_bf16_kernel, dim3(grid_for(M, rg, 8192)), dim3(256), 0, stream, dOut, ldo, arg, dDense, X, dX, dQ,
                        ldq, k, M, C, scale, shift, mean, invstd, (const double*)dbeta, (const double*)dgamma, (double)M * (double)k, act,
-                       slope);
+                       slope, inv_ns);
     LPD_CHECK_LAUNCH("lpd_edge_bn_bwd_bf16(apply)");
     return LPD_OK;
 }
 
 extern "C" int lpd_edge_bn_bwd_bf16(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* dDense, const uint16_t* X,
                                     uint16_t* dX, float* dQ, long long ldq, int k, long long M, int C, const float* scale,
-                                    const float* shift, const float* mean, const float* invstd, int act, float slope, double* dbeta,
-                                    double* dgamma, double* stat_ws, void* stream)
+                                    const float* shift, const float* mean, const float* invstd, int act, float slope, float inv_ns,
+                                    double* dbeta, double* dgamma, double* stat_ws, void* stream)
 {
-    return edge_bn_bwd_bf16_impl(dOut, ldo, arg, dDense, X, nullptr, 0, dX, dQ, ldq, k, M, C, scale, shift, mean, invstd, act, slope, dbeta,
-                                 dgamma, stat_ws, stream);
+    return edge_bn_bwd_bf16_impl(dOut, ldo, arg, dDense, X, nullptr, 0, dX, dQ, ldq, k, M, C, scale, shift, mean, invstd, act, slope, inv_ns,
+                                 dbeta, dgamma, stat_ws, stream);
 }
 
 extern "C" int lpd_edge_bn_bwd_bf16_sel(const float* dOut, long long ldo, const uint8_t* arg, const uint16_t* X, const float* Xsel,
@@ -1202,7 +1210,7 @@ extern "C" int lpd_edge_bn_bwd_bf16_sel(const float* dOut, long long ldo, const 
 {
     LPD_CHECK_ARG(Xsel, "lpd_edge_bn_bwd_bf16_sel: Xsel is null");
     return edge_bn_bwd_bf16_impl(dOut, ldo, arg, nullptr, X, Xsel, ldsel, dX, nullptr, 0, k, M, C, scale, shift, mean, invstd, act, slope,
-                                 dbeta, dgamma, stat_ws, stream);
+                                 0.0f, dbeta, dgamma, stat_ws, stream);
 }
 
 extern "C" int lpd_gather_sum_rows_bf16(const uint16_t* dU, const int32_t* rowptr, const int32_t* edges, float* dP, long long ldp,

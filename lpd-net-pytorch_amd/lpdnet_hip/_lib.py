@@ -98,7 +98,9 @@ SIGNATURES = {
                                  _c_p, _c_p, _c_p, _c_p],
     "lpd_group_max_bwd": [_c_p, _c_ll, _c_p, _c_int, _c_p, _c_ll, _c_int, _c_int, _c_p],
     "lpd_edge_bn_bwd": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int,
-                        _c_f, _c_p, _c_p, _c_p, _c_p],
+                        _c_f, _c_f, _c_p, _c_p, _c_p, _c_p],
+    "lpd_edge_mlp_train": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p,
+                           _c_int, _c_int, _c_int, _c_int, _c_f, _c_p, _c_p],
     "lpd_group_sum": [_c_p, _c_int, _c_p, _c_ll, _c_ll, _c_int, _c_p],
     "lpd_scatter_add_rows": [_c_p, _c_p, _c_p, _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_p],
     "lpd_graph_transpose": [_c_p, _c_ll, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
@@ -119,7 +121,7 @@ SIGNATURES = {
     "lpd_edge_act_max_bf16": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p],
     "lpd_group_sel_stats_bf16": [_c_p, _c_int, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_bn_bwd_bf16": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int,
-                             _c_f, _c_p, _c_p, _c_p, _c_p],
+                             _c_f, _c_f, _c_p, _c_p, _c_p, _c_p],
     "lpd_bn_sel_bwd_reduce": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_dw_sel_bf16": [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_gemm_bf16s_bnbwd": [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],

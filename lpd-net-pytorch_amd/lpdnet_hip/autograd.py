@@ -445,7 +445,21 @@ class _LPDNetTrainFn(torch.autograd.Function):
         # fp32, or bf16 under set_train_storage("bf16"))
         wcat1 = engine.split_edge_weight(net.convDG1, "cat_nc")
         pq1 = ops.linear(f0, wcat1)                                             # [M,256] = [P | Q]
-        if bf16:
+        w2 = w2d(net.convDG2[0])
+        post1 = ops.edge_mlp_train_applies(M, N, k, 128, act, slope) and w2.is_contiguous() and tuple(w2.shape) == (128, 128)
+        if post1:
+            # ONE launch for the stage (lpd_edge_mlp_train): the raw edge tensor U1 is never written.  Its BatchNorm statistics, and
+            # x1 = max_k act(BN(U1)) with its arg-max, come from the split-form gather pass (closed-form sums; the activation is monotone,
+            # so the maximum is act(BN(.)) of the selected raw value); the fused kernel builds Y1e from the gathered rows, multiplies it
+            # by W2 and leaves Y1e, Z, the statistics of Z and its per-point selection (by the sign of gamma2) behind
+            _, usel1, arg1, stg1 = ops.edge_split_fwd(pq1[:, :128], pq1[:, 128:], idx_f, N, bn=net.convDG1[1])
+            ops.affine_act(usel1, stg1.scale, stg1.shift, act, slope, out=cat[:, 0:128])                # x1
+            y1e, z, zsel, arg2, stg2 = ops.edge_mlp_train(pq1[:, :128], pq1[:, 128:], idx_f, N, stg1.scale, stg1.shift, w2,
+                                                          net.convDG2[1], act, slope, bf16)
+            ops.affine_act(zsel, stg2.scale, stg2.shift, act, slope, out=cat[:, 128:256])             # x2
+            u1 = None
+            del usel1
+        elif bf16:
             u1, stg1 = ops.edge_build_bf16(pq1[:, :128], pq1[:, 128:], idx_f, N, bn=net.convDG1[1])   # [E,128] raw + its BN statistics
             y1e, arg1 = ops.edge_act_max_bf16(u1, k, stg1, act, slope, out=cat[:, 0:128])             # post-activation edges + x1
             z = ops.gemm_bf16s(y1e, w2d(net.convDG2[0]))                        # [E,128] raw, bf16 MFMA
@@ -464,7 +478,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         ops.affine_act(usel3, stg3.scale, stg3.shift, act, slope, out=cat[:, 256:512])                # x3
         y3, st3, feat = _PointLayer.fwd(cat, w2d(net.conv3_lpd), net.bn3_lpd, act, slope)
         ctx.net, ctx.dims, ctx.actslope, ctx.bf16 = net, (B, N, M, k), (act, slope), bf16
-        ctx.saved = dict(front=front, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1,
+        ctx.saved = dict(front=front, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1, post1=post1,
                          u1=u1, stg1=stg1, arg1=arg1, y1e=y1e, z=z, zsel=zsel, stg2=stg2, arg2=arg2, wcat3=wcat3, pq3=pq3, s3=s3, usel3=usel3,
                          stg3=stg3, arg3=arg3, cat=cat, y3=y3, st3=st3)
         if engine.DEBUG_AUX is not None:
@@ -514,8 +528,9 @@ class _LPDNetTrainFn(torch.autograd.Function):
                 dw2 = ops.gemm_tn_bf16(dz, S["y1e"])                            # [Co,Ci] = dZ^T Y1e
                 dy1e = ops.gemm_bf16s(dz, w2, b_kmajor=True)                    # [E,128] = dZ W2
                 del dz
-            du1, dgs1, dbs1 = ops.edge_bn_bwd_bf16(dcat[:, 0:128], S["arg1"], k, S["u1"], S["stg1"], act, slope, dense=dy1e,
-                                                   dQ=dpq1[:, 128:])
+            # (post1: the forward kept Y1e = act(BN(U1)) instead of U1; the kernels recover the pre-activation from it)
+            du1, dgs1, dbs1 = ops.edge_bn_bwd_bf16(dcat[:, 0:128], S["arg1"], k, S["y1e"] if S["post1"] else S["u1"], S["stg1"], act, slope,
+                                                   dense=dy1e, dQ=dpq1[:, 128:], post_bn=net.convDG1[1] if S["post1"] else None)
             ops.gather_sum_rows_bf16(du1, ops.GraphT(S["idx_f"], N), dpq1[:, :128])
         else:
             # DG2: x2 = groupmax(act(BN(Z))), Z = Y1e W2^T
@@ -534,8 +549,8 @@ class _LPDNetTrainFn(torch.autograd.Function):
                 dy1e = ops.gemm(dz, w2, b_kmajor=True)                          # [E,128]
                 del dz
             # DG1: y1e = act(BN(U1)); consumers: DG2 (dense) and x1 = groupmax (sparse)
-            du1, dgs1, dbs1 = ops.edge_bn_bwd(dcat[:, 0:128], S["arg1"], k, S["u1"], S["stg1"], act, slope, dense=dy1e,
-                                              dQ=dpq1[:, 128:])
+            du1, dgs1, dbs1 = ops.edge_bn_bwd(dcat[:, 0:128], S["arg1"], k, S["y1e"] if S["post1"] else S["u1"], S["stg1"], act, slope,
+                                              dense=dy1e, dQ=dpq1[:, 128:], post_bn=net.convDG1[1] if S["post1"] else None)
             ops.gather_sum_rows(du1, ops.GraphT(S["idx_f"], N), dpq1[:, :128])
         del du1, dy1e
         dwcat1 = _dweight(dpq1, S["f0"])

@@ -1118,11 +1118,22 @@ def group_max_bwd(dOut, arg, k, dX=None, accumulate=False):
     return dX
 
 
-def edge_bn_bwd(dOut, arg, k, X, st, act, slope, dense=None, dQ=None, xsel=None):
+def _post_consts(st, post_bn, act, slope):
+    """X holds post-activation values (what edge_mlp_train stores): the kernels recover pre = y or y / ns and take
+    xhat = (pre - beta) / gamma -- `mean` := beta, `invstd` := 1 / gamma (0 where gamma == 0: that channel's scale is 0 too)."""
+    if act not in (ACT_NONE, ACT_LEAKY) or (act == ACT_LEAKY and not 0.0 < slope <= 1.0):
+        raise ValueError("post-activation edge tensors need an invertible activation (none / LeakyReLU with 0 < slope <= 1)")
+    g = post_bn.weight.detach()
+    rg = torch.where(g != 0, 1.0 / g, torch.zeros_like(g)).contiguous()
+    return post_bn.bias.detach().contiguous(), rg, (1.0 if act == ACT_NONE else 1.0 / float(slope))
+
+
+def edge_bn_bwd(dOut, arg, k, X, st, act, slope, dense=None, dQ=None, xsel=None, post_bn=None):
     """Fused backward through max-over-k + activation + train-mode BatchNorm on a materialised edge tensor X [M*k, C].
     dOut [M, C] (view allowed): gradient of the group-max output; dense [M*k, C]: optional dense gradient on the
     post-activation edges (overwritten with the result).  Returns (dX [M*k, C], dgamma, dbeta); fills dQ if given.
-    xsel [M, C] (arg-max-only form): the raw selected values the forward kept (group_max(keep_sel=True)) -- same result."""
+    xsel [M, C] (arg-max-only form): the raw selected values the forward kept (group_max(keep_sel=True)) -- same result.
+    post_bn: X holds the POST-activation values act(BN(U)) (edge_mlp_train's Y1e) and this is the BatchNorm module."""
     ldo = _rows(dOut, "dOut")
     M, C = arg.shape
     dX = dense if dense is not None else torch.empty((M * k, C), dtype=torch.float32, device=X.device)
@@ -1138,8 +1149,11 @@ def edge_bn_bwd(dOut, arg, k, X, st, act, slope, dense=None, dQ=None, xsel=None)
               _ptr(red[1]), _stat_ws(), _stream())
         redf = red.float()
         return dX, redf[1], redf[0]
+    mean, invstd, inv_ns = st.mean, st.invstd, 0.0
+    if post_bn is not None:
+        mean, invstd, inv_ns = _post_consts(st, post_bn, act, slope)
     _call(f"edge_bn_bwd[C={C}]", lib.lpd_edge_bn_bwd, _ptr(dOut), ldo, _ptr(arg), _ptr(dense), _ptr(X), _ptr(dX), _ptr(dQ), ldq, k,
-          M, C, _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(red[0]), _ptr(red[1]),
+          M, C, _ptr(st.scale), _ptr(st.shift), _ptr(mean), _ptr(invstd), act, float(slope), float(inv_ns), _ptr(red[0]), _ptr(red[1]),
           _stat_ws(), _stream())
     redf = red.float()
     return dX, redf[1], redf[0]
@@ -1303,7 +1317,7 @@ def group_sel_stats_bf16(Z, k, bn):
     return sel, arg, _bn_finalize(sums, M * k, C, bn)
 
 
-def edge_bn_bwd_bf16(dOut, arg, k, X, st, act, slope, dense=None, dQ=None, xsel=None):
+def edge_bn_bwd_bf16(dOut, arg, k, X, st, act, slope, dense=None, dQ=None, xsel=None, post_bn=None):
     """edge_bn_bwd on bf16 tensors: -> (dX bf16 [M*k, C] (aliases `dense` when given), dgamma, dbeta).  xsel [M, C] fp32: the raw
     selected values of group_sel_stats_bf16 (arg-max-only form)."""
     ldo = _rows(dOut, "dOut")
@@ -1324,11 +1338,47 @@ def edge_bn_bwd_bf16(dOut, arg, k, X, st, act, slope, dense=None, dQ=None, xsel=
               _ptr(red[0]), _ptr(red[1]), _stat_ws(), _stream())
         redf = red.float()
         return dX, redf[1], redf[0]
+    mean, invstd, inv_ns = st.mean, st.invstd, 0.0
+    if post_bn is not None:
+        mean, invstd, inv_ns = _post_consts(st, post_bn, act, slope)
     _call(f"edge_bn_bwd_bf16[C={C}]", lib.lpd_edge_bn_bwd_bf16, _ptr(dOut), ldo, _ptr(arg), _ptr(dense), _ptr(X), _ptr(dX), _ptr(dQ), ldq,
-          k, M, C, _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(red[0]), _ptr(red[1]),
+          k, M, C, _ptr(st.scale), _ptr(st.shift), _ptr(mean), _ptr(invstd), act, float(slope), float(inv_ns), _ptr(red[0]), _ptr(red[1]),
           _stat_ws(), _stream())
     redf = red.float()
     return dX, redf[1], redf[0]
+
+
+EDGE_MLP_TRAIN = os.environ.get("LPD_EDGE_MLP_TRAIN", "1") != "0"      # train-mode DG1 -> DG2 stage in one launch (lpd_edge_mlp_train)
+
+
+def edge_mlp_train_applies(M, N, k, C, act, slope):
+    return (EDGE_MLP_TRAIN and C == 128 and M % 64 == 0 and N % 64 == 0 and 0 < k <= 255 and GEMM_BF16X3 and _EXACT.depth == 0
+            and (act == ACT_NONE or (act == ACT_LEAKY and 0.0 < slope <= 1.0)))
+
+
+def edge_mlp_train(P, Q, idx, N, scale1, shift1, W2, bn2, act, slope, bf16):
+    """Train-mode DG1 -> DG2 stage in one launch (include/lpd_hip.h lpd_edge_mlp_train): -> (Y1e [E,128], Z [E,128] (bf16 or fp32),
+    zsel [M,128] raw selected values, arg2 [M,128] uint8, BNStats of Z with bn2's running statistics updated)."""
+    ldp, ldq = _rows(P, "P"), _rows(Q, "Q")
+    _req(idx, "idx", torch.int32)
+    idx = idx.reshape(-1, idx.shape[-1]).contiguous()
+    M, C = P.shape
+    k = idx.shape[1]
+    _req(W2, "W2")
+    if idx.shape[0] != M or tuple(W2.shape) != (128, 128) or not W2.is_contiguous() or C != 128:
+        raise ValueError("edge_mlp_train: shape mismatch (128 -> 128 channels)")
+    dt = torch.bfloat16 if bf16 else torch.float32
+    Y = torch.empty((M * k, 128), dtype=dt, device=P.device)
+    Z = torch.empty((M * k, 128), dtype=dt, device=P.device)
+    zsel = torch.empty((M, 128), dtype=torch.float32, device=P.device)
+    arg2 = torch.empty((M, 128), dtype=torch.uint8, device=P.device)
+    sums = torch.empty((2, 128), dtype=torch.float64, device=P.device)
+    scale1, shift1 = _vec(scale1, "scale1", 128), _vec(shift1, "shift1", 128)
+    lib = _lib.load()
+    _call(f"edge_mlp_train[{'bf16' if bf16 else 'f32'}]", lib.lpd_edge_mlp_train, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(scale1),
+          _ptr(shift1), _ptr(W2), _ptr(bn2.weight), _ptr(Y), _ptr(Z), int(bool(bf16)), _ptr(zsel), 128, _ptr(arg2), _ptr(sums[0]),
+          _ptr(sums[1]), M, N, k, act, float(slope), _stat_ws(), _stream())
+    return Y, Z, zsel, arg2, _bn_finalize(sums, M * k, 128, bn2)
 
 
 def dg2_bwd_fused_applies(M, k, C):

@@ -729,7 +729,7 @@ def test_split_form_edge_stage_equals_the_materialised_one(cuda, C, N, k, B):
         sums0 = torch.empty(2, C, dtype=torch.float64, device=cuda)
         idc = idx.reshape(-1, k).contiguous()
         rc = lib.lpd_edge_split_fwd(P.data_ptr(), P.stride(0), Q.data_ptr(), Q.stride(0), idc.data_ptr(), bn_b.weight.data_ptr(), S0.data_ptr(),
-                                    u0.data_ptr(), a0.data_ptr(), M, N, C, k, sums0[0].data_ptr(), sums0[1].data_ptr(),
+                                    u0.data_ptr(), a0.data_ptr(), M, N, C, k, sums0[0].data_ptr(), sums0[1].data_ptr(), ops._stat_ws(),
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0
         assert torch.equal(S0, S) and torch.equal(u0, usel) and torch.equal(a0, arg_b)
@@ -1154,3 +1154,76 @@ def test_gemm_x3t_rows_short_reductions(cuda, M, N, K, bk, nb):
     finally:
         ops.X3T_ROWS = True
     assert _rel(got, old) < 2e-5
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+@pytest.mark.parametrize("N,k,B", [(320, 20, 2), (256, 7, 3)])
+def test_edge_mlp_train_equals_the_materialised_stage(cuda, bf16, N, k, B):
+    """lpd_edge_mlp_train (train-mode DG1 -> DG2 stage in one launch, the raw edge tensor U1 never written; x1 and its arg-max from
+    the split-form statistics pass) against the materialised chain edge_build -> act / max -> product -> statistics / selection:
+    Y1e, Z, BatchNorm2 statistics, selected values and slots, x1 -- and the DG1 BatchNorm backward fed with Y1e (post-activation,
+    pre-activation recovered) against the one fed with U1: dU1, dQ, dgamma, dbeta.  fp32 storage: three split-bf16 products on
+    both sides; bf16 storage: the product takes the ROUNDED Y1e, the stored tensors equal the rounded fp32 ones."""
+    ops = _ops()
+    C, M = 128, B * N
+    P, Q, idx, _, _ = _edge_inputs(B, N, C, k, 900 + N + k)
+    P, Q, idx = P.to(cuda), Q.to(cuda), idx.to(cuda)
+    act, slope = ops.ACT_LEAKY, 0.01
+    g = torch.Generator().manual_seed(N)
+    W2 = (torch.randn(C, C, generator=g) / C ** 0.5).to(cuda)
+    bn1a, bn1b, bn2a, bn2b = [_bn_for(C, 3 + i // 2).to(cuda).train() for i in range(4)]
+    with torch.no_grad():
+        bn2a.weight[::3].neg_()
+        bn2b.weight.copy_(bn2a.weight)      # negative scales: the selection is a minimum there
+        # |gamma1| >= 0.2: the post-activation form takes xhat = (pre - beta) / gamma, so a stored value's rounding reaches xhat as
+        # 2^-9 |xhat + beta / gamma| (the raw form: 2^-9 |xhat + mu / sigma|) -- neither is the yardstick of the other for |gamma| << |beta|
+        w1 = bn1a.weight
+        w1.copy_(torch.where(w1.abs() < 0.2, torch.where(w1 < 0, -0.2, 0.2).to(w1), w1))
+        bn1b.weight.copy_(w1)
+    # ---- materialised reference, fp32 tensors
+    U, st1 = ops.edge_build(P, Q, idx, N, bn=bn1a)
+    x1_a = torch.empty(M, C, device=cuda)
+    Y_a, arg1_a = ops.edge_act_max(U, k, st1, act, slope, out=x1_a)
+    Yin = Y_a.to(torch.bfloat16).float() if bf16 else Y_a
+    Z_a = ops.gemm(Yin, W2, b_kmajor=False)                                      # split-bf16 product (three terms)
+    st2_a = ops.bn_train_stats(Z_a, bn2a)
+    x2_a = torch.empty(M, C, device=cuda)
+    arg2_a, zsel_a = ops.group_max(Z_a, k, st2_a.scale, st2_a.shift, act, slope, x2_a, keep_sel=True)
+    # ---- one launch
+    _, usel, arg1_b, st1b = ops.edge_split_fwd(P, Q, idx, N, bn=bn1b)
+    x1_b = ops.affine_act(usel, st1b.scale, st1b.shift, act, slope)
+    assert ops.edge_mlp_train_applies(M, N, k, C, act, slope)
+    Y_b, Z_b, zsel_b, arg2_b, st2_b = ops.edge_mlp_train(P, Q, idx, N, st1.scale, st1.shift, W2, bn2b, act, slope, bf16)
+    assert torch.equal(arg1_a, arg1_b) and _rel(x1_b, x1_a) < 1e-5
+    assert _rel(st1b.mean, st1.mean) < 1e-5 and _rel(st1b.invstd, st1.invstd) < 1e-5
+    if bf16:
+        assert Y_b.dtype == torch.bfloat16 and Z_b.dtype == torch.bfloat16
+        assert (Y_b.float() - Y_a.to(torch.bfloat16).float()).abs().max().item() <= 2e-2 * Y_a.abs().max().item() * 2 ** -7   # <= 1 bf16 ulp (fma vs mul + add)
+        assert _rel(Z_b.float(), Z_a) < 2 ** -8
+        tol = 3e-3          # statistics / selection of the fp32 accumulators against those of an independently rounded product
+    else:
+        assert _rel(Y_b, Y_a) < 1e-6 and _rel(Z_b, Z_a) < 2e-5
+        tol = 2e-5
+    assert _rel(st2_b.mean, st2_a.mean) < tol and _rel(st2_b.invstd, st2_a.invstd) < tol
+    assert _rel(bn2b.running_mean, bn2a.running_mean) < tol and _rel(bn2b.running_var, bn2a.running_var) < tol
+    assert _rel(zsel_b, zsel_a) < tol
+    same = (arg2_a == arg2_b).float().mean().item()
+    assert same > (0.995 if bf16 else 0.9995), same          # a near-tie between two slots may fall the other way
+    # selected values are consistent with the stored Z: zsel[i][c] = Z[(i, arg2[i][c])][c] up to the storage rounding
+    pick = torch.gather(Z_b.float().view(M, k, C), 1, arg2_b.long().unsqueeze(1)).squeeze(1)
+    assert _rel(pick, zsel_b) < (2 ** -8 if bf16 else 1e-6)
+    # ---- DG1 BatchNorm backward: post-activation form (Y1e) against the raw form (U1), same dense gradient
+    dOut = torch.randn(M, C + 8, generator=g).to(cuda)[:, 4:4 + C]
+    dense = torch.randn(M * k, C, generator=g).to(cuda)
+    if bf16:
+        dq_a, dq_b = torch.empty(M, C, device=cuda), torch.empty(M, C, device=cuda)
+        U16 = U.to(torch.bfloat16)
+        Y16 = ops.affine_act(U16.float(), st1.scale, st1.shift, act, slope).to(torch.bfloat16)      # Y of the SAME rounded U
+        dU_a, dg_a, db_a = ops.edge_bn_bwd_bf16(dOut, arg1_a, k, U16, st1, act, slope, dense=dense.to(torch.bfloat16), dQ=dq_a)
+        dU_b, dg_b, db_b = ops.edge_bn_bwd_bf16(dOut, arg1_a, k, Y16, st1, act, slope, dense=dense.to(torch.bfloat16), dQ=dq_b, post_bn=bn1a)
+        assert _rel(dU_b.float(), dU_a.float()) < 2e-2 and _rel(dq_b, dq_a) < 2e-2 and _rel(dg_b, dg_a) < 2e-2 and _rel(db_b, db_a) < 1e-3
+    else:
+        dq_a, dq_b = torch.empty(M, C, device=cuda), torch.empty(M, C, device=cuda)
+        dU_a, dg_a, db_a = ops.edge_bn_bwd(dOut, arg1_a, k, U, st1, act, slope, dense=dense.clone(), dQ=dq_a)
+        dU_b, dg_b, db_b = ops.edge_bn_bwd(dOut, arg1_a, k, Y_a, st1, act, slope, dense=dense.clone(), dQ=dq_b, post_bn=bn1a)
+        assert _rel(dU_b, dU_a) < 2e-4 and _rel(dq_b, dq_a) < 2e-4 and _rel(dg_b, dg_a) < 2e-4 and _rel(db_b, db_a) < 1e-5
