@@ -466,6 +466,25 @@ int lpd_edge_split_fwd(const float* P, long long ldp, const float* Q, long long 
 int lpd_edge_mlp_train(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1, const float* b1,
                        const float* W2, const float* gamma2, void* Y1e, void* Z, int bf16, float* zsel, int ldsel, uint8_t* arg2,
                        double* sum, double* sumsq, int M, int N, int k, int act, float slope, double* stat_ws, void* stream);
+/*
+ * Backward of the train-mode DG1 -> DG2 stage (the counterpart of lpd_edge_mlp_train), two launches instead of the chain
+ * product -> reduce -> apply -> gather over [E,128] tensors:
+ *   lpd_edge_mlp_train_bwd: dZ generated from the stored Z while the operand tile is built (A = z a1 + a0 + delta dpre2, cf.
+ *     lpd_gemm_bf16s_bnbwd), dY1e = dZ W2 on the MFMA, and in its epilogue G = (dY1e + delta_{t,arg1} dx1) act'(pre1) -- the gradient in
+ *     front of BatchNorm1 -- written INSTEAD of dY1e, with dbeta1 = sum G, dgamma1 = sum G xhat1 and gsum[i] = sum_t G[(i,t)];
+ *     act' and xhat1 = (pre1 - beta1) rgamma1 come from the stored post-activation Y1e (pre1 = y or y * inv_ns).
+ *   lpd_edge_dense_bwd_apply: dP, dQ of U = P[nbr] + Q in closed form from ONE gather pass over the transposed graph (a G row and a Q
+ *     row per edge): dP_j = s (sum G - deg m1 - m2 invstd (deg (P_j - mu) + sum Q_i)), dQ_j = s (gsum_j - k m1 - m2 invstd (S_j + k (Q_j - mu))).
+ * bf16 != 0: Z, Y1e, dpre2 and G are bf16.  M % 32 == 0, 128 channels, k <= 255.
+ */
+int lpd_edge_mlp_train_bwd(const void* Z, const uint8_t* arg2, const void* dpre2, const float* W2, const float* scale2, const float* mean2,
+                           const float* invstd2, const double* dbeta2, const double* dgamma2, const void* Y1e, const uint8_t* arg1,
+                           const float* dx1, int lddx1, const float* beta1, const float* rgamma1, int bf16, void* G, float* gsum,
+                           double* dbeta1, double* dgamma1, int M, int k, int act, float slope, float inv_ns, double* stat_ws, void* stream);
+int lpd_edge_dense_bwd_apply(const void* G, int bf16, const float* gsum, const float* S, const float* P, long long ldp, const float* Q,
+                             long long ldq, const int32_t* rowptr, const int32_t* edges, float* dP, long long lddp, float* dQ, long long lddq,
+                             long long M, int C, int k, const float* scale, const float* mean, const float* invstd, const double* dbeta,
+                             const double* dgamma, void* stream);
 /* The same on cloud-resident slices (the organisation of lpd_edge_gather_max16: a block holds an 8-channel slice of a whole cloud in
  * LDS and gathers the k neighbour pieces from there): idx16 from lpd_pack_idx16; k = 20, N <= 4096, C % 8 == 0.  S, usel, arg are
  * bit-identical to lpd_edge_split_fwd, the statistics equal up to the order of the fp64 additions. */

@@ -1124,6 +1124,215 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_kernel(EdgeMlpTr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward of the train-mode DG1 -> DG2 stage, dense part, in one launch (the counterpart of edge_mlp_train_kernel):
+//   dZ[(i,t)][c]  = s2_c (delta_{t,arg2[i][c]} dpre2[i][c] - m1_c - xhat2 m2_c)      generated while the A tile is built, from the stored
+//                   Z: A = z a1 + a0 + delta dpre2 (a1 = -invstd2 m2, a0 = mu2 invstd2 m2 - m1), the factor s2_c folded into the weight
+//                   fragments (cf. lpd_gemm_bf16s_bnbwd, csrc/lpd_train3.hip);
+//   dY1e = dZ W2  on the MFMA (rows = 32 points of one neighbour slot, a wave owns 32 of the 128 columns);
+//   G[(i,t)][n]   = (dY1e + delta_{t,arg1[i][n]} dx1[i][n]) act'(pre1)      the gradient in front of BatchNorm1, written INSTEAD of dY1e;
+//   sum G, sum G xhat1 per channel (BatchNorm1's dbeta / dgamma) and gsum[i][n] = sum_t G[(i,t)][n] (the centre-term sums) on the way,
+//   act' and xhat1 = (pre1 - beta1) / gamma1 from the stored post-activation Y1e (pre1 = y or y / ns).
+// The former chain wrote dY1e, read it twice with U1 (reduce, apply), wrote dU1 and gathered it; what follows this kernel is ONE
+// gather pass over the transposed graph with closed-form sums (edge_dense_bwd_apply_kernel, lpd_train2.hip).
+// ------------------------------------------------------------------------------------------
+struct EdgeMlpBwdArgs {
+    const void* Z; const uint8_t* arg2; const void* dpre2;      // [E][128] bf16 / fp32; [M][128]; [M][128] bf16 / fp32
+    const float* W2; const float* scale2; const float* mean2; const float* invstd2;
+    const double* dbeta2; const double* dgamma2;                // sums over the E edges (lpd_bn_sel_bwd_reduce)
+    const void* Y; const uint8_t* arg1; const float* dx1; int lddx1;
+    const float* beta1; const float* rgamma1;                   // BatchNorm1 bias, 1 / weight (0 where the weight is 0)
+    void* G; float* gsum;                                       // [E][128] bf16 / fp32; [M][128]
+    double* sum; double* sumx;                                  // replicas
+    int M, k, act;
+    float slope, inv_ns;
+};
+
+constexpr int EB_PTS = 32;
+
+template <bool BF16>
+__global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeMlpBwdArgs g)
+{
+    constexpr int CM = 128, LDK = CM + 8, IMG = EB_PTS * LDK, KS = CM / 16, NIMG = BF16 ? 1 : 2, ES = BF16 ? 2 : 4;
+    constexpr int RPP = EM_THREADS / (CM / 4), PASSES = EB_PTS / RPP;      // 8 rows per pass, 4 passes
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];       // [2 buffers][hi (| lo)][32][LDK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    const int m0 = lpd_xcd_remap(blockIdx.x, gridDim.x) * EB_PTS;         // M % 32 == 0 (host check)
+    const int n = wave * 32 + col;                                        // this lane's column of dY1e / G
+    const double count = (double)g.M * (double)g.k;
+
+    // weight fragments: B[k = c][n] = s2_c W2[c][n], c = 16 s + 8 h + e
+    em_bf16x8 b_hi[KS], b_lo[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = s * 16 + h * 8 + e;
+            w[e] = g.scale2[c] * g.W2[(size_t)c * CM + n];
+        }
+        em_bf16x4 h0, l0, h1, l1;
+        em_split4(w[0], w[1], w[2], w[3], h0, l0);
+        em_split4(w[4], w[5], w[6], w[7], h1, l1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b_hi[s][e] = h0[e]; b_hi[s][4 + e] = h1[e]; b_lo[s][e] = l0[e]; b_lo[s][4 + e] = l1[e]; }
+    }
+    // builder role: channel quad c4 of rows prow + 8 e
+    const int c4 = tid % (CM / 4), prow = tid / (CM / 4);
+    float a1[4], a0[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = c4 * 4 + c;
+        const float m1 = (float)(g.dbeta2[ch] / count), m2 = (float)(g.dgamma2[ch] / count);
+        a1[c] = -g.invstd2[ch] * m2;
+        a0[c] = g.mean2[ch] * g.invstd2[ch] * m2 - m1;
+    }
+    float dp2[PASSES][4];
+    uint32_t ar2[PASSES];
+#pragma unroll
+    for (int e = 0; e < PASSES; ++e) {
+        const size_t m = (size_t)(m0 + prow + RPP * e);
+        ar2[e] = *reinterpret_cast<const uint32_t*>(g.arg2 + m * CM + c4 * 4);
+        if constexpr (BF16) {
+            const uint2 d = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(g.dpre2) + m * CM + c4 * 4);
+            dp2[e][0] = __uint_as_float(d.x << 16); dp2[e][1] = __uint_as_float(d.x & 0xffff0000u);
+            dp2[e][2] = __uint_as_float(d.y << 16); dp2[e][3] = __uint_as_float(d.y & 0xffff0000u);
+        } else {
+            const float4 d = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.dpre2) + m * CM + c4 * 4);
+            dp2[e][0] = d.x; dp2[e][1] = d.y; dp2[e][2] = d.z; dp2[e][3] = d.w;
+        }
+    }
+    // the block's slabs of Z, Y1e and G (32 k rows) as buffer resources (see edge_mlp_train_kernel)
+    const unsigned slab = (unsigned)EB_PTS * (unsigned)g.k * (CM * ES);
+    const size_t slab0 = (size_t)m0 * g.k * (CM * ES);
+    const __amdgpu_buffer_rsrc_t zres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.Z)) + slab0, 0, slab, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.Y)) + slab0, 0, slab, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(g.G) + slab0, 0, slab, 0x00020000);
+    const unsigned rowb = (unsigned)g.k * (CM * ES);
+    const unsigned zoff = ((unsigned)prow * (unsigned)g.k * CM + c4 * 4) * ES;                    // builder: its rows of Z
+    const unsigned eoff = ((unsigned)(4 * h) * (unsigned)g.k * CM + n) * ES;                      // epilogue: element (row 4 h + ., column n)
+    const unsigned goff = ((unsigned)(4 * h) * (unsigned)g.k * CM + (BF16 ? (n & ~1) : n)) * ES;
+
+    // epilogue role: rows p = (r & 3) + 8 (r >> 2) + 4 h, column n
+    float dx1v[16];
+    uint32_t ar1[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const size_t m = (size_t)(m0 + (r & 3) + 8 * (r >> 2) + 4 * h);
+        dx1v[r] = g.dx1[m * g.lddx1 + n];
+        ar1[r >> 2] |= (uint32_t)g.arg1[m * CM + n] << (8 * (r & 3));
+    }
+    const float beta1 = g.beta1[n], rg1 = g.rgamma1[n];
+    const float ns = lpd_neg_slope(g.act, g.slope), inv_ns = g.inv_ns;
+
+    typedef unsigned zraw_t __attribute__((ext_vector_type(BF16 ? 2 : 4)));
+    zraw_t zr[PASSES];
+    auto load_z = [&](int t) {
+#pragma unroll
+        for (int e = 0; e < PASSES; ++e) {
+            const unsigned so = (unsigned)(RPP * e) * rowb + (unsigned)t * (CM * ES);
+            if constexpr (BF16) zr[e] = __builtin_amdgcn_raw_buffer_load_b64(zres, zoff, so, 0);
+            else zr[e] = __builtin_amdgcn_raw_buffer_load_b128(zres, zoff, so, 0);
+        }
+    };
+    auto build = [&](int buf, int t) {
+        __bf16* hi_img = smem16 + buf * NIMG * IMG;
+        const uint32_t tb = (uint32_t)t;
+#pragma unroll
+        for (int e = 0; e < PASSES; ++e) {
+            const int p = prow + RPP * e;
+            float z[4];
+            if constexpr (BF16) {
+                z[0] = __uint_as_float(zr[e][0] << 16); z[1] = __uint_as_float(zr[e][0] & 0xffff0000u);
+                z[2] = __uint_as_float(zr[e][1] << 16); z[3] = __uint_as_float(zr[e][1] & 0xffff0000u);
+            } else {
+                z[0] = __uint_as_float(zr[e][0]); z[1] = __uint_as_float(zr[e][1]); z[2] = __uint_as_float(zr[e][2]); z[3] = __uint_as_float(zr[e][3]);
+            }
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                v[c] = fmaf(z[c], a1[c], a0[c]) + (((ar2[e] >> (8 * c)) & 0xffu) == tb ? dp2[e][c] : 0.0f);
+            uint2 hh, ll;
+            em_split4_packed(v[0], v[1], v[2], v[3], hh, ll);
+            *reinterpret_cast<uint2*>(hi_img + p * LDK + c4 * 4) = hh;
+            if constexpr (!BF16) *reinterpret_cast<uint2*>(hi_img + IMG + p * LDK + c4 * 4) = ll;
+        }
+    };
+    typedef unsigned short yraw_bf; 
+    unsigned yv[16];
+    auto load_y = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * rowb + (unsigned)t * (CM * ES);
+            if constexpr (BF16) yv[r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(yres, eoff, so, 0) << 16;
+            else yv[r] = __builtin_amdgcn_raw_buffer_load_b32(yres, eoff, so, 0);
+        }
+    };
+
+    float gsum[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gsum[r] = 0.0f;
+    float sg = 0.0f, sgx = 0.0f;
+
+    load_z(0);
+    build(0, 0);
+    if (g.k > 1) load_z(1);
+    __syncthreads();
+    for (int t = 0; t < g.k; ++t) {
+        const int buf = t & 1;
+        load_y(t);                                   // this slot's Y1e elements: in flight under the MFMAs
+        const __bf16* ah = smem16 + buf * NIMG * IMG + col * LDK + h * 8;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const em_bf16x8 a_hi = *reinterpret_cast<const em_bf16x8*>(ah + s * 16);
+            if constexpr (!BF16) {
+                const em_bf16x8 a_lo = *reinterpret_cast<const em_bf16x8*>(ah + IMG + s * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi[s], acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi[s], acc, 0, 0, 0);
+        }
+        if (t + 1 < g.k) {
+            build(buf ^ 1, t + 1);                   // (its Z rows were requested a slot ago)
+            if (t + 2 < g.k) load_z(t + 2);
+        }
+        const uint32_t tb = (uint32_t)t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float y = __uint_as_float(yv[r]);
+            const float gy = acc[r] + (((ar1[r >> 2] >> (8 * (r & 3))) & 0xffu) == tb ? dx1v[r] : 0.0f);
+            const bool pos = y > 0.0f;
+            const float gg = gy * (pos ? 1.0f : ns);
+            const float pre = pos ? y : y * inv_ns;
+            sg += gg;
+            sgx = fmaf(gg, (pre - beta1) * rg1, sgx);
+            gsum[r] += gg;
+            const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * rowb + (unsigned)t * (CM * ES);
+            if constexpr (BF16) {
+                const unsigned mine = __builtin_bit_cast(unsigned short, (__bf16)gg);
+                const unsigned other = lpd_lane_xor1(mine);
+                if (!(col & 1)) __builtin_amdgcn_raw_buffer_store_b32(mine | (other << 16), gres, goff, so, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gg), gres, goff, so, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g.gsum[(size_t)(m0 + (r & 3) + 8 * (r >> 2) + 4 * h) * CM + n] = gsum[r];
+    sg += __shfl_xor(sg, 32);
+    sgx += __shfl_xor(sgx, 32);
+    if (h == 0) {
+        atomicAdd(&g.sum[lpd_stat_rofs() + n], (double)sg);
+        atomicAdd(&g.sumx[lpd_stat_rofs() + n], (double)sgx);
+    }
+}
+
 template <int CM, int CO>
 int edge_mlp_x3_launch(const EdgeMlpArgs& g, hipStream_t stream)
 {
@@ -1327,6 +1536,33 @@ extern "C" int lpd_edge_mlp_train(const float* P, int ldp, const float* Q, int l
     }
     LPD_CHECK_LAUNCH("lpd_edge_mlp_train");
     return lpd_stat_finish(ws, sum, sumsq, 128, stream);
+}
+
+// Backward of the train-mode DG1 -> DG2 stage, dense part (edge_mlp_train_bwd_kernel): G = the gradient in front of BatchNorm1 [E][128]
+// (bf16 or fp32 like Z / Y1e), gsum[i] = sum_t G[(i,t)], dbeta1 = sum G, dgamma1 = sum G xhat1.  dbeta2 / dgamma2: the sums of
+// lpd_bn_sel_bwd_reduce; beta1 / rgamma1: BatchNorm1's bias and 1 / weight; inv_ns = 1 / negative slope (1 for act none).
+extern "C" int lpd_edge_mlp_train_bwd(const void* Z, const uint8_t* arg2, const void* dpre2, const float* W2, const float* scale2,
+                                      const float* mean2, const float* invstd2, const double* dbeta2, const double* dgamma2, const void* Y1e,
+                                      const uint8_t* arg1, const float* dx1, int lddx1, const float* beta1, const float* rgamma1, int bf16,
+                                      void* G, float* gsum, double* dbeta1, double* dgamma1, int M, int k, int act, float slope, float inv_ns,
+                                      double* stat_ws, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(Z && arg2 && dpre2 && W2 && scale2 && mean2 && invstd2 && dbeta2 && dgamma2 && Y1e && arg1 && dx1 && beta1 && rgamma1 && G &&
+                  gsum && dbeta1 && dgamma1, "lpd_edge_mlp_train_bwd: null pointer");
+    LPD_CHECK_ARG(M > 0 && M % EB_PTS == 0 && k > 0 && k <= 255, "lpd_edge_mlp_train_bwd: M=%d k=%d unsupported (M %% 32 == 0, k <= 255)", M, k);
+    LPD_CHECK_ARG((act == 0 || act == 2) && inv_ns >= 1.0f, "lpd_edge_mlp_train_bwd: needs an invertible activation (none / LeakyReLU)");
+    LPD_CHECK_ARG((((uintptr_t)Z | (uintptr_t)Y1e | (uintptr_t)G | (uintptr_t)dpre2 | (uintptr_t)arg2) & 15) == 0,
+                  "lpd_edge_mlp_train_bwd: pointers must be 16-byte aligned");
+    const LpdStatWs ws = lpd_stat_arg(stat_ws);
+    LPD_CHECK_ARG(ws.rep, "lpd_edge_mlp_train_bwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
+    EdgeMlpBwdArgs g{Z, arg2, dpre2, W2, scale2, mean2, invstd2, dbeta2, dgamma2, Y1e, arg1, dx1, lddx1, beta1, rgamma1, G, gsum,
+                     ws.sum(), ws.sumsq(), M, k, act, slope, inv_ns};
+    const size_t lds = (size_t)(bf16 ? 2 : 4) * EB_PTS * (128 + 8) * sizeof(__bf16);
+    if (bf16) hipLaunchKernelGGL(edge_mlp_train_bwd_kernel<true>, dim3(M / EB_PTS), dim3(EM_THREADS), lds, stream, g);
+    else hipLaunchKernelGGL(edge_mlp_train_bwd_kernel<false>, dim3(M / EB_PTS), dim3(EM_THREADS), lds, stream, g);
+    LPD_CHECK_LAUNCH("lpd_edge_mlp_train_bwd");
+    return lpd_stat_finish(ws, dbeta1, dgamma1, 128, stream);
 }
 
 // Training forward of the split-form edge stage on cloud-resident slices (see edge_split_fwd_cloud16_kernel): same results as

@@ -1045,6 +1045,93 @@ inline int grid_for(long long items, int per_block, int cap = 4096)
     return (int)(g > cap ? cap : g);
 }
 
+
+// Dense counterpart of edge_split_bwd_apply_kernel: the gradient G [E][C] in front of a train-mode BatchNorm over the edges
+// U[(i,t)] = P[nbr(i,t)] + Q[i] is DENSE (the DG1 stage: every post-activation edge feeds convDG2).  With m1 = mean(G), m2 = mean(G xhat),
+//   dU[(i,t)] = s (G[(i,t)] - m1 - xhat[(i,t)] m2),   xhat = (P_j + Q_i - mu) invstd,
+// summed in closed form over the incoming edges of row j (transposed graph) and over the k outgoing edges of row j:
+//   dP_j = s (A_j - deg_j m1 - m2 invstd (deg_j (P_j - mu) + R_j)),      A_j = sum G[e], R_j = sum Q_i over the incoming edges e = (i, t)
+//   dQ_j = s (gsum_j - k m1 - m2 invstd (S_j + k (Q_j - mu))),           gsum_j = sum_t G[(j,t)] (lpd_edge_mlp_train_bwd), S_j = sum_t P[nbr(j,t)]
+// -- one gather pass (a G row and a Q row per edge), no dU tensor, no float atomics.  GT: uint16_t (bf16 rows) or float.
+template <int LPR, typename GT>
+__global__ __launch_bounds__(256) void edge_dense_bwd_apply_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ edges,
+                                                                   const GT* __restrict__ G, const float* __restrict__ gsum,
+                                                                   const float* __restrict__ S, const float* __restrict__ P,
+                                                                   long long ldp, const float* __restrict__ Q, long long ldq,
+                                                                   float* __restrict__ dP, long long lddp, float* __restrict__ dQ,
+                                                                   long long lddq, long long M, int k,
+                                                                   const float* __restrict__ scale, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, const double* __restrict__ dbeta,
+                                                                   const double* __restrict__ dgamma)
+{
+    constexpr int RPW = 64 / LPR;
+    constexpr int C = LPR * 4;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, cl = lane % LPR;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+    const double E = (double)M * (double)k;
+    float sc[4], mu[4], m1[4], m2i[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = cl * 4 + c;
+        sc[c] = scale[ch]; mu[c] = mean[ch];
+        m1[c] = (float)(dbeta[ch] / E);
+        m2i[c] = (float)(dgamma[ch] / E) * invstd[ch];
+    }
+    const float kf = (float)k;
+    const unsigned ku = (unsigned)k;
+    auto ldg = [&](unsigned e) -> float4 {
+        if constexpr (sizeof(GT) == 2) return ld4_bf16(reinterpret_cast<const uint16_t*>(G) + (long long)e * C + cl * 4);
+        else return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(G) + (long long)e * C + cl * 4);
+    };
+    for (long long r0 = wave * RPW; r0 < M; r0 += nw * RPW) {
+        const long long j = r0 + sub;
+        if (j >= M) continue;
+        const int beg = rowptr[j], end = rowptr[j + 1];
+        float A[4] = {0, 0, 0, 0}, R[4] = {0, 0, 0, 0};
+        int p = beg;
+        for (; p + 3 < end; p += 4) {          // four incoming edges (eight row loads) in flight
+            unsigned ee[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ee[u] = (unsigned)edges[p + u];
+            float4 q4[4], g4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                q4[u] = *reinterpret_cast<const float4*>(Q + (long long)(ee[u] / ku) * ldq + cl * 4);
+                g4[u] = ldg(ee[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {      // same order of additions as the one-edge loop
+                R[0] += q4[u].x; R[1] += q4[u].y; R[2] += q4[u].z; R[3] += q4[u].w;
+                A[0] += g4[u].x; A[1] += g4[u].y; A[2] += g4[u].z; A[3] += g4[u].w;
+            }
+        }
+        for (; p < end; ++p) {
+            const unsigned e = (unsigned)edges[p];
+            const float4 q4 = *reinterpret_cast<const float4*>(Q + (long long)(e / ku) * ldq + cl * 4);
+            const float4 g4 = ldg(e);
+            R[0] += q4.x; R[1] += q4.y; R[2] += q4.z; R[3] += q4.w;
+            A[0] += g4.x; A[1] += g4.y; A[2] += g4.z; A[3] += g4.w;
+        }
+        const float deg = (float)(end - beg);
+        const float4 p4 = *reinterpret_cast<const float4*>(P + j * ldp + cl * 4);
+        const float4 q4 = *reinterpret_cast<const float4*>(Q + j * ldq + cl * 4);
+        const float4 g4 = *reinterpret_cast<const float4*>(gsum + j * C + cl * 4);
+        const float4 s4 = *reinterpret_cast<const float4*>(S + j * C + cl * 4);
+        const float pj[4] = {p4.x, p4.y, p4.z, p4.w}, qj[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float gj[4] = {g4.x, g4.y, g4.z, g4.w}, sj[4] = {s4.x, s4.y, s4.z, s4.w};
+        float op[4], oq[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            op[c] = sc[c] * (A[c] - deg * m1[c] - m2i[c] * (deg * (pj[c] - mu[c]) + R[c]));
+            oq[c] = sc[c] * (gj[c] - kf * m1[c] - m2i[c] * (sj[c] + kf * (qj[c] - mu[c])));
+        }
+        *reinterpret_cast<float4*>(dP + j * lddp + cl * 4) = make_float4(op[0], op[1], op[2], op[3]);
+        *reinterpret_cast<float4*>(dQ + j * lddq + cl * 4) = make_float4(oq[0], oq[1], oq[2], oq[3]);
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1094,6 +1181,34 @@ extern "C" int lpd_edge_split_bwd(const float* dOut, long long ldo, const float*
     else if (C == 128) hipLaunchKernelGGL(edge_split_bwd_apply_kernel<32>, dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
     else hipLaunchKernelGGL(edge_split_bwd_apply_kernel<64>, dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
     LPD_CHECK_LAUNCH("lpd_edge_split_bwd(apply)");
+    return LPD_OK;
+}
+
+// Closed-form backward of a train-mode BatchNorm over the edges with a DENSE incoming gradient (edge_dense_bwd_apply_kernel): dP, dQ
+// from G [M k][C] (bf16 != 0: bf16 rows), gsum [M][C] = sum_t G, S [M][C] = sum_t P[nbr] (lpd_edge_split_fwd), the transposed graph
+// (lpd_graph_transpose) and the sums dbeta = sum G, dgamma = sum G xhat (lpd_edge_mlp_train_bwd).  C in {64, 128, 256}.
+extern "C" int lpd_edge_dense_bwd_apply(const void* G, int bf16, const float* gsum, const float* S, const float* P, long long ldp, const float* Q,
+                                        long long ldq, const int32_t* rowptr, const int32_t* edges, float* dP, long long lddp, float* dQ,
+                                        long long lddq, long long M, int C, int k, const float* scale, const float* mean, const float* invstd,
+                                        const double* dbeta, const double* dgamma, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    LPD_CHECK_ARG(G && gsum && S && P && Q && rowptr && edges && dP && dQ && scale && mean && invstd && dbeta && dgamma,
+                  "lpd_edge_dense_bwd_apply: null pointer");
+    LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_dense_bwd_apply: C=%d unsupported", C);
+    LPD_CHECK_ARG(M > 0 && k > 0 && ldp % 4 == 0 && ldq % 4 == 0 && lddp % 4 == 0 && lddq % 4 == 0, "lpd_edge_dense_bwd_apply: bad dims");
+    const int lpr = C / 4;
+    const int grid = grid_for(M, 4 * (64 / lpr) * 2, 8192);
+#define LPD_DENSE_APPLY(LPR, T)                                                                                                      \
+    hipLaunchKernelGGL((edge_dense_bwd_apply_kernel<LPR, T>), dim3(grid), dim3(256), 0, stream, rowptr, edges, (const T*)G, gsum, S, P, ldp, \
+                       Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, dbeta, dgamma)
+    if (bf16) {
+        if (C == 64) LPD_DENSE_APPLY(16, uint16_t); else if (C == 128) LPD_DENSE_APPLY(32, uint16_t); else LPD_DENSE_APPLY(64, uint16_t);
+    } else {
+        if (C == 64) LPD_DENSE_APPLY(16, float); else if (C == 128) LPD_DENSE_APPLY(32, float); else LPD_DENSE_APPLY(64, float);
+    }
+#undef LPD_DENSE_APPLY
+    LPD_CHECK_LAUNCH("lpd_edge_dense_bwd_apply");
     return LPD_OK;
 }
 

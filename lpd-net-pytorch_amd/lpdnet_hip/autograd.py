@@ -447,12 +447,13 @@ class _LPDNetTrainFn(torch.autograd.Function):
         pq1 = ops.linear(f0, wcat1)                                             # [M,256] = [P | Q]
         w2 = w2d(net.convDG2[0])
         post1 = ops.edge_mlp_train_applies(M, N, k, 128, act, slope) and w2.is_contiguous() and tuple(w2.shape) == (128, 128)
+        s1sum = None
         if post1:
             # ONE launch for the stage (lpd_edge_mlp_train): the raw edge tensor U1 is never written.  Its BatchNorm statistics, and
             # x1 = max_k act(BN(U1)) with its arg-max, come from the split-form gather pass (closed-form sums; the activation is monotone,
             # so the maximum is act(BN(.)) of the selected raw value); the fused kernel builds Y1e from the gathered rows, multiplies it
             # by W2 and leaves Y1e, Z, the statistics of Z and its per-point selection (by the sign of gamma2) behind
-            _, usel1, arg1, stg1 = ops.edge_split_fwd(pq1[:, :128], pq1[:, 128:], idx_f, N, bn=net.convDG1[1])
+            s1sum, usel1, arg1, stg1 = ops.edge_split_fwd(pq1[:, :128], pq1[:, 128:], idx_f, N, bn=net.convDG1[1])
             ops.affine_act(usel1, stg1.scale, stg1.shift, act, slope, out=cat[:, 0:128])                # x1
             y1e, z, zsel, arg2, stg2 = ops.edge_mlp_train(pq1[:, :128], pq1[:, 128:], idx_f, N, stg1.scale, stg1.shift, w2,
                                                           net.convDG2[1], act, slope, bf16)
@@ -478,7 +479,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         ops.affine_act(usel3, stg3.scale, stg3.shift, act, slope, out=cat[:, 256:512])                # x3
         y3, st3, feat = _PointLayer.fwd(cat, w2d(net.conv3_lpd), net.bn3_lpd, act, slope)
         ctx.net, ctx.dims, ctx.actslope, ctx.bf16 = net, (B, N, M, k), (act, slope), bf16
-        ctx.saved = dict(front=front, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1, post1=post1,
+        ctx.saved = dict(front=front, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1, post1=post1, pq1=pq1 if post1 else None, s1sum=s1sum,
                          u1=u1, stg1=stg1, arg1=arg1, y1e=y1e, z=z, zsel=zsel, stg2=stg2, arg2=arg2, wcat3=wcat3, pq3=pq3, s3=s3, usel3=usel3,
                          stg3=stg3, arg3=arg3, cat=cat, y3=y3, st3=st3)
         if engine.DEBUG_AUX is not None:
@@ -513,7 +514,28 @@ class _LPDNetTrainFn(torch.autograd.Function):
         dwcat3 = _dweight(dpq3, x2)
         ops.gemm(dpq3, S["wcat3"], b_kmajor=True, out=dcat[:, 128:256], accumulate=True)   # dx2 += dPQ3 Wcat3
         dpq1 = torch.empty((M, 256), dtype=torch.float32, device=dfeat.device)
-        if ctx.bf16:
+        w2 = w2d(net.convDG2[0])
+        closed = (S["post1"] and ops.EDGE_MLP_TRAIN_BWD and ops.dg2_bwd_fused_applies(M, k, w2.shape[0]) and w2.shape[1] == 128
+                  and w2.is_contiguous() and M % 32 == 0 and ops.GEMM_BF16X3 and ops._EXACT.depth == 0)
+        if closed:
+            # DG2 + DG1 backward without dZ, dY1e and dU1 tensors: dW2 from one pass over Y1e (arg-max product + Gram matrix); then ONE
+            # MFMA launch builds dZ from Z in its operand loader, multiplies by W2 and leaves G = the gradient in front of BatchNorm1 with its
+            # reductions (lpd_edge_mlp_train_bwd); then ONE gather pass over the transposed graph gives dP / dQ in closed form
+            dt = torch.bfloat16 if ctx.bf16 else torch.float32
+            dpre2, red2 = ops.bn_sel_bwd_reduce(dcat[:, 128:256], S["zsel"], S["stg2"], act, slope, dtype=dt)
+            dw2 = (ops.edge_dw_sel_bf16 if ctx.bf16 else ops.edge_dw_sel_f32)(S["y1e"], S["arg2"], dpre2, k, w2, S["stg2"], red2)
+            redf = red2.float()
+            dgs2, dbs2 = redf[1], redf[0]
+            G1, gsum1, red1 = ops.edge_mlp_train_bwd(S["z"], S["arg2"], dpre2, w2, S["stg2"], red2, S["y1e"], S["arg1"], dcat[:, 0:128],
+                                                     net.convDG1[1], k, act, slope)
+            pq1 = S["pq1"]
+            ops.edge_dense_bwd_apply(G1, gsum1, S["s1sum"], pq1[:, :128], pq1[:, 128:], ops.GraphT(S["idx_f"], N), S["stg1"], red1, k,
+                                     dP=dpq1[:, :128], dQ=dpq1[:, 128:])
+            red1f = red1.float()
+            dgs1, dbs1 = red1f[1], red1f[0]
+            du1 = dy1e = None
+            del G1, gsum1
+        elif ctx.bf16:
             # DG2: x2 = groupmax(act(BN(Z))), Z = Y1e W2^T  (bf16 edge tensors, bf16 MFMA products)
             w2 = w2d(net.convDG2[0])
             if ops.dg2_bwd_fused_applies(M, k, w2.shape[0]) and w2.shape[1] == 128:

@@ -1351,6 +1351,9 @@ def edge_bn_bwd_bf16(dOut, arg, k, X, st, act, slope, dense=None, dQ=None, xsel=
 EDGE_MLP_TRAIN = os.environ.get("LPD_EDGE_MLP_TRAIN", "1") != "0"      # train-mode DG1 -> DG2 stage in one launch (lpd_edge_mlp_train)
 
 
+EDGE_MLP_TRAIN_BWD = os.environ.get("LPD_EDGE_MLP_TRAIN_BWD", "1") != "0"   # ... and its backward in two launches (lpd_edge_mlp_train_bwd)
+
+
 def edge_mlp_train_applies(M, N, k, C, act, slope):
     return (EDGE_MLP_TRAIN and C == 128 and M % 64 == 0 and N % 64 == 0 and 0 < k <= 255 and GEMM_BF16X3 and _EXACT.depth == 0
             and (act == ACT_NONE or (act == ACT_LEAKY and 0.0 < slope <= 1.0)))
@@ -1379,6 +1382,46 @@ def edge_mlp_train(P, Q, idx, N, scale1, shift1, W2, bn2, act, slope, bf16):
           _ptr(shift1), _ptr(W2), _ptr(bn2.weight), _ptr(Y), _ptr(Z), int(bool(bf16)), _ptr(zsel), 128, _ptr(arg2), _ptr(sums[0]),
           _ptr(sums[1]), M, N, k, act, float(slope), _stat_ws(), _stream())
     return Y, Z, zsel, arg2, _bn_finalize(sums, M * k, 128, bn2)
+
+
+def edge_mlp_train_bwd(Z, arg2, dpre2, W2, st2, red2, Y1e, arg1, dx1, bn1, k, act, slope):
+    """Backward of edge_mlp_train, dense part (include/lpd_hip.h lpd_edge_mlp_train_bwd): -> (G [E,128] like Z: the gradient in front of
+    BatchNorm1, gsum [M,128] = its sums over the k slots of a point, red1 [2,128] fp64 = (dbeta1, dgamma1))."""
+    M, C = arg2.shape
+    bf16 = Z.dtype == torch.bfloat16
+    for t, name in ((Z, "Z"), (Y1e, "Y1e")):
+        if t.dtype != Z.dtype or tuple(t.shape) != (M * k, 128) or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError(f"edge_mlp_train_bwd: {name} must be a contiguous [M k, 128] tensor of Z's type")
+    if dpre2.dtype != Z.dtype or tuple(dpre2.shape) != (M, 128) or not dpre2.is_contiguous():
+        raise ValueError("edge_mlp_train_bwd: dpre2 must be [M, 128] of Z's type (bn_sel_bwd_reduce)")
+    _req(W2, "W2")
+    if C != 128 or tuple(W2.shape) != (128, 128) or not W2.is_contiguous() or M % 32 != 0:
+        raise ValueError("edge_mlp_train_bwd: 128 -> 128 channels, M % 32 == 0")
+    lddx1 = _rows(dx1, "dx1")
+    beta1, rgamma1, inv_ns = _post_consts(None, bn1, act, slope)
+    G = torch.empty_like(Z)
+    gsum = torch.empty((M, 128), dtype=torch.float32, device=Z.device)
+    red1 = torch.empty((2, 128), dtype=torch.float64, device=Z.device)
+    lib = _lib.load()
+    _call(f"edge_mlp_train_bwd[{'bf16' if bf16 else 'f32'}]", lib.lpd_edge_mlp_train_bwd, _ptr(Z), _ptr(arg2), _ptr(dpre2), _ptr(W2),
+          _ptr(st2.scale), _ptr(st2.mean), _ptr(st2.invstd), _ptr(red2[0]), _ptr(red2[1]), _ptr(Y1e), _ptr(arg1), _ptr(dx1), lddx1,
+          _ptr(beta1), _ptr(rgamma1), int(bf16), _ptr(G), _ptr(gsum), _ptr(red1[0]), _ptr(red1[1]), M, k, act, float(slope), float(inv_ns),
+          _stat_ws(), _stream())
+    return G, gsum, red1
+
+
+def edge_dense_bwd_apply(G, gsum, S, P, Q, graph, st, red, k, dP, dQ):
+    """dP, dQ of the edge tensor U = P[nbr] + Q behind a train-mode BatchNorm whose incoming gradient G [M k, C] is dense, in closed
+    form from one gather pass over the transposed graph (include/lpd_hip.h lpd_edge_dense_bwd_apply)."""
+    M, C = gsum.shape
+    ldp, ldq, lddp, lddq = _rows(P, "P"), _rows(Q, "Q"), _rows(dP, "dP"), _rows(dQ, "dQ")
+    bf16 = G.dtype == torch.bfloat16
+    if tuple(G.shape) != (M * k, C) or not G.is_contiguous():
+        raise ValueError("edge_dense_bwd_apply: G must be a contiguous [M k, C] tensor")
+    lib = _lib.load()
+    _call(f"edge_dense_bwd_apply[C={C}]", lib.lpd_edge_dense_bwd_apply, _ptr(G), int(bf16), _ptr(gsum), _ptr(S), _ptr(P), ldp, _ptr(Q), ldq,
+          _ptr(graph.rowptr), _ptr(graph.edges), _ptr(dP), lddp, _ptr(dQ), lddq, M, C, k, _ptr(st.scale), _ptr(st.mean), _ptr(st.invstd),
+          _ptr(red[0]), _ptr(red[1]), _stream())
 
 
 def dg2_bwd_fused_applies(M, k, C):
