@@ -460,11 +460,13 @@ int lpd_edge_split_fwd(const float* P, long long ldp, const float* Q, long long 
  *                   statistics of U = P[nbr] + Q without writing U, and x1 = max_t Y1e with its arg-max through act(s1 usel + b1))
  *   Z = Y1e W2^T (raw), sum / sumsq = its column statistics (fp64, zeroed here), zsel[i][c] = max_t Z (gamma2[c] >= 0) or min_t Z,
  *   arg2[i][c] = the first slot t that attains it.
- * bf16 != 0: Y1e and Z are bf16 tensors (bf16 storage mode) and the product takes the rounded Y1e (two MFMA products with the split
- * weight); else fp32 tensors and three split-bf16 products.  128 -> 128 channels, M % 64 == 0, N % 64 == 0, k <= 255.
+ * bf16 != 0: Y1e is a bf16 tensor (bf16 storage mode) and the product takes the rounded Y1e (two MFMA products with the split
+ * weight); else fp32 and three split-bf16 products.  z_bf16 != 0: Z is stored as bf16 (required with bf16 Y1e, the default with
+ * fp32 Y1e too: statistics and selection come from the fp32 accumulators, the stored Z only feeds the backward's xhat2 m2 term).
+ * 128 -> 128 channels, M % 64 == 0, N % 64 == 0, k <= 255.
  */
 int lpd_edge_mlp_train(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1, const float* b1,
-                       const float* W2, const float* gamma2, void* Y1e, void* Z, int bf16, float* zsel, int ldsel, uint8_t* arg2,
+                       const float* W2, const float* gamma2, void* Y1e, void* Z, int bf16, int z_bf16, float* zsel, int ldsel, uint8_t* arg2,
                        double* sum, double* sumsq, int M, int N, int k, int act, float slope, double* stat_ws, void* stream);
 /*
  * Backward of the train-mode DG1 -> DG2 stage (the counterpart of lpd_edge_mlp_train), two launches instead of the chain
@@ -475,11 +477,11 @@ int lpd_edge_mlp_train(const float* P, int ldp, const float* Q, int ldq, const i
  *     act' and xhat1 = (pre1 - beta1) rgamma1 come from the stored post-activation Y1e (pre1 = y or y * inv_ns).
  *   lpd_edge_dense_bwd_apply: dP, dQ of U = P[nbr] + Q in closed form from ONE gather pass over the transposed graph (a G row and a Q
  *     row per edge): dP_j = s (sum G - deg m1 - m2 invstd (deg (P_j - mu) + sum Q_i)), dQ_j = s (gsum_j - k m1 - m2 invstd (S_j + k (Q_j - mu))).
- * bf16 != 0: Z, Y1e, dpre2 and G are bf16.  M % 32 == 0, 128 channels, k <= 255.
+ * bf16 != 0: Y1e, dpre2 and G are bf16; z_bf16 != 0: Z is bf16 (as lpd_edge_mlp_train stored it).  M % 32 == 0, 128 channels, k <= 255.
  */
 int lpd_edge_mlp_train_bwd(const void* Z, const uint8_t* arg2, const void* dpre2, const float* W2, const float* scale2, const float* mean2,
                            const float* invstd2, const double* dbeta2, const double* dgamma2, const void* Y1e, const uint8_t* arg1,
-                           const float* dx1, int lddx1, const float* beta1, const float* rgamma1, int bf16, void* G, float* gsum,
+                           const float* dx1, int lddx1, const float* beta1, const float* rgamma1, int bf16, int z_bf16, void* G, float* gsum,
                            double* dbeta1, double* dgamma1, int M, int k, int act, float slope, float inv_ns, double* stat_ws, void* stream);
 int lpd_edge_dense_bwd_apply(const void* G, int bf16, const float* gsum, const float* S, const float* P, long long ldp, const float* Q,
                              long long ldq, const int32_t* rowptr, const int32_t* edges, float* dP, long long lddp, float* dQ, long long lddq,

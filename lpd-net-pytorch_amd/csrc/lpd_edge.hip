@@ -932,8 +932,12 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
 //   sum Z, sum Z^2 per channel (fp32 per lane over the block's 64 x k rows, fp64 across blocks through the replicas)
 //   zsel[i][c] = sel_t Z[(i,t)][c], arg2[i][c] = first t that attains it (sel = max where gamma2[c] >= 0, min otherwise: the
 //   selection needs the SIGN of the BatchNorm2 scale only, which is known before the statistics)
-// BF16 = bf16 storage (autograd.set_train_storage("bf16")): Y1e and Z are stored as bf16, the product takes the ROUNDED Y1e as its
+// BF16 = bf16 storage (autograd.set_train_storage("bf16")): Y1e is stored as bf16 and the product takes the ROUNDED Y1e as its
 // operand (a_hi only) against the split weight (two MFMA products, as lpd_gemm_bf16s); fp32 storage: three split-bf16 products.
+// ZBF16: Z is stored as bf16 -- in BOTH storage modes by default: its statistics and its selection are taken from the fp32
+// accumulators here, and the only later reader of the stored Z is the backward's xhat2 m2 term (the dense, mean-sized part of
+// BatchNorm2's backward, 1e-3 of the gradient: a 2^-9 rounding of it is 4e-6), so fp32 rows would be 1.85 GB written and read
+// back for nothing.
 // x1 = max_t Y1e and its arg-max come from the statistics pass (the activation is monotone), not from here: the running maximum
 // of 64 points x 128 channels would not fit the register budget of two workgroups per CU.
 // ------------------------------------------------------------------------------------------
@@ -950,7 +954,7 @@ struct EdgeMlpTrainArgs {
 typedef unsigned em_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned em_u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool BF16>
+template <bool BF16, bool ZBF16>
 __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_kernel(EdgeMlpTrainArgs g)
 {
     constexpr int CM = 128;
@@ -1003,18 +1007,18 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_kernel(EdgeMlpTr
             pg[e] = *reinterpret_cast<const float4*>(g.P + (size_t)row * g.ldp + c4 * 4);
         }
     };
-    constexpr int ES = BF16 ? 2 : 4;                                       // bytes per stored element
+    constexpr int ES = BF16 ? 2 : 4, ESZ = ZBF16 ? 2 : 4;                  // bytes per stored element of Y1e / of Z
     // The block's slabs of Y1e and Z (64 k rows) as buffer resources: a store is (resource, this thread's constant 32-bit offset,
     // scalar offset of the row) -- with flat pointers the compiler kept a 64-bit address register per store of the unrolled
     // epilogue (85-100 spilled registers)
-    const unsigned slab = (unsigned)EM_PTS * (unsigned)g.k * (CM * ES);
+    const unsigned slab = (unsigned)EM_PTS * (unsigned)g.k * (CM * ES), slabz = (unsigned)EM_PTS * (unsigned)g.k * (CM * ESZ);
     const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<unsigned char*>(g.Y) + (size_t)m0 * g.k * (CM * ES), 0, slab, 0x00020000);
     const __amdgpu_buffer_rsrc_t zres = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<unsigned char*>(g.Z) + (size_t)m0 * g.k * (CM * ES), 0, slab, 0x00020000);
-    const unsigned rowb = (unsigned)g.k * (CM * ES);                       // bytes between consecutive POINTS' rows of one slot
+        reinterpret_cast<unsigned char*>(g.Z) + (size_t)m0 * g.k * (CM * ESZ), 0, slabz, 0x00020000);
+    const unsigned rowb = (unsigned)g.k * (CM * ES), rowbz = (unsigned)g.k * (CM * ESZ);      // bytes between consecutive POINTS' rows of one slot
     const unsigned yoff = ((unsigned)prow * (unsigned)g.k * CM + c4 * 4) * ES;       // M k 128 ES < 2^32 (host check)
-    const unsigned zoff = ((unsigned)(4 * h) * (unsigned)g.k * CM + (BF16 ? (n & ~1) : n)) * ES;
+    const unsigned zoff = ((unsigned)(4 * h) * (unsigned)g.k * CM + (ZBF16 ? (n & ~1) : n)) * ESZ;
     // slot t's tile into LDS buffer `buf` AND its rows (i, t) into Y1e: 32 threads (c4) cover one 256- / 512-byte row
     auto build = [&](int buf, int t) {
         __bf16* hi_img = smem16 + buf * NIMG * IMG;
@@ -1084,9 +1088,9 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_kernel(EdgeMlpTr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[i][r];
-                const unsigned zsoff = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rowb + (unsigned)t * (CM * ES);      // uniform
+                const unsigned zsoff = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rowbz + (unsigned)t * (CM * ESZ);      // uniform
                 const float z = sgn * v;
-                if constexpr (BF16) {
+                if constexpr (ZBF16) {
                     // the stored value is the rounded one; statistics and selection are taken of the fp32 value (as lpd_gemm_bf16s +
                     // lpd_group_sel_stats_bf16 take them of the stored one: the difference is the 2^-9 the storage mode states)
                     const __bf16 zb = (__bf16)z;
@@ -1150,10 +1154,10 @@ struct EdgeMlpBwdArgs {
 
 constexpr int EB_PTS = 32;
 
-template <bool BF16>
+template <bool BF16, bool ZBF16>
 __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeMlpBwdArgs g)
 {
-    constexpr int CM = 128, LDK = CM + 8, IMG = EB_PTS * LDK, KS = CM / 16, NIMG = BF16 ? 1 : 2, ES = BF16 ? 2 : 4;
+    constexpr int CM = 128, LDK = CM + 8, IMG = EB_PTS * LDK, KS = CM / 16, NIMG = BF16 ? 1 : 2, ES = BF16 ? 2 : 4, ESZ = ZBF16 ? 2 : 4;
     constexpr int RPP = EM_THREADS / (CM / 4), PASSES = EB_PTS / RPP;      // 8 rows per pass, 4 passes
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];       // [2 buffers][hi (| lo)][32][LDK]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
@@ -1206,12 +1210,13 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
     const unsigned slab = (unsigned)EB_PTS * (unsigned)g.k * (CM * ES);
     const size_t slab0 = (size_t)m0 * g.k * (CM * ES);
     const __amdgpu_buffer_rsrc_t zres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.Z)) + slab0, 0, slab, 0x00020000);
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.Z)) + (size_t)m0 * g.k * (CM * ESZ), 0,
+        (unsigned)EB_PTS * (unsigned)g.k * (CM * ESZ), 0x00020000);
     const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.Y)) + slab0, 0, slab, 0x00020000);
     const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(g.G) + slab0, 0, slab, 0x00020000);
-    const unsigned rowb = (unsigned)g.k * (CM * ES);
-    const unsigned zoff = ((unsigned)prow * (unsigned)g.k * CM + c4 * 4) * ES;                    // builder: its rows of Z
+    const unsigned rowb = (unsigned)g.k * (CM * ES), rowbz = (unsigned)g.k * (CM * ESZ);
+    const unsigned zoff = ((unsigned)prow * (unsigned)g.k * CM + c4 * 4) * ESZ;                   // builder: its rows of Z
     const unsigned eoff = ((unsigned)(4 * h) * (unsigned)g.k * CM + n) * ES;                      // epilogue: element (row 4 h + ., column n)
     const unsigned goff = ((unsigned)(4 * h) * (unsigned)g.k * CM + (BF16 ? (n & ~1) : n)) * ES;
 
@@ -1227,13 +1232,13 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
     const float beta1 = g.beta1[n], rg1 = g.rgamma1[n];
     const float ns = lpd_neg_slope(g.act, g.slope), inv_ns = g.inv_ns;
 
-    typedef unsigned zraw_t __attribute__((ext_vector_type(BF16 ? 2 : 4)));
+    typedef unsigned zraw_t __attribute__((ext_vector_type(ZBF16 ? 2 : 4)));
     zraw_t zr[PASSES];
     auto load_z = [&](int t) {
 #pragma unroll
         for (int e = 0; e < PASSES; ++e) {
-            const unsigned so = (unsigned)(RPP * e) * rowb + (unsigned)t * (CM * ES);
-            if constexpr (BF16) zr[e] = __builtin_amdgcn_raw_buffer_load_b64(zres, zoff, so, 0);
+            const unsigned so = (unsigned)(RPP * e) * rowbz + (unsigned)t * (CM * ESZ);
+            if constexpr (ZBF16) zr[e] = __builtin_amdgcn_raw_buffer_load_b64(zres, zoff, so, 0);
             else zr[e] = __builtin_amdgcn_raw_buffer_load_b128(zres, zoff, so, 0);
         }
     };
@@ -1244,7 +1249,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
         for (int e = 0; e < PASSES; ++e) {
             const int p = prow + RPP * e;
             float z[4];
-            if constexpr (BF16) {
+            if constexpr (ZBF16) {
                 z[0] = __uint_as_float(zr[e][0] << 16); z[1] = __uint_as_float(zr[e][0] & 0xffff0000u);
                 z[2] = __uint_as_float(zr[e][1] << 16); z[3] = __uint_as_float(zr[e][1] & 0xffff0000u);
             } else {
@@ -1260,7 +1265,6 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
             if constexpr (!BF16) *reinterpret_cast<uint2*>(hi_img + IMG + p * LDK + c4 * 4) = ll;
         }
     };
-    typedef unsigned short yraw_bf; 
     unsigned yv[16];
     auto load_y = [&](int t) {
 #pragma unroll
@@ -1509,7 +1513,7 @@ extern "C" int lpd_edge_mlp_bf16x3s(const float* P, int ldp, const float* Q, int
 // Train-mode DG1 -> DG2 stage in one launch (edge_mlp_train_kernel): Y1e, Z (raw), the statistics of Z, the selected raw values and
 // their slots.  bf16 != 0: Y1e / Z are bf16 tensors.  M % 64 == 0, N % 64 == 0, 128 -> 128 channels, k <= 255.
 extern "C" int lpd_edge_mlp_train(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1, const float* b1,
-                                  const float* W2, const float* gamma2, void* Y1e, void* Z, int bf16, float* zsel, int ldsel,
+                                  const float* W2, const float* gamma2, void* Y1e, void* Z, int bf16, int z_bf16, float* zsel, int ldsel,
                                   uint8_t* arg2, double* sum, double* sumsq, int M, int N, int k, int act, float slope, double* stat_ws,
                                   void* stream_)
 {
@@ -1527,13 +1531,14 @@ extern "C" int lpd_edge_mlp_train(const float* P, int ldp, const float* Q, int l
     EdgeMlpTrainArgs g{P, Q, idx, s1, b1, W2, gamma2, Y1e, Z, zsel, arg2, ws.sum(), ws.sumsq(), M, N, k, ldp, ldq, ldsel, act, slope};
     using Cfg = EdgeMlpX3Cfg<128, 128>;
     const size_t lds = (size_t)(bf16 ? 2 : 4) * Cfg::IMG * sizeof(__bf16) + (size_t)EM_PTS * k * sizeof(int);
-    if (bf16) {
-        (void)hipFuncSetAttribute((const void*)edge_mlp_train_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(edge_mlp_train_kernel<true>, dim3(M / EM_PTS), dim3(EM_THREADS), lds, stream, g);
-    } else {
-        (void)hipFuncSetAttribute((const void*)edge_mlp_train_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(edge_mlp_train_kernel<false>, dim3(M / EM_PTS), dim3(EM_THREADS), lds, stream, g);
-    }
+    LPD_CHECK_ARG(!bf16 || z_bf16, "lpd_edge_mlp_train: bf16 Y1e goes with bf16 Z");
+    auto launch = [&](auto kern) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(M / EM_PTS), dim3(EM_THREADS), lds, stream, g);
+    };
+    if (bf16) launch(edge_mlp_train_kernel<true, true>);
+    else if (z_bf16) launch(edge_mlp_train_kernel<false, true>);
+    else launch(edge_mlp_train_kernel<false, false>);
     LPD_CHECK_LAUNCH("lpd_edge_mlp_train");
     return lpd_stat_finish(ws, sum, sumsq, 128, stream);
 }
@@ -1544,7 +1549,7 @@ extern "C" int lpd_edge_mlp_train(const float* P, int ldp, const float* Q, int l
 extern "C" int lpd_edge_mlp_train_bwd(const void* Z, const uint8_t* arg2, const void* dpre2, const float* W2, const float* scale2,
                                       const float* mean2, const float* invstd2, const double* dbeta2, const double* dgamma2, const void* Y1e,
                                       const uint8_t* arg1, const float* dx1, int lddx1, const float* beta1, const float* rgamma1, int bf16,
-                                      void* G, float* gsum, double* dbeta1, double* dgamma1, int M, int k, int act, float slope, float inv_ns,
+                                      int z_bf16, void* G, float* gsum, double* dbeta1, double* dgamma1, int M, int k, int act, float slope, float inv_ns,
                                       double* stat_ws, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -1559,8 +1564,10 @@ extern "C" int lpd_edge_mlp_train_bwd(const void* Z, const uint8_t* arg2, const 
     EdgeMlpBwdArgs g{Z, arg2, dpre2, W2, scale2, mean2, invstd2, dbeta2, dgamma2, Y1e, arg1, dx1, lddx1, beta1, rgamma1, G, gsum,
                      ws.sum(), ws.sumsq(), M, k, act, slope, inv_ns};
     const size_t lds = (size_t)(bf16 ? 2 : 4) * EB_PTS * (128 + 8) * sizeof(__bf16);
-    if (bf16) hipLaunchKernelGGL(edge_mlp_train_bwd_kernel<true>, dim3(M / EB_PTS), dim3(EM_THREADS), lds, stream, g);
-    else hipLaunchKernelGGL(edge_mlp_train_bwd_kernel<false>, dim3(M / EB_PTS), dim3(EM_THREADS), lds, stream, g);
+    LPD_CHECK_ARG(!bf16 || z_bf16, "lpd_edge_mlp_train_bwd: bf16 Y1e goes with bf16 Z");
+    if (bf16) hipLaunchKernelGGL((edge_mlp_train_bwd_kernel<true, true>), dim3(M / EB_PTS), dim3(EM_THREADS), lds, stream, g);
+    else if (z_bf16) hipLaunchKernelGGL((edge_mlp_train_bwd_kernel<false, true>), dim3(M / EB_PTS), dim3(EM_THREADS), lds, stream, g);
+    else hipLaunchKernelGGL((edge_mlp_train_bwd_kernel<false, false>), dim3(M / EB_PTS), dim3(EM_THREADS), lds, stream, g);
     LPD_CHECK_LAUNCH("lpd_edge_mlp_train_bwd");
     return lpd_stat_finish(ws, dbeta1, dgamma1, 128, stream);
 }

@@ -1359,9 +1359,13 @@ def edge_mlp_train_applies(M, N, k, C, act, slope):
             and (act == ACT_NONE or (act == ACT_LEAKY and 0.0 < slope <= 1.0)))
 
 
-def edge_mlp_train(P, Q, idx, N, scale1, shift1, W2, bn2, act, slope, bf16):
-    """Train-mode DG1 -> DG2 stage in one launch (include/lpd_hip.h lpd_edge_mlp_train): -> (Y1e [E,128], Z [E,128] (bf16 or fp32),
-    zsel [M,128] raw selected values, arg2 [M,128] uint8, BNStats of Z with bn2's running statistics updated)."""
+Z_BF16 = os.environ.get("LPD_Z_BF16", "1") != "0"      # fp32 storage mode: the stored Z of the DG2 stage as bf16 (see lpd_edge_mlp_train)
+
+
+def edge_mlp_train(P, Q, idx, N, scale1, shift1, W2, bn2, act, slope, bf16, z_bf16=None):
+    """Train-mode DG1 -> DG2 stage in one launch (include/lpd_hip.h lpd_edge_mlp_train): -> (Y1e [E,128] (bf16 or fp32), Z [E,128]
+    (bf16 unless z_bf16 is False), zsel [M,128] raw selected values, arg2 [M,128] uint8, BNStats of Z with bn2's running statistics updated)."""
+    z_bf16 = bool(bf16 or (Z_BF16 if z_bf16 is None else z_bf16))
     ldp, ldq = _rows(P, "P"), _rows(Q, "Q")
     _req(idx, "idx", torch.int32)
     idx = idx.reshape(-1, idx.shape[-1]).contiguous()
@@ -1372,14 +1376,14 @@ def edge_mlp_train(P, Q, idx, N, scale1, shift1, W2, bn2, act, slope, bf16):
         raise ValueError("edge_mlp_train: shape mismatch (128 -> 128 channels)")
     dt = torch.bfloat16 if bf16 else torch.float32
     Y = torch.empty((M * k, 128), dtype=dt, device=P.device)
-    Z = torch.empty((M * k, 128), dtype=dt, device=P.device)
+    Z = torch.empty((M * k, 128), dtype=torch.bfloat16 if z_bf16 else torch.float32, device=P.device)
     zsel = torch.empty((M, 128), dtype=torch.float32, device=P.device)
     arg2 = torch.empty((M, 128), dtype=torch.uint8, device=P.device)
     sums = torch.empty((2, 128), dtype=torch.float64, device=P.device)
     scale1, shift1 = _vec(scale1, "scale1", 128), _vec(shift1, "shift1", 128)
     lib = _lib.load()
     _call(f"edge_mlp_train[{'bf16' if bf16 else 'f32'}]", lib.lpd_edge_mlp_train, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(scale1),
-          _ptr(shift1), _ptr(W2), _ptr(bn2.weight), _ptr(Y), _ptr(Z), int(bool(bf16)), _ptr(zsel), 128, _ptr(arg2), _ptr(sums[0]),
+          _ptr(shift1), _ptr(W2), _ptr(bn2.weight), _ptr(Y), _ptr(Z), int(bool(bf16)), int(z_bf16), _ptr(zsel), 128, _ptr(arg2), _ptr(sums[0]),
           _ptr(sums[1]), M, N, k, act, float(slope), _stat_ws(), _stream())
     return Y, Z, zsel, arg2, _bn_finalize(sums, M * k, 128, bn2)
 
@@ -1388,24 +1392,24 @@ def edge_mlp_train_bwd(Z, arg2, dpre2, W2, st2, red2, Y1e, arg1, dx1, bn1, k, ac
     """Backward of edge_mlp_train, dense part (include/lpd_hip.h lpd_edge_mlp_train_bwd): -> (G [E,128] like Z: the gradient in front of
     BatchNorm1, gsum [M,128] = its sums over the k slots of a point, red1 [2,128] fp64 = (dbeta1, dgamma1))."""
     M, C = arg2.shape
-    bf16 = Z.dtype == torch.bfloat16
+    bf16, z_bf16 = Y1e.dtype == torch.bfloat16, Z.dtype == torch.bfloat16
     for t, name in ((Z, "Z"), (Y1e, "Y1e")):
-        if t.dtype != Z.dtype or tuple(t.shape) != (M * k, 128) or not t.is_contiguous() or not t.is_cuda:
-            raise ValueError(f"edge_mlp_train_bwd: {name} must be a contiguous [M k, 128] tensor of Z's type")
-    if dpre2.dtype != Z.dtype or tuple(dpre2.shape) != (M, 128) or not dpre2.is_contiguous():
-        raise ValueError("edge_mlp_train_bwd: dpre2 must be [M, 128] of Z's type (bn_sel_bwd_reduce)")
+        if t.dtype not in (torch.bfloat16, torch.float32) or tuple(t.shape) != (M * k, 128) or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError(f"edge_mlp_train_bwd: {name} must be a contiguous [M k, 128] bf16 / fp32 tensor")
+    if (bf16 and not z_bf16) or dpre2.dtype != Y1e.dtype or tuple(dpre2.shape) != (M, 128) or not dpre2.is_contiguous():
+        raise ValueError("edge_mlp_train_bwd: dpre2 must be [M, 128] of Y1e's type (bn_sel_bwd_reduce); bf16 Y1e goes with bf16 Z")
     _req(W2, "W2")
     if C != 128 or tuple(W2.shape) != (128, 128) or not W2.is_contiguous() or M % 32 != 0:
         raise ValueError("edge_mlp_train_bwd: 128 -> 128 channels, M % 32 == 0")
     lddx1 = _rows(dx1, "dx1")
     beta1, rgamma1, inv_ns = _post_consts(None, bn1, act, slope)
-    G = torch.empty_like(Z)
+    G = torch.empty_like(Y1e)
     gsum = torch.empty((M, 128), dtype=torch.float32, device=Z.device)
     red1 = torch.empty((2, 128), dtype=torch.float64, device=Z.device)
     lib = _lib.load()
     _call(f"edge_mlp_train_bwd[{'bf16' if bf16 else 'f32'}]", lib.lpd_edge_mlp_train_bwd, _ptr(Z), _ptr(arg2), _ptr(dpre2), _ptr(W2),
           _ptr(st2.scale), _ptr(st2.mean), _ptr(st2.invstd), _ptr(red2[0]), _ptr(red2[1]), _ptr(Y1e), _ptr(arg1), _ptr(dx1), lddx1,
-          _ptr(beta1), _ptr(rgamma1), int(bf16), _ptr(G), _ptr(gsum), _ptr(red1[0]), _ptr(red1[1]), M, k, act, float(slope), float(inv_ns),
+          _ptr(beta1), _ptr(rgamma1), int(bf16), int(z_bf16), _ptr(G), _ptr(gsum), _ptr(red1[0]), _ptr(red1[1]), M, k, act, float(slope), float(inv_ns),
           _stat_ws(), _stream())
     return G, gsum, red1
 

@@ -1193,7 +1193,11 @@ def test_edge_mlp_train_equals_the_materialised_stage(cuda, bf16, N, k, B):
     _, usel, arg1_b, st1b = ops.edge_split_fwd(P, Q, idx, N, bn=bn1b)
     x1_b = ops.affine_act(usel, st1b.scale, st1b.shift, act, slope)
     assert ops.edge_mlp_train_applies(M, N, k, C, act, slope)
-    Y_b, Z_b, zsel_b, arg2_b, st2_b = ops.edge_mlp_train(P, Q, idx, N, st1.scale, st1.shift, W2, bn2b, act, slope, bf16)
+    Y_b, Z_b, zsel_b, arg2_b, st2_b = ops.edge_mlp_train(P, Q, idx, N, st1.scale, st1.shift, W2, bn2b, act, slope, bf16, z_bf16=bf16)
+    if not bf16:      # the default of the fp32 storage mode: Z rounded to bf16, everything else as with fp32 Z
+        Y_c, Z_c, zsel_c, arg2_c, _ = ops.edge_mlp_train(P, Q, idx, N, st1.scale, st1.shift, W2, _bn_for(C, 4).to(cuda).train(), act, slope, False)
+        assert Z_c.dtype == torch.bfloat16 and torch.equal(Z_c, Z_b.to(torch.bfloat16)) and torch.equal(Y_c, Y_b)
+        assert torch.equal(zsel_c, zsel_b) and torch.equal(arg2_c, arg2_b)
     assert torch.equal(arg1_a, arg1_b) and _rel(x1_b, x1_a) < 1e-5
     assert _rel(st1b.mean, st1.mean) < 1e-5 and _rel(st1b.invstd, st1.invstd) < 1e-5
     if bf16:
@@ -1250,13 +1254,16 @@ def test_edge_mlp_train_bwd_equals_the_chain(cuda, bf16, N, k, B):
         w1.copy_(torch.where(w1.abs() < 0.2, torch.where(w1 < 0, -0.2, 0.2).to(w1), w1))
     s1sum, usel, arg1, st1 = ops.edge_split_fwd(P, Q, idx, N, bn=bn1)
     Y, Z, zsel, arg2, st2 = ops.edge_mlp_train(P, Q, idx, N, st1.scale, st1.shift, W2, bn2, act, slope, bf16)
+    assert Z.dtype == torch.bfloat16                     # both storage modes keep Z as bf16 (only the backward's xhat2 m2 term reads it)
+    Zc = Z if bf16 else ops.edge_mlp_train(P, Q, idx, N, st1.scale, st1.shift, W2, _bn_for(C, 4).to(cuda).train(), act, slope, False,
+                                           z_bf16=False)[1]      # fp32 Z for the chain's fp32 product kernel
     dcat = torch.randn(M, 512, generator=g).to(cuda)
     dx1, dx2 = dcat[:, 0:128], dcat[:, 128:256]
     dt = torch.bfloat16 if bf16 else torch.float32
     dpre2, red2 = ops.bn_sel_bwd_reduce(dx2, zsel, st2, act, slope, dtype=dt)
     graph = ops.GraphT(idx, N)
     # ---- the chain
-    dY = (ops.gemm_bf16s_bnbwd if bf16 else ops.gemm_f32s_bnbwd)(Z, arg2, dpre2, k, W2, st2, red2)
+    dY = (ops.gemm_bf16s_bnbwd if bf16 else ops.gemm_f32s_bnbwd)(Zc, arg2, dpre2, k, W2, st2, red2)
     dq_a, dp_a = torch.empty(M, C, device=cuda), torch.empty(M, C, device=cuda)
     if bf16:
         dU, dg_a, db_a = ops.edge_bn_bwd_bf16(dx1, arg1, k, Y, st1, act, slope, dense=dY, dQ=dq_a, post_bn=bn1)
