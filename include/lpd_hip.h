@@ -147,6 +147,12 @@ int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, 
  * i.e. lpd_colstats without the second pass over C. */
 int lpd_gemm_x3w_stats(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
                        double* stat_sum, double* stat_sumsq, int impl, double* stat_ws, void* stream);
+/* The product with the train-mode BatchNorm affine + activation of the layer IN FRONT applied in the operand loader:
+ * C = act(a_scale[k] A[m][k] + a_shift[k]) W^T (+ bias), the transformed rows stored to a_out [M][a_ld] on the way (or null).
+ * Row-major A, N <= 128.  util/lpdnet_model.py:262 (bn3_lpd + act) feeding util/PointNetVlad.py:48 (x . cluster_weights): the
+ * stand-alone affine pass over the [B N, 1024] map disappears.  impl: 0, or 16 = plain bf16 operands (bf16 storage mode). */
+int lpd_gemm_x3w_act(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
+                     const float* a_scale, const float* a_shift, int a_act, float a_slope, float* a_out, int a_ld, int impl, void* stream);
 
 /*
  * The same product for a SHORT reduction with cloud-panel A and C (the neighbour / centre projection of the split SN1 edge

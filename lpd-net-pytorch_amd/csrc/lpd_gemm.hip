@@ -574,6 +574,14 @@ struct X3wArgs {
     int prods;                    // 3 = split-bf16 (fp32-grade), 1 = a_hi b_hi only (bf16-storage training mode)
     double* stat_sum;             // train-mode BatchNorm statistics of the RAW product (+ bias), accumulated in the epilogue:
     double* stat_sumsq;           // column sums / sums of squares over the M rows (fp32 over a block's 128 rows, fp64 atomics); or null
+    // A-operand transform (row-major A, ONE column block: N <= 128): the product takes act(a_scale[k] A[m][k] + a_shift[k]) and the
+    // transformed rows are stored to a_out [M][a_ld] on the way -- a train-mode BatchNorm affine + activation applied where its only
+    // dense consumer reads the raw tensor (conv3 -> bn3 -> NetVLAD assignment), instead of a pass of its own
+    const float* a_scale;
+    const float* a_shift;
+    float* a_out;
+    int a_ld;
+    float a_ns;                   // negative slope of the activation (1 = none, 0 = ReLU)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -634,6 +642,8 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
     //   panels   : register e holds panel e of the chunk (8 channels), row tid / 2, half tid % 2 (one panel's 128 rows
     //              x 32 B = 4 KiB contiguous per instruction)
     float4 ra[2][NF4];
+    float4 rsc[2], rsh[2];      // a_scale / a_shift quad of the chunk in flight (row-major staging: a thread's k quad is f % QR for every e)
+    int rk0[2] = {0, 0};
     const float* a_base;        // loop-invariant part of this thread's A addresses
     {
         if constexpr (PANELS & 1) {
@@ -641,8 +651,15 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
             a_base = A + (long long)(row - m_cloud0) * 8 + (tid & 1) * 4;
         } else a_base = A;
     }
-    auto load_a = [&](int kc, float4 (&r)[NF4]) {
+    auto load_a = [&](int kc, float4 (&r)[NF4], int set) {
         const int k0 = kc * X3V_KC;
+        if constexpr (!(PANELS & 1)) {
+            if (g.a_scale) {      // uniform
+                rk0[set] = k0;
+                rsc[set] = ld4_guard(g.a_scale, k0 + (tid % QR) * 4, g.K);
+                rsh[set] = ld4_guard(g.a_shift, k0 + (tid % QR) * 4, g.K);
+            }
+        }
 #pragma unroll
         for (int e = 0; e < NF4; ++e) {
             if constexpr (PANELS & 1) {
@@ -658,7 +675,7 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
             }
         }
     };
-    auto store_a = [&](int buf, const float4 (&r)[NF4]) {
+    auto store_a = [&](int buf, const float4 (&r)[NF4], int set) {
         __bf16* hi_img = smem16 + buf * 2 * X3V_IMG;
         __bf16* lo_img = hi_img + X3V_IMG;
 #pragma unroll
@@ -666,8 +683,19 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
             int rr, k4;
             if constexpr (PANELS & 1) { rr = tid >> 1; k4 = e * 2 + (tid & 1); }
             else { const int f = e * GEMM_THREADS + tid; rr = f / QR; k4 = f % QR; }
+            float4 v = r[e];
+            if constexpr (!(PANELS & 1)) {
+                if (g.a_scale) {      // uniform: the transformed operand, stored on the way
+                    const float4 sc = rsc[set], sh = rsh[set];
+                    v.x = fmaf(sc.x, v.x, sh.x); v.y = fmaf(sc.y, v.y, sh.y); v.z = fmaf(sc.z, v.z, sh.z); v.w = fmaf(sc.w, v.w, sh.w);
+                    v.x = fmaxf(v.x, 0.0f) + g.a_ns * fminf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f) + g.a_ns * fminf(v.y, 0.0f);
+                    v.z = fmaxf(v.z, 0.0f) + g.a_ns * fminf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f) + g.a_ns * fminf(v.w, 0.0f);
+                    const int m = m0 + rr, kk = rk0[set] + k4 * 4;
+                    if (g.a_out && m < g.M && (!KTAIL || kk + 3 < g.K)) *reinterpret_cast<float4*>(g.a_out + (long long)m * g.a_ld + kk) = v;
+                }
+            }
             bf16x4 hh, ll;
-            split4(r[e].x, r[e].y, r[e].z, r[e].w, hh, ll);
+            split4(v.x, v.y, v.z, v.w, hh, ll);
             *reinterpret_cast<bf16x4*>(hi_img + rr * X3V_LDK + k4 * 4) = hh;
             *reinterpret_cast<bf16x4*>(lo_img + rr * X3V_LDK + k4 * 4) = ll;
         }
@@ -726,12 +754,12 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[set][j], acc[i][j], 0, 0, 0);
     };
     // one chunk; `cur` / `nxt`: the register sets holding A(kc + 1) (loaded during the previous chunk) / receiving A(kc + 2)
-    auto chunk = [&](int kc, float4 (&nxt)[NF4], const float4 (&cur)[NF4]) {
+    auto chunk = [&](int kc, float4 (&nxt)[NF4], const float4 (&cur)[NF4], int nset) {
         const int buf = kc & 1;
         const __bf16* ah = smem16 + buf * 2 * X3V_IMG + col * X3V_LDK + h * 8;
         const __bf16* al = ah + X3V_IMG;
         load_b(phys(kc) * KSC + 1, 1);
-        load_a(phys(min(kc + 2, nchunks - 1)), nxt);   // unconditional (the tail re-reads the last chunk): a branch here makes the
+        load_a(phys(min(kc + 2, nchunks - 1)), nxt, nset);   // unconditional (the tail re-reads the last chunk): a branch here makes the
                                                  // compiler count vmcnt for the path without these loads and over-wait
 #pragma unroll
         for (int s = 0; s < KSC; ++s) {
@@ -740,18 +768,18 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < KSC) load_b((s + 2 < KSC ? phys(kc) : phys(min(kc + 1, nchunks - 1))) * KSC + (s + 2) % KSC, s & 1);   // the set just consumed receives the step after next
         }
-        if (kc + 1 < nchunks) store_a(buf ^ 1, cur);
+        if (kc + 1 < nchunks) store_a(buf ^ 1, cur, nset ^ 1);
         __syncthreads();
     };
 
     load_b(phys(0) * KSC, 0);
-    load_a(phys(0), ra[0]);
-    if (nchunks > 1) load_a(phys(1), ra[1]);
-    store_a(0, ra[0]);
+    load_a(phys(0), ra[0], 0);
+    store_a(0, ra[0], 0);                                 // (before set 0's scale / shift quad is overwritten below)
+    if (nchunks > 1) load_a(phys(1), ra[1], 1);
     __syncthreads();
     for (int kc = 0; kc < nchunks; kc += 2) {
-        chunk(kc, ra[0], ra[1]);                          // A(kc + 1) sits in set 1, A(kc + 2) goes to set 0
-        if (kc + 1 < nchunks) chunk(kc + 1, ra[1], ra[0]);
+        chunk(kc, ra[0], ra[1], 0);                       // A(kc + 1) sits in set 1, A(kc + 2) goes to set 0
+        if (kc + 1 < nchunks) chunk(kc + 1, ra[1], ra[0], 1);
     }
 
     const float ns = g.act == 0 ? 1.0f : (g.act == 1 ? 0.0f : g.slope);
@@ -1145,7 +1173,8 @@ static void x3w_wide_launch(const X3wArgs& g, int NT, hipStream_t stream)
 static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
                          const float* scale, const float* shift, int act, float slope, int accumulate,
                          long long a_cloud, long long c_cloud, int panel_n, int panel_ld, int impl, double* stat_sum, double* stat_sumsq,
-                         double* stat_ws, void* stream_)
+                         double* stat_ws, void* stream_, const float* a_scale = nullptr, const float* a_shift = nullptr, float* a_out = nullptr,
+                         int a_ld = 0, float a_ns = 1.0f)
 {
     hipStream_t stream = (hipStream_t)stream_;
     const bool a_panels = a_cloud != 0, c_panels = c_cloud != 0;
@@ -1169,7 +1198,12 @@ static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, i
         LPD_CHECK_ARG(sws.rep, "lpd_gemm_x3w_stats: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     }
     X3wArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, K, KS, lda, ldc, bias, scale, shift, act, slope, accumulate,
-              a_cloud, c_cloud, panel_n, panel_ld, 0, prods, stat_sum ? sws.sum() : nullptr, stat_sum ? sws.sumsq() : nullptr};
+              a_cloud, c_cloud, panel_n, panel_ld, 0, prods, stat_sum ? sws.sum() : nullptr, stat_sum ? sws.sumsq() : nullptr,
+              a_scale, a_shift, a_out, a_ld, a_ns};
+    LPD_CHECK_ARG(!a_scale || (a_shift && !a_panels && N <= 128 && impl != 3 && (!a_out || (a_ld % 4 == 0 && ((uintptr_t)a_out & 15) == 0))
+                               && (((uintptr_t)a_scale | (uintptr_t)a_shift) & 15) == 0),
+                  "lpd_gemm_x3w_act: the operand transform needs a row-major A and ONE column block (N <= 128)");
+    if (a_scale) impl = 2;
     {   // (it matters for a row-major A with a power-of-two row stride; applied to every layout so that the summation
         //  order -- and with it every bit of the result -- does not depend on the layout of A)
         static const int rot = getenv("LPD_X3W_ROTATE") ? atoi(getenv("LPD_X3W_ROTATE")) : 1;
@@ -1215,4 +1249,17 @@ extern "C" int lpd_gemm_x3w_stats(const float* A, int lda, const void* frags, fl
 {
     LPD_CHECK_ARG(stat_sum && stat_sumsq, "lpd_gemm_x3w_stats: null statistics");
     return gemm_x3w_impl(A, lda, frags, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 0.0f, 0, 0, 0, 0, 0, impl, stat_sum, stat_sumsq, stat_ws, stream_);
+}
+
+// C = act_a(a_scale[k] A[m][k] + a_shift[k]) W^T (+ bias): the train-mode BatchNorm affine + activation of the layer in front applied in
+// the operand loader, the transformed rows stored to a_out [M][a_ld] on the way (may be null).  Row-major A, N <= 128 (one column
+// block: every A element is staged exactly once).  util/lpdnet_model.py:262 (bn3 + act) -> util/PointNetVlad.py:48 (assignment).
+extern "C" int lpd_gemm_x3w_act(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
+                                const float* a_scale, const float* a_shift, int a_act, float a_slope, float* a_out, int a_ld, int impl,
+                                void* stream_)
+{
+    LPD_CHECK_ARG(a_scale && a_shift, "lpd_gemm_x3w_act: null scale / shift");
+    LPD_CHECK_ARG(a_act >= 0 && a_act <= 2, "lpd_gemm_x3w_act: activation %d unsupported", a_act);
+    return gemm_x3w_impl(A, lda, frags, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 0.0f, 0, 0, 0, 0, 0, impl & 16, nullptr, nullptr, nullptr,
+                         stream_, a_scale, a_shift, a_out, a_ld, a_act == 0 ? 1.0f : (a_act == 1 ? 0.0f : a_slope));
 }

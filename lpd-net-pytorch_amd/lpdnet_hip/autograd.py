@@ -479,7 +479,15 @@ class _LPDNetTrainFn(torch.autograd.Function):
         pq3 = ops.linear(cat[:, 128:256], wcat3)                                # [M,512] = [P | Q]
         s3, usel3, arg3, stg3 = ops.edge_split_fwd(pq3[:, :256], pq3[:, 256:], idx_x, N, bn=net.convSN1[1])
         ops.affine_act(usel3, stg3.scale, stg3.shift, act, slope, out=cat[:, 256:512])                # x3
-        y3, st3, feat = _PointLayer.fwd(cat, w2d(net.conv3_lpd), net.bn3_lpd, act, slope)
+        if getattr(_LAST, "defer_act", False) and ops.gemm_act_applies(M, 64, net.conv3_lpd.weight.shape[0]):
+            # PointNetVlad's train path: bn3 + act are applied by the NetVLAD assignment product's operand loader (ops.gemm_act), which
+            # also writes the activated map; this Function hands the RAW conv3 output on, with the affine in _LAST.pending
+            y3, st3 = ops.linear_bn_stats(cat, w2d(net.conv3_lpd), net.bn3_lpd)
+            feat = y3
+            _LAST.pending = (st3.scale, st3.shift, act, slope)
+        else:
+            y3, st3, feat = _PointLayer.fwd(cat, w2d(net.conv3_lpd), net.bn3_lpd, act, slope)
+            _LAST.pending = None
         ctx.net, ctx.dims, ctx.actslope, ctx.bf16 = net, (B, N, M, k), (act, slope), bf16
         ctx.saved = dict(front=front, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1, post1=post1, pq1=pq1 if post1 else None, s1sum=s1sum,
                          u1=u1, stg1=stg1, arg1=arg1, y1e=y1e, z=z, zsel=zsel, stg2=stg2, arg2=arg2, wcat3=wcat3, pq3=pq3, s3=s3, usel3=usel3,
@@ -729,12 +737,21 @@ def _named(module, names):
     return out
 
 
-def lpdnet_features_train(net, x, reorder=True):
-    """LPDNet training-mode forward: ([B*N, E] features with autograd, B, N)."""
+def lpdnet_features_train(net, x, reorder=True, defer_act=False):
+    """LPDNet training-mode forward: ([B*N, E] features with autograd, B, N).  defer_act (PointNetVlad's train path only): where the
+    fused form is built the result is the RAW conv3 output and a 4th value (scale, shift, act, slope) -- bn3's affine and the
+    activation, which netvlad_train(pending=...) applies inside its assignment product; None when nothing is pending."""
     from . import engine
     x = engine._check_input(x, 8) if net.use_mFea else engine.reorder_points(engine._check_input(x), reorder)
     names = list(_LPDNetTrainFn.PARAMS) + _Front.tnet_param_names(net)
-    feat = _LPDNetTrainFn.apply(net, x, *_named(net, names))
+    _LAST.defer_act, _LAST.pending = bool(defer_act), None
+    try:
+        feat = _LPDNetTrainFn.apply(net, x, *_named(net, names))
+    finally:
+        _LAST.defer_act = False
+    pending, _LAST.pending = _LAST.pending, None
+    if defer_act:
+        return feat, x.shape[0], x.shape[2], pending
     return feat, x.shape[0], x.shape[2]
 
 
@@ -860,6 +877,8 @@ def to_point_major_train(x4):
 
 class _Last(__import__("threading").local):
     trans = None      # the input alignment matrix of the latest PointNet train-mode forward on this thread
+    defer_act = False # lpdnet_features_train(defer_act=True) around its Function call
+    pending = None    # ... and what that forward left for the head: (scale, shift, act, slope) of bn3 + activation
 
 
 _LAST = _Last()
@@ -909,22 +928,27 @@ class _NetVLADTrainFn(torch.autograd.Function):
 
     @staticmethod
     @_hooked_forward
-    def forward(ctx, vlad, B, N, feat, *params):
+    def forward(ctx, vlad, B, N, pending, feat, *params):
         ctx.bf16 = TRAIN_STORAGE == "bf16"
         if ctx.bf16:      # the big per-point products (assignment, pooling) take bf16 operands; the B-row head products stay
             with ops.bf16_gemm():      # on the exact / split path by their shapes (ops.gemm's policy: skinny outputs)
-                return _NetVLADTrainFn._forward(ctx, vlad, B, N, feat, *params)
+                return _NetVLADTrainFn._forward(ctx, vlad, B, N, pending, feat, *params)
         with ops.train_forward_gemm(B):
-            return _NetVLADTrainFn._forward(ctx, vlad, B, N, feat, *params)
+            return _NetVLADTrainFn._forward(ctx, vlad, B, N, pending, feat, *params)
 
     @staticmethod
-    def _forward(ctx, vlad, B, N, feat, *params):
+    def _forward(ctx, vlad, B, N, pending, feat, *params):
         from . import engine
         E, K, O = vlad.feature_size, vlad.cluster_size, vlad.output_dim
         M = B * N
         dev = feat.device
         Bp = (B + 31) // 32 * 32                                    # rows padded so K = Bp weight-gradient GEMMs are legal
-        a0 = ops.gemm(feat, vlad.cluster_weights, b_kmajor=True)    # [M,K] raw
+        if pending is not None:      # `feat` is the trunk's RAW conv3 output: bn3 affine + activation in the assignment's operand loader
+            feat, a0 = ops.gemm_act(feat.detach(), vlad.cluster_weights, *pending)
+            if engine.DEBUG_AUX is not None:      # test hook: the trunk's ACTIVATED output rows (PointNetVlad.forward records the raw ones otherwise)
+                engine.DEBUG_AUX["feat"] = feat
+        else:
+            a0 = ops.gemm(feat, vlad.cluster_weights, b_kmajor=True)    # [M,K] raw
         if vlad.add_batch_norm:
             sta = ops.bn_train_stats(a0, vlad.bn1)
             a = ops.softmax_affine(a0, sta.scale, sta.shift)
@@ -1020,14 +1044,19 @@ class _NetVLADTrainFn(torch.autograd.Function):
         rhs[:, :, K:] = vlad.cluster_weights.detach()                              # parameter-sized broadcast (plumbing)
         dfeat = ops.gemm(ada.view(B, N, 2 * K), rhs, a_kmajor=False, b_kmajor=False).view(M, E)
         ctx.saved = None
-        return (None, None, None, dfeat, dwc, dcw2.view(1, E, K), dwh) + tuple(g_assign) + (dgam_h, dbet_h) + tuple(g_gate)
+        return (None, None, None, None, dfeat, dwc, dcw2.view(1, E, K), dwh) + tuple(g_assign) + (dgam_h, dbet_h) + tuple(g_gate)
 
 
-def netvlad_train(vlad, feat, B, N):
+def netvlad_train(vlad, feat, B, N, pending=None):
+    """pending: (scale, shift, act, slope) -- `feat` is then the trunk's RAW last-layer output and that BatchNorm affine + activation
+    is applied inside the assignment product (lpdnet_features_train(defer_act=True)); the gradient this Function returns for `feat`
+    is the gradient w.r.t. the ACTIVATED features either way, which is what the trunk's backward expects."""
     if N != vlad.max_samples:
         raise ValueError(f"NetVLADLoupe was built for max_samples={vlad.max_samples}, got N={N}")
+    if pending is not None and (vlad.cluster_size != 64 or not ops.gemm_act_applies(B * N, vlad.cluster_size, vlad.feature_size)):
+        raise ValueError("netvlad_train: a pending activation needs the fused assignment product (64 clusters)")
     params = _named(vlad, _NetVLADTrainFn.param_names(vlad))
-    return _NetVLADTrainFn.apply(vlad, B, N, feat, *params)
+    return _NetVLADTrainFn.apply(vlad, B, N, pending, feat, *params)
 
 
 # ------------------------------------------------------------------------------------------------

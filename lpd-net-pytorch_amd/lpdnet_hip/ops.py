@@ -1006,6 +1006,34 @@ def linear_bn_stats(x, w, bn, bias=None):
     return y, bn_train_stats(y, bn)
 
 
+ASSIGN_ACT = os.environ.get("LPD_ASSIGN_ACT", "1") != "0"     # train mode: bn3 affine + act inside the NetVLAD assignment product's loader
+
+
+def gemm_act_applies(M, N, K):
+    return (ASSIGN_ACT and GEMM_BF16X3 and _EXACT.depth == 0 and X3W_FORWARD and M >= 1024 and 64 <= N <= 128 and K >= 256
+            and N * K <= (1 << 22))
+
+
+def gemm_act(x, w_kn, a_scale, a_shift, act, slope):
+    """(x_act, c): x_act = act(a_scale * x + a_shift) (rows [M, K]: the BatchNorm affine + activation of the layer in front, applied in
+    the product's operand loader and stored on the way) and c = x_act @ w_kn for a k-major weight [K, N], N <= 128
+    (include/lpd_hip.h lpd_gemm_x3w_act: util/lpdnet_model.py:262 -> util/PointNetVlad.py:48)."""
+    ldx = _rows(x, "x")
+    _req(w_kn, "w_kn")
+    M, K = x.shape
+    N = w_kn.shape[1]
+    if w_kn.shape[0] != K or not gemm_act_applies(M, N, K):
+        raise ValueError(f"gemm_act: shape not built (M={M}, N={N}, K={K})")
+    a_scale, a_shift = _vec(a_scale, "a_scale", K), _vec(a_shift, "a_shift", K)
+    frags = _weight_frags(w_kn, True, N, K)
+    x_act = torch.empty((M, K), dtype=torch.float32, device=x.device)
+    c = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _call(f"gemmx3w+act[{M}x{N}x{K}]", lib.lpd_gemm_x3w_act, _ptr(x), ldx, _ptr(frags), _ptr(c), N, M, N, K, None, _ptr(a_scale), _ptr(a_shift),
+          act, float(slope), _ptr(x_act), K, 16 if _FAST.depth > 0 else 0, _stream())
+    return x_act, c
+
+
 def _bn_finalize(sums, R, C, bn):
     """fp64 column sums / sums of squares over R rows -> BNStats (+ running-stat update)."""
     out = torch.empty((4, C), dtype=torch.float32, device=sums.device)

@@ -1281,3 +1281,25 @@ def test_edge_mlp_train_bwd_equals_the_chain(cuda, bf16, N, k, B):
     assert _rel(buf[:, 4:4 + C], dp_a) < tol and _rel(buf[:, 4 + C:4 + 2 * C], dq_a) < tol
     assert (buf[:, :4] == 0).all() and (buf[:, 4 + 2 * C:] == 0).all()
     assert _rel(gsum, G.float().view(M, k, C).sum(1)) < (1e-2 if bf16 else 1e-5)
+
+
+def test_gemm_act_equals_affine_act_then_product(cuda):
+    """lpd_gemm_x3w_act (BatchNorm affine + activation of the layer in front applied in the operand loader, the activated rows stored on
+    the way) against affine_act followed by the prepared-fragment product: the activated map bit for bit, the product to split-bf16
+    accuracy -- at the training step's shape class (K = 1024 -> 64 clusters) and with a ragged row count."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    for M in (4096, 1300):
+        K, N = 1024, 64
+        x = torch.randn(M, K, generator=g).to(cuda)
+        w = torch.nn.Parameter((torch.randn(K, N, generator=g) / K ** 0.5).to(cuda))
+        sc, sh = (0.5 + torch.rand(K, generator=g)).to(cuda), (0.3 * torch.randn(K, generator=g)).to(cuda)
+        sc[::5] *= -1
+        assert ops.gemm_act_applies(M, N, K)
+        xa, c = ops.gemm_act(x, w.data, sc, sh, ops.ACT_LEAKY, 0.01)
+        ref_a = ops.affine_act(x, sc, sh, ops.ACT_LEAKY, 0.01)
+        ref_c = ops.gemm(ref_a, w.data, b_kmajor=True)
+        assert torch.equal(xa, ref_a)
+        assert _rel(c, ref_c) < 1e-6
+        c64 = ref_a.double() @ w.data.double()
+        assert _rel(c, c64) < 2e-5
