@@ -174,18 +174,6 @@ int lpd_gemm_x3t_rows_applies(int M, int N, int K, int act, long long lda, long 
 int lpd_gemm_x3t_rows(const float* A, long long lda, const void* frags, float* C, long long ldc, int M, int N, int K, const float* bias,
                       const float* scale, const float* shift, int act, float slope, int batch, long long sA, long long sC,
                       long long frag_bytes, void* stream);
-/* lpd_gemm_x3t_rows' bare product where C is the gradient w.r.t. the output of a train-mode BatchNorm + activation layer
- * z = act(scale y + shift) with raw input Y [M][ldy] (sY floats between the problems): C receives dpre = (A W^T) act'(scale y + shift),
- * and dbeta[n] = sum dpre, dgamma[n] = sum dpre xhat (fp64 over all rows of all problems) come out of the epilogue; lpd_bn_bwd_apply
- * finishes (dX = scale (dpre - dbeta / R - xhat dgamma / R)).  Replaces the reduction pass of lpd_bn_act_bwd over the [B N, 1024] conv3
- * map (util/PointNetVlad.py:45-68 backward into util/lpdnet_model.py:262).  N <= 1024. */
-int lpd_gemm_x3t_rows_bnbwd(const float* A, long long lda, const void* frags, float* C, long long ldc, int M, int N, int K, const float* Y,
-                            long long ldy, long long sY, const float* scale, const float* shift, const float* mean, const float* invstd,
-                            int act, float slope, int batch, long long sA, long long sC, long long frag_bytes, double* dbeta, double* dgamma,
-                            double* stat_ws, void* stream);
-int lpd_bn_bwd_apply(const float* dpre, long long ldd, const float* X, long long ldx, float* dX, long long lddx, long long R, int C,
-                     const float* scale, const float* shift, const float* mean, const float* invstd, const double* dbeta,
-                     const double* dgamma, void* stream);
 
 int lpd_gemm_x3t(const float* A, const void* frags, float* C, int M, int N, int K, const float* bias, const float* scale,
                  const float* shift, int act, float slope, long long a_cloud, long long c_cloud, int panel_n, int panel_ld,

@@ -61,14 +61,6 @@ struct X3tArgs {
     long long a_lo;                // != 0: A is the hi plane of a pair of split bf16 planes (a_cloud in elements), lo plane a_lo behind
     long long lda, ldc;            // ROWS form: A [M][lda], C [M][ldc] row-major fp32 (no panels)
     long long sA, sC, sF;          // ROWS form, batched over blockIdx.y: floats between the problems' A / C, bf16 elements between their fragments
-    // ROWS form, bare product only: BatchNorm + activation BACKWARD of the layer whose output gradient this product is (lpd_gemm_x3t_rows_bnbwd).
-    // C receives dpre = (A W^T) * act'(bw_scale y + bw_shift) and the replicas sum dpre / sum dpre xhat per column, xhat = (y - mean) invstd,
-    // y = bw_y [M][bw_ldy] (+ blockIdx.y * bw_sy): the reduction pass of lpd_bn_act_bwd happens where the gradient is produced.
-    const float* bw_y;
-    long long bw_ldy, bw_sy;
-    const float* bw_scale; const float* bw_shift; const float* bw_mean; const float* bw_invstd;
-    float bw_ns;
-    double* bw_sum; double* bw_sumx;
 };
 
 constexpr int XT_THREADS = 256;    // 128 rows per workgroup (a panel cloud is a multiple of 128 rows)
@@ -85,7 +77,7 @@ __device__ __forceinline__ void xt_split4(const float4& a, uint2& hi, uint2& lo)
     lo = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
 }
 
-template <int KS, bool ROWS, bool BW = false>
+template <int KS, bool ROWS>
 __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
 {
     constexpr int K = KS * 16, LDK = K + 8, IMG = 128 * LDK;
@@ -175,43 +167,6 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
         for (int p = 0; p < 4; ++p)
             *reinterpret_cast<float4*>(Crow + (long long)(i * 32 + p * 8) * g.ldc + nt * 32) = *reinterpret_cast<const float4*>(str + p * 8 * 36);
     };
-    // ... with the BatchNorm + activation backward reduction of the layer in front (ROWS, bare product): this lane's four columns of
-    // rows (lane >> 3) + 8 p of row tile i; sums over the tile's rows stay in registers until the wave has done its four row tiles
-    // (buffer resources over the block's 128 rows of C and of y, a constant 32-bit lane offset and scalar row / tile offsets: with flat
-    //  pointers the 2 x 16 addresses of a tile's rows cost 64 registers on top of the accumulators and the prefetched fragments)
-    typedef unsigned bw_u32x4 __attribute__((ext_vector_type(4)));
-    __amdgpu_buffer_rsrc_t cres, yres;
-    unsigned c_lane = 0, y_lane = 0;
-    if constexpr (ROWS && BW) {
-        cres = __builtin_amdgcn_make_buffer_rsrc(g.C + (long long)blockIdx.y * g.sC + (long long)mc0 * g.ldc, 0, (unsigned)(128 * g.ldc * 4), 0x00020000);
-        yres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.bw_y) + (long long)blockIdx.y * g.bw_sy + (long long)mc0 * g.bw_ldy, 0,
-                                                 (unsigned)(128 * g.bw_ldy * 4), 0x00020000);
-        c_lane = (unsigned)(((lane >> 3) * g.ldc + (lane & 7) * 4) * 4);
-        y_lane = (unsigned)(((lane >> 3) * g.bw_ldy + (lane & 7) * 4) * 4);
-    }
-    float bsum[4], bsumx[4];
-    float4 bsc, bsh, bmu, bis;
-    auto rows_out_bw = [&](int nt, int i) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const unsigned ro = (unsigned)(i * 32 + p * 8);
-            const float4 v = *reinterpret_cast<const float4*>(str + p * 8 * 36);
-            const bw_u32x4 yr = __builtin_amdgcn_raw_buffer_load_b128(yres, y_lane, (ro * (unsigned)g.bw_ldy + nt * 32) * 4, 0);
-            const float vv[4] = {v.x, v.y, v.z, v.w};
-            const float yy[4] = {__uint_as_float(yr[0]), __uint_as_float(yr[1]), __uint_as_float(yr[2]), __uint_as_float(yr[3])};
-            const float sc[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, sh[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
-            const float mu[4] = {bmu.x, bmu.y, bmu.z, bmu.w}, is[4] = {bis.x, bis.y, bis.z, bis.w};
-            float o[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                o[c] = vv[c] * (sc[c] * yy[c] + sh[c] > 0.0f ? 1.0f : g.bw_ns);
-                bsum[c] += o[c];
-                bsumx[c] = fmaf(o[c], (yy[c] - mu[c]) * is[c], bsumx[c]);
-            }
-            __builtin_amdgcn_raw_buffer_store_b128((bw_u32x4){__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])},
-                                                   cres, c_lane, (ro * (unsigned)g.ldc + nt * 32) * 4, 0);
-        }
-    };
     for (int nt = wave; nt < NT; nt += 4) {
         // (the operand fetches do not depend on the tile: left visible, the compiler hoists all of them out of this loop -- 256
         //  registers of data fragments, spilled)
@@ -243,36 +198,6 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
         // ---- epilogue: registers 4 q .. 4 q + 3 of row tile i are columns 32 nt + 8 q + 4 h + {0..3} of row 32 i + col ----
         if (plain) {                              // uniform: the bare product (the edge projections)
             if constexpr (ROWS) {
-                if constexpr (BW) {               // + the BatchNorm / activation backward reduction (lpd_gemm_x3t_rows_bnbwd)
-                    const int n4 = nt * 32 + (lane & 7) * 4;
-                    bsc = *reinterpret_cast<const float4*>(g.bw_scale + n4); bsh = *reinterpret_cast<const float4*>(g.bw_shift + n4);
-                    bmu = *reinterpret_cast<const float4*>(g.bw_mean + n4); bis = *reinterpret_cast<const float4*>(g.bw_invstd + n4);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) bsum[c] = bsumx[c] = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            *reinterpret_cast<float4*>(stw + q * 8) = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
-                        rows_out_bw(nt, i);
-                        __builtin_amdgcn_sched_barrier(0);      // keep the next row tile's loads of y behind this one (register budget)
-                    }
-                    // the 8 lanes that hold the same four columns (lane bits 3..5), then one lane of them adds into this block's replica
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        bsum[c] += __shfl_xor(bsum[c], 8); bsum[c] += __shfl_xor(bsum[c], 16); bsum[c] += __shfl_xor(bsum[c], 32);
-                        bsumx[c] += __shfl_xor(bsumx[c], 8); bsumx[c] += __shfl_xor(bsumx[c], 16); bsumx[c] += __shfl_xor(bsumx[c], 32);
-                    }
-                    if ((lane >> 3) == 0) {
-                        const size_t rofs = (size_t)((blockIdx.x + blockIdx.y * gridDim.x) % LPD_STAT_REPLICAS) * 2 * LPD_STAT_CMAX;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            atomicAdd(g.bw_sum + rofs + n4 + c, (double)bsum[c]);
-                            atomicAdd(g.bw_sumx + rofs + n4 + c, (double)bsumx[c]);
-                        }
-                    }
-                    continue;
-                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -320,11 +245,11 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
     }
 }
 
-template <int KS, bool ROWS = false, bool BW = false>
+template <int KS, bool ROWS = false>
 void x3t_launch(const X3tArgs& g, hipStream_t stream, int batch = 1)
 {
     const size_t lds = (size_t)2 * 128 * (KS * 16 + 8) * sizeof(__bf16) + (ROWS ? 4 * 32 * 36 * sizeof(float) : 0);
-    auto kern = gemm_x3t_kernel<KS, ROWS, BW>;
+    auto kern = gemm_x3t_kernel<KS, ROWS>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(g.M / 128, batch), dim3(XT_THREADS), lds, stream, g);
 }
@@ -354,7 +279,7 @@ static int gemm_x3t_impl(const float* A, const void* frags, float* C, int M, int
     const int KS = K / 16, NT = N / 32;
     const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
     X3tArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, bias, scale, shift, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), a_cloud, c_cloud, panel_n, panel_ld, a_lo,
-              0, 0, 0, 0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 1.0f, nullptr, nullptr};
+              0, 0, 0, 0, 0};
     hipStream_t stream = (hipStream_t)stream_;
     if (KS == 8) x3t_launch<8>(g, stream);
     else x3t_launch<4>(g, stream);
@@ -405,42 +330,10 @@ extern "C" int lpd_gemm_x3t_rows(const float* A, long long lda, const void* frag
     const int KS = K / 16, NT = N / 32;
     const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
     X3tArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, bias, scale, shift, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), 0, 0, 0, 0, 0,
-              lda, ldc, sA, sC, frag_bytes / 2, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 1.0f, nullptr, nullptr};
+              lda, ldc, sA, sC, frag_bytes / 2};
     hipStream_t stream = (hipStream_t)stream_;
     if (KS == 8) x3t_launch<8, true>(g, stream, batch);
     else x3t_launch<4, true>(g, stream, batch);
     LPD_CHECK_LAUNCH("lpd_gemm_x3t_rows");
     return LPD_OK;
-}
-
-// The bare product C = A W^T of lpd_gemm_x3t_rows where C is the gradient w.r.t. the OUTPUT of a train-mode BatchNorm + activation layer
-// z = act(scale y + shift), y = Y [M][ldy] (+ sY per problem) its raw input: C receives dpre = (A W^T) act'(scale y + shift) instead, and
-// dbeta[n] = sum dpre, dgamma[n] = sum dpre xhat (xhat = (y - mean) invstd; fp64, over all rows of all problems) come out of the
-// epilogue -- the reduction pass of lpd_bn_act_bwd (a read of the gradient and of Y) is gone; lpd_bn_bwd_apply finishes.
-// (util/PointNetVlad.py:45-68 backward into util/lpdnet_model.py:262: the gradient of the [B N, 1024] conv3 map.)  N <= 1024.
-extern "C" int lpd_gemm_x3t_rows_bnbwd(const float* A, long long lda, const void* frags, float* C, long long ldc, int M, int N, int K,
-                                       const float* Y, long long ldy, long long sY, const float* scale, const float* shift, const float* mean,
-                                       const float* invstd, int act, float slope, int batch, long long sA, long long sC, long long frag_bytes,
-                                       double* dbeta, double* dgamma, double* stat_ws, void* stream_)
-{
-    LPD_CHECK_ARG(A && frags && C && Y && scale && shift && mean && invstd && dbeta && dgamma && batch >= 1 && batch <= 65535,
-                  "lpd_gemm_x3t_rows_bnbwd: bad arguments");
-    LPD_CHECK_ARG(lpd_gemm_x3t_rows_applies(M, N, K, 0, lda, ldc) && N <= LPD_STAT_CMAX && ldy % 4 == 0 && ldy >= N && sY % 4 == 0,
-                  "lpd_gemm_x3t_rows_bnbwd: K in {64, 128}, N %% 32 == 0, N <= 1024, M %% 128 == 0 (M=%d N=%d K=%d)", M, N, K);
-    LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_gemm_x3t_rows_bnbwd: activation %d unsupported", act);
-    LPD_CHECK_ARG((((uintptr_t)A | (uintptr_t)frags | (uintptr_t)C | (uintptr_t)Y | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean |
-                    (uintptr_t)invstd) & 15) == 0 && sA % 4 == 0 && sC % 4 == 0 && frag_bytes % 16 == 0,
-                  "lpd_gemm_x3t_rows_bnbwd: pointers / strides must be 16-byte aligned");
-    const LpdStatWs ws = lpd_stat_arg(stat_ws);
-    LPD_CHECK_ARG(ws.rep, "lpd_gemm_x3t_rows_bnbwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
-    const int KS = K / 16, NT = N / 32;
-    const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
-    X3tArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, nullptr, nullptr, nullptr, 1.0f, 0, 0, 0, 0, 0,
-              lda, ldc, sA, sC, frag_bytes / 2, Y, ldy, sY, scale, shift, mean, invstd, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope),
-              ws.sum(), ws.sumsq()};
-    hipStream_t stream = (hipStream_t)stream_;
-    if (KS == 8) x3t_launch<8, true, true>(g, stream, batch);
-    else x3t_launch<4, true, true>(g, stream, batch);
-    LPD_CHECK_LAUNCH("lpd_gemm_x3t_rows_bnbwd");
-    return lpd_stat_finish(ws, dbeta, dgamma, N, stream);
 }

@@ -1045,20 +1045,6 @@ extern "C" int lpd_bn_act_bwd(const float* dY, long long lddy, const float* X, l
     return LPD_OK;
 }
 
-// The second half of lpd_bn_act_bwd on its own: dX = scale (dpre - dbeta / R - xhat dgamma / R), for a gradient that already IS dpre with
-// its sums known (lpd_gemm_x3t_rows_bnbwd produced both in its epilogue).  dX may alias dpre.
-extern "C" int lpd_bn_bwd_apply(const float* dpre, long long ldd, const float* X, long long ldx, float* dX, long long lddx, long long R, int C,
-                                const float* scale, const float* shift, const float* mean, const float* invstd, const double* dbeta,
-                                const double* dgamma, void* stream)
-{
-    LPD_CHECK_ARG(dpre && X && dX && scale && shift && mean && invstd && dbeta && dgamma && R > 0, "lpd_bn_bwd_apply: bad arguments");
-    LPD_CHECK_ARG(C >= 4 && C % 4 == 0 && ldd % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0, "lpd_bn_bwd_apply: C=%d / leading dims unsupported", C);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(R * (C / 4), 256 * 4)), dim3(256), 0, ST(stream), dpre, ldd, X, ldx, dX, lddx, R, C,
-                       scale, shift, mean, invstd, dbeta, dgamma, (double)R, 0, 0.0f, 1);
-    LPD_CHECK_LAUNCH("lpd_bn_bwd_apply");
-    return LPD_OK;
-}
-
 extern "C" int lpd_edge_build(const float* P, long long ldp, const float* Q, long long ldq, const int32_t* idx, float* U,
                               long long M, int N, int C, int k, double* sum, double* sumsq, double* stat_ws, void* stream)
 {

@@ -39,9 +39,6 @@ SIGNATURES = {
     "lpd_gemm_x3t_rows_applies": [_c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll],
     "lpd_gemm_x3t_rows": [_c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_ll, _c_ll, _c_ll,
                           _c_p],
-    "lpd_gemm_x3t_rows_bnbwd": [_c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_ll, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f,
-                                _c_int, _c_ll, _c_ll, _c_ll, _c_p, _c_p, _c_p, _c_p],
-    "lpd_bn_bwd_apply": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_gemm_x3t": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_ll, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_x3w": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int,
                      _c_ll, _c_ll, _c_int, _c_int, _c_int, _c_p],

@@ -484,15 +484,10 @@ class _LPDNetTrainFn(torch.autograd.Function):
             # also writes the activated map; this Function hands the RAW conv3 output on, with the affine in _LAST.pending
             y3, st3 = ops.linear_bn_stats(cat, w2d(net.conv3_lpd), net.bn3_lpd)
             feat = y3
-            # `link`: shared with the head's Function.  Its backward produces the gradient of the activated map as a product and can run
-            # bn3's backward REDUCTION in that product's epilogue (ops.gemm_bnbwd): it then leaves the sums in link["red3"] and hands
-            # dpre instead of dfeat to this Function's backward
-            ctx.link = dict(y3=y3, st3=st3, act=act, slope=slope)
-            _LAST.pending = (st3.scale, st3.shift, act, slope, ctx.link)
+            _LAST.pending = (st3.scale, st3.shift, act, slope)
         else:
             y3, st3, feat = _PointLayer.fwd(cat, w2d(net.conv3_lpd), net.bn3_lpd, act, slope)
             _LAST.pending = None
-            ctx.link = None
         ctx.net, ctx.dims, ctx.actslope, ctx.bf16 = net, (B, N, M, k), (act, slope), bf16
         ctx.saved = dict(front=front, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1, post1=post1, pq1=pq1 if post1 else None, s1sum=s1sum,
                          u1=u1, stg1=stg1, arg1=arg1, y1e=y1e, z=z, zsel=zsel, stg2=stg2, arg2=arg2, wcat3=wcat3, pq3=pq3, s3=s3, usel3=usel3,
@@ -517,20 +512,9 @@ class _LPDNetTrainFn(torch.autograd.Function):
         act, slope = ctx.actslope
         w2d = engine._w2d
         dfeat = dfeat.contiguous()
-        link = getattr(ctx, "link", None)
-        red3 = link.pop("red3", None) if link else None
-        if red3 is not None:
-            # the head's backward already multiplied by act'(pre3) and reduced (sum dpre, sum dpre xhat) in its product's epilogue
-            dy3 = ops.bn_bwd_apply(dfeat, S["y3"], S["st3"], red3)
-            r3 = red3.float()
-            dg3, db3 = r3[1], r3[0]
-            dw3 = _dweight(dy3, S["cat"])
-            dcat = ops.gemm(dy3, w2d(net.conv3_lpd), b_kmajor=True)
-            del dy3
-        else:
-            # conv3 + bn3 (the incoming gradient buffer belongs to autograd: not modified in place)
-            dcat, dw3, dg3, db3 = _PointLayer.bwd(dfeat, S["cat"], w2d(net.conv3_lpd), S["y3"], S["st3"], act, slope,
-                                                  inplace=False)
+        # conv3 + bn3 (the incoming gradient buffer belongs to autograd: not modified in place)
+        dcat, dw3, dg3, db3 = _PointLayer.bwd(dfeat, S["cat"], w2d(net.conv3_lpd), S["y3"], S["st3"], act, slope,
+                                              inplace=False)
         # SN1: x3 = max_k act(BN(P[nbr] + Q)), split form (closed-form sums over the edges, one pass over the transposed graph)
         dpq3 = torch.empty((M, 512), dtype=torch.float32, device=dfeat.device)    # both halves are fully written below
         pq3 = S["pq3"]
@@ -959,10 +943,8 @@ class _NetVLADTrainFn(torch.autograd.Function):
         M = B * N
         dev = feat.device
         Bp = (B + 31) // 32 * 32                                    # rows padded so K = Bp weight-gradient GEMMs are legal
-        ctx.link = None
         if pending is not None:      # `feat` is the trunk's RAW conv3 output: bn3 affine + activation in the assignment's operand loader
-            ctx.link = pending[4] if len(pending) > 4 else None
-            feat, a0 = ops.gemm_act(feat.detach(), vlad.cluster_weights, *pending[:4])
+            feat, a0 = ops.gemm_act(feat.detach(), vlad.cluster_weights, *pending)
             if engine.DEBUG_AUX is not None:      # test hook: the trunk's ACTIVATED output rows (PointNetVlad.forward records the raw ones otherwise)
                 engine.DEBUG_AUX["feat"] = feat
         else:
@@ -1060,12 +1042,7 @@ class _NetVLADTrainFn(torch.autograd.Function):
         rhs = torch.empty((B, E, 2 * K), dtype=torch.float32, device=dev)
         ops.affine_act(dvraw.view(B * E, K), None, None, ops.ACT_NONE, out=rhs.view(B * E, 2 * K)[:, :K])
         rhs[:, :, K:] = vlad.cluster_weights.detach()                              # parameter-sized broadcast (plumbing)
-        link = getattr(ctx, "link", None)
-        if link is not None and ops.gemm_bnbwd_applies(B, N, E, 2 * K) and link["y3"].shape == (M, E):
-            # ... with the trunk's bn3 / activation backward reduction in the epilogue: what goes back is dpre, the sums go through `link`
-            dfeat, link["red3"] = ops.gemm_bnbwd(ada.view(B, N, 2 * K), rhs, link["y3"], link["st3"], link["act"], link["slope"])
-        else:
-            dfeat = ops.gemm(ada.view(B, N, 2 * K), rhs, a_kmajor=False, b_kmajor=False).view(M, E)
+        dfeat = ops.gemm(ada.view(B, N, 2 * K), rhs, a_kmajor=False, b_kmajor=False).view(M, E)
         ctx.saved = None
         return (None, None, None, None, dfeat, dwc, dcw2.view(1, E, K), dwh) + tuple(g_assign) + (dgam_h, dbet_h) + tuple(g_gate)
 

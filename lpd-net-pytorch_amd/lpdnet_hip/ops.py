@@ -150,9 +150,8 @@ def lpdnet_front(xyz, W1, s1, b1, W2, s2, b2, B, N, k, act=ACT_NONE, slope=0.01)
     f0 = torch.empty((M, 64), dtype=torch.float32, device=xyz.device)
     ws = torch.empty((knn_workspace_floats(B, 64, N),), dtype=torch.float32, device=xyz.device)
     lib = _lib.load()
-    s1, b1, s2, b2 = _vec(s1, "s1", 64), _vec(b1, "b1", 64), _vec(s2, "s2", 64), _vec(b2, "b2", 64)      # named: they outlive the launch call
-    _call("lpdnet_front", lib.lpd_lpdnet_front, _ptr(xyz), ldx, _ptr(W1), _ptr(s1), _ptr(b1), _ptr(W2),
-          _ptr(s2), _ptr(b2), act, float(slope), _ptr(f0), B, N, k, _ptr(ws), _stream())
+    _call("lpdnet_front", lib.lpd_lpdnet_front, _ptr(xyz), ldx, _ptr(W1), _ptr(_vec(s1, "s1", 64)), _ptr(_vec(b1, "b1", 64)), _ptr(W2),
+          _ptr(_vec(s2, "s2", 64)), _ptr(_vec(b2, "b2", 64)), act, float(slope), _ptr(f0), B, N, k, _ptr(ws), _stream())
     return f0, ws
 
 
@@ -1007,46 +1006,6 @@ def linear_bn_stats(x, w, bn, bias=None):
     return y, bn_train_stats(y, bn)
 
 
-def gemm_bnbwd_applies(nb, M, N, K):
-    lib = _lib.load()
-    return (ASSIGN_ACT and GEMM_BF16X3 and X3T_ROWS and _EXACT.depth == 0 and _FAST.depth == 0 and nb * M >= 16384 and nb <= 65535
-            and N <= 1024 and bool(lib.lpd_gemm_x3t_rows_applies(M, N, K, 0, K, N)))
-
-
-def gemm_bnbwd(A3, B3, Y, st, act, slope):
-    """Batched bare product G[b] = A3[b] @ B3[b].T (A3 [nb, M, K] row-major, B3 [nb, N, K]) where G is the gradient w.r.t. the OUTPUT of a
-    train-mode BatchNorm + activation layer with raw input Y [nb*M, N] and statistics `st`: -> (dpre [nb*M, N] = G * act'(pre), red fp64
-    [2, N] = (sum dpre, sum dpre xhat)) -- the reduction of bn_act_bwd inside the product's epilogue (lpd_gemm_x3t_rows_bnbwd)."""
-    _req(A3, "A3"), _req(B3, "B3"), _req(Y, "Y")
-    nb, M, K = A3.shape
-    N = B3.shape[1]
-    if B3.shape[0] != nb or B3.shape[2] != K or tuple(Y.shape) != (nb * M, N) or not (A3.is_contiguous() and B3.is_contiguous()) \
-            or Y.stride(1) != 1 or not gemm_bnbwd_applies(nb, M, N, K):
-        raise ValueError(f"gemm_bnbwd: shape not built (nb={nb}, M={M}, N={N}, K={K})")
-    lib = _lib.load()
-    fb = int(lib.lpd_gemm_prep_b_bytes(N, K))
-    frags = torch.empty((nb * fb,), dtype=torch.uint8, device=A3.device)
-    _call("gemm_prep_b", lib.lpd_gemm_prep_b_batch, _ptr(B3), K, 0, N, K, nb, B3.stride(0), _ptr(frags), _stream())
-    dpre = torch.empty((nb * M, N), dtype=torch.float32, device=A3.device)
-    red = torch.empty((2, N), dtype=torch.float64, device=A3.device)
-    _call(f"gemmx3t+bnbwd[{M}x{N}x{K}]x{nb}", lib.lpd_gemm_x3t_rows_bnbwd, _ptr(A3), K, _ptr(frags), _ptr(dpre), N, M, N, K, _ptr(Y), Y.stride(0),
-          M * Y.stride(0), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd), act, float(slope), nb, A3.stride(0), M * N, fb,
-          _ptr(red[0]), _ptr(red[1]), _stat_ws(), _stream())
-    return dpre, red
-
-
-def bn_bwd_apply(dpre, X, st, red, out=None):
-    """dX = scale (dpre - mean(dpre) - xhat mean(dpre xhat)) with the sums `red` already known (gemm_bnbwd); out may alias dpre."""
-    ldd, ldx = _rows(dpre, "dpre"), _rows(X, "X")
-    R, C = dpre.shape
-    if out is None:
-        out = torch.empty((R, C), dtype=torch.float32, device=dpre.device)
-    lib = _lib.load()
-    _call("bn_bwd_apply", lib.lpd_bn_bwd_apply, _ptr(dpre), ldd, _ptr(X), ldx, _ptr(out), _rows(out, "out"), R, C, _ptr(st.scale), _ptr(st.shift),
-          _ptr(st.mean), _ptr(st.invstd), _ptr(red[0]), _ptr(red[1]), _stream())
-    return out
-
-
 ASSIGN_ACT = os.environ.get("LPD_ASSIGN_ACT", "1") != "0"     # train mode: bn3 affine + act inside the NetVLAD assignment product's loader
 
 
@@ -1304,10 +1263,7 @@ def edge_split_fwd(P, Q, idx, N, bn):
     if (lib.lpd_edge_split_fwd16_applies(N, C, k) and P.data_ptr() % 16 == 0 and Q.data_ptr() % 16 == 0
             and bn.weight.data_ptr() % 16 == 0):
         # cloud-resident slices (the eval K-agg kernel's organisation): the k neighbour rows come from LDS, not through L2
-        # (a NAMED tensor: a temporary handed over as a raw pointer is freed before the launch, and the next allocation in this
-        #  argument list -- the zero-filled statistics workspace of a stream's first call -- was seen to land on it)
-        idx16 = pack_idx16(idx)
-        _call(f"edge_split_fwd[C={C}]", lib.lpd_edge_split_fwd16, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx16), _ptr(bn.weight),
+        _call(f"edge_split_fwd[C={C}]", lib.lpd_edge_split_fwd16, _ptr(P), ldp, _ptr(Q), ldq, _ptr(pack_idx16(idx)), _ptr(bn.weight),
               _ptr(S), _ptr(usel), _ptr(arg), M, N, C, k, _ptr(sums[0]), _ptr(sums[1]), _stat_ws(), _stream())
         return S, usel, arg, _bn_finalize(sums, M * k, C, bn)
     _call(f"edge_split_fwd[C={C}]", lib.lpd_edge_split_fwd, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(bn.weight), _ptr(S), _ptr(usel),

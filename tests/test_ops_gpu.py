@@ -1195,10 +1195,7 @@ def test_edge_mlp_train_equals_the_materialised_stage(cuda, bf16, N, k, B):
     assert ops.edge_mlp_train_applies(M, N, k, C, act, slope)
     Y_b, Z_b, zsel_b, arg2_b, st2_b = ops.edge_mlp_train(P, Q, idx, N, st1.scale, st1.shift, W2, bn2b, act, slope, bf16, z_bf16=bf16)
     if not bf16:      # the default of the fp32 storage mode: Z rounded to bf16, everything else as with fp32 Z
-        bn2c = _bn_for(C, 4).to(cuda).train()
-        with torch.no_grad():
-            bn2c.weight.copy_(bn2a.weight)
-        Y_c, Z_c, zsel_c, arg2_c, _ = ops.edge_mlp_train(P, Q, idx, N, st1.scale, st1.shift, W2, bn2c, act, slope, False)
+        Y_c, Z_c, zsel_c, arg2_c, _ = ops.edge_mlp_train(P, Q, idx, N, st1.scale, st1.shift, W2, _bn_for(C, 4).to(cuda).train(), act, slope, False)
         assert Z_c.dtype == torch.bfloat16 and torch.equal(Z_c, Z_b.to(torch.bfloat16)) and torch.equal(Y_c, Y_b)
         assert torch.equal(zsel_c, zsel_b) and torch.equal(arg2_c, arg2_b)
     assert torch.equal(arg1_a, arg1_b) and _rel(x1_b, x1_a) < 1e-5
@@ -1206,7 +1203,7 @@ def test_edge_mlp_train_equals_the_materialised_stage(cuda, bf16, N, k, B):
     if bf16:
         assert Y_b.dtype == torch.bfloat16 and Z_b.dtype == torch.bfloat16
         # the rounded fp32 value, up to one bf16 ulp where the fused kernel's fma and the chain's multiply + add round apart
-        assert ((Y_b.float() - Y_a.to(torch.bfloat16).float()).abs() <= 2.0 ** -7 * Y_a.abs() + 1e-6).all()      # (+ values around 0)
+        assert ((Y_b.float() - Y_a.to(torch.bfloat16).float()).abs() <= 2.0 ** -7 * Y_a.abs() + 1e-30).all()
         assert (Y_b.float() != Y_a.to(torch.bfloat16).float()).float().mean().item() < 0.01
         assert _rel(Z_b.float(), Z_a) < 2 ** -8
         tol = 3e-3          # statistics / selection of the fp32 accumulators against those of an independently rounded product
@@ -1306,31 +1303,3 @@ def test_gemm_act_equals_affine_act_then_product(cuda):
         assert _rel(c, ref_c) < 1e-6
         c64 = ref_a.double() @ w.data.double()
         assert _rel(c, c64) < 2e-5
-
-
-def test_gemm_bnbwd_equals_product_then_bn_act_bwd(cuda):
-    """lpd_gemm_x3t_rows_bnbwd + lpd_bn_bwd_apply (the BatchNorm / activation backward reduction of the layer in front inside the
-    epilogue of the batched product that produces its output gradient) against the product followed by lpd_bn_act_bwd."""
-    ops = _ops()
-    g = torch.Generator().manual_seed(11)
-    nb, M, N, K = 5, 4096, 1024, 128
-    A = torch.randn(nb, M, K, generator=g).to(cuda)
-    Bm = (torch.randn(nb, N, K, generator=g) / K ** 0.5).to(cuda)
-    Y = torch.randn(nb * M, N, generator=g).to(cuda)
-    bn = torch.nn.BatchNorm1d(N).to(cuda).train()
-    with torch.no_grad():
-        bn.weight.copy_((torch.rand(N, generator=g) - 0.3).to(cuda))
-        bn.bias.copy_((0.2 * torch.randn(N, generator=g)).to(cuda))
-    st = ops.bn_train_stats(Y, bn)
-    act, slope = ops.ACT_LEAKY, 0.01
-    assert ops.gemm_bnbwd_applies(nb, M, N, K)
-    dpre, red = ops.gemm_bnbwd(A, Bm, Y, st, act, slope)
-    dx_b = ops.bn_bwd_apply(dpre, Y, st, red)
-    G = ops.gemm(A, Bm, a_kmajor=False, b_kmajor=False).view(nb * M, N)
-    dx_a, dg_a, db_a = ops.bn_act_bwd(G.clone(), Y, st, act, slope)
-    r = red.float()
-    assert _rel(r[0], db_a) < 1e-5 and _rel(r[1], dg_a) < 1e-5
-    assert _rel(dx_b, dx_a) < 1e-5
-    # dpre itself: the product times act'
-    pre = Y * st.scale + st.shift
-    assert _rel(dpre, G * torch.where(pre > 0, 1.0, slope)) < 1e-6
