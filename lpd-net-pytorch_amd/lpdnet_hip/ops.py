@@ -150,8 +150,9 @@ def lpdnet_front(xyz, W1, s1, b1, W2, s2, b2, B, N, k, act=ACT_NONE, slope=0.01)
     f0 = torch.empty((M, 64), dtype=torch.float32, device=xyz.device)
     ws = torch.empty((knn_workspace_floats(B, 64, N),), dtype=torch.float32, device=xyz.device)
     lib = _lib.load()
-    _call("lpdnet_front", lib.lpd_lpdnet_front, _ptr(xyz), ldx, _ptr(W1), _ptr(_vec(s1, "s1", 64)), _ptr(_vec(b1, "b1", 64)), _ptr(W2),
-          _ptr(_vec(s2, "s2", 64)), _ptr(_vec(b2, "b2", 64)), act, float(slope), _ptr(f0), B, N, k, _ptr(ws), _stream())
+    s1, b1, s2, b2 = _vec(s1, "s1", 64), _vec(b1, "b1", 64), _vec(s2, "s2", 64), _vec(b2, "b2", 64)      # named: they outlive the launch call
+    _call("lpdnet_front", lib.lpd_lpdnet_front, _ptr(xyz), ldx, _ptr(W1), _ptr(s1), _ptr(b1), _ptr(W2),
+          _ptr(s2), _ptr(b2), act, float(slope), _ptr(f0), B, N, k, _ptr(ws), _stream())
     return f0, ws
 
 
@@ -1263,7 +1264,10 @@ def edge_split_fwd(P, Q, idx, N, bn):
     if (lib.lpd_edge_split_fwd16_applies(N, C, k) and P.data_ptr() % 16 == 0 and Q.data_ptr() % 16 == 0
             and bn.weight.data_ptr() % 16 == 0):
         # cloud-resident slices (the eval K-agg kernel's organisation): the k neighbour rows come from LDS, not through L2
-        _call(f"edge_split_fwd[C={C}]", lib.lpd_edge_split_fwd16, _ptr(P), ldp, _ptr(Q), ldq, _ptr(pack_idx16(idx)), _ptr(bn.weight),
+        # (a NAMED tensor: a temporary handed over as a raw pointer is freed before the launch, and the next allocation in this
+        #  argument list -- the zero-filled statistics workspace of a stream's first call -- was seen to land on it)
+        idx16 = pack_idx16(idx)
+        _call(f"edge_split_fwd[C={C}]", lib.lpd_edge_split_fwd16, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx16), _ptr(bn.weight),
               _ptr(S), _ptr(usel), _ptr(arg), M, N, C, k, _ptr(sums[0]), _ptr(sums[1]), _stat_ws(), _stream())
         return S, usel, arg, _bn_finalize(sums, M * k, C, bn)
     _call(f"edge_split_fwd[C={C}]", lib.lpd_edge_split_fwd, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(bn.weight), _ptr(S), _ptr(usel),

@@ -1195,7 +1195,10 @@ def test_edge_mlp_train_equals_the_materialised_stage(cuda, bf16, N, k, B):
     assert ops.edge_mlp_train_applies(M, N, k, C, act, slope)
     Y_b, Z_b, zsel_b, arg2_b, st2_b = ops.edge_mlp_train(P, Q, idx, N, st1.scale, st1.shift, W2, bn2b, act, slope, bf16, z_bf16=bf16)
     if not bf16:      # the default of the fp32 storage mode: Z rounded to bf16, everything else as with fp32 Z
-        Y_c, Z_c, zsel_c, arg2_c, _ = ops.edge_mlp_train(P, Q, idx, N, st1.scale, st1.shift, W2, _bn_for(C, 4).to(cuda).train(), act, slope, False)
+        bn2c = _bn_for(C, 4).to(cuda).train()
+        with torch.no_grad():
+            bn2c.weight.copy_(bn2a.weight)
+        Y_c, Z_c, zsel_c, arg2_c, _ = ops.edge_mlp_train(P, Q, idx, N, st1.scale, st1.shift, W2, bn2c, act, slope, False)
         assert Z_c.dtype == torch.bfloat16 and torch.equal(Z_c, Z_b.to(torch.bfloat16)) and torch.equal(Y_c, Y_b)
         assert torch.equal(zsel_c, zsel_b) and torch.equal(arg2_c, arg2_b)
     assert torch.equal(arg1_a, arg1_b) and _rel(x1_b, x1_a) < 1e-5
@@ -1203,7 +1206,7 @@ def test_edge_mlp_train_equals_the_materialised_stage(cuda, bf16, N, k, B):
     if bf16:
         assert Y_b.dtype == torch.bfloat16 and Z_b.dtype == torch.bfloat16
         # the rounded fp32 value, up to one bf16 ulp where the fused kernel's fma and the chain's multiply + add round apart
-        assert ((Y_b.float() - Y_a.to(torch.bfloat16).float()).abs() <= 2.0 ** -7 * Y_a.abs() + 1e-30).all()
+        assert ((Y_b.float() - Y_a.to(torch.bfloat16).float()).abs() <= 2.0 ** -7 * Y_a.abs() + 1e-6).all()      # (+ values around 0)
         assert (Y_b.float() != Y_a.to(torch.bfloat16).float()).float().mean().item() < 0.01
         assert _rel(Z_b.float(), Z_a) < 2 ** -8
         tol = 3e-3          # statistics / selection of the fp32 accumulators against those of an independently rounded product
