@@ -687,7 +687,8 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
             if constexpr (!(PANELS & 1)) {
                 if (g.a_scale) {      // uniform: the transformed operand, stored on the way
                     const float4 sc = rsc[set], sh = rsh[set];
-                    v.x = fmaf(sc.x, v.x, sh.x); v.y = fmaf(sc.y, v.y, sh.y); v.z = fmaf(sc.z, v.z, sh.z); v.w = fmaf(sc.w, v.w, sh.w);
+                    // (multiply, then add -- not fused: the same bits as lpd_affine_act)
+                    v.x = sc.x * v.x + sh.x; v.y = sc.y * v.y + sh.y; v.z = sc.z * v.z + sh.z; v.w = sc.w * v.w + sh.w;
                     v.x = fmaxf(v.x, 0.0f) + g.a_ns * fminf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f) + g.a_ns * fminf(v.y, 0.0f);
                     v.z = fmaxf(v.z, 0.0f) + g.a_ns * fminf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f) + g.a_ns * fminf(v.w, 0.0f);
                     const int m = m0 + rr, kk = rk0[set] + k4 * 4;

@@ -230,6 +230,8 @@ class PointNetVlad(nn.Module):
             # [B N, 1024] map less); `feat` is the raw conv3 output when `pending` is set
             from lpdnet_hip import autograd
             feat, B, N, pending = autograd.lpdnet_features_train(trunk, x, defer_act=True)
+            if pending is None and engine.DEBUG_AUX is not None:      # test hook (with a pending activation the head records the activated rows)
+                engine.DEBUG_AUX["feat"] = feat
             return autograd.netvlad_train(self.net_vlad, feat, B, N, pending=pending)
         feat, B, N = trunk._features(x)          # point-major: no [B,E,N,1] round trip between trunk and head
         if engine.DEBUG_AUX is not None:         # test hook: the trunk's output rows [B*N, E] (stage-probe fixtures)
