@@ -221,9 +221,10 @@ int lpd_pack_idx16(const int32_t* idx, uint16_t* idx16, long long M, int k, void
  * lpd_edge_gather_max; operands as lpd_edge_gather_max16 (row-major or cloud-panel).  idx16: the RAW uint16 copy of the
  * indices made by lpd_pack_idx16w (blocked by 32 points, quad i of point m at ((m/32)*(k/4) + i)*32 + m%32, uint2 units;
  * ceil(M/32)*32*k uint16).  k in {20, 32, 64}; N <= 57344; the clouds should be Z-ordered (lpd_morton_sort) for the window to
- * catch most neighbours -- correctness does not depend on it.
+ * catch most neighbours -- correctness does not depend on it.  lpd_pack_idx16w with N > 0 (points per cloud) also PARTITIONS every
+ * list, out-of-window neighbours first (the miss phase then stops at the longest miss list of a wave); N = 0 keeps the kNN order.
  */
-int lpd_pack_idx16w(const int32_t* idx, uint16_t* idx16, long long M, int k, void* stream);
+int lpd_pack_idx16w(const int32_t* idx, uint16_t* idx16, long long M, int k, int N, void* stream);
 int lpd_edge_gather_maxw(const float* P, int ldp, const float* Q, int ldq, const uint16_t* idx16, float* out, int ldo,
                          const float* scale, const float* shift, int M, int N, int C, int k, int act, float slope, long long p_cloud,
                          long long q_cloud, long long o_cloud, int panel_ld, void* stream);

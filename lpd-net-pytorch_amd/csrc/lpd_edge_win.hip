@@ -50,6 +50,32 @@ __global__ void pack_idx16w_kernel(const int32_t* __restrict__ in, uint2* __rest
     out[((m >> 5) * KQ + i) * 32 + (m & 31)] = make_uint2((uint32_t)(v.x & 0xffff) | ((uint32_t)v.y << 16), (uint32_t)(v.z & 0xffff) | ((uint32_t)v.w << 16));
 }
 
+// The same packing with every point's list PARTITIONED: the neighbours outside the point's window first, the others behind them, each
+// part in its kNN order (the maximum over a list does not depend on its order).  The window kernel's miss phase walks the index quads
+// and skips a quad in which no lane of the wave has a miss; with the misses scattered over the 64 slots every quad of a border wave
+// holds some (7.8 % of the gathers at N = 16384, k = 64), i.e. 16 dependent memory round trips; partitioned, the wave stops after
+// ceil(max misses of a point / 4) quads.  One wavefront per point: lane e holds list entry e, a ballot and two popcounts place it.
+// (A permutation against the LDS bank conflicts of the hit phase -- slot s of point p asking for row residue (pos(p) + s) mod 8, so
+// that the 8 points of a ds_read_b128 lane group hit 8 different bank groups -- was built and measured first: all-hit synthetic graph
+// 395 -> 335 us, the real kNN graph 731 -> 718 us at B = 16: the hit phase is not where the real graph loses its time.)
+__global__ __launch_bounds__(256) void pack_idx16w_part_kernel(const int32_t* __restrict__ in, unsigned short* __restrict__ out, long long M, int N,
+                                                               int k)
+{
+    const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int e = threadIdx.x & 63;
+    if (m >= M) return;
+    const int n = (int)(m % N);
+    const int w0 = (n / KW_ROWS) * KW_ROWS;
+    const bool live = e < k;
+    const int j = live ? in[m * k + e] : 0;
+    const bool miss = live && (((unsigned)(j - w0) & 0xffffu) >= (unsigned)KW_ROWS);
+    const unsigned long long mm = __ballot(miss), hm = __ballot(live && !miss);
+    const unsigned long long below = (1ull << e) - 1ull;
+    const int at = miss ? __popcll(mm & below) : __popcll(mm) + __popcll(hm & below);
+    // element (quad i = at / 4, entry at % 4) of point m: uint16 index ((m / 32) * KQ + i) * 32 * 4 + (m % 32) * 4 + at % 4
+    if (live) out[(((m >> 5) * (k >> 2) + (at >> 2)) * 32 + (m & 31)) * 4 + (at & 3)] = (unsigned short)j;
+}
+
 template <int KQ, bool HAS_Q>
 __global__ __launch_bounds__(1024) void edge_gather_max_window_kernel(WinArgs g, const uint2* __restrict__ idx2)
 {
@@ -137,22 +163,30 @@ __global__ __launch_bounds__(1024) void edge_gather_max_window_kernel(WinArgs g,
             // compacted into LDS and walked four or eight at a time: 1.4 ms (points near a window corner miss more than the
             // list holds and fall back, the list walk is as serial as the quads). ----
             const float4 negs = make_float4(-INFINITY * sg.x, -INFINITY * sg.y, -INFINITY * sg.z, -INFINITY * sg.w);
+            // (lpd_pack_idx16w with N > 0 puts a point's misses at the front of its list: the walk then ends at the wave's longest miss
+            //  list; two quads = eight row pieces in flight per step)
+            constexpr int QS = (KQ % 4 == 0) ? 4 : ((KQ % 2 == 0) ? 2 : 1);
 #pragma unroll
-            for (int i = 0; i < KQ; ++i) {
-                const unsigned jj[4] = {ix[i].x & 0xffffu, ix[i].x >> 16, ix[i].y & 0xffffu, ix[i].y >> 16};
-                bool ms[4];
+            for (int i = 0; i < KQ; i += QS) {
+                unsigned jj[4 * QS];
+                bool ms[4 * QS];
                 bool anym = false;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { ms[e] = ((jj[e] - (unsigned)w0) & 0xffffu) >= (unsigned)KW_ROWS; anym |= ms[e]; }
-                if (!__any(anym)) continue;
-                float4 p[4];
+                for (int u = 0; u < QS; ++u) {
+                    jj[4 * u] = ix[i + u].x & 0xffffu; jj[4 * u + 1] = ix[i + u].x >> 16;
+                    jj[4 * u + 2] = ix[i + u].y & 0xffffu; jj[4 * u + 3] = ix[i + u].y >> 16;
+                }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4 * QS; ++e) { ms[e] = ((jj[e] - (unsigned)w0) & 0xffffu) >= (unsigned)KW_ROWS; anym |= ms[e]; }
+                if (!__any(anym)) continue;
+                float4 p[4 * QS];
+#pragma unroll
+                for (int e = 0; e < 4 * QS; ++e) {
                     p[e] = negs;
                     if (ms[e]) p[e] = *reinterpret_cast<const float4*>(Pc + (size_t)jj[e] * ldp);
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4 * QS; ++e) {
                     v.x = fmaxf(v.x, sg.x * p[e].x); v.y = fmaxf(v.y, sg.y * p[e].y);
                     v.z = fmaxf(v.z, sg.z * p[e].z); v.w = fmaxf(v.w, sg.w * p[e].w);
                 }
@@ -187,12 +221,18 @@ void launch_window(const WinArgs& g, const uint2* idx2, int items, hipStream_t s
 
 }  // namespace
 
-extern "C" int lpd_pack_idx16w(const int32_t* idx, uint16_t* idx16, long long M, int k, void* stream_)
+extern "C" int lpd_pack_idx16w(const int32_t* idx, uint16_t* idx16, long long M, int k, int N, void* stream_)
 {
     LPD_CHECK_ARG(idx && idx16 && M > 0, "lpd_pack_idx16w: bad arguments");
     LPD_CHECK_ARG(k > 0 && k % 4 == 0 && k <= 64, "lpd_pack_idx16w: k = %d must be a multiple of 4, <= 64", k);
     LPD_CHECK_ARG((((uintptr_t)idx | (uintptr_t)idx16) & 15) == 0, "lpd_pack_idx16w: pointers must be 16-byte aligned");
+    LPD_CHECK_ARG(N == 0 || (N > 0 && M % N == 0 && N <= 57344), "lpd_pack_idx16w: N = %d (points per cloud; 0 = keep the list order)", N);
     const int KQ = k / 4;
+    if (N > 0) {      // out-of-window neighbours first (same sets: the result does not change; see pack_idx16w_part_kernel)
+        hipLaunchKernelGGL(pack_idx16w_part_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, idx, idx16, M, N, k);
+        LPD_CHECK_LAUNCH("lpd_pack_idx16w");
+        return LPD_OK;
+    }
     const long long threads = M * KQ;
     hipLaunchKernelGGL(pack_idx16w_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, idx,
                        reinterpret_cast<uint2*>(idx16), M, KQ);

@@ -69,7 +69,7 @@ SIGNATURES = {
                              _c_int, _c_int, _c_int, _c_int, _c_f, _c_ll, _c_int, _c_p],
     "lpd_gemm_x3ts": [_c_p, _c_ll, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_ll, _c_ll, _c_int, _c_int, _c_p],
     "lpd_pack_idx16": [_c_p, _c_p, ctypes.c_longlong, _c_int, _c_p],
-    "lpd_pack_idx16w": [_c_p, _c_p, ctypes.c_longlong, _c_int, _c_p],
+    "lpd_pack_idx16w": [_c_p, _c_p, ctypes.c_longlong, _c_int, _c_int, _c_p],
     "lpd_edge_gather_maxw": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int,
                              _c_int, _c_int, _c_f, _c_ll, _c_ll, _c_ll, _c_int, _c_p],
     "lpd_edge_mlp": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int,

@@ -733,15 +733,23 @@ def edge_gather_max16(P, Q, idx16, N, *, scale=None, shift=None, act=ACT_NONE, s
     return out
 
 
-def pack_idx16w(idx):
-    """int32 kNN indices [..., k] (k in {20, 32, 64}) -> the blocked RAW uint16 copy the windowed K-agg reads."""
+KAGGW_PERMUTE = os.environ.get("LPD_KAGGW_PERMUTE", "1") != "0"   # windowed K-agg: every list with its out-of-window neighbours first
+
+
+def pack_idx16w(idx, N=None):
+    """int32 kNN indices [..., k] (k in {20, 32, 64}) -> the blocked RAW uint16 copy the windowed K-agg reads.  N (points per cloud;
+    taken from a [B, N, k] tensor): every point's list is partitioned, the neighbours outside the point's 4095-row window first -- the
+    miss phase of edge_gather_maxw then ends after the longest miss list of a wave instead of walking all k / 4 index quads (same
+    sets, same result; include/lpd_hip.h lpd_pack_idx16w)."""
     _req(idx, "idx", torch.int32)
     k = idx.shape[-1]
+    if N is None and idx.dim() == 3:
+        N = idx.shape[1]
     idx = idx.reshape(-1, k).contiguous()
     M = idx.shape[0]
     out = torch.empty(((M + 31) // 32 * 32, k), dtype=torch.int16, device=idx.device)
     lib = _lib.load()
-    _call("pack_idx16w", lib.lpd_pack_idx16w, _ptr(idx), _ptr(out), M, k, _stream())
+    _call("pack_idx16w", lib.lpd_pack_idx16w, _ptr(idx), _ptr(out), M, k, int(N) if (N and KAGGW_PERMUTE) else 0, _stream())
     return out
 
 

@@ -882,13 +882,26 @@ def test_windowed_kagg_is_bit_identical(cuda, C, N, k, B, graph):
     idx = idx.to(cuda)
     PQ = torch.randn(M, 2 * C, generator=g).to(cuda)
     scale, shift = (torch.rand(C, generator=g) - 0.3).to(cuda), torch.randn(C, generator=g).to(cuda)
-    i16 = ops.pack_idx16w(idx)
+    i16_plain = ops.pack_idx16w(idx)
+    i16 = ops.pack_idx16w(idx, N)          # out-of-window neighbours first (the product setting: N known)
+
+    def unpack(t):                         # blocked [M32 / 32][k / 4][32 points][4] -> [M, k]
+        M32 = t.shape[0]
+        return t.view(M32 // 32, k // 4, 32, 4).permute(0, 2, 1, 3).reshape(M32, k)[:M].to(torch.int32) & 0xffff
+    assert torch.equal(unpack(i16_plain), idx)
+    # partitioned: the neighbours outside the point's window first, each part in its kNN order
+    rows, ic = unpack(i16).cpu(), idx.cpu()
+    w0 = (((torch.arange(M) % N) // 4095) * 4095).view(-1, 1)
+    mo = ((ic - w0) < 0) | ((ic - w0) >= 4095)
+    order = torch.argsort((~mo).to(torch.int8), dim=1, stable=True)
+    assert torch.equal(rows, torch.gather(ic, 1, order))
     for q in (PQ[:, C:], None):
         want = ops.edge_gather_max(PQ[:, :C], q, idx, N, scale=scale, shift=shift, act=ops.ACT_LEAKY, slope=0.01)
-        buf = torch.full((M, C + 8), -7.0, device=cuda)
-        ops.edge_gather_maxw(PQ[:, :C], q, i16, N, scale=scale, shift=shift, act=ops.ACT_LEAKY, slope=0.01, out=buf[:, 4:4 + C])
-        assert torch.equal(buf[:, 4:4 + C], want)
-        assert (buf[:, :4] == -7.0).all() and (buf[:, 4 + C:] == -7.0).all()
+        for packed in (i16, i16_plain):
+            buf = torch.full((M, C + 8), -7.0, device=cuda)
+            ops.edge_gather_maxw(PQ[:, :C], q, packed, N, scale=scale, shift=shift, act=ops.ACT_LEAKY, slope=0.01, out=buf[:, 4:4 + C])
+            assert torch.equal(buf[:, 4:4 + C], want)
+            assert (buf[:, :4] == -7.0).all() and (buf[:, 4 + C:] == -7.0).all()
     if N % 128 == 0:      # cloud-panel operands
         pq = ops.panels_empty(B, N, 2 * C, cuda)
         pq[:, :C // 8] = ops.rows_to_panels(PQ[:, :C].contiguous(), B)

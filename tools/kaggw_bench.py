@@ -24,9 +24,11 @@ pq[:, :C // 8] = ops.rows_to_panels(PQ[:, :C].contiguous(), B)
 pq[:, C // 8:] = ops.rows_to_panels(PQ[:, C:].contiguous(), B)
 outp = ops.panels_empty(B, N, C, dev)
 out = torch.empty(M, C, device=dev)
-i16 = ops.pack_idx16w(idx)
+i16 = ops.pack_idx16w(idx)                       # [B, N, k]: out-of-window neighbours first (the product setting)
+i16_plain = ops.pack_idx16w(idx.view(-1, k))     # kNN order
 near = (torch.arange(N, device=dev).view(1, N, 1) // 4095 * 4095 + torch.randint(0, 4000, (B, N, k), device=dev)).clamp_(max=N - 1).to(torch.int32)
 i16n = ops.pack_idx16w(near)
+i16n_plain = ops.pack_idx16w(near.view(-1, k))
 alg = (3 * C * 4 + 4 * k) * M
 
 
@@ -44,6 +46,10 @@ kw = dict(scale=scale, shift=shift, act=ops.ACT_LEAKY, slope=0.01)
 for name, fn in [("direct, row-major", lambda: ops.edge_gather_max(PQ[:, :C], PQ[:, C:], idx, N, out=out, **kw)),
                  ("window, row-major", lambda: ops.edge_gather_maxw(PQ[:, :C], PQ[:, C:], i16, N, out=out, **kw)),
                  ("window, panels", lambda: ops.edge_gather_maxw(pq[:, :C // 8], pq[:, C // 8:], i16, N, out=outp, **kw)),
+                 ("window, panels, kNN-order lists", lambda: ops.edge_gather_maxw(pq[:, :C // 8], pq[:, C // 8:], i16_plain, N, out=outp, **kw)),
+                 ("window, panels, all-hit, kNN order", lambda: ops.edge_gather_maxw(pq[:, :C // 8], pq[:, C // 8:], i16n_plain, N, out=outp, **kw)),
+                 ("pack_idx16w (permuting)", lambda: ops.pack_idx16w(idx)),
+                 ("pack_idx16w (plain)", lambda: ops.pack_idx16w(idx.view(-1, k))),
                  ("window, panels, all-hit graph", lambda: ops.edge_gather_maxw(pq[:, :C // 8], pq[:, C // 8:], i16n, N, out=outp, **kw)),
                  ("window, row-major, all-hit graph", lambda: ops.edge_gather_maxw(PQ[:, :C], PQ[:, C:], i16n, N, out=out, **kw))]:
     us = timeit(fn)
