@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--k", type=int, default=20, help="neighbours per point (reference hard-codes 20; configs[4] uses 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary quadruplet train-step measurement")
-    ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--train-steps", type=int, default=10)
     ap.add_argument("--no-train-bf16", action="store_true", help="skip the bf16-storage train-step measurement (configs[2] as stated)")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
                     help="nccl = RCCL, one GPU per rank (the measurement).  gloo = DRY RUN of the multi-rank path on however many GPUs are "
