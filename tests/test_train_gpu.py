@@ -643,7 +643,10 @@ def test_standalone_train_mode_forwards_of_the_submodules(cuda):
 
 
 @pytest.mark.parametrize("env", [{"LPD_DG2_BWD_FUSED": "0", "LPD_TN256": "0", "LPD_GEMM_STATS": "0", "LPD_SPLIT_LDS": "0", "LPD_X3T_ROWS": "0"},
-                                 {"LPD_GEMM_TN": "0"}],
+                                 {"LPD_GEMM_TN": "0"},
+                                 {"LPD_EDGE_MLP_TRAIN": "0"},                                  # round 4: the DG1 -> DG2 stage on the round-3 chain
+                                 {"LPD_EDGE_MLP_TRAIN_BWD": "0", "LPD_ASSIGN_ACT": "0"},       # ... its backward on the round-3 chain, bn3 as its own pass
+                                 {"LPD_Z_BF16": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_training_switches_are_live(env):
     """The training-path switches README.md documents are read at import (or at the first launch): the bf16-storage oracle
@@ -653,6 +656,6 @@ def test_training_switches_are_live(env):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_train_gpu.py"), "-k",
-           "test_train_bf16_storage_vs_oracle or (test_train_step0_vs_reference_golden and lpdnet_bq1)"]
+           "test_train_bf16_storage_vs_oracle or (test_train_step0_vs_reference_golden and lpdnet_bq1) or test_train_step0_cfg2_full_size"]
     r = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
