@@ -145,6 +145,10 @@ int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, 
 /* The bare product C = A W^T (+ bias) of a TRAIN-mode layer with its BatchNorm statistics from the epilogue: stat_sum / stat_sumsq
  * [N] fp64 (zeroed by the call) = column sums / sums of squares of C over the M rows (fp32 over a block's 128 rows, fp64 atomics),
  * i.e. lpd_colstats without the second pass over C. */
+/* lpd_gemm_x3w with per-problem weights: rows [b batch_rows, (b + 1) batch_rows) of the row-major A take fragment set b of
+ * lpd_gemm_prep_b_batch (frag_bytes = lpd_gemm_prep_b_bytes(N, K) apart); batch_rows % 128 == 0.  NetVLAD backward's dA[b] = x[b] . dV[b]. */
+int lpd_gemm_x3w_batched(const float* A, int lda, const void* frags, long long frag_bytes, int batch_rows, float* C, int ldc, int M, int N,
+                         int K, int impl, void* stream);
 int lpd_gemm_x3w_stats(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
                        double* stat_sum, double* stat_sumsq, int impl, double* stat_ws, void* stream);
 /* The product with the train-mode BatchNorm affine + activation of the layer IN FRONT applied in the operand loader:

@@ -582,6 +582,10 @@ struct X3wArgs {
     float* a_out;
     int a_ld;
     float a_ns;                   // negative slope of the activation (1 = none, 0 = ReLU)
+    // per-problem weights over consecutive row ranges (lpd_gemm_x3w_batched): rows [b batch_rows, (b + 1) batch_rows) take the fragment
+    // set b, frag_stride bf16 elements behind set b - 1 (hi and lo arrays alike); 0 = one weight for all rows
+    int batch_rows;
+    long long frag_stride;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -709,8 +713,9 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int nt = nt0 + j < NT ? nt0 + j : 0;   // strips past N read tile 0 (never stored)
-        fh[j] = g.fhi + ((long long)nt * g.KS * 64 + lane) * 8;
-        fl[j] = g.flo + ((long long)nt * g.KS * 64 + lane) * 8;
+        const long long fb = g.batch_rows ? (long long)(m0 / g.batch_rows) * g.frag_stride : 0;      // this row tile's problem
+        fh[j] = g.fhi + fb + ((long long)nt * g.KS * 64 + lane) * 8;
+        fl[j] = g.flo + fb + ((long long)nt * g.KS * 64 + lane) * 8;
     }
     auto load_b = [&](int ks, int set) {
         ks = min(ks, g.KS - 1);                       // past the end: any valid fragment (its A columns are zero)
@@ -1175,7 +1180,7 @@ static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, i
                          const float* scale, const float* shift, int act, float slope, int accumulate,
                          long long a_cloud, long long c_cloud, int panel_n, int panel_ld, int impl, double* stat_sum, double* stat_sumsq,
                          double* stat_ws, void* stream_, const float* a_scale = nullptr, const float* a_shift = nullptr, float* a_out = nullptr,
-                         int a_ld = 0, float a_ns = 1.0f)
+                         int a_ld = 0, float a_ns = 1.0f, int batch_rows = 0, long long frag_bytes = 0)
 {
     hipStream_t stream = (hipStream_t)stream_;
     const bool a_panels = a_cloud != 0, c_panels = c_cloud != 0;
@@ -1200,7 +1205,12 @@ static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, i
     }
     X3wArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, K, KS, lda, ldc, bias, scale, shift, act, slope, accumulate,
               a_cloud, c_cloud, panel_n, panel_ld, 0, prods, stat_sum ? sws.sum() : nullptr, stat_sum ? sws.sumsq() : nullptr,
-              a_scale, a_shift, a_out, a_ld, a_ns};
+              a_scale, a_shift, a_out, a_ld, a_ns, batch_rows, 0};
+    if (batch_rows) {      // per-problem fragment sets, each lpd_gemm_prep_b_bytes(N, K) bytes (hi half, then lo half): the lo array of set 0
+        LPD_CHECK_ARG(batch_rows % 128 == 0 && M % batch_rows == 0 && frag_bytes == lpd_gemm_prep_b_bytes(N, K),      // starts where a single set's would
+                      "lpd_gemm_x3w_batched: batch_rows %% 128 == 0, M %% batch_rows == 0, frag_bytes = lpd_gemm_prep_b_bytes(N, K)");
+        g.frag_stride = frag_bytes / 2;      // bf16 elements between consecutive sets (a set = hi array + lo array)
+    }
     LPD_CHECK_ARG(!a_scale || (a_shift && !a_panels && N <= 128 && impl != 3 && (!a_out || (a_ld % 4 == 0 && ((uintptr_t)a_out & 15) == 0))
                                && (((uintptr_t)a_scale | (uintptr_t)a_shift) & 15) == 0),
                   "lpd_gemm_x3w_act: the operand transform needs a row-major A and ONE column block (N <= 128)");
@@ -1245,6 +1255,18 @@ extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C
 // stat_sumsq[n] (fp64, zeroed here) receive the column sums / sums of squares of C over the M rows from the kernel's epilogue
 // (fp32 over a block's 128 rows, then fp64 atomics) -- what lpd_colstats computes with a second pass over C
 // (util/lpdnet_model.py:262: conv3_lpd + bn3_lpd over all B*N points; :251 convDG2 over all B*N*k edges).
+// lpd_gemm_x3w with per-problem weights: rows [b batch_rows, (b + 1) batch_rows) of A are multiplied by weight b, whose fragments are set b
+// of lpd_gemm_prep_b_batch (frag_bytes = lpd_gemm_prep_b_bytes(N, K) apart).  Row-major A / C over all problems (M = batch x batch_rows).
+// The NetVLAD backward's dA[b] = x[b] . dV[b] (util/PointNetVlad.py:64-67 transposed: [N, 1024] x [1024, 64] per cloud) ran on the generic
+// batched kernel at 2.6 TB/s of its 738-MB operand.
+extern "C" int lpd_gemm_x3w_batched(const float* A, int lda, const void* frags, long long frag_bytes, int batch_rows, float* C, int ldc, int M,
+                                    int N, int K, int impl, void* stream_)
+{
+    LPD_CHECK_ARG(batch_rows > 0 && frag_bytes > 0, "lpd_gemm_x3w_batched: batch_rows / frag_bytes");
+    return gemm_x3w_impl(A, lda, frags, C, ldc, M, N, K, nullptr, nullptr, nullptr, 0, 0.0f, 0, 0, 0, 0, 0, impl, nullptr, nullptr, nullptr, stream_,
+                         nullptr, nullptr, nullptr, 0, 1.0f, batch_rows, frag_bytes);
+}
+
 extern "C" int lpd_gemm_x3w_stats(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
                                   double* stat_sum, double* stat_sumsq, int impl, double* stat_ws, void* stream_)
 {

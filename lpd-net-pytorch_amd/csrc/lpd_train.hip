@@ -677,7 +677,22 @@ __global__ __launch_bounds__(256) void dw_smallk_kernel(const float* __restrict_
     const int RG = 256 / Co;
     const int o = threadIdx.x % Co, rg = threadIdx.x / Co;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long long m = (long long)blockIdx.x * RG + rg; m < M; m += (long long)gridDim.x * RG) {
+    const long long step = (long long)gridDim.x * RG;
+    long long m = (long long)blockIdx.x * RG + rg;
+    for (; m + 3 * step < M; m += 4 * step) {      // four rows in flight (one row at a time: 107 us for 46 MB at the training step's shape)
+        float g[4], x[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            g[u] = dY[(m + u * step) * lddy + o];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x[u][c] = c < Kin ? X[(m + u * step) * ldx + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] += g[u] * x[u][c];
+    }
+    for (; m < M; m += step) {
         const float g = dY[m * lddy + o];
         for (int c = 0; c < Kin; ++c) acc[c] += g * X[m * ldx + c];
     }

@@ -49,6 +49,7 @@ SIGNATURES = {
                           _c_int, _c_f, _c_p, _c_p, _c_ll, _c_p],
     "lpd_softmax_affine_parts": [_c_p, _c_int, _c_ll, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_int, _c_p],
     "lpd_split_panels": [_c_p, _c_ll, _c_int, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "lpd_gemm_x3w_batched": [_c_p, _c_int, _c_p, _c_ll, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "lpd_gemm_x3w_act": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_int, _c_int, _c_p],
     "lpd_gemm_x3w_stats": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_p, _c_p],
     "lpd_retrieval_topk": [_c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],

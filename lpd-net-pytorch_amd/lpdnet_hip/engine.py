@@ -208,15 +208,27 @@ def _dev_key(device):
 _SIDE_FORCE = __import__("threading").local()      # calibrate()'s per-thread override (DataParallel: one host thread per device)
 
 
-def _side_mode(device):
-    """use the second stream for this forward?  Explicit settings pass through; auto = the calibrated choice, one stream before."""
+# auto mode: batches of at most this many points always take the second stream.  A small batch leaves most of the chip idle -- one cloud's
+# kNN search is 128 single-wave workgroups on 256 CUs and lasts as long as its longest wave -- so the two searches side by side are a
+# structural gain (measured, tools/side_small.py: 1 / 6 / 10 / 24 clouds -18 / -14 / -12 / -7 %), not the box-dependent 3-4 % of a 32-cloud step
+# that `calibrate` is for
+SIDE_SMALL_POINTS = 24 * 4096
+
+
+def _side_mode(device, points=None):
+    """use the second stream for this forward?  Explicit settings pass through; auto = small batches always, larger ones the calibrated
+    choice (one stream before a calibration)."""
     forced = getattr(_SIDE_FORCE, "mode", None)
     if forced is not None:
         return forced
     if SIDE_STREAM != "auto":
         return bool(SIDE_STREAM)
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    if points is not None and points <= SIDE_SMALL_POINTS:
+        return True
     st = _SIDE_AUTO.get(_dev_key(device))
-    return bool(st and st["choice"]) and not torch.cuda.is_current_stream_capturing()
+    return bool(st and st["choice"])
 
 
 def calibrate(model, x, samples=None, force=False):
@@ -263,10 +275,11 @@ def side_stream_report(device):
     if SIDE_STREAM != "auto":
         return "two streams (set)" if SIDE_STREAM else "one stream (set)"
     st = _SIDE_AUTO.get(_dev_key(device))
+    small = " (batches of at most %d points always take the second stream)" % SIDE_SMALL_POINTS
     if not st:
-        return "one stream (not calibrated: engine.calibrate(model, x) measures the second stream)"
+        return "one stream (not calibrated: engine.calibrate(model, x) measures the second stream)" + small
     return "%s (calibrated at B=%d, N=%d: forward %.3f ms with the second stream, %.3f ms without; medians of %d interleaved forwards each)" % (
-        "two streams" if st["choice"] else "one stream", st["shape"][0], st["shape"][1], st["ms"][0], st["ms"][1], st["n"])
+        "two streams" if st["choice"] else "one stream", st["shape"][0], st["shape"][1], st["ms"][0], st["ms"][1], st["n"]) + small
 
 
 FUSED_FRONT = __import__("os").environ.get("LPD_FUSED_FRONT", "1") != "0"   # conv1 + conv2 + kNN operands in one launch (no T-Nets)
@@ -334,7 +347,7 @@ def lpdnet_features_eval(net, x, reorder=True, assign=None):
     B, N = x.shape[0], x.shape[2]
     act = ops.ACT_RELU if net.use_relu else ops.ACT_LEAKY
     side_ok = PANEL_LAYOUT and N % 128 == 0 and _resident_shape(net.k, N, B * N, act)
-    out = _lpdnet_features_eval_body(net, x, mfea, side_ok and _side_mode(x.device), assign)
+    out = _lpdnet_features_eval_body(net, x, mfea, side_ok and _side_mode(x.device, B * N), assign)
     return out if assign is not None else out[:3]
 
 

@@ -272,6 +272,7 @@ _FRAG_CACHE = {}
 _FRAG_LOCK = __import__("threading").Lock()     # nn.DataParallel-style callers: one forward per device thread
 X3W_FORWARD = os.environ.get("LPD_X3W_FWD", "1") != "0"    # forward layers with K >= 256 on the prepared-fragment kernel
 X3W_IMPL = int(os.environ.get("LPD_X3W_IMPL", "0"))         # lpd_gemm_x3w impl (0 = by shape); benchmarking only
+X3W_BATCHED = os.environ.get("LPD_X3W_BATCHED", "1") != "0"  # batched deep-reduction products with per-problem k-major weights on lpd_gemm_x3w_batched
 X3T_PANELS = os.environ.get("LPD_X3T", "1") != "0"          # short-reduction panel-to-panel products on lpd_gemm_x3t
 X3T_ROWS = os.environ.get("LPD_X3T_ROWS", "1") != "0"       # ... and row-major ones (K = 64 / 128) on lpd_gemm_x3t_rows
 
@@ -380,6 +381,17 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
             fb, frags = 0, _weight_frags(B, b_kmajor, N, K)
         _call(f"gemmx3t[{M}x{N}x{K}]" + (f"x{nb}" if batched else ""), lib.lpd_gemm_x3t_rows, _ptr(A), lda, _ptr(frags), _ptr(out), ldc, M, N, K,
               _ptr(bias), _ptr(scale), _ptr(shift), act, float(slope), nb, sA, sC, fb, _stream())
+        return out
+    if (GEMM_BF16X3 and X3W_BATCHED and batched and not exact and _EXACT.depth == 0 and not a_kmajor and b_kmajor and splits == 1 and not accumulate
+            and bias is None and scale is None and act == ACT_NONE and M % 128 == 0 and nb * M >= 16384 and 64 <= N <= 128 and K >= 256
+            and N * K <= (1 << 22) and sA == M * lda and sC == M * ldc and nb * M < (1 << 31)):
+        # per-problem k-major weights over consecutive row ranges of one row-major A (NetVLAD backward: dA[b] = x[b] . dV[b]): the
+        # prepared-fragment kernel with a fragment set per problem; the generic batched kernel ran this at 2.6 TB/s of the 738-MB operand
+        fb = int(lib.lpd_gemm_prep_b_bytes(N, K))
+        frags = torch.empty((nb * fb,), dtype=torch.uint8, device=A.device)
+        _call("gemm_prep_b", lib.lpd_gemm_prep_b_batch, _ptr(B), ldb, 1, N, K, nb, sB, _ptr(frags), _stream())
+        _call(f"gemmx3w[{M}x{N}x{K}]x{nb}", lib.lpd_gemm_x3w_batched, _ptr(A), lda, _ptr(frags), fb, M, _ptr(out), ldc, nb * M, N, K,
+              16 if _FAST.depth > 0 else 0, _stream())
         return out
     if (GEMM_BF16X3 and not exact and _EXACT.depth == 0 and not a_kmajor and not batched and splits == 1
             and M >= 1024 and N >= 64 and N * K <= (1 << 22)

@@ -1319,3 +1319,22 @@ def test_gemm_act_equals_affine_act_then_product(cuda):
         assert _rel(c, ref_c) < 1e-6
         c64 = ref_a.double() @ w.data.double()
         assert _rel(c, c64) < 2e-5
+
+
+def test_gemm_x3w_batched_per_problem_weights(cuda):
+    """lpd_gemm_x3w_batched (one row-major A, a k-major weight per consecutive range of rows) against fp64 and against the generic
+    batched kernel it replaces for the NetVLAD backward's dA[b] = x[b] . dV[b]."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    nb, M, K, N = 6, 4096, 1024, 64
+    A = torch.randn(nb, M, K, generator=g).to(cuda)
+    Bm = (torch.randn(nb, K, N, generator=g) / K ** 0.5).to(cuda)
+    got = ops.gemm(A, Bm, a_kmajor=False, b_kmajor=True)
+    want = torch.bmm(A.double(), Bm.double())
+    assert got.shape == (nb, M, N) and _rel(got, want) < 2e-5
+    prev, ops.X3W_BATCHED = ops.X3W_BATCHED, False
+    try:
+        old = ops.gemm(A, Bm, a_kmajor=False, b_kmajor=True)
+    finally:
+        ops.X3W_BATCHED = prev
+    assert _rel(old, want) < 2e-5 and _rel(got, old) < 2e-5
