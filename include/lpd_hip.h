@@ -147,16 +147,22 @@ int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, 
  * i.e. lpd_colstats without the second pass over C. */
 /* lpd_gemm_x3w with per-problem weights: rows [b batch_rows, (b + 1) batch_rows) of the row-major A take fragment set b of
  * lpd_gemm_prep_b_batch (frag_bytes = lpd_gemm_prep_b_bytes(N, K) apart); batch_rows % 128 == 0.  NetVLAD backward's dA[b] = x[b] . dV[b]. */
-int lpd_gemm_x3w_batched(const float* A, int lda, const void* frags, long long frag_bytes, int batch_rows, float* C, int ldc, int M, int N,
-                         int K, int impl, void* stream);
-int lpd_gemm_x3w_stats(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
+int lpd_gemm_x3w_batched(const void* A, int lda, int a_bf16, const void* frags, long long frag_bytes, int batch_rows, float* C, int ldc, int M,
+                         int N, int K, int impl, void* stream);
+/* bf16 rows as the operand (a_bf16 above, flags & 1 of lpd_gemm_x3w_act, lpd_gemm_x3w_bf16a): A [M][lda] in bf16 elements, row-major,
+ * K % 32 == 0.  A plain product takes the rows as the hi image (two MFMA products against the split weight); with an operand
+ * transform they are widened first.  flags & 2 of lpd_gemm_x3w_act: a_out is a bf16 tensor, and the product sees the rounded values.
+ * The bf16-storage training mode keeps the [B N, 1024] conv3 map, its activated form and its gradient as bf16. */
+int lpd_gemm_x3w_bf16a(const void* A16, int lda, const void* frags, float* C, int ldc, int M, int N, int K, int accumulate, int impl, void* stream);
+/* c_bf16: C receives bf16 values ([M][ldc] in bf16 elements, N % 32 == 0); the statistics stay those of the fp32 accumulators */
+int lpd_gemm_x3w_stats(const float* A, int lda, const void* frags, void* C, int ldc, int c_bf16, int M, int N, int K, const float* bias,
                        double* stat_sum, double* stat_sumsq, int impl, double* stat_ws, void* stream);
 /* The product with the train-mode BatchNorm affine + activation of the layer IN FRONT applied in the operand loader:
  * C = act(a_scale[k] A[m][k] + a_shift[k]) W^T (+ bias), the transformed rows stored to a_out [M][a_ld] on the way (or null).
  * Row-major A, N <= 128.  util/lpdnet_model.py:262 (bn3_lpd + act) feeding util/PointNetVlad.py:48 (x . cluster_weights): the
  * stand-alone affine pass over the [B N, 1024] map disappears.  impl: 0, or 16 = plain bf16 operands (bf16 storage mode). */
-int lpd_gemm_x3w_act(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
-                     const float* a_scale, const float* a_shift, int a_act, float a_slope, float* a_out, int a_ld, int impl, void* stream);
+int lpd_gemm_x3w_act(const void* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
+                     const float* a_scale, const float* a_shift, int a_act, float a_slope, void* a_out, int a_ld, int flags, int impl, void* stream);
 
 /*
  * The same product for a SHORT reduction with cloud-panel A and C (the neighbour / centre projection of the split SN1 edge
@@ -175,7 +181,8 @@ int lpd_gemm_x3ts(const void* a_hi, long long a_lo, const void* frags, float* C,
  * fragments of lpd_gemm_prep_b; K = 64 or 128, N % 32 == 0, M % 128 == 0.  batch > 1: independent problems with their own A, C
  * (strides sA, sC in floats) and fragment sets (frag_bytes apart). */
 int lpd_gemm_x3t_rows_applies(int M, int N, int K, int act, long long lda, long long ldc);
-int lpd_gemm_x3t_rows(const float* A, long long lda, const void* frags, float* C, long long ldc, int M, int N, int K, const float* bias,
+/* c_bf16: C receives bf16 values (ldc / sC in bf16 elements, ldc % 8 == 0) */
+int lpd_gemm_x3t_rows(const float* A, long long lda, const void* frags, void* C, long long ldc, int c_bf16, int M, int N, int K, const float* bias,
                       const float* scale, const float* shift, int act, float slope, int batch, long long sA, long long sC,
                       long long frag_bytes, void* stream);
 
@@ -371,6 +378,11 @@ int lpd_affine_act(const float* X, long long ldx, float* Y, long long ldy, long 
 int lpd_bn_act_bwd(const float* dY, long long lddy, const float* X, long long ldx, float* dX, long long lddx, long long R,
                    int C, const float* scale, const float* shift, const float* mean, const float* invstd, int act,
                    float slope, int has_bn, double* dbeta, double* dgamma, double* stat_ws, void* stream);
+/* the same on bf16 tensors (dY, X, dX [R][ld] in bf16 elements, ld % 8 == 0, C a power of two in 8..2048; dX may alias dY): the
+ * bf16-storage training mode's conv3 map (util/lpdnet_model.py:262 backward) */
+int lpd_bn_act_bwd_bf16(const void* dY, long long lddy, const void* X, long long ldx, void* dX, long long lddx, long long R, int C,
+                        const float* scale, const float* shift, const float* mean, const float* invstd, int act, float slope, int has_bn,
+                        double* dbeta, double* dgamma, double* stat_ws, void* stream);
 
 /* Materialised edge tensor (training only): U[(i,t)] = P[nbr(i,t)] + Q[i], rows i*k+t, [M*k][C]
  * (the split form of util/lpdnet_model.py:350-357 + the 1x1 conv).  C in {64,128,256}.
@@ -590,8 +602,9 @@ int lpd_gemm_tn_bf16(const uint16_t* A, const uint16_t* B, float* dW, float* ws,
  * pooling act^T x (util/PointNetVlad.py:64-67).  batch problems at strides sA / sB (elements) write dW [batch][KA][KB].
  * KA %% 128 == 0, KB %% 64 == 0; ws: lpd_gemm_tn_ws_floats(M, KA, KB, batch) floats. */
 long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB, int batch);
-int lpd_gemm_tn(const float* A, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
-                int batch, long long sA, long long sB, void* stream);
+int lpd_gemm_tn(const void* A, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
+                int batch, long long sA, long long sB, int a_bf16, void* stream);
+/* a_bf16 != 0: A holds bf16 rows (lda, sA in bf16 elements, multiples of 8): two MFMA products per term (bf16-storage training mode). */
 
 /*
  * conv3_lpd of the eval path (util/lpdnet_model.py:262: 512 -> emb_dims per point, + bn3 + activation) on PRE-SPLIT operands:

@@ -586,6 +586,13 @@ struct X3wArgs {
     // set b, frag_stride bf16 elements behind set b - 1 (hi and lo arrays alike); 0 = one weight for all rows
     int batch_rows;
     long long frag_stride;
+    // a_bf16 != 0: A holds bf16 rows (lda in bf16 elements; row-major, K % 32 == 0): the bf16-storage training mode's conv3-map tensors.
+    // Without an operand transform the values ARE the hi image (no lo image, prods = 2: a_hi b_lo + a_hi b_hi); with a_scale they are
+    // widened, transformed and split like fp32 rows.
+    int a_bf16;
+    int a_out_bf16;               // the transformed rows are stored as bf16 (a_ld in bf16 elements)
+    int c_bf16;                   // C receives bf16 values (ldc in bf16 elements; row-major, N % 32 == 0, no accumulate): the statistics are
+                                  // still those of the fp32 accumulators
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -604,9 +611,15 @@ struct X3wArgs {
 // ---------------------------------------------------------------------------------------------
 // KC: k per chunk (2 or 4 MFMA k-steps); 32 everywhere (64-deep chunks -- 256 instead of 128 bytes per visit of a
 // row-major A row -- changed nothing on the NetVLAD assignment).
-template <int WN, bool KTAIL, int PANELS, int KC, bool TALL = false>
+// MODE (row-major operands only): bit 0 = A holds bf16 rows (X3wArgs::a_bf16; a bf16 a_out needs it), bit 1 = C receives bf16 values.
+// Compile-time: as run-time branches the fp32 instantiations went from 9 to ~1000 spilled registers.
+template <int WN, bool KTAIL, int PANELS, int KC, bool TALL = false, int MODE = 0>
 __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kernel(X3wArgs g)
 {
+    static_assert(MODE == 0 || PANELS == 0, "bf16 operands are row-major");
+    constexpr bool A16 = (MODE & 1) != 0, C16 = (MODE & 2) != 0;
+    constexpr bool A16T = A16 && (MODE & 4) != 0;      // bf16 rows behind an operand transform (a_scale): widened, transformed, split
+    constexpr bool A16P = A16 && !A16T;                // plain bf16 rows: they ARE the hi image, no lo image, two products
     // TALL (N <= 64, WN = 1): two column tiles only -- the waves split the ROWS as well (wave = column tile + 2 x row half,
     // two row tiles each) instead of two of the four multiplying tiles that are never stored.
     constexpr int RT = TALL ? 2 : 4;            // row tiles per wave
@@ -658,7 +671,7 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
     auto load_a = [&](int kc, float4 (&r)[NF4], int set) {
         const int k0 = kc * X3V_KC;
         if constexpr (!(PANELS & 1)) {
-            if (g.a_scale) {      // uniform
+            if (A16T || (!A16P && g.a_scale)) {      // uniform
                 rk0[set] = k0;
                 rsc[set] = ld4_guard(g.a_scale, k0 + (tid % QR) * 4, g.K);
                 rsh[set] = ld4_guard(g.a_shift, k0 + (tid % QR) * 4, g.K);
@@ -674,7 +687,10 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
                 const int f = e * GEMM_THREADS + tid;
                 int row = m0 + f / QR;
                 row = row < g.M ? row : g.M - 1;
-                if constexpr (KTAIL) r[e] = ld4_guard(a_base + (long long)row * g.lda, k0 + (f % QR) * 4, g.K);
+                if constexpr (A16) {      // four bf16 values as raw bits in .x / .y
+                    const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a_base) + (long long)row * g.lda + k0 + (f % QR) * 4);
+                    r[e] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), 0.0f, 0.0f);
+                } else if constexpr (KTAIL) r[e] = ld4_guard(a_base + (long long)row * g.lda, k0 + (f % QR) * 4, g.K);
                 else r[e] = *reinterpret_cast<const float4*>(a_base + (long long)row * g.lda + k0 + (f % QR) * 4);
             }
         }
@@ -689,14 +705,32 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
             else { const int f = e * GEMM_THREADS + tid; rr = f / QR; k4 = f % QR; }
             float4 v = r[e];
             if constexpr (!(PANELS & 1)) {
-                if (g.a_scale) {      // uniform: the transformed operand, stored on the way
+                if constexpr (A16) {
+                    const unsigned w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y);
+                    if constexpr (A16P) {      // the rows ARE the hi image
+                        *reinterpret_cast<uint2*>(hi_img + rr * X3V_LDK + k4 * 4) = make_uint2(w0, w1);
+                        continue;
+                    }
+                    v = make_float4(__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u), __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u));
+                }
+                if (A16T || (!A16P && g.a_scale)) {      // uniform: the transformed operand, stored on the way
                     const float4 sc = rsc[set], sh = rsh[set];
                     // (multiply, then add -- not fused: the same bits as lpd_affine_act)
                     v.x = sc.x * v.x + sh.x; v.y = sc.y * v.y + sh.y; v.z = sc.z * v.z + sh.z; v.w = sc.w * v.w + sh.w;
                     v.x = fmaxf(v.x, 0.0f) + g.a_ns * fminf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f) + g.a_ns * fminf(v.y, 0.0f);
                     v.z = fmaxf(v.z, 0.0f) + g.a_ns * fminf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f) + g.a_ns * fminf(v.w, 0.0f);
                     const int m = m0 + rr, kk = rk0[set] + k4 * 4;
-                    if (g.a_out && m < g.M && (!KTAIL || kk + 3 < g.K)) *reinterpret_cast<float4*>(g.a_out + (long long)m * g.a_ld + kk) = v;
+                    if (g.a_out && m < g.M && (!KTAIL || kk + 3 < g.K)) {
+                        if (A16 && g.a_out_bf16) {
+                            bf16x4 ob;
+                            ob[0] = (__bf16)v.x; ob[1] = (__bf16)v.y; ob[2] = (__bf16)v.z; ob[3] = (__bf16)v.w;
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(g.a_out) + (long long)m * g.a_ld + kk) = ob;
+                            // the product and the stored map see the SAME rounded values (the backward reads the stored ones)
+                            v = make_float4((float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]);
+                        } else {
+                            *reinterpret_cast<float4*>(g.a_out + (long long)m * g.a_ld + kk) = v;
+                        }
+                    }
                 }
             }
             bf16x4 hh, ll;
@@ -739,9 +773,15 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             a_hi[i] = *reinterpret_cast<const bf16x8*>(ah + (rt0 + i) * 32 * X3V_LDK + s * 16);
-            a_lo[i] = *reinterpret_cast<const bf16x8*>(al + (rt0 + i) * 32 * X3V_LDK + s * 16);
+            if constexpr (!A16P) a_lo[i] = *reinterpret_cast<const bf16x8*>(al + (rt0 + i) * 32 * X3V_LDK + s * 16);
         }
-        if (g.prods != 1) {      // uniform
+        if constexpr (A16P) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[set][j], acc[i][j], 0, 0, 0);
+        } else if (g.prods != 1) {      // uniform
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -808,7 +848,15 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
                 else v = fmaxf(v, 0.0f) + ns * fminf(v, 0.0f);
                 float* dst;
                 if constexpr (PANELS & 2) dst = C + ((long long)(n >> 3) * g.panel_ld + (m - m_cloud0)) * 8 + (n & 7);
-                else dst = C + (long long)m * g.ldc + n;
+                else {
+                    if constexpr (C16) {      // the lane pair (n, n + 1) leaves as one 4-byte word, written by the even lane
+                        const unsigned mine = __builtin_bit_cast(unsigned short, (__bf16)v);
+                        const unsigned other = lpd_lane_xor1(mine);
+                        if (!(col & 1)) *reinterpret_cast<unsigned*>(reinterpret_cast<uint16_t*>(C) + (long long)m * g.ldc + n) = mine | (other << 16);
+                        continue;
+                    }
+                    dst = C + (long long)m * g.ldc + n;
+                }
                 if (g.accumulate) v += *dst;
                 *dst = v;
             }
@@ -1149,17 +1197,17 @@ extern "C" int lpd_gemm_prep_b_batch(const float* B, int ldb, int b_kmajor, int 
     return LPD_OK;
 }
 
-template <int WN, int PANELS, int KC, bool TALL = false>
+template <int WN, int PANELS, int KC, bool TALL = false, int MODE = 0>
 static void x3w_wide_launch_kc(const X3wArgs& g, int NT, hipStream_t stream)
 {
     const size_t lds = (size_t)4 * 128 * (KC + 8) * sizeof(__bf16);
     dim3 grid(TALL ? (NT + 1) / 2 : (NT + 4 * WN - 1) / (4 * WN), (g.M + 127) / 128);
     if (g.K % KC) {
-        auto kern = gemm_x3w_wide_kernel<WN, true, PANELS, KC, TALL>;
+        auto kern = gemm_x3w_wide_kernel<WN, true, PANELS, KC, TALL, MODE>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, stream, g);
     } else {
-        auto kern = gemm_x3w_wide_kernel<WN, false, PANELS, KC, TALL>;
+        auto kern = gemm_x3w_wide_kernel<WN, false, PANELS, KC, TALL, MODE>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, stream, g);
     }
@@ -1180,13 +1228,13 @@ static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, i
                          const float* scale, const float* shift, int act, float slope, int accumulate,
                          long long a_cloud, long long c_cloud, int panel_n, int panel_ld, int impl, double* stat_sum, double* stat_sumsq,
                          double* stat_ws, void* stream_, const float* a_scale = nullptr, const float* a_shift = nullptr, float* a_out = nullptr,
-                         int a_ld = 0, float a_ns = 1.0f, int batch_rows = 0, long long frag_bytes = 0)
+                         int a_ld = 0, float a_ns = 1.0f, int batch_rows = 0, long long frag_bytes = 0, int a_flags = 0)
 {
     hipStream_t stream = (hipStream_t)stream_;
     const bool a_panels = a_cloud != 0, c_panels = c_cloud != 0;
     LPD_CHECK_ARG(A && frags && C && M > 0 && N > 0 && K > 0, "lpd_gemm_x3w: bad arguments");
     LPD_CHECK_ARG(a_panels || (lda % 4 == 0), "lpd_gemm_x3w: lda %% 4 != 0");
-    LPD_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)frags & 15) == 0, "lpd_gemm_x3w: A and the fragments must be 16-byte aligned");
+    LPD_CHECK_ARG(((uintptr_t)A & 7) == 0 && ((uintptr_t)frags & 15) == 0, "lpd_gemm_x3w: A (8 bytes) and the fragments (16) must be aligned");
     LPD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "lpd_gemm_x3w: scale and shift must be given together");
     LPD_CHECK_ARG(!(a_panels || c_panels) || (panel_n > 0 && panel_n % 128 == 0 && M % panel_n == 0 && panel_ld >= panel_n),
                   "lpd_gemm_x3w: cloud-panel operands need points per cloud %% 128 == 0");
@@ -1205,13 +1253,20 @@ static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, i
     }
     X3wArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, K, KS, lda, ldc, bias, scale, shift, act, slope, accumulate,
               a_cloud, c_cloud, panel_n, panel_ld, 0, prods, stat_sum ? sws.sum() : nullptr, stat_sum ? sws.sumsq() : nullptr,
-              a_scale, a_shift, a_out, a_ld, a_ns, batch_rows, 0};
+              a_scale, a_shift, a_out, a_ld, a_ns, batch_rows, 0, a_flags & 1, (a_flags >> 1) & 1, (a_flags >> 2) & 1};
+    LPD_CHECK_ARG(!(a_flags & 4) || (!c_panels && !accumulate && N % 32 == 0 && ldc % 2 == 0 && ((uintptr_t)C & 3) == 0),
+                  "lpd_gemm_x3w: bf16 C needs row-major rows, N %% 32 == 0, no accumulate");
+    if (a_flags & 1) {      // bf16 rows: row-major, whole chunks, 8-byte aligned pieces; the plain product takes them as the hi image
+        LPD_CHECK_ARG(!a_panels && K % 32 == 0 && lda % 4 == 0 && ((uintptr_t)A & 7) == 0 && impl != 1, "lpd_gemm_x3w: bf16 A needs row-major rows, K %% 32 == 0");
+        if (!a_scale && g.prods == 3) g.prods = 2;
+    }
+    LPD_CHECK_ARG(!(a_flags & 2) || ((a_flags & 1) && a_out && a_ld % 4 == 0), "lpd_gemm_x3w_act: a bf16 a_out is built for bf16 rows A");
     if (batch_rows) {      // per-problem fragment sets, each lpd_gemm_prep_b_bytes(N, K) bytes (hi half, then lo half): the lo array of set 0
         LPD_CHECK_ARG(batch_rows % 128 == 0 && M % batch_rows == 0 && frag_bytes == lpd_gemm_prep_b_bytes(N, K),      // starts where a single set's would
                       "lpd_gemm_x3w_batched: batch_rows %% 128 == 0, M %% batch_rows == 0, frag_bytes = lpd_gemm_prep_b_bytes(N, K)");
         g.frag_stride = frag_bytes / 2;      // bf16 elements between consecutive sets (a set = hi array + lo array)
     }
-    LPD_CHECK_ARG(!a_scale || (a_shift && !a_panels && N <= 128 && impl != 3 && (!a_out || (a_ld % 4 == 0 && ((uintptr_t)a_out & 15) == 0))
+    LPD_CHECK_ARG(!a_scale || (a_shift && !a_panels && N <= 128 && impl != 3 && (!a_out || (a_ld % 4 == 0 && ((uintptr_t)a_out & 7) == 0))
                                && (((uintptr_t)a_scale | (uintptr_t)a_shift) & 15) == 0),
                   "lpd_gemm_x3w_act: the operand transform needs a row-major A and ONE column block (N <= 128)");
     if (a_scale) impl = 2;
@@ -1223,6 +1278,20 @@ static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, i
     // impl: 0 = by shape, 2 = 128 x 128 blocks, 3 = 128 x 256 blocks
     if (impl == 0) impl = N >= 256 ? 3 : 2;
     const int panels = (a_panels ? 1 : 0) | (c_panels ? 2 : 0);
+    if (a_flags & 5) {      // bf16 rows in (whole chunks: K % 32 == 0, checked above) or bf16 values out: their own instantiations
+        const int mode = (a_flags & 1) | ((a_flags & 4) ? 2 : 0) | (((a_flags & 1) && a_scale) ? 4 : 0);
+        LPD_CHECK_ARG(K % 32 == 0 && panels == 0, "lpd_gemm_x3w: bf16 operands need K %% 32 == 0 and row-major operands");
+        if (mode == 2 && impl == 3) x3w_wide_launch_kc<2, 0, 32, false, 2>(g, NT, stream);          // conv3 + statistics -> bf16 map
+        else if (mode == 1 && impl == 3) x3w_wide_launch_kc<2, 0, 32, false, 1>(g, NT, stream);     // dX = dY W on the bf16 gradient
+        else if (mode == 1 && impl == 2 && NT <= 2) x3w_wide_launch_kc<1, 0, 32, true, 1>(g, NT, stream);   // dA of the NetVLAD backward
+        else if (mode == 1 && impl == 2) x3w_wide_launch_kc<1, 0, 32, false, 1>(g, NT, stream);
+        else if (mode == 5 && impl == 2 && NT <= 2) x3w_wide_launch_kc<1, 0, 32, true, 5>(g, NT, stream);   // assignment + bn3 / activation
+        else if (mode == 5 && impl == 2) x3w_wide_launch_kc<1, 0, 32, false, 5>(g, NT, stream);
+        else LPD_CHECK_ARG(false, "lpd_gemm_x3w: bf16 operand combination %d with %d-wide blocks is not built", mode, impl == 3 ? 256 : 128);
+        LPD_CHECK_LAUNCH("lpd_gemm_x3w(bf16)");
+        if (stat_sum) return lpd_stat_finish(sws, stat_sum, stat_sumsq, N, stream);
+        return LPD_OK;
+    }
     if (impl == 2) {
         switch (panels) {
             case 0: x3w_wide_launch<1, 0>(g, NT, stream); break;
@@ -1259,30 +1328,42 @@ extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C
 // of lpd_gemm_prep_b_batch (frag_bytes = lpd_gemm_prep_b_bytes(N, K) apart).  Row-major A / C over all problems (M = batch x batch_rows).
 // The NetVLAD backward's dA[b] = x[b] . dV[b] (util/PointNetVlad.py:64-67 transposed: [N, 1024] x [1024, 64] per cloud) ran on the generic
 // batched kernel at 2.6 TB/s of its 738-MB operand.
-extern "C" int lpd_gemm_x3w_batched(const float* A, int lda, const void* frags, long long frag_bytes, int batch_rows, float* C, int ldc, int M,
-                                    int N, int K, int impl, void* stream_)
+extern "C" int lpd_gemm_x3w_batched(const void* A, int lda, int a_bf16, const void* frags, long long frag_bytes, int batch_rows, float* C, int ldc,
+                                    int M, int N, int K, int impl, void* stream_)
 {
     LPD_CHECK_ARG(batch_rows > 0 && frag_bytes > 0, "lpd_gemm_x3w_batched: batch_rows / frag_bytes");
-    return gemm_x3w_impl(A, lda, frags, C, ldc, M, N, K, nullptr, nullptr, nullptr, 0, 0.0f, 0, 0, 0, 0, 0, impl, nullptr, nullptr, nullptr, stream_,
-                         nullptr, nullptr, nullptr, 0, 1.0f, batch_rows, frag_bytes);
+    return gemm_x3w_impl(reinterpret_cast<const float*>(A), lda, frags, C, ldc, M, N, K, nullptr, nullptr, nullptr, 0, 0.0f, 0, 0, 0, 0, 0, impl, nullptr,
+                         nullptr, nullptr, stream_, nullptr, nullptr, nullptr, 0, 1.0f, batch_rows, frag_bytes, a_bf16 ? 1 : 0);
 }
 
-extern "C" int lpd_gemm_x3w_stats(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
+// C = A16 W^T (+= C with accumulate) for bf16 rows A16 [M][lda] (bf16 elements): the rows are the hi image, two MFMA products against
+// the split weight.  The bf16-storage training mode's dX = dY W on the bf16 gradient of the conv3 map.
+extern "C" int lpd_gemm_x3w_bf16a(const void* A16, int lda, const void* frags, float* C, int ldc, int M, int N, int K, int accumulate, int impl,
+                                  void* stream_)
+{
+    return gemm_x3w_impl(reinterpret_cast<const float*>(A16), lda, frags, C, ldc, M, N, K, nullptr, nullptr, nullptr, 0, 0.0f, accumulate, 0, 0, 0, 0,
+                         impl, nullptr, nullptr, nullptr, stream_, nullptr, nullptr, nullptr, 0, 1.0f, 0, 0, 1);
+}
+
+// c_bf16: C receives bf16 values ([M][ldc] bf16 elements; N % 32 == 0) -- the statistics stay those of the fp32 accumulators
+extern "C" int lpd_gemm_x3w_stats(const float* A, int lda, const void* frags, void* C, int ldc, int c_bf16, int M, int N, int K, const float* bias,
                                   double* stat_sum, double* stat_sumsq, int impl, double* stat_ws, void* stream_)
 {
     LPD_CHECK_ARG(stat_sum && stat_sumsq, "lpd_gemm_x3w_stats: null statistics");
-    return gemm_x3w_impl(A, lda, frags, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 0.0f, 0, 0, 0, 0, 0, impl, stat_sum, stat_sumsq, stat_ws, stream_);
+    return gemm_x3w_impl(A, lda, frags, reinterpret_cast<float*>(C), ldc, M, N, K, bias, nullptr, nullptr, 0, 0.0f, 0, 0, 0, 0, 0, impl, stat_sum,
+                         stat_sumsq, stat_ws, stream_, nullptr, nullptr, nullptr, 0, 1.0f, 0, 0, c_bf16 ? 4 : 0);
 }
 
 // C = act_a(a_scale[k] A[m][k] + a_shift[k]) W^T (+ bias): the train-mode BatchNorm affine + activation of the layer in front applied in
 // the operand loader, the transformed rows stored to a_out [M][a_ld] on the way (may be null).  Row-major A, N <= 128 (one column
 // block: every A element is staged exactly once).  util/lpdnet_model.py:262 (bn3 + act) -> util/PointNetVlad.py:48 (assignment).
-extern "C" int lpd_gemm_x3w_act(const float* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
-                                const float* a_scale, const float* a_shift, int a_act, float a_slope, float* a_out, int a_ld, int impl,
+extern "C" int lpd_gemm_x3w_act(const void* A, int lda, const void* frags, float* C, int ldc, int M, int N, int K, const float* bias,
+                                const float* a_scale, const float* a_shift, int a_act, float a_slope, void* a_out, int a_ld, int flags, int impl,
                                 void* stream_)
 {
     LPD_CHECK_ARG(a_scale && a_shift, "lpd_gemm_x3w_act: null scale / shift");
     LPD_CHECK_ARG(a_act >= 0 && a_act <= 2, "lpd_gemm_x3w_act: activation %d unsupported", a_act);
-    return gemm_x3w_impl(A, lda, frags, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 0.0f, 0, 0, 0, 0, 0, impl & 16, nullptr, nullptr, nullptr,
-                         stream_, a_scale, a_shift, a_out, a_ld, a_act == 0 ? 1.0f : (a_act == 1 ? 0.0f : a_slope));
+    return gemm_x3w_impl(reinterpret_cast<const float*>(A), lda, frags, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 0.0f, 0, 0, 0, 0, 0, impl & 16, nullptr,
+                         nullptr, nullptr, stream_, a_scale, a_shift, reinterpret_cast<float*>(a_out), a_ld,
+                         a_act == 0 ? 1.0f : (a_act == 1 ? 0.0f : a_slope), 0, 0, flags & 3);
 }

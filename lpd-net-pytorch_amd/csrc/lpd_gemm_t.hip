@@ -61,6 +61,7 @@ struct X3tArgs {
     long long a_lo;                // != 0: A is the hi plane of a pair of split bf16 planes (a_cloud in elements), lo plane a_lo behind
     long long lda, ldc;            // ROWS form: A [M][lda], C [M][ldc] row-major fp32 (no panels)
     long long sA, sC, sF;          // ROWS form, batched over blockIdx.y: floats between the problems' A / C, bf16 elements between their fragments
+    int c_bf16;                    // ROWS form: C holds bf16 values (ldc / sC in bf16 elements)
 };
 
 constexpr int XT_THREADS = 256;    // 128 rows per workgroup (a panel cloud is a multiple of 128 rows)
@@ -162,7 +163,22 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
     float* const stw = st + col * 36 + 4 * h;                 // this lane's columns 8 q + 4 h .. + 3 of row col
     const float* const str = st + (lane >> 3) * 36 + (lane & 7) * 4;
     float* const Crow = ROWS ? g.C + (long long)blockIdx.y * g.sC + (long long)(mc0 + (lane >> 3)) * g.ldc + (lane & 7) * 4 : nullptr;
+    // bf16 C: a row of the tile is 64 bytes -- a lane takes 8 columns (16 bytes) of row lane / 4, an instruction writes 16 whole rows
+    const float* const str16 = st + (lane >> 2) * 36 + (lane & 3) * 8;
+    uint16_t* const Crow16 = ROWS ? reinterpret_cast<uint16_t*>(g.C) + (long long)blockIdx.y * g.sC + (long long)(mc0 + (lane >> 2)) * g.ldc + (lane & 3) * 8
+                                  : nullptr;
     auto rows_out = [&](int nt, int i) {
+        if (g.c_bf16) {                       // uniform
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float4 lo4 = *reinterpret_cast<const float4*>(str16 + p * 16 * 36), hi4 = *reinterpret_cast<const float4*>(str16 + p * 16 * 36 + 4);
+                const xt_bf16x2 w0 = __builtin_convertvector((xt_f32x2){lo4.x, lo4.y}, xt_bf16x2), w1 = __builtin_convertvector((xt_f32x2){lo4.z, lo4.w}, xt_bf16x2);
+                const xt_bf16x2 w2 = __builtin_convertvector((xt_f32x2){hi4.x, hi4.y}, xt_bf16x2), w3 = __builtin_convertvector((xt_f32x2){hi4.z, hi4.w}, xt_bf16x2);
+                *reinterpret_cast<uint4*>(Crow16 + (long long)(i * 32 + p * 16) * g.ldc + nt * 32) =
+                    make_uint4(__builtin_bit_cast(unsigned, w0), __builtin_bit_cast(unsigned, w1), __builtin_bit_cast(unsigned, w2), __builtin_bit_cast(unsigned, w3));
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             *reinterpret_cast<float4*>(Crow + (long long)(i * 32 + p * 8) * g.ldc + nt * 32) = *reinterpret_cast<const float4*>(str + p * 8 * 36);
@@ -279,7 +295,7 @@ static int gemm_x3t_impl(const float* A, const void* frags, float* C, int M, int
     const int KS = K / 16, NT = N / 32;
     const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
     X3tArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, bias, scale, shift, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), a_cloud, c_cloud, panel_n, panel_ld, a_lo,
-              0, 0, 0, 0, 0};
+              0, 0, 0, 0, 0, 0};
     hipStream_t stream = (hipStream_t)stream_;
     if (KS == 8) x3t_launch<8>(g, stream);
     else x3t_launch<4>(g, stream);
@@ -315,10 +331,13 @@ extern "C" int lpd_gemm_x3t_rows_applies(int M, int N, int K, int act, long long
            lda >= K && ldc >= N;
 }
 
-extern "C" int lpd_gemm_x3t_rows(const float* A, long long lda, const void* frags, float* C, long long ldc, int M, int N, int K, const float* bias,
-                                 const float* scale, const float* shift, int act, float slope, int batch, long long sA, long long sC,
+// c_bf16: C receives bf16 values (ldc / sC in bf16 elements, ldc % 8 == 0).
+extern "C" int lpd_gemm_x3t_rows(const float* A, long long lda, const void* frags, void* C_, long long ldc, int c_bf16, int M, int N, int K,
+                                 const float* bias, const float* scale, const float* shift, int act, float slope, int batch, long long sA, long long sC,
                                  long long frag_bytes, void* stream_)
 {
+    float* C = reinterpret_cast<float*>(C_);
+    LPD_CHECK_ARG(!c_bf16 || (ldc % 8 == 0 && sC % 8 == 0), "lpd_gemm_x3t_rows: bf16 C needs ldc %% 8 == 0");
     LPD_CHECK_ARG(A && frags && C && batch >= 1 && batch <= 65535, "lpd_gemm_x3t_rows: bad arguments");
     LPD_CHECK_ARG(lpd_gemm_x3t_rows_applies(M, N, K, act, lda, ldc),
                   "lpd_gemm_x3t_rows: K in {64, 128}, N %% 32 == 0, M %% 128 == 0, act none / ReLU / LeakyReLU (M=%d N=%d K=%d act=%d)", M, N, K, act);
@@ -330,7 +349,7 @@ extern "C" int lpd_gemm_x3t_rows(const float* A, long long lda, const void* frag
     const int KS = K / 16, NT = N / 32;
     const __bf16* fhi = reinterpret_cast<const __bf16*>(frags);
     X3tArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, bias, scale, shift, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), 0, 0, 0, 0, 0,
-              lda, ldc, sA, sC, frag_bytes / 2};
+              lda, ldc, sA, sC, frag_bytes / 2, c_bf16 ? 1 : 0};
     hipStream_t stream = (hipStream_t)stream_;
     if (KS == 8) x3t_launch<8, true>(g, stream, batch);
     else x3t_launch<4, true>(g, stream, batch);

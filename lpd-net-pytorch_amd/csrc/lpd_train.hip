@@ -22,35 +22,69 @@ __device__ __forceinline__ float act_grad(float pre, int act, float slope)
     return pre > 0.0f ? 1.0f : lpd_neg_slope(act, slope);
 }
 
+// the same with the sigmoid case resolved at compile time (SIG) and the negative-side slope formed once (ns = lpd_neg_slope(act, slope)):
+// as a run-time test per element the uniform branch splits every element of an unrolled loop into its own basic block
+template <bool SIG>
+__device__ __forceinline__ float act_grad_t(float pre, float ns)
+{
+    if constexpr (SIG) {
+        const float s = lpd_sigmoid(pre);
+        return s * (1.0f - s);
+    } else {
+        return pre > 0.0f ? 1.0f : ns;
+    }
+}
+
+// The last step of the column-reduction kernels: thread (o, rg) holds V partial sums for each of two output arrays (channels o V + e), the
+// block adds its RG row groups and sends one fp64 atomic per channel and array.  Laid out so that consecutive LANES own consecutive
+// CHANNELS: an atomic instruction of a wave then touches 4 cache lines -- issued by the thread that holds the partials (lanes V doubles
+// apart) it touched 32 (V = 4) or 64 (V = 8) lines with one or two live lanes each, 2048 single-lane line operations per block.
+template <int V>
+__device__ __forceinline__ void col_reduce_atomics(double* red /* [2 V][256] */, const double (&a)[V], const double (&b)[V], int O, int C,
+                                                   double* __restrict__ out_a, double* __restrict__ out_b)
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < V; ++e) { red[e * 256 + tid] = a[e]; red[(V + e) * 256 + tid] = b[e]; }
+    __syncthreads();
+    const int RG = 256 / O;
+    for (int j = tid; j < 2 * C; j += 256) {
+        const int half = j >= C, c = half ? j - C : j;
+        const int o = c / V, e = c % V;
+        const double* src = red + ((half ? V : 0) + e) * 256 + o;
+        double v = 0.0;
+        for (int g = 0; g < RG; ++g) v += src[g * O];
+        atomicAdd((half ? out_b : out_a) + lpd_stat_rofs() + c, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // column statistics: sum and sum of squares over R rows.  C/4 <= 256 and 256 % (C/4) == 0.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ X, long long ld, long long R, int C,
                                                        double* __restrict__ sum, double* __restrict__ sumsq)
 {
-    __shared__ double red[256][8];
+    __shared__ double red[8 * 256];
     const int Q = C >> 2;
     const int RG = 256 / Q;
     const int q = threadIdx.x % Q, rg = threadIdx.x / Q;
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-    for (long long r = (long long)blockIdx.x * RG + rg; r < R; r += (long long)gridDim.x * RG) {
-        const float4 v = *reinterpret_cast<const float4*>(X + r * ld + q * 4);
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-        ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y; ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
-    }
+    // four rows per trip, summed in fp32; the trips in fp64 (an fp64 add + fma per element bound the kernel: 2.4 TB/s on the conv3 map)
+    const long long S = (long long)gridDim.x * RG;
+    for (long long r = (long long)blockIdx.x * RG + rg; r < R; r += 4 * S) {
+        float4 v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s[e]; red[threadIdx.x][4 + e] = ss[e]; }
-    __syncthreads();
-    if (rg == 0) {
-        for (int g = 1; g < RG; ++g)
+        for (int u = 0; u < 4; ++u) v[u] = r + u * S < R ? *reinterpret_cast<const float4*>(X + (r + u * S) * ld + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float p[4] = {0, 0, 0, 0}, pp[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[q][e] += red[g * Q + q][e];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            atomicAdd(&sum[lpd_stat_rofs() + q * 4 + e], red[q][e]);
-            atomicAdd(&sumsq[lpd_stat_rofs() + q * 4 + e], red[q][4 + e]);
+        for (int u = 0; u < 4; ++u) {
+            p[0] += v[u].x; p[1] += v[u].y; p[2] += v[u].z; p[3] += v[u].w;
+            pp[0] += v[u].x * v[u].x; pp[1] += v[u].y * v[u].y; pp[2] += v[u].z * v[u].z; pp[3] += v[u].w * v[u].w;
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += p[e]; ss[e] += pp[e]; }
     }
+    col_reduce_atomics<4>(red, s, ss, Q, C, sum, sumsq);
 }
 
 // mean / biased var -> scale, shift, mean, invstd; running-stat update (momentum, unbiased var)
@@ -112,6 +146,7 @@ __global__ void affine_act_kernel(const float* __restrict__ X, long long ldx, fl
 }
 
 // backward reductions of  Y = act(scale * X + shift):  dbeta = sum dpre, dgamma = sum dpre * xhat
+template <bool SIG>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ dY, long long lddy,
                                                                 const float* __restrict__ X, long long ldx, long long R,
                                                                 int C, const float* __restrict__ scale,
@@ -120,7 +155,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
                                                                 const float* __restrict__ invstd, int act, float slope,
                                                                 double* __restrict__ dbeta, double* __restrict__ dgamma)
 {
-    __shared__ double red[256][8];
+    const float ns = lpd_neg_slope(act, slope);
+    __shared__ double red[8 * 256];
     const int Q = C >> 2;
     const int RG = 256 / Q;
     const int q = threadIdx.x % Q, rg = threadIdx.x / Q;
@@ -131,35 +167,39 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
         if (mean) { mu[e] = mean[q * 4 + e]; is[e] = invstd[q * 4 + e]; }
     }
     double sb[4] = {0, 0, 0, 0}, sg[4] = {0, 0, 0, 0};
-    for (long long r = (long long)blockIdx.x * RG + rg; r < R; r += (long long)gridDim.x * RG) {
-        const float4 xv = *reinterpret_cast<const float4*>(X + r * ldx + q * 4);
-        const float4 gv = *reinterpret_cast<const float4*>(dY + r * lddy + q * 4);
-        const float x[4] = {xv.x, xv.y, xv.z, xv.w};
-        const float g[4] = {gv.x, gv.y, gv.z, gv.w};
+    // four rows per trip: eight 16-byte loads in flight, the four rows summed in fp32 and the trips in fp64 (with an fp64 add and an fp64
+    // fma per element the kernel was bound by them: 378 us for the 1.5 GB of the conv3 map)
+    const long long S = (long long)gridDim.x * RG;
+    for (long long r = (long long)blockIdx.x * RG + rg; r < R; r += 4 * S) {
+        float4 xv[4], gv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float dpre = g[e] * act_grad(sc[e] * x[e] + sh[e], act, slope);
-            sb[e] += dpre;
-            sg[e] += (double)dpre * ((x[e] - mu[e]) * is[e]);
+        for (int u = 0; u < 4; ++u) {
+            const long long ru = r + u * S < R ? r + u * S : R - 1;       // past the end: a valid row, its gradient zeroed below
+            xv[u] = *reinterpret_cast<const float4*>(X + ru * ldx + q * 4);
+            gv[u] = *reinterpret_cast<const float4*>(dY + ru * lddy + q * 4);
         }
-    }
+        float pb[4] = {0, 0, 0, 0}, pg[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = sb[e]; red[threadIdx.x][4 + e] = sg[e]; }
-    __syncthreads();
-    if (rg == 0) {
-        for (int g = 1; g < RG; ++g)
+        for (int u = 0; u < 4; ++u) {
+            const float live = r + u * S < R ? 1.0f : 0.0f;
+            const float x[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            const float g[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[q][e] += red[g * Q + q][e];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            atomicAdd(&dbeta[lpd_stat_rofs() + q * 4 + e], red[q][e]);
-            atomicAdd(&dgamma[lpd_stat_rofs() + q * 4 + e], red[q][4 + e]);
+            for (int e = 0; e < 4; ++e) {
+                const float dpre = live * g[e] * act_grad_t<SIG>(sc[e] * x[e] + sh[e], ns);
+                pb[e] += dpre;
+                pg[e] += dpre * ((x[e] - mu[e]) * is[e]);
+            }
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sb[e] += pb[e]; sg[e] += pg[e]; }
     }
+    col_reduce_atomics<4>(red, sb, sg, Q, C, dbeta, dgamma);
 }
 
 // dX = scale * (dpre - dbeta/R - xhat * dgamma/R)   (has_bn)   or   dX = dpre   (no BN).  In-place on dY allowed.
 // Per-column constants (incl. the two fp64 means) are formed once per thread: see affine_act_kernel.
+template <bool SIG>
 __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dY, long long lddy, const float* __restrict__ X,
                                         long long ldx, float* __restrict__ dX, long long lddx, long long R, int C,
                                         const float* __restrict__ scale, const float* __restrict__ shift,
@@ -167,6 +207,7 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dY, long long 
                                         const double* __restrict__ dbeta, const double* __restrict__ dgamma,
                                         double count, int act, float slope, int has_bn)
 {
+    const float ns = lpd_neg_slope(act, slope);
     const int Q = C >> 2;
     const long long total = R * Q;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -197,10 +238,130 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dY, long long 
         float o[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float dpre = g[c] * act_grad(sc[c] * x[c] + sh[c], act, slope);
+            const float dpre = g[c] * act_grad_t<SIG>(sc[c] * x[c] + sh[c], ns);
             o[c] = has_bn ? sc[c] * (dpre - mb[c] - (x[c] - mu[c]) * is[c] * mg[c]) : dpre;
         }
         *reinterpret_cast<float4*>(dX + r * lddx + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// The same two passes on bf16 tensors (the bf16-storage training mode keeps the conv3 map -- y3, its gradient -- in bf16): eight channels
+// (16 bytes) per thread; the arithmetic is the fp32 kernels' on the widened values, the result is rounded once on the way out.
+__device__ __forceinline__ void bf16x8_widen(const uint4& w, float (&v)[8])
+{
+    const unsigned u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { v[2 * p] = __uint_as_float(u[p] << 16); v[2 * p + 1] = __uint_as_float(u[p] & 0xffff0000u); }
+}
+
+// Four rows per thread and trip (eight 16-byte loads in flight): at 101 registers / 32 KiB of LDS the kernel holds half the waves of the fp32
+// one; with one row per trip and an fp64 add + fma per element it ran at 1.55 TB/s (bound by the fp64 operations).  sum dpre xhat is formed as invstd (sum dpre x - mean sum dpre) from fp64 sums.
+template <bool SIG>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce16_kernel(const uint16_t* __restrict__ dY, long long lddy, const uint16_t* __restrict__ X,
+                                                                  long long ldx, long long R, int C, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, int act, float slope,
+                                                                  double* __restrict__ dbeta, double* __restrict__ dgamma)
+{
+    const float ns = lpd_neg_slope(act, slope);
+    __shared__ double red[16 * 256];
+    const int O = C >> 3;
+    const int RG = 256 / O;
+    const int o = threadIdx.x % O, rg = threadIdx.x / O;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = scale ? scale[o * 8 + e] : 1.0f; sh[e] = scale ? shift[o * 8 + e] : 0.0f; }
+    double sb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long S = (long long)gridDim.x * RG;
+    for (long long r = (long long)blockIdx.x * RG + rg; r < R; r += 4 * S) {
+        uint4 xw[4], gw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long ru = r + u * S < R ? r + u * S : R - 1;       // past the end: a valid row, its gradient zeroed below
+            xw[u] = *reinterpret_cast<const uint4*>(X + ru * ldx + o * 8);
+            gw[u] = *reinterpret_cast<const uint4*>(dY + ru * lddy + o * 8);
+        }
+        // the four rows are summed in fp32, the trips in fp64 (one fp64 add per four elements: the kernel was bound by them)
+        float pb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float x[8], g[8];
+            bf16x8_widen(xw[u], x);
+            bf16x8_widen(gw[u], g);
+            const float live = r + u * S < R ? 1.0f : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float dpre = live * g[e] * act_grad_t<SIG>(sc[e] * x[e] + sh[e], ns);
+                pb[e] += dpre;
+                pg[e] += dpre * x[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sb[e] += pb[e]; sg[e] += pg[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float mu = mean ? mean[o * 8 + e] : 0.0f, is = mean ? invstd[o * 8 + e] : 1.0f;
+        sg[e] = (sg[e] - (double)mu * sb[e]) * (double)is;
+    }
+    col_reduce_atomics<8>(red, sb, sg, O, C, dbeta, dgamma);
+}
+
+template <bool SIG>
+__global__ void bn_act_bwd_apply16_kernel(const uint16_t* __restrict__ dY, long long lddy, const uint16_t* __restrict__ X, long long ldx,
+                                          uint16_t* __restrict__ dX, long long lddx, long long R, int C, const float* __restrict__ scale,
+                                          const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                          const double* __restrict__ dbeta, const double* __restrict__ dgamma, double count, int act, float slope,
+                                          int has_bn)
+{
+    const float ns = lpd_neg_slope(act, slope);
+    const int O = C >> 3;
+    const long long total = R * O;
+    const long long stride = (long long)gridDim.x * blockDim.x;      // (C / 8 divides 256: a thread keeps its channels)
+    const long long e0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int o = (int)(e0 % O);
+    // dX = a dpre + b x + c per channel:  a = scale, b = -scale invstd mg, c = -scale (mb - mean invstd mg)   (no BN: a = 1, b = c = 0)
+    float sc[8], sh[8], ka[8], kb[8], kc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = o * 8 + c;
+        sc[c] = scale ? scale[ch] : 1.0f;
+        sh[c] = scale ? shift[ch] : 0.0f;
+        const float mu = has_bn ? mean[ch] : 0.0f, is = has_bn ? invstd[ch] : 1.0f;
+        const float mb = has_bn ? (float)(dbeta[ch] / count) : 0.0f, mg = has_bn ? (float)(dgamma[ch] / count) : 0.0f;
+        ka[c] = has_bn ? sc[c] : 1.0f;
+        kb[c] = has_bn ? -sc[c] * is * mg : 0.0f;
+        kc[c] = has_bn ? -sc[c] * (mb - mu * is * mg) : 0.0f;
+    }
+    for (long long e = e0; e < total; e += 4 * stride) {
+        uint4 xw[4], gw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long eu = e + u * stride < total ? e + u * stride : e;
+            const long long r = eu / O;
+            xw[u] = *reinterpret_cast<const uint4*>(X + r * ldx + o * 8);
+            gw[u] = *reinterpret_cast<const uint4*>(dY + r * lddy + o * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (e + u * stride >= total) break;
+            float x[8], g[8];
+            bf16x8_widen(xw[u], x);
+            bf16x8_widen(gw[u], g);
+            unsigned w[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float v[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int c = 2 * p + q;
+                    const float dpre = g[c] * act_grad_t<SIG>(sc[c] * x[c] + sh[c], ns);
+                    v[q] = ka[c] * dpre + kb[c] * x[c] + kc[c];
+                }
+                w[p] = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16);
+            }
+            *reinterpret_cast<uint4*>(dX + ((e + u * stride) / O) * lddx + o * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
     }
 }
 
@@ -1050,13 +1211,37 @@ extern "C" int lpd_bn_act_bwd(const float* dY, long long lddy, const float* X, l
     const LpdStatWs ws = lpd_stat_arg(stat_ws);
     LPD_CHECK_ARG(ws.rep, "lpd_bn_act_bwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     const int RG = 256 / (C / 4);
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream), dY, lddy, X, ldx, R, C,
-                       scale, shift, has_bn ? mean : nullptr, has_bn ? invstd : nullptr, act, slope, ws.sum(), ws.sumsq());
+    hipLaunchKernelGGL(act == 3 ? bn_act_bwd_reduce_kernel<true> : bn_act_bwd_reduce_kernel<false>, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream),
+                       dY, lddy, X, ldx, R, C, scale, shift, has_bn ? mean : nullptr, has_bn ? invstd : nullptr, act, slope, ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_bn_act_bwd(reduce)");
     if (int rc = lpd_stat_finish(ws, dbeta, dgamma, C, ST(stream))) return rc;
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(R * (C / 4), 256 * 4)), dim3(256), 0, ST(stream), dY, lddy, X,
+    hipLaunchKernelGGL(act == 3 ? bn_act_bwd_apply_kernel<true> : bn_act_bwd_apply_kernel<false>, dim3(grid_for(R * (C / 4), 256 * 4)), dim3(256), 0, ST(stream), dY, lddy, X,
                        ldx, dX, lddx, R, C, scale, shift, mean, invstd, dbeta, dgamma, (double)R, act, slope, has_bn);
     LPD_CHECK_LAUNCH("lpd_bn_act_bwd(apply)");
+    return LPD_OK;
+}
+
+// lpd_bn_act_bwd on bf16 tensors (dY, X, dX: [R][ld] bf16 elements, ld % 8 == 0, C a power of two in 8..2048); dX may alias dY.
+extern "C" int lpd_bn_act_bwd_bf16(const void* dY, long long lddy, const void* X, long long ldx, void* dX, long long lddx, long long R, int C,
+                                   const float* scale, const float* shift, const float* mean, const float* invstd, int act, float slope,
+                                   int has_bn, double* dbeta, double* dgamma, double* stat_ws, void* stream)
+{
+    LPD_CHECK_ARG(dY && X && dX && dbeta && dgamma && R > 0, "lpd_bn_act_bwd_bf16: bad arguments");
+    LPD_CHECK_ARG(C >= 8 && C <= 2048 && (C & (C - 1)) == 0 && lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 &&
+                      (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dX) & 15) == 0, "lpd_bn_act_bwd_bf16: C=%d / leading dims / alignment unsupported", C);
+    LPD_CHECK_ARG(!has_bn || (scale && shift && mean && invstd), "lpd_bn_act_bwd_bf16: BatchNorm form needs scale/shift/mean/invstd");
+    const LpdStatWs ws = lpd_stat_arg(stat_ws);
+    LPD_CHECK_ARG(ws.rep, "lpd_bn_act_bwd_bf16: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
+    const int RG = 256 / (C / 8);
+    hipLaunchKernelGGL(act == 3 ? bn_act_bwd_reduce16_kernel<true> : bn_act_bwd_reduce16_kernel<false>, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream), reinterpret_cast<const uint16_t*>(dY), lddy,
+                       reinterpret_cast<const uint16_t*>(X), ldx, R, C, scale, shift, has_bn ? mean : nullptr, has_bn ? invstd : nullptr, act, slope,
+                       ws.sum(), ws.sumsq());
+    LPD_CHECK_LAUNCH("lpd_bn_act_bwd_bf16(reduce)");
+    if (int rc = lpd_stat_finish(ws, dbeta, dgamma, C, ST(stream))) return rc;
+    hipLaunchKernelGGL(act == 3 ? bn_act_bwd_apply16_kernel<true> : bn_act_bwd_apply16_kernel<false>, dim3(grid_for(R * (C / 8), 256 * 4)), dim3(256), 0, ST(stream), reinterpret_cast<const uint16_t*>(dY),
+                       lddy, reinterpret_cast<const uint16_t*>(X), ldx, reinterpret_cast<uint16_t*>(dX), lddx, R, C, scale, shift, mean, invstd, dbeta,
+                       dgamma, (double)R, act, slope, has_bn);
+    LPD_CHECK_LAUNCH("lpd_bn_act_bwd_bf16(apply)");
     return LPD_OK;
 }
 

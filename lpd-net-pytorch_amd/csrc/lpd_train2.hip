@@ -775,11 +775,13 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint16_t* __res
 // (split over grid.z); per 64-row chunk a thread loads an 8 x 8 fp32 patch (sixteen 16-byte loads, requested one chunk
 // ahead), converts it to packed bf16 hi / lo pairs, transposes both in registers (v_perm_b32) and writes sixteen 16-byte
 // channel pieces into four [channel][row] LDS images.
-template <int KBT>
+template <int KBT, bool ABF16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B,
                                                          long long ldb, float* __restrict__ slabs, long long M, int KA, int KB,
                                                          long long rows_per_split, int nsplit, long long sA, long long sB)
 {
+    // ABF16: A holds bf16 rows (lda / sA in bf16 elements): its patches ARE the hi image, there is no lo image and the a_lo b_hi product
+    // is skipped (the bf16-storage training mode's conv3-map tensors: pooling, the assignment and conv3 weight gradients)
     constexpr int CH = 64, LDT = CH + 8;
     constexpr int TB = KBT / 32;               // output tiles along b; 4 along a
     constexpr int TPW = TB;                    // tiles per wave: wave w owns a-tile w, all b-tiles
@@ -796,6 +798,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float* __restr
     const int lin = lpd_xcd_remap(blockIdx.x, gridDim.x);
     const int tile = lin % (ntile_a * ntile_b), zall = lin / (ntile_a * ntile_b);      // zall = batch * nsplit + split
     const int zsplit = zall % nsplit, zb = zall / nsplit;
+    const uint16_t* A16 = reinterpret_cast<const uint16_t*>(A) + (long long)zb * sA;
     A += (long long)zb * sA;
     B += (long long)zb * sB;
     const int a0 = (tile % ntile_a) * 128, b0 = (tile / ntile_a) * KBT;
@@ -813,6 +816,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float* __restr
     uint16_t* dlo = (isA ? al : bl) + (c8 * 8) * LDT + swz;
     float4 pr[16];
     auto load_patch = [&](long long m0) {
+        if (ABF16 && isA) {           // wave-uniform: eight bf16 values = one 16-byte piece per row, kept as raw bits
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long long m = m0 + rg * 8 + i;
+                pr[2 * i] = m < m_end ? *reinterpret_cast<const float4*>(A16 + a0 + c8 * 8 + m * lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+                pr[2 * i + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const long long m = m0 + rg * 8 + i;
@@ -825,6 +837,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float* __restr
         if (!active) return;
         // one channel pair at a time (its eight rows converted, transposed, written): 16 temporaries live instead of 64 -- with all
         // four pairs converted first the <128> kernel needed 264 registers, i.e. ONE block per CU
+        if (ABF16 && isA) {                    // wave-uniform: the rows are the hi image already (word p of a row = channels 2p, 2p+1)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                uint32_t wh[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 q = pr[2 * i];
+                    wh[i] = __float_as_uint(p == 0 ? q.x : p == 1 ? q.y : p == 2 ? q.z : q.w);
+                }
+                uint4 lo, hi;
+                lo.x = __builtin_amdgcn_perm(wh[1], wh[0], 0x05040100u); hi.x = __builtin_amdgcn_perm(wh[1], wh[0], 0x07060302u);
+                lo.y = __builtin_amdgcn_perm(wh[3], wh[2], 0x05040100u); hi.y = __builtin_amdgcn_perm(wh[3], wh[2], 0x07060302u);
+                lo.z = __builtin_amdgcn_perm(wh[5], wh[4], 0x05040100u); hi.z = __builtin_amdgcn_perm(wh[5], wh[4], 0x07060302u);
+                lo.w = __builtin_amdgcn_perm(wh[7], wh[6], 0x05040100u); hi.w = __builtin_amdgcn_perm(wh[7], wh[6], 0x07060302u);
+                *reinterpret_cast<uint4*>(dhi + (2 * p) * LDT) = lo;
+                *reinterpret_cast<uint4*>(dhi + (2 * p + 1) * LDT) = hi;
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             uint32_t wh[8], wl[8];             // row i: packed bf16 (channel 2p | channel 2p+1 << 16)
@@ -874,7 +905,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float* __restr
                 const int ob = cb * LDT + (((s * 2 + h) ^ (cb >> 4)) & 7) * 8;
                 const bf16x8 bvh = *reinterpret_cast<const bf16x8*>(bh + ob);
                 const bf16x8 bvl = *reinterpret_cast<const bf16x8*>(bl + ob);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl, bvh, acc[j], 0, 0, 0);
+                if constexpr (!ABF16) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl, bvh, acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avh, bvl, acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avh, bvh, acc[j], 0, 0, 0);
             }
@@ -899,10 +930,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float* __restr
 // of 8 lanes = 4 row groups x 2 channel quads 576 bytes apart covers 128 contiguous bytes of banks), ONE barrier per chunk:
 // while the MFMAs of chunk n read one half, the same waves convert chunk n+1 (requested a whole iteration earlier) and write
 // it to the other half, and request chunk n+2.  All loads are unconditional (M % 32 == 0, ranges of whole chunks).
+template <bool ABF16>
 __global__ __launch_bounds__(512, 2) void gemm_tn_x3_256_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B,
                                                                 long long ldb, float* __restrict__ slabs, int KA, int KB,
                                                                 long long rows_per_split, long long M)
 {
+    // ABF16: A holds bf16 rows (lda in bf16 elements): hi image only, the a_lo b_hi product skipped (cf. gemm_tn_x3_kernel)
     constexpr int LDB = 144;                       // bytes per channel row of an image
     extern __shared__ __attribute__((aligned(16))) unsigned char tn3_lds[];
     unsigned char* const img_hi = tn3_lds;                  // [512 channels: A 0..255, B 256..511][144]
@@ -919,9 +952,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_x3_256_kernel(const float* __r
     // this thread's patch: 8 rows (row group rg) x 4 channels (quad); waves 0..3 stage A, waves 4..7 stage B
     const int rg = tid & 3, quad = tid >> 2;
     const bool isA = quad < 64;
+    const bool raw = ABF16 && isA;                 // wave-uniform (waves 0..3 stage A)
     const float* src = isA ? A + a0 + quad * 4 : B + b0 + (quad - 64) * 4;
     const long long ldsrc = isA ? lda : ldb;
     src += (m_begin + rg * 8) * ldsrc;
+    const uint16_t* src16 = reinterpret_cast<const uint16_t*>(A) + a0 + quad * 4 + (m_begin + rg * 8) * lda;
     const long long chunk_step = 32 * ldsrc;
     const int wr_off = (quad * 4) * LDB + rg * 16;             // + 64 * half + channel * 144
     const int wa = wave & 3, wb = wave >> 2;                  // wave's tiles: A channels 64 wa .. +63, B channels 128 wb .. +127
@@ -938,9 +973,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_x3_256_kernel(const float* __r
 
     float4 r0[8], r1[8];
     auto load = [&](float4 (&r)[8], int chunk) {
-        const float* p = src + (long long)chunk * chunk_step;
+        if (ABF16 && raw) {                        // four bf16 values per row piece, kept as raw bits in .x / .y
+            const uint16_t* p16 = src16 + (long long)chunk * 32 * lda;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = *reinterpret_cast<const float4*>(p + i * ldsrc);
+            for (int i = 0; i < 8; ++i) {
+                const uint2 w = *reinterpret_cast<const uint2*>(p16 + i * lda);
+                r[i] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), 0.0f, 0.0f);
+            }
+        } else {
+            const float* p = src + (long long)chunk * chunk_step;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = *reinterpret_cast<const float4*>(p + i * ldsrc);
+        }
     };
     // conversion of a patch in eight pieces (channel pair p = piece / 4: rows 0..3, rows 4..7, the two hi stores, the two lo stores)
     uint32_t wh[8], wl[8];
@@ -951,10 +995,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_x3_256_kernel(const float* __r
             for (int i = 4 * sub; i < 4 * sub + 4; ++i) {
                 const float v0 = p ? r[i].z : r[i].x, v1 = p ? r[i].w : r[i].y;
                 const uint32_t hp = pack_bf16(v0, v1);
-                wh[i] = hp;
+                wh[i] = (ABF16 && raw) ? __float_as_uint(p ? r[i].y : r[i].x) : hp;
                 wl[i] = pack_bf16(v0 - __uint_as_float(hp << 16), v1 - __uint_as_float(hp & 0xffff0000u));
             }
         } else {
+            if (ABF16 && raw && sub == 3) return;  // no lo image
             const uint32_t* w = sub == 2 ? wh : wl;
             uint4 e, o;                            // even / odd channel of the pair: rows 0..7 as four dwords
             e.x = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u); o.x = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
@@ -995,7 +1040,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_x3_256_kernel(const float* __r
             if (step < 7) read_b(sl ^ 1, half, (step + 1) >> 2, (step + 1) & 3);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[sl], acc[i][j], 0, 0, 0);
+                if constexpr (!ABF16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[sl], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[sl], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[sl], acc[i][j], 0, 0, 0);
             }
@@ -1413,13 +1458,14 @@ extern "C" long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB, int batc
     return gemm_tn_splits(M, KA, KB, batch) * batch * KA * KB;
 }
 
-extern "C" int lpd_gemm_tn(const float* A, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
-                           int batch, long long sA, long long sB, void* stream_)
+extern "C" int lpd_gemm_tn(const void* A_, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
+                           int batch, long long sA, long long sB, int a_bf16, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    const float* A = reinterpret_cast<const float*>(A_);      // a_bf16: bf16 rows (lda, sA in bf16 elements)
     LPD_CHECK_ARG(A && B && dW && ws && M > 0 && batch >= 1, "lpd_gemm_tn: bad arguments");
     LPD_CHECK_ARG(KA > 0 && KA % 128 == 0 && KB > 0 && KB % 64 == 0, "lpd_gemm_tn: KA %% 128 and KB %% 64 required (KA=%d KB=%d)", KA, KB);
-    LPD_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && sA % 4 == 0 && sB % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
+    LPD_CHECK_ARG(lda % (a_bf16 ? 8 : 4) == 0 && ldb % 4 == 0 && sA % (a_bf16 ? 8 : 4) == 0 && sB % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
                   "lpd_gemm_tn: operands must be 16-byte aligned rows");
     const long long splits = gemm_tn_splits(M, KA, KB, batch);
     long long rps = (M + splits - 1) / splits;
@@ -1427,8 +1473,13 @@ extern "C" int lpd_gemm_tn(const float* A, long long lda, const float* B, long l
     if (gemm_tn_256(M, KA, KB, batch)) {
         const long long blocks = (long long)(KA / 256) * (KB / 256) * splits;
         constexpr int lds = 2 * 512 * 144;
-        (void)hipFuncSetAttribute((const void*)gemm_tn_x3_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(gemm_tn_x3_256_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, A, lda, B, ldb, ws, KA, KB, rps, M);
+        if (a_bf16) {
+            (void)hipFuncSetAttribute((const void*)gemm_tn_x3_256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL(gemm_tn_x3_256_kernel<true>, dim3((unsigned)blocks), dim3(512), lds, stream, A, lda, B, ldb, ws, KA, KB, rps, M);
+        } else {
+            (void)hipFuncSetAttribute((const void*)gemm_tn_x3_256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL(gemm_tn_x3_256_kernel<false>, dim3((unsigned)blocks), dim3(512), lds, stream, A, lda, B, ldb, ws, KA, KB, rps, M);
+        }
         LPD_CHECK_LAUNCH("lpd_gemm_tn(256)");
         const int n = KA * KB;
         hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, stream, (const float*)ws, dW, n, (int)splits);
@@ -1438,8 +1489,10 @@ extern "C" int lpd_gemm_tn(const float* A, long long lda, const float* B, long l
     const int kbt = KB % 128 == 0 ? 128 : 64;
     const long long blocks = (long long)(KA / 128) * (KB / kbt) * splits * batch;
     LPD_CHECK_ARG(blocks < (1ll << 31), "lpd_gemm_tn: too many blocks");
-    if (kbt == 128) hipLaunchKernelGGL((gemm_tn_x3_kernel<128>), dim3((unsigned)blocks), dim3(256), 0, stream, A, lda, B, ldb, ws, M, KA, KB, rps, (int)splits, sA, sB);
-    else hipLaunchKernelGGL((gemm_tn_x3_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, stream, A, lda, B, ldb, ws, M, KA, KB, rps, (int)splits, sA, sB);
+#define LPD_TN_LAUNCH(KBT_, AB_) hipLaunchKernelGGL((gemm_tn_x3_kernel<KBT_, AB_>), dim3((unsigned)blocks), dim3(256), 0, stream, A, lda, B, ldb, ws, M, KA, KB, rps, (int)splits, sA, sB)
+    if (kbt == 128) { if (a_bf16) LPD_TN_LAUNCH(128, true); else LPD_TN_LAUNCH(128, false); }
+    else { if (a_bf16) LPD_TN_LAUNCH(64, true); else LPD_TN_LAUNCH(64, false); }
+#undef LPD_TN_LAUNCH
     LPD_CHECK_LAUNCH("lpd_gemm_tn");
     const int n = KA * KB;
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, stream, (const float*)ws, dW, n, (int)splits);

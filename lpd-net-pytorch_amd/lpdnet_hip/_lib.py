@@ -37,7 +37,7 @@ SIGNATURES = {
     "lpd_gemm_prep_b_batch": [_c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_p, _c_p],
     "lpd_gemm_x3t_applies": [_c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_int],
     "lpd_gemm_x3t_rows_applies": [_c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll],
-    "lpd_gemm_x3t_rows": [_c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_ll, _c_ll, _c_ll,
+    "lpd_gemm_x3t_rows": [_c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_ll, _c_ll, _c_ll,
                           _c_p],
     "lpd_gemm_x3t": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_ll, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_x3w": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int,
@@ -49,9 +49,10 @@ SIGNATURES = {
                           _c_int, _c_f, _c_p, _c_p, _c_ll, _c_p],
     "lpd_softmax_affine_parts": [_c_p, _c_int, _c_ll, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_int, _c_p],
     "lpd_split_panels": [_c_p, _c_ll, _c_int, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_p],
-    "lpd_gemm_x3w_batched": [_c_p, _c_int, _c_p, _c_ll, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
-    "lpd_gemm_x3w_act": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_int, _c_int, _c_p],
-    "lpd_gemm_x3w_stats": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_p, _c_p],
+    "lpd_gemm_x3w_batched": [_c_p, _c_int, _c_int, _c_p, _c_ll, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "lpd_gemm_x3w_bf16a": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "lpd_gemm_x3w_act": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_int, _c_int, _c_int, _c_p],
+    "lpd_gemm_x3w_stats": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_p, _c_p],
     "lpd_retrieval_topk": [_c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_f64_to_f32": [_c_p, _c_p, _c_ll, _c_p],
     "lpd_best_pos_bwd": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p],
@@ -90,6 +91,8 @@ SIGNATURES = {
     "lpd_bn_finalize": [_c_p, _c_p, ctypes.c_double, _c_int, _c_p, _c_p, _c_p, _c_p, _c_f, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_affine_act": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p],
     "lpd_bn_act_bwd": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int,
+                       _c_p, _c_p, _c_p, _c_p],
+    "lpd_bn_act_bwd_bf16": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int,
                        _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_build": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_group_max": [_c_p, _c_ll, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p, _c_ll, _c_p, _c_ll, _c_int, _c_p],
@@ -140,7 +143,7 @@ SIGNATURES = {
     "lpd_edge_dw_sel_bf16_ws_bytes": [_c_ll],
     "lpd_gemm_tn_bf16": [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_tn_ws_floats": [_c_ll, _c_int, _c_int, _c_int],
-    "lpd_gemm_tn": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_p],
+    "lpd_gemm_tn": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_int, _c_p],
     "lpd_metric_loss": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_int, _c_int, _c_int,
                         _c_int, _c_f, _c_f, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
 }

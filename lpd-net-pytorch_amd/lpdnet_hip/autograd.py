@@ -163,6 +163,11 @@ TRAIN_STORAGES = ("f32", "bf16")
 TRAIN_STORAGE = "f32"
 
 
+# bf16 storage also keeps the [B N, 1024] conv3 map -- the raw conv3 output, its activated form and both gradients -- in bf16 where the
+# trunk hands the raw map to the NetVLAD head (PointNetVlad's train path, lpdnet_features_train(defer_act=True)); LPD_MAP_BF16=0: fp32 map
+MAP_BF16 = __import__("os").environ.get("LPD_MAP_BF16", "1") != "0"
+
+
 def set_train_storage(kind):
     """-> the previous setting"""
     global TRAIN_STORAGE
@@ -482,7 +487,12 @@ class _LPDNetTrainFn(torch.autograd.Function):
         if getattr(_LAST, "defer_act", False) and ops.gemm_act_applies(M, 64, net.conv3_lpd.weight.shape[0]):
             # PointNetVlad's train path: bn3 + act are applied by the NetVLAD assignment product's operand loader (ops.gemm_act), which
             # also writes the activated map; this Function hands the RAW conv3 output on, with the affine in _LAST.pending
-            y3, st3 = ops.linear_bn_stats(cat, w2d(net.conv3_lpd), net.bn3_lpd)
+            Co3 = net.conv3_lpd.weight.shape[0]
+            map16 = (bf16 and MAP_BF16 and ops.GEMM_TN and ops.linear_bn_stats_fused_applies(M, Co3, 512) and Co3 % 128 == 0 and Co3 <= 2048
+                     and (Co3 & (Co3 - 1)) == 0 and N % 128 == 0 and N >= 256 and M >= 16384 and ops.X3T_ROWS and ops.X3W_BATCHED)
+            # (the shapes every bf16-map kernel of the head is built for: pooling and weight gradients >= 4096 rows, the batched short
+            #  products >= 16384 rows over clouds of whole 128-row tiles; smaller steps keep the fp32 map)
+            y3, st3 = ops.linear_bn_stats(cat, w2d(net.conv3_lpd), net.bn3_lpd, out_bf16=map16)      # (bf16 storage: a bfloat16 tensor)
             feat = y3
             _LAST.pending = (st3.scale, st3.shift, act, slope)
         else:
@@ -513,8 +523,14 @@ class _LPDNetTrainFn(torch.autograd.Function):
         w2d = engine._w2d
         dfeat = dfeat.contiguous()
         # conv3 + bn3 (the incoming gradient buffer belongs to autograd: not modified in place)
-        dcat, dw3, dg3, db3 = _PointLayer.bwd(dfeat, S["cat"], w2d(net.conv3_lpd), S["y3"], S["st3"], act, slope,
-                                              inplace=False)
+        if S["y3"].dtype == torch.bfloat16:      # bf16 map (forward: map16): bf16 gradient in, bf16 dY3, two-product GEMMs on it
+            dy3, dg3, db3 = ops.bn_act_bwd_bf16(dfeat, S["y3"], S["st3"], act, slope)
+            dw3 = ops.gemm_tn(dy3, S["cat"])
+            dcat = ops.gemm_bf16a(dy3, w2d(net.conv3_lpd), b_kmajor=True)
+            del dy3
+        else:
+            dcat, dw3, dg3, db3 = _PointLayer.bwd(dfeat, S["cat"], w2d(net.conv3_lpd), S["y3"], S["st3"], act, slope,
+                                                  inplace=False)
         # SN1: x3 = max_k act(BN(P[nbr] + Q)), split form (closed-form sums over the edges, one pass over the transposed graph)
         dpq3 = torch.empty((M, 512), dtype=torch.float32, device=dfeat.device)    # both halves are fully written below
         pq3 = S["pq3"]
@@ -944,7 +960,7 @@ class _NetVLADTrainFn(torch.autograd.Function):
         dev = feat.device
         Bp = (B + 31) // 32 * 32                                    # rows padded so K = Bp weight-gradient GEMMs are legal
         if pending is not None:      # `feat` is the trunk's RAW conv3 output: bn3 affine + activation in the assignment's operand loader
-            feat, a0 = ops.gemm_act(feat.detach(), vlad.cluster_weights, *pending)
+            feat, a0 = ops.gemm_act(feat.detach(), vlad.cluster_weights, *pending, out_bf16=feat.dtype == torch.bfloat16)
             if engine.DEBUG_AUX is not None:      # test hook: the trunk's ACTIVATED output rows (PointNetVlad.forward records the raw ones otherwise)
                 engine.DEBUG_AUX["feat"] = feat
         else:
@@ -1042,7 +1058,7 @@ class _NetVLADTrainFn(torch.autograd.Function):
         rhs = torch.empty((B, E, 2 * K), dtype=torch.float32, device=dev)
         ops.affine_act(dvraw.view(B * E, K), None, None, ops.ACT_NONE, out=rhs.view(B * E, 2 * K)[:, :K])
         rhs[:, :, K:] = vlad.cluster_weights.detach()                              # parameter-sized broadcast (plumbing)
-        dfeat = ops.gemm(ada.view(B, N, 2 * K), rhs, a_kmajor=False, b_kmajor=False).view(M, E)
+        dfeat = ops.gemm(ada.view(B, N, 2 * K), rhs, a_kmajor=False, b_kmajor=False, out_bf16=feat.dtype == torch.bfloat16).view(M, E)
         ctx.saved = None
         return (None, None, None, None, dfeat, dwc, dcw2.view(1, E, K), dwh) + tuple(g_assign) + (dgam_h, dbet_h) + tuple(g_gate)
 

@@ -324,8 +324,12 @@ def consumer_sync(mark, *tensors):
 
 
 def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=None, act=ACT_NONE, slope=0.01,
-         out=None, splits=1, accumulate=False, exact=False, a_panels=False, out_panels=False):
+         out=None, splits=1, accumulate=False, exact=False, a_panels=False, out_panels=False, out_bf16=False):
     """Single (2-D) or batched (3-D) GEMM with fused epilogue.
+
+    out_bf16: the result is a bfloat16 tensor (built on the transposed short-reduction kernel only: lpd_gemm_x3t_rows).
+    A may be bfloat16 rows for the batched per-problem-weight product (lpd_gemm_x3w_batched) -- the bf16-storage training mode's
+    conv3-map tensors; every other combination raises.
 
     a_panels / out_panels: A / out are cloud-panel tensors [B, cols/8, N, 8] (the layout the cloud-resident K-agg kernel
     streams; see panels_empty / panels_to_rows) instead of row-major matrices.
@@ -333,7 +337,8 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
     A: [M,K] (a_kmajor False) or [K,M] (True); B: [K,N] (b_kmajor True) or [N,K] (False).
     3-D inputs add a leading batch dim (must be contiguous in that dim ordering).
     """
-    _req(A, "A")
+    a16 = isinstance(A, torch.Tensor) and A.dtype == torch.bfloat16
+    _req(A, "A", torch.bfloat16 if a16 else torch.float32)
     _req(B, "B")
     if a_panels or out_panels:
         return _gemm_panels(A, B, a_kmajor, b_kmajor, bias, scale, shift, act, slope, out, accumulate, exact, a_panels, out_panels)
@@ -346,16 +351,20 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
         sA, sB = A.stride(0), B.stride(0)
     else:
         nb, A2, B2, sA, sB = 1, A, B, 0, 0
-    lda, ldb = _rows(A2, "A"), _rows(B2, "B")
+    if a16 and (A2.dim() != 2 or A2.stride(1) != 1):
+        raise ValueError("gemm: bf16 A needs contiguous rows")
+    lda, ldb = A2.stride(0) if a16 else _rows(A2, "A"), _rows(B2, "B")
     M, K = (A2.shape[1], A2.shape[0]) if a_kmajor else (A2.shape[0], A2.shape[1])
     Kb, N = (B2.shape[0], B2.shape[1]) if b_kmajor else (B2.shape[1], B2.shape[0])
     if K != Kb:
         raise ValueError(f"gemm: inner dims differ ({K} vs {Kb})")
     if out is None:
-        out = torch.empty((nb, M, N) if batched else (M, N), dtype=torch.float32, device=A.device)
-    _req(out, "out")
+        out = torch.empty((nb, M, N) if batched else (M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=A.device)
+    _req(out, "out", torch.bfloat16 if out_bf16 else torch.float32)
     O2 = out[0] if batched else out
-    ldc = _rows(O2, "out")
+    if O2.dim() != 2 or O2.stride(1) != 1:
+        raise ValueError("gemm: out needs contiguous rows")
+    ldc = O2.stride(0)
     if O2.shape[0] != M or O2.shape[1] != N:
         raise ValueError("gemm: out has the wrong shape")
     sC = out.stride(0) if batched else 0
@@ -370,29 +379,34 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
     # (SN1 projection 142 vs 149 us, DG1 projection 52 vs 58 us), and k-major weights transpose in registers there.
     # a short reduction (K = 64 / 128) over many rows: the transposed product lpd_gemm_x3t_rows (data rows as the MFMA's B operand, one
     # barrier, float4 stores) -- the 128 x 128 block kernel spends it in barriers and 4-byte stores (SN1 projection of the training step 211 us)
-    if (GEMM_BF16X3 and X3T_ROWS and not exact and _EXACT.depth == 0 and _FAST.depth == 0 and not a_kmajor and splits == 1
+    if (GEMM_BF16X3 and X3T_ROWS and not exact and _EXACT.depth == 0 and (_FAST.depth == 0 or out_bf16) and not a_kmajor and splits == 1 and not a16
             and not accumulate and nb * M >= 16384 and nb <= 65535 and lib.lpd_gemm_x3t_rows_applies(M, N, K, act, lda, ldc)
-            and A.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and sA % 4 == 0 and sC % 4 == 0):
+            and A.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and sA % 4 == 0 and sC % (8 if out_bf16 else 4) == 0
+            and (not out_bf16 or ldc % 8 == 0)):
         if batched:      # per-problem weights (the NetVLAD backward's [a | dA0] . [dVraw_b | Wc]^T): their fragments, every call
             fb = int(lib.lpd_gemm_prep_b_bytes(N, K))
             frags = torch.empty((nb * fb,), dtype=torch.uint8, device=A.device)
             _call("gemm_prep_b", lib.lpd_gemm_prep_b_batch, _ptr(B), ldb, int(bool(b_kmajor)), N, K, nb, sB, _ptr(frags), _stream())
         else:
             fb, frags = 0, _weight_frags(B, b_kmajor, N, K)
-        _call(f"gemmx3t[{M}x{N}x{K}]" + (f"x{nb}" if batched else ""), lib.lpd_gemm_x3t_rows, _ptr(A), lda, _ptr(frags), _ptr(out), ldc, M, N, K,
-              _ptr(bias), _ptr(scale), _ptr(shift), act, float(slope), nb, sA, sC, fb, _stream())
+        _call(f"gemmx3t[{M}x{N}x{K}]" + (f"x{nb}" if batched else ""), lib.lpd_gemm_x3t_rows, _ptr(A), lda, _ptr(frags), _ptr(out), ldc,
+              int(bool(out_bf16)), M, N, K, _ptr(bias), _ptr(scale), _ptr(shift), act, float(slope), nb, sA, sC, fb, _stream())
         return out
+    if out_bf16:
+        raise ValueError(f"gemm: a bf16 result is built on the transposed short-reduction kernel only (M={M}, N={N}, K={K}, batch {nb})")
     if (GEMM_BF16X3 and X3W_BATCHED and batched and not exact and _EXACT.depth == 0 and not a_kmajor and b_kmajor and splits == 1 and not accumulate
             and bias is None and scale is None and act == ACT_NONE and M % 128 == 0 and nb * M >= 16384 and 64 <= N <= 128 and K >= 256
-            and N * K <= (1 << 22) and sA == M * lda and sC == M * ldc and nb * M < (1 << 31)):
+            and N * K <= (1 << 22) and sA == M * lda and sC == M * ldc and nb * M < (1 << 31) and (not a16 or (K % 32 == 0 and lda % 4 == 0))):
         # per-problem k-major weights over consecutive row ranges of one row-major A (NetVLAD backward: dA[b] = x[b] . dV[b]): the
         # prepared-fragment kernel with a fragment set per problem; the generic batched kernel ran this at 2.6 TB/s of the 738-MB operand
         fb = int(lib.lpd_gemm_prep_b_bytes(N, K))
         frags = torch.empty((nb * fb,), dtype=torch.uint8, device=A.device)
         _call("gemm_prep_b", lib.lpd_gemm_prep_b_batch, _ptr(B), ldb, 1, N, K, nb, sB, _ptr(frags), _stream())
-        _call(f"gemmx3w[{M}x{N}x{K}]x{nb}", lib.lpd_gemm_x3w_batched, _ptr(A), lda, _ptr(frags), fb, M, _ptr(out), ldc, nb * M, N, K,
-              16 if _FAST.depth > 0 else 0, _stream())
+        _call(f"gemmx3w[{M}x{N}x{K}]x{nb}", lib.lpd_gemm_x3w_batched, _ptr(A), lda, int(a16), _ptr(frags), fb, M, _ptr(out), ldc, nb * M, N, K,
+              16 if (_FAST.depth > 0 and not a16) else 0, _stream())
         return out
+    if a16:
+        raise ValueError(f"gemm: bf16 rows as A are built for the batched per-problem-weight product only (M={M}, N={N}, K={K}, batch {nb})")
     if (GEMM_BF16X3 and not exact and _EXACT.depth == 0 and not a_kmajor and not batched and splits == 1
             and M >= 1024 and N >= 64 and N * K <= (1 << 22)
             and ((b_kmajor and K >= 128) or (X3W_FORWARD and K >= 256))):
@@ -1004,25 +1018,32 @@ def bn_train_stats(X, bn, rows=None):
 STATS_IN_GEMM = os.environ.get("LPD_GEMM_STATS", "1") != "0"
 
 
-def linear_bn_stats(x, w, bn, bias=None):
+def linear_bn_stats_fused_applies(M, N, K):
+    return (STATS_IN_GEMM and GEMM_BF16X3 and _EXACT.depth == 0 and _FAST.depth == 0 and X3W_FORWARD
+            and M >= 1024 and N >= 64 and K >= 128 and N * K <= (1 << 22) and (K >= 256 or N >= 128))
+
+
+def linear_bn_stats(x, w, bn, bias=None, out_bf16=False):
     """(y, BNStats): y = x @ w.T (+ bias) raw and the train-mode statistics of `bn` over its rows (running stats updated).  Where the
     product runs on the prepared-fragment split-bf16 kernel (the policy of ops.gemm), the column sums come out of its epilogue
-    (lpd_gemm_x3w_stats) instead of a second pass over y (lpd_colstats); otherwise linear + bn_train_stats."""
+    (lpd_gemm_x3w_stats) instead of a second pass over y (lpd_colstats); otherwise linear + bn_train_stats.
+    out_bf16: y is stored as bfloat16 (the statistics are those of the fp32 accumulators); needs the fused kernel (N % 32 == 0)."""
     ldx = _rows(x, "x")
     _req(w, "w")
     w2 = w.reshape(w.shape[0], -1)
     M, K = x.shape
     N = w2.shape[0]
-    if (STATS_IN_GEMM and GEMM_BF16X3 and _EXACT.depth == 0 and _FAST.depth == 0 and X3W_FORWARD and w2.is_contiguous() and w2.shape[1] == K
-            and M >= 1024 and N >= 64 and K >= 128 and N * K <= (1 << 22) and (K >= 256 or N >= 128)):
+    if linear_bn_stats_fused_applies(M, N, K) and w2.is_contiguous() and w2.shape[1] == K and (not out_bf16 or N % 32 == 0):
         bias = _vec(bias, "bias", N)
         frags = _weight_frags(w2, False, N, K)
-        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        y = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
         sums = torch.empty((2, N), dtype=torch.float64, device=x.device)
         lib = _lib.load()
-        _call(f"gemmx3w+stats[{M}x{N}x{K}]", lib.lpd_gemm_x3w_stats, _ptr(x), ldx, _ptr(frags), _ptr(y), N, M, N, K, _ptr(bias), _ptr(sums[0]),
-              _ptr(sums[1]), X3W_IMPL, _stat_ws(), _stream())
+        _call(f"gemmx3w+stats[{M}x{N}x{K}]", lib.lpd_gemm_x3w_stats, _ptr(x), ldx, _ptr(frags), _ptr(y), N, int(bool(out_bf16)), M, N, K, _ptr(bias),
+              _ptr(sums[0]), _ptr(sums[1]), X3W_IMPL, _stat_ws(), _stream())
         return y, _bn_finalize(sums, M, N, bn)
+    if out_bf16:
+        raise ValueError(f"linear_bn_stats: a bf16 result needs the fused kernel (M={M}, N={N}, K={K})")
     y = linear(x, w, bias=bias)
     return y, bn_train_stats(y, bn)
 
@@ -1035,11 +1056,16 @@ def gemm_act_applies(M, N, K):
             and N * K <= (1 << 22))
 
 
-def gemm_act(x, w_kn, a_scale, a_shift, act, slope):
+def gemm_act(x, w_kn, a_scale, a_shift, act, slope, out_bf16=False):
     """(x_act, c): x_act = act(a_scale * x + a_shift) (rows [M, K]: the BatchNorm affine + activation of the layer in front, applied in
     the product's operand loader and stored on the way) and c = x_act @ w_kn for a k-major weight [K, N], N <= 128
-    (include/lpd_hip.h lpd_gemm_x3w_act: util/lpdnet_model.py:262 -> util/PointNetVlad.py:48)."""
-    ldx = _rows(x, "x")
+    (include/lpd_hip.h lpd_gemm_x3w_act: util/lpdnet_model.py:262 -> util/PointNetVlad.py:48).
+    x may be bfloat16 rows (K % 32 == 0); out_bf16: x_act is stored as bfloat16 and the product takes the stored (rounded) values."""
+    x16 = x.dtype == torch.bfloat16
+    _req(x, "x", torch.bfloat16 if x16 else torch.float32)
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("gemm_act: x needs contiguous rows")
+    ldx = x.stride(0)
     _req(w_kn, "w_kn")
     M, K = x.shape
     N = w_kn.shape[1]
@@ -1047,12 +1073,38 @@ def gemm_act(x, w_kn, a_scale, a_shift, act, slope):
         raise ValueError(f"gemm_act: shape not built (M={M}, N={N}, K={K})")
     a_scale, a_shift = _vec(a_scale, "a_scale", K), _vec(a_shift, "a_shift", K)
     frags = _weight_frags(w_kn, True, N, K)
-    x_act = torch.empty((M, K), dtype=torch.float32, device=x.device)
+    if x16 and (K % 32 != 0 or ldx % 4 != 0):
+        raise ValueError("gemm_act: bf16 rows need K % 32 == 0")
+    x_act = torch.empty((M, K), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     c = torch.empty((M, N), dtype=torch.float32, device=x.device)
     lib = _lib.load()
     _call(f"gemmx3w+act[{M}x{N}x{K}]", lib.lpd_gemm_x3w_act, _ptr(x), ldx, _ptr(frags), _ptr(c), N, M, N, K, None, _ptr(a_scale), _ptr(a_shift),
-          act, float(slope), _ptr(x_act), K, 16 if _FAST.depth > 0 else 0, _stream())
+          act, float(slope), _ptr(x_act), K, int(x16) | (2 if out_bf16 else 0), 16 if _FAST.depth > 0 else 0, _stream())
     return x_act, c
+
+
+def gemm_bf16a(A16, W, b_kmajor=True, out=None, accumulate=False):
+    """out [M, N] fp32 (+)= A16 @ W for bfloat16 rows A16 [M, K] (K % 32 == 0) and a weight W ([K, N] k-major or [N, K]): the rows are the hi
+    image of the split product, two MFMA products against the split weight (lpd_gemm_x3w_bf16a).  dX = dY W of the bf16-storage training
+    mode's conv3 backward (util/lpdnet_model.py:262)."""
+    _req(A16, "A16", torch.bfloat16)
+    _req(W, "W")
+    if A16.dim() != 2 or A16.stride(1) != 1 or A16.stride(0) % 4 != 0:
+        raise ValueError("gemm_bf16a: A16 needs contiguous rows")
+    M, K = A16.shape
+    Kb, N = (W.shape[0], W.shape[1]) if b_kmajor else (W.shape[1], W.shape[0])
+    if K != Kb or K % 32 != 0 or N * K > (1 << 22) or not GEMM_BF16X3:
+        raise ValueError(f"gemm_bf16a: shape not built (M={M}, N={N}, K={K}, inner {Kb})")
+    if out is None:
+        if accumulate:
+            raise ValueError("gemm_bf16a: accumulate needs out")
+        out = torch.empty((M, N), dtype=torch.float32, device=A16.device)
+    ldc = _rows(out, "out")
+    frags = _weight_frags(W, b_kmajor, N, K)
+    lib = _lib.load()
+    _call(f"gemmx2w[{M}x{N}x{K}]", lib.lpd_gemm_x3w_bf16a, _ptr(A16), A16.stride(0), _ptr(frags), _ptr(out), ldc, M, N, K, int(bool(accumulate)),
+          X3W_IMPL, _stream())
+    return out
 
 
 def _bn_finalize(sums, R, C, bn):
@@ -1112,6 +1164,26 @@ def bn_act_bwd(dY, X, st, act=ACT_NONE, slope=0.01, out=None, rows=None):
     lib = _lib.load()
     has_bn = st is not None
     _call("bn_act_bwd", lib.lpd_bn_act_bwd, _ptr(dY), lddy, _ptr(X), ldx, _ptr(out), lddx, R, C,
+          _ptr(st.scale) if has_bn else None, _ptr(st.shift) if has_bn else None, _ptr(st.mean) if has_bn else None,
+          _ptr(st.invstd) if has_bn else None, act, float(slope), int(has_bn), _ptr(red[0]), _ptr(red[1]), _stat_ws(), _stream())
+    redf = red.float()
+    return out, redf[1], redf[0]
+
+
+def bn_act_bwd_bf16(dY, X, st, act=ACT_NONE, slope=0.01, out=None):
+    """bn_act_bwd on bfloat16 tensors (dY, X, the result: [R, C] rows, C a power of two; lpd_bn_act_bwd_bf16): the arithmetic of the fp32
+    kernels on the widened values, one rounding on the way out.  out may alias dY."""
+    for t, n in ((dY, "dY"), (X, "X"), (out, "out")):
+        _req(t, n, torch.bfloat16)
+        if t is not None and (t.dim() != 2 or t.stride(1) != 1):
+            raise ValueError(f"bn_act_bwd_bf16: {n} needs contiguous rows")
+    R, C = X.shape
+    if out is None:
+        out = torch.empty((R, C), dtype=torch.bfloat16, device=X.device)
+    red = torch.empty((2, C), dtype=torch.float64, device=X.device)
+    lib = _lib.load()
+    has_bn = st is not None
+    _call("bn_act_bwd_bf16", lib.lpd_bn_act_bwd_bf16, _ptr(dY), dY.stride(0), _ptr(X), X.stride(0), _ptr(out), out.stride(0), R, C,
           _ptr(st.scale) if has_bn else None, _ptr(st.shift) if has_bn else None, _ptr(st.mean) if has_bn else None,
           _ptr(st.invstd) if has_bn else None, act, float(slope), int(has_bn), _ptr(red[0]), _ptr(red[1]), _stat_ws(), _stream())
     redf = red.float()
@@ -1599,17 +1671,23 @@ GEMM_TN = os.environ.get("LPD_GEMM_TN", "1") != "0"      # weight gradients on t
 
 def gemm_tn(A, B, rows=None):
     """dW [KA, KB] = A^T B over the (first `rows`) rows; A [M, KA], B [M, KB] fp32 row-major (column slices allowed);
-    KA % 128 == 0, KB % 64 == 0.  Split-bf16 (three products): the accuracy of lpd_gemm_bf16x3."""
+    KA % 128 == 0, KB % 64 == 0.  Split-bf16 (three products): the accuracy of lpd_gemm_bf16x3.  A may be bfloat16 rows (they are
+    the hi image: two products)."""
+    a16 = A.dtype == torch.bfloat16
+    if a16:
+        _req(A, "A", torch.bfloat16)
+        if A.stride(-1) != 1 or A.stride(-2) % 8 != 0:
+            raise ValueError("gemm_tn: bf16 A needs contiguous rows, leading dim % 8 == 0")
     if A.dim() == 3:      # batched: A [nb, M, KA], B [nb, M, KB] -> [nb, KA, KB]
         nb = A.shape[0]
-        lda, ldb = _rows(A[0], "A"), _rows(B[0], "B")
+        lda, ldb = A.stride(1) if a16 else _rows(A[0], "A"), _rows(B[0], "B")
         M, KA, KB, sA, sB = A.shape[1], A.shape[2], B.shape[2], A.stride(0), B.stride(0)
         if B.shape[0] != nb or B.shape[1] != M:
             raise ValueError("gemm_tn: batched operands must agree on batch and rows")
         shape = (nb, KA, KB)
     else:
         nb, sA, sB = 1, 0, 0
-        lda, ldb = _rows(A, "A"), _rows(B, "B")
+        lda, ldb = A.stride(0) if a16 else _rows(A, "A"), _rows(B, "B")
         M = A.shape[0] if rows is None else rows
         KA, KB = A.shape[1], B.shape[1]
         shape = (KA, KB)
@@ -1617,13 +1695,14 @@ def gemm_tn(A, B, rows=None):
     ws = torch.empty((int(lib.lpd_gemm_tn_ws_floats(M, KA, KB, nb)),), dtype=torch.float32, device=A.device)
     dW = torch.empty(shape, dtype=torch.float32, device=A.device)
     _call(f"gemm_tn[{KA}x{KB}x{M}]" + (f"x{nb}" if nb > 1 else ""), lib.lpd_gemm_tn, _ptr(A), lda, _ptr(B), ldb, _ptr(dW), _ptr(ws), M, KA,
-          KB, nb, sA, sB, _stream())
+          KB, nb, sA, sB, int(a16), _stream())
     return dW
 
 
 def gemm_tn_applies(A, B, rows):
     return (GEMM_TN and GEMM_BF16X3 and _EXACT.depth == 0 and A.dim() == 2 and B.dim() == 2 and A.shape[1] % 128 == 0
-            and B.shape[1] % 64 == 0 and rows >= 4096 and A.stride(1) == 1 and B.stride(1) == 1 and A.stride(0) % 4 == 0
+            and B.shape[1] % 64 == 0 and rows >= 4096 and A.stride(1) == 1 and B.stride(1) == 1
+            and A.stride(0) % (8 if A.dtype == torch.bfloat16 else 4) == 0
             and B.stride(0) % 4 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
 
 

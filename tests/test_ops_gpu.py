@@ -1338,3 +1338,96 @@ def test_gemm_x3w_batched_per_problem_weights(cuda):
     finally:
         ops.X3W_BATCHED = prev
     assert _rel(old, want) < 2e-5 and _rel(got, old) < 2e-5
+
+
+def test_bf16_map_operators(cuda):
+    """The bf16-storage training mode keeps the [B N, 1024] conv3 map, its activated form and both gradients as bfloat16
+    (autograd.MAP_BF16).  Every kernel that reads or writes them, against fp64 on the SAME (already rounded) bf16 inputs -- a bf16 row is
+    the hi image of the split product, so the products stay fp32-grade -- and the bf16 results within one rounding (2^-8 relative) of the
+    fp32 kernel's."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    bf = torch.bfloat16
+
+    def rounds_to(got16, want32):      # got is want rounded to bf16 (up to fp32 summation-order noise deciding a tie)
+        assert got16.dtype == bf
+        d = (got16.float() - want32).abs()
+        assert bool((d <= want32.abs() * 2.0 ** -8 + 1e-6).all()), float((d / (want32.abs() + 1e-6)).max())
+
+    # conv3 + statistics with a bf16 result (lpd_gemm_x3w_stats, c_bf16): statistics bit-identical to the fp32 launch's
+    M, K, N = 4096 + 128, 512, 1024
+    x = torch.randn(M, K, generator=g).to(cuda)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    bn_a, bn_b = torch.nn.BatchNorm1d(N).to(cuda), torch.nn.BatchNorm1d(N).to(cuda)
+    y32, st32 = ops.linear_bn_stats(x, w, bn_a)
+    y16, st16 = ops.linear_bn_stats(x, w, bn_b, out_bf16=True)
+    rounds_to(y16, y32)
+    assert torch.equal(st16.scale, st32.scale) and torch.equal(st16.shift, st32.shift) and torch.equal(bn_a.running_var, bn_b.running_var)
+
+    # assignment product with the affine + activation in the loader: bf16 rows in, bf16 activated rows out (lpd_gemm_x3w_act flags 3)
+    K2, N2 = 1024, 64
+    wc = (torch.randn(K2, N2, generator=g) / K2 ** 0.5).to(cuda)
+    sc, sh = (0.5 + torch.rand(K2, generator=g)).to(cuda), (0.3 * torch.randn(K2, generator=g)).to(cuda)
+    sc[::5] *= -1
+    for Mr in (4096, 1300):
+        xr = y16[:Mr]
+        xa16, c = ops.gemm_act(xr, wc, sc, sh, ops.ACT_LEAKY, 0.2, out_bf16=True)
+        ref_a = ops.affine_act(xr.float(), sc, sh, ops.ACT_LEAKY, 0.2)
+        assert torch.equal(xa16, ref_a.to(bf))                    # the same multiply-then-add, one rounding
+        assert _rel(c, xa16.double() @ wc.double()) < 2e-5        # the product takes the STORED values
+    feat16 = ops.gemm_act(y16, wc, sc, sh, ops.ACT_LEAKY, 0.2, out_bf16=True)[0]
+
+    # pooling / weight gradients with bf16 rows as A (lpd_gemm_tn a_bf16: 128-wide, 64-wide and 256 x 256 tiles, batched)
+    for KB in (64, 128, 512):
+        Bm = torch.randn(M, KB, generator=g).to(cuda)
+        got = ops.gemm_tn(feat16, Bm)
+        assert _rel(got, feat16.double().t() @ Bm.double()) < 2e-5
+        got_r = ops.gemm_tn(feat16, Bm, rows=M - 100)
+        assert _rel(got_r, feat16[:M - 100].double().t() @ Bm[:M - 100].double()) < 2e-5
+    M2 = 16384
+    big16 = torch.randn(M2, 1024, generator=g).to(cuda).to(bf)
+    Bm = torch.randn(M2, 512, generator=g).to(cuda)
+    assert _rel(ops.gemm_tn(big16, Bm), big16.double().t() @ Bm.double()) < 2e-5        # 256 x 256 tiles
+    A3, B3 = big16.view(4, 4096, 1024), Bm[:, :64].contiguous().view(4, 4096, 64)
+    assert _rel(ops.gemm_tn(A3, B3), torch.einsum("bma,bmc->bac", A3.double(), B3.double())) < 2e-5
+
+    # dA[b] = x[b] . dV[b] with bf16 rows (lpd_gemm_x3w_batched a_bf16) and dX = dY W (lpd_gemm_x3w_bf16a), fresh and accumulating
+    dV = (torch.randn(4, 1024, 64, generator=g) / 32).to(cuda)
+    got = ops.gemm(A3, dV, a_kmajor=False, b_kmajor=True)
+    assert got.dtype == torch.float32 and _rel(got, torch.bmm(A3.double(), dV.double())) < 2e-5
+    w3 = (torch.randn(1024, 512, generator=g) / 32).to(cuda)          # [Co, Kin]: dX = dY W, k-major for this product
+    dx = ops.gemm_bf16a(big16, w3, b_kmajor=True)
+    want = big16.double() @ w3.double()
+    assert _rel(dx, want) < 2e-5
+    base = torch.randn(M2, 512, generator=g).to(cuda)
+    acc = ops.gemm_bf16a(big16, w3, b_kmajor=True, out=base.clone(), accumulate=True)
+    assert _rel(acc, want + base.double()) < 2e-5
+
+    # the gradient of the map from the short batched product, stored as bf16 (lpd_gemm_x3t_rows c_bf16)
+    ada = torch.randn(4, 4096, 128, generator=g).to(cuda)
+    rhs = (torch.randn(4, 1024, 128, generator=g) / 11).to(cuda)
+    d32 = ops.gemm(ada, rhs, a_kmajor=False, b_kmajor=False)
+    d16 = ops.gemm(ada, rhs, a_kmajor=False, b_kmajor=False, out_bf16=True)
+    assert torch.equal(d16, d32.to(bf))                            # the same accumulators, one rounding
+
+    # BatchNorm + activation backward on bf16 tensors (lpd_bn_act_bwd_bf16) against the fp32 kernel on the widened inputs
+    dY16, X16 = d16.view(M2, 1024), big16
+    bn = torch.nn.BatchNorm1d(1024).to(cuda)
+    with torch.no_grad():
+        bn.weight.copy_(0.5 + torch.rand(1024, generator=g))
+        bn.weight[::7] *= -1
+        bn.bias.copy_(0.2 * torch.randn(1024, generator=g))
+    st = ops.bn_train_stats(X16.float(), bn)
+    for act in (ops.ACT_LEAKY, ops.ACT_RELU, ops.ACT_NONE):
+        dx16, dg16, db16 = ops.bn_act_bwd_bf16(dY16, X16, st, act, 0.2)
+        dx32, dg32, db32 = ops.bn_act_bwd(dY16.float(), X16.float(), st, act, 0.2)
+        assert _rel(dg16, dg32) < 1e-5 and _rel(db16, db32) < 1e-5
+        rounds_to(dx16, dx32)
+    inplace = dY16.clone()
+    ops.bn_act_bwd_bf16(inplace, X16, st, ops.ACT_LEAKY, 0.2, out=inplace)
+    assert torch.equal(inplace, ops.bn_act_bwd_bf16(dY16, X16, st, ops.ACT_LEAKY, 0.2)[0])
+    # what is not built says so
+    with pytest.raises(ValueError):
+        ops.gemm(ada, rhs.transpose(1, 2).contiguous(), a_kmajor=False, b_kmajor=True, out_bf16=True, splits=2)
+    with pytest.raises(ValueError):
+        ops.gemm(big16, w3, b_kmajor=True)
