@@ -1073,6 +1073,35 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_x3_256_kernel(const float* __r
             }
 }
 
+// the same sum with 16 slab groups per block (16 threads x 4 elements each; n % 64 == 0): with many slabs of a small product (256 x 64 over
+// 256 row ranges) one thread per element walked the 256 slabs one dependent load at a time
+__global__ __launch_bounds__(256) void gemm_tn_reduce16_kernel(const float* __restrict__ slabs, float* __restrict__ out, int n, int nslabs)
+{
+    __shared__ double red[16][16][4];
+    const int t = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int e = (blockIdx.x * 16 + t) * 4;
+    slabs += (size_t)blockIdx.y * nslabs * n;
+    double s[4] = {0, 0, 0, 0};
+    for (int b = grp; b < nslabs; b += 64) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = b + 16 * u < nslabs ? *reinterpret_cast<const float4*>(slabs + (size_t)(b + 16 * u) * n + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[grp][t][c] = s[c];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int tt = threadIdx.x >> 2, c = threadIdx.x & 3;
+        double v = 0.0;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) v += red[g2][tt][c];
+        out[(size_t)blockIdx.y * n + (blockIdx.x * 16 + tt) * 4 + c] = (float)v;
+    }
+}
+
 __global__ void gemm_tn_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int n, int nslabs)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;      // blockIdx.y = problem of a batch (its slabs are consecutive)
@@ -1426,10 +1455,172 @@ extern "C" int lpd_gemm_tn_bf16(const uint16_t* A, const uint16_t* B, float* dW,
     else hipLaunchKernelGGL((gemm_tn_bf16_kernel<64, 64>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, ws, M, rpb);
     LPD_CHECK_LAUNCH("lpd_gemm_tn_bf16");
     const int n = KA * KB;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)ws, dW, n, (int)blocks);
+    if (n % 64 == 0) hipLaunchKernelGGL(gemm_tn_reduce16_kernel, dim3(n / 64), dim3(256), 0, stream, (const float*)ws, dW, n, (int)blocks);
+    else hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)ws, dW, n, (int)blocks);
     LPD_CHECK_LAUNCH("lpd_gemm_tn_bf16(reduce)");
     return LPD_OK;
 }
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// The wide weight gradient on ROW-MAJOR LDS images read with ds_read_b64_tr_b16 (gfx950's transposed LDS read): the reduction runs
+// over the ROWS of both operands, so every MFMA operand is a column slice (one channel, 8 consecutive rows) of a row-major tensor.
+// The kernels above transpose in registers on the way into [channel][row] images (v_perm + 16-byte writes per 8 x 8 patch; dW3 ran at
+// 24 % of the MFMA time its products need, and bf16 rows as A changed nothing: the staging, not the operands, set the time).  Here the
+// staged rows keep their layout -- bf16 rows are copied, fp32 rows split into a hi and a lo image, 8-byte writes -- and the hardware
+// transposes on the read: per 16-lane group a block of 4 rows x 16 channels comes back channel-major, two reads give a lane its 8
+// rows of one channel = the 32x32x16 operand (lanes 0..31 channels 0..31 rows 0..7, lanes 32..63 rows 8..15).
+// Image rows are 512 + 64 bytes apart: the 4 rows of a read then sit on 4 x 64 bytes of different banks (conflict-free; on 512-byte
+// rows all four would share their banks).  256 x 256 output tile, 8 waves (a wave: 64 x 128 = 2 x 4 accumulator tiles), 32-row
+// chunks double-buffered, one barrier per chunk, the next chunk's rows requested before the MFMAs of this one.
+// A16: A holds bf16 rows (hi image only, two products); else fp32 rows (hi + lo, three products).
+// ---------------------------------------------------------------------------------------------
+typedef short tr_i16x4 __attribute__((ext_vector_type(4)));
+typedef short tr_i16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned tr_u32x4 __attribute__((ext_vector_type(4)));     // (HIP's uint4 as a lambda-captured array element stayed in scratch memory)
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigned char* p1)
+{
+    typedef tr_i16x4 __attribute__((address_space(3))) * lds_ptr;
+    const tr_i16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p0);
+    const tr_i16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p1);
+    const tr_i16x8 v = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// TB: b-channels per block (256 / 128 / 64; a-channels: 256).  Wave tiles: TB = 256: 64 x 128 (2 x 4 accumulator tiles), 128: 64 x 64,
+// 64: 32 x 64 -- narrow products (64 clusters, 64-channel layers) are bound by streaming A, whose rows every block reads exactly once.
+// Batched over consecutive problems (sA / sB elements apart): the NetVLAD pooling, one problem per cloud.
+template <bool A16, int TB>
+__global__ __launch_bounds__(512, TB == 256 ? 1 : 2) void gemm_tn_tr_kernel(const void* __restrict__ A_, long long lda, const float* __restrict__ B,
+                                                                            long long ldb, float* __restrict__ slabs, int KA, int KB,
+                                                                            long long rows_per_split, int nsplit, long long M, long long sA,
+                                                                            long long sB)
+{
+    constexpr int ROWA = 576;                      // bytes per row of an A image (256 channels x 2 + 64)
+    constexpr int ROWB = TB * 2 + 64;              // ... of a B image: 576 / 320 / 192, all = 64 mod 128 -> the 4 rows of a read on 4 bank groups
+    constexpr int IMGA = 32 * ROWA, IMGB = 32 * ROWB;
+    constexpr int BUF = (A16 ? 1 : 2) * IMGA + 2 * IMGB;
+    constexpr int A_HI = 0, A_LO = IMGA, B_HI = (A16 ? 1 : 2) * IMGA, B_LO = B_HI + IMGB;
+    constexpr int NI = TB == 64 ? 1 : 2, NJ = TB == 256 ? 4 : 2;        // accumulator tiles of a wave
+    constexpr int WGA = 256 / (NI * 32);                                // wave groups along a (4 or 8)
+    constexpr int BQ = TB / 4;                                          // float4 per B row (64 / 32 / 16)
+    constexpr int BP = TB * 32 / 4 / 512;                               // float4 of B per thread and chunk (4 / 2 / 1)
+    extern __shared__ __attribute__((aligned(16))) unsigned char trl[];      // [2 buffers][A hi [A lo] B hi B lo]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int ntile_a = KA / 256, ntile_b = KB / TB;
+    const int lin = lpd_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = lin % (ntile_a * ntile_b), zall = lin / (ntile_a * ntile_b);      // zall = batch * nsplit + split
+    const int split = zall % nsplit, zb = zall / nsplit;
+    const int a0 = (tile % ntile_a) * 256, b0 = (tile / ntile_a) * TB;
+    const long long m_begin = (long long)split * rows_per_split;
+    const long long m_end = min(M, m_begin + rows_per_split);
+    const int nchunk = m_end > m_begin ? (int)((m_end - m_begin) / 32) : 0;
+    // staging: fp32 rows of A -- 4 passes of (row tid / 64 + 8 p, channels 4 (tid % 64) ..); bf16 rows -- 2 passes of (row tid / 32 + 16 p,
+    // channels 8 (tid % 32) ..); B -- BP passes of (row tid / BQ + (512 / BQ) p, channels 4 (tid % BQ) ..): whole contiguous row pieces per wave
+    const float* srcB = B + zb * sB + b0 + (tid % BQ) * 4 + (m_begin + tid / BQ) * ldb;
+    const float* srcA = reinterpret_cast<const float*>(A_) + zb * sA + a0 + (tid & 63) * 4 + (m_begin + (tid >> 6)) * lda;
+    const uint16_t* srcA16 = reinterpret_cast<const uint16_t*>(A_) + zb * sA + a0 + (tid & 31) * 8 + (m_begin + (tid >> 5)) * lda;
+    const int wrb = (tid / BQ) * ROWB + (tid % BQ) * 8;        // + (512 / BQ) p rows
+    const int wr32 = (tid >> 6) * ROWA + (tid & 63) * 8;       // + 8 p rows
+    const int wr16 = (tid >> 5) * ROWA + (tid & 31) * 16;      // + 16 p rows
+    float4 rb[BP], ra[4];
+    tr_u32x4 ra16[2];
+    auto request = [&](int c) {
+        const long long r = (long long)c * 32;
+#pragma unroll
+        for (int p = 0; p < BP; ++p) rb[p] = *reinterpret_cast<const float4*>(srcB + (r + (512 / BQ) * p) * ldb);
+        if constexpr (A16) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) ra16[p] = *reinterpret_cast<const tr_u32x4*>(srcA16 + (r + 16 * p) * lda);
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) ra[p] = *reinterpret_cast<const float4*>(srcA + (r + 8 * p) * lda);
+        }
+    };
+    auto split_store = [&](unsigned char* hi, unsigned char* lo, const float4& v) {
+        const uint32_t h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
+        const uint32_t l01 = pack_bf16(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+        const uint32_t l23 = pack_bf16(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+        *reinterpret_cast<uint2*>(hi) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(lo) = make_uint2(l01, l23);
+    };
+    auto stage = [&](int buf) {
+        unsigned char* base = trl + buf * BUF;
+#pragma unroll
+        for (int p = 0; p < BP; ++p)
+            split_store(base + B_HI + wrb + (512 / BQ) * p * ROWB, base + B_LO + wrb + (512 / BQ) * p * ROWB, rb[p]);
+        if constexpr (A16) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) *reinterpret_cast<tr_u32x4*>(base + A_HI + wr16 + 16 * p * ROWA) = ra16[p];
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) split_store(base + A_HI + wr32 + 8 * p * ROWA, base + A_LO + wr32 + 8 * p * ROWA, ra[p]);
+        }
+    };
+    // transposed reads: lane 4 q + pp of 16-lane group g addresses row q, channels 4 pp .. of the group's 4 x 16 block; groups 0 / 1 take
+    // channels 0..15 / 16..31 of the tile, groups 2 / 3 the same channels 8 rows further (the operand's second k half)
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int wa = wave % WGA, wb = wave / WGA;    // the wave's tiles: A channels 32 NI wa .., B channels 32 NJ wb ..
+    const int rd_a = ((g >> 1) * 8 + q) * ROWA + ((g & 1) * 16 + pp * 4 + wa * NI * 32) * 2;
+    const int rd_b = ((g >> 1) * 8 + q) * ROWB + ((g & 1) * 16 + pp * 4 + wb * NJ * 32) * 2;
+    f32x16 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    if (nchunk > 0) {
+        request(0);
+        stage(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const unsigned char* base = trl + (c & 1) * BUF;
+        if (c + 1 < nchunk) request(c + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 ah[NI], al[NI], bh[NJ], bl[NJ];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const unsigned char* pa = base + rd_a + s * 16 * ROWA + i * 64;
+                ah[i] = tr_frag(pa + A_HI, pa + A_HI + 4 * ROWA);
+                if constexpr (!A16) al[i] = tr_frag(pa + A_LO, pa + A_LO + 4 * ROWA);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const unsigned char* pb = base + rd_b + s * 16 * ROWB + j * 64;
+                bh[j] = tr_frag(pb + B_HI, pb + B_HI + 4 * ROWB);
+                bl[j] = tr_frag(pb + B_LO, pb + B_LO + 4 * ROWB);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if constexpr (!A16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (c + 1 < nchunk) stage((c + 1) & 1);
+        __syncthreads();
+    }
+    float* slab = slabs + (size_t)zall * KA * KB;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int arow = a0 + (wa * NI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                slab[(size_t)arow * KB + b0 + (wb * NJ + j) * 32 + col] = acc[i][j][r];
+            }
+}
+
+}  // namespace
 
 // the 256 x 256-tile kernel: wide products over whole 32-row chunks (LPD_TN256=0 keeps the 128-wide kernel)
 static bool gemm_tn_256(long long M, int KA, int KB, int batch)
@@ -1438,8 +1629,23 @@ static bool gemm_tn_256(long long M, int KA, int KB, int batch)
     return on && batch == 1 && KA % 256 == 0 && KB % 256 == 0 && M % 32 == 0 && M >= 8192;
 }
 
-static long long gemm_tn_splits(long long M, int KA, int KB, int batch)
+// the transposed-read kernel (gemm_tn_tr_kernel): b-channels per block, or 0 where it is not built (LPD_TN_TR=0: never)
+static int tn_tr_tb(long long M, int KA, int KB)
 {
+    static const bool on = [] { const char* e = getenv("LPD_TN_TR"); return !(e && e[0] == '0'); }();
+    if (!on || KA % 256 != 0 || KB % 64 != 0 || M % 32 != 0 || M < 2048) return 0;
+    return KB % 256 == 0 ? 256 : (KB % 128 == 0 ? 128 : 64);
+}
+
+static long long gemm_tn_splits(long long M, int KA, int KB, int batch, bool a_bf16 = true)
+{
+    if (const int tb = tn_tr_tb(M, KA, KB)) {
+        // blocks per CU by LDS: two with bf16 rows as A and narrow B tiles (61 / 82 KiB), else one
+        const long long tiles = (long long)(KA / 256) * (KB / tb) * batch, cap = (tb == 256 || !a_bf16) ? 256 : 512;
+        long long splits = 1;
+        while (tiles * splits * 2 <= cap && M / (splits * 2) >= 256) splits *= 2;
+        return splits;
+    }
     if (gemm_tn_256(M, KA, KB, batch)) {
         const long long tiles = (long long)(KA / 256) * (KB / 256);
         long long splits = 1;
@@ -1467,9 +1673,30 @@ extern "C" int lpd_gemm_tn(const void* A_, long long lda, const float* B, long l
     LPD_CHECK_ARG(KA > 0 && KA % 128 == 0 && KB > 0 && KB % 64 == 0, "lpd_gemm_tn: KA %% 128 and KB %% 64 required (KA=%d KB=%d)", KA, KB);
     LPD_CHECK_ARG(lda % (a_bf16 ? 8 : 4) == 0 && ldb % 4 == 0 && sA % (a_bf16 ? 8 : 4) == 0 && sB % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
                   "lpd_gemm_tn: operands must be 16-byte aligned rows");
-    const long long splits = gemm_tn_splits(M, KA, KB, batch);
+    const long long splits = gemm_tn_splits(M, KA, KB, batch, a_bf16 != 0);
     long long rps = (M + splits - 1) / splits;
     rps = (rps + 63) / 64 * 64;
+    if (const int tb = tn_tr_tb(M, KA, KB)) {
+        rps = (M + splits - 1) / splits;
+        rps = (rps + 31) / 32 * 32;
+        const long long blocks = (long long)(KA / 256) * (KB / tb) * splits * batch;
+        LPD_CHECK_ARG(blocks < (1ll << 31), "lpd_gemm_tn: too many blocks");
+        const int lds_tr = 2 * ((a_bf16 ? 1 : 2) * 32 * 576 + 2 * 32 * (tb * 2 + 64));
+#define LPD_TN_TR_LAUNCH(AB_, TB_)                                                                                                          \
+    do {                                                                                                                                    \
+        (void)hipFuncSetAttribute((const void*)gemm_tn_tr_kernel<AB_, TB_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_tr);            \
+        hipLaunchKernelGGL((gemm_tn_tr_kernel<AB_, TB_>), dim3((unsigned)blocks), dim3(512), lds_tr, stream, A_, lda, B, ldb, ws, KA, KB, rps, \
+                           (int)splits, M, sA, sB);                                                                                         \
+    } while (0)
+        if (a_bf16) { if (tb == 256) LPD_TN_TR_LAUNCH(true, 256); else if (tb == 128) LPD_TN_TR_LAUNCH(true, 128); else LPD_TN_TR_LAUNCH(true, 64); }
+        else { if (tb == 256) LPD_TN_TR_LAUNCH(false, 256); else if (tb == 128) LPD_TN_TR_LAUNCH(false, 128); else LPD_TN_TR_LAUNCH(false, 64); }
+#undef LPD_TN_TR_LAUNCH
+        LPD_CHECK_LAUNCH("lpd_gemm_tn(tr)");
+        const int n = KA * KB;
+        hipLaunchKernelGGL(gemm_tn_reduce16_kernel, dim3(n / 64, batch), dim3(256), 0, stream, (const float*)ws, dW, n, (int)splits);
+        LPD_CHECK_LAUNCH("lpd_gemm_tn(reduce)");
+        return LPD_OK;
+    }
     if (gemm_tn_256(M, KA, KB, batch)) {
         const long long blocks = (long long)(KA / 256) * (KB / 256) * splits;
         constexpr int lds = 2 * 512 * 144;
@@ -1482,7 +1709,8 @@ extern "C" int lpd_gemm_tn(const void* A_, long long lda, const float* B, long l
         }
         LPD_CHECK_LAUNCH("lpd_gemm_tn(256)");
         const int n = KA * KB;
-        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, stream, (const float*)ws, dW, n, (int)splits);
+        if (n % 64 == 0) hipLaunchKernelGGL(gemm_tn_reduce16_kernel, dim3(n / 64, 1), dim3(256), 0, stream, (const float*)ws, dW, n, (int)splits);
+        else hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, stream, (const float*)ws, dW, n, (int)splits);
         LPD_CHECK_LAUNCH("lpd_gemm_tn(reduce)");
         return LPD_OK;
     }
@@ -1495,7 +1723,8 @@ extern "C" int lpd_gemm_tn(const void* A_, long long lda, const float* B, long l
 #undef LPD_TN_LAUNCH
     LPD_CHECK_LAUNCH("lpd_gemm_tn");
     const int n = KA * KB;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, stream, (const float*)ws, dW, n, (int)splits);
+    if (n % 64 == 0) hipLaunchKernelGGL(gemm_tn_reduce16_kernel, dim3(n / 64, batch), dim3(256), 0, stream, (const float*)ws, dW, n, (int)splits);
+    else hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, stream, (const float*)ws, dW, n, (int)splits);
     LPD_CHECK_LAUNCH("lpd_gemm_tn(reduce)");
     return LPD_OK;
 }

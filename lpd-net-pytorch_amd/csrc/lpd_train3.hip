@@ -241,13 +241,32 @@ __global__ __launch_bounds__(512, 2) void edge_dw_sel_bf16_kernel(const uint16_t
     }
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, double* __restrict__ out, int n, int nslabs)
+// out[e] = sum over the slabs, fp64.  16 slab groups per block (16 threads x 4 elements each; n % 64 == 0): one thread per element walked
+// the 256 slabs one dependent load at a time (129 blocks on 256 CUs).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, double* __restrict__ out, int n, int nslabs)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    double s = 0.0;
-    for (int b = 0; b < nslabs; ++b) s += slabs[(size_t)b * n + e];
-    out[e] = s;
+    __shared__ double red[16][16][4];
+    const int t = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int e = (blockIdx.x * 16 + t) * 4;
+    double s[4] = {0, 0, 0, 0};
+    for (int b = grp; b < nslabs; b += 64) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = b + 16 * u < nslabs ? *reinterpret_cast<const float4*>(slabs + (size_t)(b + 16 * u) * n + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[grp][t][c] = s[c];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int tt = threadIdx.x >> 2, c = threadIdx.x & 3;
+        double v = 0.0;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) v += red[g2][tt][c];
+        out[(blockIdx.x * 16 + tt) * 4 + c] = v;
+    }
 }
 
 // dW2[c][n] = s_c (S[c][n] - m1_c s[n] - m2_c invstd_c (sum_m W2[c][m] G[m][n] - mu_c s[n]))      one block per c, one thread per n
@@ -752,7 +771,8 @@ extern "C" int lpd_edge_dw_sel_bf16(const uint16_t* Y, const uint8_t* arg, const
     (void)hipFuncSetAttribute((const void*)edge_dw_sel_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(edge_dw_sel_bf16_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, Y, arg, dpre16, k, E, M, rpb, slabs);
     LPD_CHECK_LAUNCH("lpd_edge_dw_sel_bf16");
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)slabs, red, n, (int)blocks);
+    static_assert(n % 64 == 0, "slab_reduce_kernel: 64 elements per block");
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(n / 64), dim3(256), 0, stream, (const float*)slabs, red, n, (int)blocks);
     LPD_CHECK_LAUNCH("lpd_edge_dw_sel_bf16(reduce)");
     hipLaunchKernelGGL(dw2_finish_kernel, dim3(128), dim3(128), 0, stream, (const double*)red, W2, ldw, scale, mean, invstd, dbeta, dgamma,
                        (double)M * (double)k, dW2);
@@ -801,7 +821,8 @@ extern "C" int lpd_edge_dw_sel_f32(const float* Y, const uint8_t* arg, const flo
     (void)hipFuncSetAttribute((const void*)edge_dw_sel_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(edge_dw_sel_f32_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, Y, arg, dpre, k, E, M, rpb, slabs);
     LPD_CHECK_LAUNCH("lpd_edge_dw_sel_f32");
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)slabs, red, n, (int)blocks);
+    static_assert(n % 64 == 0, "slab_reduce_kernel: 64 elements per block");
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(n / 64), dim3(256), 0, stream, (const float*)slabs, red, n, (int)blocks);
     LPD_CHECK_LAUNCH("lpd_edge_dw_sel_f32(reduce)");
     hipLaunchKernelGGL(dw2_finish_kernel, dim3(128), dim3(128), 0, stream, (const double*)red, W2, ldw, scale, mean, invstd, dbeta, dgamma,
                        (double)M * (double)k, dW2);

@@ -913,11 +913,13 @@ def test_windowed_kagg_is_bit_identical(cuda, C, N, k, B, graph):
 
 
 @pytest.mark.parametrize("M,KA,KB", [(8192, 128, 64), (20000, 256, 128), (4096 + 37, 1024, 512), (70000, 512, 128),
-                                     (16384, 1024, 512), (8352, 256, 256), (33 * 1024 + 32, 512, 256)])   # the last three: 256 x 256 tiles
+                                     (16384, 1024, 512), (8352, 256, 256), (33 * 1024 + 32, 512, 256),   # the last three: 256 x 256 tiles
+                                     (16384, 512, 64), (2048, 256, 192)])
 def test_gemm_tn_weight_gradient_kernel(cuda, M, KA, KB):
     """lpd_gemm_tn: dW = A^T B over the rows (register-transposed staging, split-bf16): fp32-grade against fp64, ragged row
-    counts, column-slice operands, and agreement with the generic k-major product.  Wide products over whole 32-row chunks run on
-    256 x 256 tiles (gemm_tn_x3_256_kernel: odd and even chunk counts per split, a short last split)."""
+    counts, column-slice operands, and agreement with the generic k-major product.  Products with KA % 256 == 0 over whole 32-row
+    chunks run on the transposed-read kernel (gemm_tn_tr_kernel: 256-, 128- and 64-wide b tiles, odd and even chunk counts per split,
+    a short last split, batched), everything else on the register-transposing kernels."""
     ops = _ops()
     g = torch.Generator().manual_seed(M + KA)
     wide = torch.randn(M, KA + KB + 8, generator=g).to(cuda)
