@@ -518,7 +518,9 @@ int lpd_edge_split_fwd16(const float* P, long long ldp, const float* Q, long lon
                          float* usel, uint8_t* arg, long long M, int N, int C, int k, double* sum, double* sumsq, double* stat_ws, void* stream);
 
 /*
- * Backward of the split-form stage: dOut [M][ldo] = gradient of x3.  G [M][C] (scratch, receives dpre = dOut * act'),
+ * Backward of the split-form stage: dOut [M][ldo] = gradient of x3.  half != 0 (bf16 storage, C = 256): the rows the second pass gathers
+ * over the transposed graph -- G and Q -- are bf16 copies made by the first pass, kept in the same scratch ([2][M][C] bf16).
+ * G [M][C] (scratch, receives dpre = dOut * act'),
  * dbeta / dgamma [C] doubles (the BatchNorm parameter gradients), dP [M][lddp] and dQ [M][lddq]:
  *   dQ_i = s (dpre_i - k m1 - m2 invstd (S_i + k (Q_i - mu)))
  *   dP_j = s (A_j - deg_j m1 - m2 invstd (deg_j (P_j - mu) + R_j)),  A_j / R_j summed over the incoming edges of j in the
@@ -527,7 +529,7 @@ int lpd_edge_split_fwd16(const float* P, long long ldp, const float* Q, long lon
 int lpd_edge_split_bwd(const float* dOut, long long ldo, const float* usel, const uint8_t* arg, const float* S, const float* P,
                        long long ldp, const float* Q, long long ldq, const int32_t* rowptr, const int32_t* edges, float* G,
                        float* dP, long long lddp, float* dQ, long long lddq, long long M, int C, int k, const float* scale,
-                       const float* shift, const float* mean, const float* invstd, int act, float slope, double* dbeta,
+                       const float* shift, const float* mean, const float* invstd, int act, float slope, int half, double* dbeta,
                        double* dgamma, double* stat_ws, void* stream);
 
 /*

@@ -139,8 +139,12 @@ __global__ __launch_bounds__(256) void edge_split_fwd_kernel(const float* __rest
 }
 
 // G = dOut * act'(scale * usel + shift);  dbeta = sum G,  dgamma = sum G * (usel - mean) * invstd    (fp64)
+// H (bf16 storage): G is written as bf16 rows, and a bf16 copy of Q behind it ([2][M][C] bf16 in the fp32 buffer's bytes) -- the apply
+// kernel gathers both over the transposed graph (k rows each per point: 2.25 KiB per edge in fp32), the sums stay those of the fp32 G
+template <bool H>
 __global__ __launch_bounds__(256) void edge_split_bwd_reduce_kernel(const float* __restrict__ dOut, long long ldo,
                                                                     const float* __restrict__ usel, float* __restrict__ G,
+                                                                    const float* __restrict__ Q, long long ldq,
                                                                     long long M, int C, const float* __restrict__ scale,
                                                                     const float* __restrict__ shift, const float* __restrict__ mean,
                                                                     const float* __restrict__ invstd, int act, float slope,
@@ -166,7 +170,13 @@ __global__ __launch_bounds__(256) void edge_split_bwd_reduce_kernel(const float*
             sb[c] += o[c];
             sg[c] += (double)o[c] * ((u[c] - mu[c]) * is[c]);
         }
-        *reinterpret_cast<float4*>(G + i * C + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        if constexpr (H) {
+            uint16_t* G16 = reinterpret_cast<uint16_t*>(G);
+            st4_bf16(G16 + i * C + q * 4, make_float4(o[0], o[1], o[2], o[3]));
+            st4_bf16(G16 + (M + i) * C + q * 4, *reinterpret_cast<const float4*>(Q + i * ldq + q * 4));
+        } else {
+            *reinterpret_cast<float4*>(G + i * C + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        }
     }
     reduce_quads<256>(red, sb, sg, LQ, dbeta, dgamma);
 }
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(256) void edge_split_bwd_reduce_kernel(const float*
 // backward: a block holding the 4-channel slices of Q, dpre and arg of a whole cloud in LDS and walking a degree-sorted, slot-major
 // transposed graph (built by LDS atomics + a counting sort in 56 us; heavy rows by a scan kernel): correct, but 8.3 GB of random
 // 16 / 16 / 4-byte LDS reads plus the scattered slice fills cost 762 us against 930 here.)
-template <int LPR>
+template <int LPR, bool H = false>
 __global__ __launch_bounds__(256) void edge_split_bwd_apply_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ edges,
                                                                    const float* __restrict__ G, const uint8_t* __restrict__ arg,
                                                                    const float* __restrict__ S, const float* __restrict__ P,
@@ -207,6 +217,17 @@ __global__ __launch_bounds__(256) void edge_split_bwd_apply_kernel(const int32_t
     }
     const float kf = (float)k;
     const unsigned ku = (unsigned)k;
+    // H: bf16 rows of G and Q (the reduce kernel's copies), four channels = 8 bytes per lane
+    const uint16_t* G16 = reinterpret_cast<const uint16_t*>(G);
+    const uint16_t* Q16 = G16 + M * C;
+    auto row4 = [&](const float* f32, long long ld, const uint16_t* b16, long long i) -> float4 {
+        if constexpr (H) {
+            const uint2 w = *reinterpret_cast<const uint2*>(b16 + i * C + cl * 4);
+            return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u));
+        } else {
+            return *reinterpret_cast<const float4*>(f32 + i * ld + cl * 4);
+        }
+    };
     for (long long r0 = wave * RPW; r0 < M; r0 += nw * RPW) {
         const long long j = r0 + sub;
         if (j >= M) continue;
@@ -225,8 +246,8 @@ __global__ __launch_bounds__(256) void edge_split_bwd_apply_kernel(const int32_t
             uchar4 a4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                q4[u] = *reinterpret_cast<const float4*>(Q + (long long)ii[u] * ldq + cl * 4);
-                g4[u] = *reinterpret_cast<const float4*>(G + (long long)ii[u] * C + cl * 4);
+                q4[u] = row4(Q, ldq, Q16, (long long)ii[u]);
+                g4[u] = row4(G, C, G16, (long long)ii[u]);
                 a4[u] = *reinterpret_cast<const uchar4*>(arg + (long long)ii[u] * C + cl * 4);
             }
 #pragma unroll
@@ -239,8 +260,8 @@ __global__ __launch_bounds__(256) void edge_split_bwd_apply_kernel(const int32_t
         for (; p < end; ++p) {
             const unsigned e = (unsigned)edges[p];
             const unsigned i = e / ku, t = e - i * ku;
-            const float4 q4 = *reinterpret_cast<const float4*>(Q + (long long)i * ldq + cl * 4);
-            const float4 g4 = *reinterpret_cast<const float4*>(G + (long long)i * C + cl * 4);
+            const float4 q4 = row4(Q, ldq, Q16, (long long)i);
+            const float4 g4 = row4(G, C, G16, (long long)i);
             const uchar4 a4 = *reinterpret_cast<const uchar4*>(arg + (long long)i * C + cl * 4);
             R[0] += q4.x; R[1] += q4.y; R[2] += q4.z; R[3] += q4.w;
             A[0] += a4.x == t ? g4.x : 0.f; A[1] += a4.y == t ? g4.y : 0.f;
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(256) void edge_split_bwd_apply_kernel(const int32_t
         const float deg = (float)(end - beg);
         const float4 p4 = *reinterpret_cast<const float4*>(P + j * ldp + cl * 4);
         const float4 q4 = *reinterpret_cast<const float4*>(Q + j * ldq + cl * 4);
-        const float4 g4 = *reinterpret_cast<const float4*>(G + j * C + cl * 4);
+        const float4 g4 = row4(G, C, G16, j);
         const float4 s4 = *reinterpret_cast<const float4*>(S + j * C + cl * 4);
         const float pj[4] = {p4.x, p4.y, p4.z, p4.w}, qj[4] = {q4.x, q4.y, q4.z, q4.w};
         const float gj[4] = {g4.x, g4.y, g4.z, g4.w}, sj[4] = {s4.x, s4.y, s4.z, s4.w};
@@ -1234,24 +1255,29 @@ extern "C" int lpd_edge_split_bwd(const float* dOut, long long ldo, const float*
                                   const float* P, long long ldp, const float* Q, long long ldq, const int32_t* rowptr,
                                   const int32_t* edges, float* G, float* dP, long long lddp, float* dQ, long long lddq, long long M,
                                   int C, int k, const float* scale, const float* shift, const float* mean, const float* invstd,
-                                  int act, float slope, double* dbeta, double* dgamma, double* stat_ws, void* stream_)
+                                  int act, float slope, int half, double* dbeta, double* dgamma, double* stat_ws, void* stream_)
 {
+    // half != 0 (bf16 storage): the workspace G holds bf16 rows of G and of Q ([2][M][C] bf16 = the same M C floats); C = 256 only
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(dOut && usel && arg && S && P && Q && rowptr && edges && G && dP && dQ && dbeta && dgamma,
                   "lpd_edge_split_bwd: null pointer");
+    LPD_CHECK_ARG(!half || C == 256, "lpd_edge_split_bwd: the bf16 form is built for C = 256");
     LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_split_bwd: C=%d unsupported", C);
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_split_bwd: activation %d unsupported", act);
     LPD_CHECK_ARG(ldo % 4 == 0 && ldp % 4 == 0 && ldq % 4 == 0 && lddp % 4 == 0 && lddq % 4 == 0, "lpd_edge_split_bwd: leading dims % 4");
     const LpdStatWs ws = lpd_stat_arg(stat_ws);
     LPD_CHECK_ARG(ws.rep, "lpd_edge_split_bwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     const int rg = 256 / (C / 4);
-    hipLaunchKernelGGL(edge_split_bwd_reduce_kernel, dim3(grid_for(M, rg * 8, 2048)), dim3(256), 0, stream, dOut, ldo, usel, G, M, C,
-                       scale, shift, mean, invstd, act, slope, ws.sum(), ws.sumsq());
+    if (half) hipLaunchKernelGGL(edge_split_bwd_reduce_kernel<true>, dim3(grid_for(M, rg * 8, 2048)), dim3(256), 0, stream, dOut, ldo, usel, G, Q, ldq, M, C,
+                                 scale, shift, mean, invstd, act, slope, ws.sum(), ws.sumsq());
+    else hipLaunchKernelGGL(edge_split_bwd_reduce_kernel<false>, dim3(grid_for(M, rg * 8, 2048)), dim3(256), 0, stream, dOut, ldo, usel, G, Q, ldq, M, C,
+                            scale, shift, mean, invstd, act, slope, ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_edge_split_bwd(reduce)");
     if (int rc = lpd_stat_finish(ws, dbeta, dgamma, C, stream)) return rc;
     const int lpr = C / 4;
     const int grid = grid_for(M, 4 * (64 / lpr) * 2, 8192);
-    if (C == 64) hipLaunchKernelGGL(edge_split_bwd_apply_kernel<16>, dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
+    if (half) hipLaunchKernelGGL((edge_split_bwd_apply_kernel<64, true>), dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
+    else if (C == 64) hipLaunchKernelGGL(edge_split_bwd_apply_kernel<16>, dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
     else if (C == 128) hipLaunchKernelGGL(edge_split_bwd_apply_kernel<32>, dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
     else hipLaunchKernelGGL(edge_split_bwd_apply_kernel<64>, dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
     LPD_CHECK_LAUNCH("lpd_edge_split_bwd(apply)");

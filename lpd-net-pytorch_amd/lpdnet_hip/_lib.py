@@ -122,7 +122,7 @@ SIGNATURES = {
     "lpd_vlad_finalize_bwd": [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "lpd_edge_split_fwd": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_split_bwd": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_ll,
-                           _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p],
+                           _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_split_fwd16_applies": [_c_int, _c_int, _c_int],
     "lpd_edge_split_fwd16": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_build_bf16": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p],

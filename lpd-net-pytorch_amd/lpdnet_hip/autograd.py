@@ -535,7 +535,8 @@ class _LPDNetTrainFn(torch.autograd.Function):
         dpq3 = torch.empty((M, 512), dtype=torch.float32, device=dfeat.device)    # both halves are fully written below
         pq3 = S["pq3"]
         dgs3, dbs3 = ops.edge_split_bwd(dcat[:, 256:512], S["usel3"], S["arg3"], S["s3"], pq3[:, :256], pq3[:, 256:],
-                                        ops.GraphT(S["idx_x"], N), S["stg3"], act, slope, k, dP=dpq3[:, :256], dQ=dpq3[:, 256:])
+                                        ops.GraphT(S["idx_x"], N), S["stg3"], act, slope, k, dP=dpq3[:, :256], dQ=dpq3[:, 256:],
+                                        half=ctx.bf16)
         x2 = S["cat"][:, 128:256]
         dwcat3 = _dweight(dpq3, x2)
         ops.gemm(dpq3, S["wcat3"], b_kmajor=True, out=dcat[:, 128:256], accumulate=True)   # dx2 += dPQ3 Wcat3

@@ -1367,8 +1367,12 @@ def edge_split_fwd(P, Q, idx, N, bn):
     return S, usel, arg, _bn_finalize(sums, M * k, C, bn)
 
 
-def edge_split_bwd(dOut, usel, arg, S, P, Q, graph, st, act, slope, k, dP, dQ):
-    """Backward half: dOut [M,C] (view allowed) -> fills dP, dQ ([M,C] views), returns (dgamma, dbeta) fp32."""
+SPLIT_BWD_BF16 = os.environ.get("LPD_SPLIT_BWD_BF16", "1") != "0"   # bf16 storage: the SN1 backward gathers bf16 rows of G and Q
+
+
+def edge_split_bwd(dOut, usel, arg, S, P, Q, graph, st, act, slope, k, dP, dQ, half=False):
+    """Backward half: dOut [M,C] (view allowed) -> fills dP, dQ ([M,C] views), returns (dgamma, dbeta) fp32.
+    half (bf16 storage, C = 256): the rows gathered over the transposed graph are bf16 copies (lpd_edge_split_bwd)."""
     ldo, ldp, ldq, lddp, lddq = _rows(dOut, "dOut"), _rows(P, "P"), _rows(Q, "Q"), _rows(dP, "dP"), _rows(dQ, "dQ")
     M, C = usel.shape
     G = torch.empty((M, C), dtype=torch.float32, device=usel.device)
@@ -1376,7 +1380,8 @@ def edge_split_bwd(dOut, usel, arg, S, P, Q, graph, st, act, slope, k, dP, dQ):
     lib = _lib.load()
     _call(f"edge_split_bwd[C={C}]", lib.lpd_edge_split_bwd, _ptr(dOut), ldo, _ptr(usel), _ptr(arg), _ptr(S), _ptr(P), ldp, _ptr(Q), ldq,
           _ptr(graph.rowptr), _ptr(graph.edges), _ptr(G), _ptr(dP), lddp, _ptr(dQ), lddq, M, C, k, _ptr(st.scale), _ptr(st.shift),
-          _ptr(st.mean), _ptr(st.invstd), act, float(slope), _ptr(red[0]), _ptr(red[1]), _stat_ws(), _stream())
+          _ptr(st.mean), _ptr(st.invstd), act, float(slope), int(bool(half) and SPLIT_BWD_BF16 and C == 256), _ptr(red[0]), _ptr(red[1]),
+          _stat_ws(), _stream())
     redf = red.float()
     return redf[1], redf[0]
 

@@ -746,6 +746,13 @@ def test_split_form_edge_stage_equals_the_materialised_one(cuda, C, N, k, B):
     assert _rel(buf[:, 4:4 + C], dP_a) < 2e-5 and _rel(buf[:, 4 + C:4 + 2 * C], dQ_a) < 2e-5
     assert _rel(dg_b, dg_a) < 1e-5 and _rel(db_b, db_a) < 1e-5
     assert (buf[:, :4] == 0).all() and (buf[:, 4 + 2 * C:] == 0).all()
+    if C == 256:      # bf16 storage: the gathered rows (G, Q) are bf16 copies -- the statistics stay exact, dP / dQ carry one rounding per term
+        buf16 = torch.zeros_like(buf)
+        dg_h, db_h = ops.edge_split_bwd(dOut, usel, arg_b, S, P, Q, ops.GraphT(idx, N), st_b, act, slope, k, dP=buf16[:, 4:4 + C],
+                                        dQ=buf16[:, 4 + C:4 + 2 * C], half=True)
+        assert torch.equal(dg_h, dg_b) and torch.equal(db_h, db_b)
+        assert _rel(buf16[:, 4:4 + C], dP_a) < 6e-3 and _rel(buf16[:, 4 + C:4 + 2 * C], dQ_a) < 6e-3
+        assert not torch.equal(buf16, buf)
 
 
 def test_bf16_storage_edge_kernels(cuda):
