@@ -1519,7 +1519,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigne
 // 64: 32 x 64 -- narrow products (64 clusters, 64-channel layers) are bound by streaming A, whose rows every block reads exactly once.
 // Batched over consecutive problems (sA / sB elements apart): the NetVLAD pooling, one problem per cloud.
 template <bool A16, int TB>
-__global__ __launch_bounds__(512, TB == 256 ? 1 : 2) void gemm_tn_tr_kernel(const void* __restrict__ A_, long long lda, const float* __restrict__ B,
+__global__ __launch_bounds__(512, (A16 && TB != 256) ? 4 : 2) void gemm_tn_tr_kernel(const void* __restrict__ A_, long long lda, const float* __restrict__ B,
                                                                             long long ldb, float* __restrict__ slabs, int KA, int KB,
                                                                             long long rows_per_split, int nsplit, long long M, long long sA,
                                                                             long long sB)
@@ -1607,29 +1607,41 @@ __global__ __launch_bounds__(512, TB == 256 ? 1 : 2) void gemm_tn_tr_kernel(cons
     for (int c = 0; c < nchunk; ++c) {
         const unsigned char* base = trl + (c & 1) * BUF;
         if (c + 1 < nchunk) request(c + 1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 ah[NI], al[NI], bh[NJ], bl[NJ];
+        // 2 NJ stages (k-step s, b tile j), software-pipelined by one: the transposed reads of stage t + 1 are issued in front of the
+        // MFMAs of stage t (with all reads of a k-step in front of its MFMAs both waves of a SIMD -- in step behind the barrier -- read,
+        // then multiply: the compute phase took twice the MFMA time)
+        bf16x8 ah[2][NI], al[2][NI], bh[2], bl[2];
+        auto load_a = [&](int s) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const unsigned char* pa = base + rd_a + s * 16 * ROWA + i * 64;
-                ah[i] = tr_frag(pa + A_HI, pa + A_HI + 4 * ROWA);
-                if constexpr (!A16) al[i] = tr_frag(pa + A_LO, pa + A_LO + 4 * ROWA);
+                ah[s & 1][i] = tr_frag(pa + A_HI, pa + A_HI + 4 * ROWA);
+                if constexpr (!A16) al[s & 1][i] = tr_frag(pa + A_LO, pa + A_LO + 4 * ROWA);
             }
+        };
+        auto load_b = [&](int t) {
+            const int s = t / NJ, j = t % NJ;
+            const unsigned char* pb = base + rd_b + s * 16 * ROWB + j * 64;
+            bh[t & 1] = tr_frag(pb + B_HI, pb + B_HI + 4 * ROWB);
+            bl[t & 1] = tr_frag(pb + B_LO, pb + B_LO + 4 * ROWB);
+        };
+        load_a(0);
+        load_b(0);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const unsigned char* pb = base + rd_b + s * 16 * ROWB + j * 64;
-                bh[j] = tr_frag(pb + B_HI, pb + B_HI + 4 * ROWB);
-                bl[j] = tr_frag(pb + B_LO, pb + B_LO + 4 * ROWB);
+        for (int t = 0; t < 2 * NJ; ++t) {
+            const int s = t / NJ, j = t % NJ;
+            if (t + 1 < 2 * NJ) {
+                if ((t + 1) % NJ == 0) load_a((t + 1) / NJ);
+                load_b(t + 1);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    if constexpr (!A16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
+            for (int i = 0; i < NI; ++i) {
+                if constexpr (!A16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s & 1][i], bh[t & 1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s & 1][i], bl[t & 1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s & 1][i], bh[t & 1], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (c + 1 < nchunk) stage((c + 1) & 1);
         __syncthreads();

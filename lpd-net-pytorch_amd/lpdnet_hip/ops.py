@@ -1107,6 +1107,32 @@ def gemm_bf16a(A16, W, b_kmajor=True, out=None, accumulate=False):
     return out
 
 
+class _BatchCounts(__import__("threading").local):
+    pending = None
+
+
+_BATCH_COUNTS = _BatchCounts()
+
+
+class deferred_batch_counts:
+    """with ops.deferred_batch_counts(): the `num_batches_tracked += 1` of every train-mode BatchNorm inside is queued and applied by ONE
+    launch on exit (torch._foreach_add_) instead of one 5-us launch per layer; layers with momentum=None read the counter and are
+    updated at once.  Nested uses flush at the outermost exit."""
+
+    def __enter__(self):
+        self.outer = _BATCH_COUNTS.pending is None
+        if self.outer:
+            _BATCH_COUNTS.pending = []
+        return self
+
+    def __exit__(self, *exc):
+        if self.outer:
+            pend, _BATCH_COUNTS.pending = _BATCH_COUNTS.pending, None
+            if pend:
+                torch._foreach_add_(pend, 1)
+        return False
+
+
 def _bn_finalize(sums, R, C, bn):
     """fp64 column sums / sums of squares over R rows -> BNStats (+ running-stat update)."""
     out = torch.empty((4, C), dtype=torch.float32, device=sums.device)
@@ -1122,7 +1148,11 @@ def _bn_finalize(sums, R, C, bn):
           _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None, float(momentum),
           float(bn.eps), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _stream())
     if track:
-        bn.num_batches_tracked += 1
+        pend = getattr(_BATCH_COUNTS, "pending", None)
+        if pend is not None and bn.momentum is not None:
+            pend.append(bn.num_batches_tracked)      # one launch for all layers of the step (deferred_batch_counts)
+        else:
+            bn.num_batches_tracked += 1
         bn.__dict__.pop("_lpd_cache", None)      # the folded eval-mode affine (engine.bn_affine) is stale now
     return BNStats(out[0], out[1], out[2], out[3], R)
 

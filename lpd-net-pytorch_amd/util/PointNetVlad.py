@@ -228,11 +228,12 @@ class PointNetVlad(nn.Module):
         if isinstance(trunk, LPDNet) and trunk.training and self.net_vlad.training and self.net_vlad.cluster_size == 64:
             # train mode: bn3 + activation of the trunk's last layer are applied inside the head's assignment product (one pass over the
             # [B N, 1024] map less); `feat` is the raw conv3 output when `pending` is set
-            from lpdnet_hip import autograd
-            feat, B, N, pending = autograd.lpdnet_features_train(trunk, x, defer_act=True)
-            if pending is None and engine.DEBUG_AUX is not None:      # test hook (with a pending activation the head records the activated rows)
-                engine.DEBUG_AUX["feat"] = feat
-            return autograd.netvlad_train(self.net_vlad, feat, B, N, pending=pending)
+            from lpdnet_hip import autograd, ops
+            with ops.deferred_batch_counts():      # the nine BatchNorm step counters advance in one launch
+                feat, B, N, pending = autograd.lpdnet_features_train(trunk, x, defer_act=True)
+                if pending is None and engine.DEBUG_AUX is not None:      # test hook (with a pending activation the head records the activated rows)
+                    engine.DEBUG_AUX["feat"] = feat
+                return autograd.netvlad_train(self.net_vlad, feat, B, N, pending=pending)
         feat, B, N = trunk._features(x)          # point-major: no [B,E,N,1] round trip between trunk and head
         if engine.DEBUG_AUX is not None:         # test hook: the trunk's output rows [B*N, E] (stage-probe fixtures)
             engine.DEBUG_AUX["feat"] = feat
