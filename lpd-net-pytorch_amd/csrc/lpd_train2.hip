@@ -1668,16 +1668,19 @@ static bool gemm_tn_256(long long M, int KA, int KB, int batch)
 }
 
 // the transposed-read kernel (gemm_tn_tr_kernel): b-channels per block, or 0 where it is not built (LPD_TN_TR=0: never)
-static int tn_tr_tb(long long M, int KA, int KB)
+static int tn_tr_tb(long long M, int KA, int KB, int batch, bool a_bf16)
 {
     static const bool on = [] { const char* e = getenv("LPD_TN_TR"); return !(e && e[0] == '0'); }();
     if (!on || KA % 256 != 0 || KB % 64 != 0 || M % 32 != 0 || M < 2048) return 0;
+    // fp32 rows as A leave room for ONE block per CU: the pooling's 4 x 44 tiles of 4096 rows then run as 176 or 352 blocks on 256 CUs
+    // (208 us against 190 on the register-transposing kernel, which holds several blocks per CU)
+    if (!a_bf16 && batch > 1) return 0;
     return KB % 256 == 0 ? 256 : (KB % 128 == 0 ? 128 : 64);
 }
 
 static long long gemm_tn_splits(long long M, int KA, int KB, int batch, bool a_bf16 = true)
 {
-    if (const int tb = tn_tr_tb(M, KA, KB)) {
+    if (const int tb = tn_tr_tb(M, KA, KB, batch, a_bf16)) {
         // blocks per CU by LDS: two with bf16 rows as A and narrow B tiles (61 / 82 KiB), else one
         const long long tiles = (long long)(KA / 256) * (KB / tb) * batch, cap = (tb == 256 || !a_bf16) ? 256 : 512;
         long long splits = 1;
@@ -1699,7 +1702,8 @@ static long long gemm_tn_splits(long long M, int KA, int KB, int batch, bool a_b
 extern "C" long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB, int batch)
 {
     if (batch < 1) batch = 1;
-    return gemm_tn_splits(M, KA, KB, batch) * batch * KA * KB;
+    const long long a = gemm_tn_splits(M, KA, KB, batch, true), b = gemm_tn_splits(M, KA, KB, batch, false);      // either operand type
+    return (a > b ? a : b) * batch * KA * KB;
 }
 
 extern "C" int lpd_gemm_tn(const void* A_, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
@@ -1714,7 +1718,7 @@ extern "C" int lpd_gemm_tn(const void* A_, long long lda, const float* B, long l
     const long long splits = gemm_tn_splits(M, KA, KB, batch, a_bf16 != 0);
     long long rps = (M + splits - 1) / splits;
     rps = (rps + 63) / 64 * 64;
-    if (const int tb = tn_tr_tb(M, KA, KB)) {
+    if (const int tb = tn_tr_tb(M, KA, KB, batch, a_bf16 != 0)) {
         rps = (M + splits - 1) / splits;
         rps = (rps + 31) / 32 * 32;
         const long long blocks = (long long)(KA / 256) * (KB / tb) * splits * batch;
