@@ -147,8 +147,10 @@ int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C, int ldc, 
  * i.e. lpd_colstats without the second pass over C. */
 /* lpd_gemm_x3w with per-problem weights: rows [b batch_rows, (b + 1) batch_rows) of the row-major A take fragment set b of
  * lpd_gemm_prep_b_batch (frag_bytes = lpd_gemm_prep_b_bytes(N, K) apart); batch_rows % 128 == 0.  NetVLAD backward's dA[b] = x[b] . dV[b]. */
+/* a_scale / a_shift (or null): the rows of A are act(a_scale[k] A[m][k] + a_shift[k]) -- lpd_gemm_x3w_act's operand transform with
+ * nothing stored (bf16 rows: the transformed values rounded to bf16 = the map a bf16-storing lpd_gemm_x3w_act writes) */
 int lpd_gemm_x3w_batched(const void* A, int lda, int a_bf16, const void* frags, long long frag_bytes, int batch_rows, float* C, int ldc, int M,
-                         int N, int K, int impl, void* stream);
+                         int N, int K, const float* a_scale, const float* a_shift, int a_act, float a_slope, int impl, void* stream);
 /* bf16 rows as the operand (a_bf16 above, flags & 1 of lpd_gemm_x3w_act, lpd_gemm_x3w_bf16a): A [M][lda] in bf16 elements, row-major,
  * K % 32 == 0.  A plain product takes the rows as the hi image (two MFMA products against the split weight); with an operand
  * transform they are widened first.  flags & 2 of lpd_gemm_x3w_act: a_out is a bf16 tensor, and the product sees the rounded values.
@@ -606,6 +608,13 @@ int lpd_gemm_tn_bf16(const uint16_t* A, const uint16_t* B, float* dW, float* ws,
 long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB, int batch);
 int lpd_gemm_tn(const void* A, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
                 int batch, long long sA, long long sB, int a_bf16, void* stream);
+/* lpd_gemm_tn with the rows of A taken as act(a_scale[a] A[m][a] + a_shift[a]) (multiply, then add: lpd_affine_act's bits; bf16 rows:
+ * rounded to bf16 again): a train-mode BatchNorm affine + activation applied where the raw map is staged, so that the activated
+ * [B N, 1024] map of util/lpdnet_model.py:262 need not be stored for util/PointNetVlad.py:64-67 (pooling) and the assignment's weight
+ * gradient.  KA % 256 == 0, KB % 64 == 0 and KB % 128 != 0, M % 32 == 0, M >= 2048; workspace: lpd_gemm_tn_act_ws_floats. */
+long long lpd_gemm_tn_act_ws_floats(long long M, int KA, int KB, int batch, int a_bf16);
+int lpd_gemm_tn_act(const void* A, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB, int batch,
+                    long long sA, long long sB, int a_bf16, const float* a_scale, const float* a_shift, int a_act, float a_slope, void* stream);
 /* a_bf16 != 0: A holds bf16 rows (lda, sA in bf16 elements, multiples of 8): two MFMA products per term (bf16-storage training mode). */
 
 /*

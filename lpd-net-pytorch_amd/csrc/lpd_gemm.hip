@@ -720,16 +720,16 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
                     v.x = fmaxf(v.x, 0.0f) + g.a_ns * fminf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f) + g.a_ns * fminf(v.y, 0.0f);
                     v.z = fmaxf(v.z, 0.0f) + g.a_ns * fminf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f) + g.a_ns * fminf(v.w, 0.0f);
                     const int m = m0 + rr, kk = rk0[set] + k4 * 4;
-                    if (g.a_out && m < g.M && (!KTAIL || kk + 3 < g.K)) {
-                        if (A16 && g.a_out_bf16) {
-                            bf16x4 ob;
-                            ob[0] = (__bf16)v.x; ob[1] = (__bf16)v.y; ob[2] = (__bf16)v.z; ob[3] = (__bf16)v.w;
-                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(g.a_out) + (long long)m * g.a_ld + kk) = ob;
-                            // the product and the stored map see the SAME rounded values (the backward reads the stored ones)
-                            v = make_float4((float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]);
-                        } else {
-                            *reinterpret_cast<float4*>(g.a_out + (long long)m * g.a_ld + kk) = v;
-                        }
+                    const bool put = g.a_out && m < g.M && (!KTAIL || kk + 3 < g.K);
+                    if (A16 && g.a_out_bf16) {
+                        // the transformed map IS a bf16 tensor (stored here, or re-formed by every consumer's loader): the product takes
+                        // the rounded values, so that all of them see the same map
+                        bf16x4 ob;
+                        ob[0] = (__bf16)v.x; ob[1] = (__bf16)v.y; ob[2] = (__bf16)v.z; ob[3] = (__bf16)v.w;
+                        if (put) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(g.a_out) + (long long)m * g.a_ld + kk) = ob;
+                        v = make_float4((float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]);
+                    } else if (put) {
+                        *reinterpret_cast<float4*>(g.a_out + (long long)m * g.a_ld + kk) = v;
                     }
                 }
             }
@@ -781,6 +781,21 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[set][j], acc[i][j], 0, 0, 0);
+        } else if constexpr (A16T) {
+            if (g.prods == 3) {      // uniform (a transformed map that is NOT rounded to bf16 again has a lo image)
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[set][j], acc[i][j], 0, 0, 0);
+            }
+            if (g.prods != 1) {      // uniform
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[set][j], acc[i][j], 0, 0, 0);
+            }
         } else if (g.prods != 1) {      // uniform
 #pragma unroll
             for (int i = 0; i < RT; ++i)
@@ -1258,9 +1273,9 @@ static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, i
                   "lpd_gemm_x3w: bf16 C needs row-major rows, N %% 32 == 0, no accumulate");
     if (a_flags & 1) {      // bf16 rows: row-major, whole chunks, 8-byte aligned pieces; the plain product takes them as the hi image
         LPD_CHECK_ARG(!a_panels && K % 32 == 0 && lda % 4 == 0 && ((uintptr_t)A & 7) == 0 && impl != 1, "lpd_gemm_x3w: bf16 A needs row-major rows, K %% 32 == 0");
-        if (!a_scale && g.prods == 3) g.prods = 2;
+        if ((!a_scale || (a_flags & 2)) && g.prods == 3) g.prods = 2;      // plain bf16 rows, or a transformed map rounded to bf16: no lo image
     }
-    LPD_CHECK_ARG(!(a_flags & 2) || ((a_flags & 1) && a_out && a_ld % 4 == 0), "lpd_gemm_x3w_act: a bf16 a_out is built for bf16 rows A");
+    LPD_CHECK_ARG(!(a_flags & 2) || ((a_flags & 1) && a_scale && (!a_out || a_ld % 4 == 0)), "lpd_gemm_x3w_act: a bf16 map is built for bf16 rows A");
     if (batch_rows) {      // per-problem fragment sets, each lpd_gemm_prep_b_bytes(N, K) bytes (hi half, then lo half): the lo array of set 0
         LPD_CHECK_ARG(batch_rows % 128 == 0 && M % batch_rows == 0 && frag_bytes == lpd_gemm_prep_b_bytes(N, K),      // starts where a single set's would
                       "lpd_gemm_x3w_batched: batch_rows %% 128 == 0, M %% batch_rows == 0, frag_bytes = lpd_gemm_prep_b_bytes(N, K)");
@@ -1328,12 +1343,17 @@ extern "C" int lpd_gemm_x3w(const float* A, int lda, const void* frags, float* C
 // of lpd_gemm_prep_b_batch (frag_bytes = lpd_gemm_prep_b_bytes(N, K) apart).  Row-major A / C over all problems (M = batch x batch_rows).
 // The NetVLAD backward's dA[b] = x[b] . dV[b] (util/PointNetVlad.py:64-67 transposed: [N, 1024] x [1024, 64] per cloud) ran on the generic
 // batched kernel at 2.6 TB/s of its 738-MB operand.
+// a_scale / a_shift (or null): the rows of A are act(a_scale[k] A[m][k] + a_shift[k]) (lpd_gemm_x3w_act's operand transform, nothing
+// stored; bf16 rows: the transformed values rounded to bf16, i.e. the map a bf16-storing lpd_gemm_x3w_act would have written).
 extern "C" int lpd_gemm_x3w_batched(const void* A, int lda, int a_bf16, const void* frags, long long frag_bytes, int batch_rows, float* C, int ldc,
-                                    int M, int N, int K, int impl, void* stream_)
+                                    int M, int N, int K, const float* a_scale, const float* a_shift, int a_act, float a_slope, int impl,
+                                    void* stream_)
 {
     LPD_CHECK_ARG(batch_rows > 0 && frag_bytes > 0, "lpd_gemm_x3w_batched: batch_rows / frag_bytes");
+    LPD_CHECK_ARG((a_scale == nullptr) == (a_shift == nullptr) && a_act >= 0 && a_act <= 2, "lpd_gemm_x3w_batched: operand transform");
     return gemm_x3w_impl(reinterpret_cast<const float*>(A), lda, frags, C, ldc, M, N, K, nullptr, nullptr, nullptr, 0, 0.0f, 0, 0, 0, 0, 0, impl, nullptr,
-                         nullptr, nullptr, stream_, nullptr, nullptr, nullptr, 0, 1.0f, batch_rows, frag_bytes, a_bf16 ? 1 : 0);
+                         nullptr, nullptr, stream_, a_scale, a_shift, nullptr, 0, a_act == 0 ? 1.0f : (a_act == 1 ? 0.0f : a_slope), batch_rows,
+                         frag_bytes, a_bf16 ? (a_scale ? 3 : 1) : 0);
 }
 
 // C = A16 W^T (+= C with accumulate) for bf16 rows A16 [M][lda] (bf16 elements): the rows are the hi image, two MFMA products against

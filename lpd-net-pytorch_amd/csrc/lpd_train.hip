@@ -69,20 +69,18 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
     const int RG = 256 / Q;
     const int q = threadIdx.x % Q, rg = threadIdx.x / Q;
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-    // four rows per trip, summed in fp32; the trips in fp64 (an fp64 add + fma per element bound the kernel: 2.4 TB/s on the conv3 map)
+    // four rows per trip (eight loads in flight); every element enters the fp64 sums directly -- var = E[x^2] - mean^2 cancels, and a
+    // BatchNorm over the 6 rows of a T-Net fc layer with |mean| >> std turned fp32 partial sums (1e-7 of mean^2) into 3e-3 of the output
     const long long S = (long long)gridDim.x * RG;
     for (long long r = (long long)blockIdx.x * RG + rg; r < R; r += 4 * S) {
         float4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = r + u * S < R ? *reinterpret_cast<const float4*>(X + (r + u * S) * ld + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float p[4] = {0, 0, 0, 0}, pp[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            p[0] += v[u].x; p[1] += v[u].y; p[2] += v[u].z; p[3] += v[u].w;
-            pp[0] += v[u].x * v[u].x; pp[1] += v[u].y * v[u].y; pp[2] += v[u].z * v[u].z; pp[3] += v[u].w * v[u].w;
+            s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w;
+            ss[0] += (double)v[u].x * v[u].x; ss[1] += (double)v[u].y * v[u].y; ss[2] += (double)v[u].z * v[u].z; ss[3] += (double)v[u].w * v[u].w;
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { s[e] += p[e]; ss[e] += pp[e]; }
     }
     col_reduce_atomics<4>(red, s, ss, Q, C, sum, sumsq);
 }

@@ -1518,11 +1518,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigne
 // TB: b-channels per block (256 / 128 / 64; a-channels: 256).  Wave tiles: TB = 256: 64 x 128 (2 x 4 accumulator tiles), 128: 64 x 64,
 // 64: 32 x 64 -- narrow products (64 clusters, 64-channel layers) are bound by streaming A, whose rows every block reads exactly once.
 // Batched over consecutive problems (sA / sB elements apart): the NetVLAD pooling, one problem per cloud.
-template <bool A16, int TB>
+// a_scale / a_shift (or null): the rows of A are act(a_scale[a] A[m][a] + a_shift[a]) -- a train-mode BatchNorm affine + activation
+// applied where the raw map is staged (multiply, then add: the bits of lpd_affine_act; bf16 rows: rounded to bf16 again = the map a
+// bf16-storing pass would have written), so that the activated [B N, 1024] map need not exist.
+template <bool A16, int TB, bool ATR = false>
 __global__ __launch_bounds__(512, (A16 && TB != 256) ? 4 : 2) void gemm_tn_tr_kernel(const void* __restrict__ A_, long long lda, const float* __restrict__ B,
                                                                             long long ldb, float* __restrict__ slabs, int KA, int KB,
                                                                             long long rows_per_split, int nsplit, long long M, long long sA,
-                                                                            long long sB)
+                                                                            long long sB, const float* __restrict__ a_scale,
+                                                                            const float* __restrict__ a_shift, float a_ns)
 {
     constexpr int ROWA = 576;                      // bytes per row of an A image (256 channels x 2 + 64)
     constexpr int ROWB = TB * 2 + 64;              // ... of a B image: 576 / 320 / 192, all = 64 mod 128 -> the 4 rows of a read on 4 bank groups
@@ -1554,6 +1558,17 @@ __global__ __launch_bounds__(512, (A16 && TB != 256) ? 4 : 2) void gemm_tn_tr_ke
     const int wr16 = (tid >> 5) * ROWA + (tid & 31) * 16;      // + 16 p rows
     float4 rb[BP], ra[4];
     tr_u32x4 ra16[2];
+    // this thread's channels of A are the same in every chunk: their affine, once
+    float asc[ATR ? 8 : 1], ash[ATR ? 8 : 1];
+    if constexpr (ATR) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = A16 ? a0 + (tid & 31) * 8 + e : a0 + (tid & 63) * 4 + (e & 3);
+            asc[e] = a_scale[ch];
+            ash[e] = a_shift[ch];
+        }
+    }
+    auto tf = [&](float v, int e) { v = asc[ATR ? e : 0] * v + ash[ATR ? e : 0]; return fmaxf(v, 0.0f) + a_ns * fminf(v, 0.0f); };
     auto request = [&](int c) {
         const long long r = (long long)c * 32;
 #pragma unroll
@@ -1580,10 +1595,22 @@ __global__ __launch_bounds__(512, (A16 && TB != 256) ? 4 : 2) void gemm_tn_tr_ke
             split_store(base + B_HI + wrb + (512 / BQ) * p * ROWB, base + B_LO + wrb + (512 / BQ) * p * ROWB, rb[p]);
         if constexpr (A16) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) *reinterpret_cast<tr_u32x4*>(base + A_HI + wr16 + 16 * p * ROWA) = ra16[p];
+            for (int p = 0; p < 2; ++p) {
+                tr_u32x4 w = ra16[p];
+                if constexpr (ATR) {      // widen, transform, round
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        w[d] = pack_bf16(tf(__uint_as_float(w[d] << 16), 2 * d), tf(__uint_as_float(w[d] & 0xffff0000u), 2 * d + 1));
+                }
+                *reinterpret_cast<tr_u32x4*>(base + A_HI + wr16 + 16 * p * ROWA) = w;
+            }
         } else {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) split_store(base + A_HI + wr32 + 8 * p * ROWA, base + A_LO + wr32 + 8 * p * ROWA, ra[p]);
+            for (int p = 0; p < 4; ++p) {
+                float4 v = ra[p];
+                if constexpr (ATR) v = make_float4(tf(v.x, 0), tf(v.y, 1), tf(v.z, 2), tf(v.w, 3));
+                split_store(base + A_HI + wr32 + 8 * p * ROWA, base + A_LO + wr32 + 8 * p * ROWA, v);
+            }
         }
     };
     // transposed reads: lane 4 q + pp of 16-lane group g addresses row q, channels 4 pp .. of the group's 4 x 16 block; groups 0 / 1 take
@@ -1668,19 +1695,21 @@ static bool gemm_tn_256(long long M, int KA, int KB, int batch)
 }
 
 // the transposed-read kernel (gemm_tn_tr_kernel): b-channels per block, or 0 where it is not built (LPD_TN_TR=0: never)
-static int tn_tr_tb(long long M, int KA, int KB, int batch, bool a_bf16)
+static int tn_tr_tb(long long M, int KA, int KB, int batch, bool a_bf16, bool act = false)      // act: with the operand transform (this kernel only)
 {
     static const bool on = [] { const char* e = getenv("LPD_TN_TR"); return !(e && e[0] == '0'); }();
-    if (!on || KA % 256 != 0 || KB % 64 != 0 || M % 32 != 0 || M < 2048) return 0;
+    if (KA % 256 != 0 || KB % 64 != 0 || M % 32 != 0 || M < 2048) return 0;
+    if (act) return KB % 256 == 0 ? 256 : (KB % 128 == 0 ? 128 : 64);
+    if (!on) return 0;
     // fp32 rows as A leave room for ONE block per CU: the pooling's 4 x 44 tiles of 4096 rows then run as 176 or 352 blocks on 256 CUs
     // (208 us against 190 on the register-transposing kernel, which holds several blocks per CU)
     if (!a_bf16 && batch > 1) return 0;
     return KB % 256 == 0 ? 256 : (KB % 128 == 0 ? 128 : 64);
 }
 
-static long long gemm_tn_splits(long long M, int KA, int KB, int batch, bool a_bf16 = true)
+static long long gemm_tn_splits(long long M, int KA, int KB, int batch, bool a_bf16 = true, bool act = false)
 {
-    if (const int tb = tn_tr_tb(M, KA, KB, batch, a_bf16)) {
+    if (const int tb = tn_tr_tb(M, KA, KB, batch, a_bf16, act)) {
         // blocks per CU by LDS: two with bf16 rows as A and narrow B tiles (61 / 82 KiB), else one
         const long long tiles = (long long)(KA / 256) * (KB / tb) * batch, cap = (tb == 256 || !a_bf16) ? 256 : 512;
         long long splits = 1;
@@ -1706,8 +1735,40 @@ extern "C" long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB, int batc
     return (a > b ? a : b) * batch * KA * KB;
 }
 
+extern "C" long long lpd_gemm_tn_act_ws_floats(long long M, int KA, int KB, int batch, int a_bf16);
+
+// lpd_gemm_tn with the operand transform of gemm_tn_tr_kernel: the rows of A are act(a_scale[a] A[m][a] + a_shift[a]).  Built on the
+// transposed-read kernel only (KA % 256 == 0, M % 32 == 0, M >= 2048).
+extern "C" int lpd_gemm_tn_act(const void* A_, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
+                               int batch, long long sA, long long sB, int a_bf16, const float* a_scale, const float* a_shift, int a_act,
+                               float a_slope, void* stream_);
+
+static int gemm_tn_impl(const void* A_, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
+                        int batch, long long sA, long long sB, int a_bf16, const float* a_scale, const float* a_shift, float a_ns, void* stream_);
+
+extern "C" long long lpd_gemm_tn_act_ws_floats(long long M, int KA, int KB, int batch, int a_bf16)
+{
+    if (batch < 1) batch = 1;
+    return gemm_tn_splits(M, KA, KB, batch, a_bf16 != 0, true) * batch * KA * KB;
+}
+
 extern "C" int lpd_gemm_tn(const void* A_, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
                            int batch, long long sA, long long sB, int a_bf16, void* stream_)
+{
+    return gemm_tn_impl(A_, lda, B, ldb, dW, ws, M, KA, KB, batch, sA, sB, a_bf16, nullptr, nullptr, 1.0f, stream_);
+}
+
+extern "C" int lpd_gemm_tn_act(const void* A_, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
+                               int batch, long long sA, long long sB, int a_bf16, const float* a_scale, const float* a_shift, int a_act,
+                               float a_slope, void* stream_)
+{
+    LPD_CHECK_ARG(a_scale && a_shift && a_act >= 0 && a_act <= 2, "lpd_gemm_tn_act: scale / shift / activation");
+    return gemm_tn_impl(A_, lda, B, ldb, dW, ws, M, KA, KB, batch, sA, sB, a_bf16, a_scale, a_shift,
+                        a_act == 0 ? 1.0f : (a_act == 1 ? 0.0f : a_slope), stream_);
+}
+
+static int gemm_tn_impl(const void* A_, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
+                        int batch, long long sA, long long sB, int a_bf16, const float* a_scale, const float* a_shift, float a_ns, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     const float* A = reinterpret_cast<const float*>(A_);      // a_bf16: bf16 rows (lda, sA in bf16 elements)
@@ -1715,23 +1776,29 @@ extern "C" int lpd_gemm_tn(const void* A_, long long lda, const float* B, long l
     LPD_CHECK_ARG(KA > 0 && KA % 128 == 0 && KB > 0 && KB % 64 == 0, "lpd_gemm_tn: KA %% 128 and KB %% 64 required (KA=%d KB=%d)", KA, KB);
     LPD_CHECK_ARG(lda % (a_bf16 ? 8 : 4) == 0 && ldb % 4 == 0 && sA % (a_bf16 ? 8 : 4) == 0 && sB % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
                   "lpd_gemm_tn: operands must be 16-byte aligned rows");
-    const long long splits = gemm_tn_splits(M, KA, KB, batch, a_bf16 != 0);
+    const bool act = a_scale != nullptr;
+    LPD_CHECK_ARG(!act || tn_tr_tb(M, KA, KB, batch, a_bf16 != 0, true),
+                  "lpd_gemm_tn_act: the operand transform is built for KA %% 256 == 0, M %% 32 == 0, M >= 2048 (M=%lld KA=%d)", M, KA);
+    const long long splits = gemm_tn_splits(M, KA, KB, batch, a_bf16 != 0, act);
     long long rps = (M + splits - 1) / splits;
     rps = (rps + 63) / 64 * 64;
-    if (const int tb = tn_tr_tb(M, KA, KB, batch, a_bf16 != 0)) {
+    if (const int tb = tn_tr_tb(M, KA, KB, batch, a_bf16 != 0, act)) {
         rps = (M + splits - 1) / splits;
         rps = (rps + 31) / 32 * 32;
         const long long blocks = (long long)(KA / 256) * (KB / tb) * splits * batch;
         LPD_CHECK_ARG(blocks < (1ll << 31), "lpd_gemm_tn: too many blocks");
         const int lds_tr = 2 * ((a_bf16 ? 1 : 2) * 32 * 576 + 2 * 32 * (tb * 2 + 64));
-#define LPD_TN_TR_LAUNCH(AB_, TB_)                                                                                                          \
+#define LPD_TN_TR_LAUNCH(AB_, TB_, TR_)                                                                                                     \
     do {                                                                                                                                    \
-        (void)hipFuncSetAttribute((const void*)gemm_tn_tr_kernel<AB_, TB_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_tr);            \
-        hipLaunchKernelGGL((gemm_tn_tr_kernel<AB_, TB_>), dim3((unsigned)blocks), dim3(512), lds_tr, stream, A_, lda, B, ldb, ws, KA, KB, rps, \
-                           (int)splits, M, sA, sB);                                                                                         \
+        (void)hipFuncSetAttribute((const void*)gemm_tn_tr_kernel<AB_, TB_, TR_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_tr);       \
+        hipLaunchKernelGGL((gemm_tn_tr_kernel<AB_, TB_, TR_>), dim3((unsigned)blocks), dim3(512), lds_tr, stream, A_, lda, B, ldb, ws, KA, KB, \
+                           rps, (int)splits, M, sA, sB, a_scale, a_shift, a_ns);                                                            \
     } while (0)
-        if (a_bf16) { if (tb == 256) LPD_TN_TR_LAUNCH(true, 256); else if (tb == 128) LPD_TN_TR_LAUNCH(true, 128); else LPD_TN_TR_LAUNCH(true, 64); }
-        else { if (tb == 256) LPD_TN_TR_LAUNCH(false, 256); else if (tb == 128) LPD_TN_TR_LAUNCH(false, 128); else LPD_TN_TR_LAUNCH(false, 64); }
+        if (act) {      // the operand transform: the 64-wide tile (NetVLAD pooling and assignment weight gradient)
+            LPD_CHECK_ARG(tb == 64, "lpd_gemm_tn_act: built for KB %% 128 != 0 (64-wide b tiles), KB=%d", KB);
+            if (a_bf16) LPD_TN_TR_LAUNCH(true, 64, true); else LPD_TN_TR_LAUNCH(false, 64, true);
+        } else if (a_bf16) { if (tb == 256) LPD_TN_TR_LAUNCH(true, 256, false); else if (tb == 128) LPD_TN_TR_LAUNCH(true, 128, false); else LPD_TN_TR_LAUNCH(true, 64, false); }
+        else { if (tb == 256) LPD_TN_TR_LAUNCH(false, 256, false); else if (tb == 128) LPD_TN_TR_LAUNCH(false, 128, false); else LPD_TN_TR_LAUNCH(false, 64, false); }
 #undef LPD_TN_TR_LAUNCH
         LPD_CHECK_LAUNCH("lpd_gemm_tn(tr)");
         const int n = KA * KB;

@@ -49,7 +49,7 @@ SIGNATURES = {
                           _c_int, _c_f, _c_p, _c_p, _c_ll, _c_p],
     "lpd_softmax_affine_parts": [_c_p, _c_int, _c_ll, _c_p, _c_int, _c_p, _c_p, _c_int, _c_p, _c_int, _c_p],
     "lpd_split_panels": [_c_p, _c_ll, _c_int, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_p],
-    "lpd_gemm_x3w_batched": [_c_p, _c_int, _c_int, _c_p, _c_ll, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "lpd_gemm_x3w_batched": [_c_p, _c_int, _c_int, _c_p, _c_ll, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_int, _c_f, _c_int, _c_p],
     "lpd_gemm_x3w_bf16a": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "lpd_gemm_x3w_act": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_p, _c_int, _c_int, _c_int, _c_p],
     "lpd_gemm_x3w_stats": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_p, _c_p],
@@ -144,11 +144,14 @@ SIGNATURES = {
     "lpd_gemm_tn_bf16": [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_p],
     "lpd_gemm_tn_ws_floats": [_c_ll, _c_int, _c_int, _c_int],
     "lpd_gemm_tn": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_int, _c_p],
+    "lpd_gemm_tn_act": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p],
+    "lpd_gemm_tn_act_ws_floats": [_c_ll, _c_int, _c_int, _c_int, _c_int],
     "lpd_metric_loss": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_ll, _c_p, _c_ll, _c_int, _c_int, _c_int,
                         _c_int, _c_f, _c_f, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
 }
 _RESTYPES = {"lpd_last_error": ctypes.c_char_p, "lpd_stat_ws_bytes": ctypes.c_longlong, "lpd_knn_workspace_floats": ctypes.c_longlong,
              "lpd_gemm_prep_b_bytes": ctypes.c_longlong, "lpd_gemm_tn_bf16_ws_floats": ctypes.c_longlong, "lpd_gemm_tn_ws_floats": ctypes.c_longlong,
+             "lpd_gemm_tn_act_ws_floats": ctypes.c_longlong,
              "lpd_edge_dw_sel_bf16_ws_bytes": ctypes.c_longlong}
 
 _lib = None

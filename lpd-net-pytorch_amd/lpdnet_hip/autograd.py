@@ -960,10 +960,20 @@ class _NetVLADTrainFn(torch.autograd.Function):
         M = B * N
         dev = feat.device
         Bp = (B + 31) // 32 * 32                                    # rows padded so K = Bp weight-gradient GEMMs are legal
+        aff = None
         if pending is not None:      # `feat` is the trunk's RAW conv3 output: bn3 affine + activation in the assignment's operand loader
-            feat, a0 = ops.gemm_act(feat.detach(), vlad.cluster_weights, *pending, out_bf16=feat.dtype == torch.bfloat16)
-            if engine.DEBUG_AUX is not None:      # test hook: the trunk's ACTIVATED output rows (PointNetVlad.forward records the raw ones otherwise)
-                engine.DEBUG_AUX["feat"] = feat
+            raw, raw16 = feat.detach(), feat.dtype == torch.bfloat16
+            if ops.feat_in_loader_applies(B, N, E, K):
+                # ... and in the loaders of the pooling, dA and assignment-weight-gradient products: the activated map is never stored
+                _, a0 = ops.gemm_act(raw, vlad.cluster_weights, *pending, out_bf16=raw16, store=False)
+                feat, aff = raw, tuple(pending)
+                if engine.DEBUG_AUX is not None:      # test hook: the trunk's ACTIVATED output rows
+                    act_rows = ops.affine_act(raw.float() if raw16 else raw, *pending)
+                    engine.DEBUG_AUX["feat"] = act_rows.to(torch.bfloat16) if raw16 else act_rows
+            else:
+                feat, a0 = ops.gemm_act(raw, vlad.cluster_weights, *pending, out_bf16=raw16)
+                if engine.DEBUG_AUX is not None:
+                    engine.DEBUG_AUX["feat"] = feat
         else:
             a0 = ops.gemm(feat, vlad.cluster_weights, b_kmajor=True)    # [M,K] raw
         if vlad.add_batch_norm:
@@ -972,7 +982,7 @@ class _NetVLADTrainFn(torch.autograd.Function):
         else:
             sta = None
             a = ops.softmax_affine(a0, torch.ones_like(vlad.cluster_biases), vlad.cluster_biases)
-        vraw = ops.pool_tn(feat.view(B, N, E), a.view(B, N, K))
+        vraw = ops.gemm_tn(feat.view(B, N, E), a.view(B, N, K), a_affine=aff) if aff is not None else ops.pool_tn(feat.view(B, N, E), a.view(B, N, K))
         if vraw is None:
             vraw = ops.gemm(feat.view(B, N, E), a.view(B, N, K), a_kmajor=True, b_kmajor=True, splits=engine._pool_splits(B, N, E))
         aux = {}
@@ -983,7 +993,7 @@ class _NetVLADTrainFn(torch.autograd.Function):
         h = torch.zeros((Bp, O), dtype=torch.float32, device=dev)
         ops.affine_act(h0, sth.scale, sth.shift, out=h, rows=B)
         ctx.vlad, ctx.dims = vlad, (B, N, M, E, K, O, Bp)
-        S = dict(feat=feat, a0=a0, sta=sta, a=a, aux=aux, v=v, h0=h0, sth=sth, h=h)
+        S = dict(feat=feat, aff=aff, a0=a0, sta=sta, a=a, aux=aux, v=v, h0=h0, sth=sth, h=h)
         ctx.saved = S
         if not vlad.gating:
             return h[:B].clone()
@@ -1038,9 +1048,9 @@ class _NetVLADTrainFn(torch.autograd.Function):
         cw2 = vlad.cluster_weights2.view(E, K)
         dvraw, dasum, dcw2 = ops.vlad_finalize_bwd(dv, S["v"], S["aux"], cw2, B, E, K)
         del dv
-        feat, a = S["feat"], S["a"]
+        feat, a, aff = S["feat"], S["a"], S["aff"]      # (aff: `feat` holds the RAW map, the products transform it in their loaders)
         # vraw[b] = feat[b]^T a[b]
-        da = ops.gemm(feat.view(B, N, E), dvraw, a_kmajor=False, b_kmajor=True)    # [B,N,K]
+        da = ops.gemm(feat.view(B, N, E), dvraw, a_kmajor=False, b_kmajor=True, a_affine=aff)    # [B,N,K]
         ds = ops.softmax_bwd(a, da.view(M, K), dasum, N)
         del da
         # dfeat = a dVraw^T (pooling) + dA0 Wc^T (assignment): ONE batched product with the operands side by side,
@@ -1055,7 +1065,7 @@ class _NetVLADTrainFn(torch.autograd.Function):
         else:
             da0 = ops.affine_act(ds, None, None, ops.ACT_NONE, out=ada[:, K:])         # a = softmax(a0 + cluster_biases)
             g_assign = [ops.colsum(ds)]
-        dwc = _dweight(feat, da0)                                                  # feat^T dA0 [E,K]
+        dwc = ops.gemm_tn(feat, da0, a_affine=aff) if aff is not None else _dweight(feat, da0)      # feat^T dA0 [E,K]
         rhs = torch.empty((B, E, 2 * K), dtype=torch.float32, device=dev)
         ops.affine_act(dvraw.view(B * E, K), None, None, ops.ACT_NONE, out=rhs.view(B * E, 2 * K)[:, :K])
         rhs[:, :, K:] = vlad.cluster_weights.detach()                              # parameter-sized broadcast (plumbing)

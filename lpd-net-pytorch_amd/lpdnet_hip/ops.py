@@ -324,12 +324,14 @@ def consumer_sync(mark, *tensors):
 
 
 def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=None, act=ACT_NONE, slope=0.01,
-         out=None, splits=1, accumulate=False, exact=False, a_panels=False, out_panels=False, out_bf16=False):
+         out=None, splits=1, accumulate=False, exact=False, a_panels=False, out_panels=False, out_bf16=False, a_affine=None):
     """Single (2-D) or batched (3-D) GEMM with fused epilogue.
 
     out_bf16: the result is a bfloat16 tensor (built on the transposed short-reduction kernel only: lpd_gemm_x3t_rows).
     A may be bfloat16 rows for the batched per-problem-weight product (lpd_gemm_x3w_batched) -- the bf16-storage training mode's
     conv3-map tensors; every other combination raises.
+    a_affine = (scale [K], shift [K], act, slope): A's rows are act(scale * A + shift) -- applied in the operand loader of the batched
+    per-problem-weight product (nothing stored; bf16 rows: rounded to bf16 again); every other path raises.
 
     a_panels / out_panels: A / out are cloud-panel tensors [B, cols/8, N, 8] (the layout the cloud-resident K-agg kernel
     streams; see panels_empty / panels_to_rows) instead of row-major matrices.
@@ -380,7 +382,7 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
     # a short reduction (K = 64 / 128) over many rows: the transposed product lpd_gemm_x3t_rows (data rows as the MFMA's B operand, one
     # barrier, float4 stores) -- the 128 x 128 block kernel spends it in barriers and 4-byte stores (SN1 projection of the training step 211 us)
     if (GEMM_BF16X3 and X3T_ROWS and not exact and _EXACT.depth == 0 and (_FAST.depth == 0 or out_bf16) and not a_kmajor and splits == 1 and not a16
-            and not accumulate and nb * M >= 16384 and nb <= 65535 and lib.lpd_gemm_x3t_rows_applies(M, N, K, act, lda, ldc)
+            and a_affine is None and not accumulate and nb * M >= 16384 and nb <= 65535 and lib.lpd_gemm_x3t_rows_applies(M, N, K, act, lda, ldc)
             and A.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and sA % 4 == 0 and sC % (8 if out_bf16 else 4) == 0
             and (not out_bf16 or ldc % 8 == 0)):
         if batched:      # per-problem weights (the NetVLAD backward's [a | dA0] . [dVraw_b | Wc]^T): their fragments, every call
@@ -402,9 +404,16 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
         fb = int(lib.lpd_gemm_prep_b_bytes(N, K))
         frags = torch.empty((nb * fb,), dtype=torch.uint8, device=A.device)
         _call("gemm_prep_b", lib.lpd_gemm_prep_b_batch, _ptr(B), ldb, 1, N, K, nb, sB, _ptr(frags), _stream())
+        if a_affine is not None:
+            a_sc, a_sh, a_act, a_slope = _vec(a_affine[0], "a_affine scale", K), _vec(a_affine[1], "a_affine shift", K), a_affine[2], a_affine[3]
+        else:
+            a_sc = a_sh = None
+            a_act, a_slope = ACT_NONE, 0.0
         _call(f"gemmx3w[{M}x{N}x{K}]x{nb}", lib.lpd_gemm_x3w_batched, _ptr(A), lda, int(a16), _ptr(frags), fb, M, _ptr(out), ldc, nb * M, N, K,
-              16 if (_FAST.depth > 0 and not a16) else 0, _stream())
+              _ptr(a_sc), _ptr(a_sh), a_act, float(a_slope), 16 if (_FAST.depth > 0 and not a16 and a_affine is None) else 0, _stream())
         return out
+    if a_affine is not None:
+        raise ValueError(f"gemm: an operand transform is built for the batched per-problem-weight product only (M={M}, N={N}, K={K}, batch {nb})")
     if a16:
         raise ValueError(f"gemm: bf16 rows as A are built for the batched per-problem-weight product only (M={M}, N={N}, K={K}, batch {nb})")
     if (GEMM_BF16X3 and not exact and _EXACT.depth == 0 and not a_kmajor and not batched and splits == 1
@@ -1056,11 +1065,13 @@ def gemm_act_applies(M, N, K):
             and N * K <= (1 << 22))
 
 
-def gemm_act(x, w_kn, a_scale, a_shift, act, slope, out_bf16=False):
+def gemm_act(x, w_kn, a_scale, a_shift, act, slope, out_bf16=False, store=True):
     """(x_act, c): x_act = act(a_scale * x + a_shift) (rows [M, K]: the BatchNorm affine + activation of the layer in front, applied in
     the product's operand loader and stored on the way) and c = x_act @ w_kn for a k-major weight [K, N], N <= 128
     (include/lpd_hip.h lpd_gemm_x3w_act: util/lpdnet_model.py:262 -> util/PointNetVlad.py:48).
-    x may be bfloat16 rows (K % 32 == 0); out_bf16: x_act is stored as bfloat16 and the product takes the stored (rounded) values."""
+    x may be bfloat16 rows (K % 32 == 0); out_bf16: x_act is stored as bfloat16 and the product takes the stored (rounded) values.
+    store=False: x_act is not written (None is returned for it) -- its consumers apply the same transform in their own loaders
+    (gemm_tn / gemm with a_affine); with out_bf16 the product still takes the values rounded to bfloat16."""
     x16 = x.dtype == torch.bfloat16
     _req(x, "x", torch.bfloat16 if x16 else torch.float32)
     if x.dim() != 2 or x.stride(1) != 1:
@@ -1075,7 +1086,7 @@ def gemm_act(x, w_kn, a_scale, a_shift, act, slope, out_bf16=False):
     frags = _weight_frags(w_kn, True, N, K)
     if x16 and (K % 32 != 0 or ldx % 4 != 0):
         raise ValueError("gemm_act: bf16 rows need K % 32 == 0")
-    x_act = torch.empty((M, K), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    x_act = torch.empty((M, K), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device) if store else None
     c = torch.empty((M, N), dtype=torch.float32, device=x.device)
     lib = _lib.load()
     _call(f"gemmx3w+act[{M}x{N}x{K}]", lib.lpd_gemm_x3w_act, _ptr(x), ldx, _ptr(frags), _ptr(c), N, M, N, K, None, _ptr(a_scale), _ptr(a_shift),
@@ -1704,10 +1715,29 @@ DG2_BWD_FUSED = os.environ.get("LPD_DG2_BWD_FUSED", "1") != "0"    # bf16 storag
 GEMM_TN = os.environ.get("LPD_GEMM_TN", "1") != "0"      # weight gradients on the register-transposing kernel (lpd_gemm_tn)
 
 
-def gemm_tn(A, B, rows=None):
+FEAT_IN_LOADER = os.environ.get("LPD_FEAT_IN_LOADER", "1") != "0"   # train mode: no activated conv3 map -- its consumers transform the raw one
+
+
+def feat_in_loader_applies(B, N, E, K):
+    """the NetVLAD head can run on the trunk's RAW last-layer output (BatchNorm affine + activation in the loaders of the assignment,
+    pooling, dA and assignment-weight-gradient products): shapes all four kernels are built for"""
+    return (FEAT_IN_LOADER and GEMM_TN and GEMM_BF16X3 and X3W_BATCHED and _EXACT.depth == 0 and _FAST.depth == 0 and K == 64 and E % 256 == 0
+            and E >= 256 and E * K <= (1 << 22) and N % 128 == 0 and N >= 2048 and B * N >= 16384 and B * N < (1 << 31))
+
+
+def gemm_tn_act_applies(A, B):
+    """the operand transform of gemm_tn(a_affine=...) is built for these operands"""
+    M, KA, KB = A.shape[-2], A.shape[-1], B.shape[-1]
+    return (GEMM_TN and GEMM_BF16X3 and _EXACT.depth == 0 and KA % 256 == 0 and KB % 64 == 0 and KB % 128 != 0 and M % 32 == 0 and M >= 2048
+            and A.stride(-1) == 1 and B.stride(-1) == 1 and A.stride(-2) % (8 if A.dtype == torch.bfloat16 else 4) == 0 and B.stride(-2) % 4 == 0
+            and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def gemm_tn(A, B, rows=None, a_affine=None):
     """dW [KA, KB] = A^T B over the (first `rows`) rows; A [M, KA], B [M, KB] fp32 row-major (column slices allowed);
     KA % 128 == 0, KB % 64 == 0.  Split-bf16 (three products): the accuracy of lpd_gemm_bf16x3.  A may be bfloat16 rows (they are
-    the hi image: two products)."""
+    the hi image: two products).  a_affine = (scale [KA], shift [KA], act, slope): A's rows are act(scale * A + shift), applied where
+    they are staged (lpd_gemm_tn_act; gemm_tn_act_applies)."""
     a16 = A.dtype == torch.bfloat16
     if a16:
         _req(A, "A", torch.bfloat16)
@@ -1727,8 +1757,16 @@ def gemm_tn(A, B, rows=None):
         KA, KB = A.shape[1], B.shape[1]
         shape = (KA, KB)
     lib = _lib.load()
-    ws = torch.empty((int(lib.lpd_gemm_tn_ws_floats(M, KA, KB, nb)),), dtype=torch.float32, device=A.device)
     dW = torch.empty(shape, dtype=torch.float32, device=A.device)
+    if a_affine is not None:
+        if rows is not None or not gemm_tn_act_applies(A, B):
+            raise ValueError(f"gemm_tn: the operand transform is not built for these operands (M={M}, KA={KA}, KB={KB})")
+        a_sc, a_sh = _vec(a_affine[0], "a_affine scale", KA), _vec(a_affine[1], "a_affine shift", KA)
+        ws = torch.empty((int(lib.lpd_gemm_tn_act_ws_floats(M, KA, KB, nb, int(a16))),), dtype=torch.float32, device=A.device)
+        _call(f"gemm_tn+act[{KA}x{KB}x{M}]" + (f"x{nb}" if nb > 1 else ""), lib.lpd_gemm_tn_act, _ptr(A), lda, _ptr(B), ldb, _ptr(dW), _ptr(ws), M,
+              KA, KB, nb, sA, sB, int(a16), _ptr(a_sc), _ptr(a_sh), a_affine[2], float(a_affine[3]), _stream())
+        return dW
+    ws = torch.empty((int(lib.lpd_gemm_tn_ws_floats(M, KA, KB, nb)),), dtype=torch.float32, device=A.device)
     _call(f"gemm_tn[{KA}x{KB}x{M}]" + (f"x{nb}" if nb > 1 else ""), lib.lpd_gemm_tn, _ptr(A), lda, _ptr(B), ldb, _ptr(dW), _ptr(ws), M, KA,
           KB, nb, sA, sB, int(a16), _stream())
     return dW

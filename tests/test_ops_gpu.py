@@ -1440,3 +1440,40 @@ def test_bf16_map_operators(cuda):
         ops.gemm(ada, rhs.transpose(1, 2).contiguous(), a_kmajor=False, b_kmajor=True, out_bf16=True, splits=2)
     with pytest.raises(ValueError):
         ops.gemm(big16, w3, b_kmajor=True)
+
+
+@pytest.mark.parametrize("a16", [False, True])
+def test_operand_transform_without_a_stored_map(cuda, a16):
+    """The NetVLAD head on the trunk's RAW last-layer output (ops.feat_in_loader_applies): the BatchNorm affine + activation is applied in
+    the operand loaders of the assignment (lpd_gemm_x3w_act without a_out), the pooling and the assignment weight gradient
+    (lpd_gemm_tn_act, batched and plain, strided B) and dA (lpd_gemm_x3w_batched with a_scale) -- each against the same product on the
+    map lpd_gemm_x3w_act stores: equal bits for fp32 rows (the same multiply-then-add), and for bf16 rows (the same rounded map)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    nb, Np, E, K = 4, 4096, 1024, 64
+    M = nb * Np
+    raw = torch.randn(M, E, generator=g).to(cuda)
+    if a16:
+        raw = raw.to(torch.bfloat16)
+    wc = (torch.randn(E, K, generator=g) / 32).to(cuda)
+    sc, sh = (0.5 + torch.rand(E, generator=g)).to(cuda), (0.3 * torch.randn(E, generator=g)).to(cuda)
+    sc[::5] *= -1
+    aff = (sc, sh, ops.ACT_LEAKY, 0.2)
+    assert ops.feat_in_loader_applies(nb, Np, E, K)
+    stored, c_ref = ops.gemm_act(raw, wc, *aff, out_bf16=a16)
+    none, c = ops.gemm_act(raw, wc, *aff, out_bf16=a16, store=False)
+    assert none is None and torch.equal(c, c_ref)
+    a = torch.softmax(torch.randn(M, K, generator=g), dim=1).to(cuda)
+    pooled = ops.gemm_tn(raw.view(nb, Np, E), a.view(nb, Np, K), a_affine=aff)
+    assert _rel(pooled, torch.einsum("bme,bmk->bek", stored.double().view(nb, Np, E), a.double().view(nb, Np, K))) < 2e-5
+    if a16:      # the same kernel on the stored bf16 map: identical bits
+        assert torch.equal(pooled, ops.gemm_tn(stored.view(nb, Np, E), a.view(nb, Np, K)))
+    wide = torch.randn(M, 2 * K, generator=g).to(cuda)
+    da0 = wide[:, K:]
+    dwc = ops.gemm_tn(raw, da0, a_affine=aff)
+    assert _rel(dwc, stored.double().t() @ da0.double()) < 2e-5
+    dv = (torch.randn(nb, E, K, generator=g) / 32).to(cuda)
+    da = ops.gemm(raw.view(nb, Np, E), dv, a_kmajor=False, b_kmajor=True, a_affine=aff)
+    assert torch.equal(da, ops.gemm(stored.view(nb, Np, E), dv, a_kmajor=False, b_kmajor=True))
+    with pytest.raises(ValueError):
+        ops.gemm_tn(raw, wide, a_affine=aff)          # 128-wide B: not built
