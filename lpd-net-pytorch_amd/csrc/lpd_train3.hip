@@ -571,6 +571,184 @@ __global__ __launch_bounds__(512, 2) void edge_dw_sel_f32_kernel(const float* __
     }
 }
 
+// ------------------------------------------------------------------------------------------ (2t)
+// The same slab (S = D^T Y | G = Y^T Y | column sums of Y) on ROW-MAJOR LDS images read with ds_read_b64_tr_b16 (cf. gemm_tn_tr_kernel,
+// lpd_train2.hip): the rows of Y are copied (bf16) or split into hi / lo (fp32) where they are staged, D is built row by row from (arg,
+// dpre) of the row's point -- no register transposes -- and every MFMA operand (one channel, 8 consecutive rows) comes out of two
+// transposed reads.  Image rows 256 + 64 bytes apart (the 4 rows of a read on 4 x 64 bytes of different banks), 32-row chunks in two
+// buffers, one barrier per chunk, the rows of chunk n + 2 requested at the top of chunk n.  H: bf16 tensors, one product per term; else
+// fp32 tensors, three.  Wave (wa, wb): row tiles wa of S and of G, column tiles 2 wb, 2 wb + 1 (the slab layout of the kernels above).
+typedef short dw_i16x4 __attribute__((ext_vector_type(4)));
+typedef short dw_i16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned dw_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned dw_u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bf16x8 dw_tr_frag(const unsigned char* p0, const unsigned char* p1)
+{
+    typedef dw_i16x4 __attribute__((address_space(3))) * lds_ptr;
+    const dw_i16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p0);
+    const dw_i16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p1);
+    const dw_i16x8 v = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool H>
+__global__ __launch_bounds__(512, 2) void edge_dw_sel_tr_kernel(const void* __restrict__ Y_, const uint8_t* __restrict__ arg,
+                                                                const void* __restrict__ dpre_, int k, long long E, long long Mp,
+                                                                long long rows_per_block, float* __restrict__ slabs)
+{
+    constexpr int ROWB = 320, IMG = 32 * ROWB;
+    constexpr int BUF = (H ? 2 : 4) * IMG;
+    constexpr int Y_HI = 0, Y_LO = IMG, D_HI = (H ? 1 : 2) * IMG, D_LO = D_HI + IMG;
+    constexpr int NR = H ? 1 : 2;                  // rows of a chunk per staging thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char dwt[];       // [2 buffers][Y hi [Y lo] D hi [D lo]][32][ROWB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const long long m_begin = (long long)blockIdx.x * rows_per_block;
+    const long long m_end = min(E, m_begin + rows_per_block);
+    const int nchunk = m_end > m_begin ? (int)((m_end - m_begin) / 32) : 0;      // whole chunks (host check)
+    // staging: fp32 -- rows tid / 32 + 16 p, channel quad tid % 32; bf16 -- row tid / 16, channel octet tid % 16
+    const int srow = H ? tid >> 4 : tid >> 5, sq = H ? tid & 15 : tid & 31;
+    const float* Y32 = reinterpret_cast<const float*>(Y_);
+    const uint16_t* Y16 = reinterpret_cast<const uint16_t*>(Y_);
+    const float* dp32 = reinterpret_cast<const float*>(dpre_);
+    const uint16_t* dp16 = reinterpret_cast<const uint16_t*>(dpre_);
+    const unsigned ku = (unsigned)k;
+    struct Raw { float4 y[NR]; dw_u32x4 d[NR]; dw_u32x2 a[NR]; unsigned t[NR]; };      // rows of Y; dpre and arg of the row's point; its slot
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto load = [&](Raw& R, int chunk) {
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const long long e = m_begin + (long long)chunk * 32 + srow + 16 * p;
+            const unsigned i = (unsigned)e / ku;
+            R.t[p] = (unsigned)e - i * ku;
+            if constexpr (H) {
+                R.y[p] = *reinterpret_cast<const float4*>(Y16 + e * 128 + sq * 8);                        // eight bf16 values as raw bits
+                R.d[p] = *reinterpret_cast<const dw_u32x4*>(dp16 + (long long)i * 128 + sq * 8);
+                R.a[p] = *reinterpret_cast<const dw_u32x2*>(arg + (long long)i * 128 + sq * 8);
+            } else {
+                R.y[p] = *reinterpret_cast<const float4*>(Y32 + e * 128 + sq * 4);
+                R.d[p] = *reinterpret_cast<const dw_u32x4*>(dp32 + (long long)i * 128 + sq * 4);
+                R.a[p][0] = *reinterpret_cast<const unsigned*>(arg + (long long)i * 128 + sq * 4);
+                R.a[p][1] = 0u;
+            }
+        }
+    };
+    auto split_store = [&](unsigned char* hi, unsigned char* lo, float v0, float v1, float v2, float v3) {
+        const uint32_t h01 = pack_bf16(v0, v1), h23 = pack_bf16(v2, v3);
+        const uint32_t l01 = pack_bf16(v0 - __uint_as_float(h01 << 16), v1 - __uint_as_float(h01 & 0xffff0000u));
+        const uint32_t l23 = pack_bf16(v2 - __uint_as_float(h23 << 16), v3 - __uint_as_float(h23 & 0xffff0000u));
+        *reinterpret_cast<uint2*>(hi) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(lo) = make_uint2(l01, l23);
+    };
+    auto stage = [&](const Raw& R, int buf) {
+        unsigned char* base = dwt + buf * BUF;
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const int row = srow + 16 * p;
+            const unsigned t = R.t[p];
+            if constexpr (H) {
+                const dw_u32x4 yw = __builtin_bit_cast(dw_u32x4, R.y[p]);
+                dw_u32x4 dw;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {      // channels 2 d, 2 d + 1 of the octet: bytes 2 d, 2 d + 1 of the arg octet
+                    const unsigned a = R.a[p][d >> 1] >> (16 * (d & 1));
+                    const unsigned keep = ((a & 0xffu) == t ? 0x0000ffffu : 0u) | (((a >> 8) & 0xffu) == t ? 0xffff0000u : 0u);
+                    dw[d] = R.d[p][d] & keep;
+                    cs[2 * d] += __uint_as_float(yw[d] << 16);
+                    cs[2 * d + 1] += __uint_as_float(yw[d] & 0xffff0000u);
+                }
+                *reinterpret_cast<dw_u32x4*>(base + Y_HI + row * ROWB + sq * 16) = yw;
+                *reinterpret_cast<dw_u32x4*>(base + D_HI + row * ROWB + sq * 16) = dw;
+            } else {
+                const float4 y = R.y[p];
+                cs[0] += y.x; cs[1] += y.y; cs[2] += y.z; cs[3] += y.w;
+                split_store(base + Y_HI + row * ROWB + sq * 8, base + Y_LO + row * ROWB + sq * 8, y.x, y.y, y.z, y.w);
+                const unsigned a = R.a[p][0];
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = ((a >> (8 * c)) & 0xffu) == t ? __uint_as_float(R.d[p][c]) : 0.0f;
+                split_store(base + D_HI + row * ROWB + sq * 8, base + D_LO + row * ROWB + sq * 8, v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int rd = ((g >> 1) * 8 + q) * ROWB + ((g & 1) * 16 + pp * 4) * 2;
+    const int wa = wave & 3, wb = wave >> 2;
+    const int rd_a = rd + wa * 64, rd_b = rd + wb * 128;          // + 64 j
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    auto mma = [&](int buf, int s) {
+        const unsigned char* base = dwt + buf * BUF + s * 16 * ROWB;
+        const bf16x8 adh = dw_tr_frag(base + D_HI + rd_a, base + D_HI + rd_a + 4 * ROWB);
+        const bf16x8 ayh = dw_tr_frag(base + Y_HI + rd_a, base + Y_HI + rd_a + 4 * ROWB);
+        bf16x8 adl, ayl;
+        if constexpr (!H) {
+            adl = dw_tr_frag(base + D_LO + rd_a, base + D_LO + rd_a + 4 * ROWB);
+            ayl = dw_tr_frag(base + Y_LO + rd_a, base + Y_LO + rd_a + 4 * ROWB);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16x8 bh = dw_tr_frag(base + Y_HI + rd_b + 64 * j, base + Y_HI + rd_b + 64 * j + 4 * ROWB);
+            if constexpr (!H) {
+                const bf16x8 bl = dw_tr_frag(base + Y_LO + rd_b + 64 * j, base + Y_LO + rd_b + 64 * j + 4 * ROWB);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(adl, bh, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ayl, bh, acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(adh, bl, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ayh, bl, acc[1][j], 0, 0, 0);
+            }
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(adh, bh, acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ayh, bh, acc[1][j], 0, 0, 0);
+        }
+    };
+    Raw r0, r1;
+    auto chunk = [&](int n, const Raw& cur, Raw& nxt) {
+        load(nxt, n + 2 < nchunk ? n + 2 : nchunk - 1);        // unconditional: the last chunks are re-read and dropped
+        mma(n & 1, 0);
+        if (n + 1 < nchunk) stage(cur, (n + 1) & 1);
+        mma(n & 1, 1);
+        __syncthreads();
+    };
+    if (nchunk > 0) {
+        load(r0, 0);
+        stage(r0, 0);
+        load(r0, nchunk > 1 ? 1 : 0);
+        __syncthreads();
+        for (int n = 0; n < nchunk; n += 2) {
+            chunk(n, r0, r1);
+            if (n + 1 < nchunk) chunk(n + 1, r1, r0);
+        }
+    }
+    float* slab = slabs + (size_t)blockIdx.x * (256 * 128 + 128);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int arow = i * 128 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                slab[(size_t)arow * 128 + wb * 64 + j * 32 + col] = acc[i][j][r];
+            }
+    // column sums of Y: the threads that share a channel group, in a fixed order
+    __syncthreads();
+    float* tmp = reinterpret_cast<float*>(dwt);
+    constexpr int CPT = H ? 8 : 4, NG = H ? 16 : 32, NRG = 512 / NG;      // channels per thread, channel groups, threads per group
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) tmp[(sq * NRG + srow) * CPT + e] = cs[e];
+    __syncthreads();
+    if (tid < 128) {
+        const int grp = tid / CPT, e = tid % CPT;
+        float t = 0.0f;
+        for (int r = 0; r < NRG; ++r) t += tmp[(grp * NRG + r) * CPT + e];
+        slab[256 * 128 + tid] = t;
+    }
+}
+
 // (3f) dY [E][128] (fp32) = dZ W2 with dZ generated in the loader from fp32 z: A = z a1 + a0 + delta dpre, split hi + lo, three products
 // with the staged weight rows s_c W2[c][:] (hi + lo).  512 threads share the weight images; a wave owns 32 rows and all 128 columns
 // (transposed tile); the result leaves through a wave-private LDS tile as whole 128-byte rows (cf. lpd_gemm_x3t_rows).
@@ -740,6 +918,13 @@ extern "C" int lpd_bn_sel_bwd_reduce_f32(const float* dOut, long long ldo, const
     return bn_sel_bwd_reduce_impl(dOut, ldo, Xsel, ldsel, M, C, scale, shift, mean, invstd, act, slope, nullptr, dpre, dbeta, dgamma, stat_ws, stream);
 }
 
+// LPD_DW_SEL_TR=0: the register-transposing kernels
+static bool edge_dw_sel_tr()
+{
+    static const bool on = [] { const char* e = getenv("LPD_DW_SEL_TR"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static long long edge_dw_sel_blocks(long long E)
 {
     long long b = E / 4096;
@@ -768,8 +953,17 @@ extern "C" int lpd_edge_dw_sel_bf16(const uint16_t* Y, const uint8_t* arg, const
     constexpr int lds = 2 * 128 * 528;
     double* red = reinterpret_cast<double*>(ws);
     float* slabs = reinterpret_cast<float*>(red + n);
-    (void)hipFuncSetAttribute((const void*)edge_dw_sel_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(edge_dw_sel_bf16_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, Y, arg, dpre16, k, E, M, rpb, slabs);
+    // (bf16 tensors: measured 343 us against 326 on the register-transposing kernel -- one product per term, the staging is copies
+    //  either way; the transposed-read kernel runs for LPD_DW_SEL_TR=2 only)
+    static const bool tr16 = [] { const char* e = getenv("LPD_DW_SEL_TR"); return e && e[0] == '2'; }();
+    if (tr16 && E < (1ll << 32)) {
+        constexpr int lds_tr = 2 * 2 * 32 * 320;
+        (void)hipFuncSetAttribute((const void*)edge_dw_sel_tr_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_tr);
+        hipLaunchKernelGGL(edge_dw_sel_tr_kernel<true>, dim3((unsigned)blocks), dim3(512), lds_tr, stream, Y, arg, dpre16, k, E, M, rpb, slabs);
+    } else {
+        (void)hipFuncSetAttribute((const void*)edge_dw_sel_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(edge_dw_sel_bf16_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, Y, arg, dpre16, k, E, M, rpb, slabs);
+    }
     LPD_CHECK_LAUNCH("lpd_edge_dw_sel_bf16");
     static_assert(n % 64 == 0, "slab_reduce_kernel: 64 elements per block");
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(n / 64), dim3(256), 0, stream, (const float*)slabs, red, n, (int)blocks);
@@ -818,8 +1012,14 @@ extern "C" int lpd_edge_dw_sel_f32(const float* Y, const uint8_t* arg, const flo
     constexpr int lds = 4 * 128 * 272;
     double* red = reinterpret_cast<double*>(ws);
     float* slabs = reinterpret_cast<float*>(red + n);
-    (void)hipFuncSetAttribute((const void*)edge_dw_sel_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(edge_dw_sel_f32_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, Y, arg, dpre, k, E, M, rpb, slabs);
+    if (edge_dw_sel_tr() && E < (1ll << 32)) {
+        constexpr int lds_tr = 2 * 4 * 32 * 320;
+        (void)hipFuncSetAttribute((const void*)edge_dw_sel_tr_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_tr);
+        hipLaunchKernelGGL(edge_dw_sel_tr_kernel<false>, dim3((unsigned)blocks), dim3(512), lds_tr, stream, Y, arg, dpre, k, E, M, rpb, slabs);
+    } else {
+        (void)hipFuncSetAttribute((const void*)edge_dw_sel_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(edge_dw_sel_f32_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, Y, arg, dpre, k, E, M, rpb, slabs);
+    }
     LPD_CHECK_LAUNCH("lpd_edge_dw_sel_f32");
     static_assert(n % 64 == 0, "slab_reduce_kernel: 64 elements per block");
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(n / 64), dim3(256), 0, stream, (const float*)slabs, red, n, (int)blocks);
