@@ -503,11 +503,13 @@ int lpd_edge_mlp_train(const float* P, int ldp, const float* Q, int ldq, const i
  *   lpd_edge_dense_bwd_apply: dP, dQ of U = P[nbr] + Q in closed form from ONE gather pass over the transposed graph (a G row and a Q
  *     row per edge): dP_j = s (sum G - deg m1 - m2 invstd (deg (P_j - mu) + sum Q_i)), dQ_j = s (gsum_j - k m1 - m2 invstd (S_j + k (Q_j - mu))).
  * bf16 != 0: Y1e, dpre2 and G are bf16; z_bf16 != 0: Z is bf16 (as lpd_edge_mlp_train stored it).  M % 32 == 0, 128 channels, k <= 255.
+ * Z may be NULL in both calls: lpd_edge_mlp_train then stores no Z, and lpd_edge_mlp_train_bwd forms the dense part of BatchNorm2's
+ *     backward as Y1e K (K = W2^T diag(-invstd2 m2 s2) W2, one bf16 product) from `kws` (128 * 128 + 128 floats of caller scratch).
  */
 int lpd_edge_mlp_train_bwd(const void* Z, const uint8_t* arg2, const void* dpre2, const float* W2, const float* scale2, const float* mean2,
                            const float* invstd2, const double* dbeta2, const double* dgamma2, const void* Y1e, const uint8_t* arg1,
                            const float* dx1, int lddx1, const float* beta1, const float* rgamma1, int bf16, int z_bf16, void* G, float* gsum,
-                           double* dbeta1, double* dgamma1, int M, int k, int act, float slope, float inv_ns, double* stat_ws, void* stream);
+                           double* dbeta1, double* dgamma1, int M, int k, int act, float slope, float inv_ns, float* kws, double* stat_ws, void* stream);
 int lpd_edge_dense_bwd_apply(const void* G, int bf16, const float* gsum, const float* S, const float* P, long long ldp, const float* Q,
                              long long ldq, const int32_t* rowptr, const int32_t* edges, float* dP, long long lddp, float* dQ, long long lddq,
                              long long M, int C, int k, const float* scale, const float* mean, const float* invstd, const double* dbeta,

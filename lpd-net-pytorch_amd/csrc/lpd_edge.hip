@@ -1011,11 +1011,13 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_kernel(EdgeMlpTr
     // The block's slabs of Y1e and Z (64 k rows) as buffer resources: a store is (resource, this thread's constant 32-bit offset,
     // scalar offset of the row) -- with flat pointers the compiler kept a 64-bit address register per store of the unrolled
     // epilogue (85-100 spilled registers)
-    const unsigned slab = (unsigned)EM_PTS * (unsigned)g.k * (CM * ES), slabz = (unsigned)EM_PTS * (unsigned)g.k * (CM * ESZ);
+    // (Z == null: a resource of ZERO records over Y -- out-of-range buffer stores are dropped by the hardware, so the epilogue's stores
+    //  stay in the instruction stream and move nothing: the backward then works without Z, lpd_edge_mlp_train_bwd)
+    const unsigned slab = (unsigned)EM_PTS * (unsigned)g.k * (CM * ES), slabz = g.Z ? (unsigned)EM_PTS * (unsigned)g.k * (CM * ESZ) : 0u;
     const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<unsigned char*>(g.Y) + (size_t)m0 * g.k * (CM * ES), 0, slab, 0x00020000);
     const __amdgpu_buffer_rsrc_t zres = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<unsigned char*>(g.Z) + (size_t)m0 * g.k * (CM * ESZ), 0, slabz, 0x00020000);
+        g.Z ? reinterpret_cast<unsigned char*>(g.Z) + (size_t)m0 * g.k * (CM * ESZ) : reinterpret_cast<unsigned char*>(g.Y), 0, slabz, 0x00020000);
     const unsigned rowb = (unsigned)g.k * (CM * ES), rowbz = (unsigned)g.k * (CM * ESZ);      // bytes between consecutive POINTS' rows of one slot
     const unsigned yoff = ((unsigned)prow * (unsigned)g.k * CM + c4 * 4) * ES;       // M k 128 ES < 2^32 (host check)
     const unsigned zoff = ((unsigned)(4 * h) * (unsigned)g.k * CM + (ZBF16 ? (n & ~1) : n)) * ESZ;
@@ -1150,20 +1152,66 @@ struct EdgeMlpBwdArgs {
     double* sum; double* sumx;                                  // replicas
     int M, k, act;
     float slope, inv_ns;
+    const uint16_t* Kb; const float* cvec;                      // NOZ: K as bf16 [n][m], constants [128] (edge_mlp_bwd_prep_kernel)
 };
 
 constexpr int EB_PTS = 32;
 
-template <bool BF16, bool ZBF16>
+// Without Z (NOZ).  dY1e = dZ (S2 W2) with dZ_c = delta dpre_c + a0_c + a1_c Z_c, and Z = Y1e W2^T, so the dense part is a product with
+// Y1e itself:   dY1e[e][n] = sum_c delta dpre[c] s2_c W2[c][n]  +  sum_m Y1e[e][m] K[m][n]  +  cvec[n],
+//     K[m][n] = sum_c a1_c s2_c W2[c][m] W2[c][n],   cvec[n] = sum_c a0_c s2_c W2[c][n]          (a1 = -invstd2 m2, a0 = mean2 invstd2 m2 - m1).
+// The forward need not store Z (0.92 GB at configs[2]) and this kernel reads Y1e once, as whole rows for the operand image, instead
+// of Z rows plus sixteen 2- / 4-byte elements of Y1e per lane and slot.  The K term is the mean-sized part of BatchNorm2's backward
+// (~1e-3 of the gradient in the trained net): ONE bf16 product (the stored Z it replaces carried a 2^-9 too, but of the SUM: on
+// random data the product of rounded operands is ~6x further off, 2e-3 of the gradient -- fine at the bf16 mode's tolerances, not at
+// the fp32 mode's: built for bf16 storage only).  K sits in LDS as an [n][m] image (its fragments in registers: 68 spilled registers).
+__global__ __launch_bounds__(128) void edge_mlp_bwd_prep_kernel(const float* __restrict__ W2, const float* __restrict__ scale2,
+                                                                const float* __restrict__ mean2, const float* __restrict__ invstd2,
+                                                                const double* __restrict__ dbeta2, const double* __restrict__ dgamma2,
+                                                                double count, uint16_t* __restrict__ Kb, float* __restrict__ cvec)
+{
+    // Kb [n][m] bf16: row n = the 128 contraction values of output column n (what a lane of the backward kernel reads as 16-byte pieces)
+    __shared__ float a1s[128], a0s[128], wn[128];
+    const int n = blockIdx.x, t = threadIdx.x;
+    {
+        const float m1 = (float)(dbeta2[t] / count), m2 = (float)(dgamma2[t] / count);
+        a1s[t] = -invstd2[t] * m2;
+        a0s[t] = mean2[t] * invstd2[t] * m2 - m1;
+        wn[t] = scale2[t] * W2[(size_t)t * 128 + n];
+    }
+    __syncthreads();
+    float acc = 0.0f, cv = 0.0f;
+    for (int c = 0; c < 128; ++c) {
+        acc = fmaf(a1s[c] * wn[c], W2[(size_t)c * 128 + t], acc);
+        cv = fmaf(a0s[c], wn[c], cv);
+    }
+    Kb[(size_t)n * 128 + t] = __builtin_bit_cast(unsigned short, (__bf16)acc);
+    if (t == 0) cvec[n] = cv;
+}
+
+template <bool BF16, bool ZBF16, bool NOZ = false>
 __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeMlpBwdArgs g)
 {
     constexpr int CM = 128, LDK = CM + 8, IMG = EB_PTS * LDK, KS = CM / 16, NIMG = BF16 ? 1 : 2, ES = BF16 ? 2 : 4, ESZ = ZBF16 ? 2 : 4;
+    constexpr int NB = NIMG + (NOZ ? 1 : 0), YI = NIMG * IMG;      // images per buffer: dZ hi (| lo) (| Y1e hi); offset of the Y1e image
+    static_assert(!NOZ || BF16, "the form without Z is built for bf16 storage");
+    constexpr int KIMG = 2 * NB * IMG;                             // NOZ: the K image [128 n][LDK] behind the two buffers
     constexpr int RPP = EM_THREADS / (CM / 4), PASSES = EB_PTS / RPP;      // 8 rows per pass, 4 passes
-    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];       // [2 buffers][hi (| lo)][32][LDK]
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];       // [2 buffers][hi (| lo) (| Y1e hi)][32][LDK]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
     const int m0 = lpd_xcd_remap(blockIdx.x, gridDim.x) * EB_PTS;         // M % 32 == 0 (host check)
     const int n = wave * 32 + col;                                        // this lane's column of dY1e / G
     const double count = (double)g.M * (double)g.k;
+    // NOZ: K into LDS ([n][m] bf16, 16-byte pieces), this column's constant
+    float cvn = 0.0f;
+    if constexpr (NOZ) {
+        for (int e = tid; e < CM * CM / 8; e += EM_THREADS) {
+            const int kn = e >> 4, kp = e & 15;
+            *reinterpret_cast<uint4*>(smem16 + KIMG + kn * LDK + kp * 8) = *reinterpret_cast<const uint4*>(g.Kb + (size_t)kn * CM + kp * 8);
+        }
+        cvn = g.cvec[n];
+    }
+    const __bf16* kfrag = smem16 + KIMG + n * LDK + h * 8;        // + 16 s
 
     // weight fragments: B[k = c][n] = s2_c W2[c][n], c = 16 s + 8 h + e
     em_bf16x8 b_hi[KS], b_lo[KS];
@@ -1188,8 +1236,8 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
     for (int c = 0; c < 4; ++c) {
         const int ch = c4 * 4 + c;
         const float m1 = (float)(g.dbeta2[ch] / count), m2 = (float)(g.dgamma2[ch] / count);
-        a1[c] = -g.invstd2[ch] * m2;
-        a0[c] = g.mean2[ch] * g.invstd2[ch] * m2 - m1;
+        a1[c] = NOZ ? 0.0f : -g.invstd2[ch] * m2;
+        a0[c] = NOZ ? 0.0f : g.mean2[ch] * g.invstd2[ch] * m2 - m1;
     }
     float dp2[PASSES][4];
     uint32_t ar2[PASSES];
@@ -1210,13 +1258,14 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
     const unsigned slab = (unsigned)EB_PTS * (unsigned)g.k * (CM * ES);
     const size_t slab0 = (size_t)m0 * g.k * (CM * ES);
     const __amdgpu_buffer_rsrc_t zres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.Z)) + (size_t)m0 * g.k * (CM * ESZ), 0,
-        (unsigned)EB_PTS * (unsigned)g.k * (CM * ESZ), 0x00020000);
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(NOZ ? g.Y : g.Z)) + (size_t)m0 * g.k * (CM * ESZ), 0,
+        NOZ ? 0u : (unsigned)EB_PTS * (unsigned)g.k * (CM * ESZ), 0x00020000);
     const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(g.Y)) + slab0, 0, slab, 0x00020000);
     const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(g.G) + slab0, 0, slab, 0x00020000);
     const unsigned rowb = (unsigned)g.k * (CM * ES), rowbz = (unsigned)g.k * (CM * ESZ);
     const unsigned zoff = ((unsigned)prow * (unsigned)g.k * CM + c4 * 4) * ESZ;                   // builder: its rows of Z
+    const unsigned yqoff = ((unsigned)prow * (unsigned)g.k * CM + c4 * 4) * ES;                  // builder (NOZ): its rows of Y1e
     const unsigned eoff = ((unsigned)(4 * h) * (unsigned)g.k * CM + n) * ES;                      // epilogue: element (row 4 h + ., column n)
     const unsigned goff = ((unsigned)(4 * h) * (unsigned)g.k * CM + (BF16 ? (n & ~1) : n)) * ES;
 
@@ -1232,22 +1281,45 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
     const float beta1 = g.beta1[n], rg1 = g.rgamma1[n];
     const float ns = lpd_neg_slope(g.act, g.slope), inv_ns = g.inv_ns;
 
-    typedef unsigned zraw_t __attribute__((ext_vector_type(ZBF16 ? 2 : 4)));
-    zraw_t zr[PASSES];
+    typedef unsigned zraw_t __attribute__((ext_vector_type((NOZ ? BF16 : ZBF16) ? 2 : 4)));
+    zraw_t zr[PASSES];          // the builder's rows of Z -- NOZ: of Y1e
     auto load_z = [&](int t) {
 #pragma unroll
         for (int e = 0; e < PASSES; ++e) {
-            const unsigned so = (unsigned)(RPP * e) * rowbz + (unsigned)t * (CM * ESZ);
-            if constexpr (ZBF16) zr[e] = __builtin_amdgcn_raw_buffer_load_b64(zres, zoff, so, 0);
-            else zr[e] = __builtin_amdgcn_raw_buffer_load_b128(zres, zoff, so, 0);
+            if constexpr (NOZ) {
+                const unsigned so = (unsigned)(RPP * e) * rowb + (unsigned)t * (CM * ES);
+                if constexpr (BF16) zr[e] = __builtin_amdgcn_raw_buffer_load_b64(yres, yqoff, so, 0);
+                else zr[e] = __builtin_amdgcn_raw_buffer_load_b128(yres, yqoff, so, 0);
+            } else {
+                const unsigned so = (unsigned)(RPP * e) * rowbz + (unsigned)t * (CM * ESZ);
+                if constexpr (ZBF16) zr[e] = __builtin_amdgcn_raw_buffer_load_b64(zres, zoff, so, 0);
+                else zr[e] = __builtin_amdgcn_raw_buffer_load_b128(zres, zoff, so, 0);
+            }
         }
     };
     auto build = [&](int buf, int t) {
-        __bf16* hi_img = smem16 + buf * NIMG * IMG;
+        __bf16* hi_img = smem16 + buf * NB * IMG;
         const uint32_t tb = (uint32_t)t;
 #pragma unroll
         for (int e = 0; e < PASSES; ++e) {
             const int p = prow + RPP * e;
+            if constexpr (NOZ) {      // the rows of Y1e: its hi image (bf16 rows: copied); dZ is the selected gradient alone
+                uint2 yh;
+                if constexpr (BF16) yh = make_uint2(zr[e][0], zr[e][1]);
+                else {
+                    uint2 ylo;
+                    em_split4_packed(__uint_as_float(zr[e][0]), __uint_as_float(zr[e][1]), __uint_as_float(zr[e][2]), __uint_as_float(zr[e][3]), yh, ylo);
+                }
+                *reinterpret_cast<uint2*>(hi_img + YI + p * LDK + c4 * 4) = yh;
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = ((ar2[e] >> (8 * c)) & 0xffu) == tb ? dp2[e][c] : 0.0f;
+                uint2 hh, ll;
+                em_split4_packed(v[0], v[1], v[2], v[3], hh, ll);
+                *reinterpret_cast<uint2*>(hi_img + p * LDK + c4 * 4) = hh;
+                if constexpr (!BF16) *reinterpret_cast<uint2*>(hi_img + IMG + p * LDK + c4 * 4) = ll;
+                continue;
+            }
             float z[4];
             if constexpr (ZBF16) {
                 z[0] = __uint_as_float(zr[e][0] << 16); z[1] = __uint_as_float(zr[e][0] & 0xffff0000u);
@@ -1286,8 +1358,8 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
     __syncthreads();
     for (int t = 0; t < g.k; ++t) {
         const int buf = t & 1;
-        load_y(t);                                   // this slot's Y1e elements: in flight under the MFMAs
-        const __bf16* ah = smem16 + buf * NIMG * IMG + col * LDK + h * 8;
+        if constexpr (!(NOZ && BF16)) load_y(t);     // this slot's Y1e elements: in flight under the MFMAs (NOZ, bf16: read from the image)
+        const __bf16* ah = smem16 + buf * NB * IMG + col * LDK + h * 8;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -1300,7 +1372,14 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi[s], acc, 0, 0, 0);
+            if constexpr (NOZ) {
+                const em_bf16x8 a_y = *reinterpret_cast<const em_bf16x8*>(ah + YI + s * 16);
+                const em_bf16x8 b_k = *reinterpret_cast<const em_bf16x8*>(kfrag + s * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_y, b_k, acc, 0, 0, 0);
+            }
         }
+        // (NOZ: this slot's Y1e elements -- rows p(r), column n -- are read out of the image the MFMAs just used, where they are needed)
+        const __bf16* yi = smem16 + buf * NB * IMG + YI + (4 * h) * LDK + n;
         if (t + 1 < g.k) {
             build(buf ^ 1, t + 1);                   // (its Z rows were requested a slot ago)
             if (t + 2 < g.k) load_z(t + 2);
@@ -1308,8 +1387,10 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
         const uint32_t tb = (uint32_t)t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float y = __uint_as_float(yv[r]);
-            const float gy = acc[r] + (((ar1[r >> 2] >> (8 * (r & 3))) & 0xffu) == tb ? dx1v[r] : 0.0f);
+            float y;
+            if constexpr (NOZ) y = __uint_as_float((unsigned)__builtin_bit_cast(unsigned short, yi[((r & 3) + 8 * (r >> 2)) * LDK]) << 16);
+            else y = __uint_as_float(yv[r]);
+            const float gy = acc[r] + cvn + (((ar1[r >> 2] >> (8 * (r & 3))) & 0xffu) == tb ? dx1v[r] : 0.0f);
             const bool pos = y > 0.0f;
             const float gg = gy * (pos ? 1.0f : ns);
             const float pre = pos ? y : y * inv_ns;
@@ -1518,7 +1599,7 @@ extern "C" int lpd_edge_mlp_train(const float* P, int ldp, const float* Q, int l
                                   void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    LPD_CHECK_ARG(P && idx && s1 && b1 && W2 && gamma2 && Y1e && Z && zsel && arg2 && sum && sumsq, "lpd_edge_mlp_train: null pointer");
+    LPD_CHECK_ARG(P && idx && s1 && b1 && W2 && gamma2 && Y1e && zsel && arg2 && sum && sumsq, "lpd_edge_mlp_train: null pointer");      // (Z may be null)
     LPD_CHECK_ARG(M > 0 && N > 0 && M % N == 0 && M % EM_PTS == 0 && N % EM_PTS == 0 && k > 0 && k <= 255,
                   "lpd_edge_mlp_train: M=%d N=%d k=%d unsupported (multiples of 64, k <= 255)", M, N, k);
     LPD_CHECK_ARG(act >= 0 && act <= 2 && (act != 2 || (slope >= 0.0f && slope <= 1.0f)), "lpd_edge_mlp_train: activation unsupported");
@@ -1550,10 +1631,11 @@ extern "C" int lpd_edge_mlp_train_bwd(const void* Z, const uint8_t* arg2, const 
                                       const float* mean2, const float* invstd2, const double* dbeta2, const double* dgamma2, const void* Y1e,
                                       const uint8_t* arg1, const float* dx1, int lddx1, const float* beta1, const float* rgamma1, int bf16,
                                       int z_bf16, void* G, float* gsum, double* dbeta1, double* dgamma1, int M, int k, int act, float slope, float inv_ns,
-                                      double* stat_ws, void* stream_)
+                                      float* kws, double* stat_ws, void* stream_)
 {
+    // Z == null: the form without Z (edge_mlp_bwd_prep_kernel); kws: 128 * 128 + 128 floats of scratch for it
     hipStream_t stream = (hipStream_t)stream_;
-    LPD_CHECK_ARG(Z && arg2 && dpre2 && W2 && scale2 && mean2 && invstd2 && dbeta2 && dgamma2 && Y1e && arg1 && dx1 && beta1 && rgamma1 && G &&
+    LPD_CHECK_ARG((Z || kws) && arg2 && dpre2 && W2 && scale2 && mean2 && invstd2 && dbeta2 && dgamma2 && Y1e && arg1 && dx1 && beta1 && rgamma1 && G &&
                   gsum && dbeta1 && dgamma1, "lpd_edge_mlp_train_bwd: null pointer");
     LPD_CHECK_ARG(M > 0 && M % EB_PTS == 0 && k > 0 && k <= 255, "lpd_edge_mlp_train_bwd: M=%d k=%d unsupported (M %% 32 == 0, k <= 255)", M, k);
     LPD_CHECK_ARG((act == 0 || act == 2) && inv_ns >= 1.0f, "lpd_edge_mlp_train_bwd: needs an invertible activation (none / LeakyReLU)");
@@ -1562,7 +1644,19 @@ extern "C" int lpd_edge_mlp_train_bwd(const void* Z, const uint8_t* arg2, const 
     const LpdStatWs ws = lpd_stat_arg(stat_ws);
     LPD_CHECK_ARG(ws.rep, "lpd_edge_mlp_train_bwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     EdgeMlpBwdArgs g{Z, arg2, dpre2, W2, scale2, mean2, invstd2, dbeta2, dgamma2, Y1e, arg1, dx1, lddx1, beta1, rgamma1, G, gsum,
-                     ws.sum(), ws.sumsq(), M, k, act, slope, inv_ns};
+                     ws.sum(), ws.sumsq(), M, k, act, slope, inv_ns, reinterpret_cast<const uint16_t*>(kws), kws ? kws + 128 * 128 : nullptr};
+    if (!Z) {
+        LPD_CHECK_ARG(bf16, "lpd_edge_mlp_train_bwd: the form without Z is built for bf16 storage");
+        LPD_CHECK_ARG(((uintptr_t)kws & 15) == 0, "lpd_edge_mlp_train_bwd: kws must be 16-byte aligned");
+        hipLaunchKernelGGL(edge_mlp_bwd_prep_kernel, dim3(128), dim3(128), 0, stream, W2, scale2, mean2, invstd2, dbeta2, dgamma2,
+                           (double)M * (double)k, reinterpret_cast<uint16_t*>(kws), kws + 128 * 128);
+        LPD_CHECK_LAUNCH("lpd_edge_mlp_train_bwd(prep)");
+        const size_t lds_n = ((size_t)2 * 2 * EB_PTS + 128) * (128 + 8) * sizeof(__bf16);      // two buffers of (dZ hi | Y1e hi) + the K image
+        (void)hipFuncSetAttribute((const void*)edge_mlp_train_bwd_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n);
+        hipLaunchKernelGGL((edge_mlp_train_bwd_kernel<true, true, true>), dim3(M / EB_PTS), dim3(EM_THREADS), lds_n, stream, g);
+        LPD_CHECK_LAUNCH("lpd_edge_mlp_train_bwd(noz)");
+        return lpd_stat_finish(ws, dbeta1, dgamma1, 128, stream);
+    }
     const size_t lds = (size_t)(bf16 ? 2 : 4) * EB_PTS * (128 + 8) * sizeof(__bf16);
     LPD_CHECK_ARG(!bf16 || z_bf16, "lpd_edge_mlp_train_bwd: bf16 Y1e goes with bf16 Z");
     if (bf16) hipLaunchKernelGGL((edge_mlp_train_bwd_kernel<true, true>), dim3(M / EB_PTS), dim3(EM_THREADS), lds, stream, g);

@@ -105,7 +105,7 @@ SIGNATURES = {
     "lpd_edge_bn_bwd": [_c_p, _c_ll, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int,
                         _c_f, _c_f, _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_mlp_train_bwd": [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_p, _c_p,
-                               _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_f, _c_p, _c_p],
+                               _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_f, _c_p, _c_p, _c_p],
     "lpd_edge_dense_bwd_apply": [_c_p, _c_int, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_int,
                                  _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_edge_mlp_train": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p,

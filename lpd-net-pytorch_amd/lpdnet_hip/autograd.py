@@ -462,8 +462,11 @@ class _LPDNetTrainFn(torch.autograd.Function):
             ops.affine_act(usel1, stg1.scale, stg1.shift, act, slope, out=cat[:, 0:128])                # x1
             # (fp32 storage: Z as bf16 when the backward is the one that only takes xhat2 from it, lpd_edge_mlp_train_bwd)
             z16 = bf16 or (ops.Z_BF16 and ops.EDGE_MLP_TRAIN_BWD and ops.dg2_bwd_fused_applies(M, k, 128) and M % 32 == 0)
+            # ... and (bf16 storage) no Z at all when that backward will run: it forms the xhat2 term as Y1e K (ops.EDGE_NOZ)
+            noz = (bf16 and ops.EDGE_NOZ and ops.EDGE_MLP_TRAIN_BWD and ops.dg2_bwd_fused_applies(M, k, 128) and M % 32 == 0 and ops.GEMM_BF16X3
+                   and w2.is_contiguous())
             y1e, z, zsel, arg2, stg2 = ops.edge_mlp_train(pq1[:, :128], pq1[:, 128:], idx_f, N, stg1.scale, stg1.shift, w2,
-                                                          net.convDG2[1], act, slope, bf16, z_bf16=z16)
+                                                          net.convDG2[1], act, slope, bf16, z_bf16=z16, store_z=not noz)
             ops.affine_act(zsel, stg2.scale, stg2.shift, act, slope, out=cat[:, 128:256])             # x2
             u1 = None
             del usel1
@@ -543,7 +546,11 @@ class _LPDNetTrainFn(torch.autograd.Function):
         dpq1 = torch.empty((M, 256), dtype=torch.float32, device=dfeat.device)
         w2 = w2d(net.convDG2[0])
         closed = (S["post1"] and ops.EDGE_MLP_TRAIN_BWD and ops.dg2_bwd_fused_applies(M, k, w2.shape[0]) and w2.shape[1] == 128
-                  and w2.is_contiguous() and M % 32 == 0 and ops.GEMM_BF16X3 and (ops._EXACT.depth == 0 or S["z"].dtype != S["y1e"].dtype))
+                  and w2.is_contiguous() and M % 32 == 0 and ops.GEMM_BF16X3
+                  and (ops._EXACT.depth == 0 or S["z"] is None or S["z"].dtype != S["y1e"].dtype))
+        if S["z"] is None and not closed:
+            raise RuntimeError("the forward stored no Z (ops.EDGE_NOZ) but the fused DG2 backward is not available now: "
+                               "the switches / weights changed between forward and backward")
         if closed:
             # DG2 + DG1 backward without dZ, dY1e and dU1 tensors: dW2 from one pass over Y1e (arg-max product + Gram matrix); then ONE
             # MFMA launch builds dZ from Z in its operand loader, multiplies by W2 and leaves G = the gradient in front of BatchNorm1 with its

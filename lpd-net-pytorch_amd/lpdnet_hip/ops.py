@@ -1532,9 +1532,13 @@ def edge_mlp_train_applies(M, N, k, C, act, slope):
 Z_BF16 = os.environ.get("LPD_Z_BF16", "1") != "0"      # fp32 storage mode: the stored Z of the DG2 stage as bf16 (see lpd_edge_mlp_train)
 
 
-def edge_mlp_train(P, Q, idx, N, scale1, shift1, W2, bn2, act, slope, bf16, z_bf16=None):
+EDGE_NOZ = os.environ.get("LPD_EDGE_NOZ", "1") != "0"     # bf16 storage: the DG2 output Z is not stored; its backward term is Y1e K (lpd_edge_mlp_train_bwd)
+
+
+def edge_mlp_train(P, Q, idx, N, scale1, shift1, W2, bn2, act, slope, bf16, z_bf16=None, store_z=True):
     """Train-mode DG1 -> DG2 stage in one launch (include/lpd_hip.h lpd_edge_mlp_train): -> (Y1e [E,128] (bf16 or fp32), Z [E,128]
-    (bf16 unless z_bf16 is False), zsel [M,128] raw selected values, arg2 [M,128] uint8, BNStats of Z with bn2's running statistics updated)."""
+    (bf16 unless z_bf16 is False; None with store_z=False), zsel [M,128] raw selected values, arg2 [M,128] uint8, BNStats of Z with
+    bn2's running statistics updated)."""
     z_bf16 = bool(bf16 or (Z_BF16 if z_bf16 is None else z_bf16))
     ldp, ldq = _rows(P, "P"), _rows(Q, "Q")
     _req(idx, "idx", torch.int32)
@@ -1546,7 +1550,7 @@ def edge_mlp_train(P, Q, idx, N, scale1, shift1, W2, bn2, act, slope, bf16, z_bf
         raise ValueError("edge_mlp_train: shape mismatch (128 -> 128 channels)")
     dt = torch.bfloat16 if bf16 else torch.float32
     Y = torch.empty((M * k, 128), dtype=dt, device=P.device)
-    Z = torch.empty((M * k, 128), dtype=torch.bfloat16 if z_bf16 else torch.float32, device=P.device)
+    Z = torch.empty((M * k, 128), dtype=torch.bfloat16 if z_bf16 else torch.float32, device=P.device) if store_z else None
     zsel = torch.empty((M, 128), dtype=torch.float32, device=P.device)
     arg2 = torch.empty((M, 128), dtype=torch.uint8, device=P.device)
     sums = torch.empty((2, 128), dtype=torch.float64, device=P.device)
@@ -1559,11 +1563,14 @@ def edge_mlp_train(P, Q, idx, N, scale1, shift1, W2, bn2, act, slope, bf16, z_bf
 
 
 def edge_mlp_train_bwd(Z, arg2, dpre2, W2, st2, red2, Y1e, arg1, dx1, bn1, k, act, slope):
-    """Backward of edge_mlp_train, dense part (include/lpd_hip.h lpd_edge_mlp_train_bwd): -> (G [E,128] like Z: the gradient in front of
-    BatchNorm1, gsum [M,128] = its sums over the k slots of a point, red1 [2,128] fp64 = (dbeta1, dgamma1))."""
+    """Backward of edge_mlp_train, dense part (include/lpd_hip.h lpd_edge_mlp_train_bwd): -> (G [E,128] like Y1e: the gradient in front of
+    BatchNorm1, gsum [M,128] = its sums over the k slots of a point, red1 [2,128] fp64 = (dbeta1, dgamma1)).  Z None: the form that
+    does not need the stored DG2 output (edge_mlp_train(store_z=False))."""
     M, C = arg2.shape
-    bf16, z_bf16 = Y1e.dtype == torch.bfloat16, Z.dtype == torch.bfloat16
+    bf16, z_bf16 = Y1e.dtype == torch.bfloat16, (Z is None or Z.dtype == torch.bfloat16)
     for t, name in ((Z, "Z"), (Y1e, "Y1e")):
+        if t is None:
+            continue
         if t.dtype not in (torch.bfloat16, torch.float32) or tuple(t.shape) != (M * k, 128) or not t.is_contiguous() or not t.is_cuda:
             raise ValueError(f"edge_mlp_train_bwd: {name} must be a contiguous [M k, 128] bf16 / fp32 tensor")
     if (bf16 and not z_bf16) or dpre2.dtype != Y1e.dtype or tuple(dpre2.shape) != (M, 128) or not dpre2.is_contiguous():
@@ -1574,13 +1581,14 @@ def edge_mlp_train_bwd(Z, arg2, dpre2, W2, st2, red2, Y1e, arg1, dx1, bn1, k, ac
     lddx1 = _rows(dx1, "dx1")
     beta1, rgamma1, inv_ns = _post_consts(None, bn1, act, slope)
     G = torch.empty_like(Y1e)
-    gsum = torch.empty((M, 128), dtype=torch.float32, device=Z.device)
-    red1 = torch.empty((2, 128), dtype=torch.float64, device=Z.device)
+    gsum = torch.empty((M, 128), dtype=torch.float32, device=Y1e.device)
+    red1 = torch.empty((2, 128), dtype=torch.float64, device=Y1e.device)
+    kws = torch.empty((128 * 128 + 128,), dtype=torch.float32, device=Y1e.device) if Z is None else None
     lib = _lib.load()
     _call(f"edge_mlp_train_bwd[{'bf16' if bf16 else 'f32'}]", lib.lpd_edge_mlp_train_bwd, _ptr(Z), _ptr(arg2), _ptr(dpre2), _ptr(W2),
           _ptr(st2.scale), _ptr(st2.mean), _ptr(st2.invstd), _ptr(red2[0]), _ptr(red2[1]), _ptr(Y1e), _ptr(arg1), _ptr(dx1), lddx1,
           _ptr(beta1), _ptr(rgamma1), int(bf16), int(z_bf16), _ptr(G), _ptr(gsum), _ptr(red1[0]), _ptr(red1[1]), M, k, act, float(slope), float(inv_ns),
-          _stat_ws(), _stream())
+          _ptr(kws), _stat_ws(), _stream())
     return G, gsum, red1
 
 

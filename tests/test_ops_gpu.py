@@ -1306,6 +1306,24 @@ def test_edge_mlp_train_bwd_equals_the_chain(cuda, bf16, N, k, B):
     assert _rel(buf[:, 4:4 + C], dp_a) < tol and _rel(buf[:, 4 + C:4 + 2 * C], dq_a) < tol
     assert (buf[:, :4] == 0).all() and (buf[:, 4 + 2 * C:] == 0).all()
     assert _rel(gsum, G.float().view(M, k, C).sum(1)) < (1e-2 if bf16 else 1e-5)
+    # ---- without Z (ops.EDGE_NOZ, bf16 storage): the forward stores none (same Y1e, statistics, selection), the backward takes the xhat2
+    # term as Y1e K
+    if not bf16:
+        with pytest.raises(Exception):
+            ops.edge_mlp_train_bwd(None, arg2, dpre2, W2, st2, red2, Y, arg1, dx1, bn1, k, act, slope)
+        return
+    bn2n = _bn_for(C, 4).to(cuda).train()
+    Yn, Zn, zseln, arg2n, st2n = ops.edge_mlp_train(P, Q, idx, N, st1.scale, st1.shift, W2, bn2n, act, slope, bf16, store_z=False)
+    assert Zn is None and torch.equal(Yn, Y) and torch.equal(zseln, zsel) and torch.equal(arg2n, arg2) and torch.equal(st2n.scale, st2.scale)
+    Gn, gsumn, red1n = ops.edge_mlp_train_bwd(None, arg2, dpre2, W2, st2, red2, Y, arg1, dx1, bn1, k, act, slope)
+    bufn = torch.zeros_like(buf)
+    ops.edge_dense_bwd_apply(Gn, gsumn, s1sum, P, Q, graph, st1, red1n, k, dP=bufn[:, 4:4 + C], dQ=bufn[:, 4 + C:4 + 2 * C])
+    r1n = red1n.float()
+    assert _rel(r1n[0], db_a) < tol and _rel(r1n[1], dg_a) < tol
+    assert _rel(bufn[:, 4:4 + C], dp_a) < tol and _rel(bufn[:, 4 + C:4 + 2 * C], dq_a) < tol
+    # the two backward forms differ by the rounding of the K product (bf16 x bf16 on the mean-sized term) against that of the stored Z
+    assert _rel(Gn.float(), G.float()) < 8e-3, _rel(Gn.float(), G.float())
+    assert _rel(gsumn, Gn.float().view(M, k, C).sum(1)) < 1e-2
 
 
 def test_gemm_act_equals_affine_act_then_product(cuda):
