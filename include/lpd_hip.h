@@ -156,7 +156,8 @@ int lpd_gemm_x3w_batched(const void* A, int lda, int a_bf16, const void* frags, 
  * transform they are widened first.  flags & 2 of lpd_gemm_x3w_act: a_out is a bf16 tensor, and the product sees the rounded values.
  * The bf16-storage training mode keeps the [B N, 1024] conv3 map, its activated form and its gradient as bf16. */
 int lpd_gemm_x3w_bf16a(const void* A16, int lda, const void* frags, float* C, int ldc, int M, int N, int K, int accumulate, int impl, void* stream);
-/* c_bf16: C receives bf16 values ([M][ldc] in bf16 elements, N % 32 == 0); the statistics stay those of the fp32 accumulators */
+/* c_bf16 & 1: C receives bf16 values ([M][ldc] in bf16 elements, N % 32 == 0); the statistics stay those of the fp32 accumulators.
+ * c_bf16 & 2: A holds bf16 rows too (lda in bf16 elements, K % 32 == 0; with a bf16 C and N >= 256): two products per term */
 int lpd_gemm_x3w_stats(const float* A, int lda, const void* frags, void* C, int ldc, int c_bf16, int M, int N, int K, const float* bias,
                        double* stat_sum, double* stat_sumsq, int impl, double* stat_ws, void* stream);
 /* The product with the train-mode BatchNorm affine + activation of the layer IN FRONT applied in the operand loader:
@@ -373,6 +374,9 @@ int lpd_bn_finalize(const double* sum, const double* sumsq, double count, int C,
 /* Y = act(scale * X + shift) elementwise per column (scale/shift NULL = identity affine).  In-place allowed. */
 int lpd_affine_act(const float* X, long long ldx, float* Y, long long ldy, long long R, int C, const float* scale,
                    const float* shift, int act, float slope, void* stream);
+/* the same with a bf16 copy of the result rows beside the fp32 ones (Y16 [R][ld16] in bf16 elements, ld16 % 4 == 0) */
+int lpd_affine_act2(const float* X, long long ldx, float* Y, long long ldy, void* Y16, long long ld16, long long R, int C, const float* scale,
+                    const float* shift, int act, float slope, void* stream);
 
 /* Backward of Y = act(BN(X)) given dY: dbeta = sum dpre, dgamma = sum dpre*xhat (fp64 [C]) and
  * dX = scale*(dpre - dbeta/R - xhat*dgamma/R); has_bn = 0: plain activation backward (dbeta = bias gradient).
@@ -606,7 +610,9 @@ int lpd_gemm_tn_bf16(const uint16_t* A, const uint16_t* B, float* dW, float* ws,
 /* dW [KA][KB] (fp32) = sum_m A[m][:]^T B[m][:] for fp32 operands A [M][lda], B [M][ldb] in split-bf16 form (three MFMA products per
  * term, fp32-grade): the weight gradients dW = dY^T X of the training path and, batched over the clouds, the NetVLAD residual
  * pooling act^T x (util/PointNetVlad.py:64-67).  batch problems at strides sA / sB (elements) write dW [batch][KA][KB].
- * KA %% 128 == 0, KB %% 64 == 0; ws: lpd_gemm_tn_ws_floats(M, KA, KB, batch) floats. */
+ * KA %% 128 == 0, KB %% 64 == 0; ws: lpd_gemm_tn_ws_floats(M, KA, KB, batch) floats.  * a_bf16 is a flag word: bit 0 = A holds bf16 rows (lda / sA in bf16 elements), bit 1 = B holds bf16 rows as well (ldb in bf16 elements;
+ * needs bit 0, KA % 256 == 0, KB % 256 == 0, M % 32 == 0, M >= 2048, batch 1): one product per term, exact in the operands.
+ */
 long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB, int batch);
 int lpd_gemm_tn(const void* A, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
                 int batch, long long sA, long long sB, int a_bf16, void* stream);

@@ -1297,6 +1297,7 @@ static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, i
         const int mode = (a_flags & 1) | ((a_flags & 4) ? 2 : 0) | (((a_flags & 1) && a_scale) ? 4 : 0);
         LPD_CHECK_ARG(K % 32 == 0 && panels == 0, "lpd_gemm_x3w: bf16 operands need K %% 32 == 0 and row-major operands");
         if (mode == 2 && impl == 3) x3w_wide_launch_kc<2, 0, 32, false, 2>(g, NT, stream);          // conv3 + statistics -> bf16 map
+        else if (mode == 3 && impl == 3) x3w_wide_launch_kc<2, 0, 32, false, 3>(g, NT, stream);     // ... from bf16 point features
         else if (mode == 1 && impl == 3) x3w_wide_launch_kc<2, 0, 32, false, 1>(g, NT, stream);     // dX = dY W on the bf16 gradient
         else if (mode == 1 && impl == 2 && NT <= 2) x3w_wide_launch_kc<1, 0, 32, true, 1>(g, NT, stream);   // dA of the NetVLAD backward
         else if (mode == 1 && impl == 2) x3w_wide_launch_kc<1, 0, 32, false, 1>(g, NT, stream);
@@ -1366,12 +1367,13 @@ extern "C" int lpd_gemm_x3w_bf16a(const void* A16, int lda, const void* frags, f
 }
 
 // c_bf16: C receives bf16 values ([M][ldc] bf16 elements; N % 32 == 0) -- the statistics stay those of the fp32 accumulators
+// c_bf16 & 2: A holds bf16 rows as well (lda in bf16 elements, K % 32 == 0; built with a bf16 C and N >= 256)
 extern "C" int lpd_gemm_x3w_stats(const float* A, int lda, const void* frags, void* C, int ldc, int c_bf16, int M, int N, int K, const float* bias,
                                   double* stat_sum, double* stat_sumsq, int impl, double* stat_ws, void* stream_)
 {
     LPD_CHECK_ARG(stat_sum && stat_sumsq, "lpd_gemm_x3w_stats: null statistics");
     return gemm_x3w_impl(A, lda, frags, reinterpret_cast<float*>(C), ldc, M, N, K, bias, nullptr, nullptr, 0, 0.0f, 0, 0, 0, 0, 0, impl, stat_sum,
-                         stat_sumsq, stat_ws, stream_, nullptr, nullptr, nullptr, 0, 1.0f, 0, 0, c_bf16 ? 4 : 0);
+                         stat_sumsq, stat_ws, stream_, nullptr, nullptr, nullptr, 0, 1.0f, 0, 0, ((c_bf16 & 1) ? 4 : 0) | ((c_bf16 & 2) ? 1 : 0));
 }
 
 // C = act_a(a_scale[k] A[m][k] + a_shift[k]) W^T (+ bias): the train-mode BatchNorm affine + activation of the layer in front applied in

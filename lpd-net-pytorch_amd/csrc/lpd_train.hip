@@ -112,9 +112,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sum, const double*
 // Y = act(scale * X + shift), float4 per thread.  In-place allowed.
 // The grid stride (gridDim * 256 threads) is a multiple of the C/4 column quads whenever C/4 divides 256 (all layer
 // widths here), so a thread keeps ONE column quad for its whole loop and the per-column constants are loaded once.
+// Y16 (or null): a bf16 copy of the result rows ([R][ld16] bf16 elements) next to the fp32 ones.
 __global__ void affine_act_kernel(const float* __restrict__ X, long long ldx, float* __restrict__ Y, long long ldy,
                                   long long R, int C, const float* __restrict__ scale, const float* __restrict__ shift,
-                                  int act, float slope)
+                                  int act, float slope, uint16_t* __restrict__ Y16 = nullptr, long long ld16 = 0)
 {
     const int Q = C >> 2;
     const long long total = R * Q;
@@ -140,6 +141,11 @@ __global__ void affine_act_kernel(const float* __restrict__ X, long long ldx, fl
             y.x = lpd_act_pl(y.x, ns); y.y = lpd_act_pl(y.y, ns); y.z = lpd_act_pl(y.z, ns); y.w = lpd_act_pl(y.w, ns);
         }
         *reinterpret_cast<float4*>(Y + r * ldy + q * 4) = y;
+        if (Y16) {       // uniform
+            const unsigned w0 = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)y.x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)y.y) << 16);
+            const unsigned w1 = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)y.z) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)y.w) << 16);
+            *reinterpret_cast<uint2*>(Y16 + r * ld16 + q * 4) = make_uint2(w0, w1);
+        }
     }
 }
 
@@ -1195,6 +1201,20 @@ extern "C" int lpd_affine_act(const float* X, long long ldx, float* Y, long long
     hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(R * (C / 4), 256 * 4)), dim3(256), 0, ST(stream), X, ldx, Y, ldy, R,
                        C, scale, shift, act, slope);
     LPD_CHECK_LAUNCH("lpd_affine_act");
+    return LPD_OK;
+}
+
+// lpd_affine_act with a bf16 copy of the result rows beside the fp32 ones (Y16 [R][ld16] bf16 elements, ld16 % 4 == 0): the bf16 storage
+// mode's second form of the point features [x1 | x2 | x3] (the conv3 operand and the B operand of its weight gradient)
+extern "C" int lpd_affine_act2(const float* X, long long ldx, float* Y, long long ldy, void* Y16, long long ld16, long long R, int C,
+                               const float* scale, const float* shift, int act, float slope, void* stream)
+{
+    LPD_CHECK_ARG(X && Y && Y16 && R > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ld16 % 4 == 0 && ((uintptr_t)Y16 & 7) == 0,
+                  "lpd_affine_act2: bad arguments");
+    LPD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "lpd_affine_act2: scale and shift come in pairs");
+    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(R * (C / 4), 256 * 4)), dim3(256), 0, ST(stream), X, ldx, Y, ldy, R,
+                       C, scale, shift, act, slope, reinterpret_cast<uint16_t*>(Y16), ld16);
+    LPD_CHECK_LAUNCH("lpd_affine_act2");
     return LPD_OK;
 }
 

@@ -1521,7 +1521,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigne
 // a_scale / a_shift (or null): the rows of A are act(a_scale[a] A[m][a] + a_shift[a]) -- a train-mode BatchNorm affine + activation
 // applied where the raw map is staged (multiply, then add: the bits of lpd_affine_act; bf16 rows: rounded to bf16 again = the map a
 // bf16-storing pass would have written), so that the activated [B N, 1024] map need not exist.
-template <bool A16, int TB, bool ATR = false>
+// B16: B holds bf16 rows too (ldb / sB in bf16 elements; TB = 256): copied like A's, no lo image -- with bf16 rows on both sides a term
+// is ONE product, exact in the operands (dW3 of the bf16 storage mode: the bf16 gradient of the conv3 map against the bf16 point features).
+template <bool A16, int TB, bool ATR = false, bool B16 = false>
 __global__ __launch_bounds__(512, (A16 && TB != 256) ? 4 : 2) void gemm_tn_tr_kernel(const void* __restrict__ A_, long long lda, const float* __restrict__ B,
                                                                             long long ldb, float* __restrict__ slabs, int KA, int KB,
                                                                             long long rows_per_split, int nsplit, long long M, long long sA,
@@ -1531,7 +1533,8 @@ __global__ __launch_bounds__(512, (A16 && TB != 256) ? 4 : 2) void gemm_tn_tr_ke
     constexpr int ROWA = 576;                      // bytes per row of an A image (256 channels x 2 + 64)
     constexpr int ROWB = TB * 2 + 64;              // ... of a B image: 576 / 320 / 192, all = 64 mod 128 -> the 4 rows of a read on 4 bank groups
     constexpr int IMGA = 32 * ROWA, IMGB = 32 * ROWB;
-    constexpr int BUF = (A16 ? 1 : 2) * IMGA + 2 * IMGB;
+    static_assert(!B16 || TB == 256, "bf16 rows as B: the 256-wide tile");
+    constexpr int BUF = (A16 ? 1 : 2) * IMGA + (B16 ? 1 : 2) * IMGB;
     constexpr int A_HI = 0, A_LO = IMGA, B_HI = (A16 ? 1 : 2) * IMGA, B_LO = B_HI + IMGB;
     constexpr int NI = TB == 64 ? 1 : 2, NJ = TB == 256 ? 4 : 2;        // accumulator tiles of a wave
     constexpr int WGA = 256 / (NI * 32);                                // wave groups along a (4 or 8)
@@ -1551,13 +1554,14 @@ __global__ __launch_bounds__(512, (A16 && TB != 256) ? 4 : 2) void gemm_tn_tr_ke
     // staging: fp32 rows of A -- 4 passes of (row tid / 64 + 8 p, channels 4 (tid % 64) ..); bf16 rows -- 2 passes of (row tid / 32 + 16 p,
     // channels 8 (tid % 32) ..); B -- BP passes of (row tid / BQ + (512 / BQ) p, channels 4 (tid % BQ) ..): whole contiguous row pieces per wave
     const float* srcB = B + zb * sB + b0 + (tid % BQ) * 4 + (m_begin + tid / BQ) * ldb;
+    const uint16_t* srcB16 = reinterpret_cast<const uint16_t*>(B) + zb * sB + b0 + (tid & 31) * 8 + (m_begin + (tid >> 5)) * ldb;      // B16: as A16
     const float* srcA = reinterpret_cast<const float*>(A_) + zb * sA + a0 + (tid & 63) * 4 + (m_begin + (tid >> 6)) * lda;
     const uint16_t* srcA16 = reinterpret_cast<const uint16_t*>(A_) + zb * sA + a0 + (tid & 31) * 8 + (m_begin + (tid >> 5)) * lda;
     const int wrb = (tid / BQ) * ROWB + (tid % BQ) * 8;        // + (512 / BQ) p rows
     const int wr32 = (tid >> 6) * ROWA + (tid & 63) * 8;       // + 8 p rows
     const int wr16 = (tid >> 5) * ROWA + (tid & 31) * 16;      // + 16 p rows
     float4 rb[BP], ra[4];
-    tr_u32x4 ra16[2];
+    tr_u32x4 ra16[2], rb16[2];
     // this thread's channels of A are the same in every chunk: their affine, once
     float asc[ATR ? 8 : 1], ash[ATR ? 8 : 1];
     if constexpr (ATR) {
@@ -1571,8 +1575,13 @@ __global__ __launch_bounds__(512, (A16 && TB != 256) ? 4 : 2) void gemm_tn_tr_ke
     auto tf = [&](float v, int e) { v = asc[ATR ? e : 0] * v + ash[ATR ? e : 0]; return fmaxf(v, 0.0f) + a_ns * fminf(v, 0.0f); };
     auto request = [&](int c) {
         const long long r = (long long)c * 32;
+        if constexpr (B16) {
 #pragma unroll
-        for (int p = 0; p < BP; ++p) rb[p] = *reinterpret_cast<const float4*>(srcB + (r + (512 / BQ) * p) * ldb);
+            for (int p = 0; p < 2; ++p) rb16[p] = *reinterpret_cast<const tr_u32x4*>(srcB16 + (r + 16 * p) * ldb);
+        } else {
+#pragma unroll
+            for (int p = 0; p < BP; ++p) rb[p] = *reinterpret_cast<const float4*>(srcB + (r + (512 / BQ) * p) * ldb);
+        }
         if constexpr (A16) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) ra16[p] = *reinterpret_cast<const tr_u32x4*>(srcA16 + (r + 16 * p) * lda);
@@ -1590,9 +1599,14 @@ __global__ __launch_bounds__(512, (A16 && TB != 256) ? 4 : 2) void gemm_tn_tr_ke
     };
     auto stage = [&](int buf) {
         unsigned char* base = trl + buf * BUF;
+        if constexpr (B16) {
 #pragma unroll
-        for (int p = 0; p < BP; ++p)
-            split_store(base + B_HI + wrb + (512 / BQ) * p * ROWB, base + B_LO + wrb + (512 / BQ) * p * ROWB, rb[p]);
+            for (int p = 0; p < 2; ++p) *reinterpret_cast<tr_u32x4*>(base + B_HI + wr16 + 16 * p * ROWB) = rb16[p];      // (ROWB == ROWA at TB = 256)
+        } else {
+#pragma unroll
+            for (int p = 0; p < BP; ++p)
+                split_store(base + B_HI + wrb + (512 / BQ) * p * ROWB, base + B_LO + wrb + (512 / BQ) * p * ROWB, rb[p]);
+        }
         if constexpr (A16) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -1650,7 +1664,7 @@ __global__ __launch_bounds__(512, (A16 && TB != 256) ? 4 : 2) void gemm_tn_tr_ke
             const int s = t / NJ, j = t % NJ;
             const unsigned char* pb = base + rd_b + s * 16 * ROWB + j * 64;
             bh[t & 1] = tr_frag(pb + B_HI, pb + B_HI + 4 * ROWB);
-            bl[t & 1] = tr_frag(pb + B_LO, pb + B_LO + 4 * ROWB);
+            if constexpr (!B16) bl[t & 1] = tr_frag(pb + B_LO, pb + B_LO + 4 * ROWB);
         };
         load_a(0);
         load_b(0);
@@ -1665,7 +1679,7 @@ __global__ __launch_bounds__(512, (A16 && TB != 256) ? 4 : 2) void gemm_tn_tr_ke
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 if constexpr (!A16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s & 1][i], bh[t & 1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s & 1][i], bl[t & 1], acc[i][j], 0, 0, 0);
+                if constexpr (!B16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s & 1][i], bl[t & 1], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s & 1][i], bh[t & 1], acc[i][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1768,15 +1782,19 @@ extern "C" int lpd_gemm_tn_act(const void* A_, long long lda, const float* B, lo
 }
 
 static int gemm_tn_impl(const void* A_, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
-                        int batch, long long sA, long long sB, int a_bf16, const float* a_scale, const float* a_shift, float a_ns, void* stream_)
+                        int batch, long long sA, long long sB, int ab_flags, const float* a_scale, const float* a_shift, float a_ns, void* stream_)
 {
+    // ab_flags: bit 0 = A holds bf16 rows, bit 1 = B holds bf16 rows (with bit 0, KB % 256 == 0, the transposed-read kernel)
+    const int a_bf16 = ab_flags & 1, b_bf16 = (ab_flags >> 1) & 1;
     hipStream_t stream = (hipStream_t)stream_;
     const float* A = reinterpret_cast<const float*>(A_);      // a_bf16: bf16 rows (lda, sA in bf16 elements)
     LPD_CHECK_ARG(A && B && dW && ws && M > 0 && batch >= 1, "lpd_gemm_tn: bad arguments");
     LPD_CHECK_ARG(KA > 0 && KA % 128 == 0 && KB > 0 && KB % 64 == 0, "lpd_gemm_tn: KA %% 128 and KB %% 64 required (KA=%d KB=%d)", KA, KB);
-    LPD_CHECK_ARG(lda % (a_bf16 ? 8 : 4) == 0 && ldb % 4 == 0 && sA % (a_bf16 ? 8 : 4) == 0 && sB % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
-                  "lpd_gemm_tn: operands must be 16-byte aligned rows");
-    const bool act = a_scale != nullptr;
+    LPD_CHECK_ARG(lda % (a_bf16 ? 8 : 4) == 0 && ldb % (b_bf16 ? 8 : 4) == 0 && sA % (a_bf16 ? 8 : 4) == 0 && sB % (b_bf16 ? 8 : 4) == 0 &&
+                      (((uintptr_t)A | (uintptr_t)B) & 15) == 0, "lpd_gemm_tn: operands must be 16-byte aligned rows");
+    LPD_CHECK_ARG(!b_bf16 || (a_bf16 && !a_scale && batch == 1 && tn_tr_tb(M, KA, KB, batch, true, true) == 256),
+                  "lpd_gemm_tn: bf16 rows as B are built with bf16 rows as A, KA %% 256 == 0, KB %% 256 == 0, M %% 32 == 0, M >= 2048");
+    const bool act = a_scale != nullptr || b_bf16;      // (both forms exist on the transposed-read kernel only)
     LPD_CHECK_ARG(!act || tn_tr_tb(M, KA, KB, batch, a_bf16 != 0, true),
                   "lpd_gemm_tn_act: the operand transform is built for KA %% 256 == 0, M %% 32 == 0, M >= 2048 (M=%lld KA=%d)", M, KA);
     const long long splits = gemm_tn_splits(M, KA, KB, batch, a_bf16 != 0, act);
@@ -1787,14 +1805,18 @@ static int gemm_tn_impl(const void* A_, long long lda, const float* B, long long
         rps = (rps + 31) / 32 * 32;
         const long long blocks = (long long)(KA / 256) * (KB / tb) * splits * batch;
         LPD_CHECK_ARG(blocks < (1ll << 31), "lpd_gemm_tn: too many blocks");
-        const int lds_tr = 2 * ((a_bf16 ? 1 : 2) * 32 * 576 + 2 * 32 * (tb * 2 + 64));
+        const int lds_tr = 2 * ((a_bf16 ? 1 : 2) * 32 * 576 + (b_bf16 ? 1 : 2) * 32 * (tb * 2 + 64));
 #define LPD_TN_TR_LAUNCH(AB_, TB_, TR_)                                                                                                     \
     do {                                                                                                                                    \
         (void)hipFuncSetAttribute((const void*)gemm_tn_tr_kernel<AB_, TB_, TR_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_tr);       \
         hipLaunchKernelGGL((gemm_tn_tr_kernel<AB_, TB_, TR_>), dim3((unsigned)blocks), dim3(512), lds_tr, stream, A_, lda, B, ldb, ws, KA, KB, \
                            rps, (int)splits, M, sA, sB, a_scale, a_shift, a_ns);                                                            \
     } while (0)
-        if (act) {      // the operand transform: the 64-wide tile (NetVLAD pooling and assignment weight gradient)
+        if (b_bf16) {
+            (void)hipFuncSetAttribute((const void*)gemm_tn_tr_kernel<true, 256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_tr);
+            hipLaunchKernelGGL((gemm_tn_tr_kernel<true, 256, false, true>), dim3((unsigned)blocks), dim3(512), lds_tr, stream, A_, lda, B, ldb, ws, KA, KB,
+                               rps, (int)splits, M, sA, sB, a_scale, a_shift, a_ns);
+        } else if (act) {      // the operand transform: the 64-wide tile (NetVLAD pooling and assignment weight gradient)
             LPD_CHECK_ARG(tb == 64, "lpd_gemm_tn_act: built for KB %% 128 != 0 (64-wide b tiles), KB=%d", KB);
             if (a_bf16) LPD_TN_TR_LAUNCH(true, 64, true); else LPD_TN_TR_LAUNCH(false, 64, true);
         } else if (a_bf16) { if (tb == 256) LPD_TN_TR_LAUNCH(true, 256, false); else if (tb == 128) LPD_TN_TR_LAUNCH(true, 128, false); else LPD_TN_TR_LAUNCH(true, 64, false); }

@@ -90,6 +90,7 @@ SIGNATURES = {
     "lpd_colstats": [_c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p],
     "lpd_bn_finalize": [_c_p, _c_p, ctypes.c_double, _c_int, _c_p, _c_p, _c_p, _c_p, _c_f, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p],
     "lpd_affine_act": [_c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p],
+    "lpd_affine_act2": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_int, _c_f, _c_p],
     "lpd_bn_act_bwd": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int,
                        _c_p, _c_p, _c_p, _c_p],
     "lpd_bn_act_bwd_bf16": [_c_p, _c_ll, _c_p, _c_ll, _c_p, _c_ll, _c_ll, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_int,

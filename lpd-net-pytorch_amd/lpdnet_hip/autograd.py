@@ -166,6 +166,9 @@ TRAIN_STORAGE = "f32"
 # bf16 storage also keeps the [B N, 1024] conv3 map -- the raw conv3 output, its activated form and both gradients -- in bf16 where the
 # trunk hands the raw map to the NetVLAD head (PointNetVlad's train path, lpdnet_features_train(defer_act=True)); LPD_MAP_BF16=0: fp32 map
 MAP_BF16 = __import__("os").environ.get("LPD_MAP_BF16", "1") != "0"
+# ... and a bf16 COPY of the point features [x1 | x2 | x3] beside the fp32 ones (written by the activation passes that produce them):
+# conv3 takes it as bf16 rows (two products per term), its weight gradient as bf16 rows on both sides (one).  LPD_CAT_BF16=0: off
+CAT_BF16 = __import__("os").environ.get("LPD_CAT_BF16", "1") != "0"
 
 
 def set_train_storage(kind):
@@ -453,13 +456,22 @@ class _LPDNetTrainFn(torch.autograd.Function):
         w2 = w2d(net.convDG2[0])
         post1 = ops.edge_mlp_train_applies(M, N, k, 128, act, slope) and w2.is_contiguous() and tuple(w2.shape) == (128, 128)
         s1sum = None
+        Co3 = net.conv3_lpd.weight.shape[0]
+        defer = getattr(_LAST, "defer_act", False) and ops.gemm_act_applies(M, 64, Co3)
+        map16 = (defer and bf16 and MAP_BF16 and ops.GEMM_TN and ops.linear_bn_stats_fused_applies(M, Co3, 512) and Co3 % 128 == 0 and Co3 <= 2048
+                 and (Co3 & (Co3 - 1)) == 0 and N % 128 == 0 and N >= 256 and M >= 16384 and ops.X3T_ROWS and ops.X3W_BATCHED)
+        # (the shapes every bf16-map kernel of the head is built for: pooling and weight gradients >= 4096 rows, the batched short
+        #  products >= 16384 rows over clouds of whole 128-row tiles; smaller steps keep the fp32 map)
+        cat16 = (torch.empty((M, 512), dtype=torch.bfloat16, device=x.device)
+                 if (map16 and post1 and CAT_BF16 and Co3 % 256 == 0 and M % 32 == 0) else None)
+        c16 = (lambda a, b: cat16[:, a:b]) if cat16 is not None else (lambda a, b: None)
         if post1:
             # ONE launch for the stage (lpd_edge_mlp_train): the raw edge tensor U1 is never written.  Its BatchNorm statistics, and
             # x1 = max_k act(BN(U1)) with its arg-max, come from the split-form gather pass (closed-form sums; the activation is monotone,
             # so the maximum is act(BN(.)) of the selected raw value); the fused kernel builds Y1e from the gathered rows, multiplies it
             # by W2 and leaves Y1e, Z, the statistics of Z and its per-point selection (by the sign of gamma2) behind
             s1sum, usel1, arg1, stg1 = ops.edge_split_fwd(pq1[:, :128], pq1[:, 128:], idx_f, N, bn=net.convDG1[1])
-            ops.affine_act(usel1, stg1.scale, stg1.shift, act, slope, out=cat[:, 0:128])                # x1
+            ops.affine_act(usel1, stg1.scale, stg1.shift, act, slope, out=cat[:, 0:128], out16=c16(0, 128))                # x1
             # (fp32 storage: Z as bf16 when the backward is the one that only takes xhat2 from it, lpd_edge_mlp_train_bwd)
             z16 = bf16 or (ops.Z_BF16 and ops.EDGE_MLP_TRAIN_BWD and ops.dg2_bwd_fused_applies(M, k, 128) and M % 32 == 0)
             # ... and (bf16 storage) no Z at all when that backward will run: it forms the xhat2 term as Y1e K (ops.EDGE_NOZ)
@@ -467,7 +479,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
                    and w2.is_contiguous())
             y1e, z, zsel, arg2, stg2 = ops.edge_mlp_train(pq1[:, :128], pq1[:, 128:], idx_f, N, stg1.scale, stg1.shift, w2,
                                                           net.convDG2[1], act, slope, bf16, z_bf16=z16, store_z=not noz)
-            ops.affine_act(zsel, stg2.scale, stg2.shift, act, slope, out=cat[:, 128:256])             # x2
+            ops.affine_act(zsel, stg2.scale, stg2.shift, act, slope, out=cat[:, 128:256], out16=c16(128, 256))             # x2
             u1 = None
             del usel1
         elif bf16:
@@ -486,16 +498,11 @@ class _LPDNetTrainFn(torch.autograd.Function):
         wcat3 = engine.split_edge_weight(net.convSN1, "cat_nc")
         pq3 = ops.linear(cat[:, 128:256], wcat3)                                # [M,512] = [P | Q]
         s3, usel3, arg3, stg3 = ops.edge_split_fwd(pq3[:, :256], pq3[:, 256:], idx_x, N, bn=net.convSN1[1])
-        ops.affine_act(usel3, stg3.scale, stg3.shift, act, slope, out=cat[:, 256:512])                # x3
-        if getattr(_LAST, "defer_act", False) and ops.gemm_act_applies(M, 64, net.conv3_lpd.weight.shape[0]):
+        ops.affine_act(usel3, stg3.scale, stg3.shift, act, slope, out=cat[:, 256:512], out16=c16(256, 512))                # x3
+        if defer:
             # PointNetVlad's train path: bn3 + act are applied by the NetVLAD assignment product's operand loader (ops.gemm_act), which
             # also writes the activated map; this Function hands the RAW conv3 output on, with the affine in _LAST.pending
-            Co3 = net.conv3_lpd.weight.shape[0]
-            map16 = (bf16 and MAP_BF16 and ops.GEMM_TN and ops.linear_bn_stats_fused_applies(M, Co3, 512) and Co3 % 128 == 0 and Co3 <= 2048
-                     and (Co3 & (Co3 - 1)) == 0 and N % 128 == 0 and N >= 256 and M >= 16384 and ops.X3T_ROWS and ops.X3W_BATCHED)
-            # (the shapes every bf16-map kernel of the head is built for: pooling and weight gradients >= 4096 rows, the batched short
-            #  products >= 16384 rows over clouds of whole 128-row tiles; smaller steps keep the fp32 map)
-            y3, st3 = ops.linear_bn_stats(cat, w2d(net.conv3_lpd), net.bn3_lpd, out_bf16=map16)      # (bf16 storage: a bfloat16 tensor)
+            y3, st3 = ops.linear_bn_stats(cat if cat16 is None else cat16, w2d(net.conv3_lpd), net.bn3_lpd, out_bf16=map16)      # (bf16 storage: a bfloat16 tensor)
             feat = y3
             _LAST.pending = (st3.scale, st3.shift, act, slope)
         else:
@@ -504,7 +511,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         ctx.net, ctx.dims, ctx.actslope, ctx.bf16 = net, (B, N, M, k), (act, slope), bf16
         ctx.saved = dict(front=front, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1, post1=post1, pq1=pq1 if post1 else None, s1sum=s1sum,
                          u1=u1, stg1=stg1, arg1=arg1, y1e=y1e, z=z, zsel=zsel, stg2=stg2, arg2=arg2, wcat3=wcat3, pq3=pq3, s3=s3, usel3=usel3,
-                         stg3=stg3, arg3=arg3, cat=cat, y3=y3, st3=st3)
+                         stg3=stg3, arg3=arg3, cat=cat, cat16=cat16, y3=y3, st3=st3)
         if engine.DEBUG_AUX is not None:
             engine.DEBUG_AUX.update(F0=f0, idx_feat=idx_f, idx_xyz=idx_x, cat=cat, argsel=dict(x1=arg1, x2=arg2, x3=arg3))
         return feat
@@ -528,7 +535,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         # conv3 + bn3 (the incoming gradient buffer belongs to autograd: not modified in place)
         if S["y3"].dtype == torch.bfloat16:      # bf16 map (forward: map16): bf16 gradient in, bf16 dY3, two-product GEMMs on it
             dy3, dg3, db3 = ops.bn_act_bwd_bf16(dfeat, S["y3"], S["st3"], act, slope)
-            dw3 = ops.gemm_tn(dy3, S["cat"])
+            dw3 = ops.gemm_tn(dy3, S["cat"] if S["cat16"] is None else S["cat16"])
             dcat = ops.gemm_bf16a(dy3, w2d(net.conv3_lpd), b_kmajor=True)
             del dy3
         else:

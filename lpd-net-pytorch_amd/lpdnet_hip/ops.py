@@ -1036,23 +1036,32 @@ def linear_bn_stats(x, w, bn, bias=None, out_bf16=False):
     """(y, BNStats): y = x @ w.T (+ bias) raw and the train-mode statistics of `bn` over its rows (running stats updated).  Where the
     product runs on the prepared-fragment split-bf16 kernel (the policy of ops.gemm), the column sums come out of its epilogue
     (lpd_gemm_x3w_stats) instead of a second pass over y (lpd_colstats); otherwise linear + bn_train_stats.
-    out_bf16: y is stored as bfloat16 (the statistics are those of the fp32 accumulators); needs the fused kernel (N % 32 == 0)."""
-    ldx = _rows(x, "x")
+    out_bf16: y is stored as bfloat16 (the statistics are those of the fp32 accumulators); needs the fused kernel (N % 32 == 0).
+    x may be bfloat16 rows (with out_bf16, N >= 256, K % 32 == 0): the rows are the hi image, two products per term."""
+    x16 = x.dtype == torch.bfloat16
+    if x16:
+        _req(x, "x", torch.bfloat16)
+        if x.dim() != 2 or x.stride(1) != 1 or x.stride(0) % 4 != 0 or not out_bf16:
+            raise ValueError("linear_bn_stats: bf16 rows need unit column stride and a bf16 result")
+        ldx = x.stride(0)
+    else:
+        ldx = _rows(x, "x")
     _req(w, "w")
     w2 = w.reshape(w.shape[0], -1)
     M, K = x.shape
     N = w2.shape[0]
-    if linear_bn_stats_fused_applies(M, N, K) and w2.is_contiguous() and w2.shape[1] == K and (not out_bf16 or N % 32 == 0):
+    if (linear_bn_stats_fused_applies(M, N, K) and w2.is_contiguous() and w2.shape[1] == K and (not out_bf16 or N % 32 == 0)
+            and (not x16 or (N >= 256 and K % 32 == 0))):
         bias = _vec(bias, "bias", N)
         frags = _weight_frags(w2, False, N, K)
         y = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
         sums = torch.empty((2, N), dtype=torch.float64, device=x.device)
         lib = _lib.load()
-        _call(f"gemmx3w+stats[{M}x{N}x{K}]", lib.lpd_gemm_x3w_stats, _ptr(x), ldx, _ptr(frags), _ptr(y), N, int(bool(out_bf16)), M, N, K, _ptr(bias),
+        _call(f"gemmx3w+stats[{M}x{N}x{K}]", lib.lpd_gemm_x3w_stats, _ptr(x), ldx, _ptr(frags), _ptr(y), N, int(bool(out_bf16)) | (2 if x16 else 0), M, N, K, _ptr(bias),
               _ptr(sums[0]), _ptr(sums[1]), X3W_IMPL, _stat_ws(), _stream())
         return y, _bn_finalize(sums, M, N, bn)
-    if out_bf16:
-        raise ValueError(f"linear_bn_stats: a bf16 result needs the fused kernel (M={M}, N={N}, K={K})")
+    if out_bf16 or x16:
+        raise ValueError(f"linear_bn_stats: bf16 operands need the fused kernel (M={M}, N={N}, K={K})")
     y = linear(x, w, bias=bias)
     return y, bn_train_stats(y, bn)
 
@@ -1179,7 +1188,9 @@ def colsum(X, rows=None):
     return sums[0].float()
 
 
-def affine_act(X, scale, shift, act=ACT_NONE, slope=0.01, out=None, rows=None):
+def affine_act(X, scale, shift, act=ACT_NONE, slope=0.01, out=None, rows=None, out16=None):
+    """out = act(scale * X + shift) over the (first `rows`) rows; out16: a bfloat16 tensor (column slices allowed) that receives a copy
+    of the result rows rounded to bf16 (lpd_affine_act2)."""
     ldx = _rows(X, "X")
     R = X.shape[0] if rows is None else rows
     C = X.shape[1]
@@ -1187,6 +1198,13 @@ def affine_act(X, scale, shift, act=ACT_NONE, slope=0.01, out=None, rows=None):
         out = torch.empty((X.shape[0], C), dtype=torch.float32, device=X.device)
     ldy = _rows(out, "out")
     lib = _lib.load()
+    if out16 is not None:
+        _req(out16, "out16", torch.bfloat16)
+        if out16.dim() != 2 or out16.stride(1) != 1 or out16.shape[1] != C or out16.shape[0] < R or out16.stride(0) % 4 != 0:
+            raise ValueError("affine_act: out16 must be bf16 rows of the result's shape")
+        _call("affine_act", lib.lpd_affine_act2, _ptr(X), ldx, _ptr(out), ldy, _ptr(out16), out16.stride(0), R, C, _ptr(scale), _ptr(shift), act,
+              float(slope), _stream())
+        return out
     _call("affine_act", lib.lpd_affine_act, _ptr(X), ldx, _ptr(out), ldy, R, C, _ptr(scale), _ptr(shift), act, float(slope),
           _stream())
     return out
@@ -1747,10 +1765,15 @@ def gemm_tn(A, B, rows=None, a_affine=None):
     the hi image: two products).  a_affine = (scale [KA], shift [KA], act, slope): A's rows are act(scale * A + shift), applied where
     they are staged (lpd_gemm_tn_act; gemm_tn_act_applies)."""
     a16 = A.dtype == torch.bfloat16
+    b16 = B.dtype == torch.bfloat16      # (with a bf16 A, KA % 256 == 0, KB % 256 == 0: one product per term)
     if a16:
         _req(A, "A", torch.bfloat16)
         if A.stride(-1) != 1 or A.stride(-2) % 8 != 0:
             raise ValueError("gemm_tn: bf16 A needs contiguous rows, leading dim % 8 == 0")
+    if b16:
+        _req(B, "B", torch.bfloat16)
+        if not a16 or B.dim() != 2 or B.stride(1) != 1 or B.stride(0) % 8 != 0 or a_affine is not None:
+            raise ValueError("gemm_tn: bf16 B goes with a bf16 A (2-D, leading dim % 8 == 0, no operand transform)")
     if A.dim() == 3:      # batched: A [nb, M, KA], B [nb, M, KB] -> [nb, KA, KB]
         nb = A.shape[0]
         lda, ldb = A.stride(1) if a16 else _rows(A[0], "A"), _rows(B[0], "B")
@@ -1760,7 +1783,7 @@ def gemm_tn(A, B, rows=None, a_affine=None):
         shape = (nb, KA, KB)
     else:
         nb, sA, sB = 1, 0, 0
-        lda, ldb = A.stride(0) if a16 else _rows(A, "A"), _rows(B, "B")
+        lda, ldb = A.stride(0) if a16 else _rows(A, "A"), B.stride(0) if b16 else _rows(B, "B")
         M = A.shape[0] if rows is None else rows
         KA, KB = A.shape[1], B.shape[1]
         shape = (KA, KB)
@@ -1776,7 +1799,7 @@ def gemm_tn(A, B, rows=None, a_affine=None):
         return dW
     ws = torch.empty((int(lib.lpd_gemm_tn_ws_floats(M, KA, KB, nb)),), dtype=torch.float32, device=A.device)
     _call(f"gemm_tn[{KA}x{KB}x{M}]" + (f"x{nb}" if nb > 1 else ""), lib.lpd_gemm_tn, _ptr(A), lda, _ptr(B), ldb, _ptr(dW), _ptr(ws), M, KA,
-          KB, nb, sA, sB, int(a16), _stream())
+          KB, nb, sA, sB, int(a16) | (2 if b16 else 0), _stream())
     return dW
 
 

@@ -1495,3 +1495,37 @@ def test_operand_transform_without_a_stored_map(cuda, a16):
     assert torch.equal(da, ops.gemm(stored.view(nb, Np, E), dv, a_kmajor=False, b_kmajor=True))
     with pytest.raises(ValueError):
         ops.gemm_tn(raw, wide, a_affine=aff)          # 128-wide B: not built
+
+
+def test_bf16_point_feature_copy_operators(cuda):
+    """bf16 storage keeps a bf16 COPY of the point features [x1 | x2 | x3] (autograd.CAT_BF16): the activation pass writes it beside the fp32
+    rows (lpd_affine_act2), conv3 + statistics takes it as bf16 rows (two products per term, bf16 result), the conv3 weight gradient takes
+    bf16 rows on BOTH sides (one product per term, exact in the operands)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    bf = torch.bfloat16
+    M = 16384 + 128
+    raw = torch.randn(M, 256, generator=g).to(cuda)
+    sc, sh = (0.5 + torch.rand(256, generator=g)).to(cuda), (0.3 * torch.randn(256, generator=g)).to(cuda)
+    cat, cat16 = torch.zeros(M, 512, device=cuda), torch.zeros(M, 512, dtype=bf, device=cuda)
+    ops.affine_act(raw, sc, sh, ops.ACT_LEAKY, 0.2, out=cat[:, 256:512], out16=cat16[:, 256:512])
+    want = ops.affine_act(raw, sc, sh, ops.ACT_LEAKY, 0.2)
+    assert torch.equal(cat[:, 256:512], want) and torch.equal(cat16[:, 256:512], want.to(bf))
+    assert (cat[:, :256] == 0).all() and (cat16[:, :256] == 0).all()
+    cat[:, :256] = torch.randn(M, 256, generator=g).to(cuda)
+    cat16[:, :256] = cat[:, :256].to(bf)
+    # conv3 + statistics on the bf16 rows
+    w = (torch.randn(1024, 512, generator=g) / 22).to(cuda)
+    bn_a, bn_b = torch.nn.BatchNorm1d(1024).to(cuda), torch.nn.BatchNorm1d(1024).to(cuda)
+    y16, st16 = ops.linear_bn_stats(cat16, w, bn_a, out_bf16=True)
+    ref = cat16.double() @ w.double().t()
+    assert y16.dtype == bf and float(((y16.double() - ref).abs() / (ref.abs() * 2.0 ** -8 + 1e-5)).max()) < 1.0
+    mean_ref = ref.mean(0)
+    assert _rel(st16.mean, mean_ref) < 1e-5 and _rel(st16.invstd, 1.0 / torch.sqrt(ref.var(0, unbiased=False) + bn_a.eps)) < 1e-5
+    y32, st32 = ops.linear_bn_stats(cat16.float(), w, bn_b, out_bf16=True)      # the fp32-row kernel on the same values
+    assert _rel(st16.scale, st32.scale) < 1e-5
+    # weight gradient with bf16 rows on both sides: one product, exact in the operands
+    dW = ops.gemm_tn(y16, cat16)
+    assert _rel(dW, y16.double().t() @ cat16.double()) < 2e-6
+    with pytest.raises(Exception):
+        ops.gemm_tn(y16[:, :128].contiguous(), cat16[:, :128].contiguous())      # KA = 128: not built
