@@ -527,7 +527,8 @@ int lpd_edge_split_fwd16(const float* P, long long ldp, const float* Q, long lon
 
 /*
  * Backward of the split-form stage: dOut [M][ldo] = gradient of x3.  half != 0 (bf16 storage, C = 256): the rows the second pass gathers
- * over the transposed graph -- G and Q -- are bf16 copies made by the first pass, kept in the same scratch ([2][M][C] bf16).
+ * over the transposed graph -- G and Q -- are bf16 copies made by the first pass, kept in the same scratch ([2][M][C] bf16); half & 2:
+ * dP / dQ (passed as float*) are bf16 rows as well, lddp / lddq in bf16 elements.
  * G [M][C] (scratch, receives dpre = dOut * act'),
  * dbeta / dgamma [C] doubles (the BatchNorm parameter gradients), dP [M][lddp] and dQ [M][lddq]:
  *   dQ_i = s (dpre_i - k m1 - m2 invstd (S_i + k (Q_i - mu)))

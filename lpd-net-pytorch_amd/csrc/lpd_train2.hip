@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void edge_split_bwd_reduce_kernel(const float*
 // backward: a block holding the 4-channel slices of Q, dpre and arg of a whole cloud in LDS and walking a degree-sorted, slot-major
 // transposed graph (built by LDS atomics + a counting sort in 56 us; heavy rows by a scan kernel): correct, but 8.3 GB of random
 // 16 / 16 / 4-byte LDS reads plus the scattered slice fills cost 762 us against 930 here.)
-template <int LPR, bool H = false>
+// OUT16 (with H): dP / dQ are written as bf16 rows (lddp / lddq in bf16 elements): the gradient of the SN1 projection in the bf16 mode
+template <int LPR, bool H = false, bool OUT16 = false>
 __global__ __launch_bounds__(256) void edge_split_bwd_apply_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ edges,
                                                                    const float* __restrict__ G, const uint8_t* __restrict__ arg,
                                                                    const float* __restrict__ S, const float* __restrict__ P,
@@ -280,8 +281,13 @@ __global__ __launch_bounds__(256) void edge_split_bwd_apply_kernel(const int32_t
             op[c] = sc[c] * (A[c] - deg * m1[c] - m2i[c] * (deg * (pj[c] - mu[c]) + R[c]));
             oq[c] = sc[c] * (gj[c] - kf * m1[c] - m2i[c] * (sj[c] + kf * (qj[c] - mu[c])));
         }
-        *reinterpret_cast<float4*>(dP + j * lddp + cl * 4) = make_float4(op[0], op[1], op[2], op[3]);
-        *reinterpret_cast<float4*>(dQ + j * lddq + cl * 4) = make_float4(oq[0], oq[1], oq[2], oq[3]);
+        if constexpr (OUT16) {
+            st4_bf16(reinterpret_cast<uint16_t*>(dP) + j * lddp + cl * 4, make_float4(op[0], op[1], op[2], op[3]));
+            st4_bf16(reinterpret_cast<uint16_t*>(dQ) + j * lddq + cl * 4, make_float4(oq[0], oq[1], oq[2], oq[3]));
+        } else {
+            *reinterpret_cast<float4*>(dP + j * lddp + cl * 4) = make_float4(op[0], op[1], op[2], op[3]);
+            *reinterpret_cast<float4*>(dQ + j * lddq + cl * 4) = make_float4(oq[0], oq[1], oq[2], oq[3]);
+        }
     }
 }
 
@@ -1258,10 +1264,12 @@ extern "C" int lpd_edge_split_bwd(const float* dOut, long long ldo, const float*
                                   int act, float slope, int half, double* dbeta, double* dgamma, double* stat_ws, void* stream_)
 {
     // half != 0 (bf16 storage): the workspace G holds bf16 rows of G and of Q ([2][M][C] bf16 = the same M C floats); C = 256 only
+    // half & 2: dP / dQ are bf16 rows too (lddp / lddq in bf16 elements)
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(dOut && usel && arg && S && P && Q && rowptr && edges && G && dP && dQ && dbeta && dgamma,
                   "lpd_edge_split_bwd: null pointer");
     LPD_CHECK_ARG(!half || C == 256, "lpd_edge_split_bwd: the bf16 form is built for C = 256");
+    LPD_CHECK_ARG(!(half & 2) || (half & 1), "lpd_edge_split_bwd: bf16 outputs go with the bf16 gather rows");
     LPD_CHECK_ARG(C == 64 || C == 128 || C == 256, "lpd_edge_split_bwd: C=%d unsupported", C);
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_split_bwd: activation %d unsupported", act);
     LPD_CHECK_ARG(ldo % 4 == 0 && ldp % 4 == 0 && ldq % 4 == 0 && lddp % 4 == 0 && lddq % 4 == 0, "lpd_edge_split_bwd: leading dims % 4");
@@ -1276,7 +1284,8 @@ extern "C" int lpd_edge_split_bwd(const float* dOut, long long ldo, const float*
     if (int rc = lpd_stat_finish(ws, dbeta, dgamma, C, stream)) return rc;
     const int lpr = C / 4;
     const int grid = grid_for(M, 4 * (64 / lpr) * 2, 8192);
-    if (half) hipLaunchKernelGGL((edge_split_bwd_apply_kernel<64, true>), dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
+    if (half & 2) hipLaunchKernelGGL((edge_split_bwd_apply_kernel<64, true, true>), dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
+    else if (half) hipLaunchKernelGGL((edge_split_bwd_apply_kernel<64, true>), dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
     else if (C == 64) hipLaunchKernelGGL(edge_split_bwd_apply_kernel<16>, dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
     else if (C == 128) hipLaunchKernelGGL(edge_split_bwd_apply_kernel<32>, dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);
     else hipLaunchKernelGGL(edge_split_bwd_apply_kernel<64>, dim3(grid), dim3(256), 0, stream, rowptr, edges, (const float*)G, arg, S, P, ldp, Q, ldq, dP, lddp, dQ, lddq, M, k, scale, mean, invstd, (const double*)dbeta, (const double*)dgamma);

@@ -169,6 +169,7 @@ MAP_BF16 = __import__("os").environ.get("LPD_MAP_BF16", "1") != "0"
 # ... and a bf16 COPY of the point features [x1 | x2 | x3] beside the fp32 ones (written by the activation passes that produce them):
 # conv3 takes it as bf16 rows (two products per term), its weight gradient as bf16 rows on both sides (one).  LPD_CAT_BF16=0: off
 CAT_BF16 = __import__("os").environ.get("LPD_CAT_BF16", "1") != "0"
+PQ3_BF16 = __import__("os").environ.get("LPD_PQ3_BF16", "1") != "0"      # ... and the gradient of the SN1 projection [B N, 512]
 
 
 def set_train_storage(kind):
@@ -542,14 +543,21 @@ class _LPDNetTrainFn(torch.autograd.Function):
             dcat, dw3, dg3, db3 = _PointLayer.bwd(dfeat, S["cat"], w2d(net.conv3_lpd), S["y3"], S["st3"], act, slope,
                                                   inplace=False)
         # SN1: x3 = max_k act(BN(P[nbr] + Q)), split form (closed-form sums over the edges, one pass over the transposed graph)
-        dpq3 = torch.empty((M, 512), dtype=torch.float32, device=dfeat.device)    # both halves are fully written below
+        # (bf16 storage: the gradient of the SN1 projection as bf16 rows -- its two consumers take them as the hi image)
+        pq16 = (ctx.bf16 and PQ3_BF16 and ops.SPLIT_BWD_BF16 and ops.GEMM_TN and ops.GEMM_BF16X3 and M % 32 == 0 and M >= 2048
+                and ops._EXACT.depth == 0)
+        dpq3 = torch.empty((M, 512), dtype=torch.bfloat16 if pq16 else torch.float32, device=dfeat.device)    # both halves are fully written below
         pq3 = S["pq3"]
         dgs3, dbs3 = ops.edge_split_bwd(dcat[:, 256:512], S["usel3"], S["arg3"], S["s3"], pq3[:, :256], pq3[:, 256:],
                                         ops.GraphT(S["idx_x"], N), S["stg3"], act, slope, k, dP=dpq3[:, :256], dQ=dpq3[:, 256:],
                                         half=ctx.bf16)
         x2 = S["cat"][:, 128:256]
-        dwcat3 = _dweight(dpq3, x2)
-        ops.gemm(dpq3, S["wcat3"], b_kmajor=True, out=dcat[:, 128:256], accumulate=True)   # dx2 += dPQ3 Wcat3
+        if pq16:
+            dwcat3 = ops.gemm_tn(dpq3, x2)
+            ops.gemm_bf16a(dpq3, S["wcat3"], b_kmajor=True, out=dcat[:, 128:256], accumulate=True)
+        else:
+            dwcat3 = _dweight(dpq3, x2)
+            ops.gemm(dpq3, S["wcat3"], b_kmajor=True, out=dcat[:, 128:256], accumulate=True)   # dx2 += dPQ3 Wcat3
         dpq1 = torch.empty((M, 256), dtype=torch.float32, device=dfeat.device)
         w2 = w2d(net.convDG2[0])
         closed = (S["post1"] and ops.EDGE_MLP_TRAIN_BWD and ops.dg2_bwd_fused_applies(M, k, w2.shape[0]) and w2.shape[1] == 128

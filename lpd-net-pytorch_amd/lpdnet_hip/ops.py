@@ -1432,14 +1432,24 @@ SPLIT_BWD_BF16 = os.environ.get("LPD_SPLIT_BWD_BF16", "1") != "0"   # bf16 stora
 def edge_split_bwd(dOut, usel, arg, S, P, Q, graph, st, act, slope, k, dP, dQ, half=False):
     """Backward half: dOut [M,C] (view allowed) -> fills dP, dQ ([M,C] views), returns (dgamma, dbeta) fp32.
     half (bf16 storage, C = 256): the rows gathered over the transposed graph are bf16 copies (lpd_edge_split_bwd)."""
-    ldo, ldp, ldq, lddp, lddq = _rows(dOut, "dOut"), _rows(P, "P"), _rows(Q, "Q"), _rows(dP, "dP"), _rows(dQ, "dQ")
+    out16 = dP.dtype == torch.bfloat16      # (bf16 storage: the gradient rows of the projection as bf16, with half)
+    if out16:
+        for t_, n_ in ((dP, "dP"), (dQ, "dQ")):
+            _req(t_, n_, torch.bfloat16)
+            if t_.dim() != 2 or t_.stride(1) != 1 or t_.stride(0) % 4 != 0:
+                raise ValueError(f"edge_split_bwd: {n_} must be bf16 rows")
+        if not (half and SPLIT_BWD_BF16 and usel.shape[1] == 256):
+            raise ValueError("edge_split_bwd: bf16 dP / dQ go with the bf16 gather rows (half=True, C = 256)")
+        ldo, ldp, ldq, lddp, lddq = _rows(dOut, "dOut"), _rows(P, "P"), _rows(Q, "Q"), dP.stride(0), dQ.stride(0)
+    else:
+        ldo, ldp, ldq, lddp, lddq = _rows(dOut, "dOut"), _rows(P, "P"), _rows(Q, "Q"), _rows(dP, "dP"), _rows(dQ, "dQ")
     M, C = usel.shape
     G = torch.empty((M, C), dtype=torch.float32, device=usel.device)
     red = torch.empty((2, C), dtype=torch.float64, device=usel.device)
     lib = _lib.load()
     _call(f"edge_split_bwd[C={C}]", lib.lpd_edge_split_bwd, _ptr(dOut), ldo, _ptr(usel), _ptr(arg), _ptr(S), _ptr(P), ldp, _ptr(Q), ldq,
           _ptr(graph.rowptr), _ptr(graph.edges), _ptr(G), _ptr(dP), lddp, _ptr(dQ), lddq, M, C, k, _ptr(st.scale), _ptr(st.shift),
-          _ptr(st.mean), _ptr(st.invstd), act, float(slope), int(bool(half) and SPLIT_BWD_BF16 and C == 256), _ptr(red[0]), _ptr(red[1]),
+          _ptr(st.mean), _ptr(st.invstd), act, float(slope), (3 if out16 else 1) if (half and SPLIT_BWD_BF16 and C == 256) else 0, _ptr(red[0]), _ptr(red[1]),
           _stat_ws(), _stream())
     redf = red.float()
     return redf[1], redf[0]

@@ -753,6 +753,11 @@ def test_split_form_edge_stage_equals_the_materialised_one(cuda, C, N, k, B):
         assert torch.equal(dg_h, dg_b) and torch.equal(db_h, db_b)
         assert _rel(buf16[:, 4:4 + C], dP_a) < 6e-3 and _rel(buf16[:, 4 + C:4 + 2 * C], dQ_a) < 6e-3
         assert not torch.equal(buf16, buf)
+        out16 = torch.zeros(M, 2 * C + 16, dtype=torch.bfloat16, device=cuda)      # ... and dP / dQ themselves as bf16 rows (half & 2)
+        dg_o, db_o = ops.edge_split_bwd(dOut, usel, arg_b, S, P, Q, ops.GraphT(idx, N), st_b, act, slope, k, dP=out16[:, 8:8 + C],
+                                        dQ=out16[:, 8 + C:8 + 2 * C], half=True)
+        assert torch.equal(dg_o, dg_b) and torch.equal(out16[:, 8:8 + 2 * C], buf16[:, 4:4 + 2 * C].to(torch.bfloat16))
+        assert (out16[:, :8] == 0).all() and (out16[:, 8 + 2 * C:] == 0).all()
 
 
 def test_bf16_storage_edge_kernels(cuda):

@@ -648,7 +648,7 @@ def test_standalone_train_mode_forwards_of_the_submodules(cuda):
                                  {"LPD_EDGE_MLP_TRAIN_BWD": "0", "LPD_ASSIGN_ACT": "0"},       # ... its backward on the round-3 chain, bn3 as its own pass
                                  {"LPD_Z_BF16": "0"},
                                  {"LPD_MAP_BF16": "0", "LPD_TN_TR": "0", "LPD_DW_SEL_TR": "0"},  # fp32 conv3 map in the bf16 mode, register-transposing dW
-                                 {"LPD_SPLIT_BWD_BF16": "0", "LPD_FEAT_IN_LOADER": "0", "LPD_X3W_BATCHED": "0", "LPD_EDGE_NOZ": "0", "LPD_CAT_BF16": "0"}],
+                                 {"LPD_SPLIT_BWD_BF16": "0", "LPD_FEAT_IN_LOADER": "0", "LPD_X3W_BATCHED": "0", "LPD_EDGE_NOZ": "0", "LPD_CAT_BF16": "0", "LPD_PQ3_BF16": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_training_switches_are_live(env):
     """The training-path switches README.md documents are read at import (or at the first launch): the bf16-storage oracle
