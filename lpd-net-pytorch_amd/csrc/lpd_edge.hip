@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
         ar1[r >> 2] |= (uint32_t)g.arg1[m * CM + n] << (8 * (r & 3));
     }
     const float beta1 = g.beta1[n], rg1 = g.rgamma1[n];
-    const float ns = lpd_neg_slope(g.act, g.slope), inv_ns = g.inv_ns;
+    const float ns = lpd_neg_slope(g.act, g.slope);
 
     typedef unsigned zraw_t __attribute__((ext_vector_type((NOZ ? BF16 : ZBF16) ? 2 : 4)));
     zraw_t zr[PASSES];          // the builder's rows of Z -- NOZ: of Y1e
@@ -1391,11 +1391,9 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
             if constexpr (NOZ) y = __uint_as_float((unsigned)__builtin_bit_cast(unsigned short, yi[((r & 3) + 8 * (r >> 2)) * LDK]) << 16);
             else y = __uint_as_float(yv[r]);
             const float gy = acc[r] + cvn + (((ar1[r >> 2] >> (8 * (r & 3))) & 0xffu) == tb ? dx1v[r] : 0.0f);
-            const bool pos = y > 0.0f;
-            const float gg = gy * (pos ? 1.0f : ns);
-            const float pre = pos ? y : y * inv_ns;
+            const float gg = gy * (y > 0.0f ? 1.0f : ns);
             sg += gg;
-            sgx = fmaf(gg, (pre - beta1) * rg1, sgx);
+            sgx = fmaf(gy, y, sgx);      // sum G pre1: G pre1 = gy y on BOTH sides of the activation (G = gy ns, pre1 = y / ns); xhat1 at the end
             gsum[r] += gg;
             const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * rowb + (unsigned)t * (CM * ES);
             if constexpr (BF16) {
@@ -1412,6 +1410,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
     for (int r = 0; r < 16; ++r) g.gsum[(size_t)(m0 + (r & 3) + 8 * (r >> 2) + 4 * h) * CM + n] = gsum[r];
     sg += __shfl_xor(sg, 32);
     sgx += __shfl_xor(sgx, 32);
+    sgx = (sgx - beta1 * sg) * rg1;      // sum G xhat1 = (sum G pre1 - beta1 sum G) / gamma1
     if (h == 0) {
         atomicAdd(&g.sum[lpd_stat_rofs() + n], (double)sg);
         atomicAdd(&g.sumx[lpd_stat_rofs() + n], (double)sgx);
