@@ -954,7 +954,8 @@ struct EdgeMlpTrainArgs {
 typedef unsigned em_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned em_u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool BF16, bool ZBF16>
+// ZST = false: Z is not stored at all (its conversion, lane exchange and store instructions leave the epilogue: the kernel is bound by them)
+template <bool BF16, bool ZBF16, bool ZST = true>
 __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_kernel(EdgeMlpTrainArgs g)
 {
     constexpr int CM = 128;
@@ -1092,7 +1093,8 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_kernel(EdgeMlpTr
                 const float v = acc[i][r];
                 const unsigned zsoff = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rowbz + (unsigned)t * (CM * ESZ);      // uniform
                 const float z = sgn * v;
-                if constexpr (ZBF16) {
+                if constexpr (!ZST) {
+                } else if constexpr (ZBF16) {
                     // the stored value is the rounded one; statistics and selection are taken of the fp32 value (as lpd_gemm_bf16s +
                     // lpd_group_sel_stats_bf16 take them of the stored one: the difference is the 2^-9 the storage mode states)
                     const __bf16 zb = (__bf16)z;
@@ -1616,7 +1618,8 @@ extern "C" int lpd_edge_mlp_train(const float* P, int ldp, const float* Q, int l
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(M / EM_PTS), dim3(EM_THREADS), lds, stream, g);
     };
-    if (bf16) launch(edge_mlp_train_kernel<true, true>);
+    if (bf16 && !Z) launch(edge_mlp_train_kernel<true, true, false>);
+    else if (bf16) launch(edge_mlp_train_kernel<true, true>);
     else if (z_bf16) launch(edge_mlp_train_kernel<false, true>);
     else launch(edge_mlp_train_kernel<false, false>);
     LPD_CHECK_LAUNCH("lpd_edge_mlp_train");

@@ -727,7 +727,9 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
                         bf16x4 ob;
                         ob[0] = (__bf16)v.x; ob[1] = (__bf16)v.y; ob[2] = (__bf16)v.z; ob[3] = (__bf16)v.w;
                         if (put) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(g.a_out) + (long long)m * g.a_ld + kk) = ob;
-                        v = make_float4((float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]);
+                        // (the rounded values ARE the hi image and the lo image is zero: prods = 2 never reads it -- no split, no second store)
+                        *reinterpret_cast<bf16x4*>(hi_img + rr * X3V_LDK + k4 * 4) = ob;
+                        continue;
                     } else if (put) {
                         *reinterpret_cast<float4*>(g.a_out + (long long)m * g.a_ld + kk) = v;
                     }
