@@ -611,12 +611,12 @@ int lpd_gemm_tn_bf16(const uint16_t* A, const uint16_t* B, float* dW, float* ws,
 /* dW [KA][KB] (fp32) = sum_m A[m][:]^T B[m][:] for fp32 operands A [M][lda], B [M][ldb] in split-bf16 form (three MFMA products per
  * term, fp32-grade): the weight gradients dW = dY^T X of the training path and, batched over the clouds, the NetVLAD residual
  * pooling act^T x (util/PointNetVlad.py:64-67).  batch problems at strides sA / sB (elements) write dW [batch][KA][KB].
- * KA %% 128 == 0, KB %% 64 == 0; ws: lpd_gemm_tn_ws_floats(M, KA, KB, batch) floats.  * a_bf16 is a flag word: bit 0 = A holds bf16 rows (lda / sA in bf16 elements), bit 1 = B holds bf16 rows as well (ldb in bf16 elements;
+ * KA %% 128 == 0, KB %% 64 == 0; ws: lpd_gemm_tn_ws_floats(M, KA, KB, batch) floats.  * bf16_rows is a flag word: bit 0 = A holds bf16 rows (lda / sA in bf16 elements), bit 1 = B holds bf16 rows as well (ldb in bf16 elements;
  * needs bit 0, KA % 256 == 0, KB % 256 == 0, M % 32 == 0, M >= 2048, batch 1): one product per term, exact in the operands.
  */
 long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB, int batch);
 int lpd_gemm_tn(const void* A, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
-                int batch, long long sA, long long sB, int a_bf16, void* stream);
+                int batch, long long sA, long long sB, int bf16_rows, void* stream);
 /* lpd_gemm_tn with the rows of A taken as act(a_scale[a] A[m][a] + a_shift[a]) (multiply, then add: lpd_affine_act's bits; bf16 rows:
  * rounded to bf16 again): a train-mode BatchNorm affine + activation applied where the raw map is staged, so that the activated
  * [B N, 1024] map of util/lpdnet_model.py:262 need not be stored for util/PointNetVlad.py:64-67 (pooling) and the assignment's weight

@@ -1776,9 +1776,9 @@ extern "C" long long lpd_gemm_tn_act_ws_floats(long long M, int KA, int KB, int 
 }
 
 extern "C" int lpd_gemm_tn(const void* A_, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
-                           int batch, long long sA, long long sB, int a_bf16, void* stream_)
+                           int batch, long long sA, long long sB, int bf16_rows, void* stream_)
 {
-    return gemm_tn_impl(A_, lda, B, ldb, dW, ws, M, KA, KB, batch, sA, sB, a_bf16, nullptr, nullptr, 1.0f, stream_);
+    return gemm_tn_impl(A_, lda, B, ldb, dW, ws, M, KA, KB, batch, sA, sB, bf16_rows, nullptr, nullptr, 1.0f, stream_);
 }
 
 extern "C" int lpd_gemm_tn_act(const void* A_, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
