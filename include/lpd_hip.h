@@ -611,8 +611,11 @@ int lpd_gemm_tn_bf16(const uint16_t* A, const uint16_t* B, float* dW, float* ws,
 /* dW [KA][KB] (fp32) = sum_m A[m][:]^T B[m][:] for fp32 operands A [M][lda], B [M][ldb] in split-bf16 form (three MFMA products per
  * term, fp32-grade): the weight gradients dW = dY^T X of the training path and, batched over the clouds, the NetVLAD residual
  * pooling act^T x (util/PointNetVlad.py:64-67).  batch problems at strides sA / sB (elements) write dW [batch][KA][KB].
- * KA %% 128 == 0, KB %% 64 == 0; ws: lpd_gemm_tn_ws_floats(M, KA, KB, batch) floats.  * bf16_rows is a flag word: bit 0 = A holds bf16 rows (lda / sA in bf16 elements), bit 1 = B holds bf16 rows as well (ldb in bf16 elements;
- * needs bit 0, KA % 256 == 0, KB % 256 == 0, M % 32 == 0, M >= 2048, batch 1): one product per term, exact in the operands.
+ * KA %% 128 == 0, KB %% 64 == 0; ws: lpd_gemm_tn_ws_floats(M, KA, KB, batch) floats.
+ * bf16_rows is a flag word: bit 0 = A holds bf16 rows (lda / sA in bf16 elements; they are the hi image: two products), bit 1 = B holds
+ * bf16 rows as well (ldb in bf16 elements; needs bit 0, KA % 256 == 0, KB % 256 == 0, M % 32 == 0, M >= 2048, batch 1): one product per
+ * term, exact in the operands.  Products with KA % 256 == 0 over whole 32-row chunks run on row-major LDS images read with
+ * ds_read_b64_tr_b16, the others on the register-transposing kernels.
  */
 long long lpd_gemm_tn_ws_floats(long long M, int KA, int KB, int batch);
 int lpd_gemm_tn(const void* A, long long lda, const float* B, long long ldb, float* dW, float* ws, long long M, int KA, int KB,
