@@ -36,7 +36,46 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-KAGG_ROW_BYTES = 3 * 256 * 4   # C=256 fp32, split form: P row + Q row + out row; + 4*k for the indices
+KAGG_ROW_BYTES = 3 * 256 * 4   # C=256 fp32, split form: P row + Q row + out row; + KAGG_IDX_BYTES * k for the indices
+KAGG_IDX_BYTES = 2             # the K-agg kernels read uint16 indices (lpd_pack_idx16 / lpd_pack_idx16w), not the int32 of SURVEY 8d
+MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
+VALU_F32_PEAK_TF = 157.3       # fp32 vector peak (= f32-input MFMA peak): the bound of the exact-fp32 kNN distance arithmetic
+
+
+def kernel_rooflines(kern, batch, points, k, split_bf16):
+    """Roofline entries of the step's DOMINANT kernels (the K-agg the headline `roofline` names is ~5 % of the step): algorithmic FLOPs of
+    SURVEY.md 8(d) per launch / HIP-event time of the launch (this run's `kernels` table) / the peak of the unit that bounds it.
+    `executed` = the FLOPs the matrix cores actually issue (three bf16 products per term on the split-bf16 path)."""
+    M = batch * points
+    out = {}
+
+    def add(name, key, flops, peak, bound, note, mult=1.0):
+        if key not in kern:
+            return
+        t = kern[key]["avg_us"] * 1e-6
+        ach = flops / t / 1e12
+        out[name] = {"key": key, "bound": bound, "avg_launch_us": kern[key]["avg_us"], "algorithmic_flops_per_launch": int(flops),
+                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                     **({"executed_frac": round(mult * ach / peak, 4)} if mult != 1.0 else {}), "note": note}
+    x3 = 3.0 if split_bf16 else 1.0
+    pk = MFMA_BF16_PEAK_TF if split_bf16 else VALU_F32_PEAK_TF
+    how = "three bf16 MFMA products per term (split-bf16), fp32 accumulate" if split_bf16 else "f32-input MFMA (exact fp32)"
+    key = next((k_ for k_ in kern if k_.startswith("gemm_p8")), None) or next((k_ for k_ in kern if k_.endswith(f"[{M}x1024x512]")), None)
+    if key:
+        fused = "+assign" in key
+        add("conv3" + (" + NetVLAD assignment" if fused else ""), key, 2.0 * M * 512 * 1024 + (2.0 * M * 1024 * 64 if fused else 0.0), pk, "mfma",
+            "SURVEY 8d K-mlp conv3 (512 -> 1024)" + (" + the assignment product x . cluster_weights (PointNetVlad.py:48) in the same launch" if fused else "") + "; " + how, x3)
+    key = next((k_ for k_ in kern if k_.startswith("edge_mlp")), None)
+    if key:
+        add("edge MLP (DG1 act -> DG2 conv -> max over k)", key, 2.0 * M * k * 128 * 128, pk, "mfma",
+            "SURVEY 8d K-agg DG1->DG2 fused: 2 N k 128 128 per cloud; " + how, x3)
+    for C, what in ((64, "feature-space kNN"), (3, "xyz kNN")):
+        key = f"knn[C={C},k={k}]"
+        add(what, key, float(batch) * (2.0 * points * points * C + 3.0 * points * points), VALU_F32_PEAK_TF, "fp32 vector / f32-input MFMA",
+            "SURVEY 8d K-knn: 2 N^2 C + 3 N^2 per cloud, exact fp32 (bit-exact indices forbid reduced precision); the entry covers every "
+            "launch of the search (bounds, launch order, best-first walk); the best-first walk skips tiles, so `frac` is against the "
+            "FULL distance matrix's FLOPs")
+    return out
 
 
 def parse():
@@ -210,6 +249,7 @@ def cpu_train_baseline(points, threads, seconds_target=25.0):
     B, t6, n6 = run(1, 2, 2, 3)
     rec = {"value": round(1.0 / t6, 4), "unit": "steps/s", "cores": threads, "kind": "port", "clouds_per_step": B,
            "clouds_per_s": round(B / t6, 3),
+           "compare": f"per cloud: this step holds {B} clouds, the GPU step 44 -- divide clouds_per_s by clouds_per_s, not steps/s by steps/s",
            "sample": f"torch-CPU oracle (ATen + autograd: the reference's formulation), quadruplet train step bq=1 P=2 Ng=2 -> {B} clouds "
                      f"x {points} pts, forward + lazy quadruplet loss + backward + Adam, {threads} threads, median of {n6} after a warm-up step"}
     try:
@@ -258,7 +298,7 @@ def _dist_max(dist, dev, value):
     return float(t.item())
 
 
-def train_bench(dev, dist, world, rank, points, steps, warmup=4, storage="f32", tuple_shape=(2, 2, 18), label=None):
+def train_bench(dev, dist, world, rank, points, steps, warmup=4, storage="f32", tuple_shape=(2, 2, 18), label=None, featnet="lpdnet"):
     """Secondary metric of BASELINE.json: quadruplet train-steps/s (configs[2]: bq=2, P=2, Ng=18 -> 44 clouds/rank,
     lazy quadruplet loss, Adam), data-parallel across ranks with the RCCL gradient all-reduce (configs[3]).
     Four untimed steps first: the leg starts from an emptied allocator cache (12 GiB of blocks to re-create), and with two
@@ -269,7 +309,7 @@ def train_bench(dev, dist, world, rank, points, steps, warmup=4, storage="f32", 
     bq, P, Ng = tuple_shape
     B = bq * (1 + P + Ng + 1)
     torch.manual_seed(1234)
-    model = PointNetVlad(num_points=points, featnet="lpdnet", emb_dims=1024, output_dim=256).to(dev).train()
+    model = PointNetVlad(num_points=points, featnet=featnet, emb_dims=1024, output_dim=256).to(dev).train()
     net = model
     if dist is not None:
         from lpdnet_hip.parallel import GradAllReduce
@@ -337,54 +377,79 @@ def train_bench(dev, dist, world, rank, points, steps, warmup=4, storage="f32", 
     finally:
         autograd.set_train_storage(prev_storage)
     return {"metric": "quadruplet train-steps/sec", "value": round(steps / el, 3), "unit": "steps/s",
-            "tuples_per_s": round(bq * world * steps / el, 3), "ms_per_step": round(1e3 * el / steps, 2), "steps": steps,
-            "config": (label or f"BASELINE configs[{2 if world == 1 else 3}]") + f": bq={bq} P={P} Ng={Ng} -> {B} clouds/rank, N={points}, lazy quadruplet, "
+            "tuples_per_s": round(bq * world * steps / el, 3), "clouds_per_s": round(B * world * steps / el, 1),
+            "ms_per_step": round(1e3 * el / steps, 2), "steps": steps,
+            "config": (label or f"BASELINE configs[{2 if world == 1 else 3}]") + f": featnet={featnet}, bq={bq} P={P} Ng={Ng} -> {B} clouds/rank, N={points}, lazy quadruplet, "
                       f"Adam (torch fused), {storage} storage; x{world} ranks data-parallel (per-rank BN, gradient all-reduce)",
             "dtype": storage, "losses": losses, "peak_hbm_gib": round(peak, 2), "exchange": comm, "per_step": per_step}
 
 
-def secondary_eval(dev, points, k, batch, steps, warmup=2):
+def secondary_eval(dev, points, k, batch, steps, warmup=2, featnet="lpdnet", exact=False, kernels=False):
     """One more eval-forward measurement on rank 0's GPU (world 1 only), reported INSIDE the JSON line next to the headline
     workload: same model family, random-init weights, clouds resident in HBM; the K-agg launches of the SN1 stage are bracketed
-    by HIP events inside the timed region, like the headline's."""
+    by HIP events inside the timed region, like the headline's.  featnet: the trunk ('lpdnetorigin' = the reference's argparse
+    default, util/initPara.py:74).  exact: every product on the f32-input MFMA (what LPD_GEMM_FP32=1 selects) instead of split-bf16.
+    kernels: add the per-op table (a separate untimed pass) and the dominant kernels' roofline entries."""
     from lpdnet_hip import ops
     from util.PointNetVlad import PointNetVlad
     torch.manual_seed(1234)
-    model = PointNetVlad(num_points=points, featnet="lpdnet", emb_dims=1024, output_dim=256)
+    model = PointNetVlad(num_points=points, featnet=featnet, emb_dims=1024, output_dim=256)
     model.emb_nn.k = k
     model = model.to(dev).eval()
     gen = torch.Generator().manual_seed(4321)
     clouds = [(torch.rand((batch, 1, points, 3), generator=gen) * 2 - 1).to(dev) for _ in range(2)]
-    with torch.no_grad():
-        gc.collect()
-        gc.disable()                                    # until the timed steps are over (see _time_steps)
-        for i in range(warmup + 1):
-            model(clouds[i % 2])
-        torch.cuda.synchronize()
-        ops.PROFILE, ops.PROFILE_ONLY = {}, ("edge_gather_max",)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            model(clouds[i % 2])
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+    was_x3 = ops.GEMM_BF16X3
+    if exact:
+        ops.GEMM_BF16X3 = False      # the module switch LPD_GEMM_FP32=1 sets at import
+    try:
+        with torch.no_grad():
+            gc.collect()
+            gc.disable()                                    # until the timed steps are over (see _time_steps)
+            for i in range(warmup + 1):
+                model(clouds[i % 2])
+            torch.cuda.synchronize()
+            ops.PROFILE, ops.PROFILE_ONLY = {}, ("edge_gather_max",)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                model(clouds[i % 2])
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            gc.enable()
+            kern = kernel_table(ops.PROFILE)
+            kern_all = None
+            if kernels:
+                ops.PROFILE, ops.PROFILE_ONLY = {}, None
+                for i in range(3):
+                    model(clouds[i % 2])
+                torch.cuda.synchronize()
+                kern_all = kernel_table(ops.PROFILE)
+                kern_all.update(kern)
+            ops.PROFILE, ops.PROFILE_ONLY = None, None
+        split = ops.GEMM_BF16X3
+    finally:
+        ops.GEMM_BF16X3 = was_x3
+        ops.PROFILE, ops.PROFILE_ONLY = None, None
         gc.enable()
-    kern = kernel_table(ops.PROFILE)
-    ops.PROFILE, ops.PROFILE_ONLY = None, None
     rec = {"metric": "global descriptors/sec", "value": round(batch * steps / el, 2), "unit": "descriptors/s",
            "ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "warmup": warmup + 1,
-           "config": {"num_points": points, "k": k, "clouds_per_step": batch}}
+           "config": {"featnet": featnet, "num_points": points, "k": k, "clouds_per_step": batch,
+                      "arithmetic": "every product on the f32-input MFMA (exact fp32; LPD_GEMM_FP32=1)" if exact else "split-bf16 products, fp32 accumulate"}}
     key = next((k_ for k_ in kern if k_.startswith("edge_gather_max") and k_.endswith("[C=256]")), None)
     if key is not None:
         t_s = kern[key]["avg_us"] * 1e-6
         per_step = max(1, round(kern[key]["launches"] / steps))      # a large batch runs as slices (engine.EVAL_CHUNK): one launch per slice
         pts = batch * points // per_step
-        alg = (KAGG_ROW_BYTES + 4 * k) * pts
+        alg = (KAGG_ROW_BYTES + KAGG_IDX_BYTES * k) * pts
         alg_direct = (128 * 4 + 256 * 4 + 4 * k) * pts
         rec["config"]["clouds_per_launch"] = batch // per_step
         rec["roofline"] = {"kernel": f"{ops.KAGG_KERNEL_NAMES.get(key.split('[')[0], key)}, SN1 stage, C=256, k={k}", "bound": "hbm",
                            "achieved": round(alg / t_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(alg / t_s / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_us": kern[key]["avg_us"],
                            "algorithmic_bytes_per_launch": alg, "frac_direct_form": round(alg_direct / t_s / 1e9 / HBM_PEAK_GBS, 4)}
+    if kern_all is not None:
+        rec["kernels"] = kern_all
+        if featnet == "lpdnet":
+            rec["roofline_kernels"] = kernel_rooflines(kern_all, batch, points, k, split)
     del model, clouds
     torch.cuda.empty_cache()
     return rec
@@ -456,13 +521,12 @@ def main():
 
     # Settling phase, before the W warm-up steps of the contract: a box that has been idle runs its first ~second of kernels
     # below its steady clocks (first process on a fresh box: 3.0-3.2 ms per step for a whole 20-step region, 2.1 ms in the
-    # process that follows), and engine.calibrate times the forward with and without the second HIP stream (interleaved, medians).
+    # process that follows).
     t_settle = time.perf_counter()
     n_settle = 0
     for _ in range(4):                                  # allocator, fragment caches, clocks
         step(n_settle)
         n_settle += 1
-    engine.calibrate(model, clouds[0])                  # one or two HIP streams on this device: measured here, never inside a forward
     while n_settle < 6 or time.perf_counter() - t_settle < args.settle_seconds:
         step(n_settle)
         n_settle += 1
@@ -508,22 +572,14 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = ops.PROFILE
-    # the per-op tables of the JSON line come from separate, untimed passes with every launch bracketed:
-    # (a) as the forward runs (two HIP streams: entries of kernels that overlap include the time they share the chip),
-    # (b) on ONE stream (engine.SIDE_STREAM off): clean per-op durations
+    # the per-op table of the JSON line comes from a separate, untimed pass with every launch bracketed (HIP events on the launch stream);
+    # a 32-cloud step runs on ONE stream (engine._side_mode), so the entries are clean per-op durations
     ops.PROFILE, ops.PROFILE_ONLY = {}, None
-    for i in range(min(args.steps, 5)):
+    for i in range(min(args.steps, 5) + 1):
         step(i)
     torch.cuda.synchronize()
     prof_all = ops.PROFILE
     prof_all.update({k_: v for k_, v in prof.items()})      # K-agg entries: the timed region's own measurements
-    engine._SIDE_FORCE.mode = False
-    ops.PROFILE = {}
-    for i in range(min(args.steps, 5) + 1):
-        step(i)
-    torch.cuda.synchronize()
-    prof_serial = ops.PROFILE
-    engine._SIDE_FORCE.mode = None
     ops.PROFILE = None
     per_rank = [round(args.batch * args.steps / my_elapsed, 1)]
     if dist is not None:
@@ -537,7 +593,6 @@ def main():
     value = total_desc / elapsed
 
     kern = kernel_table(prof_all)
-    kern1 = kernel_table(prof_serial)
     roof = None
     key, kname = "edge_gather_max16[C=256]", "edge_gather_max_cloud16p_kernel (persistent workgroups, LDS-resident cloud slice)"
     if key not in kern:     # k != 20 or N > 4096
@@ -546,7 +601,7 @@ def main():
     if key in kern:
         t_s = kern[key]["avg_us"] * 1e-6
         pts = args.batch * args.points
-        alg = (KAGG_ROW_BYTES + 4 * args.k) * pts
+        alg = (KAGG_ROW_BYTES + KAGG_IDX_BYTES * args.k) * pts
         alg_direct = (128 * 4 + 256 * 4 + 4 * args.k) * pts      # SURVEY 8d direct form: x2 row in, indices, x3 row out
         ach = alg / t_s / 1e9
         traffic, traffic_source = None, None
@@ -577,14 +632,15 @@ def main():
         roof = {"kernel": f"{kname}, SN1 stage, C=256, k={args.k}", "bound": "hbm", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_us": kern[key]["avg_us"],
-                "numerator": "split form: P row + Q row + out row + int32 indices per point (the rows this kernel reads and "
-                             "writes once; P and Q exist because the SN1 convolution is split, DESIGN.md 3.3)",
+                "numerator": "split form: P row + Q row + out row + uint16 indices (2 k bytes) per point (the bytes this kernel reads and "
+                             "writes once; P and Q exist because the SN1 convolution is split, DESIGN.md); frac_direct_form keeps SURVEY 8d's "
+                             "1616 B/pt (x2 row, int32 indices, x3 row)",
                 "frac_direct_form": round(alg_direct / t_s / 1e9 / HBM_PEAK_GBS, 4),
                 "direct_form_bytes_per_launch": alg_direct}
         # the SN1 stage as a whole: projection GEMM + K-agg for the stage's own inputs/outputs (x2 in, indices, x3 out)
-        pk = next((k_ for k_ in kern1 if k_.startswith("gemm") and k_.endswith(f"[{pts}x512x128]")), None)
-        if pk is not None and key in kern1:
-            t_stage = (kern1[pk]["avg_us"] + kern1[key]["avg_us"]) * 1e-6
+        pk = next((k_ for k_ in kern if k_.startswith("gemm") and k_.endswith(f"[{pts}x512x128]")), None)
+        if pk is not None:
+            t_stage = (kern[pk]["avg_us"] + kern[key]["avg_us"]) * 1e-6
             roof["stage"] = {"kernels": [pk, key], "us": round(t_stage * 1e6, 1),
                              "frac_direct_form": round(alg_direct / t_stage / 1e9 / HBM_PEAK_GBS, 4)}
 
@@ -593,7 +649,11 @@ def main():
         # configs[1] "run both" batch sizes (evaluate.py:101-102 multiplies eval_batch_size by 1+P+Ng), and the
         # stress configuration configs[4] with its K-agg roofline, so that neither is builder-run only
         secondary = {"configs[1] at 128 clouds/step": secondary_eval(dev, 4096, 20, 128, 10),
-                     "configs[4] stress (N=16384, k=64, 64 clouds/step)": secondary_eval(dev, 16384, 64, 64, 5)}
+                     "configs[4] stress (N=16384, k=64, 64 clouds/step)": secondary_eval(dev, 16384, 64, 64, 5, kernels=True),
+                     # the headline step with every product on the f32-input MFMA (exact fp32) beside the split-bf16 headline
+                     "configs[1] exact fp32 products (LPD_GEMM_FP32=1)": secondary_eval(dev, 4096, 20, 32, 10, exact=True, kernels=True),
+                     # the reference's argparse-default trunk (util/initPara.py:74; model at util/lpdnet_model.py:68-114)
+                     "featnet=lpdnetorigin eval, 32 clouds/step": secondary_eval(dev, 4096, 20, 32, 10, featnet="lpdnetorigin", kernels=True)}
         # the reference's OWN operating points (util/data.py:117-133 embeds one cloud at a time, util/initPara.py:32-43 gives an eval
         # batch of 6 x (1 + 1 + 2) = 24 and a train batch of bq=2, P=1, Ng=2 -> 10 clouds): small batches, where launch counts and
         # the 256-workgroup persistent kernels matter more than bandwidth
@@ -611,6 +671,11 @@ def main():
             torch.cuda.empty_cache()
             train_bf16 = train_bench(dev, dist, world, rank, args.points, args.train_steps, storage="bf16")
         if world == 1 and not args.no_secondary and secondary is not None:
+            torch.cuda.empty_cache()       # the reference's default trunk at configs[2]'s batch
+            secondary["featnet=lpdnetorigin train (bq=2, P=2, Ng=18 -> 44 clouds)"] = {
+                kk: vv for kk, vv in train_bench(dev, None, 1, 0, args.points, max(3, args.train_steps // 2), featnet="lpdnetorigin",
+                                                 label="reference default trunk (util/initPara.py:74)").items()
+                if kk in ("value", "unit", "ms_per_step", "steps", "config", "losses", "peak_hbm_gib")}
             torch.cuda.empty_cache()       # the reference's default train batch (initPara.py:32-43): bq=2, P=1, Ng=2 -> 10 clouds
             secondary["reference default train batch (bq=2, P=1, Ng=2 -> 10 clouds)"] = {
                 st: {kk: vv for kk, vv in train_bench(dev, None, 1, 0, args.points, args.train_steps, storage=st, tuple_shape=(2, 1, 2),
@@ -637,7 +702,8 @@ def main():
                                       "products as 3-product split-bf16 MFMA with fp32 accumulation (DESIGN.md 3.2)"
                                       if ops.GEMM_BF16X3 else "fp32 tensors, every product on the f32-input MFMA / fp32 FMA")},
             "descriptors_per_s_per_rank": per_rank,
-            "roofline": roof, "kernels": kern, "kernels_one_stream": kern1, "train": train,
+            "roofline": roof, "roofline_kernels": kernel_rooflines(kern, args.batch, args.points, args.k, ops.GEMM_BF16X3),
+            "kernels": kern, "train": train,
         }
         if secondary is not None:
             line["secondary"] = secondary

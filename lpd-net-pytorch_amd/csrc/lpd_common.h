@@ -74,6 +74,10 @@ struct LpdStatWs {
     double* sumsq() const { return rep + LPD_STAT_CMAX; }
 };
 inline LpdStatWs lpd_stat_arg(double* stat_ws) { return LpdStatWs{stat_ws}; }      // the caller's workspace (may be null: checked by the entry points)
+// every entry point that hands ws.sum() / ws.sumsq() to a kernel checks its column count first: column c of a replica sits at + c, the
+// second array LPD_STAT_CMAX doubles behind the first -- a wider layer would add into the other array and past the last replica
+#define LPD_CHECK_STAT_COLS(name, ncols) \
+    LPD_CHECK_ARG((ncols) > 0 && (ncols) <= LPD_STAT_CMAX, "%s: %d columns exceed the %d of the statistics workspace", name, (int)(ncols), LPD_STAT_CMAX)
 // o0[c] = sum over the replicas of column c (c < ncols <= LPD_STAT_CMAX), o1 likewise; clears the replicas
 int lpd_stat_finish(LpdStatWs ws, double* o0, double* o1, int ncols, hipStream_t stream);
 // offset of this block's replica, to be added to the column index of both pointers

@@ -1610,6 +1610,7 @@ extern "C" int lpd_edge_mlp_train(const float* P, int ldp, const float* Q, int l
                   "lpd_edge_mlp_train: pointers must be 16-byte aligned");
     const LpdStatWs ws = lpd_stat_arg(stat_ws);
     LPD_CHECK_ARG(ws.rep, "lpd_edge_mlp_train: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
+    LPD_CHECK_STAT_COLS("lpd_edge_mlp_train", 128);
     EdgeMlpTrainArgs g{P, Q, idx, s1, b1, W2, gamma2, Y1e, Z, zsel, arg2, ws.sum(), ws.sumsq(), M, N, k, ldp, ldq, ldsel, act, slope};
     using Cfg = EdgeMlpX3Cfg<128, 128>;
     const size_t lds = (size_t)(bf16 ? 2 : 4) * Cfg::IMG * sizeof(__bf16) + (size_t)EM_PTS * k * sizeof(int);
@@ -1645,6 +1646,7 @@ extern "C" int lpd_edge_mlp_train_bwd(const void* Z, const uint8_t* arg2, const 
                   "lpd_edge_mlp_train_bwd: pointers must be 16-byte aligned");
     const LpdStatWs ws = lpd_stat_arg(stat_ws);
     LPD_CHECK_ARG(ws.rep, "lpd_edge_mlp_train_bwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
+    LPD_CHECK_STAT_COLS("lpd_edge_mlp_train_bwd", 128);
     EdgeMlpBwdArgs g{Z, arg2, dpre2, W2, scale2, mean2, invstd2, dbeta2, dgamma2, Y1e, arg1, dx1, lddx1, beta1, rgamma1, G, gsum,
                      ws.sum(), ws.sumsq(), M, k, act, slope, inv_ns, reinterpret_cast<const uint16_t*>(kws), kws ? kws + 128 * 128 : nullptr};
     if (!Z) {
@@ -1690,6 +1692,7 @@ extern "C" int lpd_edge_split_fwd16(const float* P, long long ldp, const float* 
     LPD_CHECK_ARG((unsigned long long)M * (unsigned long long)C * 4ull < (1ull << 34), "lpd_edge_split_fwd16: tensor too large");
     const LpdStatWs ws = lpd_stat_arg(stat_ws);
     LPD_CHECK_ARG(ws.rep, "lpd_edge_split_fwd16: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
+    LPD_CHECK_STAT_COLS("lpd_edge_split_fwd16", C);
     SplitFwdArgs g{P, Q, gamma, S, usel, arg, ws.sum(), ws.sumsq(), N, C, (int)ldp, (int)ldq};
     const int nslices = C / 8;
     const size_t lds = (size_t)KAGG_IMG1 + (size_t)N * 16;

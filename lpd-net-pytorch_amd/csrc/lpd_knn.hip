@@ -1271,8 +1271,17 @@ __device__ __forceinline__ void knn7_insert(float (&v)[KMAX], int (&id)[KMAX], f
 // WAVES: waves per workgroup.  A workgroup's LDS and wave slots stay taken until its slowest wave is done and the tile
 // counts of neighbouring waves differ (C = 64: mean 51, p90 69, max 89 tiles): single-wave workgroups at C = 64
 // (638 -> 607 us), four waves at C = 3 (shorter waves; the larger groups launch faster: 278 vs 287 us).
-template <int CP, int KMAX, int WAVES, bool ONFLY, bool FULLT = false>
-__global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SIMD)) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
+// SPLIT (round 5): SPLIT waves of one workgroup share ONE query tile W and divide its walk among them -- the visited tiles in walk
+// order, dealt round-robin (each wave still meets the tiles above W in ascending and the tiles below W in descending order, which is
+// all the one-compare insertion needs) -- each with its own pair of half-lists; the waves exchange thresholds through LDS (no barrier:
+// a stale threshold is a looser one) and the 2 * SPLIT half-lists of a query are merged at the end.  A cloud is 128 query tiles: at one
+// wave per tile a small batch leaves most of the chip idle and a search lasts as long as its longest wave's walk over ~50 candidate
+// tiles (one cloud: 195 + 138 us of a 0.55 ms forward); with four waves per tile the walk is a quarter as long.  The bound table of the
+// tile is ONE LDS copy per workgroup.  Bounds on the union's KMAX-th best that every wave may use: the best wave-level bound, and the
+// minimum over all 2 * SPLIT half-lists of their ceil(KMAX / (2 SPLIT))-th best (then the lists together hold KMAX candidates >= it).
+// Large batches keep SPLIT = 1: the total work is the same, the early thresholds are looser and the final merge is extra.
+template <int CP, int KMAX, int WAVES, bool ONFLY, bool FULLT = false, int SPLIT = 1>
+__global__ __launch_bounds__(WAVES * SPLIT * 64, ((SPLIT > 1 && CP == 2) ? 3 : Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SIMD)) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
                                                              const float* __restrict__ cenp, const float* __restrict__ cnorm,
                                                              const float* __restrict__ rad, const float* __restrict__ txmax,
                                                              int32_t* __restrict__ idx, const int32_t* __restrict__ order,
@@ -1290,7 +1299,9 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
     if (order) vb = order[vb];                   // longest-first inside the XCD's range (single-wave workgroups)
     const int b = vb / blocks_per_cloud;
     const int qb = vb - b * blocks_per_cloud;
-    const int q0 = qb * (WAVES * 32) + wave * 32;
+    static_assert(SPLIT == 1 || (WAVES == 1 && FULLT && KMAX <= 20 && !(ONFLY && CP == 32)), "SPLIT: whole tiles, short lists, bounds from the LDS table or from centroids");
+    const int sw = SPLIT > 1 ? wave : 0;               // this wave's share of the walk
+    const int q0 = SPLIT > 1 ? qb * 32 : qb * (WAVES * 32) + wave * 32;
     const int W = q0 >> 5;
     const bool wave_ok = q0 < N;                 // the last block of a cloud may hold waves without queries
     const int q = q0 + col;
@@ -1304,8 +1315,16 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
     const bool vec_ok_t = (nt & 3) == 0;
     using L = Knn7Cfg<CP, KMAX, ONFLY>;
     static_assert(CP != 2 || ONFLY, "three coordinates: bounds on the fly");
-    uint16_t* ubt = reinterpret_cast<uint16_t*>(smem7 + (size_t)wave * L::WAVE);                          // [MAXT][32] (CP > 2)
-    float2* myq = reinterpret_cast<float2*>(smem7 + (size_t)wave * L::WAVE + L::QOFF) + lane;             // slot s at myq[s*64]
+    // LDS: SPLIT == 1: per wave [table | queue]; SPLIT > 1: [table (shared)] [SPLIT queues] [thresholds: SPLIT x 2 x 64 floats]
+    uint16_t* ubt = reinterpret_cast<uint16_t*>(smem7 + (SPLIT > 1 ? (size_t)0 : (size_t)wave * L::WAVE));   // [MAXT][32] (CP > 2)
+    unsigned char* qreg_base = SPLIT > 1 ? smem7 + L::TBYTES + (size_t)wave * L::QBYTES : smem7 + (size_t)wave * L::WAVE + L::QOFF;
+    float2* myq = reinterpret_cast<float2*>(qreg_base) + lane;                                            // slot s at myq[s*64]
+    volatile float* thr_sh = reinterpret_cast<volatile float*>(smem7 + L::TBYTES + (size_t)SPLIT * L::QBYTES);    // SPLIT > 1 only
+    static_assert(SPLIT == 1 || L::QBYTES >= 64 * KMAX * 8, "SPLIT: a wave's queue region holds its two half-lists for the merge");
+    if constexpr (SPLIT > 1) {
+        thr_sh[(sw * 2 + 0) * 64 + lane] = -INFINITY;
+        thr_sh[(sw * 2 + 1) * 64 + lane] = -INFINITY;
+    }
 
     float qreg[CP];
     knn3_ld_ops<CP>(xpb, N, q, h, qreg);
@@ -1328,13 +1347,13 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
     // ---- bound table: from the low-precision pass (knn7_bound_kernel) when it ran ... ----
     if (wave_ok && !ONFLY && ubq) {
         const uint16_t* src = ubq + ((size_t)b * nt + W) * nt * 32;
-        for (int e = lane * 8; e < nt * 32; e += 64 * 8)       // 16 bytes per lane and trip (nt * 32 % 8 == 0)
+        for (int e = (SPLIT > 1 ? tid : lane) * 8; e < nt * 32; e += SPLIT * 64 * 8)       // 16 bytes per lane and trip (nt * 32 % 8 == 0)
             *reinterpret_cast<uint4*>(ubt + e) = *reinterpret_cast<const uint4*>(src + e);
     }
     // ---- ... else pd of every query against every tile centroid (the centroids are a 'cloud' of nt points) ----
     if (wave_ok && !ONFLY && !ubq) {
         const int nct = (nt + 31) / 32;
-        for (int ct = 0; ct < nct; ++ct) {
+        for (int ct = sw; ct < nct; ct += SPLIT) {      // (SPLIT > 1: the waves fill the shared table together)
             float4 r4[4];
             knn3_ld_ops<CP>(cenb, nt, ct * 32 + col, h, a);
             knn3_ld_xx(cnb, nt, ct * 32, h, vec_ok_t, x4);
@@ -1355,6 +1374,8 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
         }
     }
 
+    if constexpr (SPLIT > 1) __syncthreads();      // the shared bound table and the threshold slots are in place
+
     float lv[KMAX];
     int li[KMAX];
 #pragma unroll
@@ -1364,16 +1385,39 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
     }
     float thrv = q_ok ? -INFINITY : INFINITY;   // k-th best so far (admission + skip threshold); padded queries admit nothing
     int cnt = 0;
+    // SPLIT > 1: thresholds of the other waves of the workgroup (see the kernel's comment): the union's KMAX-th best is at least the
+    // best wave-level bound and at least the smallest M3-th best of the 2 * SPLIT half-lists
+    constexpr int M3 = (KMAX + 2 * SPLIT - 1) / (2 * SPLIT);
+    auto refresh = [&]() {
+        if constexpr (SPLIT > 1) {
+            float best = thr_sh[(sw * 2 + 0) * 64 + lane];      // this wave's own bound (published by its last drain)
+            const float t3 = lv[M3 - 1];
+            float m3 = fminf(t3, __shfl_xor(t3, 32, 64));
+#pragma unroll
+            for (int o = 1; o < SPLIT; ++o) {
+                const int s2 = (sw + o) % SPLIT;
+                best = fmaxf(best, thr_sh[(s2 * 2 + 0) * 64 + lane]);
+                m3 = fminf(m3, fminf(thr_sh[(s2 * 2 + 1) * 64 + lane], thr_sh[(s2 * 2 + 1) * 64 + (lane ^ 32)]));
+            }
+            thrv = q_ok ? fmaxf(best, m3) : INFINITY;
+        }
+    };
     int stat_tiles = 0, stat_it = 0, stat_adm = 0, stat_drains = 0, stat_fn = 0;   // diagnostics (dbg): visited tiles, drain iterations, admitted, drains
 
     // visiting order: outwards along the Z-curve, W, W+1, W-1, W+2, ... (the visited tiles always form an interval around
     // W, which is what makes the one-compare insertion exact)
     int spos = 0;
+    int vcount = 0;                        // SPLIT > 1: tiles of the cloud met so far in walk order (dealt round-robin to the waves)
     auto find_next_walk = [&]() -> int {   // next tile in order that some query of the wave can still gain from; -1 at the end
         while (spos < 2 * nt) {
             const int T = (spos & 1) ? W + ((spos + 1) >> 1) : W - (spos >> 1);
             ++spos;
             if (T < 0 || T >= nt) continue;
+            if constexpr (SPLIT > 1) {
+                const bool mine = (vcount % SPLIT) == sw;
+                ++vcount;
+                if (!mine) continue;
+            }
             if constexpr ((CP == 32) && !ONFLY && !FULLT) ++stat_fn;
             float ub;
             if constexpr (CP == 2) {   // centroid in operand order (c0, c2 | c1, 0), like the query's own row
@@ -1475,6 +1519,11 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
         const float pK = __shfl_xor(tK, 32, 64), pH = __shfl_xor(tH, 32, 64);
         const float thr = fmaxf(fmaxf(tK, pK), fminf(tH, pH));
         thrv = q_ok ? thr : INFINITY;
+        if constexpr (SPLIT > 1) {      // publish this wave's bounds, then take the others' into account
+            thr_sh[(sw * 2 + 0) * 64 + lane] = thr;
+            thr_sh[(sw * 2 + 1) * 64 + lane] = lv[M3 - 1];
+            refresh();
+        }
     };
 
     long long tm_adv = 0, tm_tile = 0, tm_sel = 0, tm_drain = 0, tm0 = 0, tm_start = 0;   // dbg: cycles per phase (s_memtime)
@@ -1511,6 +1560,7 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
         float mx = fmaxf(fmaxf(fmaxf(pd[0], pd[1]), fmaxf(pd[2], pd[3])), fmaxf(fmaxf(pd[4], pd[5]), fmaxf(pd[6], pd[7])));
         mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(pd[8], pd[9]), fmaxf(pd[10], pd[11])), fmaxf(fmaxf(pd[12], pd[13]), fmaxf(pd[14], pd[15]))));
         if (TIMERS && dbg) { const long long t = tick(); tm_tile += t - tm0; tm0 = t; }
+        refresh();      // (SPLIT > 1: what the other waves of the workgroup have found meanwhile)
         if (__any(mx >= thrv)) {
             if (cur >= W) {   // rows ascending: later arrivals have larger indices
 #pragma unroll
@@ -1557,6 +1607,7 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
             float mx = fmaxf(fmaxf(fmaxf(pd[0], pd[1]), fmaxf(pd[2], pd[3])), fmaxf(fmaxf(pd[4], pd[5]), fmaxf(pd[6], pd[7])));
             mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(pd[8], pd[9]), fmaxf(pd[10], pd[11])), fmaxf(fmaxf(pd[12], pd[13]), fmaxf(pd[14], pd[15]))));
             if (TIMERS && dbg) { const long long t = tick(); tm_tile += t - tm0; tm0 = t; }
+            refresh();      // (SPLIT > 1: what the other waves of the workgroup have found meanwhile)
             if (__any(mx >= thrv)) {
                 if (cur >= W) {   // rows ascending: later arrivals have larger indices
     #pragma unroll
@@ -1607,7 +1658,7 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
         return;
     } else {
     // ---- merge the two half-lists (same as the ascending kernel); region: this wave's table + queue (20 KiB >= 64*KMAX*8) ----
-    float* mv = reinterpret_cast<float*>(smem7 + (size_t)wave * L::WAVE);
+    float* mv = reinterpret_cast<float*>(SPLIT > 1 ? qreg_base : smem7 + (size_t)wave * L::WAVE);
     int* mi = reinterpret_cast<int*>(mv + 64 * KMAX);
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) {
@@ -1615,6 +1666,77 @@ __global__ __launch_bounds__(WAVES * 64, (Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SI
         mi[lane * KMAX + s] = li[s];
     }
     __syncthreads();
+    if constexpr (SPLIT > 1) {
+        // stage 1, every wave: its two half-lists -> one sorted list of KMAX per query, in the registers of the h == 0 lanes (the merged
+        // list replaces the half-lists in the wave's region: lanes of one wave run in program order, nobody else reads this region yet)
+        {
+            const float* av = mv + lane * KMAX;
+            const int* ai = mi + lane * KMAX;
+            const float* bv = mv + (lane ^ 32) * KMAX;
+            const int* bi = mi + (lane ^ 32) * KMAX;
+            int pa = 0, pb = 0;
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {      // (both half-lanes run it: the h == 1 copy is not used)
+                const float va = av[pa], vb2 = bv[pb];
+                const int ia = ai[pa], ib = bi[pb];
+                const bool take_a = knn_before(va, ia, vb2, ib);      // -inf / 0x7fffffff padding ranks last; indices are distinct
+                lv[s] = take_a ? va : vb2;
+                li[s] = take_a ? ia : ib;
+                pa += take_a ? 1 : 0;
+                pb += take_a ? 0 : 1;
+                pa = min(pa, KMAX - 1);           // (a list that has given all KMAX entries is never asked again: s < KMAX)
+                pb = min(pb, KMAX - 1);
+            }
+        }
+        float* gv = mv;                           // merged lists of this wave: [32 queries][KMAX] values, then indices
+        int* gi = reinterpret_cast<int*>(gv + 32 * KMAX);
+        if (h == 0) {
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {
+                gv[col * KMAX + s] = lv[s];
+                gi[col * KMAX + s] = li[s];
+            }
+        }
+        __syncthreads();
+        // stage 2, wave 0: SPLIT-way merge of the waves' lists (distinct indices: the order is total and it is the reference's)
+        if (wave == 0 && h == 0 && q_ok) {
+            float hv[SPLIT];
+            int hi[SPLIT], pos[SPLIT];
+            const float* mbase = reinterpret_cast<const float*>(smem7 + L::TBYTES) + col * KMAX;      // wave w2's merged lists at + w2 * QBYTES / 4
+            constexpr int WSTRIDE = L::QBYTES / 4, IOFF = 32 * KMAX;
+#pragma unroll
+            for (int w2 = 0; w2 < SPLIT; ++w2) {
+                hv[w2] = mbase[w2 * WSTRIDE];
+                hi[w2] = __float_as_int(mbase[w2 * WSTRIDE + IOFF]);
+                pos[w2] = 0;
+            }
+            int32_t* out = idx + ((size_t)b * N + q) * k;
+            for (int s = 0; s < k; ++s) {
+                int bw = 0;
+                float bvv = hv[0];
+                int bii = hi[0];
+#pragma unroll
+                for (int w2 = 1; w2 < SPLIT; ++w2) {
+                    const bool better = knn_before(hv[w2], hi[w2], bvv, bii);
+                    bw = better ? w2 : bw;
+                    bvv = better ? hv[w2] : bvv;
+                    bii = better ? hi[w2] : bii;
+                }
+                out[s] = bii;
+#pragma unroll
+                for (int w2 = 0; w2 < SPLIT; ++w2) {
+                    if (bw == w2) {
+                        pos[w2] += 1;
+                        const bool more = pos[w2] < KMAX;
+                        const int pp = pos[w2] < KMAX ? pos[w2] : KMAX - 1;
+                        hv[w2] = more ? mbase[w2 * WSTRIDE + pp] : -INFINITY;
+                        hi[w2] = more ? __float_as_int(mbase[w2 * WSTRIDE + IOFF + pp]) : 0x7fffffff;
+                    }
+                }
+            }
+        }
+        return;
+    }
     if (dbg && q_ok) {   // diagnostics instead of indices
         int32_t* o = idx + ((size_t)b * N + q) * k;
         if (h == 0) {   // (the phase clocks are not ordered against vector work: the wait for the operand prefetch lands in 'advance')
@@ -1736,20 +1858,40 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
             LPD_CHECK_LAUNCH("lpd_knn(low-precision bounds)");
         }
     }
-    if (lpt) {
+    static const bool branchy = getenv("LPD_KNN_FULLT") && atoi(getenv("LPD_KNN_FULLT")) == 0;     // 0: the branchy tile body for every N
+    // Small batches: KNN7_SPLIT waves per query tile (see knn7_kernel).  LPD_KNN_SPLIT=0 never, =1 always (where it is built); default:
+    // while the single-wave grid would not fill the wave slots of the chip (256 CUs x 4 SIMDs x WAVES_PER_SIMD) -- up to there the
+    // split launch is the shorter one (more, shorter waves), beyond it both are the same number of rounds.
+    constexpr int KNN7_SPLIT = 4;
+    constexpr bool split_built = KMAX <= 20 && !(ONFLY && CP == 32);
+    static const int split_env = getenv("LPD_KNN_SPLIT") ? atoi(getenv("LPD_KNN_SPLIT")) : -1;
+    const bool split = split_built && N % 32 == 0 && !branchy && !dbg && split_env != 0 &&
+                       (split_env == 1 || (long long)nitems <= 1024ll * L::WAVES_PER_SIMD);
+    // (longest-first order: pointless while every workgroup of the launch is resident at once)
+    const bool use_order = lpt && !(split && (long long)nitems * KNN7_SPLIT <= 1024ll * L::WAVES_PER_SIMD);
+    if (use_order) {
         hipLaunchKernelGGL(knn7_predict_kernel<CP>, dim3(nt, B), dim3(128), 0, stream, (const float*)cenp, (const float*)rad, pred, nt);
         hipLaunchKernelGGL(knn7_order_kernel, dim3((nitems / 8 + 1 + 1023) / 1024, 8), dim3(1024), 0, stream, (const int32_t*)pred, order, nitems);
         LPD_CHECK_LAUNCH("lpd_knn(launch order)");
     }
     {
         size_t lds = (size_t)WAVES * L::WAVE;
-        static const bool branchy = getenv("LPD_KNN_FULLT") && atoi(getenv("LPD_KNN_FULLT")) == 0;     // 0: the branchy tile body for every N
+        int threads = WAVES * 64;
         auto go = [&](auto kern) {
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(WAVES * 64), lds, stream, (const float*)xp, xx, (const float*)cenp,
-                               (const float*)cnorm, (const float*)rad, (const float*)txmax, idx, (const int32_t*)(lpt ? order : nullptr),
+            hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(threads), lds, stream, (const float*)xp, xx, (const float*)cenp,
+                               (const float*)cnorm, (const float*)rad, (const float*)txmax, idx, (const int32_t*)(use_order ? order : nullptr),
                                N, k, nt, C, bpc, dbg, (const uint16_t*)ubq);
         };
+        if constexpr (split_built) {
+            if (split) {
+                lds = (size_t)L::TBYTES + (size_t)KNN7_SPLIT * L::QBYTES + (size_t)KNN7_SPLIT * 2 * 64 * sizeof(float);
+                threads = KNN7_SPLIT * 64;
+                go(knn7_kernel<CP, KMAX, WAVES, ONFLY, true, KNN7_SPLIT>);
+                LPD_CHECK_LAUNCH("lpd_knn(best-first, split)");
+                return LPD_OK;
+            }
+        }
         if (N % 32 == 0 && !branchy && !dbg) go(knn7_kernel<CP, KMAX, WAVES, ONFLY, true>);      // whole tiles: branch-free tile body
         else go(knn7_kernel<CP, KMAX, WAVES, ONFLY, false>);
         LPD_CHECK_LAUNCH("lpd_knn(best-first)");

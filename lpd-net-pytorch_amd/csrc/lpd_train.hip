@@ -1228,6 +1228,7 @@ extern "C" int lpd_bn_act_bwd(const float* dY, long long lddy, const float* X, l
     LPD_CHECK_ARG(!has_bn || (scale && shift && mean && invstd), "lpd_bn_act_bwd: BatchNorm form needs scale/shift/mean/invstd");
     const LpdStatWs ws = lpd_stat_arg(stat_ws);
     LPD_CHECK_ARG(ws.rep, "lpd_bn_act_bwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
+    LPD_CHECK_STAT_COLS("lpd_bn_act_bwd", C);
     const int RG = 256 / (C / 4);
     hipLaunchKernelGGL(act == 3 ? bn_act_bwd_reduce_kernel<true> : bn_act_bwd_reduce_kernel<false>, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream),
                        dY, lddy, X, ldx, R, C, scale, shift, has_bn ? mean : nullptr, has_bn ? invstd : nullptr, act, slope, ws.sum(), ws.sumsq());
@@ -1250,12 +1251,18 @@ extern "C" int lpd_bn_act_bwd_bf16(const void* dY, long long lddy, const void* X
     LPD_CHECK_ARG(!has_bn || (scale && shift && mean && invstd), "lpd_bn_act_bwd_bf16: BatchNorm form needs scale/shift/mean/invstd");
     const LpdStatWs ws = lpd_stat_arg(stat_ws);
     LPD_CHECK_ARG(ws.rep, "lpd_bn_act_bwd_bf16: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
-    const int RG = 256 / (C / 8);
-    hipLaunchKernelGGL(act == 3 ? bn_act_bwd_reduce16_kernel<true> : bn_act_bwd_reduce16_kernel<false>, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream), reinterpret_cast<const uint16_t*>(dY), lddy,
-                       reinterpret_cast<const uint16_t*>(X), ldx, R, C, scale, shift, has_bn ? mean : nullptr, has_bn ? invstd : nullptr, act, slope,
-                       ws.sum(), ws.sumsq());
-    LPD_CHECK_LAUNCH("lpd_bn_act_bwd_bf16(reduce)");
-    if (int rc = lpd_stat_finish(ws, dbeta, dgamma, C, ST(stream))) return rc;
+    // the reduction goes through the statistics replicas in column panels of at most LPD_STAT_CMAX columns (like lpd_colstats): column c
+    // of a replica sits at + c and the second array LPD_STAT_CMAX doubles behind the first, so a 2048-wide layer takes two passes
+    for (int c0 = 0; c0 < C; c0 += LPD_STAT_CMAX) {
+        const int w = C - c0 < LPD_STAT_CMAX ? C - c0 : LPD_STAT_CMAX;      // a power of two >= 8
+        LPD_CHECK_STAT_COLS("lpd_bn_act_bwd_bf16", w);
+        const int RG = 256 / (w / 8);
+        hipLaunchKernelGGL(act == 3 ? bn_act_bwd_reduce16_kernel<true> : bn_act_bwd_reduce16_kernel<false>, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream),
+                           reinterpret_cast<const uint16_t*>(dY) + c0, lddy, reinterpret_cast<const uint16_t*>(X) + c0, ldx, R, w, scale ? scale + c0 : nullptr,
+                           shift ? shift + c0 : nullptr, has_bn ? mean + c0 : nullptr, has_bn ? invstd + c0 : nullptr, act, slope, ws.sum(), ws.sumsq());
+        LPD_CHECK_LAUNCH("lpd_bn_act_bwd_bf16(reduce)");
+        if (int rc = lpd_stat_finish(ws, dbeta + c0, dgamma + c0, w, ST(stream))) return rc;
+    }
     hipLaunchKernelGGL(act == 3 ? bn_act_bwd_apply16_kernel<true> : bn_act_bwd_apply16_kernel<false>, dim3(grid_for(R * (C / 8), 256 * 4)), dim3(256), 0, ST(stream), reinterpret_cast<const uint16_t*>(dY),
                        lddy, reinterpret_cast<const uint16_t*>(X), ldx, reinterpret_cast<uint16_t*>(dX), lddx, R, C, scale, shift, mean, invstd, dbeta,
                        dgamma, (double)R, act, slope, has_bn);
@@ -1273,6 +1280,7 @@ extern "C" int lpd_edge_build(const float* P, long long ldp, const float* Q, lon
     if (sum) {
         ws = lpd_stat_arg(stat_ws);
         LPD_CHECK_ARG(ws.rep, "lpd_edge_build: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
+        LPD_CHECK_STAT_COLS("lpd_edge_build", C);
         sum = ws.sum();
         sumsq = ws.sumsq();
     }
@@ -1339,6 +1347,7 @@ static int edge_bn_bwd_impl(const float* dOut, long long ldo, const uint8_t* arg
                   "lpd_edge_bn_bwd: C=%d / leading dims unsupported", C);
     const LpdStatWs ws = lpd_stat_arg(stat_ws);
     LPD_CHECK_ARG(ws.rep, "lpd_edge_bn_bwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
+    LPD_CHECK_STAT_COLS("lpd_edge_bn_bwd", C);
     const int RG = 256 / (C / 4);
     hipLaunchKernelGGL(edge_bn_bwd_reduce_kernel, dim3(grid_for(M, RG * 2)), dim3(256), 0, ST(stream), dOut, ldo, arg, dDense, X, Xsel,
                        ldsel, k, M, C, scale, shift, mean, invstd, act, slope, inv_ns, ws.sum(), ws.sumsq());

@@ -1248,6 +1248,7 @@ extern "C" int lpd_edge_split_fwd(const float* P, long long ldp, const float* Q,
     LPD_CHECK_ARG(M > 0 && N > 0 && k > 0 && k <= 255 && M % N == 0 && ldp % 4 == 0 && ldq % 4 == 0, "lpd_edge_split_fwd: bad dims");
     const LpdStatWs ws = lpd_stat_arg(stat_ws);
     LPD_CHECK_ARG(ws.rep, "lpd_edge_split_fwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
+    LPD_CHECK_STAT_COLS("lpd_edge_split_fwd", C);
     const int lpp = C / 4;
     const int grid = grid_for(M, 4 * (64 / lpp) * 4, 2048);
     if (C == 64) hipLaunchKernelGGL(edge_split_fwd_kernel<16>, dim3(grid), dim3(256), 0, stream, P, ldp, Q, ldq, idx, gamma, S, usel, arg, M, N, k, ws.sum(), ws.sumsq());
@@ -1275,6 +1276,7 @@ extern "C" int lpd_edge_split_bwd(const float* dOut, long long ldo, const float*
     LPD_CHECK_ARG(ldo % 4 == 0 && ldp % 4 == 0 && ldq % 4 == 0 && lddp % 4 == 0 && lddq % 4 == 0, "lpd_edge_split_bwd: leading dims % 4");
     const LpdStatWs ws = lpd_stat_arg(stat_ws);
     LPD_CHECK_ARG(ws.rep, "lpd_edge_split_bwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
+    LPD_CHECK_STAT_COLS("lpd_edge_split_bwd", C);
     const int rg = 256 / (C / 4);
     if (half) hipLaunchKernelGGL(edge_split_bwd_reduce_kernel<true>, dim3(grid_for(M, rg * 8, 2048)), dim3(256), 0, stream, dOut, ldo, usel, G, Q, ldq, M, C,
                                  scale, shift, mean, invstd, act, slope, ws.sum(), ws.sumsq());
@@ -1334,6 +1336,7 @@ extern "C" int lpd_edge_build_bf16(const float* P, long long ldp, const float* Q
     if (sum) {
         ws = lpd_stat_arg(stat_ws);
         LPD_CHECK_ARG(ws.rep, "lpd_edge_build_bf16: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
+        LPD_CHECK_STAT_COLS("lpd_edge_build_bf16", C);
         sum = ws.sum();
         sumsq = ws.sumsq();
     }
@@ -1385,6 +1388,7 @@ extern "C" int lpd_group_sel_stats_bf16(const uint16_t* Z, int k, const float* g
     LPD_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && k <= 255 && lds % 4 == 0, "lpd_group_sel_stats_bf16: bad dims");
     const LpdStatWs ws = lpd_stat_arg(stat_ws);
     LPD_CHECK_ARG(ws.rep, "lpd_group_sel_stats_bf16: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
+    LPD_CHECK_STAT_COLS("lpd_group_sel_stats_bf16", C);
     const int rg = 256 / (C / 4);
     hipLaunchKernelGGL(group_sel_stats_bf16_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, Z, k, gamma, sel, lds, arg, M, C,
                        ws.sum(), ws.sumsq());
@@ -1406,6 +1410,7 @@ static int edge_bn_bwd_bf16_impl(const float* dOut, long long ldo, const uint8_t
     LPD_CHECK_ARG(act >= 0 && act <= 2, "lpd_edge_bn_bwd_bf16: activation %d unsupported", act);
     const LpdStatWs ws = lpd_stat_arg(stat_ws);
     LPD_CHECK_ARG(ws.rep, "lpd_edge_bn_bwd_bf16: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
+    LPD_CHECK_STAT_COLS("lpd_edge_bn_bwd_bf16", C);
     const int rg = 256 / (C / 4);
     hipLaunchKernelGGL(edge_bn_bwd_reduce_bf16_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, dOut, ldo, arg, dDense, X, Xsel,
                        ldsel, k, M, C, scale, shift, mean, invstd, act, slope, inv_ns, ws.sum(), ws.sumsq());

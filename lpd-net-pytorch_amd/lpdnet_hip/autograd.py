@@ -14,7 +14,9 @@ from .ops import _ptr, _req, _stream
 # ------------------------------------------------------------------------------------------------
 # The measurement / test hooks (ops.PROFILE, ops.PROFILE_ONLY, engine.DEBUG_AUX) are per host thread, and autograd runs a CUDA
 # node's backward on ITS OWN worker thread: every Function remembers the hooks of the thread that ran its forward and its backward
-# runs under them, so that a profile or a debug dict opened around `loss.backward()` sees the backward's launches -- and nobody else's.
+# runs under them, so that a profile or a debug dict sees the backward's launches of ITS forward -- and nobody else's.  The hooks
+# are captured when the forward runs: open `ops.PROFILE` / `engine.DEBUG_AUX` BEFORE the forward whose backward is to be recorded
+# (a dict opened only around `loss.backward()` records nothing: the worker thread cannot know which thread called backward()).
 # ------------------------------------------------------------------------------------------------
 def _hooked_forward(fn):
     def forward(ctx, *args):
@@ -459,7 +461,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         s1sum = None
         Co3 = net.conv3_lpd.weight.shape[0]
         defer = getattr(_LAST, "defer_act", False) and ops.gemm_act_applies(M, 64, Co3)
-        map16 = (defer and bf16 and MAP_BF16 and ops.GEMM_TN and ops.linear_bn_stats_fused_applies(M, Co3, 512) and Co3 % 128 == 0 and Co3 <= 2048
+        map16 = (defer and bf16 and MAP_BF16 and ops.GEMM_TN and ops.linear_bn_stats_fused_applies(M, Co3, 512) and Co3 % 128 == 0 and Co3 <= ops.STAT_CMAX
                  and (Co3 & (Co3 - 1)) == 0 and N % 128 == 0 and N >= 256 and M >= 16384 and ops.X3T_ROWS and ops.X3W_BATCHED)
         # (the shapes every bf16-map kernel of the head is built for: pooling and weight gradients >= 4096 rows, the batched short
         #  products >= 16384 rows over clouds of whole 128-row tiles; smaller steps keep the fp32 map)

@@ -23,15 +23,32 @@ class _PerThread(__import__("threading").local):
     DEBUG_AUX = None
     # Z-order the points of each cloud once per forward (descriptor is order-invariant; makes the neighbour
     # gathers cache-local).  Tests switch it off to compare intermediate index tensors in the caller's order.
-    MORTON_ORDER = True
+    # None = this thread has not set it: the process-wide value below applies
+    MORTON_ORDER = None
 
 
 _TLS = _PerThread()
+# MORTON_ORDER is configuration as well as a test hook: set from the MAIN thread it becomes the process-wide default, which threads
+# that never set it themselves (nn.DataParallel's replica threads, autograd's backward worker) read; set from any other thread it is
+# that thread's own override.  DEBUG_AUX stays strictly per thread (a dict one thread opened must not collect another's tensors).
+_MORTON_DEFAULT = [True]
+
+
+def _morton_order():
+    v = _TLS.MORTON_ORDER
+    return _MORTON_DEFAULT[0] if v is None else v
+
+
+def _set_morton_order(v):
+    th = __import__("threading")
+    if th.current_thread() is th.main_thread():
+        _MORTON_DEFAULT[0] = bool(v)
+    _TLS.MORTON_ORDER = bool(v)
 
 
 class _EngineModule(__import__("types").ModuleType):
     DEBUG_AUX = property(lambda self: _TLS.DEBUG_AUX, lambda self, v: setattr(_TLS, "DEBUG_AUX", v))
-    MORTON_ORDER = property(lambda self: _TLS.MORTON_ORDER, lambda self, v: setattr(_TLS, "MORTON_ORDER", v))
+    MORTON_ORDER = property(lambda self: _morton_order(), lambda self, v: _set_morton_order(v))
 
 
 __import__("sys").modules[__name__].__class__ = _EngineModule
@@ -43,7 +60,7 @@ EVAL_CHUNK = int(__import__("os").environ.get("LPD_EVAL_CHUNK", "32"))
 def reorder_points(x, reorder=True):
     """x [B,1,N,3] -> Z-ordered copy (or x itself when disabled / too large).  reorder=False: the caller needs the per-point
     output in ITS point order (the public LPDNet.forward / LPDNetOrign.forward); PointNetVlad's descriptor is order-invariant."""
-    if reorder and _TLS.MORTON_ORDER and 64 <= x.shape[2] <= MORTON_MAX_POINTS:
+    if reorder and _morton_order() and 64 <= x.shape[2] <= MORTON_MAX_POINTS:
         return ops.morton_sort(x)
     return x
 
@@ -189,35 +206,29 @@ def _knn_rows(rows, B, N, C, k):
 
 # cloud-panel [B, C/8, N, 8] buffers for x1|x2|x3 and the SN1 projections (LPD_PANELS=0: row-major everywhere)
 PANEL_LAYOUT = __import__("os").environ.get("LPD_PANELS", "1") != "0"
-# xyz kNN (and the DG1 stage's projection and K-agg) on a second HIP stream in the eval path.  LPD_SIDE_STREAM=1 / 0 force it on /
-# off; the default "auto" runs on ONE stream until `calibrate(model, x)` has measured both modes on this device (bench.py and
-# harness.get_latent_vectors call it; a bare `model(x)` never synchronises or times anything).  On most MI355X boxes of the pool
-# the second stream takes 3 % off the step; on some it ADDS 10-20 % and makes the step time erratic (2.40 / 2.67 ms against 2.23 on
-# one stream, same binaries, same inputs), so neither setting is right everywhere.
+# The second HIP stream of the eval path: ONE rule per batch class (round 5; DESIGN.md "HIP streams").
+#   * batches of at most SIDE_SMALL_POINTS points (24 clouds x 4096): the xyz kNN, the DG1 projection and the DG1-stage K-agg run on a
+#     second stream next to the feature-space kNN and the fused edge MLP.  A small batch leaves most of the chip idle -- one cloud's kNN
+#     search is 128 single-wave workgroups on 256 CUs and lasts as long as its longest wave -- so the two searches side by side are a
+#     structural gain (measured, tools/side_small.py: 1 / 6 / 10 / 24 clouds -18 / -14 / -12 / -7 %);
+#   * larger batches: one stream.  At 32 clouds the second stream bought 1 % of the step (1.977 vs 2.000 ms in round 4's driver line),
+#     cost 3-20 % on some boxes of the pool, and made the DG1-stage K-agg 4x slower per launch (350 us against 80: it shares the CUs
+#     with the fused edge MLP).  The calibration machinery that chose per device (engine.calibrate, rounds 3-4) is gone.
+# LPD_SIDE_STREAM=1 / 0 force the second stream on / off for every batch size (tests, A/B timing).
 _side_env = __import__("os").environ.get("LPD_SIDE_STREAM", "auto")
 SIDE_STREAM = "auto" if _side_env == "auto" else (_side_env != "0")
-_SIDE_AUTO = {}      # device key -> {"choice": bool, "ms": (two-stream median, one-stream median), "n": samples per mode, "shape": (B, N)}
-CALIBRATE_SAMPLES = 7
-CALIBRATE_MIN_GAIN = 0.01      # the second stream must win by more than 1 % of the median forward to be switched on
+SIDE_SMALL_POINTS = 24 * 4096
 
 
 def _dev_key(device):
     return (device.type, device.index if device.index is not None else torch.cuda.current_device())
 
 
-_SIDE_FORCE = __import__("threading").local()      # calibrate()'s per-thread override (DataParallel: one host thread per device)
-
-
-# auto mode: batches of at most this many points always take the second stream.  A small batch leaves most of the chip idle -- one cloud's
-# kNN search is 128 single-wave workgroups on 256 CUs and lasts as long as its longest wave -- so the two searches side by side are a
-# structural gain (measured, tools/side_small.py: 1 / 6 / 10 / 24 clouds -18 / -14 / -12 / -7 %), not the box-dependent 3-4 % of a 32-cloud step
-# that `calibrate` is for
-SIDE_SMALL_POINTS = 24 * 4096
+_SIDE_FORCE = __import__("threading").local()      # per-thread override for A/B timing (tools/side_small.py, bench.py's one-stream kernel table)
 
 
 def _side_mode(device, points=None):
-    """use the second stream for this forward?  Explicit settings pass through; auto = small batches always, larger ones the calibrated
-    choice (one stream before a calibration)."""
+    """use the second stream for this forward?  An explicit setting passes through; auto = batches of at most SIDE_SMALL_POINTS points."""
     forced = getattr(_SIDE_FORCE, "mode", None)
     if forced is not None:
         return forced
@@ -225,61 +236,14 @@ def _side_mode(device, points=None):
         return bool(SIDE_STREAM)
     if torch.cuda.is_current_stream_capturing():
         return False
-    if points is not None and points <= SIDE_SMALL_POINTS:
-        return True
-    st = _SIDE_AUTO.get(_dev_key(device))
-    return bool(st and st["choice"])
+    return points is not None and points <= SIDE_SMALL_POINTS
 
 
-def calibrate(model, x, samples=None, force=False):
-    """Measure the eval forward `model(x)` with and without the second HIP stream on x's device and keep the faster mode for the
-    rest of the process (LPD_SIDE_STREAM=auto only; returns the report string).  `samples` forwards per mode, interleaved
-    (two, one, two, one, ...) after two warm-up forwards per mode, each timed with HIP events on the caller's current stream (the
-    second stream is joined into it before the forward returns, so the pair of events brackets both); medians decide.  Nothing
-    but the caller's stream is synchronised.  Call it once per device with a batch of the shape the job runs."""
-    if SIDE_STREAM != "auto" or not x.is_cuda:
-        return side_stream_report(x.device)
-    key = _dev_key(x.device)
-    with _SIDE_LOCK:
-        if key in _SIDE_AUTO and not force:
-            return side_stream_report(x.device)
-    n = int(samples or CALIBRATE_SAMPLES)
-    times = ([], [])
-    was_training = model.training
-    model.eval()
-    stream = torch.cuda.current_stream(x.device)
-    try:
-        with torch.no_grad():
-            for it in range(2 * (n + 2)):
-                slot = it & 1                                   # 0: two streams, 1: one stream
-                _SIDE_FORCE.mode = (slot == 0)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                model(x)
-                e1.record(stream)
-                e1.synchronize()
-                if it >= 4:
-                    times[slot].append(e0.elapsed_time(e1))
-    finally:
-        _SIDE_FORCE.mode = None
-        model.train(was_training)
-    med = tuple(sorted(t)[len(t) // 2] for t in times)
-    with _SIDE_LOCK:
-        _SIDE_AUTO[key] = {"choice": med[0] < (1.0 - CALIBRATE_MIN_GAIN) * med[1], "ms": med, "n": n,
-                           "shape": (int(x.shape[0]), int(x.shape[2]))}
-    return side_stream_report(x.device)
-
-
-def side_stream_report(device):
-    """what the eval forward does on this device: 'two streams' / 'one stream', with the calibration medians when auto decided"""
+def side_stream_report(device=None):
+    """what the eval forward does: the rule above as one line (bench.py prints it into its JSON line)"""
     if SIDE_STREAM != "auto":
-        return "two streams (set)" if SIDE_STREAM else "one stream (set)"
-    st = _SIDE_AUTO.get(_dev_key(device))
-    small = " (batches of at most %d points always take the second stream)" % SIDE_SMALL_POINTS
-    if not st:
-        return "one stream (not calibrated: engine.calibrate(model, x) measures the second stream)" + small
-    return "%s (calibrated at B=%d, N=%d: forward %.3f ms with the second stream, %.3f ms without; medians of %d interleaved forwards each)" % (
-        "two streams" if st["choice"] else "one stream", st["shape"][0], st["shape"][1], st["ms"][0], st["ms"][1], st["n"]) + small
+        return "two streams (LPD_SIDE_STREAM=1)" if SIDE_STREAM else "one stream (LPD_SIDE_STREAM=0)"
+    return "one stream; batches of at most %d points (24 clouds x 4096) put the xyz kNN and the DG1 stage on a second stream" % SIDE_SMALL_POINTS
 
 
 FUSED_FRONT = __import__("os").environ.get("LPD_FUSED_FRONT", "1") != "0"   # conv1 + conv2 + kNN operands in one launch (no T-Nets)

@@ -53,9 +53,6 @@ def train_step(model, optimizer, queries, positives, negatives, other_neg, *, ma
     return loss
 
 
-CALIBRATE_MIN_BATCHES = 64      # engine.calibrate costs ~18 forwards: only jobs of at least this many batches pay for it
-
-
 def get_latent_vectors(model, clouds, batch_size):
     """clouds: [n, N, 3] array-like (float64 like the benchmark's .bin submaps, or float32) -> [n, D] float32 numpy.
 
@@ -71,9 +68,6 @@ def get_latent_vectors(model, clouds, batch_size):
         with torch.no_grad():
             for s in range(0, n, batch_size):
                 chunk = torch.from_numpy(np.ascontiguousarray(clouds[s:s + batch_size])).float().unsqueeze(1).to(dev)
-                if s == 0 and n >= CALIBRATE_MIN_BATCHES * batch_size and chunk.is_cuda:
-                    from . import engine            # a long job: measure the second HIP stream once per device (a no-op afterwards)
-                    engine.calibrate(model, chunk)
                 outs.append(model(chunk).detach().cpu().numpy())
     finally:
         model.train(was_training)

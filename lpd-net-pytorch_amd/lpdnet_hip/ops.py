@@ -35,13 +35,18 @@ __import__("sys").modules[__name__].__class__ = _OpsModule
 def _call(label, fn, *args):
     prof, only = _TLS.PROFILE, _TLS.PROFILE_ONLY
     if prof is None or (only is not None and not label.startswith(only)):
-        _lib.check(fn(*args), fn.__name__)
+        rc = fn(*args)
+        if rc != 0:
+            _stat_ws_drop()
+        _lib.check(rc, fn.__name__)
         return
     a = torch.cuda.Event(enable_timing=True)
     b = torch.cuda.Event(enable_timing=True)
     a.record()
     rc = fn(*args)
     b.record()
+    if rc != 0:
+        _stat_ws_drop()
     _lib.check(rc, fn.__name__)
     prof.setdefault(label, []).append((a, b))
 
@@ -78,10 +83,25 @@ def _stat_ws():
         n = int(_lib.load().lpd_stat_ws_bytes()) // 8
         t = torch.zeros(n, dtype=torch.float64, device=torch.device("cuda", dev))      # memset on the current stream: ordered
         if torch.cuda.is_current_stream_capturing():
-            return ctypes.c_void_p(t.data_ptr())      # graph-private memory: not cached beyond the capture (the memset is a graph node)
+            # graph-private memory: not cached beyond the capture (the memset is a graph node); the tensor stays referenced until this
+            # thread's next call outside a capture, so the block cannot be handed out again in front of the launch that uses it
+            keep = _TLS.__dict__.setdefault("capture_keep", [])
+            keep.append(t)
+            return ctypes.c_void_p(t.data_ptr())
         with _STAT_LOCK:
             t = _STAT_WS.setdefault((dev, raw), t)
+    if _TLS.__dict__.get("capture_keep") and not torch.cuda.is_current_stream_capturing():
+        _TLS.__dict__["capture_keep"] = []
     return ctypes.c_void_p(t.data_ptr())
+
+
+def _stat_ws_drop():
+    """An entry point returned an error: if it had launched its reduction before failing, the cached workspace of this (device, stream)
+    is no longer all-zero and every later statistic on the stream would be silently wrong.  Forget it: the next call zero-fills a new one."""
+    dev = _cur_device() if _cur_device is not None else torch.cuda.current_device()
+    raw = _raw_stream(dev) if _raw_stream is not None else torch.cuda.current_stream().cuda_stream
+    with _STAT_LOCK:
+        _STAT_WS.pop((dev, raw), None)
 
 
 def _req(t, name, dtype=torch.float32):
@@ -1027,9 +1047,12 @@ def bn_train_stats(X, bn, rows=None):
 STATS_IN_GEMM = os.environ.get("LPD_GEMM_STATS", "1") != "0"
 
 
+STAT_CMAX = 1024      # columns of the statistics workspace (csrc/lpd_common.h LPD_STAT_CMAX): lpd_gemm_x3w_stats refuses wider layers
+
+
 def linear_bn_stats_fused_applies(M, N, K):
     return (STATS_IN_GEMM and GEMM_BF16X3 and _EXACT.depth == 0 and _FAST.depth == 0 and X3W_FORWARD
-            and M >= 1024 and N >= 64 and K >= 128 and N * K <= (1 << 22) and (K >= 256 or N >= 128))
+            and M >= 1024 and 64 <= N <= STAT_CMAX and K >= 128 and N * K <= (1 << 22) and (K >= 256 or N >= 128))
 
 
 def linear_bn_stats(x, w, bn, bias=None, out_bf16=False):

@@ -176,3 +176,38 @@ def test_load_pc_file_contract(tmp_path):
     assert ingest.load_pc_file("b.bin", str(tmp_path)).shape == (0,)
     pcs = ingest.load_pc_files(["a.bin", "b.bin", "c.bin"], str(tmp_path))
     assert pcs.shape == (2, 4096, 3) and np.array_equal(pcs, good)
+
+
+def test_morton_order_set_on_the_main_thread_reaches_worker_threads():
+    """engine.MORTON_ORDER is configuration as well as a test hook: set once on the main thread it must reach threads that never
+    set it themselves (nn.DataParallel replica threads, train_pointnetvlad.py:80); a worker's own setting stays its own."""
+    import threading
+    from lpdnet_hip import engine
+    seen = {}
+
+    def worker():
+        seen["inherited"] = engine.MORTON_ORDER
+        engine.MORTON_ORDER = True           # this thread's override
+        seen["own"] = engine.MORTON_ORDER
+    assert engine.MORTON_ORDER is True
+    engine.MORTON_ORDER = False
+    try:
+        t = threading.Thread(target=worker)
+        t.start()
+        t.join()
+        assert seen == {"inherited": False, "own": True}
+        assert engine.MORTON_ORDER is False  # the worker's override did not leak back
+    finally:
+        engine.MORTON_ORDER = True
+    assert engine.MORTON_ORDER is True
+
+
+def test_fused_statistics_gates_stop_at_the_workspace_width():
+    """The statistics workspace holds LPD_STAT_CMAX = 1024 columns: wider layers (emb_dims = 2048) must fall back to the separate
+    statistics pass / the fp32 map instead of reaching lpd_gemm_x3w_stats, which refuses them."""
+    from lpdnet_hip import ops
+    assert ops.STAT_CMAX == 1024
+    assert ops.linear_bn_stats_fused_applies(44 * 4096, 1024, 512)
+    assert not ops.linear_bn_stats_fused_applies(44 * 4096, 2048, 512)
+    src = open(os.path.join(ROOT, "lpd-net-pytorch_amd", "csrc", "lpd_common.h")).read()
+    assert re.search(r"#define\s+LPD_STAT_CMAX\s+1024\b", src)

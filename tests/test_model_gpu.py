@@ -596,6 +596,27 @@ def test_eval_128_clouds_in_slices_equals_4x32_and_one_piece(cuda):
     assert _norm_rel(sliced[pick], torch.from_numpy(want)) < DESC_TOL
 
 
+def test_eval_cfg5_at_its_stated_batch_vs_c_oracle(cuda):
+    """configs[4] as BASELINE.json states it: 64 clouds x 16384 points, k = 64, ONE forward (what bench.py's secondary record times).
+    Its feature map is 64 * 16384 * 1024 * 4 B = 4.29 GB -- past 2^32 bytes, where 32-bit byte offsets break -- and the reference's
+    formulation cannot run the size at all (util/lpdnet_model.py:318-324: a [64, 16384, 16384] distance tensor), so the checker is
+    the plain-C restatement on 8 of the 64 clouds (the first, the last, six in between: every descriptor depends on its own cloud
+    only in eval mode): within 1e-4, norm-relative.  And the 64-cloud forward must agree with the same clouds in batches of 8."""
+    N, B, k = 16384, 64, 64
+    m, sd = _model("lpdnet", N, cuda)
+    m.emb_nn.k = k
+    x = torch.from_numpy(synth.cloud(6400, B, N)).unsqueeze(1)
+    xg = x.to(cuda)
+    with torch.no_grad():
+        got = m(xg)
+        assert got.shape == (B, 256) and bool(torch.isfinite(got).all())
+        tail = m(xg[56:64])                                  # the clouds whose rows sit past the 2^32-byte mark of the big buffers
+    assert _norm_rel(got[56:64], tail) < 1e-5
+    pick = torch.tensor([0, 9, 18, 27, 36, 45, 54, 63])
+    want, _ = orc.forward_lpdnet_c(sd, x[pick], k=k, threads=_host_threads(len(pick)))
+    assert _norm_rel(got[pick], torch.from_numpy(want)) < DESC_TOL
+
+
 # ------------------------------------------------------------------ N4 on the GPU: checkpoint round trip of a TRAINED model
 def test_checkpoint_round_trip_of_a_trained_model(cuda, tmp_path):
     """train_pointnetvlad.py:64-77,172-199 around the HIP model: two Adam steps, save_checkpoint from an nn.DataParallel wrapper

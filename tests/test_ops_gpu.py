@@ -1465,6 +1465,43 @@ def test_bf16_map_operators(cuda):
         ops.gemm(big16, w3, b_kmajor=True)
 
 
+def test_bn_act_bwd_bf16_2048_columns_stays_inside_the_statistics_workspace(cuda):
+    """lpd_bn_act_bwd_bf16 at C = 2048 (emb_dims = 2048): the statistics workspace holds 1024 columns per array and replica, so the
+    reduction runs in two column panels.  Each half must equal the 1024-column call on that half (same kernels, same bits), and the
+    workspace must come back all-zero: the next reduction on the stream is checked against a fresh computation."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    R, C = 2048 + 64, 2048
+    bf = torch.bfloat16
+    X = torch.randn(R, C, generator=g).to(cuda).to(bf)
+    dY = (torch.randn(R, C, generator=g) / 7).to(cuda).to(bf)
+    bn = torch.nn.BatchNorm1d(C).to(cuda)
+    with torch.no_grad():
+        bn.weight.copy_(0.5 + torch.rand(C, generator=g))
+        bn.weight[::5] *= -1
+        bn.bias.copy_(0.2 * torch.randn(C, generator=g))
+    st = ops.bn_train_stats(X.float(), bn)
+    dx, dg, db = ops.bn_act_bwd_bf16(dY, X, st, ops.ACT_LEAKY, 0.2)
+    for h in (0, 1):
+        sl = slice(h * 1024, (h + 1) * 1024)
+        sth = ops.BNStats(st.scale[sl].contiguous(), st.shift[sl].contiguous(), st.mean[sl].contiguous(), st.invstd[sl].contiguous(), st.count)
+        dxh, dgh, dbh = ops.bn_act_bwd_bf16(dY[:, sl].contiguous(), X[:, sl].contiguous(), sth, ops.ACT_LEAKY, 0.2)
+        assert torch.equal(dg[sl], dgh) and torch.equal(db[sl], dbh)
+        assert torch.equal(dx[:, sl], dxh)
+    # fp64 reference of the two sums (the widened bf16 inputs are exact in fp64)
+    pre = (st.scale.double() * X.double() + st.shift.double())
+    dpre = dY.double() * torch.where(pre > 0, 1.0, 0.2)
+    xhat = (X.double() - st.mean.double()) * st.invstd.double()
+    assert _rel(db, dpre.sum(0)) < 1e-5 and _rel(dg, (dpre * xhat).sum(0)) < 1e-4
+    # the workspace is all-zero again: a following reduction on the same stream is exact
+    Y = torch.randn(4096, 1024, generator=g).to(cuda)
+    bn2 = torch.nn.BatchNorm1d(1024).to(cuda)
+    st2 = ops.bn_train_stats(Y, bn2)
+    assert _rel(st2.mean, Y.double().mean(0)) < 1e-5
+    ws = ops._STAT_WS[(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)]
+    assert float(ws.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("a16", [False, True])
 def test_operand_transform_without_a_stored_map(cuda, a16):
     """The NetVLAD head on the trunk's RAW last-layer output (ops.feat_in_loader_applies): the BatchNorm affine + activation is applied in

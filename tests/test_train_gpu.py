@@ -240,6 +240,83 @@ def test_train_grads_flip_free_vs_oracle(cuda, featnet, bq, P, Ng, N):
     assert float(np.median(list(errs.values()))) < FLIP_FREE_MEDIAN, errs
 
 
+def _mem_available_gib():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return int(ln.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
+
+
+CFG2_FLIP_FREE_HOST_GIB = 150      # the fp64 oracle with autograd at 44 x 4096 points keeps ~110 GiB of [B, C, N, k] tensors alive
+
+
+def test_train_cfg2_full_size_flip_free_vs_fp64_oracle(cuda, golden_dir):
+    """BASELINE configs[2] at its stated size (bq = 2, P = 2, Ng = 18 -> 44 clouds x 4096 points, the fixture's clouds), fp32 storage,
+    WITHOUT the two sources of legitimate disagreement: the fp64 oracle runs on the GPU's own kNN graphs (bit-exactness of the kNN is
+    tested separately) and on the GPU's own arg-max choices behind every max over k.  What is left is rounding, so north_star's bar
+    applies undiluted: every descriptor within 1e-4 (norm-relative) and every gradient tensor within FLIP_FREE_TOL = 3e-3 relative L2
+    (median 1e-3).  test_train_step0_cfg2_full_size_vs_reference gates the same step against the REFERENCE's runs at 1e-3 because two
+    evaluations of it differ through feature-space kNN near-ties; this test is the evidence that near-ties and arg-max flips are the
+    whole of that excess (train_pointnetvlad.py:202-217)."""
+    from lpdnet_hip import engine
+    if _mem_available_gib() < CFG2_FLIP_FREE_HOST_GIB:
+        pytest.skip(f"host has {_mem_available_gib():.0f} GiB available; the fp64 autograd oracle at 44 x 4096 needs ~{CFG2_FLIP_FREE_HOST_GIB}")
+    g = np.load(os.path.join(golden_dir, "train_lpdnet_bq2_p2_n18_n4096.npz"))
+    bq, P, Ng, N = [int(v) for v in g["dims"]]
+    B = bq * (1 + P + Ng + 1)
+    assert (B, N) == (44, 4096)
+    m, sd0 = _train_model(N, cuda, "lpdnet")
+    xc = torch.from_numpy(synth.scene_cloud(int(g["seed"]), B, N)).unsqueeze(1)
+    engine.DEBUG_AUX = {}
+    engine.MORTON_ORDER = False
+    try:
+        out, loss = _step(m, xc.to(cuda), bq, P, Ng)
+        aux = engine.DEBUG_AUX
+    finally:
+        engine.DEBUG_AUX = None
+        engine.MORTON_ORDER = True
+    k = m.emb_nn.k
+    argsel = {n: a.view(B, N, -1).permute(0, 2, 1).contiguous().cpu().long() for n, a in aux["argsel"].items()}   # [B,C,N]
+    assert all(int(a.max()) < k for a in argsel.values())
+    graphs = iter([aux["idx_feat"].cpu().long(), aux["idx_xyz"].cpu().long()])
+    got = {name: prm.grad.detach().cpu().double() for name, prm in m.named_parameters() if prm.grad is not None}
+    outc, lossv = out.detach().cpu().double(), loss.item()
+    del aux, m, out, loss
+    torch.cuda.empty_cache()
+    dt = torch.float64
+    sd = {kk: (v.to(dt).requires_grad_(True) if v.dtype == torch.float32 and not kk.endswith(("running_mean", "running_var"))
+               else (v.to(dt) if v.dtype == torch.float32 else v.clone())) for kk, v in sd0.items()}
+    orig = orc.knn
+    orc.knn = lambda xx, kk: next(graphs)
+    try:
+        od = orc.pointnetvlad_forward(sd, xc.to(dt), featnet="lpdnet", train=True, argsel=argsel)
+    finally:
+        orc.knn = orig
+    q, p, n, o = torch.split(od.view(bq, -1, 256), [1, P, Ng, 1], dim=1)
+    ol = orc.quadruplet_loss(q, p, n, o, 0.5, 0.2, use_min=True, lazy=True, ignore_zero_loss=False)
+    assert ol.item() > 0
+    ol.backward()
+    rel = ((outc - od.detach()).abs().amax(dim=1) / od.detach().abs().amax(dim=1))
+    errs = {}
+    for name, have in got.items():
+        want = sd[name].grad
+        if want is None or want.norm().item() < 1e-6 * max(1.0, sd[name].detach().norm().item()):
+            continue
+        errs[name] = ((have - want).norm() / want.norm()).item()
+    _cfg2_report("flip-free f32", desc_max=rel.max().item(), desc_median=rel.median().item(), loss=lossv, loss64=ol.item(),
+                 grad_max=max(errs.values()), grad_median=float(np.median(list(errs.values()))),
+                 worst=sorted(((round(e, 6), n_) for n_, e in errs.items()), reverse=True)[:4])
+    assert rel.max().item() < 1e-4, rel.max().item()
+    assert abs(lossv - ol.item()) < 5e-4 * abs(ol.item())
+    assert len(errs) >= 18
+    bad = {n_: e for n_, e in errs.items() if e >= FLIP_FREE_TOL}
+    assert not bad, bad
+    assert float(np.median(list(errs.values()))) < FLIP_FREE_MEDIAN, errs
+
+
 # bf16 storage of the DG-chain edge tensors: every stored value carries a 2^-9 relative rounding; BatchNorm turns that into
 # 2^-9 |z| / sigma per normalised value and the head's BatchNorms over B = 6..16 descriptor rows amplify it once more (~100x,
 # as for the fp32 rounding, which lands at 1e-4 there).  Measured on these fixtures: descriptors 1.3e-2 / 1.8e-2 norm-relative,

@@ -6,7 +6,7 @@ Per MI355X_MICROARCH.md (HBM / rocprofv3): one `rocprofv3 --kernel-trace --pmc <
 WRITE_SIZE, TCC_HIT_sum + TCC_MISS_sum), no other trace domain; FETCH_SIZE / WRITE_SIZE are KiB summed over the XCDs, and on
 gfx950 FETCH_SIZE counts half of the bytes of 16-byte-per-lane reads, so it is doubled.  The profiled command is bench.py itself
 (3 steps, one stream), i.e. the benched binary and workload; the SN1-stage launches are the dispatches whose kernel name matches and
-whose grid is the largest of the two K-agg stages.  This script makes no HIP call itself: it only spawns rocprofv3 with python3
+the second one of each forward (the DG1 stage launches the same template first); every pass is averaged over the same last launches.  This script makes no HIP call itself: it only spawns rocprofv3 with python3
 right behind the `--`.  bench.py copies `hbm_bytes_per_launch` into `roofline.traffic` only while
 sha256(csrc/lpd_edge.hip + csrc/lpd_edge_win.hip) still equals the recorded `kernel_source_sha256`.
 """
@@ -55,16 +55,27 @@ def one_pass(tag, counters, bench_args):
     return per, meta
 
 
-def mean_for(per, meta, match, counter):
-    grids = [g for (n, g) in meta.values() if match in n]
-    if not grids:
+def sn1_dispatches(meta, match):
+    """Dispatch ids of the SN1-stage (C = 256) launches, deterministically: on one stream every forward launches this kernel template
+    twice, the DG1 stage (C = 128) first and the SN1 stage second, so the matching dispatches in id order pair up (first, second) and
+    the SN1 launches are the second of each pair.  Where the two stages have different grids the grid decides instead."""
+    ids = sorted((d for d, (n, g) in meta.items() if match in n), key=int)
+    if not ids:
         raise SystemExit(f"no dispatch of {match} in the counter pass")
-    vals = [v for (d, c), v in per.items() if c == counter and match in meta[d][0]]
-    # both K-agg stages run the same kernel template; C = 256 moves twice the bytes of C = 128: keep the upper half by value
-    vals.sort()
-    top = vals[len(vals) // 2:] if len(set(grids)) == 1 else [v for (d, c), v in per.items()
-                                                              if c == counter and match in meta[d][0] and meta[d][1] == max(grids)]
-    return sum(top) / len(top), len(top)
+    grids = {meta[d][1] for d in ids}
+    if len(grids) > 1:
+        return [d for d in ids if meta[d][1] == max(grids)]
+    if len(ids) % 2:
+        raise SystemExit(f"{len(ids)} dispatches of {match}: expected two per forward")
+    return ids[1::2]
+
+
+def mean_for(per, meta, match, counter, last):
+    """mean of `counter` over the LAST `last` SN1-stage launches of the pass (the same positions of the program in every pass: the
+    timed steps and what follows them, not the clock-settling forwards whose number differs from run to run)"""
+    ids = sn1_dispatches(meta, match)[-last:]
+    vals = [per[(d, counter)] for d in ids]
+    return sum(vals) / len(vals), len(vals)
 
 
 def main():
@@ -74,16 +85,19 @@ def main():
     sha = kernel_source_sha256()
     for name in which:
         c = CFG[name]
-        fetch, n_f = mean_for(*one_pass(name + "_fetch", ["FETCH_SIZE"], c["args"]), c["match"], "FETCH_SIZE")
-        write, n_w = mean_for(*one_pass(name + "_write", ["WRITE_SIZE"], c["args"]), c["match"], "WRITE_SIZE")
-        per, meta = one_pass(name + "_tcc", ["TCC_HIT_sum", "TCC_MISS_sum"], c["args"])
-        hit, _ = mean_for(per, meta, c["match"], "TCC_HIT_sum")
-        miss, n_t = mean_for(per, meta, c["match"], "TCC_MISS_sum")
+        p_f, p_w, p_t = (one_pass(name + "_fetch", ["FETCH_SIZE"], c["args"]), one_pass(name + "_write", ["WRITE_SIZE"], c["args"]),
+                         one_pass(name + "_tcc", ["TCC_HIT_sum", "TCC_MISS_sum"], c["args"]))
+        last = min(len(sn1_dispatches(p[1], c["match"])) for p in (p_f, p_w, p_t))      # the same launch positions in all three passes
+        last = min(last, 8)
+        fetch, n_f = mean_for(*p_f, c["match"], "FETCH_SIZE", last)
+        write, n_w = mean_for(*p_w, c["match"], "WRITE_SIZE", last)
+        hit, _ = mean_for(*p_t, c["match"], "TCC_HIT_sum", last)
+        miss, n_t = mean_for(*p_t, c["match"], "TCC_MISS_sum", last)
         pts = c["batch"] * c["points"]
-        alg = (3 * 256 * 4 + 4 * c["k"]) * pts
+        alg = (3 * 256 * 4 + 2 * c["k"]) * pts      # the kernel reads its indices as uint16 (pack_idx16)
         hbm = int(round((2.0 * fetch + write) * 1024))
         run = {"batch": c["batch"], "points": c["points"], "k": c["k"], "bench_key": c["bench_key"],
-               "kernel": f"{c['match']} (SN1 stage, C=256; the upper half by counter value of the dispatches of this template)",
+               "kernel": f"{c['match']} (SN1 stage, C=256: the second launch of this template in each forward)",
                "FETCH_SIZE_KiB": round(fetch, 2), "WRITE_SIZE_KiB": round(write, 2), "hbm_bytes_per_launch": hbm,
                "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": round(hbm / alg, 4),
                "TCC_HIT_sum": round(hit, 1), "TCC_MISS_sum": round(miss, 1), "l2_hit_rate": round(hit / max(hit + miss, 1.0), 3),
