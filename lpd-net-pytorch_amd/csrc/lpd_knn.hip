@@ -1037,7 +1037,8 @@ __global__ __launch_bounds__(256) void knn7_bf16_kernel(const float* __restrict_
 // (Four query tiles per wave at one wave per SIMD, software-pipelined by hand, was slower: 133 us against 113.)
 constexpr int KNN7_BQT = 2;
 __global__ __launch_bounds__(256, 2) void knn7_bound_kernel(const __bf16* __restrict__ xb, const float* __restrict__ xx,
-                                                            const float* __restrict__ txmax, uint16_t* __restrict__ ubq, int N, int nt, int C)
+                                                            const float* __restrict__ txmax, uint16_t* __restrict__ ubq, int N, int nt, int C,
+                                                            int tchunk)
 {
     constexpr int QT = KNN7_BQT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1102,13 +1103,16 @@ __global__ __launch_bounds__(256, 2) void knn7_bound_kernel(const __bf16* __rest
             if (h == 0 && W0 + i < nt) ubq[(((size_t)b * nt + (W0 + i)) * nt + T) * 32 + col] = (uint16_t)bits;
         }
     };
+    // blockIdx.z: this block's range of candidate tiles (tchunk, a multiple of RING).  One range for large batches; a small batch
+    // (one cloud = 16 blocks of a 256-CU chip, each walking all 128 candidate tiles: 85 us of latency) is cut into up to 8 ranges
+    const int tbeg = blockIdx.z * tchunk, tend = min(nt, tbeg + tchunk);
 #pragma unroll
-    for (int d = 0; d < RING - 1; ++d) load_c(d, cop[d]);
-    for (int T0 = 0; T0 < nt; T0 += RING) {
+    for (int d = 0; d < RING - 1; ++d) load_c(tbeg + d, cop[d]);
+    for (int T0 = tbeg; T0 < tend; T0 += RING) {
 #pragma unroll
         for (int d = 0; d < RING; ++d) {
             load_c(T0 + d + RING - 1, cop[(d + RING - 1) % RING]);      // the set tile T0 + d - 1 has just released
-            if (T0 + d < nt) one_tile(T0 + d, cop[d]);
+            if (T0 + d < tend) one_tile(T0 + d, cop[d]);
         }
     }
 }
@@ -1246,6 +1250,9 @@ __global__ __launch_bounds__(1024) void knn7_order_kernel(const int32_t* __restr
 template <int KMAX>
 __device__ __forceinline__ void knn7_insert(float (&v)[KMAX], int (&id)[KMAX], float x, float y, int j)
 {
+    // (Round 5, tried and dropped: leaving the unrolled chain at the first check -- every 2 / 4 / 8 slots -- at which no lane is still
+    //  shifting.  A shift is over for a lane at the first element that ranks before its candidate, but some lane of the 64 nearly always
+    //  inserts deep: 32 x 4096 x k20 405 / 198 us with the checks against 393 / 198 without, k = 64 lists 3.82 / 1.77 ms against 3.77 / 1.64.)
     unsigned long long cc, cp;
     int ti;
     asm volatile("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(cc) : "v"(v[KMAX - 1]), "v"(y));
@@ -1853,22 +1860,30 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
             __bf16* xb = knn7_xb_of(xx, B, N);
             ubq = reinterpret_cast<uint16_t*>(xb + (size_t)B * nt * 32 * KNN7_XB);
             if (!xb_ready) hipLaunchKernelGGL(knn7_bf16_kernel, dim3((nt * 64 + 255) / 256, B), dim3(256), 0, stream, (const float*)xp, xx, xb, N, nt);
-            hipLaunchKernelGGL(knn7_bound_kernel, dim3((nt + 4 * KNN7_BQT - 1) / (4 * KNN7_BQT), B), dim3(256), 0, stream, (const __bf16*)xb, xx,
-                               (const float*)txmax, ubq, N, nt, C);
+            const int bx = (nt + 4 * KNN7_BQT - 1) / (4 * KNN7_BQT);
+            int zs = 1;                                  // ranges of candidate tiles per query block: until the grid has ~512 blocks
+            while (zs < 8 && (long long)bx * B * zs < 512 && (nt + 2 * zs - 1) / (2 * zs) >= 8) zs *= 2;
+            const int tchunk = (((nt + zs - 1) / zs) + 3) & ~3;
+            hipLaunchKernelGGL(knn7_bound_kernel, dim3(bx, B, (nt + tchunk - 1) / tchunk), dim3(256), 0, stream, (const __bf16*)xb, xx,
+                               (const float*)txmax, ubq, N, nt, C, tchunk);
             LPD_CHECK_LAUNCH("lpd_knn(low-precision bounds)");
         }
     }
     static const bool branchy = getenv("LPD_KNN_FULLT") && atoi(getenv("LPD_KNN_FULLT")) == 0;     // 0: the branchy tile body for every N
     // Small batches: KNN7_SPLIT waves per query tile (see knn7_kernel).  LPD_KNN_SPLIT=0 never, =1 always (where it is built); default:
-    // while the single-wave grid would not fill the wave slots of the chip (256 CUs x 4 SIMDs x WAVES_PER_SIMD) -- up to there the
-    // split launch is the shorter one (more, shorter waves), beyond it both are the same number of rounds.
+    // while the split grid fits the wave slots of the chip (256 CUs x 4 SIMDs x waves per SIMD).
     constexpr int KNN7_SPLIT = 4;
     constexpr bool split_built = KMAX <= 20 && !(ONFLY && CP == 32);
     static const int split_env = getenv("LPD_KNN_SPLIT") ? atoi(getenv("LPD_KNN_SPLIT")) : -1;
+    // Measured (tools/knn_split_bench.py, one stream, N = 4096): 1 cloud 193 -> 144 us (64 channels) / 136 -> 92 us (xyz); 6 clouds
+    // 221 -> 239 / 142 -> 116; 10 clouds 233 -> 313 / 155 -> 186; 16 clouds 262 -> 421 / 158 -> 259: the split launch does MORE work
+    // (every wave pays the first tile's 16-entry drain, the early thresholds are looser, the lists are merged twice), so it pays
+    // exactly while all of its waves are resident at once -- it then is latency, not throughput, that sets the launch time.
+    const int split_wps = CP == 2 ? 3 : L::WAVES_PER_SIMD;      // (the split xyz kernel holds 146 registers: three waves per SIMD)
     const bool split = split_built && N % 32 == 0 && !branchy && !dbg && split_env != 0 &&
-                       (split_env == 1 || (long long)nitems <= 1024ll * L::WAVES_PER_SIMD);
+                       (split_env == 1 || (long long)nitems * KNN7_SPLIT <= 1024ll * split_wps);
     // (longest-first order: pointless while every workgroup of the launch is resident at once)
-    const bool use_order = lpt && !(split && (long long)nitems * KNN7_SPLIT <= 1024ll * L::WAVES_PER_SIMD);
+    const bool use_order = lpt && !(split && (long long)nitems * KNN7_SPLIT <= 1024ll * split_wps);
     if (use_order) {
         hipLaunchKernelGGL(knn7_predict_kernel<CP>, dim3(nt, B), dim3(128), 0, stream, (const float*)cenp, (const float*)rad, pred, nt);
         hipLaunchKernelGGL(knn7_order_kernel, dim3((nitems / 8 + 1 + 1023) / 1024, 8), dim3(1024), 0, stream, (const int32_t*)pred, order, nitems);
