@@ -55,8 +55,11 @@ long long lpd_stat_ws_bytes(void);
  *   ws     workspace of lpd_knn_workspace_floats(B, C, N, k) floats: per-point sums of squares, the packed MFMA operand
  *          image xp[b][n][h][s] = x[b][2s+h][n], and (best-first path) per-tile centroids / radii / visiting orders
  *   impl   0 = product path: f32-MFMA distance tiles + queued selection; best-first tile order with exact skip bounds for
- *          N <= 4096, k <= 20, C <= 64, ascending scan otherwise; 4 = ascending scan forced (A/B timing);
- *          1 = VALU fmaf cross-check (k <= 20); 2 = first-generation MFMA kernel with in-scan insertion
+ *          C <= 64, k <= 64 (four waves per query tile while the grid would not fill the chip), the first-generation kernel for
+ *          64 < C <= 256.  Everything else is NOT a product path: 4 / 6 = ascending scan / best-first walk forced (A/B timing, same
+ *          indices), 5 = per-wave walk statistics INSTEAD of indices (tools/knn7_stats.py), 1 = VALU fmaf cross-check of the MFMA
+ *          arithmetic (k <= 20; an on-device oracle for tests), 2 = first-generation kernel forced.  Other values: LPD_ERR_ARG.
+ *          (impl 3 and the timing ablations 10..137 of rounds 1-2 were removed in round 5.)
  * Supported: C <= 256, k <= 64, k <= N.  Bit-exact vs the reference CPU path on tie-free rows.
  */
 int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* ws, int impl, void* stream);

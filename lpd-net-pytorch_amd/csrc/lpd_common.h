@@ -94,6 +94,28 @@ __device__ __forceinline__ int lpd_xcd_remap(int bid, int nblocks)
     return base + slot;
 }
 
+// Grid-stride walk over `nwork` wave-sized items for the row-gather kernels of the training path, XCD-aware.  Blocks b, b + 8, ... share
+// an XCD and its L2.  With the plain walk (item = global wave id, stride = all waves) the blocks resident at one time cover ONE window
+// of consecutive rows that is spread over all eight XCDs, so every L2 fills with the same gathered neighbour rows: SN1's backward gather
+// moved 2.85 GB through the fabric for ~1 GB of distinct bytes (rocprofv3 FETCH_SIZE, profiles/r05_pmc_train_bf16.txt).  Here each XCD
+// owns one contiguous range of items and its resident blocks sweep that range together (the walk lpd_edge_gather_max_kernel has used
+// since round 1): the rows a window gathers -- Z-ordered clouds: neighbours are nearby rows -- are fetched into ONE L2.
+struct LpdXcdSweep { long long begin, end, step; };
+__device__ __forceinline__ LpdXcdSweep lpd_xcd_sweep(long long nwork)
+{
+    const int nx = 8;
+    const int wpb = blockDim.x >> 6;
+    const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
+    const long long blocks_here = gridDim.x / nx + (xcd < (int)(gridDim.x % nx) ? 1 : 0);      // blocks of this launch on this XCD
+    const long long per_xcd = (nwork + nx - 1) / nx;
+    LpdXcdSweep s;
+    const long long b = xcd * per_xcd;
+    s.end = b + per_xcd < nwork ? b + per_xcd : nwork;
+    s.begin = b + (long long)slot * wpb + (threadIdx.x >> 6);
+    s.step = blocks_here * wpb;
+    return s;
+}
+
 // ---- split-bf16 activation planes (what lpd_gemm_p8 / lpd_gemm_x3t read): x = hi + lo, hi = bf16(x), lo = bf16(x - hi) ----
 typedef __bf16 lpd_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float lpd_f32x2 __attribute__((ext_vector_type(2)));

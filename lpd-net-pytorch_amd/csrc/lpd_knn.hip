@@ -574,7 +574,7 @@ void knn3_kernel(const float* __restrict__ xp, const float* __restrict__ xx, int
     };
     reset_lists();
 
-    const int ntiles = (dbg & 16) ? 0 : (N + 31) / 32;   // dbg&16: timing ablation, empty scan
+    const int ntiles = (N + 31) / 32;
     float a[CP];
     float4 x4[4];
     float pd[16];
@@ -589,7 +589,6 @@ void knn3_kernel(const float* __restrict__ xp, const float* __restrict__ xx, int
         if (t_lo < 0) t_lo = 0;
         knn3_ld_ops<CP>(xpb, N, t_lo * 32 + col, h, a);
         knn3_ld_xx(xxb, N, t_lo * 32, h, vec_ok, x4);
-        if (dbg & 2) t_hi = t_lo;   // timing ablation: no admission threshold
         for (int t = t_lo; t < t_hi; ++t) {
             knn3_tile<CP>(a, x4, qreg, xq, xpb, xxb, N, (t + 1) * 32, t + 1 < t_hi, col, h, vec_ok, pd);
             // unconditional, branch-free insertion: a value that does not beat the K-th best (or NaN padding) is replaced
@@ -632,14 +631,14 @@ void knn3_kernel(const float* __restrict__ xp, const float* __restrict__ xx, int
     knn3_ld_ops<CP>(xpb, N, col, h, a);
     knn3_ld_xx(xxb, N, 0, h, vec_ok, x4);
     for (int t = 0; t < ntiles; ++t) {
-        knn3_tile<CP>(a, x4, qreg, xq, xpb, xxb, N, (t + 1) * 32, (t + 1 < ntiles) && !(dbg & 4), col, h, vec_ok, pd);   // dbg&4: timing ablation, no operand refill
+        knn3_tile<CP>(a, x4, qreg, xq, xpb, xxb, N, (t + 1) * 32, (t + 1 < ntiles), col, h, vec_ok, pd);
         const float thr = fmaxf(t0, lv[KMAX - 1]);
         const bool list_full = lv[KMAX - 1] > -INFINITY;
         // tile-level reject: most tiles are far from all 32 (Z-ordered, hence clustered) queries of the wave; one max
         // over the 16 values and a wave vote replace 16 exec-masked append sequences (~100 executed instructions)
         float mx = fmaxf(fmaxf(fmaxf(pd[0], pd[1]), fmaxf(pd[2], pd[3])), fmaxf(fmaxf(pd[4], pd[5]), fmaxf(pd[6], pd[7])));
         mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(pd[8], pd[9]), fmaxf(pd[10], pd[11])), fmaxf(fmaxf(pd[12], pd[13]), fmaxf(pd[14], pd[15]))));
-        if (!__any(list_full ? (mx > thr) : (mx >= thr)) || (dbg & 1)) continue;   // dbg&1: timing ablation
+        if (!__any(list_full ? (mx > thr) : (mx >= thr))) continue;
         ++stat_pass;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -651,9 +650,9 @@ void knn3_kernel(const float* __restrict__ xp, const float* __restrict__ xx, int
                 ++cnt;
             }
         }
-        if (__any(cnt > KNN3_QCAP - 16)) { if (dbg & 32) cnt = 0; else drain(); }   // dbg&32: timing ablation, drop instead of drain
+        if (__any(cnt > KNN3_QCAP - 16)) drain();
     }
-    if (!(dbg & 32)) drain();
+    drain();
 
     // ---- merge the two half-lists: both halves publish their sorted lists in this wave's (now free) queue region and
     // the lower half-wave walks the two lists with a 2-pointer merge (k steps of two LDS reads and a compare) ----
@@ -669,7 +668,7 @@ void knn3_kernel(const float* __restrict__ xp, const float* __restrict__ xx, int
         if (h == 0) { int32_t* o = idx + ((size_t)b * N + q) * k; o[0] = stat_adm; o[1] = stat_it; o[2] = stat_pass; o[3] = __float_as_int(t0); }
         else { int32_t* o = idx + ((size_t)b * N + q) * k; o[4] = stat_adm; }
     } else
-    if (h == 0 && q_ok && !(dbg & 8)) {   // dbg&8: timing ablation, no merge / no output
+    if (h == 0 && q_ok) {
         const float* av = mv + lane * KMAX;
         const int* ai = mi + lane * KMAX;
         const float* bv = mv + (lane + 32) * KMAX;
@@ -686,212 +685,6 @@ void knn3_kernel(const float* __restrict__ xp, const float* __restrict__ xx, int
             }
             if (take_a) out[s] = ai[pa++];
             else out[s] = bi[pb++];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// impl 3 (experimental): the LDS-staged candidate stream of the first generation (no exposed memory
-// latency: chunks are double-buffered through LDS and shared by the 4 waves of a block) combined with
-// the admission threshold T0, the tile-level reject and the queued selection of the streaming kernel.
-// With T0 the per-tile selection work is small and uniform across waves, so the per-chunk barrier no
-// longer couples a slow wave to the others.
-// ---------------------------------------------------------------------------------------------
-template <int CP>
-struct Knn6Cfg {
-    static constexpr int CHUNK = (CP <= 2) ? 128 : (CP <= 32 ? 64 : 32);
-    static constexpr int ROWS = 2 * CP;
-    static constexpr int FLOATS = ROWS * CHUNK;
-    static constexpr int PER_THREAD = (FLOATS + KNN_THREADS - 1) / KNN_THREADS;
-    static constexpr int QCAP = 24;
-};
-
-template <int CP, int KMAX>
-__global__ __launch_bounds__(KNN_THREADS, 2) void knn6_kernel(const float* __restrict__ x, const float* __restrict__ xx,
-                                                               int32_t* __restrict__ idx, int C, int N, int k, int blocks_per_cloud)
-{
-    using Cfg = Knn6Cfg<CP>;
-    constexpr int CHUNK = Cfg::CHUNK;
-    constexpr int QCAP = Cfg::QCAP;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;                                                 // [2][ROWS][CHUNK]
-    float* xxs = smem + 2 * Cfg::FLOATS;                              // [2][CHUNK]
-    float2* queue = reinterpret_cast<float2*>(xxs + 2 * CHUNK);       // [4 waves][QCAP][64]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int h = lane >> 5;
-    const int col = lane & 31;
-    const int vb = lpd_xcd_remap(blockIdx.x, gridDim.x);
-    const int b = vb / blocks_per_cloud;
-    const int qb = vb - b * blocks_per_cloud;
-    const int q0 = qb * KNN_QPB + wave * 32;
-    const int q = q0 + col;
-    const bool q_ok = q < N;
-    const float* xb = x + (size_t)b * C * N;
-    const float* xxb = xx + (size_t)b * N;
-    float2* myq = queue + (size_t)wave * QCAP * 64 + lane;
-
-    float qreg[CP];
-#pragma unroll
-    for (int s = 0; s < CP; ++s) {
-        const int c = 2 * s + h;
-        qreg[s] = (q_ok && c < C) ? xb[(size_t)c * N + q] : 0.0f;
-    }
-    const float xq = q_ok ? xxb[q] : 0.0f;
-
-    float lv[KMAX];
-    int li[KMAX];
-    auto reset_lists = [&]() {
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s) {
-            lv[s] = -INFINITY;
-            li[s] = 0x7fffffff;
-        }
-    };
-    reset_lists();
-    const int ntiles = (N + 31) / 32;
-    const float nanv = __builtin_nanf("");
-
-    // ---- phase A: admission threshold from the tiles around the wave's own tile (direct from global/L2) ----
-    {
-        const int t_own = q0 / 32;
-        int t_lo = t_own - 1, t_hi = t_own + 2;
-        while ((t_hi - t_lo) * 16 < KMAX) { --t_lo; ++t_hi; }
-        if (t_lo < 0) { t_hi -= t_lo; t_lo = 0; }
-        if (t_hi > ntiles) { t_lo -= t_hi - ntiles; t_hi = ntiles; }
-        if (t_lo < 0) t_lo = 0;
-        for (int t = t_lo; t < t_hi; ++t) {
-            const int j = t * 32 + col;
-            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < CP; ++s) {
-                const int c = 2 * s + h;
-                const float a = (j < N && c < C) ? xb[(size_t)c * N + j] : 0.0f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jr = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float xxj = jr < N ? xxb[jr] : nanv;
-                const float pdv = __fsub_rn(__fsub_rn(-xxj, __fmul_rn(-2.0f, acc[r])), xq);
-                if (pdv > lv[KMAX - 1]) knn_insert<KMAX>(lv, li, pdv, 0);
-            }
-        }
-    }
-    float t0 = lv[KMAX - 1];
-    t0 = fmaxf(t0, __shfl_xor(t0, 32, 64));
-    reset_lists();
-
-    // ---- phase B: ascending scan over LDS-staged chunks ----
-    const int nchunks = (N + CHUNK - 1) / CHUNK;
-    float stage[Cfg::PER_THREAD];
-    float stage_xx = 0.0f;
-    auto load_chunk = [&](int ch) {
-        const int j0 = ch * CHUNK;
-#pragma unroll
-        for (int e = 0; e < Cfg::PER_THREAD; ++e) {
-            const int f = e * KNN_THREADS + tid;
-            const int c = f / CHUNK, jj = f % CHUNK;
-            const int j = j0 + jj;
-            stage[e] = (f < Cfg::FLOATS && c < C && j < N) ? xb[(size_t)c * N + j] : 0.0f;
-        }
-        if (tid < CHUNK) {
-            const int j = j0 + tid;
-            stage_xx = j < N ? xxb[j] : nanv;
-        }
-    };
-    auto store_chunk = [&](int buf) {
-        float* dst = xs + buf * Cfg::FLOATS;
-#pragma unroll
-        for (int e = 0; e < Cfg::PER_THREAD; ++e) {
-            const int f = e * KNN_THREADS + tid;
-            if (f < Cfg::FLOATS) dst[f] = stage[e];
-        }
-        if (tid < CHUNK) xxs[buf * CHUNK + tid] = stage_xx;
-    };
-    int cnt = 0;
-    auto drain = [&]() {
-        for (int e = 0; __any(e < cnt); ++e) {
-            if (e < cnt) {
-                const float2 ent = myq[e * 64];
-                if (ent.x > lv[KMAX - 1]) knn_insert<KMAX>(lv, li, ent.x, __float_as_int(ent.y));
-            }
-        }
-        cnt = 0;
-    };
-
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < nchunks) load_chunk(ch + 1);
-        const float* cx = xs + buf * Cfg::FLOATS;
-        const float* cxx = xxs + buf * CHUNK;
-        const int j0 = ch * CHUNK;
-#pragma unroll 1
-        for (int t = 0; t < CHUNK / 32; ++t) {
-            if (j0 + t * 32 >= N) break;
-            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < CP; ++s) {
-                const float a = cx[(2 * s + h) * CHUNK + t * 32 + col];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], acc, 0, 0, 0);
-            }
-            float pd[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jj = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                pd[r] = __fsub_rn(__fsub_rn(-cxx[jj], __fmul_rn(-2.0f, acc[r])), xq);
-            }
-            const float thr = fmaxf(t0, lv[KMAX - 1]);
-            const bool list_full = lv[KMAX - 1] > -INFINITY;
-            float mx = fmaxf(fmaxf(fmaxf(pd[0], pd[1]), fmaxf(pd[2], pd[3])), fmaxf(fmaxf(pd[4], pd[5]), fmaxf(pd[6], pd[7])));
-            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(pd[8], pd[9]), fmaxf(pd[10], pd[11])), fmaxf(fmaxf(pd[12], pd[13]), fmaxf(pd[14], pd[15]))));
-            if (__any(list_full ? (mx > thr) : (mx >= thr))) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool admit = list_full ? (pd[r] > thr) : (pd[r] >= thr);
-                    if (admit) {
-                        const int jj = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        myq[cnt * 64] = make_float2(pd[r], __int_as_float(j0 + jj));
-                        ++cnt;
-                    }
-                }
-                if (__any(cnt > QCAP - 16)) drain();
-            }
-        }
-        if (ch + 1 < nchunks) store_chunk(buf ^ 1);
-        __syncthreads();
-    }
-    drain();
-
-    // ---- merge the two half-lists through this wave's queue region ----
-    float* mv = reinterpret_cast<float*>(queue) + (size_t)wave * QCAP * 128;
-    int* mi = reinterpret_cast<int*>(mv + 32 * KMAX);
-    if (h == 1) {
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s) {
-            mv[col * KMAX + s] = lv[s];
-            mi[col * KMAX + s] = li[s];
-        }
-    }
-    __syncthreads();
-    if (h == 0) {
-        for (int e = 0; e < KMAX; ++e) {
-            const float pv = mv[col * KMAX + e];
-            const int pj = mi[col * KMAX + e];
-            const bool enters = (pv > lv[KMAX - 1]) || (pv == lv[KMAX - 1] && pj < li[KMAX - 1]);
-            if (!enters) break;
-            knn_insert_any<KMAX>(lv, li, pv, pj);
-        }
-        if (q_ok) {
-            int32_t* out = idx + ((size_t)b * N + q) * k;
-#pragma unroll
-            for (int s = 0; s < KMAX; ++s)
-                if (s < k) out[s] = li[s];
         }
     }
 }
@@ -1774,20 +1567,6 @@ __global__ __launch_bounds__(WAVES * SPLIT * 64, ((SPLIT > 1 && CP == 2) ? 3 : K
 }
 
 template <int CP, int KMAX>
-int knn6_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream)
-{
-    using Cfg = Knn6Cfg<CP>;
-    static_assert(Cfg::QCAP * 128 >= 2 * 32 * KMAX, "merge region must fit the wave's queue region");
-    size_t lds = (size_t)(2 * Cfg::FLOATS + 2 * Cfg::CHUNK) * sizeof(float) + (size_t)KNN_WAVES * Cfg::QCAP * 64 * sizeof(float2);
-    const int bpc = (N + KNN_QPB - 1) / KNN_QPB;
-    auto kern = knn6_kernel<CP, KMAX>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(bpc * B), dim3(KNN_THREADS), lds, stream, x, xx, idx, C, N, k, bpc);
-    LPD_CHECK_LAUNCH("lpd_knn(impl 3)");
-    return LPD_OK;
-}
-
-template <int CP, int KMAX>
 int knn3_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int N, int k, hipStream_t stream, int dbg = 0)
 {
     // packed operands live behind the squared norms in the caller's workspace: [xx: B*N][xp: B*N*2*CP]
@@ -2000,6 +1779,7 @@ extern "C" int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
     LPD_CHECK_ARG(B > 0 && C > 0 && N > 0, "lpd_knn: bad dims B=%d C=%d N=%d", B, C, N);
     LPD_CHECK_ARG(k > 0 && k <= N, "lpd_knn: need 0 < k <= N (k=%d N=%d)", k, N);
     LPD_CHECK_ARG(B <= 65535, "lpd_knn: B=%d exceeds grid.y", B);
+    LPD_CHECK_ARG(impl == 0 || impl == 1 || impl == 2 || impl == 4 || impl == 5 || impl == 6, "lpd_knn: impl=%d (0 product; 4 / 6 force the ascending / best-first kernel; 5 statistics; 1 VALU cross-check; 2 first-generation kernel)", impl);
     hipLaunchKernelGGL(knn_sumsq_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, xx_ws, C, N);
     LPD_CHECK_LAUNCH("lpd_knn(sumsq)");
     if (((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && knn7_applies(C, N, k))   // best-first (5: statistics)
@@ -2008,12 +1788,6 @@ extern "C" int lpd_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
         if (C <= 4) return knn3_dispatch_k<2>(x, xx_ws, idx, B, C, N, k, stream);
         if (C <= 64) return knn3_dispatch_k<32>(x, xx_ws, idx, B, C, N, k, stream);
         if (C <= 256) return knn_dispatch_k<128>(x, xx_ws, idx, B, C, N, k, 0, stream);   // wide features: v1
-    } else if (impl >= 10 && impl < 138 && k <= 20 && C <= 64) {   // timing ablations of the product kernel (wrong results)
-        if (C <= 4) return knn3_launch<2, 20>(x, xx_ws, idx, B, C, N, k, stream, impl - 10);
-        return knn3_launch<32, 20>(x, xx_ws, idx, B, C, N, k, stream, impl - 10);
-    } else if (impl == 3 && k <= 20 && C <= 64) {
-        if (C <= 4) return knn6_launch<2, 20>(x, xx_ws, idx, B, C, N, k, stream);
-        return knn6_launch<32, 20>(x, xx_ws, idx, B, C, N, k, stream);
     } else {
         const int v1impl = impl == 1 ? 1 : 0;   // 1: VALU cross-check, 2: v1 MFMA + in-scan insertion
         if (C <= 4) return knn_dispatch_k<2>(x, xx_ws, idx, B, C, N, k, v1impl, stream);
@@ -2058,6 +1832,7 @@ extern "C" int lpd_knn_pm(const float* x_pm, int ld, int B, int C, int N, int k,
     float* xp = ws + M;
     const bool prepped = (impl & LPD_KNN_PM_PREPARED) != 0;     // the operands are in ws already (lpd_lpdnet_front)
     impl &= ~LPD_KNN_PM_PREPARED;
+    LPD_CHECK_ARG(impl == 0 || impl == 4 || impl == 5 || impl == 6, "lpd_knn_pm: impl=%d (0 product; 4 / 6 force the ascending / best-first kernel; 5 statistics)", impl);
     const bool best_first = ((impl == 0 && KNN7_DEFAULT) || (impl == 5 || impl == 6)) && knn7_applies(C, N, k);
     // the bf16 operand image of the low-precision bound pass is written with the operands when that pass will run
     const bool xb_ready = knn_pm_wants_xb(C, N, k, impl) && (prepped || ld % 4 == 0);

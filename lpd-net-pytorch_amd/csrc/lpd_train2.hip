@@ -205,8 +205,7 @@ __global__ __launch_bounds__(256) void edge_split_bwd_apply_kernel(const int32_t
     constexpr int C = LPR * 4;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, cl = lane % LPR;
-    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+    const LpdXcdSweep sweep = lpd_xcd_sweep((M + RPW - 1) / RPW);
     const double E = (double)M * (double)k;
     float sc[4], mu[4], is[4], m1[4], m2i[4];
 #pragma unroll
@@ -229,8 +228,8 @@ __global__ __launch_bounds__(256) void edge_split_bwd_apply_kernel(const int32_t
             return *reinterpret_cast<const float4*>(f32 + i * ld + cl * 4);
         }
     };
-    for (long long r0 = wave * RPW; r0 < M; r0 += nw * RPW) {
-        const long long j = r0 + sub;
+    for (long long wi = sweep.begin; wi < sweep.end; wi += sweep.step) {
+        const long long j = wi * RPW + sub;
         if (j >= M) continue;
         const int beg = rowptr[j], end = rowptr[j + 1];
         float A[4] = {0, 0, 0, 0}, R[4] = {0, 0, 0, 0};
@@ -1169,8 +1168,7 @@ __global__ __launch_bounds__(256) void edge_dense_bwd_apply_kernel(const int32_t
     constexpr int C = LPR * 4;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, cl = lane % LPR;
-    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+    const LpdXcdSweep sweep = lpd_xcd_sweep((M + RPW - 1) / RPW);
     const double E = (double)M * (double)k;
     float sc[4], mu[4], m1[4], m2i[4];
 #pragma unroll
@@ -1186,8 +1184,8 @@ __global__ __launch_bounds__(256) void edge_dense_bwd_apply_kernel(const int32_t
         if constexpr (sizeof(GT) == 2) return ld4_bf16(reinterpret_cast<const uint16_t*>(G) + (long long)e * C + cl * 4);
         else return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(G) + (long long)e * C + cl * 4);
     };
-    for (long long r0 = wave * RPW; r0 < M; r0 += nw * RPW) {
-        const long long j = r0 + sub;
+    for (long long wi = sweep.begin; wi < sweep.end; wi += sweep.step) {
+        const long long j = wi * RPW + sub;
         if (j >= M) continue;
         const int beg = rowptr[j], end = rowptr[j + 1];
         float A[4] = {0, 0, 0, 0}, R[4] = {0, 0, 0, 0};

@@ -61,7 +61,7 @@ _cur_device = getattr(torch._C, "_cuda_getDevice", None)
 
 def _stream():
     """torch's current stream on the current device as a raw pointer.  torch.cuda.current_stream() builds a Stream object
-    through three layers of Python (10 us a call, a quarter of the host time of an eval forward: tools/host_profile.py); the raw
+    through three layers of Python (10 us a call, a quarter of the host time of an eval forward: measured with cProfile in round 2, HISTORY.md); the raw
     accessor is what torch's own code generators use."""
     if _raw_stream is not None and _cur_device is not None:
         return ctypes.c_void_p(_raw_stream(_cur_device()))

@@ -23,9 +23,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "lpd-net-pytorch_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_out", "kagg_pmc")
-CFG = {"cfg2": dict(batch=32, points=4096, k=20, bench_key="edge_gather_max16[C=256]", match="edge_gather_max_cloud16p_kernel", args=[]),
+# per_forward: launches of the matching kernel template in one forward (cfg2: the DG1 stage, two items per CU, runs the non-persistent
+# template `edge_gather_max_cloud16_kernel`, so the persistent one is the SN1 stage alone; cfg5: both stages run the window kernel)
+CFG = {"cfg2": dict(batch=32, points=4096, k=20, bench_key="edge_gather_max16[C=256]", match="edge_gather_max_cloud16p_kernel", args=[],
+                    per_forward=1),
        "cfg5": dict(batch=64, points=16384, k=64, bench_key="edge_gather_maxw[C=256]", match="edge_gather_max_window_kernel",
-                    args=["--batch", "64", "--points", "16384", "--k", "64"])}
+                    args=["--batch", "64", "--points", "16384", "--k", "64"], per_forward=2)}
 
 
 def kernel_source_sha256():
@@ -55,25 +58,25 @@ def one_pass(tag, counters, bench_args):
     return per, meta
 
 
-def sn1_dispatches(meta, match):
-    """Dispatch ids of the SN1-stage (C = 256) launches, deterministically: on one stream every forward launches this kernel template
-    twice, the DG1 stage (C = 128) first and the SN1 stage second, so the matching dispatches in id order pair up (first, second) and
-    the SN1 launches are the second of each pair.  Where the two stages have different grids the grid decides instead."""
-    ids = sorted((d for d, (n, g) in meta.items() if match in n), key=int)
+def sn1_dispatches(meta, match, per_forward):
+    """Dispatch ids of the SN1-stage (C = 256) launches, deterministically: on one stream a forward launches the matching template
+    `per_forward` times, the DG1 stage (C = 128) first and the SN1 stage last, so the matching dispatches in id order form groups of
+    that size and the SN1 launch is the last of each group.  Where the stages have different grids the grid decides instead."""
+    ids = sorted((d for d, (n, g) in meta.items() if match + "<" in n or n.endswith(match)), key=int)
     if not ids:
         raise SystemExit(f"no dispatch of {match} in the counter pass")
     grids = {meta[d][1] for d in ids}
-    if len(grids) > 1:
+    if per_forward > 1 and len(grids) > 1:
         return [d for d in ids if meta[d][1] == max(grids)]
-    if len(ids) % 2:
-        raise SystemExit(f"{len(ids)} dispatches of {match}: expected two per forward")
-    return ids[1::2]
+    if len(ids) % per_forward:
+        raise SystemExit(f"{len(ids)} dispatches of {match}: expected {per_forward} per forward")
+    return ids[per_forward - 1::per_forward]
 
 
-def mean_for(per, meta, match, counter, last):
+def mean_for(per, meta, match, counter, last, per_forward):
     """mean of `counter` over the LAST `last` SN1-stage launches of the pass (the same positions of the program in every pass: the
     timed steps and what follows them, not the clock-settling forwards whose number differs from run to run)"""
-    ids = sn1_dispatches(meta, match)[-last:]
+    ids = sn1_dispatches(meta, match, per_forward)[-last:]
     vals = [per[(d, counter)] for d in ids]
     return sum(vals) / len(vals), len(vals)
 
@@ -87,12 +90,13 @@ def main():
         c = CFG[name]
         p_f, p_w, p_t = (one_pass(name + "_fetch", ["FETCH_SIZE"], c["args"]), one_pass(name + "_write", ["WRITE_SIZE"], c["args"]),
                          one_pass(name + "_tcc", ["TCC_HIT_sum", "TCC_MISS_sum"], c["args"]))
-        last = min(len(sn1_dispatches(p[1], c["match"])) for p in (p_f, p_w, p_t))      # the same launch positions in all three passes
+        pf = c["per_forward"]
+        last = min(len(sn1_dispatches(p[1], c["match"], pf)) for p in (p_f, p_w, p_t))      # the same launch positions in all three passes
         last = min(last, 8)
-        fetch, n_f = mean_for(*p_f, c["match"], "FETCH_SIZE", last)
-        write, n_w = mean_for(*p_w, c["match"], "WRITE_SIZE", last)
-        hit, _ = mean_for(*p_t, c["match"], "TCC_HIT_sum", last)
-        miss, n_t = mean_for(*p_t, c["match"], "TCC_MISS_sum", last)
+        fetch, n_f = mean_for(*p_f, c["match"], "FETCH_SIZE", last, pf)
+        write, n_w = mean_for(*p_w, c["match"], "WRITE_SIZE", last, pf)
+        hit, _ = mean_for(*p_t, c["match"], "TCC_HIT_sum", last, pf)
+        miss, n_t = mean_for(*p_t, c["match"], "TCC_MISS_sum", last, pf)
         pts = c["batch"] * c["points"]
         alg = (3 * 256 * 4 + 2 * c["k"]) * pts      # the kernel reads its indices as uint16 (pack_idx16)
         hbm = int(round((2.0 * fetch + write) * 1024))
