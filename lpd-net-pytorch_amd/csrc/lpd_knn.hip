@@ -1079,7 +1079,10 @@ __device__ __forceinline__ void knn7_insert(float (&v)[KMAX], int (&id)[KMAX], f
 // tiles (one cloud: 195 + 138 us of a 0.55 ms forward); with four waves per tile the walk is a quarter as long.  The bound table of the
 // tile is ONE LDS copy per workgroup.  Bounds on the union's KMAX-th best that every wave may use: the best wave-level bound, and the
 // minimum over all 2 * SPLIT half-lists of their ceil(KMAX / (2 SPLIT))-th best (then the lists together hold KMAX candidates >= it).
-// Large batches keep SPLIT = 1: the total work is the same, the early thresholds are looser and the final merge is extra.
+// Large batches keep SPLIT = 1: a split launch does ~1.6x the work of the single-wave one.  Not because every wave fills an empty list
+// on its first tile -- letting wave 0 take the query tile alone first, the others starting from its bound, changed nothing (16 clouds
+// 444 us against 421) -- but because a drain lasts as long as its fullest lane, and a wave that sees a quarter of the candidates has
+// the same maximum for a quarter of the average.
 template <int CP, int KMAX, int WAVES, bool ONFLY, bool FULLT = false, int SPLIT = 1>
 __global__ __launch_bounds__(WAVES * SPLIT * 64, ((SPLIT > 1 && CP == 2) ? 3 : Knn7Cfg<CP, KMAX, ONFLY>::WAVES_PER_SIMD)) void knn7_kernel(const float* __restrict__ xp, const float* __restrict__ xx,
                                                              const float* __restrict__ cenp, const float* __restrict__ cnorm,
