@@ -611,8 +611,16 @@ def test_train_step0_cfg2_full_size_vs_reference(cuda, golden_dir, storage):
 # bf16 storage 2.7e-3 / 1.4e-3, loss 4.9e-4, gradients 3.2e-2 max / 9.2e-3 median -- 5-10x tighter than on the B = 6 / B = 16
 # fixtures (test_train_bf16_storage_vs_oracle: 1.8e-2, 1.5 %, 7-12 %), as expected when the head's BatchNorms run over 44 rows
 # instead of 6, and that is what the gates below state.
+# Round 5.  fp32 storage: the 1e-3 / 1.5e-4 descriptor gate stands on test_train_cfg2_full_size_flip_free_vs_fp64_oracle -- with the GPU's
+# own graphs and arg-max choices the same step is within 1.9e-5 of fp64, so the excess against the reference's runs IS near-ties.
+# bf16 storage, derived from the format: every stored edge value / map element carries a relative rounding of u = 2^-9 (uniform in +-u/2:
+# rms u / sqrt(12) = 5.6e-4); a BatchNorm turns it into that fraction of |z| / sigma ~ 1-3 normalised units, the pooling over 4096 points
+# and the max over k average it down, and the head's two BatchNorms over the B = 44 descriptor rows amplify what is left ~10x (the fp32
+# rounding of the same step, 6e-8, lands at 2.3e-4 / 3e-5: 500x at the maximum, 50x at the median; 5.6e-4 / sqrt(4096 * 20) * 500 = 1e-3).
+# Measured: descriptors 1.5e-3 max / 8.9e-4 median, loss 3.1e-4, gradients 1.9e-2 max / 7.7e-3 median (rounds 4 and 5, unchanged by the
+# round-5 kernels).  Gates at 1.6-2x of that: one more rounding of a stored tensor (a factor sqrt(2)) still passes, a second one does not.
 CFG2_GATES = {"f32": (1e-3, 1.5e-4, 5e-4, 5e-3, 2e-3),
-              "bf16": (6e-3, 3e-3, 2e-3, 0.07, 0.02)}     # about twice the measured values above (unchanged by the round-3 kernels)
+              "bf16": (3e-3, 1.5e-3, 1e-3, 0.035, 0.013)}
 
 
 def test_bf16_storage_converges_like_fp32(cuda):
