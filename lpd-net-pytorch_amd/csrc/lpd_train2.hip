@@ -234,6 +234,10 @@ __global__ __launch_bounds__(256) void edge_split_bwd_apply_kernel(const int32_t
         const int beg = rowptr[j], end = rowptr[j + 1];
         float A[4] = {0, 0, 0, 0}, R[4] = {0, 0, 0, 0};
         int p = beg;
+        // (Round 5, tried and dropped: the row's edge ids in ONE load handed out by lane shuffles + eight edges' rows per batch -- the chain
+        //  rowptr -> ids -> rows shortened from 11 to 5 dependent round trips at degree 20.  No gain: this kernel 690 -> 933 us in the bf16
+        //  form (134 registers, three waves per SIMD), 788 -> 789 us in fp32, the dense counterpart 367 -> 358: the chain is not what the
+        //  parked waves wait for; profiles/r05_train_gather_batch8.txt.)
         for (; p + 3 < end; p += 4) {          // four incoming edges at a time: twelve independent row loads in flight (1104 -> 930 us)
             unsigned ii[4], tt[4];
 #pragma unroll
