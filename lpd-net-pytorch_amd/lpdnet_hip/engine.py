@@ -234,8 +234,8 @@ def _side_mode(device, points=None):
         return forced
     if SIDE_STREAM != "auto":
         return bool(SIDE_STREAM)
-    if torch.cuda.is_current_stream_capturing():
-        return False
+    if torch.cuda.is_current_stream_capturing():      # (a capture that forks onto the second stream replays at HALF the eager rate:
+        return False                                  #  1.1 vs 0.50 ms at one cloud, 2.04 vs 1.45 at 24 -- measured in round 5)
     return points is not None and points <= SIDE_SMALL_POINTS
 
 
