@@ -68,11 +68,16 @@ def reorder_points(x, reorder=True):
 # ------------------------------------------------------------------------------------------------
 # cached derived parameters
 # ------------------------------------------------------------------------------------------------
+# Derived tensors live OUTSIDE the module, weakly keyed by it: an entry holds a HIP event (ops.producer_mark), which cannot be pickled --
+# in module.__dict__ (rounds 1-4) it made copy.deepcopy(model) and torch.save(model) fail after the first forward -- and
+# nn.DataParallel's shallow replicas must not share (and thrash) the original's entries.
+_CACHES = __import__("weakref").WeakKeyDictionary()
+
+
 def _cache_of(module):
-    c = module.__dict__.get("_lpd_cache")
+    c = _CACHES.get(module)
     if c is None:
-        c = {}
-        module.__dict__["_lpd_cache"] = c  # not a parameter/buffer: never enters state_dict
+        c = _CACHES[module] = {}
     return c
 
 
@@ -246,6 +251,106 @@ def side_stream_report(device=None):
     return "one stream; batches of at most %d points (24 clouds x 4096) put the xyz kNN and the DG1 stage on a second stream" % SIDE_SMALL_POINTS
 
 
+def _join(waiter, signaller):
+    """`waiter` waits for what `signaller` has been given so far (noted on an open launch tape: a replay re-issues the join)"""
+    waiter.wait_stream(signaller)
+    tape = ops._TLS.TAPE
+    if tape is not None:
+        tape.actions.append((ops.Tape.JOIN, waiter, signaller, torch.cuda.Event()))
+
+
+# ------------------------------------------------------------------------------------------------
+# Launch-tape replay of small-batch eval forwards (round 5).  The one-cloud forward is HOST-bound: 0.56 ms of Python per forward
+# (argument checks, derived-parameter caches, 19 allocations, the stream fork / join; tools/host_profile.py) against ~0.41 ms of GPU
+# critical path, and a HIP graph is no way out on this runtime (a capture that forks onto the second stream replays at half the eager
+# rate).  So the second eval forward of a (model state, input shape, stream) is RECORDED -- every C-ABI call with its marshalled
+# arguments, torch's zero-fills and the stream joins in between, all tensors kept alive -- and later forwards re-issue that list:
+# 17 ctypes calls and 5 event pairs, no Python around them.  Same launches, same arguments, same streams: bit-identical results.
+# A recording is valid for ONE signature: every parameter / buffer (address, version), the input shape, the caller's stream and the
+# switches that steer the dispatch; anything else re-records.  Hooks (DEBUG_AUX, ops.PROFILE) and captures bypass it.  LPD_REPLAY=0: off.
+# ------------------------------------------------------------------------------------------------
+REPLAY = __import__("os").environ.get("LPD_REPLAY", "1") != "0"
+REPLAY_MAX_POINTS = 8 * 4096       # where the forward is host-bound (beyond ~6 clouds the GPU is the limit and the tape would only hold memory)
+REPLAY_MAX_PLANS = 4               # per model (a plan keeps the forward's buffers: ~50 MB per cloud)
+
+
+class _Plan:
+    __slots__ = ("sig", "x_in", "out", "actions", "keep", "hits")
+
+
+# Plans live OUTSIDE the module (weakly keyed by it): they hold ctypes function pointers and device buffers, which must not travel with
+# copy.deepcopy(model) / torch.save(model) / nn.DataParallel's shallow replicas (whose parameters are fresh tensors every forward).
+_PLANS = __import__("weakref").WeakKeyDictionary()        # model -> {key: _Plan}
+_SIG_TENSORS = __import__("weakref").WeakKeyDictionary()  # model -> [parameters and buffers]
+
+
+def _model_sig(model):
+    ts = _SIG_TENSORS.get(model)
+    if ts is None:
+        ts = _SIG_TENSORS[model] = list(model.parameters()) + list(model.buffers())
+    return tuple((t.data_ptr(), t._version) for t in ts)
+
+
+def replay_eval(model, x, eager):
+    """model(x) in eval mode through the launch tape where that applies, else `eager(x)`.  eager: the eval forward as a function of
+    the input tensor (PointNetVlad.forward's lpdnet branch)."""
+    if (not REPLAY or _TLS.DEBUG_AUX is not None or ops._TLS.PROFILE is not None or ops._TLS.TAPE is not None
+            or not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4
+            or x.shape[0] * x.shape[2] > REPLAY_MAX_POINTS or torch.cuda.is_current_stream_capturing()
+            or getattr(model, "_is_replica", False) or x.shape[1] != 1 or x.shape[3] != 3
+            or getattr(model.emb_nn, "t3d", True) or getattr(model.emb_nn, "tfea", True) or getattr(model.emb_nn, "use_mFea", True)):
+        return eager(x)      # (T-Net / 8-column variants run torch ops between their launches that a tape would not hold)
+    stream = torch.cuda.current_stream(x.device)
+    key = (tuple(x.shape), x.device.index, stream.cuda_stream)
+    sig = (_model_sig(model), _morton_order(), SIDE_STREAM, getattr(_SIDE_FORCE, "mode", None), ops.GEMM_BF16X3, ops._EXACT.depth, ops._FAST.depth,
+           tuple(int(getattr(m, "k", 0)) for m in (model.emb_nn,) if m is not None))
+    plans = _PLANS.get(model)
+    if plans is None:
+        plans = _PLANS[model] = {}
+    ent = plans.get(key)
+    if ent is not None and ent.sig == sig:
+        if ent.actions is not None:
+            return _replay(ent, x)
+        return _record(ent, x, eager)        # second sighting of this state: worth a tape
+    if len(plans) >= REPLAY_MAX_PLANS:
+        plans.pop(next(iter(plans)))
+    ent = _Plan()
+    ent.sig, ent.actions, ent.keep, ent.x_in, ent.out, ent.hits = sig, None, None, None, None, 0
+    plans[key] = ent
+    return eager(x)
+
+
+def _record(ent, x, eager):
+    x_in = x.detach().clone().contiguous()      # the plan's own input buffer: replays copy into it
+    tape = ops.Tape()
+    ops._TLS.TAPE = tape
+    try:
+        out = eager(x_in)
+    finally:
+        ops._TLS.TAPE = None
+    ent.x_in, ent.out, ent.actions, ent.keep = x_in, out, tape.actions, tape.keep
+    return out.clone()
+
+
+def _replay(ent, x):
+    ent.x_in.copy_(x)
+    CALL, ZERO = ops.Tape.CALL, ops.Tape.ZERO
+    for a in ent.actions:
+        kind = a[0]
+        if kind == CALL:
+            rc = a[1](*a[2])
+            if rc != 0:
+                ent.actions = None
+                ops._lib.check(rc, a[1].__name__)
+        elif kind == ZERO:
+            a[1].zero_()
+        else:
+            a[3].record(a[2])
+            a[1].wait_event(a[3])
+    ent.hits += 1
+    return ent.out.clone()
+
+
 FUSED_FRONT = __import__("os").environ.get("LPD_FUSED_FRONT", "1") != "0"   # conv1 + conv2 + kNN operands in one launch (no T-Nets)
 _SIDE = {}
 _SIDE_LOCK = __import__("threading").Lock()      # nn.DataParallel calls forward from one host thread per device
@@ -331,7 +436,7 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side, assign=None):
         # The static graph in Cartesian space depends on the input alone: its kNN (wave-slot-bound, two waves per SIMD) runs
         # on a second HIP stream next to the per-point layers and the feature-space kNN and is joined in front of the SN1 K-agg.
         main, side = torch.cuda.current_stream(), _side_stream(x.device)
-        side.wait_stream(main)
+        _join(side, main)
         with torch.cuda.stream(side):
             idx_x = _knn_rows(xyz, B, N, 3, k)
             i16_x = ops.pack_idx16(idx_x)
@@ -363,7 +468,7 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side, assign=None):
     if side_job is not None:
         # the DG1 projection needs F0 only: it follows the xyz kNN on the second stream, under the feature-space kNN
         main, side = torch.cuda.current_stream(), side_job[0]
-        side.wait_stream(main)
+        _join(side, main)
         f.record_stream(side)
         with torch.cuda.stream(side):
             pq = ops.linear(f, wdg1)                                                      # [M,256] = [P | Q]
@@ -394,9 +499,9 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side, assign=None):
             # the DG1-stage K-agg (HBM-bound) runs on the second stream next to the fused edge MLP (MFMA / VALU-bound); both
             # read pq and the feature-space graph and write different panels of `cat`
             main, side = torch.cuda.current_stream(), side_job[0]
-            main.wait_stream(side)                       # pq (and the xyz graph) are ready
+            _join(main, side)                            # pq (and the xyz graph) are ready
             pq.record_stream(main)
-            side.wait_stream(main)                       # ... and so are idx_f / cat for the second stream
+            _join(side, main)                            # ... and so are idx_f / cat for the second stream
             for t in (idx_f, cat):
                 t.record_stream(side)
             with torch.cuda.stream(side):
@@ -411,7 +516,7 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side, assign=None):
         if side_job is not None:
             side, idx_x, i16_x = side_job
             main = torch.cuda.current_stream()
-            main.wait_stream(side)
+            _join(main, side)
             idx_x.record_stream(main)
             i16_x.record_stream(main)
         else:
@@ -431,7 +536,7 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side, assign=None):
             feat = ops.gemm(cat, _w2d(net.conv3_lpd), b_kmajor=False, a_panels=True, scale=sc, shift=bc, act=act, slope=slope)
         return feat, B, N, parts
     if side_job is not None:
-        torch.cuda.current_stream().wait_stream(side_job[0])
+        _join(torch.cuda.current_stream(), side_job[0])
         pq.record_stream(torch.cuda.current_stream())
     cat = torch.empty((M, 512), dtype=torch.float32, device=x.device)                   # [x1 | x2 | x3]
     kagg(pq[:, :128], pq[:, 128:], idx_f, N, scale=s1, shift=b1, act=act, slope=slope, out=cat[:, 0:128])
@@ -440,7 +545,7 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side, assign=None):
     # static graph in Cartesian space (raw xyz even when t3d, lpdnet_model.py:226,255)
     if side_job is not None:
         side, idx_x, _ = side_job
-        torch.cuda.current_stream().wait_stream(side)
+        _join(torch.cuda.current_stream(), side)
         idx_x.record_stream(torch.cuda.current_stream())
     else:
         idx_x = _knn_rows(x.view(B * N, 3), B, N, 3, k)

@@ -19,6 +19,18 @@ class _PerThread(__import__("threading").local):
     PROFILE = None
     PROFILE_ONLY = None   # tuple of label prefixes: only those calls get events (90 event pairs per eval step cost 1.6 ms of host
                           # time -- more than the GPU needs for the step -- so a timed region brackets only what it reports)
+    # Launch tape (engine.replay_eval): while a Tape is open on this thread every C-ABI call is also appended to it with its marshalled
+    # arguments, every tensor whose address goes into a call is kept alive by it, and the zero-fills / stream joins that torch issues
+    # between the calls are noted -- enough to re-issue the whole forward later without running any of the Python around the calls.
+    TAPE = None
+
+
+class Tape:
+    CALL, ZERO, JOIN = 0, 1, 2
+
+    def __init__(self):
+        self.actions = []      # (CALL, fn, args) | (ZERO, tensor) | (JOIN, waiting stream, signalling stream, event)
+        self.keep = []         # every tensor a recorded call points into
 
 
 _TLS = _PerThread()
@@ -33,6 +45,8 @@ __import__("sys").modules[__name__].__class__ = _OpsModule
 
 
 def _call(label, fn, *args):
+    if _TLS.TAPE is not None:
+        _TLS.TAPE.actions.append((Tape.CALL, fn, args))
     prof, only = _TLS.PROFILE, _TLS.PROFILE_ONLY
     if prof is None or (only is not None and not label.startswith(only)):
         rc = fn(*args)
@@ -52,7 +66,20 @@ def _call(label, fn, *args):
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    if t is None:
+        return None
+    if _TLS.TAPE is not None:
+        _TLS.TAPE.keep.append(t)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _zeros(shape, dtype, device):
+    """torch.zeros for a workspace a kernel ACCUMULATES into: a launch of torch's, not ours -- noted on an open tape so that a replay
+    re-zeroes the buffer."""
+    t = torch.zeros(shape, dtype=dtype, device=device)
+    if _TLS.TAPE is not None:
+        _TLS.TAPE.actions.append((Tape.ZERO, t))
+    return t
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -918,7 +945,7 @@ def softmax_affine(x, scale=None, shift=None, out=None, colsum_rows=None):
         return out
     if colsum_rows % 16 or rows % colsum_rows:
         raise ValueError("softmax_affine: colsum_rows must be a multiple of 16 that divides the row count")
-    ws = torch.zeros((rows // colsum_rows, 2 * n), dtype=torch.float32, device=x.device)
+    ws = _zeros((rows // colsum_rows, 2 * n), torch.float32, x.device)
     _call("softmax_affine", lib.lpd_softmax_affine, _ptr(x), _ptr(out), rows, n, _ptr(scale), _ptr(shift), colsum_rows, _ptr(ws), 2 * n,
           _stream())
     return out, ws
@@ -935,7 +962,7 @@ def softmax_affine_parts(parts, scale=None, shift=None, colsum_rows=None):
         raise ValueError("softmax_affine_parts: colsum_rows must be a multiple of 64 that divides the row count")
     out = torch.empty((rows, n), dtype=torch.float32, device=parts.device)
     scale, shift = _vec(scale, "scale", n), _vec(shift, "shift", n)
-    ws = torch.zeros((rows // colsum_rows, 2 * n), dtype=torch.float32, device=parts.device)
+    ws = _zeros((rows // colsum_rows, 2 * n), torch.float32, parts.device)
     lib = _lib.load()
     _call("softmax_affine", lib.lpd_softmax_affine_parts, _ptr(parts), P, parts.stride(0), _ptr(out), rows, _ptr(scale), _ptr(shift),
           colsum_rows, _ptr(ws), 2 * n, _stream())
@@ -1196,7 +1223,8 @@ def _bn_finalize(sums, R, C, bn):
             pend.append(bn.num_batches_tracked)      # one launch for all layers of the step (deferred_batch_counts)
         else:
             bn.num_batches_tracked += 1
-        bn.__dict__.pop("_lpd_cache", None)      # the folded eval-mode affine (engine.bn_affine) is stale now
+        from . import engine
+        engine._CACHES.pop(bn, None)             # the folded eval-mode affine (engine.bn_affine) is stale now
     return BNStats(out[0], out[1], out[2], out[3], R)
 
 

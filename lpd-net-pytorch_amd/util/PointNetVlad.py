@@ -207,6 +207,12 @@ class PointNetVlad(nn.Module):
         self.net_vlad = NetVLADLoupe(feature_size=emb_dims, max_samples=num_points, cluster_size=64,
                                      output_dim=output_dim, gating=True, add_batch_norm=True, is_training=True)
 
+    def _eval_lpdnet(self, x):
+        feat, B, N, parts = engine.lpdnet_features_eval(self.emb_nn, x, assign=self.net_vlad)
+        if engine.DEBUG_AUX is not None:
+            engine.DEBUG_AUX["feat"] = feat
+        return engine.netvlad_eval(self.net_vlad, feat, B, N, logit_parts=parts)
+
     def forward(self, x):
         trunk = self.emb_nn if self.emb_nn is not None else self.point_net
         # the eval fast paths below need EVERY part in eval mode: after model.eval(); model.net_vlad.train() (or emb_nn.train()) each
@@ -220,11 +226,9 @@ class PointNetVlad(nn.Module):
             per = max(1, engine.EVAL_CHUNK * 4096 // x.shape[2])
             return torch.cat([self.forward(x[i:i + per]) for i in range(0, x.shape[0], per)], dim=0)
         if all_eval and isinstance(trunk, LPDNet):
-            # eval: conv3 and the NetVLAD assignment product share a launch where that is built (engine.lpdnet_features_eval)
-            feat, B, N, parts = engine.lpdnet_features_eval(trunk, x, assign=self.net_vlad)
-            if engine.DEBUG_AUX is not None:
-                engine.DEBUG_AUX["feat"] = feat
-            return engine.netvlad_eval(self.net_vlad, feat, B, N, logit_parts=parts)
+            # eval: conv3 and the NetVLAD assignment product share a launch where that is built (engine.lpdnet_features_eval); small
+            # batches, whose forward is host-bound, re-issue a recorded launch list from their third call on (engine.replay_eval)
+            return engine.replay_eval(self, x, self._eval_lpdnet)
         if isinstance(trunk, LPDNet) and trunk.training and self.net_vlad.training and self.net_vlad.cluster_size == 64:
             # train mode: bn3 + activation of the trunk's last layer are applied inside the head's assignment product (one pass over the
             # [B N, 1024] map less); `feat` is the raw conv3 output when `pending` is set

@@ -519,7 +519,7 @@ def test_second_backward_raises_a_clear_error(cuda):
         loss.backward()
 
 
-@pytest.mark.parametrize("env", [{"LPD_GEMM_FP32": "1"}, {"LPD_SIDE_STREAM": "0"}, {"LPD_SIDE_STREAM": "1"}, {"LPD_P8": "0"},
+@pytest.mark.parametrize("env", [{"LPD_GEMM_FP32": "1"}, {"LPD_SIDE_STREAM": "0"}, {"LPD_SIDE_STREAM": "1"}, {"LPD_P8": "0"}, {"LPD_REPLAY": "0"}, {"LPD_KNN_SPLIT": "0"},
                                  {"LPD_PANELS": "0"}, {"LPD_FUSED_FRONT": "0"}, {"LPD_KNN_PRE": "0"}, {"LPD_X3T_ROWS": "0"},
                                  {"LPD_FUSE_ASSIGN": "0"}, {"LPD_KAGG_PERSIST": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
@@ -615,6 +615,57 @@ def test_eval_cfg5_at_its_stated_batch_vs_c_oracle(cuda):
     pick = torch.tensor([0, 9, 18, 27, 36, 45, 54, 63])
     want, _ = orc.forward_lpdnet_c(sd, x[pick], k=k, threads=_host_threads(len(pick)))
     assert _norm_rel(got[pick], torch.from_numpy(want)) < DESC_TOL
+
+
+@pytest.mark.parametrize("B", [1, 3, 8])
+def test_small_batch_eval_replays_its_launch_tape(cuda, B):
+    """Small-batch eval forwards are host-bound, so from the third call of a (model state, shape, stream) on PointNetVlad.forward
+    re-issues a recorded list of C-ABI calls (engine.replay_eval).  Same launches, arguments and streams: every replay must equal
+    the eager forward of the same input to 2e-6 (two eager forwards differ by ~1e-6 themselves: float atomics in the NetVLAD column
+    sums) -- on fresh inputs each time, so that a workspace that is accumulated into and not re-zeroed, a missed stream join or a
+    stale pointer shows (any of them is an O(1) error) -- a weight update must invalidate the tape, and hooks bypass it."""
+    from lpdnet_hip import engine
+    N = 4096
+    m, sd = _model("lpdnet", N, cuda)
+    xs = [torch.from_numpy(synth.cloud(300 + i, B, N)).unsqueeze(1).to(cuda) for i in range(6)]
+    prev, engine.REPLAY = engine.REPLAY, False
+    try:
+        with torch.no_grad():
+            want = [m(x).clone() for x in xs]
+    finally:
+        engine.REPLAY = prev
+    assert engine.REPLAY
+    with torch.no_grad():
+        got = [m(x).clone() for x in xs]                   # eager, recorded, then four replays
+    plan = next(iter(engine._PLANS[m].values()))
+    assert plan.actions is not None and plan.hits == 4
+    import copy
+    import io
+    m2 = copy.deepcopy(m)                                  # plans and derived-tensor caches (ctypes pointers, HIP events, device buffers) live
+    assert m2 not in engine._PLANS                         # outside the module: deepcopy / torch.save of a model that has run must work
+    assert not any(k.startswith("_lpd") for mod in m.modules() for k in mod.__dict__)
+    torch.save(m, io.BytesIO())
+    with torch.no_grad():
+        assert _norm_rel(m2(xs[1]), want[1]) < 2e-6
+    for g_, w_ in zip(got, want):
+        assert _norm_rel(g_, w_) < 2e-6
+    # outputs of different replays do not alias
+    assert got[4].data_ptr() != got[5].data_ptr()
+    # a weight update invalidates the tape: the next forwards are eager / re-recorded and follow the new weights
+    with torch.no_grad():
+        m.net_vlad.hidden1_weights.mul_(1.01)
+        a = m(xs[0]).clone()
+        b = m(xs[0]).clone()
+        c = m(xs[0]).clone()
+    assert _norm_rel(a, want[0]) > 1e-4 and _norm_rel(b, a) < 2e-6 and _norm_rel(c, a) < 2e-6
+    # hooks bypass the tape
+    engine.DEBUG_AUX = {}
+    try:
+        with torch.no_grad():
+            d = m(xs[0])
+        assert "idx_feat" in engine.DEBUG_AUX and _norm_rel(d, a) < 2e-6
+    finally:
+        engine.DEBUG_AUX = None
 
 
 # ------------------------------------------------------------------ N4 on the GPU: checkpoint round trip of a TRAINED model
