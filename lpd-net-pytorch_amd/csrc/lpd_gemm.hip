@@ -965,6 +965,92 @@ __global__ __launch_bounds__(256 * RG) void linear_smallm_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: the same product as a weight STREAM for M <= 4 rows and a deep reduction (the NetVLAD hidden projection [B, 65536] x
+// [65536, 256]: 67 MB of weights, the whole cost).  linear_smallm_kernel gives every thread one weight COLUMN -- 4-byte loads, 256
+// bytes per wave-instruction, 2.3 TB/s (29 us at 32 rows; 33 us at ONE row, where the forward's critical path has nothing else to
+// hide it behind; at 32 rows the column form stays: see the dispatch).  Here a wave reads whole 1-KiB weight ROWS, 16 bytes per lane (lane l: columns 4 l .. 4 l + 3), FR_DEPTH of them in
+// flight; the four waves of a block take the k-rows of the block's slice in turn, every lane keeps MT rows x 4 columns of partial
+// sums, the X slice sits in LDS as [k][MT] (one broadcast read per four rows), and the waves' partial sums are added through LDS
+// before ONE slab per block is written (K / FR_KPER slabs instead of K / 128).  fp32 FMA chains; the slab reduce is the existing one.
+// ---------------------------------------------------------------------------------------------
+constexpr int FR_KPER = 256;     // k-rows per block (K = 65536: 256 blocks, one per CU; 128: 26.5 us against 23.4 at one row)
+constexpr int FR_DEPTH = 8;      // weight rows in flight per wave (8 KiB)
+
+template <int MT>
+__global__ __launch_bounds__(256) void linear_fewrows_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
+                                                              float* __restrict__ slabs, int M, int N, int K)
+{
+    extern __shared__ __attribute__((aligned(16))) float fr_lds[];      // [FR_KPER][MT] X slice, then the reduction buffer
+    float* xs = fr_lds;
+    float* red = fr_lds + FR_KPER * MT;                                   // [2][MT][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k0 = blockIdx.x * FR_KPER;
+    const int kn = min(FR_KPER, K - k0);                                  // k-rows of this block
+    for (int i = tid; i < FR_KPER * MT; i += 256) {
+        const int k = i / MT, m = i - k * MT;
+        xs[i] = (m < M && k < kn) ? X[(long long)m * ldx + k0 + k] : 0.0f;
+    }
+    __syncthreads();
+    const int n0 = blockIdx.y * 256 + lane * 4;
+    const float* wp = W + n0;
+    float4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto wrow = [&](int k) { return *reinterpret_cast<const float4*>(wp + (long long)(k0 + min(k, kn - 1)) * ldw); };   // past the slice: re-read (X is zero there)
+    float4 wn[FR_DEPTH];
+#pragma unroll
+    for (int d = 0; d < FR_DEPTH; ++d) wn[d] = wrow(wave + 4 * d);
+    for (int kk = wave; kk < kn; kk += 4 * FR_DEPTH) {
+        float4 wc[FR_DEPTH];
+#pragma unroll
+        for (int d = 0; d < FR_DEPTH; ++d) wc[d] = wn[d];
+#pragma unroll
+        for (int d = 0; d < FR_DEPTH; ++d) wn[d] = wrow(kk + 4 * (FR_DEPTH + d));
+#pragma unroll
+        for (int d = 0; d < FR_DEPTH; ++d) {
+            const int k = min(kk + 4 * d, FR_KPER - 1);                   // rows past kn meet zeros of X
+            const float* xr = xs + k * MT;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float x = xr[m];
+                acc[m].x = fmaf(x, wc[d].x, acc[m].x); acc[m].y = fmaf(x, wc[d].y, acc[m].y);
+                acc[m].z = fmaf(x, wc[d].z, acc[m].z); acc[m].w = fmaf(x, wc[d].w, acc[m].w);
+            }
+        }
+    }
+    // waves 2, 3 -> LDS, waves 0, 1 add; wave 1 -> LDS, wave 0 adds and stores the block's slab
+    __syncthreads();                                                      // (xs is dead: red may alias nothing of it, but keep the phases apart)
+    if (wave >= 2) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) *reinterpret_cast<float4*>(red + ((wave - 2) * MT + m) * 256 + lane * 4) = acc[m];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float4 o = *reinterpret_cast<const float4*>(red + (wave * MT + m) * 256 + lane * 4);
+            acc[m].x += o.x; acc[m].y += o.y; acc[m].z += o.z; acc[m].w += o.w;
+        }
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) *reinterpret_cast<float4*>(red + m * 256 + lane * 4) = acc[m];
+    }
+    __syncthreads();
+    if (wave == 0 && n0 < N) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m < M) {
+                const float4 o = *reinterpret_cast<const float4*>(red + m * 256 + lane * 4);
+                *reinterpret_cast<float4*>(slabs + ((long long)blockIdx.x * M + m) * N + n0) =
+                    make_float4(acc[m].x + o.x, acc[m].y + o.y, acc[m].z + o.z, acc[m].w + o.w);
+            }
+        }
+    }
+}
+
 // sums split-K slabs and applies the epilogue.  one thread per output element.
 __global__ void gemm_splitk_reduce_kernel(const float* slabs, float* C, int M, int N,   // (C may be the slabs: staged reduction)
                                           int ldc, int splits, long long slab_stride, long long sWs_batch,
@@ -1107,6 +1193,31 @@ static int gemm_entry(int mode /* 0 f32-input MFMA, 3 split-bf16, 1 plain bf16 *
     }
     const int tn = N > 64 ? 2 : 1;
     int rc;
+    static const bool fewrows_on = !(getenv("LPD_FEWROWS") && atoi(getenv("LPD_FEWROWS")) == 0);
+    // (measured, the hidden projection on one stream: 1 row 32.8 -> 23.4 us, 4 rows 36.5 -> 30 us, 8 rows no gain; 32 rows 42.4 -> 61.4 us
+    //  -- 128 partial sums per lane make the wide form FMA- and register-bound -- so the stream form serves up to FR_MAXM rows)
+    constexpr int FR_MAXM = 4;
+    if (fewrows_on && splits > 1 && !x3 && !a_kmajor && b_kmajor && batch == 1 && M <= FR_MAXM && N % 256 == 0 && K >= 8192 && ldb % 4 == 0 &&
+        (((uintptr_t)B | (uintptr_t)splitk_ws) & 15) == 0 && (long long)((K + FR_KPER - 1) / FR_KPER) <= (long long)splits) {
+        // weight-stream form (linear_fewrows_kernel): K / FR_KPER slabs of the caller's `splits` are used
+        const int nsl = (K + FR_KPER - 1) / FR_KPER;
+        const dim3 grid(nsl, N / 256);
+#define LPD_FEWROWS(MT_)                                                                                                          \
+        do {                                                                                                                      \
+            const size_t lds = (size_t)(FR_KPER * MT_ + 2 * MT_ * 256) * sizeof(float);                                           \
+            auto kern = linear_fewrows_kernel<MT_>;                                                                              \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, A, lda, B, ldb, splitk_ws, M, N, K);                           \
+        } while (0)
+        if (M <= 1) LPD_FEWROWS(1);
+        else if (M <= 2) LPD_FEWROWS(2);
+        else LPD_FEWROWS(4);
+#undef LPD_FEWROWS
+        LPD_CHECK_LAUNCH("lpd_gemm(few rows, weight stream)");
+        splits = nsl;
+        g.sCsplit = (long long)M * N;
+        rc = LPD_OK;
+    } else
     if (splits > 1 && !x3 && !a_kmajor && b_kmajor && batch == 1 && M <= 64 && g.K == SMALLM_KC) {
         const int rgs = (M + 15) / 16;
         const size_t lds = (size_t)rgs * 16 * SMALLM_KC * sizeof(float);
