@@ -7,8 +7,8 @@
 // points live in a few nearby rows and the gathers of the kNN-aggregation kernels
 // (lpd_edge.hip) are served by L1/L2 instead of the Infinity Cache.
 //
-// One 1024-thread block per cloud: bounding box -> 10 bits per axis -> 30-bit key -> bitonic sort of
-// (key, index) in registers / lane shuffles / LDS -> permuted copy of the cloud.  N <= 16384 (128 KiB of LDS).
+// One 1024-thread block per cloud: bounding box -> 10 bits per axis -> 30-bit Morton code -> bitonic sort of 32-bit words
+// (top bits of the code | index) in registers / lane shuffles / LDS -> permuted copy of the cloud.  N <= 16384 (64 KiB of LDS).
 #include "lpd_common.h"
 #include <math.h>
 
@@ -26,29 +26,33 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v)
 
 // One compare-exchange partner step of the bitonic network for an element held by this thread: `o` is the partner's
 // value, `lower` says whether this element has the smaller index of the pair, `up` the direction of the pair's block.
-__device__ __forceinline__ uint64_t bitonic_keep(uint64_t v, uint64_t o, bool lower, bool up)
+__device__ __forceinline__ uint32_t bitonic_keep(uint32_t v, uint32_t o, bool lower, bool up)
 {
-    const uint64_t mn = v < o ? v : o, mx = v < o ? o : v;
+    const uint32_t mn = v < o ? v : o, mx = v < o ? o : v;
     return (lower == up) ? mn : mx;
 }
 
 // E elements per thread (NP = 1024 E keys): thread t owns the E consecutive positions E t .. E t + E - 1 of the network.
-// Keys are (morton << 32 | index): one 64-bit compare orders by (key, index), so equal keys keep a deterministic order.
-// Strides below E exchange inside the thread's registers, strides below 64 E between lanes (two 32-bit shuffles), only
-// the strides that cross waves (10 of the 78 steps at N = 4096) go through LDS -- the first version ran every step
-// through LDS with a block barrier and half of the threads idle (84 us at B = 32, on 32 of the 256 CUs).
-template <int E>
-__global__ __launch_bounds__(1024) void morton_sort_kernel(const float* __restrict__ xyz, float* __restrict__ out,
-                                                            int32_t* __restrict__ perm, int N)
+// Sort words are 32 bits (round 5): the top 32 - IB bits of the 30-bit Morton code above the IB = log2(NP) index bits -- one
+// shuffle, one compare and one select per exchange instead of two / a 64-bit pair (the kernel is instruction-bound on the ONE CU a
+// cloud's block runs on: 33 us at N = 4096 whatever the batch, at the head of every forward).  20 code bits at N = 4096 are a
+// 128 x 128 x 64 grid over the bounding box, ~0.004 points per cell: a prefix of the same Z-curve; points that share a cell keep their
+// input order (the index breaks the tie), so the order is deterministic.  Strides below E exchange inside the thread's registers,
+// strides below 64 E between lanes, only the strides that cross waves (10 of the 78 steps at N = 4096) go through LDS.
+template <int E, int T = 1024>
+__global__ __launch_bounds__(T) void morton_sort_kernel(const float* __restrict__ xyz, float* __restrict__ out,
+                                                         int32_t* __restrict__ perm, int N)
 {
-    constexpr int NP = 1024 * E;
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];   // [E][1024]
+    constexpr int NP = T * E;
+    constexpr int IB = NP == 1024 ? 10 : NP == 2048 ? 11 : NP == 4096 ? 12 : NP == 8192 ? 13 : 14;      // index bits
+    static_assert(NP >= 1024 && NP <= 16384 && (NP & (NP - 1)) == 0, "1024 .. 16384 keys");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [E][T]
     __shared__ float red[6][16];
     __shared__ float box[6];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* p = xyz + (size_t)b * N * 3;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < N; i += 1024)
+    for (int i = tid; i < N; i += T)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float v = p[i * 3 + c];
@@ -67,16 +71,16 @@ __global__ __launch_bounds__(1024) void morton_sort_kernel(const float* __restri
     __syncthreads();
     if (tid < 3) {
         float a = red[tid][0], z = red[3 + tid][0];
-        for (int w = 1; w < 16; ++w) { a = fminf(a, red[tid][w]); z = fmaxf(z, red[3 + tid][w]); }
+        for (int w = 1; w < T / 64; ++w) { a = fminf(a, red[tid][w]); z = fmaxf(z, red[3 + tid][w]); }
         box[tid] = a;
         box[3 + tid] = z > a ? 1023.0f / (z - a) : 0.0f;
     }
     __syncthreads();
-    uint64_t v[E];
+    uint32_t v[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = tid * E + e;
-        uint32_t key = 0xffffffffu;
+        uint32_t word = 0xffffffffu;                         // padding sorts to the end
         if (i < N) {
             uint32_t q[3];
 #pragma unroll
@@ -85,9 +89,10 @@ __global__ __launch_bounds__(1024) void morton_sort_kernel(const float* __restri
                 t = fminf(fmaxf(t, 0.0f), 1023.0f);
                 q[c] = (uint32_t)t;
             }
-            key = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+            const uint32_t key = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);      // 30 bits
+            word = ((key >> (IB - 2)) << IB) | (uint32_t)i;                                          // its top 32 - IB bits | index
         }
-        v[e] = ((uint64_t)key << 32) | (uint32_t)i;
+        v[e] = word;
     }
     // bitonic sort, ascending
 #pragma unroll
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(1024) void morton_sort_kernel(const float* __restri
                 for (int e = 0; e < E; ++e)
                     if ((e & j) == 0) {
                         const bool up = ((tid * E + e) & k) == 0;
-                        const uint64_t a = v[e], c = v[e | j];
+                        const uint32_t a = v[e], c = v[e | j];
                         const bool sw = (a > c) == up;
                         v[e] = sw ? c : a;
                         v[e | j] = sw ? a : c;
@@ -108,19 +113,17 @@ __global__ __launch_bounds__(1024) void morton_sort_kernel(const float* __restri
                 const int lj = j / E;
                 const bool lower = (tid & lj) == 0;
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const uint32_t lo = __shfl_xor((uint32_t)v[e], lj, 64), hi = __shfl_xor((uint32_t)(v[e] >> 32), lj, 64);
-                    v[e] = bitonic_keep(v[e], ((uint64_t)hi << 32) | lo, lower, ((tid * E + e) & k) == 0);
-                }
+                for (int e = 0; e < E; ++e)
+                    v[e] = bitonic_keep(v[e], __shfl_xor(v[e], lj, 64), lower, ((tid * E + e) & k) == 0);
             } else {                                         // partner in another wave: through LDS
                 const int tj = j / E;
                 const bool lower = (tid & tj) == 0;
 #pragma unroll
-                for (int e = 0; e < E; ++e) lds[e * 1024 + tid] = v[e];
+                for (int e = 0; e < E; ++e) lds[e * T + tid] = v[e];
                 __syncthreads();
 #pragma unroll
                 for (int e = 0; e < E; ++e)
-                    v[e] = bitonic_keep(v[e], lds[e * 1024 + (tid ^ tj)], lower, ((tid * E + e) & k) == 0);
+                    v[e] = bitonic_keep(v[e], lds[e * T + (tid ^ tj)], lower, ((tid * E + e) & k) == 0);
                 __syncthreads();
             }
         }
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(1024) void morton_sort_kernel(const float* __restri
     for (int e = 0; e < E; ++e) {
         const int r = tid * E + e;
         if (r < N) {
-            const uint32_t src = (uint32_t)v[e];
+            const uint32_t src = v[e] & ((1u << IB) - 1u);
             o[r * 3 + 0] = p[src * 3 + 0];
             o[r * 3 + 1] = p[src * 3 + 1];
             o[r * 3 + 2] = p[src * 3 + 2];
@@ -139,13 +142,13 @@ __global__ __launch_bounds__(1024) void morton_sort_kernel(const float* __restri
     }
 }
 
-template <int E>
+template <int E, int T = 1024>
 void morton_launch(const float* xyz, float* out, int32_t* perm, int B, int N, hipStream_t stream)
 {
-    const size_t lds = (size_t)E * 1024 * sizeof(uint64_t);
-    auto kern = morton_sort_kernel<E>;
+    const size_t lds = (size_t)E * T * sizeof(uint32_t);
+    auto kern = morton_sort_kernel<E, T>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds, stream, xyz, out, perm, N);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(T), lds, stream, xyz, out, perm, N);
 }
 
 }  // namespace
@@ -161,7 +164,7 @@ extern "C" int lpd_morton_sort(const float* xyz, float* out, int32_t* perm, int 
     }
     if (N <= 1024) morton_launch<1>(xyz, out, perm, B, N, stream);
     else if (N <= 2048) morton_launch<2>(xyz, out, perm, B, N, stream);
-    else if (N <= 4096) morton_launch<4>(xyz, out, perm, B, N, stream);
+    else if (N <= 4096) morton_launch<4>(xyz, out, perm, B, N, stream);      // (8 keys x 512 threads: 24 us against 23; 16 x 256: 34)
     else if (N <= 8192) morton_launch<8>(xyz, out, perm, B, N, stream);
     else morton_launch<16>(xyz, out, perm, B, N, stream);
     LPD_CHECK_LAUNCH("lpd_morton_sort");

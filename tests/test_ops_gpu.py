@@ -172,7 +172,8 @@ def test_morton_sort_is_a_permutation_and_improves_locality(cuda):
 
 
 def _morton_order_np(pts):
-    """numpy restatement of lpd_morton.hip: fp32 bounding box, 10 bits per axis, stable order by (key, index)."""
+    """numpy restatement of lpd_morton.hip: fp32 bounding box, 10 bits per axis, stable order by (top bits of the 30-bit code, index):
+    the sort word holds 32 - log2(1024 E) code bits, E = keys per thread of the instantiation that serves N."""
     mn, mx = pts.min(0), pts.max(0)
     with np.errstate(divide="ignore"):
         scale = np.where(mx > mn, np.float32(1023.0) / (mx - mn).astype(np.float32), np.float32(0)).astype(np.float32)
@@ -185,7 +186,9 @@ def _morton_order_np(pts):
         v = (v | (v << 4)) & 0x030c30c3
         return (v | (v << 2)) & 0x09249249
     key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
-    return np.argsort(key, kind="stable")
+    n = pts.shape[0]
+    ib = 10 if n <= 1024 else 11 if n <= 2048 else 12 if n <= 4096 else 13 if n <= 8192 else 14
+    return np.argsort(key >> (ib - 2), kind="stable")
 
 
 @pytest.mark.parametrize("N", [1, 37, 1000, 1024, 1500, 4096, 5000, 16384])
