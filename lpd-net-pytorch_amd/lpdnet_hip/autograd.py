@@ -468,6 +468,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         cat16 = (torch.empty((M, 512), dtype=torch.bfloat16, device=x.device)
                  if (map16 and post1 and CAT_BF16 and Co3 % 256 == 0 and M % 32 == 0) else None)
         c16 = (lambda a, b: cat16[:, a:b]) if cat16 is not None else (lambda a, b: None)
+        post1c = None
         if post1:
             # ONE launch for the stage (lpd_edge_mlp_train): the raw edge tensor U1 is never written.  Its BatchNorm statistics, and
             # x1 = max_k act(BN(U1)) with its arg-max, come from the split-form gather pass (closed-form sums; the activation is monotone,
@@ -484,6 +485,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
                                                           net.convDG2[1], act, slope, bf16, z_bf16=z16, store_z=not noz)
             ops.affine_act(zsel, stg2.scale, stg2.shift, act, slope, out=cat[:, 128:256], out16=c16(128, 256))             # x2
             u1 = None
+            post1c = ops.post_consts(net.convDG1[1], act, slope)      # (beta1, 1 / gamma1, 1 / ns) as of THIS forward, for the backward
             del usel1
         elif bf16:
             u1, stg1 = ops.edge_build_bf16(pq1[:, :128], pq1[:, 128:], idx_f, N, bn=net.convDG1[1])   # [E,128] raw + its BN statistics
@@ -512,7 +514,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
             y3, st3, feat = _PointLayer.fwd(cat, w2d(net.conv3_lpd), net.bn3_lpd, act, slope)
             _LAST.pending = None
         ctx.net, ctx.dims, ctx.actslope, ctx.bf16 = net, (B, N, M, k), (act, slope), bf16
-        ctx.saved = dict(front=front, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1, post1=post1, pq1=pq1 if post1 else None, s1sum=s1sum,
+        ctx.saved = dict(front=front, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1, post1=post1, post1c=post1c, pq1=pq1 if post1 else None, s1sum=s1sum,
                          u1=u1, stg1=stg1, arg1=arg1, y1e=y1e, z=z, zsel=zsel, stg2=stg2, arg2=arg2, wcat3=wcat3, pq3=pq3, s3=s3, usel3=usel3,
                          stg3=stg3, arg3=arg3, cat=cat, cat16=cat16, y3=y3, st3=st3)
         if engine.DEBUG_AUX is not None:
@@ -578,7 +580,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
             redf = red2.float()
             dgs2, dbs2 = redf[1], redf[0]
             G1, gsum1, red1 = ops.edge_mlp_train_bwd(S["z"], S["arg2"], dpre2, w2, S["stg2"], red2, S["y1e"], S["arg1"], dcat[:, 0:128],
-                                                     net.convDG1[1], k, act, slope)
+                                                     S["post1c"], k, act, slope)
             pq1 = S["pq1"]
             ops.edge_dense_bwd_apply(G1, gsum1, S["s1sum"], pq1[:, :128], pq1[:, 128:], ops.GraphT(S["idx_f"], N), S["stg1"], red1, k,
                                      dP=dpq1[:, :128], dQ=dpq1[:, 128:])
@@ -603,7 +605,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
                 del dz
             # (post1: the forward kept Y1e = act(BN(U1)) instead of U1; the kernels recover the pre-activation from it)
             du1, dgs1, dbs1 = ops.edge_bn_bwd_bf16(dcat[:, 0:128], S["arg1"], k, S["y1e"] if S["post1"] else S["u1"], S["stg1"], act, slope,
-                                                   dense=dy1e, dQ=dpq1[:, 128:], post_bn=net.convDG1[1] if S["post1"] else None)
+                                                   dense=dy1e, dQ=dpq1[:, 128:], post_bn=S["post1c"] if S["post1"] else None)
             ops.gather_sum_rows_bf16(du1, ops.GraphT(S["idx_f"], N), dpq1[:, :128])
         else:
             # DG2: x2 = groupmax(act(BN(Z))), Z = Y1e W2^T
@@ -623,7 +625,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
                 del dz
             # DG1: y1e = act(BN(U1)); consumers: DG2 (dense) and x1 = groupmax (sparse)
             du1, dgs1, dbs1 = ops.edge_bn_bwd(dcat[:, 0:128], S["arg1"], k, S["y1e"] if S["post1"] else S["u1"], S["stg1"], act, slope,
-                                              dense=dy1e, dQ=dpq1[:, 128:], post_bn=net.convDG1[1] if S["post1"] else None)
+                                              dense=dy1e, dQ=dpq1[:, 128:], post_bn=S["post1c"] if S["post1"] else None)
             ops.gather_sum_rows(du1, ops.GraphT(S["idx_f"], N), dpq1[:, :128])
         del du1, dy1e
         dwcat1 = _dweight(dpq1, S["f0"])

@@ -1349,14 +1349,25 @@ def group_max_bwd(dOut, arg, k, dX=None, accumulate=False):
     return dX
 
 
-def _post_consts(st, post_bn, act, slope):
-    """X holds post-activation values (what edge_mlp_train stores): the kernels recover pre = y or y / ns and take
-    xhat = (pre - beta) / gamma -- `mean` := beta, `invstd` := 1 / gamma (0 where gamma == 0: that channel's scale is 0 too)."""
+def post_consts(post_bn, act, slope):
+    """What the backward of a stage that kept POST-activation values (edge_mlp_train's Y1e = act(gamma xhat + beta)) needs to recover
+    xhat = (pre - beta) / gamma, pre = y or y / ns: (beta, 1 / gamma, 1 / ns), SNAPSHOT at the time of the call -- autograd takes it in
+    the forward, so a parameter that changes between forward and backward cannot give an inconsistent xhat (beta is copied).
+    A channel whose gamma is exactly 0 has no recoverable xhat (its Y1e is the constant act(beta)): 1 / gamma := 0 there, i.e. that
+    channel's dgamma comes out 0 instead of sum(dpre xhat) -- the one case in which this path differs from the U1-storing chain
+    (LPD_EDGE_MLP_TRAIN=0), which a model with an exactly-zero BatchNorm scale should use."""
     if act not in (ACT_NONE, ACT_LEAKY) or (act == ACT_LEAKY and not 0.0 < slope <= 1.0):
         raise ValueError("post-activation edge tensors need an invertible activation (none / LeakyReLU with 0 < slope <= 1)")
     g = post_bn.weight.detach()
     rg = torch.where(g != 0, 1.0 / g, torch.zeros_like(g)).contiguous()
-    return post_bn.bias.detach().contiguous(), rg, (1.0 if act == ACT_NONE else 1.0 / float(slope))
+    return post_bn.bias.detach().clone().contiguous(), rg, (1.0 if act == ACT_NONE else 1.0 / float(slope))
+
+
+def _post_consts(st, post_bn, act, slope):
+    """post_bn: the BatchNorm module (constants read now) or the triple post_consts() returned at forward time"""
+    if isinstance(post_bn, tuple):
+        return post_bn
+    return post_consts(post_bn, act, slope)
 
 
 def edge_bn_bwd(dOut, arg, k, X, st, act, slope, dense=None, dQ=None, xsel=None, post_bn=None):
@@ -1658,7 +1669,7 @@ def edge_mlp_train_bwd(Z, arg2, dpre2, W2, st2, red2, Y1e, arg1, dx1, bn1, k, ac
     if C != 128 or tuple(W2.shape) != (128, 128) or not W2.is_contiguous() or M % 32 != 0:
         raise ValueError("edge_mlp_train_bwd: 128 -> 128 channels, M % 32 == 0")
     lddx1 = _rows(dx1, "dx1")
-    beta1, rgamma1, inv_ns = _post_consts(None, bn1, act, slope)
+    beta1, rgamma1, inv_ns = _post_consts(None, bn1, act, slope)      # bn1: the module, or post_consts(bn1, ...) taken at forward time
     G = torch.empty_like(Y1e)
     gsum = torch.empty((M, 128), dtype=torch.float32, device=Y1e.device)
     red1 = torch.empty((2, 128), dtype=torch.float64, device=Y1e.device)
