@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void edge_gather_max_kernel(GatherArgs g)
 // they come as uint16 (lpd_pack_idx16; 40 B instead of 80 B per point and slice) and the per-pass operands (indices,
 // centre term) rotate through three register sets, two passes of lookahead, no copies.  Straight-line body: the
 // activation is the branch-free  max(v,0) + ns * min(v,0)  with ns = 1 / 0 / slope for none / ReLU / LeakyReLU.
-// (Tried and dropped, profiles/r01d_kagg_variants.txt: Z-order windows of 256..1024 rows in LDS with the misses from
+// (Tried and dropped in round 1, HISTORY.md 3.3: Z-order windows of 256..1024 rows in LDS with the misses from
 // L2 -- 13 % misses cost more instructions than the hits save; panel-major P/Q -- no gain, the 32-B row pieces are
 // not over-fetched.)
 // ------------------------------------------------------------------------------------------

@@ -318,7 +318,7 @@ template <int KMAX>
 constexpr int knn3_wave_floats() { return KNN3_QCAP * 128 > 2 * 64 * KMAX ? KNN3_QCAP * 128 : 2 * 64 * KMAX; }
 
 // ---- packed operand layout -------------------------------------------------------------------------------
-// Ablations on MI355X (tools/knn_bench.py, impl 10..41) showed the scan is INSTRUCTION-ISSUE bound, not MFMA- or
+// Ablations on MI355X (round 1: compile-time variants behind impl 10..41, removed in round 5; HISTORY.md 3.1) showed the scan is INSTRUCTION-ISSUE bound, not MFMA- or
 // memory-bound: with channel-major operands every MFMA needed its own dword load plus ~6 scalar address
 // instructions (each channel row is N floats away), and the per-candidate exec-masked appends cost ~100 executed
 // instructions per tile even when nothing is admitted -- ~650 instructions per 32x32 tile against 32 MFMAs.

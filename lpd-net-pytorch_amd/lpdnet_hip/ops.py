@@ -423,7 +423,7 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=True, bias=None, scale=None, shift=No
     bias, scale, shift = _vec(bias, "bias", N), _vec(scale, "scale", N), _vec(shift, "shift", N)
     lib = _lib.load()
     # weight-shaped B (a layer's weights in either layout; dX = dY W of the backward pass) and a deep reduction:
-    # fragments of B prepared once, B never staged through LDS (lpd_gemm_x3w).  Measured (tools/x3w_bench.py, M = 131072):
+    # fragments of B prepared once, B never staged through LDS (lpd_gemm_x3w).  Measured (a one-off script of round 2, HISTORY.md 3.2; M = 131072):
     # conv3 512 -> 1024 660 -> 505 us, dX 1024 -> 512 433 us; at K <= 128 the generic kernel is as fast or faster
     # (SN1 projection 142 vs 149 us, DG1 projection 52 vs 58 us), and k-major weights transpose in registers there.
     # a short reduction (K = 64 / 128) over many rows: the transposed product lpd_gemm_x3t_rows (data rows as the MFMA's B operand, one
