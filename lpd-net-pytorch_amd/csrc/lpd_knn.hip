@@ -996,11 +996,49 @@ __global__ __launch_bounds__(128) void knn7_predict_kernel(const float* __restri
     if (tid == 0) pred[(size_t)b * nt + W] = part[0] + part[1];
 }
 
+// The same estimate with the cloud's centroids staged in LDS (round 5): knn7_predict_kernel reads every candidate centroid row from
+// global memory per lane -- 64 lanes on 64 different 256-byte rows per load -- and took 27 us at 32 clouds x 64 channels for 0.27 GFLOP.
+// One block = 16 query tiles of one cloud; all nt centroids in LDS (row stride 2 CP + 1 floats: the 16 lanes of a query tile read 16
+// different rows of one column conflict-free); a lane takes every 16th candidate tile, the 16 lanes of a query tile add up their
+// counts.  Same formula; built for nt (2 CP + 1) 4 <= 64 KiB (N <= 8192 at 64 channels), the global-memory form serves the rest.
+constexpr int KNN7_PRED_WPB = 16;
+template <int CP>
+__global__ __launch_bounds__(256) void knn7_predict_lds_kernel(const float* __restrict__ cenp, const float* __restrict__ rad,
+                                                               int32_t* __restrict__ pred, int nt)
+{
+    constexpr int CH = 2 * CP, LD = CH + 1;
+    extern __shared__ float pcen[];                 // [nt][LD], then rad [nt]
+    float* prad = pcen + (size_t)nt * LD;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float* cb = cenp + (size_t)b * nt * CH;
+    for (int i = tid; i < nt * CH; i += 256) pcen[(i / CH) * LD + (i % CH)] = cb[i];
+    for (int i = tid; i < nt; i += 256) prad[i] = rad[(size_t)b * nt + i];
+    __syncthreads();
+    const int W = blockIdx.x * KNN7_PRED_WPB + (tid >> 4), l = tid & 15;
+    const int Wc = min(W, nt - 1);
+    const float* cw = pcen + (size_t)Wc * LD;
+    const float rw = prad[Wc];
+    int n = 0;
+    for (int T = l; T < nt; T += 16) {
+        const float* ct = pcen + (size_t)T * LD;
+        float d2 = 0.f;
+#pragma unroll 16
+        for (int c = 0; c < CH; ++c) { const float d = ct[c] - cw[c]; d2 = fmaf(d, d, d2); }
+        const float gap = fmaxf(sqrtf(d2) - rw - prad[T], 0.0f);
+        n += gap <= 0.5f * rw ? 1 : 0;
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) n += __shfl_xor(n, m, 64);
+    if (l == 0 && W < nt) pred[(size_t)b * nt + W] = n;
+}
+
 // order[range of XCD x] = that range's item ids sorted by pred descending (ties: id ascending), chunk by chunk.
 // grid (chunks, 8), 1024 threads: one key per thread; strides below 64 by lane shuffles, the rest through LDS.
 __global__ __launch_bounds__(1024) void knn7_order_kernel(const int32_t* __restrict__ pred, int32_t* __restrict__ order, int nitems)
 {
-    __shared__ unsigned long long sk[1024];
+    // 32-bit sort words (round 5; 64-bit (pred, item) pairs before: two shuffles and a 64-bit compare per exchange, 17 us per launch):
+    // (0xffff - pred) << 16 | position inside the chunk.  pred <= tiles per cloud <= 2048, position < 1024.
+    __shared__ unsigned sk[1024];
     const int tid = threadIdx.x, xcd = blockIdx.y;
     const int q = nitems / 8, r = nitems % 8;
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -1008,29 +1046,24 @@ __global__ __launch_bounds__(1024) void knn7_order_kernel(const int32_t* __restr
     const int c0 = blockIdx.x * 1024;
     if (c0 >= len) return;
     const int cl = min(1024, len - c0);
-    unsigned long long v = ~0ull;                              // padding sorts to the end
-    if (tid < cl) {
-        const int item = base + c0 + tid;
-        v = ((unsigned long long)(0x7fffffffu - (unsigned)pred[item]) << 32) | (unsigned)item;
-    }
+    unsigned v = ~0u;                                          // padding sorts to the end
+    if (tid < cl) v = ((0xffffu - (unsigned)min(pred[base + c0 + tid], 0xfffe)) << 16) | (unsigned)tid;
     for (int k = 2; k <= 1024; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            unsigned long long o;
-            if (j < 64) {
-                const unsigned lo = __shfl_xor((unsigned)v, j, 64), hi = __shfl_xor((unsigned)(v >> 32), j, 64);
-                o = ((unsigned long long)hi << 32) | lo;
-            } else {
+            unsigned o;
+            if (j < 64) o = __shfl_xor(v, j, 64);
+            else {
                 sk[tid] = v;
                 __syncthreads();
                 o = sk[tid ^ j];
                 __syncthreads();
             }
             const bool lower = (tid & j) == 0, up = (tid & k) == 0;
-            const unsigned long long mn = v < o ? v : o, mx = v < o ? o : v;
+            const unsigned mn = v < o ? v : o, mx = v < o ? o : v;
             v = (lower == up) ? mn : mx;
         }
     }
-    if (tid < cl) order[base + c0 + tid] = (int32_t)(unsigned)v;
+    if (tid < cl) order[base + c0 + tid] = base + c0 + (int)(v & 0xffffu);
 }
 
 // In-place insertion for the best-first kernel.  The tiles are visited W, W+1, W-1, W+2, ...: the set of visited tiles
@@ -1667,7 +1700,13 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
     // (longest-first order: pointless while every workgroup of the launch is resident at once)
     const bool use_order = lpt && !(split && (long long)nitems * KNN7_SPLIT <= 1024ll * split_wps);
     if (use_order) {
-        hipLaunchKernelGGL(knn7_predict_kernel<CP>, dim3(nt, B), dim3(128), 0, stream, (const float*)cenp, (const float*)rad, pred, nt);
+        const size_t plds = ((size_t)nt * (2 * CP + 1) + nt) * sizeof(float);
+        if (plds <= 65536) {
+            auto pk = knn7_predict_lds_kernel<CP>;
+            (void)hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+            hipLaunchKernelGGL(pk, dim3((nt + KNN7_PRED_WPB - 1) / KNN7_PRED_WPB, B), dim3(256), plds, stream, (const float*)cenp, (const float*)rad, pred, nt);
+        } else
+            hipLaunchKernelGGL(knn7_predict_kernel<CP>, dim3(nt, B), dim3(128), 0, stream, (const float*)cenp, (const float*)rad, pred, nt);
         hipLaunchKernelGGL(knn7_order_kernel, dim3((nitems / 8 + 1 + 1023) / 1024, 8), dim3(1024), 0, stream, (const int32_t*)pred, order, nitems);
         LPD_CHECK_LAUNCH("lpd_knn(launch order)");
     }
