@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void lpdnet_front_kernel(FrontArgs g)
             const int m = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             float v = acc[j][r] * sc + sh;
             v = lpd_act_pl(v, g.ns);
-            g.F0[(m0 + m) * 64 + n] = v;
+            if (!g.xx) g.F0[(m0 + m) * 64 + n] = v;      // (with kNN operands the rows leave from the LDS tile below: 16-byte stores)
             Fs[m * FR_LDF + n] = v;
         }
     }
@@ -131,6 +131,8 @@ __global__ __launch_bounds__(256) void lpdnet_front_kernel(FrontArgs g)
         for (int q = 0; q < 4; ++q) {
             const float4 t = *reinterpret_cast<const float4*>(Fs + p * FR_LDF + 16 * j + 4 * q);
             v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            // the F0 row: four lanes x 64 bytes (round 5; from the accumulators it was 32 four-byte stores per lane: store-issue-bound)
+            *reinterpret_cast<float4*>(g.F0 + m * 64 + 16 * j + 4 * q) = t;
         }
         float sq = __fmul_rn(v[0], v[0]);
 #pragma unroll
