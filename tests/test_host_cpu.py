@@ -211,3 +211,28 @@ def test_fused_statistics_gates_stop_at_the_workspace_width():
     assert not ops.linear_bn_stats_fused_applies(44 * 4096, 2048, 512)
     src = open(os.path.join(ROOT, "lpd-net-pytorch_amd", "csrc", "lpd_common.h")).read()
     assert re.search(r"#define\s+LPD_STAT_CMAX\s+1024\b", src)
+
+
+def test_bench_kernel_rooflines_from_a_kernel_table():
+    """bench.py's per-kernel roofline entries (conv3, edge MLP, both kNN searches): SURVEY 8(d)'s algorithmic FLOPs over the op's event
+    time over the peak, the executed fraction (three bf16 products) beside it.  Pure arithmetic on a kernel table: checked here on CPU."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    kern = {"gemm_p8+assign[131072x1024x512]": {"launches": 5, "avg_us": 450.0}, "edge_mlpx3[128->128]": {"launches": 5, "avg_us": 270.0},
+            "knn[C=64,k=20]": {"launches": 5, "avg_us": 400.0}, "knn[C=3,k=20]": {"launches": 5, "avg_us": 200.0}}
+    r = bench.kernel_rooflines(kern, 32, 4096, 20, True)
+    conv3 = r["conv3 + NetVLAD assignment"]
+    assert conv3["algorithmic_flops_per_launch"] == 2 * 131072 * 512 * 1024 + 2 * 131072 * 1024 * 64
+    assert abs(conv3["frac"] - conv3["algorithmic_flops_per_launch"] / 450e-6 / 1e12 / 2500.0) < 1e-4
+    assert abs(conv3["executed_frac"] - 3 * conv3["frac"]) < 2e-4
+    mlp = r["edge MLP (DG1 act -> DG2 conv -> max over k)"]
+    assert mlp["algorithmic_flops_per_launch"] == 2 * 131072 * 20 * 128 * 128 and mlp["peak"] == 2500.0
+    knn = r["feature-space kNN"]
+    assert knn["algorithmic_flops_per_launch"] == 32 * (2 * 4096 * 4096 * 64 + 3 * 4096 * 4096) and knn["peak"] == 157.3
+    assert r["xyz kNN"]["algorithmic_flops_per_launch"] == 32 * (2 * 4096 * 4096 * 3 + 3 * 4096 * 4096)
+    # the K-agg numerator counts the uint16 indices the kernel reads
+    assert bench.KAGG_IDX_BYTES == 2 and bench.KAGG_ROW_BYTES == 3 * 256 * 4
+    exact = bench.kernel_rooflines(kern, 32, 4096, 20, False)
+    assert "executed_frac" not in exact["conv3 + NetVLAD assignment"] and exact["conv3 + NetVLAD assignment"]["peak"] == 157.3
