@@ -40,9 +40,12 @@ KAGG_ROW_BYTES = 3 * 256 * 4   # C=256 fp32, split form: P row + Q row + out row
 KAGG_IDX_BYTES = 2             # the K-agg kernels read uint16 indices (lpd_pack_idx16 / lpd_pack_idx16w), not the int32 of SURVEY 8d
 MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
 VALU_F32_PEAK_TF = 157.3       # fp32 vector peak (= f32-input MFMA peak): the bound of the exact-fp32 kNN distance arithmetic
+# SQ_VALU_MFMA_BUSY_CYCLES share of the kNN walk kernels, from the committed PMC table (not collected inside a bench run)
+KNN_MFMA_BUSY = {64: {"value": 0.29, "source": "profiles/r05_pmc_train_bf16_final.txt"}, 3: {"value": 0.05, "source": "profiles/r05_pmc_train_bf16_final.txt"}}
+LINE_MAX_BYTES = 4096          # the driver parses the final stdout line: it stays below this; everything else goes to bench_detail.json
 
 
-def kernel_rooflines(kern, batch, points, k, split_bf16):
+def kernel_rooflines(kern, batch, points, k, split_bf16, knn_visits=None):
     """Roofline entries of the step's DOMINANT kernels (the K-agg the headline `roofline` names is ~5 % of the step): algorithmic FLOPs of
     SURVEY.md 8(d) per launch / HIP-event time of the launch (this run's `kernels` table) / the peak of the unit that bounds it.
     `executed` = the FLOPs the matrix cores actually issue (three bf16 products per term on the split-bf16 path)."""
@@ -71,13 +74,142 @@ def kernel_rooflines(kern, batch, points, k, split_bf16):
             "SURVEY 8d K-agg DG1->DG2 fused: 2 N k 128 128 per cloud; " + how, x3)
     for C, what in ((64, "feature-space kNN"), (3, "xyz kNN")):
         key = f"knn[C={C},k={k}]"
-        add(what, key, float(batch) * (2.0 * points * points * C + 3.0 * points * points), VALU_F32_PEAK_TF, "fp32 vector / f32-input MFMA",
-            "SURVEY 8d K-knn: 2 N^2 C + 3 N^2 per cloud, exact fp32 (bit-exact indices forbid reduced precision); the entry covers every "
-            "launch of the search (bounds, launch order, best-first walk).  `frac` prices the FULL distance matrix at the fp32 peak, "
-            "i.e. it is the search's speed relative to a perfect brute-force kernel: the best-first walk proves most tiles irrelevant "
-            "without multiplying them (23 of 128 visited at C = 64), so a value above 1 is the algorithm's saving, not a wrong peak; "
-            "the walk itself is bound by its list insertions and dependent loads (DESIGN.md 4.1: MFMA pipe 0.29 busy)")
+        if key not in kern:
+            continue
+        # The search is exact fp32 (bit-exact indices forbid reduced precision), so its distance tiles are bound by the fp32 vector /
+        # f32-input MFMA peak.  `frac` prices the FLOPs the search EXECUTES: query tiles x candidate tiles actually multiplied x
+        # 32 x 32 x 2 C (the visit rate is measured on this run's own operands by the kernel's statistics variant, knn_visit_stats),
+        # over the time of ALL launches of the search (bound pass, launch order, walk) -- at most 1 by construction.  What the
+        # best-first walk saves against multiplying the full N x N matrix is a separate field, not a roofline fraction.
+        t = kern[key]["avg_us"] * 1e-6
+        full = float(batch) * (2.0 * points * points * C + 3.0 * points * points)       # SURVEY 8d K-knn
+        nt = (points + 31) // 32
+        ent = {"key": key, "bound": "fp32 vector / f32-input MFMA", "avg_launch_us": kern[key]["avg_us"], "peak": VALU_F32_PEAK_TF, "unit": "TFLOP/s",
+               "bruteforce_flops_per_launch": int(full),
+               "speedup_vs_bruteforce_at_peak": round(full / t / 1e12 / VALU_F32_PEAK_TF, 3),
+               "mfma_busy": KNN_MFMA_BUSY.get(C)}
+        v = (knn_visits or {}).get(C)
+        if v is not None:
+            v = min(float(v), float(nt))
+            execd = float(batch) * nt * v * 32 * 32 * 2 * (4 if C <= 4 else C)      # three coordinates run as two channel pairs
+            ach = execd / t / 1e12
+            ent.update({"tiles_visited_per_query_tile": round(v, 2), "tiles_per_cloud": nt, "executed_flops_per_launch": int(execd),
+                        "achieved": round(ach, 2), "frac": round(min(ach / VALU_F32_PEAK_TF, 1.0), 4)})
+        else:
+            ent.update({"achieved": None, "frac": None})
+        out[what] = ent
     return out
+
+
+def knn_visit_stats(model, x):
+    """Candidate tiles the best-first kNN walk multiplies per query tile, measured on THIS run's operands: one hooked forward hands
+    out F0, then the search's statistics variant (impl 5: per-wave counters instead of indices, tools/knn7_stats.py) runs on the
+    feature rows and on the Z-ordered coordinates.  {64: tiles, 3: tiles}; a search that has no statistics variant is left out."""
+    from lpdnet_hip import engine, ops
+    out = {}
+    try:
+        B, N = x.shape[0], x.shape[2]
+        k = model.emb_nn.k
+        engine.DEBUG_AUX = {}
+        with torch.no_grad():
+            model(x)
+        f0 = engine.DEBUG_AUX.get("F0")
+        engine.DEBUG_AUX = None
+        xs = ops.morton_sort(x) if engine.MORTON_ORDER else x
+        for C, rows in ((64, f0), (3, xs.reshape(B * N, 3))):
+            if rows is None:
+                continue
+            try:        # (a large batch runs as slices: the hook then holds the last slice's rows)
+                raw = ops.knn(ops.transpose(rows.reshape(-1, N, C)[:32].contiguous()), k, impl=5).view(-1, 32, k)
+                out[C] = float(raw[:, 0, 0].float().mean().item())       # first query of each tile carries the wave's counters
+            except Exception:
+                pass
+    except Exception:
+        pass
+    finally:
+        try:
+            engine.DEBUG_AUX = None
+        except Exception:
+            pass
+    return out
+
+
+def _pick(d, keys):
+    return {k_: d[k_] for k_ in keys if isinstance(d, dict) and k_ in d and d[k_] is not None}
+
+
+def compact_line(full, detail_name="bench_detail.json"):
+    """The ONE stdout line the driver parses, cut down to what the contract names (< LINE_MAX_BYTES): headline, `roofline`,
+    `cpu_baseline`, the train steps, one number per secondary record and per dominant kernel.  Kernel tables, per-step arrays,
+    notes and the full secondary records stay in `full`, which main() writes to bench_detail.json and prints to stderr."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dry_run", "higher_is_better", "scaling"))
+    line["vs_baseline"] = full.get("vs_baseline")
+    line.update(_pick(full, ("dtype", "data")))
+    line["data"] = str(line.get("data", "synthetic"))[:80]
+    cfg = full.get("config") or {}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:200], **_pick(cfg, ("clouds_per_step_per_gpu", "num_points")),
+                      "parallelism": str(cfg.get("parallelism", ""))[:80], "arithmetic": str(cfg.get("arithmetic", ""))[:200]}
+    if full.get("descriptors_per_s_per_rank") and full.get("n_gpus", 1) > 1:
+        line["descriptors_per_s_per_rank"] = full["descriptors_per_s_per_rank"]
+    roof = full.get("roofline")
+    if roof:
+        r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "frac_direct_form", "algorithmic_bytes_per_launch", "avg_launch_us"))
+        r["kernel"] = str(roof.get("kernel", ""))[:120]
+        r["traffic"] = roof.get("traffic")
+        if isinstance(roof.get("stage"), dict):
+            r["stage_frac_direct_form"] = roof["stage"].get("frac_direct_form")
+        line["roofline"] = r
+    else:
+        line["roofline"] = None
+    rk = full.get("roofline_kernels") or {}
+    if rk:
+        line["roofline_kernels"] = {name[:24]: _pick(e, ("bound", "avg_launch_us", "frac", "executed_frac", "speedup_vs_bruteforce_at_peak"))
+                                    for name, e in rk.items()}
+        for e in line["roofline_kernels"].values():
+            if "bound" in e:
+                e["bound"] = "mfma" if "mfma" == e["bound"] else "fp32"
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, ("value", "unit", "cores", "kind"))
+        c["sample"] = str(cb.get("sample_short") or cb.get("sample", ""))[:120]
+        if isinstance(cb.get("torch_cpu_cross_check"), dict):
+            c["torch_cpu_value"] = cb["torch_cpu_cross_check"].get("value")
+        line["cpu_baseline"] = c
+    if "parity_norm_rel_vs_oracle" in full:
+        line["parity_norm_rel_vs_oracle"] = full["parity_norm_rel_vs_oracle"]
+    for name in ("train", "train_bf16"):
+        t = full.get(name)
+        if t:
+            e = _pick(t, ("value", "unit", "ms_per_step", "dtype", "clouds_per_s", "steps"))
+            if isinstance(t.get("cpu_baseline"), dict):
+                e["cpu_clouds_per_s"] = t["cpu_baseline"].get("clouds_per_s")
+            if isinstance(t.get("exchange"), dict):
+                e["exchange"] = _pick(t["exchange"], ("allreduce_ms_per_step_isolated", "allreduce_busbw_GBps", "allreduce_exposed_ms_per_step"))
+            line[name] = e
+    sec = full.get("secondary") or {}
+    if sec:
+        short = {}
+        for name, rec in sec.items():
+            if not isinstance(rec, dict):
+                continue
+            if "ms_per_step" in rec:
+                e = _pick(rec, ("value", "ms_per_step"))
+                if isinstance(rec.get("roofline"), dict):
+                    e["kagg_frac"] = rec["roofline"].get("frac")
+                short[name[:40]] = e
+            else:                       # one level of nesting (operating points, storage variants): ms per step only
+                short[name[:40]] = {str(k_)[:16]: v_.get("ms_per_step") for k_, v_ in rec.items() if isinstance(v_, dict)}
+        line["secondary"] = short
+    line["detail"] = detail_name
+    # size guard: the optional blocks go first, the contract's keys never
+    for drop in ("secondary", "roofline_kernels", "descriptors_per_s_per_rank"):
+        if len(json.dumps(line)) < LINE_MAX_BYTES - 64:
+            break
+        line.pop(drop, None)
+    if len(json.dumps(line)) >= LINE_MAX_BYTES:
+        line["config"] = {"workload": line["config"]["workload"][:120]}
+        line["data"] = "synthetic"
+    return line
 
 
 def parse():
@@ -208,6 +340,7 @@ def cpu_baseline(model, points, seconds_target=20.0):
     agree = float((np.abs(dc[:Bs] - ref.numpy()).max(1) / np.abs(ref.numpy()).max(1)).max())
     return {"value": round(nC / tc, 3), "unit": "descriptors/s", "cores": used, "kind": "port",
             "host_cpu": host_cpu_model(), "host_cores": avail,
+            "sample_short": f"{nC} clouds x {points} pts, plain-C port of the reference path (OpenMP, {used} threads), median of {len(times)}",
             "sample": f"eval forward of {nC} clouds x {points} pts by the plain-C restatement of the reference path (oracle/lpd_forward.c, "
                       f"gcc -O3 -march=native, OpenMP: one cloud per thread, {used} threads of {avail} host cores), median of {len(times)} after a warm-up run",
             "torch_cpu_cross_check": {"value": round(Bs / t, 3), "unit": "descriptors/s", "cores": threads,
@@ -452,7 +585,7 @@ def secondary_eval(dev, points, k, batch, steps, warmup=2, featnet="lpdnet", exa
     if kern_all is not None:
         rec["kernels"] = kern_all
         if featnet == "lpdnet":
-            rec["roofline_kernels"] = kernel_rooflines(kern_all, batch, points, k, split)
+            rec["roofline_kernels"] = kernel_rooflines(kern_all, batch, points, k, split, knn_visit_stats(model, clouds[0]))
     del model, clouds
     torch.cuda.empty_cache()
     return rec
@@ -687,6 +820,7 @@ def main():
                      if kk in ("value", "unit", "ms_per_step", "steps", "config", "losses", "peak_hbm_gib")}
                 for st in ("f32", "bf16")}
 
+    knn_visits = knn_visit_stats(model, clouds[0]) if rank == 0 else None
     if rank == 0:
         line = {
             "metric": "global descriptors/sec (4096-pt clouds)", "value": round(value, 2), "unit": "descriptors/s",
@@ -706,7 +840,7 @@ def main():
                                       "products as 3-product split-bf16 MFMA with fp32 accumulation (DESIGN.md 3.2)"
                                       if ops.GEMM_BF16X3 else "fp32 tensors, every product on the f32-input MFMA / fp32 FMA")},
             "descriptors_per_s_per_rank": per_rank,
-            "roofline": roof, "roofline_kernels": kernel_rooflines(kern, args.batch, args.points, args.k, ops.GEMM_BF16X3),
+            "roofline": roof, "roofline_kernels": kernel_rooflines(kern, args.batch, args.points, args.k, ops.GEMM_BF16X3, knn_visits),
             "kernels": kern, "train": train,
         }
         if secondary is not None:
@@ -725,7 +859,22 @@ def main():
                 train["cpu_baseline"] = tb
                 if train_bf16 is not None:
                     train_bf16["cpu_baseline"] = tb
-        line_out.write(json.dumps(line) + "\n")
+        # the full record (kernel tables, per-step arrays, secondary records, notes) goes to a side file and to stderr; stdout
+        # carries ONE line below LINE_MAX_BYTES (the driver parses it: a 20 KB line was not parseable)
+        detail = json.dumps(line)
+        detail_name = "bench_detail.json" if world == 1 else f"bench_detail_n{world}.json"
+        for d_ in (ROOT, __import__("tempfile").gettempdir()):
+            try:
+                with open(os.path.join(d_, detail_name), "w") as f_:
+                    f_.write(detail + "\n")
+                break
+            except OSError:
+                continue
+        sys.stderr.write("bench detail: " + detail + "\n")
+        sys.stderr.flush()
+        short = json.dumps(compact_line(line, detail_name))
+        assert len(short) < LINE_MAX_BYTES, len(short)
+        line_out.write(short + "\n")
         line_out.flush()
     if dist is not None:
         dist.destroy_process_group()

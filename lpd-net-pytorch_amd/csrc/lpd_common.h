@@ -103,7 +103,9 @@ __device__ __forceinline__ int lpd_xcd_remap(int bid, int nblocks)
 struct LpdXcdSweep { long long begin, end, step; };
 __device__ __forceinline__ LpdXcdSweep lpd_xcd_sweep(long long nwork)
 {
-    const int nx = 8;
+    // a launch of fewer than 8 blocks occupies only that many XCDs: the range is cut into as many shares as there are XCDs WITH a
+    // block (with 8 fixed shares the shares of the empty XCDs were never visited: rows of dP / dQ left unwritten for M <= 56 at C = 256)
+    const int nx = gridDim.x < 8 ? (int)gridDim.x : 8;
     const int wpb = blockDim.x >> 6;
     const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
     const long long blocks_here = gridDim.x / nx + (xcd < (int)(gridDim.x % nx) ? 1 : 0);      // blocks of this launch on this XCD

@@ -81,9 +81,9 @@ def _cache_of(module):
     return c
 
 
-def _cached(module, key, tensors, build):
-    """Derived tensors keyed on the (data_ptr, version, device) of their sources."""
-    sig = tuple((t.data_ptr(), t._version, t.device) for t in tensors)
+def _cached(module, key, tensors, build, extra=None):
+    """Derived tensors keyed on the (data_ptr, version, device) of their sources (+ `extra`: non-tensor attributes they depend on)."""
+    sig = tuple((t.data_ptr(), t._version, t.device) for t in tensors) + (extra,)
     c = _cache_of(module)
     hit = c.get(key)
     if hit is not None and hit[0] == sig:
@@ -110,7 +110,7 @@ def bn_affine(bn):
     src = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
     if bn.num_batches_tracked is not None:
         src = src + (bn.num_batches_tracked,)
-    return _cached(bn, "affine", src, build)
+    return _cached(bn, "affine", src, build, extra=bn.eps)
 
 
 def _w2d(conv):
@@ -148,7 +148,7 @@ def conv3_folded(net):
     src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
     if bn.num_batches_tracked is not None:
         src = src + (bn.num_batches_tracked,)
-    return _cached(net, "conv3_folded", src, lambda: (_w2d(conv) * bn_affine(bn)[0].unsqueeze(1)).contiguous())
+    return _cached(net, "conv3_folded", src, lambda: (_w2d(conv) * bn_affine(bn)[0].unsqueeze(1)).contiguous(), extra=bn.eps)
 
 
 def _check_input(x, dims=3):
@@ -275,20 +275,66 @@ REPLAY_MAX_PLANS = 4               # per model (a plan keeps the forward's buffe
 
 
 class _Plan:
-    __slots__ = ("sig", "x_in", "out", "actions", "keep", "hits")
+    __slots__ = ("x_in", "out", "actions", "keep", "hits", "lock")
+
+
+class _ModelPlans:
+    """the plans of ONE model state: `sig` covers everything but the input shape and the stream; when it changes (weights updated,
+    a switch flipped, a parameter re-registered) every plan of the model is dropped at once, with the buffers it held"""
+    __slots__ = ("sig", "plans")
 
 
 # Plans live OUTSIDE the module (weakly keyed by it): they hold ctypes function pointers and device buffers, which must not travel with
 # copy.deepcopy(model) / torch.save(model) / nn.DataParallel's shallow replicas (whose parameters are fresh tensors every forward).
-_PLANS = __import__("weakref").WeakKeyDictionary()        # model -> {key: _Plan}
-_SIG_TENSORS = __import__("weakref").WeakKeyDictionary()  # model -> [parameters and buffers]
+_PLANS = __import__("weakref").WeakKeyDictionary()        # model -> _ModelPlans
+_SIG_TENSORS = __import__("weakref").WeakKeyDictionary()  # model -> (registration epoch, [parameters and buffers], non-tensor attributes)
+_PLANS_LOCK = __import__("threading").Lock()              # the two tables above (host threads of one process share a model)
+# Registration epoch: bumped whenever ANY module of the process registers a parameter, a buffer or a sub-module (torch's global
+# registration hooks: `m.weight = nn.Parameter(...)`, `m.net_vlad = new_head`, load_state_dict(assign=True), prune / parametrize).  The
+# cached tensor list of a model is valid for one epoch: a replaced Parameter can never be mistaken for the old one.
+_EPOCH = [0]
+
+
+def _bump_epoch(*_a, **_k):
+    _EPOCH[0] += 1
+    return None
+
+
+for _reg in ("register_module_parameter_registration_hook", "register_module_buffer_registration_hook", "register_module_module_registration_hook"):
+    getattr(torch.nn.modules.module, _reg)(_bump_epoch)
+
+
+def invalidate(model=None):
+    """Drop the recorded launch lists (and the buffers they keep) of `model`, or of every model.  Needed only after changes torch does
+    not version: writes through `p.data` / raw pointers into a parameter or buffer, or edits of `module._parameters` behind
+    `__setattr__`.  Everything else (optimizer steps, load_state_dict, `copy_`, re-registration, the dispatch switches) is seen by the
+    signature."""
+    with _PLANS_LOCK:
+        if model is None:
+            _PLANS.clear()
+            _SIG_TENSORS.clear()
+        else:
+            _PLANS.pop(model, None)
+            _SIG_TENSORS.pop(model, None)
+    _EPOCH[0] += 1
 
 
 def _model_sig(model):
-    ts = _SIG_TENSORS.get(model)
-    if ts is None:
-        ts = _SIG_TENSORS[model] = list(model.parameters()) + list(model.buffers())
-    return tuple((t.data_ptr(), t._version) for t in ts)
+    ent = _SIG_TENSORS.get(model)
+    if ent is None or ent[0] != _EPOCH[0]:
+        # non-tensor attributes the forward reads: activation choice, neighbour count, BatchNorm eps / widths of the head
+        mods = list(model.modules())
+        ent = _SIG_TENSORS[model] = (_EPOCH[0], list(model.parameters()) + list(model.buffers()), mods)
+    attrs = tuple((getattr(m, "eps", None), getattr(m, "use_relu", None), getattr(m, "k", None), getattr(m, "training", None)) for m in ent[2])
+    return ent[0], tuple((t.data_ptr(), t._version) for t in ent[1]), attrs
+
+
+def _switch_sig():
+    """the module-level switches that steer the eval dispatch (tools and tests flip them at run time)"""
+    g = globals()
+    return (_morton_order(), SIDE_STREAM, getattr(_SIDE_FORCE, "mode", None), PANEL_LAYOUT, g["FUSED_FRONT"], g["FUSE_ASSIGN"], g["CONV3_P8"],
+            g["KAGG_WINDOW"], EVAL_CHUNK, ops.GEMM_BF16X3, ops._EXACT.depth, ops._FAST.depth, ops.KNN_IMPL, ops.BF16_SINGLE_PRODUCT,
+            ops.X3W_FORWARD, ops.X3W_IMPL, ops.X3W_BATCHED, ops.X3T_PANELS, ops.X3T_ROWS, ops.P8_IMPL, ops.KAGGW_PERMUTE)
 
 
 def replay_eval(model, x, eager):
@@ -302,22 +348,34 @@ def replay_eval(model, x, eager):
         return eager(x)      # (T-Net / 8-column variants run torch ops between their launches that a tape would not hold)
     stream = torch.cuda.current_stream(x.device)
     key = (tuple(x.shape), x.device.index, stream.cuda_stream)
-    sig = (_model_sig(model), _morton_order(), SIDE_STREAM, getattr(_SIDE_FORCE, "mode", None), ops.GEMM_BF16X3, ops._EXACT.depth, ops._FAST.depth,
-           tuple(int(getattr(m, "k", 0)) for m in (model.emb_nn,) if m is not None))
-    plans = _PLANS.get(model)
-    if plans is None:
-        plans = _PLANS[model] = {}
-    ent = plans.get(key)
-    if ent is not None and ent.sig == sig:
+    with _PLANS_LOCK:
+        sig = (_model_sig(model), _switch_sig())
+        mp = _PLANS.get(model)
+        if mp is None or mp.sig != sig:      # another model state: every plan recorded for the old one goes, with its buffers
+            mp = _PLANS[model] = _ModelPlans()
+            mp.sig, mp.plans = sig, {}
+        ent = mp.plans.get(key)
+        if ent is None:                      # first sighting of this (shape, stream): run eagerly, record on the second
+            if len(mp.plans) >= REPLAY_MAX_PLANS:
+                mp.plans.pop(next(iter(mp.plans)))
+            ent = _Plan()
+            ent.actions, ent.keep, ent.x_in, ent.out, ent.hits, ent.lock = None, None, None, None, 0, __import__("threading").Lock()
+            mp.plans[key] = ent
+            return_eager = True
+        else:
+            return_eager = False
+    if return_eager:
+        return eager(x)
+    # One plan has ONE input and ONE output buffer: two host threads calling the model on the same stream (DataLoader workers,
+    # util/data.py:117-133) must not interleave copy -> launches -> clone.  The second thread does not wait: the eager path is re-entrant.
+    if not ent.lock.acquire(blocking=False):
+        return eager(x)
+    try:
         if ent.actions is not None:
             return _replay(ent, x)
         return _record(ent, x, eager)        # second sighting of this state: worth a tape
-    if len(plans) >= REPLAY_MAX_PLANS:
-        plans.pop(next(iter(plans)))
-    ent = _Plan()
-    ent.sig, ent.actions, ent.keep, ent.x_in, ent.out, ent.hits = sig, None, None, None, None, 0
-    plans[key] = ent
-    return eager(x)
+    finally:
+        ent.lock.release()
 
 
 def _record(ent, x, eager):

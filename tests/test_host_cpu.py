@@ -229,10 +229,80 @@ def test_bench_kernel_rooflines_from_a_kernel_table():
     assert abs(conv3["executed_frac"] - 3 * conv3["frac"]) < 2e-4
     mlp = r["edge MLP (DG1 act -> DG2 conv -> max over k)"]
     assert mlp["algorithmic_flops_per_launch"] == 2 * 131072 * 20 * 128 * 128 and mlp["peak"] == 2500.0
+    # kNN: no visit rate -> no roofline fraction at all (only the speed against a perfect brute-force kernel, as its own field)
     knn = r["feature-space kNN"]
-    assert knn["algorithmic_flops_per_launch"] == 32 * (2 * 4096 * 4096 * 64 + 3 * 4096 * 4096) and knn["peak"] == 157.3
-    assert r["xyz kNN"]["algorithmic_flops_per_launch"] == 32 * (2 * 4096 * 4096 * 3 + 3 * 4096 * 4096)
+    assert knn["frac"] is None and knn["peak"] == 157.3
+    assert knn["bruteforce_flops_per_launch"] == 32 * (2 * 4096 * 4096 * 64 + 3 * 4096 * 4096)
+    assert abs(knn["speedup_vs_bruteforce_at_peak"] - knn["bruteforce_flops_per_launch"] / 400e-6 / 1e12 / 157.3) < 1e-3
+    assert r["xyz kNN"]["bruteforce_flops_per_launch"] == 32 * (2 * 4096 * 4096 * 3 + 3 * 4096 * 4096)
+    # with the walk's measured visit rate: executed FLOPs = query tiles x visited tiles x 32 x 32 x 2 C; never above 1
+    r = bench.kernel_rooflines(kern, 32, 4096, 20, True, {64: 23.3, 3: 40.0})
+    knn = r["feature-space kNN"]
+    assert knn["executed_flops_per_launch"] == int(32 * 128 * 23.3 * 32 * 32 * 2 * 64)
+    assert abs(knn["frac"] - knn["executed_flops_per_launch"] / 400e-6 / 1e12 / 157.3) < 1e-4 and knn["frac"] < 0.3
+    assert r["xyz kNN"]["executed_flops_per_launch"] == int(32 * 128 * 40.0 * 32 * 32 * 2 * 4)
+    crazy = bench.kernel_rooflines({"knn[C=64,k=20]": {"launches": 1, "avg_us": 1.0}}, 32, 4096, 20, True, {64: 1e9})
+    assert crazy["feature-space kNN"]["frac"] <= 1.0 and crazy["feature-space kNN"]["tiles_visited_per_query_tile"] == 128
+    for e in r.values():
+        assert e["frac"] is None or e["frac"] <= 1.0
     # the K-agg numerator counts the uint16 indices the kernel reads
     assert bench.KAGG_IDX_BYTES == 2 and bench.KAGG_ROW_BYTES == 3 * 256 * 4
     exact = bench.kernel_rooflines(kern, 32, 4096, 20, False)
     assert "executed_frac" not in exact["conv3 + NetVLAD assignment"] and exact["conv3 + NetVLAD assignment"]["peak"] == 157.3
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_bench_stdout_line_stays_parseable():
+    """The driver parses bench.py's final stdout line; round 5's 20 KB line (kernel tables, notes, five secondary records) came back
+    unparsed.  compact_line() must keep the contract's keys and stay below 4 KB whatever the full record holds."""
+    import json
+    bench = _load_bench()
+    kern = {f"op{i}[{131072}x{i}x512]": {"launches": 5, "avg_us": 10.0 + i} for i in range(60)}
+    kern.update({"gemm_p8+assign[131072x1024x512]": {"launches": 5, "avg_us": 450.0}, "edge_mlpx3[128->128]": {"launches": 5, "avg_us": 270.0},
+                 "knn[C=64,k=20]": {"launches": 5, "avg_us": 400.0}, "knn[C=3,k=20]": {"launches": 5, "avg_us": 200.0}})
+    rk = bench.kernel_rooflines(kern, 32, 4096, 20, True, {64: 23.3, 3: 40.0})
+    note = "a paragraph-long note " * 40
+    train = {"metric": "quadruplet train-steps/sec", "value": 122.0, "unit": "steps/s", "ms_per_step": 8.2, "dtype": "bf16", "steps": 10,
+             "clouds_per_s": 5368.3, "config": note, "losses": [0.1] * 10, "per_step": {"gpu_ms": [8.2] * 10, "host_enqueue_ms": [3.0] * 10},
+             "cpu_baseline": {"value": 0.16, "clouds_per_s": 0.99, "sample": note},
+             "exchange": {"allreduce_ms_per_step_isolated": 0.5, "allreduce_busbw_GBps": 250.0, "allreduce_exposed_ms_per_step": 0.1, "buckets": note}}
+    sec = {f"secondary record number {i} with a long descriptive name " * 2: {"value": 1.0, "ms_per_step": 2.0, "kernels": kern, "roofline_kernels": rk,
+                                                                             "roofline": {"frac": 0.2, "kernel": note}} for i in range(6)}
+    sec["operating points"] = {f"{b} clouds/step": {"value": 1.0, "ms_per_step": 0.4} for b in (1, 2, 6, 10, 24)}
+    full = {"metric": "global descriptors/sec (4096-pt clouds)", "value": 16468.35, "unit": "descriptors/s", "n_gpus": 8, "steps": 20, "warmup": 3,
+            "ms_per_step": 1.943, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": note,
+            "config": {"workload": "BASELINE configs[1]: " + note, "parallelism": note, "arithmetic": note, "hip_streams": note, "settle": note},
+            "descriptors_per_s_per_rank": [16000.0] * 8,
+            "roofline": {"kernel": note, "bound": "hbm", "achieved": 4290.5, "peak": 8000.0, "unit": "GB/s", "frac": 0.5363, "traffic": 423756192,
+                         "traffic_source": note, "algorithmic_bytes_per_launch": 407896064, "avg_launch_us": 95.07, "numerator": note,
+                         "frac_direct_form": 0.2785, "stage": {"kernels": ["a", "b"], "us": 168.0, "frac_direct_form": 0.158}},
+            "roofline_kernels": rk, "kernels": kern, "train": dict(train, dtype="f32"), "train_bf16": train, "secondary": sec,
+            "cpu_baseline": {"value": 22.1, "unit": "descriptors/s", "cores": 128, "kind": "port", "sample": note, "sample_short": "128 clouds x 4096 pts, plain-C port",
+                             "torch_cpu_cross_check": {"value": 3.6, "sample": note}, "host_cpu": "EPYC"},
+            "parity_norm_rel_vs_oracle": 4.0e-7}
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < 4096 and "\n" not in text
+    back = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "parity_norm_rel_vs_oracle", "train", "train_bf16", "detail"):
+        assert key in back, key
+    assert back["config"]["workload"].startswith("BASELINE configs[1]")
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "frac_direct_form", "algorithmic_bytes_per_launch", "avg_launch_us"):
+        assert key in back["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in back["cpu_baseline"], key
+    assert len(back["cpu_baseline"]["sample"]) <= 120
+    assert back["train_bf16"]["ms_per_step"] == 8.2 and back["train_bf16"]["dtype"] == "bf16"
+    assert "kernels" not in back and back["detail"].endswith(".json")
+    # a record without the optional blocks (--no-train --no-secondary --no-cpu-baseline, N > 1) still yields a line
+    small = bench.compact_line({k_: full[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")})
+    assert small["value"] == full["value"] and small["roofline"]["frac"] == 0.5363

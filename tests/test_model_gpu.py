@@ -637,7 +637,7 @@ def test_small_batch_eval_replays_its_launch_tape(cuda, B):
     assert engine.REPLAY
     with torch.no_grad():
         got = [m(x).clone() for x in xs]                   # eager, recorded, then four replays
-    plan = next(iter(engine._PLANS[m].values()))
+    plan = next(iter(engine._PLANS[m].plans.values()))
     assert plan.actions is not None and plan.hits == 4
     import copy
     import io
@@ -666,6 +666,96 @@ def test_small_batch_eval_replays_its_launch_tape(cuda, B):
         assert "idx_feat" in engine.DEBUG_AUX and _norm_rel(d, a) < 2e-6
     finally:
         engine.DEBUG_AUX = None
+    # a REPLACED parameter (m.w = nn.Parameter(...), load_state_dict(assign=True)) is a new tensor object: the tape's cached tensor list
+    # must not keep looking at the old one (the registration epoch drops it)
+    with torch.no_grad():
+        for _ in range(3):
+            m(xs[2])
+        assert next(iter(engine._PLANS[m].plans.values())).actions is not None
+        m.net_vlad.hidden1_weights = torch.nn.Parameter(m.net_vlad.hidden1_weights.detach() * 0.5)
+        e = m(xs[2]).clone()
+        engine.REPLAY = False
+        try:
+            e_want = m(xs[2]).clone()
+        finally:
+            engine.REPLAY = True
+    assert _norm_rel(e, e_want) < 2e-6 and _norm_rel(e, want[2]) > 1e-4
+    sd2 = {k_: v_.detach().clone() for k_, v_ in m.state_dict().items()}
+    sd2["net_vlad.cluster_weights"] = sd2["net_vlad.cluster_weights"] * 1.5
+    with torch.no_grad():
+        for _ in range(3):
+            f0 = m(xs[3]).clone()
+        m.load_state_dict(sd2, assign=True)
+        f1 = m(xs[3]).clone()
+    assert _norm_rel(f1, f0) > 1e-4
+    # a dispatch switch flipped at run time re-records (A/B timing scripts must measure the path they selected), a non-tensor attribute too
+    with torch.no_grad():
+        for _ in range(3):
+            g0 = m(xs[4]).clone()
+        mp = engine._PLANS[m]
+        engine.FUSE_ASSIGN = False
+        try:
+            g1 = m(xs[4]).clone()
+            assert engine._PLANS[m] is not mp and not any(p_.actions for p_ in engine._PLANS[m].plans.values())
+        finally:
+            engine.FUSE_ASSIGN = True
+        assert _norm_rel(g1, g0) < 1e-5
+        for _ in range(3):
+            m(xs[4])
+        m.emb_nn.bn3_lpd.eps = 0.5
+        g2 = m(xs[4]).clone()
+        m.emb_nn.bn3_lpd.eps = 1e-5
+    assert _norm_rel(g2, g0) > 1e-4
+    # engine.invalidate: for writes torch does not version (p.data, raw pointers)
+    with torch.no_grad():
+        for _ in range(3):
+            m(xs[5])
+        engine.invalidate(m)
+        assert m not in engine._PLANS
+        engine.invalidate()
+
+
+def test_two_host_threads_on_one_stream_share_a_launch_tape(cuda):
+    """util/data.py:117-133 runs the model from DataLoader workers: two host threads call ONE model on the SAME stream (the default
+    one) with different inputs while a launch tape exists for that (shape, stream).  A plan has one input and one output buffer:
+    without the per-plan lock thread B's copy into it can land between A's copy and A's launches.  Every result must be its own input's."""
+    import threading
+    from lpdnet_hip import engine
+    N, B = 1024, 2
+    m, _ = _model("lpdnet", N, cuda)
+    xs = [torch.from_numpy(synth.cloud(700 + i, B, N)).unsqueeze(1).to(cuda) for i in range(8)]
+    prev, engine.REPLAY = engine.REPLAY, False
+    try:
+        with torch.no_grad():
+            want = [m(x).clone() for x in xs]
+    finally:
+        engine.REPLAY = prev
+    with torch.no_grad():
+        for _ in range(3):
+            m(xs[0])                                           # eager, recorded, replayed: the tape exists
+    assert next(iter(engine._PLANS[m].plans.values())).actions is not None
+    torch.cuda.synchronize()
+    res, errs = {}, []
+    barrier = threading.Barrier(2)
+
+    def work(t):
+        try:
+            barrier.wait()
+            with torch.no_grad():
+                for rep in range(40):
+                    i = (2 * rep + t) % len(xs)
+                    res[(t, rep)] = (i, m(xs[i]))
+        except Exception as exc:      # noqa: BLE001
+            errs.append(exc)
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    torch.cuda.synchronize()
+    assert not errs, errs
+    assert len(res) == 80
+    for (t, rep), (i, got) in res.items():
+        assert _norm_rel(got, want[i]) < 2e-6, (t, rep, i)
+    assert next(iter(engine._PLANS[m].plans.values())).hits > 1
 
 
 # ------------------------------------------------------------------ N4 on the GPU: checkpoint round trip of a TRAINED model

@@ -703,7 +703,9 @@ def _bn_for(C, seed):
     return bn
 
 
-@pytest.mark.parametrize("C,N,k,B", [(256, 512, 20, 2), (128, 300, 20, 3), (64, 128, 7, 2), (256, 256, 64, 1), (256, 4096, 20, 2), (64, 1000, 20, 1)])
+@pytest.mark.parametrize("C,N,k,B", [(256, 512, 20, 2), (128, 300, 20, 3), (64, 128, 7, 2), (256, 256, 64, 1), (256, 4096, 20, 2), (64, 1000, 20, 1),
+                                     # launches of fewer than 8 blocks in the backward gather (lpd_xcd_sweep): M <= 56 / 112 / 224 rows at C = 256 / 128 / 64
+                                     (256, 32, 7, 1), (256, 24, 5, 2), (128, 64, 7, 1), (128, 36, 20, 3), (64, 32, 5, 2), (64, 200, 20, 1)])
 def test_split_form_edge_stage_equals_the_materialised_one(cuda, C, N, k, B):
     """lpd_edge_split_fwd / _bwd (no [M*k, C] edge tensor; closed-form BatchNorm sums, one pass over the transposed graph)
     against the materialised formulation edge_build -> group_max -> edge_bn_bwd -> gather_sum_rows: outputs, arg-max,
@@ -1272,7 +1274,7 @@ def test_edge_mlp_train_equals_the_materialised_stage(cuda, bf16, N, k, B):
 
 
 @pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
-@pytest.mark.parametrize("N,k,B", [(320, 20, 2), (256, 16, 3)])
+@pytest.mark.parametrize("N,k,B", [(320, 20, 2), (256, 16, 3), (64, 16, 1), (40, 8, 2)])      # the last two: fewer than 8 blocks in the gather pass
 def test_edge_mlp_train_bwd_equals_the_chain(cuda, bf16, N, k, B):
     """lpd_edge_mlp_train_bwd + lpd_edge_dense_bwd_apply (DG2 dY1e product with dZ built in the operand loader, the gradient in front of
     BatchNorm1 and its reductions in the epilogue, dP / dQ in closed form from one gather pass) against the chain they replace:
