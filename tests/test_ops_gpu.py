@@ -61,7 +61,7 @@ def test_knn_bit_exact_vs_oracle(cuda, C, N, k, B, impl):
 
 
 @pytest.mark.parametrize("impl", [0, 4, 2])
-@pytest.mark.parametrize("C,N,k", [(3, 1024, 20), (3, 4096, 20), (64, 700, 20), (3, 6000, 64), (64, 5000, 64), (64, 4500, 20), (3, 900, 40)])
+@pytest.mark.parametrize("C,N,k", [(3, 1024, 20), (3, 4096, 20), (64, 700, 20), (3, 6000, 64), (64, 5000, 64), (64, 4500, 20), (3, 900, 40), (2, 777, 20), (1, 300, 9)])
 def test_knn_exact_ties_lower_index_first(cuda, C, N, k, impl):
     """Clouds on a coarse lattice with duplicated points: thousands of exact pd ties, inside the lists and at the k-th
     boundary.  Every row must equal the oracle's (value descending, lower index first) -- for the best-first kernel this
@@ -80,6 +80,64 @@ def test_knn_exact_ties_lower_index_first(cuda, C, N, k, impl):
     if impl == 0:
         got_pm = ops.knn_pm(torch.from_numpy(x_pm.reshape(-1, C)).to(cuda).contiguous(), 2, N, k).cpu().numpy()
         assert (got_pm == oidx).all()
+
+
+def _zsort(x):
+    """x [B, N, 3] -> the same clouds with their points in Z-curve (Morton) order on a 1024^3 grid of each cloud's bounding box: the order
+    lpd_morton_sort gives the model's clouds, in which 8 consecutive points are a compact box and the leaf-box search really prunes."""
+    out = np.empty_like(x)
+    for b in range(x.shape[0]):
+        p = x[b].astype(np.float64)
+        lo, hi = p.min(0), p.max(0)
+        g = np.clip(((p - lo) / np.maximum(hi - lo, 1e-30) * 1023.0), 0, 1023).astype(np.uint64)
+        key = np.zeros(len(p), dtype=np.uint64)
+        for bit in range(10):
+            for a in range(3):
+                key |= ((g[:, a] >> np.uint64(bit)) & np.uint64(1)) << np.uint64(3 * bit + a)
+        out[b] = x[b][np.argsort(key, kind="stable")]
+    return out
+
+
+@pytest.mark.parametrize("N,k,B", [(4096, 20, 3), (16384, 64, 1), (1000, 20, 2), (520, 7, 2), (72, 64, 2), (16384, 20, 1), (2048, 33, 2)])
+@pytest.mark.parametrize("case", ["uniform", "surface", "clusters", "lattice", "offset", "huge", "dupes"])
+def test_knn_on_z_ordered_clouds(cuda, N, k, B, case):
+    """The xyz search on clouds in Z-curve order -- the model's order (lpd_morton_sort), where the best-first walk's tile bounds decide
+    most tiles (on unordered clouds every tile spans the cloud and nearly everything is visited).  Every row equals the oracle's,
+    ties by lower index: uniform volumes, a LiDAR-like surface (ground plane + walls: empty space and dense sheets), tight clusters at
+    mixed separations, a coarse lattice (exact ties inside the lists and at the k-th boundary), a cloud far from the origin (pd
+    quantised at ulp(|x|^2): the slack E0 dominates the bounds), large coordinates, duplicated points."""
+    ops = _ops()
+    g = np.random.default_rng(N + k + len(case))
+    x = g.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    if case == "surface":
+        x[:, : N // 2, 2] = (-0.9 + 0.01 * g.normal(0, 1, (B, N // 2))).astype(np.float32)
+        x[:, N // 2: 3 * N // 4, 0] = (0.7 + 0.005 * g.normal(0, 1, (B, 3 * N // 4 - N // 2))).astype(np.float32)
+    elif case == "clusters":
+        nc = max(1, N // 50)
+        cen = g.normal(0, 1, (B, nc, 1, 3)) * g.choice([0.05, 0.3, 2.0], (B, nc, 1, 1))
+        pts = (cen + 0.02 * g.normal(0, 1, (B, nc, 50, 3))).reshape(B, nc * 50, 3)
+        x[:, : nc * 50] = pts[:, :N].astype(np.float32)
+    elif case == "lattice":
+        x = (g.integers(-4, 5, size=(B, N, 3)) / 4.0).astype(np.float32)
+    elif case == "offset":
+        x = (x + np.float32(100.0)).astype(np.float32)
+    elif case == "huge":
+        x = (x * np.float32(3e4)).astype(np.float32)
+    elif case == "dupes":
+        x[:, N // 2:] = x[:, : N - N // 2]
+    x = _zsort(x)
+    oidx, _ = orc.knn_np(x, k)
+    tie = orc.knn_tie_rows(x, k)
+    rows = torch.from_numpy(x.reshape(-1, 3)).to(cuda)
+    got = ops.knn_pm(rows, B, N, k).cpu().numpy()
+    bad = (got != oidx).any(-1)
+    if case in ("lattice", "offset", "dupes"):      # the oracle's tie rule is the contract: every row
+        assert bad.sum() == 0, f"{bad.sum()} rows differ; first: {np.argwhere(bad)[:3].tolist()}"
+    else:
+        assert (bad & ~tie).sum() == 0, f"{(bad & ~tie).sum()} tie-free rows differ; first: {np.argwhere(bad & ~tie)[:3].tolist()}"
+    assert (got == ops.knn_pm(rows, B, N, k, impl=4).cpu().numpy()).all()           # best-first walk == ascending scan
+    x_cm = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1))).to(cuda)    # ... == the channel-major entry
+    assert (ops.knn(x_cm, k).cpu().numpy() == got).all()
 
 
 def test_knn_many_small_clouds(cuda):
