@@ -1051,6 +1051,131 @@ __global__ __launch_bounds__(256) void linear_fewrows_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 6: the same product for 5 .. 32 rows on the f32-input MFMA (the NetVLAD hidden projection of an eval slice: [32, 65536] x
+// [65536, 256], 67 MB of weights read once).  linear_smallm_kernel spends 1.07 GFLOP on the VALU from 4-byte column loads and writes
+// 512 slabs (29 us + 13 us of slab reduction at 32 rows = 0.20 of the HBM roofline for the weights).  Here the weights are a STREAM of
+// whole rows through the matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32 = the k-ordered fmaf chain):
+//   * block = 256 k-rows x 256 columns (one block per CU at K = 65536), X slice [256][32] in LDS (zero rows past M);
+//   * wave (column half ch, k phase kq of 4): per k-pair ONE 16-byte load per lane -- lane (c, h) reads W[k0 + 2 i + h][128 ch + 4 c .. + 3],
+//     512 contiguous bytes per half-wave -- feeds FOUR MFMAs (tile j holds columns 128 ch + 4 c + j: a permutation of the columns, undone
+//     by the float4 stores of the epilogue); R32_DEPTH loads in flight per lane; 4 x 64 cycles of MFMA per KiB and wave = 9 TB/s for
+//     the chip: the matrix cores stay just ahead of HBM;
+//   * the four k phases of a column half are added through LDS, ONE slab per block (K / 256 slabs), the existing slab reduce.
+// ---------------------------------------------------------------------------------------------
+constexpr int R32_KPER = 256;    // k-rows per block
+constexpr int R32_DEPTH = 16;    // weight loads in flight per lane (16 KiB per wave, 128 KiB per block: the stream is latency-bound below that)
+constexpr int R32_XLD = 33;      // LDS row stride of the X slice (k-major rows of 32 floats, padded: staging writes walk k)
+constexpr int R32_PH = 4;        // k phases: wave (column half ch, phase kq) takes the k-pairs i = kq, kq + 4, ...
+constexpr int R32_LDS_FLOATS = 2 * 2 * 4 * 16 * 64;      // partner exchange: [stage slot 0..1][column half][tile][r][lane]
+
+__global__ __launch_bounds__(512) void linear_rows32_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
+                                                             float* __restrict__ slabs, int M, int N, int K)
+{
+    extern __shared__ __attribute__((aligned(16))) float r32_lds[];      // X slice [k][m] (33 KiB); afterwards the partner exchange (64 KiB)
+    float* xs = r32_lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = wave & 1, kq = wave >> 1;
+    const int k0 = blockIdx.x * R32_KPER;
+    const int kn = min(R32_KPER, K - k0);
+    const int c = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * 256 + ch * 128 + 4 * c;
+    const float* wp = W + n0;
+    // this wave's k-pairs: i = kq + 4 t, t = 0 .. NT - 1; its rows 2 i + h (rows past the slice are re-reads of its last row: X is zero there)
+    auto wrow = [&](int t) { return *reinterpret_cast<const float4*>(wp + (long long)(k0 + min(2 * (kq + R32_PH * t) + h, kn - 1)) * ldw); };
+    constexpr int NT = R32_KPER / 2 / R32_PH;      // 32 k-pairs per wave
+    static_assert(NT == 2 * R32_DEPTH, "two rounds of R32_DEPTH loads");
+    float4 wn[R32_DEPTH];
+    {   // X slice: 16 values per thread, all requested before the first is stored (a rolled loop waited for every load in turn:
+        // 16 round trips to a cold X, 20 of the kernel's 31 us) and BEFORE the weight rows: loads return in order, so the slice is
+        // staged while the first round of weights is still on its way
+        constexpr int NX = 32 * R32_KPER / 512;
+        float xv[NX];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + 512 * j, m = i / R32_KPER, k = i - m * R32_KPER;
+            xv[j] = X[(long long)min(m, M - 1) * ldx + k0 + min(k, kn - 1)];      // (no branch around the load; masked below)
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < R32_DEPTH; ++d) wn[d] = wrow(d);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + 512 * j, m = i / R32_KPER, k = i - m * R32_KPER;
+            xv[j] = (m < M && k < kn) ? xv[j] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + 512 * j, m = i / R32_KPER, k = i - m * R32_KPER;
+            xs[k * R32_XLD + m] = xv[j];
+        }
+    }
+    __syncthreads();
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+#pragma unroll
+        for (int d = 0; d < R32_DEPTH; ++d) {
+            const int t = rd * R32_DEPTH + d;
+            const float a = xs[(2 * (kq + R32_PH * t) + h) * R32_XLD + c];
+            const float4 w = wn[d];
+            if (rd == 0) {                                     // the register set is free again: request the second round's row NOW
+                wn[d] = wrow(R32_DEPTH + d);
+                asm volatile("" ::: "memory");                 // (the scheduler sank these loads behind the round's 64 MFMAs)
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w.y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w.z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w.w, acc[3], 0, 0, 0);
+        }
+    }
+    // phases 2, 3 -> LDS, phases 0, 1 add; phase 1 -> LDS, phase 0 adds and stores the block's slab.  Accumulator element r of lane
+    // (c, h): row (r & 3) + 8 (r >> 2) + 4 h, columns n0 .. n0 + 3 from the four tiles
+    __syncthreads();                                               // the X slice is dead
+    float* red = r32_lds + ((kq & 1) * 2 + ch) * (4 * 16 * 64);
+    if (kq >= 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(j * 16 + r) * 64 + lane] = acc[j][r];
+    }
+    __syncthreads();
+    if (kq < 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] += red[(j * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+    if (kq == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(j * 16 + r) * 64 + lane] = acc[j][r];
+    }
+    __syncthreads();
+    if (kq == 0 && n0 < N) {
+        const float* r1 = r32_lds + (1 * 2 + ch) * (4 * 16 * 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < M) {
+                float4 o;
+                o.x = acc[0][r] + r1[(0 * 16 + r) * 64 + lane];
+                o.y = acc[1][r] + r1[(1 * 16 + r) * 64 + lane];
+                o.z = acc[2][r] + r1[(2 * 16 + r) * 64 + lane];
+                o.w = acc[3][r] + r1[(3 * 16 + r) * 64 + lane];
+                *reinterpret_cast<float4*>(slabs + ((long long)blockIdx.x * M + m) * N + n0) = o;
+            }
+        }
+    }
+}
+
 // sums split-K slabs and applies the epilogue.  one thread per output element.
 __global__ void gemm_splitk_reduce_kernel(const float* slabs, float* C, int M, int N,   // (C may be the slabs: staged reduction)
                                           int ldc, int splits, long long slab_stride, long long sWs_batch,
@@ -1194,6 +1319,7 @@ static int gemm_entry(int mode /* 0 f32-input MFMA, 3 split-bf16, 1 plain bf16 *
     const int tn = N > 64 ? 2 : 1;
     int rc;
     static const bool fewrows_on = !(getenv("LPD_FEWROWS") && atoi(getenv("LPD_FEWROWS")) == 0);
+    static const bool rows32_on = fewrows_on;
     // (measured, the hidden projection on one stream: 1 row 32.8 -> 23.4 us, 4 rows 36.5 -> 30 us, 8 rows no gain; 32 rows 42.4 -> 61.4 us
     //  -- 128 partial sums per lane make the wide form FMA- and register-bound -- so the stream form serves up to FR_MAXM rows)
     constexpr int FR_MAXM = 4;
@@ -1214,6 +1340,19 @@ static int gemm_entry(int mode /* 0 f32-input MFMA, 3 split-bf16, 1 plain bf16 *
         else LPD_FEWROWS(4);
 #undef LPD_FEWROWS
         LPD_CHECK_LAUNCH("lpd_gemm(few rows, weight stream)");
+        splits = nsl;
+        g.sCsplit = (long long)M * N;
+        rc = LPD_OK;
+    } else
+    if (rows32_on && splits > 1 && !x3 && !a_kmajor && b_kmajor && batch == 1 && M > FR_MAXM && M <= 32 && N % 256 == 0 && K >= 8192 && ldb % 4 == 0 &&
+        (((uintptr_t)B | (uintptr_t)splitk_ws) & 15) == 0 && (long long)((K + R32_KPER - 1) / R32_KPER) <= (long long)splits) {
+        // 5 .. 32 rows: the weight stream through the f32-input MFMA (linear_rows32_kernel), K / R32_KPER slabs
+        const int nsl = (K + R32_KPER - 1) / R32_KPER;
+        const size_t lds = (size_t)R32_LDS_FLOATS * sizeof(float);      // 64 KiB >= the 33-KiB X slice
+        static_assert(R32_LDS_FLOATS >= R32_KPER * R32_XLD, "the exchange region covers the X slice");
+        (void)hipFuncSetAttribute((const void*)linear_rows32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(linear_rows32_kernel, dim3(nsl, N / 256), dim3(512), lds, stream, A, lda, B, ldb, splitk_ws, M, N, K);
+        LPD_CHECK_LAUNCH("lpd_gemm(rows32, weight stream)");
         splits = nsl;
         g.sCsplit = (long long)M * N;
         rc = LPD_OK;

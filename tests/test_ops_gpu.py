@@ -295,11 +295,13 @@ def test_gemm_modes(cuda, M, N, K, ak, bk, exact):
 
 @pytest.mark.parametrize("M,N,K,splits", [(1, 256, 4096, 16), (17, 200, 5000, 20), (32, 256, 65536, 256), (44, 256, 8200, 32),
                                           (64, 72, 3000, 12), (65, 256, 4096, 16),
-                                          (1, 256, 65536, 512), (2, 256, 16384, 64), (3, 512, 8292, 40), (4, 256, 65536, 256), (9, 256, 16384, 128)])
+                                          (1, 256, 65536, 512), (2, 256, 16384, 64), (3, 512, 8292, 40), (4, 256, 65536, 256), (9, 256, 16384, 128),
+                                          (5, 512, 8292, 40), (31, 256, 8200, 40), (32, 256, 65536, 512), (24, 256, 65536, 512)])
 def test_gemm_splitk_few_rows(cuda, M, N, K, splits):
     """Few rows against a k-major weight matrix (NetVLAD hidden projection, per-cloud layers): the column-streaming split-K
-    kernel for M <= 64 (M = 65: the MFMA kernel), the weight-stream kernel for M <= 4, N % 256 == 0, K >= 8192 (every row tile,
-    a ragged last k-slice, two column blocks), ragged K / N, epilogue applied by the slab reduction, output slice."""
+    kernel for M <= 64 (M = 65: the MFMA kernel), the weight-stream kernels for N % 256 == 0, K >= 8192 -- M <= 4 on the VALU, 5 .. 32 rows
+    through the f32-input MFMA (every row count class, a ragged last k-slice, two column blocks) --, ragged K / N, epilogue applied by
+    the slab reduction, output slice."""
     ops = _ops()
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn(M, K + 4, generator=g)[:, :K]
