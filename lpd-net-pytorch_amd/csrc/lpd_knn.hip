@@ -1324,8 +1324,46 @@ __global__ __launch_bounds__(WAVES * SPLIT * 64, ((SPLIT > 1 && CP == 2) ? 3 : K
         }
         return -1;
     };
+    // Round 6: the same eight-at-a-time test for the table in LDS (N <= 4096, one wave per tile).  find_next_walk reads ONE bound, votes
+    // and branches per candidate tile -- a dependent LDS round trip for each of the cloud's 128 tiles: 65 k of a wave's 276 k cycles went
+    // into the walk (tools/knn7_stats.py) for 23 visited tiles.  Eight independent ds_read_u16 per trip, the votes on cached bounds.
+    auto find_next_lds8 = [&]() -> int {
+        while (spos < 2 * nt) {
+            if (spos >= cbase + 8) {
+                cbase = spos & ~7;
+                cvalid = 0;
+                uint32_t raw[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int T = walk_tile(cbase + j);
+                    const bool ok = T >= 0 && T < nt;                                   // uniform
+                    cvalid |= (ok ? 1u : 0u) << j;
+                    raw[j] = (uint32_t)ubt[(ok ? T : W) * 32 + col];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ubp[j] = raw[2 * j] | (raw[2 * j + 1] << 16);
+            }
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float ub = __uint_as_float((j & 1) ? (ubp[j >> 1] & 0xffff0000u) : (ubp[j >> 1] << 16));
+                m |= (__any(ub >= thrv) ? 1u : 0u) << j;
+            }
+            m &= cvalid & ~((1u << (spos - cbase)) - 1u);          // tiles of the cloud, not yet consumed
+            if (m == 0) { spos = cbase + 8; continue; }
+            const int j = __builtin_ctz(m);
+            spos = cbase + j + 1;
+            if constexpr ((CP == 32) && !ONFLY && !FULLT) stat_fn += j + 1;
+            return walk_tile(cbase + j);
+        }
+        return -1;
+    };
+    // (The same batching for three coordinates -- centroids and radii of eight walk positions requested together, eight bounds cached
+    //  -- made the xyz walk SLOWER, 177 -> 201 us at 32 clouds: its per-tile test is a scalar load and a dozen vector instructions, not a
+    //  dependent LDS round trip, and the cached form re-votes eight bounds per call.)
     auto find_next = [&]() -> int {
         if constexpr (ONFLY && CP == 32) { if (ubq) return find_next_tab(); }
+        if constexpr (!ONFLY && CP == 32 && SPLIT == 1) return find_next_lds8();
         return find_next_walk();
     };
     auto drain = [&]() {
