@@ -23,6 +23,23 @@
  *     "channel-major" = the reference's [B][C][N].
  *   - activation codes: 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 sigmoid.
  */
+/*
+ * Entry points that are NOT on a default path (tools/abi_coverage.py, profiles/r06_abi_coverage.txt: eval forwards and train steps of
+ * every trunk in both storage modes and both product modes, ragged cloud sizes, the callers' helpers -- 81 of the 101 entry points
+ * are called, 3 more are infrastructure: lpd_version, lpd_last_error, lpd_knn_pm_layout).  The 17 below are SUPERSEDED formulations,
+ * kept because tests use them as on-device cross-checks of the fused kernels that replaced them; the Python mirror reaches them only
+ * through an LPD_DEBUG token.  A binding that wants the product path does not need them:
+ *   lpd_gemm_bf16x1                      one bf16 product per term (LPD_DEBUG=bf16-x1)
+ *   lpd_split_panels                     fp32 panels -> split bf16 planes as a pass of its own (the producers write planes)
+ *   lpd_edge_gather_max                  K-agg with every gather through L2 (superseded by the cloud-resident / windowed kernels)
+ *   lpd_group_max, lpd_group_max_bwd, lpd_scatter_add_rows, lpd_edge_split_fwd (wave-per-point form)
+ *                                        materialised [M k, C] edge tensors of rounds 1-2 (the split-form stage works from gather sums)
+ *   lpd_edge_build_bf16, lpd_edge_act_max_bf16, lpd_group_sel_stats_bf16, lpd_edge_bn_bwd_bf16, lpd_edge_bn_bwd_bf16_sel,
+ *   lpd_gemm_bf16s, lpd_gemm_bf16s_bnbwd, lpd_gather_sum_rows_bf16
+ *                                        round 3's chain of passes for the bf16-storage DG1 -> DG2 stage (one launch forward, two backward now)
+ *   lpd_gemm_tn_bf16 (+ _ws_floats)      weight gradients on the register-transposing kernel (superseded by the transposed-read kernel)
+ * The kNN `impl` values 1 / 2 / 4 / 6 of lpd_knn are test cross-checks and A/B timing forms as well (see lpd_knn below).
+ */
 #ifndef LPD_HIP_H
 #define LPD_HIP_H
 

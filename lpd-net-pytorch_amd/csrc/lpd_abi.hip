@@ -1,6 +1,9 @@
 // lpd_abi.hip -- error text + version for the C-ABI (include/lpd_hip.h).
 #include "lpd_common.h"
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
 
 static thread_local char g_lpd_err[512] = "";
 
@@ -13,6 +16,27 @@ void lpd_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* lpd_last_error(void) { return g_lpd_err; }
+
+// LPD_DEBUG tokens (lpd_common.h): parsed on every call -- the callers keep the result in a function-local static
+int lpd_debug(const char* name, int dflt)
+{
+    const char* e = getenv("LPD_DEBUG");
+    if (!e) return dflt;
+    const size_t nl = strlen(name);
+    for (const char* p = e; *p;) {
+        while (*p == ',' || *p == ' ') ++p;
+        const char* q = p;
+        while (*q && *q != ',') ++q;
+        const size_t len = (size_t)(q - p);
+        if (len >= nl && strncasecmp(p, name, nl) == 0) {
+            if (len == nl) return 1;
+            if (p[nl] == '=') return atoi(p + nl + 1);
+        }
+        if (len == nl + 3 && strncasecmp(p, "no-", 3) == 0 && strncasecmp(p + 3, name, nl) == 0) return 0;
+        p = q;
+    }
+    return dflt;
+}
 extern "C" int lpd_version(void) { return 100; }  // 0.1.0
 
 // ---- workspace of the cross-block column statistics (lpd_common.h): owned by the caller ----

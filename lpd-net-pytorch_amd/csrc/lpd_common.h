@@ -12,6 +12,11 @@
 // thread-local last-error text (lpd_last_error()); defined in lpd_abi.hip
 void lpd_set_error(const char* fmt, ...);
 
+// A/B ablation switches: ONE environment variable, LPD_DEBUG = "name,no-name,name=value,..." (read once; README.md lists the names;
+// lpdnet_hip/_debug.py reads the same variable).  Value of `name` (a bare name is 1, no-name is 0), else dflt.  For timing comparisons
+// and tests of superseded paths only: the product never needs it set.
+int lpd_debug(const char* name, int dflt);
+
 #define LPD_CHECK_ARG(cond, ...)          \
     do {                                  \
         if (!(cond)) {                    \

@@ -1522,8 +1522,8 @@ static int edge_gather_max16_impl(const float* P, int ldp, const float* Q, int l
     const int nslices = C / 8;
     const size_t lds = (size_t)KAGG_IMG1 + (size_t)N * 16;
     const float ns = act == 0 ? 1.0f : (act == 1 ? 0.0f : slope);
-    // persistent form: one workgroup per CU, (items / 256 CUs) consecutive items each; LPD_KAGG_PERSIST = 0 disables, n forces n
-    static const int persist = getenv("LPD_KAGG_PERSIST") ? atoi(getenv("LPD_KAGG_PERSIST")) : -1;
+    // persistent form: one workgroup per CU, (items / 256 CUs) consecutive items each; LPD_DEBUG=kagg-persist=0 disables, n forces n
+    static const int persist = lpd_debug("kagg-persist", -1);
     const int nwork = (M / N) * nslices;
     const int per_auto = (nwork + 255) / 256;
     const bool persistent = persist != 0 && N > 3584 && N <= 4096 && (persist > 0 ? persist : per_auto) >= 3;   // eight passes of 512
@@ -1675,7 +1675,7 @@ extern "C" int lpd_edge_mlp_train_bwd(const void* Z, const uint8_t* arg2, const 
 // k = 20, N <= 4096, C % 8 == 0, row-major P / Q.
 extern "C" int lpd_edge_split_fwd16_applies(int N, int C, int k)
 {
-    static const bool on = [] { const char* e = getenv("LPD_SPLIT_LDS"); return !(e && e[0] == '0'); }();
+    static const bool on = lpd_debug("split-lds", 1) != 0;
     return on && k == 20 && N >= 32 && N <= 4096 && C > 0 && C % 8 == 0 && C <= LPD_STAT_CMAX;
 }
 

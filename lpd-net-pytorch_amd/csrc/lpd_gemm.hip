@@ -1318,7 +1318,7 @@ static int gemm_entry(int mode /* 0 f32-input MFMA, 3 split-bf16, 1 plain bf16 *
     }
     const int tn = N > 64 ? 2 : 1;
     int rc;
-    static const bool fewrows_on = !(getenv("LPD_FEWROWS") && atoi(getenv("LPD_FEWROWS")) == 0);
+    static const bool fewrows_on = lpd_debug("fewrows", 1) != 0;
     static const bool rows32_on = fewrows_on;
     // (measured, the hidden projection on one stream: 1 row 32.8 -> 23.4 us, 4 rows 36.5 -> 30 us, 8 rows no gain; 32 rows 42.4 -> 61.4 us
     //  -- 128 partial sums per lane make the wide form FMA- and register-bound -- so the stream form serves up to FR_MAXM rows)
@@ -1486,7 +1486,7 @@ static void x3w_wide_launch(const X3wArgs& g, int NT, hipStream_t stream)
     if constexpr (WN == 1) {
         if (NT <= 2) { x3w_wide_launch_kc<1, PANELS, 32, true>(g, NT, stream); return; }   // N <= 64: the NetVLAD assignment
     }
-    static const int kc64 = getenv("LPD_X3W_KC") ? atoi(getenv("LPD_X3W_KC")) == 64 : 0;   // experiment: 64-deep chunks
+    static const int kc64 = lpd_debug("x3w-kc", 0) == 64;   // experiment: 64-deep chunks
     if (kc64 && g.K % 64 == 0) { x3w_wide_launch_kc<WN, PANELS, 64>(g, NT, stream); return; }
     x3w_wide_launch_kc<WN, PANELS, 32>(g, NT, stream);
 }
@@ -1539,7 +1539,7 @@ static int gemm_x3w_impl(const float* A, int lda, const void* frags, float* C, i
     if (a_scale) impl = 2;
     {   // (it matters for a row-major A with a power-of-two row stride; applied to every layout so that the summation
         //  order -- and with it every bit of the result -- does not depend on the layout of A)
-        static const int rot = getenv("LPD_X3W_ROTATE") ? atoi(getenv("LPD_X3W_ROTATE")) : 1;
+        static const int rot = lpd_debug("x3w-rotate", 1);
         g.rotate = rot;
     }
     // impl: 0 = by shape, 2 = 128 x 128 blocks, 3 = 128 x 256 blocks

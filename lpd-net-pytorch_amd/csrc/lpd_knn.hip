@@ -1670,10 +1670,10 @@ inline size_t knn7_extra_floats(int B, int N, int CP)
     return n;
 }
 
-// the low-precision bound pass (LPD_KNN_PRE=0: centroid / radius bounds) and where its bf16 operand image lives in the workspace
+// the low-precision bound pass (LPD_DEBUG=knn-pre=0: centroid / radius bounds) and where its bf16 operand image lives in the workspace
 inline bool knn7_tight()
 {
-    static const bool tight = !(getenv("LPD_KNN_PRE") && atoi(getenv("LPD_KNN_PRE")) == 0);
+    static const bool tight = lpd_debug("knn-pre", 1) != 0;
     return tight;
 }
 inline __bf16* knn7_xb_of(const float* xx, int B, int N)      // 64 channels (CP = 32), one wave per workgroup
@@ -1703,7 +1703,7 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
     LPD_CHECK_LAUNCH("lpd_knn(tile pre-pass)");
     constexpr int WAVES = 1;
     const int bpc = (N + WAVES * 32 - 1) / (WAVES * 32);
-    static const bool lpt = !(getenv("LPD_KNN_ORDER") && atoi(getenv("LPD_KNN_ORDER")) == 0);
+    static const bool lpt = lpd_debug("knn-order", 1) != 0;
     int32_t* pred = reinterpret_cast<int32_t*>(txmax + (size_t)B * nt + 4);
     int32_t* order = pred + (size_t)B * nt;
     const int nitems = bpc * B;
@@ -1722,12 +1722,12 @@ int knn7_launch(const float* x, const float* xx, int32_t* idx, int B, int C, int
             LPD_CHECK_LAUNCH("lpd_knn(low-precision bounds)");
         }
     }
-    static const bool branchy = getenv("LPD_KNN_FULLT") && atoi(getenv("LPD_KNN_FULLT")) == 0;     // 0: the branchy tile body for every N
-    // Small batches: KNN7_SPLIT waves per query tile (see knn7_kernel).  LPD_KNN_SPLIT=0 never, =1 always (where it is built); default:
+    static const bool branchy = lpd_debug("knn-fullt", 1) == 0;     // 0: the branchy tile body for every N
+    // Small batches: KNN7_SPLIT waves per query tile (see knn7_kernel).  LPD_DEBUG=knn-split=0 never, =1 always (where it is built); default:
     // while the split grid fits the wave slots of the chip (256 CUs x 4 SIMDs x waves per SIMD).
     constexpr int KNN7_SPLIT = 4;
     constexpr bool split_built = KMAX <= 20 && !(ONFLY && CP == 32);
-    static const int split_env = getenv("LPD_KNN_SPLIT") ? atoi(getenv("LPD_KNN_SPLIT")) : -1;
+    static const int split_env = lpd_debug("knn-split", -1);
     // Measured (tools/knn_split_bench.py, one stream, N = 4096): 1 cloud 193 -> 144 us (64 channels) / 136 -> 92 us (xyz); 6 clouds
     // 221 -> 239 / 142 -> 116; 10 clouds 233 -> 313 / 155 -> 186; 16 clouds 262 -> 421 / 158 -> 259: the split launch does MORE work
     // (every wave pays the first tile's 16-entry drain, the early thresholds are looser, the lists are merged twice), so it pays

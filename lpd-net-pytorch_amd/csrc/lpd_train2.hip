@@ -1717,17 +1717,17 @@ __global__ __launch_bounds__(512, (A16 && TB != 256) ? 4 : 2) void gemm_tn_tr_ke
 
 }  // namespace
 
-// the 256 x 256-tile kernel: wide products over whole 32-row chunks (LPD_TN256=0 keeps the 128-wide kernel)
+// the 256 x 256-tile kernel: wide products over whole 32-row chunks (LPD_DEBUG=tn256=0 keeps the 128-wide kernel)
 static bool gemm_tn_256(long long M, int KA, int KB, int batch)
 {
-    static const bool on = [] { const char* e = getenv("LPD_TN256"); return !(e && e[0] == '0'); }();
+    static const bool on = lpd_debug("tn256", 1) != 0;
     return on && batch == 1 && KA % 256 == 0 && KB % 256 == 0 && M % 32 == 0 && M >= 8192;
 }
 
-// the transposed-read kernel (gemm_tn_tr_kernel): b-channels per block, or 0 where it is not built (LPD_TN_TR=0: never)
+// the transposed-read kernel (gemm_tn_tr_kernel): b-channels per block, or 0 where it is not built (LPD_DEBUG=tn-tr=0: never)
 static int tn_tr_tb(long long M, int KA, int KB, int batch, bool a_bf16, bool act = false)      // act: with the operand transform (this kernel only)
 {
-    static const bool on = [] { const char* e = getenv("LPD_TN_TR"); return !(e && e[0] == '0'); }();
+    static const bool on = lpd_debug("tn-tr", 1) != 0;
     if (KA % 256 != 0 || KB % 64 != 0 || M % 32 != 0 || M < 2048) return 0;
     if (act) return KB % 256 == 0 ? 256 : (KB % 128 == 0 ? 128 : 64);
     if (!on) return 0;

@@ -919,10 +919,10 @@ extern "C" int lpd_bn_sel_bwd_reduce_f32(const float* dOut, long long ldo, const
     return bn_sel_bwd_reduce_impl(dOut, ldo, Xsel, ldsel, M, C, scale, shift, mean, invstd, act, slope, nullptr, dpre, dbeta, dgamma, stat_ws, stream);
 }
 
-// LPD_DW_SEL_TR=0: the register-transposing kernels
+// LPD_DEBUG=dw-sel-tr=0: the register-transposing kernels
 static bool edge_dw_sel_tr()
 {
-    static const bool on = [] { const char* e = getenv("LPD_DW_SEL_TR"); return !(e && e[0] == '0'); }();
+    static const bool on = lpd_debug("dw-sel-tr", 1) != 0;
     return on;
 }
 
@@ -955,8 +955,8 @@ extern "C" int lpd_edge_dw_sel_bf16(const uint16_t* Y, const uint8_t* arg, const
     double* red = reinterpret_cast<double*>(ws);
     float* slabs = reinterpret_cast<float*>(red + n);
     // (bf16 tensors: measured 343 us against 326 on the register-transposing kernel -- one product per term, the staging is copies
-    //  either way; the transposed-read kernel runs for LPD_DW_SEL_TR=2 only)
-    static const bool tr16 = [] { const char* e = getenv("LPD_DW_SEL_TR"); return e && e[0] == '2'; }();
+    //  either way; the transposed-read kernel runs for LPD_DEBUG=dw-sel-tr=2 only)
+    static const bool tr16 = lpd_debug("dw-sel-tr", 1) == 2;
     if (tr16 && E < (1ll << 32)) {
         constexpr int lds_tr = 2 * 2 * 32 * 320;
         (void)hipFuncSetAttribute((const void*)edge_dw_sel_tr_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_tr);

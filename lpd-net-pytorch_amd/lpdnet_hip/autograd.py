@@ -7,7 +7,7 @@ import ctypes
 
 import torch
 
-from . import _lib, ops
+from . import _debug, _lib, ops
 from .ops import _ptr, _req, _stream
 
 
@@ -166,12 +166,12 @@ TRAIN_STORAGE = "f32"
 
 
 # bf16 storage also keeps the [B N, 1024] conv3 map -- the raw conv3 output, its activated form and both gradients -- in bf16 where the
-# trunk hands the raw map to the NetVLAD head (PointNetVlad's train path, lpdnet_features_train(defer_act=True)); LPD_MAP_BF16=0: fp32 map
-MAP_BF16 = __import__("os").environ.get("LPD_MAP_BF16", "1") != "0"
+# trunk hands the raw map to the NetVLAD head (PointNetVlad's train path, lpdnet_features_train(defer_act=True)); LPD_DEBUG=map-bf16=0: fp32 map
+MAP_BF16 = _debug.on("map-bf16")
 # ... and a bf16 COPY of the point features [x1 | x2 | x3] beside the fp32 ones (written by the activation passes that produce them):
-# conv3 takes it as bf16 rows (two products per term), its weight gradient as bf16 rows on both sides (one).  LPD_CAT_BF16=0: off
-CAT_BF16 = __import__("os").environ.get("LPD_CAT_BF16", "1") != "0"
-PQ3_BF16 = __import__("os").environ.get("LPD_PQ3_BF16", "1") != "0"      # ... and the gradient of the SN1 projection [B N, 512]
+# conv3 takes it as bf16 rows (two products per term), its weight gradient as bf16 rows on both sides (one).  LPD_DEBUG=cat-bf16=0: off
+CAT_BF16 = _debug.on("cat-bf16")
+PQ3_BF16 = _debug.on("pq3-bf16")      # ... and the gradient of the SN1 projection [B N, 512]
 
 
 def set_train_storage(kind):

@@ -11,7 +11,7 @@ re-derived when any of the four BN tensors changes (tensor._version) or moves de
 """
 import torch
 
-from . import ops
+from . import _debug, ops
 
 LEAKY_SLOPE = 0.01
 
@@ -209,8 +209,8 @@ def _knn_rows(rows, B, N, C, k):
     return ops.knn(ops.transpose(rows.view(B, N, C).contiguous()), k)
 
 
-# cloud-panel [B, C/8, N, 8] buffers for x1|x2|x3 and the SN1 projections (LPD_PANELS=0: row-major everywhere)
-PANEL_LAYOUT = __import__("os").environ.get("LPD_PANELS", "1") != "0"
+# cloud-panel [B, C/8, N, 8] buffers for x1|x2|x3 and the SN1 projections (LPD_DEBUG=panels=0: row-major everywhere)
+PANEL_LAYOUT = _debug.on("panels")
 # The second HIP stream of the eval path: ONE rule per batch class (round 5; DESIGN.md "HIP streams").
 #   * batches of at most SIDE_SMALL_POINTS points (24 clouds x 4096): the xyz kNN, the DG1 projection and the DG1-stage K-agg run on a
 #     second stream next to the feature-space kNN and the fused edge MLP.  A small batch leaves most of the chip idle -- one cloud's kNN
@@ -409,7 +409,7 @@ def _replay(ent, x):
     return ent.out.clone()
 
 
-FUSED_FRONT = __import__("os").environ.get("LPD_FUSED_FRONT", "1") != "0"   # conv1 + conv2 + kNN operands in one launch (no T-Nets)
+FUSED_FRONT = _debug.on("fused-front")   # conv1 + conv2 + kNN operands in one launch (no T-Nets)
 _SIDE = {}
 _SIDE_LOCK = __import__("threading").Lock()      # nn.DataParallel calls forward from one host thread per device
 
@@ -421,7 +421,7 @@ def _side_stream(device):
         if st is None:
             # high priority: its kernels are the short ones that fill in next to the long kernels of the main stream (measured:
             # 2.39 -> 2.33 ms per step; at default priority the overlap even turned into a loss once RCCL's own streams existed)
-            st = _SIDE[key] = torch.cuda.Stream(device=device, priority=int(__import__('os').environ.get('LPD_SIDE_PRIO', '-1')))
+            st = _SIDE[key] = torch.cuda.Stream(device=device, priority=_debug.value("side-prio", -1))
     return st
 
 
@@ -434,8 +434,8 @@ def _kagg_cloud_resident(idx, N, M, act):
     return _resident_shape(idx.shape[-1], N, M, act)
 
 
-KAGG_WINDOW = __import__("os").environ.get("LPD_KAGG_WINDOW", "1") != "0"
-CONV3_P8 = __import__("os").environ.get("LPD_P8", "1") != "0"      # conv3 on lpd_gemm_p8 with split-bf16 [x1 | x2 | x3] planes (0: lpd_gemm_x3w)
+KAGG_WINDOW = _debug.on("kagg-window")
+CONV3_P8 = _debug.on("p8")      # conv3 on lpd_gemm_p8 with split-bf16 [x1 | x2 | x3] planes (0: lpd_gemm_x3w)
 
 
 def _kagg_windowed(idx, N, act):
@@ -462,7 +462,7 @@ def split_mfea(x):
     return rows[:, :3].contiguous(), rows
 
 
-FUSE_ASSIGN = __import__("os").environ.get("LPD_FUSE_ASSIGN", "1") != "0"    # conv3 + the NetVLAD assignment product in one launch
+FUSE_ASSIGN = _debug.on("fuse-assign")    # conv3 + the NetVLAD assignment product in one launch
 
 
 def lpdnet_features_eval(net, x, reorder=True, assign=None):

@@ -7,7 +7,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _debug, _lib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 
@@ -160,7 +160,7 @@ def _vec(t, name, n):
     return t.contiguous()
 
 
-KNN_IMPL = int(__import__("os").environ.get("LPD_KNN_IMPL", "0"))   # A/B switch for benchmarking (0 = product kernel)
+KNN_IMPL = _debug.value("knn-impl", 0)   # A/B switch for benchmarking (0 = product kernel)
 
 
 def knn_workspace_floats(B, C, N, k=20):
@@ -250,9 +250,9 @@ _EXACT = _ExactState()
 # itself at 0.5e-4) -- so batches of fewer than TRAIN_FWD_X3_MIN_CLOUDS clouds keep the exact f32-input MFMA (at 16 clouds the flip-free gradient gate of 3e-3 still sees 4.8e-3).  From 32 clouds on
 # (BASELINE configs[2]: 44) the head's BatchNorms average over enough rows: measured on the reference's B = 44, N = 4096 step-0
 # fixture the split-bf16 forward stays as close to the reference's fp64 forward as the exact one (tests/test_train_gpu.py,
-# cfg2 test), and the forward products of a step cost 2.2 ms instead of 4.8.  LPD_TRAIN_FWD_X3 = 1 / 0: always / never.
+# cfg2 test), and the forward products of a step cost 2.2 ms instead of 4.8.  LPD_DEBUG=train-fwd-x3=1 / 0: always / never.
 # Eval forward and every backward product use the fast form regardless.
-_tfx = __import__("os").environ.get("LPD_TRAIN_FWD_X3", "auto")
+_tfx = _debug.value("train-fwd-x3", "auto")
 TRAIN_FWD_BF16X3 = "auto" if _tfx == "auto" else (_tfx == "1")
 TRAIN_FWD_X3_MIN_CLOUDS = 32
 
@@ -266,12 +266,12 @@ _FAST = _FastState()
 
 # Measured on the bf16 training step (B = 44, N = 4096): one product instead of three changes the fp32-operand GEMMs by
 # -0.4 ms of 18.6 (conv3 forward 0.70 -> 0.56 ms, its dX 0.57 -> 0.43; the k-major weight-gradient products not at all: they are
-# bound by staging, not by the MFMA) and costs another factor ~2 on the loss error, so it is off unless LPD_BF16_X1=1.
-BF16_SINGLE_PRODUCT = os.environ.get("LPD_BF16_X1", "0") == "1"
+# bound by staging, not by the MFMA) and costs another factor ~2 on the loss error, so it is off unless LPD_DEBUG=bf16-x1=1.
+BF16_SINGLE_PRODUCT = _debug.on("bf16-x1", False)
 
 
 class bf16_gemm:
-    """with ops.bf16_gemm(): (LPD_BF16_X1=1 only) split-bf16 products on fp32 operands run with ONE bf16 product per term
+    """with ops.bf16_gemm(): (LPD_DEBUG=bf16-x1=1 only) split-bf16 products on fp32 operands run with ONE bf16 product per term
     (operands rounded to bf16, fp32 accumulation) instead of three.  exact_gemm() regions inside stay exact."""
 
     def __enter__(self):
@@ -317,11 +317,11 @@ class train_forward_gemm(exact_gemm):
 
 _FRAG_CACHE = {}
 _FRAG_LOCK = __import__("threading").Lock()     # nn.DataParallel-style callers: one forward per device thread
-X3W_FORWARD = os.environ.get("LPD_X3W_FWD", "1") != "0"    # forward layers with K >= 256 on the prepared-fragment kernel
-X3W_IMPL = int(os.environ.get("LPD_X3W_IMPL", "0"))         # lpd_gemm_x3w impl (0 = by shape); benchmarking only
-X3W_BATCHED = os.environ.get("LPD_X3W_BATCHED", "1") != "0"  # batched deep-reduction products with per-problem k-major weights on lpd_gemm_x3w_batched
-X3T_PANELS = os.environ.get("LPD_X3T", "1") != "0"          # short-reduction panel-to-panel products on lpd_gemm_x3t
-X3T_ROWS = os.environ.get("LPD_X3T_ROWS", "1") != "0"       # ... and row-major ones (K = 64 / 128) on lpd_gemm_x3t_rows
+X3W_FORWARD = _debug.on("x3w-fwd")    # forward layers with K >= 256 on the prepared-fragment kernel
+X3W_IMPL = _debug.value("x3w-impl", 0)         # lpd_gemm_x3w impl (0 = by shape); benchmarking only
+X3W_BATCHED = _debug.on("x3w-batched")  # batched deep-reduction products with per-problem k-major weights on lpd_gemm_x3w_batched
+X3T_PANELS = _debug.on("x3t")          # short-reduction panel-to-panel products on lpd_gemm_x3t
+X3T_ROWS = _debug.on("x3t-rows")       # ... and row-major ones (K = 64 / 128) on lpd_gemm_x3t_rows
 
 
 def _weight_frags(B2, b_kmajor, N, K):
@@ -540,7 +540,7 @@ def split_to_rows(S):
     return x.permute(0, 2, 1, 3).reshape(Bc * N, Pn * 8).contiguous()
 
 
-P8_IMPL = int(os.environ.get("LPD_P8_IMPL", "0"))
+P8_IMPL = _debug.value("p8-impl", 0)
 
 
 def gemm_x3t_split(S, W, *, out=None):
@@ -815,7 +815,7 @@ def edge_gather_max16(P, Q, idx16, N, *, scale=None, shift=None, act=ACT_NONE, s
     return out
 
 
-KAGGW_PERMUTE = os.environ.get("LPD_KAGGW_PERMUTE", "1") != "0"   # windowed K-agg: every list with its out-of-window neighbours first
+KAGGW_PERMUTE = _debug.on("kaggw-permute")   # windowed K-agg: every list with its out-of-window neighbours first
 
 
 def pack_idx16w(idx, N=None):
@@ -1071,7 +1071,7 @@ def bn_train_stats(X, bn, rows=None):
     return _bn_finalize(sums, R, C, bn)
 
 
-STATS_IN_GEMM = os.environ.get("LPD_GEMM_STATS", "1") != "0"
+STATS_IN_GEMM = _debug.on("gemm-stats")
 
 
 STAT_CMAX = 1024      # columns of the statistics workspace (csrc/lpd_common.h LPD_STAT_CMAX): lpd_gemm_x3w_stats refuses wider layers
@@ -1116,7 +1116,7 @@ def linear_bn_stats(x, w, bn, bias=None, out_bf16=False):
     return y, bn_train_stats(y, bn)
 
 
-ASSIGN_ACT = os.environ.get("LPD_ASSIGN_ACT", "1") != "0"     # train mode: bn3 affine + act inside the NetVLAD assignment product's loader
+ASSIGN_ACT = _debug.on("assign-act")     # train mode: bn3 affine + act inside the NetVLAD assignment product's loader
 
 
 def gemm_act_applies(M, N, K):
@@ -1355,7 +1355,7 @@ def post_consts(post_bn, act, slope):
     the forward, so a parameter that changes between forward and backward cannot give an inconsistent xhat (beta is copied).
     A channel whose gamma is exactly 0 has no recoverable xhat (its Y1e is the constant act(beta)): 1 / gamma := 0 there, i.e. that
     channel's dgamma comes out 0 instead of sum(dpre xhat) -- the one case in which this path differs from the U1-storing chain
-    (LPD_EDGE_MLP_TRAIN=0), which a model with an exactly-zero BatchNorm scale should use."""
+    (LPD_DEBUG=edge-mlp-train=0), which a model with an exactly-zero BatchNorm scale should use."""
     if act not in (ACT_NONE, ACT_LEAKY) or (act == ACT_LEAKY and not 0.0 < slope <= 1.0):
         raise ValueError("post-activation edge tensors need an invertible activation (none / LeakyReLU with 0 < slope <= 1)")
     g = post_bn.weight.detach()
@@ -1488,7 +1488,7 @@ def edge_split_fwd(P, Q, idx, N, bn):
     return S, usel, arg, _bn_finalize(sums, M * k, C, bn)
 
 
-SPLIT_BWD_BF16 = os.environ.get("LPD_SPLIT_BWD_BF16", "1") != "0"   # bf16 storage: the SN1 backward gathers bf16 rows of G and Q
+SPLIT_BWD_BF16 = _debug.on("split-bwd-bf16")   # bf16 storage: the SN1 backward gathers bf16 rows of G and Q
 
 
 def edge_split_bwd(dOut, usel, arg, S, P, Q, graph, st, act, slope, k, dP, dQ, half=False):
@@ -1608,10 +1608,10 @@ def edge_bn_bwd_bf16(dOut, arg, k, X, st, act, slope, dense=None, dQ=None, xsel=
     return dX, redf[1], redf[0]
 
 
-EDGE_MLP_TRAIN = os.environ.get("LPD_EDGE_MLP_TRAIN", "1") != "0"      # train-mode DG1 -> DG2 stage in one launch (lpd_edge_mlp_train)
+EDGE_MLP_TRAIN = _debug.on("edge-mlp-train")      # train-mode DG1 -> DG2 stage in one launch (lpd_edge_mlp_train)
 
 
-EDGE_MLP_TRAIN_BWD = os.environ.get("LPD_EDGE_MLP_TRAIN_BWD", "1") != "0"   # ... and its backward in two launches (lpd_edge_mlp_train_bwd)
+EDGE_MLP_TRAIN_BWD = _debug.on("edge-mlp-train-bwd")   # ... and its backward in two launches (lpd_edge_mlp_train_bwd)
 
 
 def edge_mlp_train_applies(M, N, k, C, act, slope):
@@ -1619,10 +1619,10 @@ def edge_mlp_train_applies(M, N, k, C, act, slope):
             and (act == ACT_NONE or (act == ACT_LEAKY and 0.0 < slope <= 1.0)))
 
 
-Z_BF16 = os.environ.get("LPD_Z_BF16", "1") != "0"      # fp32 storage mode: the stored Z of the DG2 stage as bf16 (see lpd_edge_mlp_train)
+Z_BF16 = _debug.on("z-bf16")      # fp32 storage mode: the stored Z of the DG2 stage as bf16 (see lpd_edge_mlp_train)
 
 
-EDGE_NOZ = os.environ.get("LPD_EDGE_NOZ", "1") != "0"     # bf16 storage: the DG2 output Z is not stored; its backward term is Y1e K (lpd_edge_mlp_train_bwd)
+EDGE_NOZ = _debug.on("edge-noz")     # bf16 storage: the DG2 output Z is not stored; its backward term is Y1e K (lpd_edge_mlp_train_bwd)
 
 
 def edge_mlp_train(P, Q, idx, N, scale1, shift1, W2, bn2, act, slope, bf16, z_bf16=None, store_z=True):
@@ -1809,11 +1809,11 @@ def gemm_tn_bf16(A, B):
     return dW
 
 
-DG2_BWD_FUSED = os.environ.get("LPD_DG2_BWD_FUSED", "1") != "0"    # bf16 storage: DG2 backward without the dZ tensor (lpd_train3.hip)
-GEMM_TN = os.environ.get("LPD_GEMM_TN", "1") != "0"      # weight gradients on the register-transposing kernel (lpd_gemm_tn)
+DG2_BWD_FUSED = _debug.on("dg2-bwd-fused")    # bf16 storage: DG2 backward without the dZ tensor (lpd_train3.hip)
+GEMM_TN = _debug.on("gemm-tn")      # weight gradients on the register-transposing kernel (lpd_gemm_tn)
 
 
-FEAT_IN_LOADER = os.environ.get("LPD_FEAT_IN_LOADER", "1") != "0"   # train mode: no activated conv3 map -- its consumers transform the raw one
+FEAT_IN_LOADER = _debug.on("feat-in-loader")   # train mode: no activated conv3 map -- its consumers transform the raw one
 
 
 def feat_in_loader_applies(B, N, E, K):

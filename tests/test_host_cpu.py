@@ -306,3 +306,28 @@ def test_bench_stdout_line_stays_parseable():
     # a record without the optional blocks (--no-train --no-secondary --no-cpu-baseline, N > 1) still yields a line
     small = bench.compact_line({k_: full[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")})
     assert small["value"] == full["value"] and small["roofline"]["frac"] == 0.5363
+
+
+def test_header_marks_superseded_entry_points_and_debug_switches_are_one_variable():
+    """include/lpd_hip.h lists the entry points that are not on a default path (measured by tools/abi_coverage.py): every name it lists
+    is a declared entry point.  The A/B ablation switches are ONE environment variable (LPD_DEBUG, lpdnet_hip/_debug.py + lpd_debug()
+    in csrc/lpd_abi.hip): no other LPD_* variable is read anywhere but the documented product switches."""
+    hdr = open(os.path.join(ROOT, "include", "lpd_hip.h")).read()
+    block = hdr[hdr.index("NOT on a default path"):hdr.index("#ifndef LPD_HIP_H")]
+    declared = set(re.findall(r"\b(lpd_[a-z0-9_]+)\s*\(", hdr[hdr.index("#ifndef LPD_HIP_H"):]))
+    listed = set(re.findall(r"\b(lpd_[a-z0-9_]+)\b", block)) - {"lpd_knn", "lpd_debug"}
+    listed = {n + "_ws_floats" if n == "_ws_floats" else n for n in listed}
+    assert len(listed) >= 17 and listed <= declared | {"lpd_hip"}, sorted(listed - declared)
+    allowed = {"LPD_DEBUG", "LPD_HIP_LIB", "LPD_GEMM_FP32", "LPD_EVAL_CHUNK", "LPD_SIDE_STREAM", "LPD_REPLAY", "LPD_EXTRA_FLAGS"}
+    read = set()
+    pkg = os.path.join(ROOT, "lpd-net-pytorch_amd")
+    for d, _, files in os.walk(pkg):
+        if os.sep + "build" in d:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(d, f)).read()
+                read |= set(re.findall(r"(?:getenv\(|environ\.get\(|environ\[)\s*[\"'](LPD_[A-Z0-9_]+)", src))
+    assert read <= allowed, sorted(read - allowed)
+    from lpdnet_hip import _debug
+    assert _debug.on("anything-unset") and not _debug.on("anything-unset", False) and _debug.value("unset-int", 7) == 7

@@ -638,7 +638,7 @@ def test_lpdnet_front_fused(cuda, B, N, k, act):
 def test_gemm_x3t_panels(cuda, K, N, act):
     """lpd_gemm_x3t (short reduction, cloud panels in and out, computed transposed: the SN1 projection): fp32-grade against a
     float64 product, every epilogue term, A and C as panel sub-ranges of wider buffers, untouched neighbours; exact mode and
-    LPD_X3T = 0 keep the generic kernels."""
+    LPD_DEBUG=x3t=0 keep the generic kernels."""
     ops = _ops()
     g = torch.Generator().manual_seed(41 + K + N)
     Bc, Np = 5, 384
@@ -1334,7 +1334,7 @@ def test_edge_mlp_train_equals_the_materialised_stage(cuda, bf16, N, k, B):
 
 
 @pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
-@pytest.mark.parametrize("N,k,B", [(320, 20, 2), (256, 16, 3), (64, 16, 1), (40, 8, 2)])      # the last two: fewer than 8 blocks in the gather pass
+@pytest.mark.parametrize("N,k,B", [(320, 20, 2), (256, 16, 3), (64, 16, 1), (64, 8, 1)])      # the last two: fewer than 8 blocks in the gather pass (N % 64 == 0 is the kernels' contract)
 def test_edge_mlp_train_bwd_equals_the_chain(cuda, bf16, N, k, B):
     """lpd_edge_mlp_train_bwd + lpd_edge_dense_bwd_apply (DG2 dY1e product with dZ built in the operand loader, the gradient in front of
     BatchNorm1 and its reductions in the epilogue, dP / dQ in closed form from one gather pass) against the chain they replace:

@@ -727,13 +727,13 @@ def test_standalone_train_mode_forwards_of_the_submodules(cuda):
     run(GatingContext(256, add_batch_norm=False), "g.", xh, gating_oracle(False), ["gating_weights", "gating_biases"])
 
 
-@pytest.mark.parametrize("env", [{"LPD_DG2_BWD_FUSED": "0", "LPD_TN256": "0", "LPD_GEMM_STATS": "0", "LPD_SPLIT_LDS": "0", "LPD_X3T_ROWS": "0"},
-                                 {"LPD_GEMM_TN": "0"},
-                                 {"LPD_EDGE_MLP_TRAIN": "0"},                                  # round 4: the DG1 -> DG2 stage on the round-3 chain
-                                 {"LPD_EDGE_MLP_TRAIN_BWD": "0", "LPD_ASSIGN_ACT": "0"},       # ... its backward on the round-3 chain, bn3 as its own pass
-                                 {"LPD_Z_BF16": "0"},
-                                 {"LPD_MAP_BF16": "0", "LPD_TN_TR": "0", "LPD_DW_SEL_TR": "0"},  # fp32 conv3 map in the bf16 mode, register-transposing dW
-                                 {"LPD_SPLIT_BWD_BF16": "0", "LPD_FEAT_IN_LOADER": "0", "LPD_X3W_BATCHED": "0", "LPD_EDGE_NOZ": "0", "LPD_CAT_BF16": "0", "LPD_PQ3_BF16": "0"}],
+@pytest.mark.parametrize("env", [{"LPD_DEBUG": "no-dg2-bwd-fused,no-tn256,no-gemm-stats,no-split-lds,no-x3t-rows"},
+                                 {"LPD_DEBUG": "no-gemm-tn"},
+                                 {"LPD_DEBUG": "no-edge-mlp-train"},                                  # round 4: the DG1 -> DG2 stage on the round-3 chain
+                                 {"LPD_DEBUG": "no-edge-mlp-train-bwd,no-assign-act"},       # ... its backward on the round-3 chain, bn3 as its own pass
+                                 {"LPD_DEBUG": "no-z-bf16"},
+                                 {"LPD_DEBUG": "no-map-bf16,no-tn-tr,no-dw-sel-tr"},  # fp32 conv3 map in the bf16 mode, register-transposing dW
+                                 {"LPD_DEBUG": "no-split-bwd-bf16,no-feat-in-loader,no-x3w-batched,no-edge-noz,no-cat-bf16,no-pq3-bf16"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_training_switches_are_live(env):
     """The training-path switches README.md documents are read at import (or at the first launch): the bf16-storage oracle

@@ -1,4 +1,4 @@
-"""Per-kernel table of one profiled program from the PMC passes of tools/prof_r05.sh:
+"""Per-kernel table of one profiled program from the PMC passes of tools/prof_round.sh:
     python tools/pmc_table.py <gpurun_out/r05prof> <tag prefix, e.g. tb or c5> [min total us]
 For every (kernel, grid): dispatches per run, mean duration (the kernel trace of the FETCH pass: durations under counter collection, a few
 per cent above an unprofiled run), HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB, summed over the XCDs; FETCH_SIZE counts half of the bytes of
