@@ -183,6 +183,8 @@ def compact_line(full, detail_name="bench_detail.json"):
             e = _pick(t, ("value", "unit", "ms_per_step", "dtype", "clouds_per_s", "steps"))
             if isinstance(t.get("cpu_baseline"), dict):
                 e["cpu_clouds_per_s"] = t["cpu_baseline"].get("clouds_per_s")
+                if isinstance(t["cpu_baseline"].get("cfg2_batch"), dict):      # the same 44-cloud step on the host cores
+                    e["cpu_steps_per_s_same_batch"] = t["cpu_baseline"]["cfg2_batch"].get("steps_per_s")
             if isinstance(t.get("exchange"), dict):
                 e["exchange"] = _pick(t["exchange"], ("allreduce_ms_per_step_isolated", "allreduce_busbw_GBps", "allreduce_exposed_ms_per_step"))
             line[name] = e
@@ -367,7 +369,7 @@ def cpu_train_baseline(points, threads, seconds_target=25.0):
         sd = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd0.items()}
         opt = torch.optim.Adam([sd[k] for k in names], lr=1e-5)
         ts = []
-        for it in range(reps + 1):
+        for it in range(max(reps, 0) + 1):
             t0 = time.time()
             opt.zero_grad(set_to_none=True)
             d = orc.pointnetvlad_forward(sd, x, featnet="lpdnet", train=True, new_stats={})
@@ -375,7 +377,7 @@ def cpu_train_baseline(points, threads, seconds_target=25.0):
             loss = orc.quadruplet_loss(q, p, n, o, 0.5, 0.2, use_min=True, lazy=True, ignore_zero_loss=False)
             loss.backward()
             opt.step()
-            if it:
+            if it or reps == 0:                      # reps == 0: the one (cold) step is the sample
                 ts.append(time.time() - t0)
             elif reps > 1 and time.time() - t0 > seconds_target / 3:
                 reps = 1
@@ -395,6 +397,18 @@ def cpu_train_baseline(points, threads, seconds_target=25.0):
         B2, t22, _ = run(1, 2, 18, 1)
         rec["half_cfg2_batch"] = {"clouds_per_step": B2, "seconds_per_step": round(t22, 3), "clouds_per_s": round(B2 / t22, 3),
                                   "sample": "one timed step after a warm-up step, bq=1 P=2 Ng=18"}
+    # ... and configs[2]'s own batch (bq=2, P=2, Ng=18 -> 44 clouds, ~35 GB in this formulation) where the host has the memory and the
+    # step is predicted to stay under a minute: ONE step, not warmed up (its first-touch page faults included) -- the same 44 clouds
+    # the GPU step holds, so that steps/s compare directly
+    if free_gb > 96 and 44.0 / B * t6 < 60.0:
+        t0 = time.time()
+        try:
+            B44, t44, _ = run(2, 2, 18, 0)
+        except (RuntimeError, MemoryError, IndexError):
+            B44, t44 = 0, 0.0
+        if B44:
+            rec["cfg2_batch"] = {"clouds_per_step": B44, "seconds_per_step": round(t44, 3), "steps_per_s": round(1.0 / t44, 4),
+                                 "clouds_per_s": round(B44 / t44, 3), "sample": "ONE step, not warmed up, bq=2 P=2 Ng=18 (the GPU step's batch)"}
     return rec
 
 
