@@ -138,8 +138,12 @@ def test_bench_two_ranks_dry_run_over_gloo_on_one_gpu(cuda):
     assert rec["n_gpus"] == 2 and "dry_run" in rec and rec["scaling"] == "weak" and rec["unit"] == "descriptors/s"
     assert len(rec["descriptors_per_s_per_rank"]) == 2 and rec["value"] > 0
     assert rec["steps"] == 2 and rec["config"]["clouds_per_step_per_gpu"] == 4
-    ex = rec["train"]["exchange"]
+    assert len(lines[0]) < 4096 and rec["detail"] == "bench_detail_n2.json"      # the parsed line is the short one ...
+    for key in ("allreduce_ms_per_step_isolated", "allreduce_busbw_GBps", "allreduce_exposed_ms_per_step"):
+        assert key in rec["train"]["exchange"]
+    full = json.load(open(os.path.join(root, rec["detail"])))                      # ... everything else is in the side file
+    ex = full["train"]["exchange"]
     assert ex is not None and ex["gradient_bytes"] > 4 * 17_000_000      # 17.6 M fp32 parameters
     for key in ("allreduce_ms_per_step_isolated", "allreduce_busbw_GBps", "ms_per_step_without_exchange", "allreduce_exposed_ms_per_step"):
         assert key in ex
-    assert "gloo" in ex["backend"] and rec["train"]["tuples_per_s"] > 0
+    assert "gloo" in ex["backend"] and full["train"]["tuples_per_s"] > 0 and full["value"] == rec["value"]
