@@ -283,6 +283,13 @@ int lpd_edge_mlp_bf16x3(const float* P, int ldp, const float* Q, int ldq, const 
 int lpd_edge_mlp_bf16x3s(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
                  const float* b1, const float* W2, const float* s2, const float* b2, void* out_hi, long long out_lo, int M,
                  int N, int CM, int CO, int k, int act, float slope, long long out_cloud, int panel_ld, void* stream);
+/* ... and with x1 = max over k of the stage-1 activation act(s1 (P_j + Q_i) + b1) -- the DG1-stage K-agg of LPDNet.forward
+ * (util/lpdnet_model.py:249-250), which is the maximum over the slots of the very tile this kernel builds for the DG2 product --
+ * written on the way as a second pair of planes (x1_hi, x1_hi + out_lo; layout of out_hi): one launch instead of lpd_pack_idx16 +
+ * lpd_edge_gather_max16s + lpd_edge_mlp_bf16x3s over the same graph.  128 -> 128 channels, M % 32 == 0, N % 64 == 0. */
+int lpd_edge_mlp_x1_bf16x3s(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
+                 const float* b1, const float* W2, const float* s2, const float* b2, void* out_hi, void* x1_hi, long long out_lo,
+                 int M, int N, int k, int act, float slope, long long out_cloud, int panel_ld, void* stream);
 
 /* Per-point linear layer with K <= 8 inputs (+bias, affine, activation): the 3 -> 64 first layers
  * (util/lpdnet_model.py:185,231; util/PointNetVlad.py:190,213; T-Net conv1 lpdnet_model.py:276) and the

@@ -532,6 +532,8 @@ struct EdgeMlpArgs {
     int panel_ld;         // rows allotted to one panel (>= N)
     long long out_lo;     // != 0 (split-bf16 kernel, cloud-panel out): `out` is the hi plane of a pair of bf16 planes, the lo plane
                           // out_lo elements behind it; out_cloud counts bf16 elements
+    void* x1_hi;          // != null (split planes only): ALSO x1 = max over k of the stage-1 activation (util/lpdnet_model.py:249-250), as
+                          // a second pair of planes with the layout of `out` (same cloud stride, panel rows and lo offset)
 };
 
 // m = m0 + (row inside the block); a block's 64 points lie in one cloud when the output is in cloud-panel form
@@ -758,25 +760,34 @@ __device__ __forceinline__ float em_opaque_inf()
 }
 __device__ __forceinline__ float em_vmax(float a, float b, float pinf) { return __builtin_amdgcn_fmed3f(a, b, pinf); }
 
-template <int CM, int CO>
+template <int CM, int CO, int PTS = EM_PTS>
 struct EdgeMlpX3Cfg {
     static constexpr int LDK = CM + 8;                      // bf16 per LDS row
-    static constexpr int IMG = EM_PTS * LDK;                // bf16 per image (hi or lo)
-    static constexpr int WM = CO == 128 ? 2 : 1;            // m-tiles (32 points) per wave
+    static constexpr int IMG = PTS * LDK;                   // bf16 per image (hi or lo)
+    static constexpr int WM = (CO == 128 ? 2 : 1) * PTS / EM_PTS;   // m-tiles (32 points) per wave
     static constexpr int KS = CM / 16;                      // k-steps
     static constexpr int F4_PER_ROW = CM / 4;
     static constexpr int ROWS_PER_PASS = EM_THREADS / F4_PER_ROW;
-    static constexpr int PASSES = EM_PTS / ROWS_PER_PASS;
+    static constexpr int PASSES = PTS / ROWS_PER_PASS;
+    static_assert(WM >= 1 && PASSES >= 1, "32-point blocks are built for 128 -> 128");
 };
 
-template <int CM, int CO>
-__global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs g)
+// X1 (round 6; 128 -> 128, split planes, 32 points per block): the DG1-stage K-agg rides along.  x1 = max over k of the stage-1
+// activation act(s1 (P_j + Q_i) + b1) is the maximum over the slots of exactly the values the tile builder produces for the MFMA
+// (the activation is monotone: act(max ya) = max act(ya)), so every builder thread keeps a running maximum of its (row, 4 channels)
+// elements and stores them at the end -- the separate lpd_edge_gather_max16 launch over the same graph (80 us at 32 clouds: 512 items
+// on 256 CUs, two rounds of exposed 128-KiB fills; 0.33 of its HBM roofline) and its uint16 index packing disappear.  The 32 extra
+// accumulators per thread do not fit beside the 64-point block's state (239 of 256 registers), so the fused form takes 32 points per
+// block: half the builder state per thread, one m-tile per wave.
+template <int CM, int CO, int PTS = EM_PTS, bool X1 = false>
+__global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs g)      // (three 32-point blocks per CU: 168 registers with 9 spilled, 285 us against 288)
 {
-    using Cfg = EdgeMlpX3Cfg<CM, CO>;
+    using Cfg = EdgeMlpX3Cfg<CM, CO, PTS>;
     constexpr int LDK = Cfg::LDK, IMG = Cfg::IMG, WM = Cfg::WM, KS = Cfg::KS, PASSES = Cfg::PASSES;
     static_assert((CM == 128 && CO == 128) || (CM == 64 && CO == 64), "edge_mlp_x3: built for 128->128 and 64->64");
+    static_assert(!X1 || (CM == 128 && CO == 128), "the x1 output rides with the 128 -> 128 stage");
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];   // [2 buffers][hi | lo][64][LDK], then idx
-    int* idxs = reinterpret_cast<int*>(smem16 + 4 * IMG);             // [EM_PTS][k]
+    int* idxs = reinterpret_cast<int*>(smem16 + 4 * IMG);             // [PTS][k]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -785,7 +796,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
     const int col = lane & 31;
     const int ntile = CO == 128 ? wave : (wave >> 1);       // output-column tile of this wave
     const int ptile = CO == 128 ? 0 : (wave & 1);           // first point tile of this wave
-    const int m0 = lpd_xcd_remap(blockIdx.x, gridDim.x) * EM_PTS;
+    const int m0 = lpd_xcd_remap(blockIdx.x, gridDim.x) * PTS;
 
     // W2 fragments of this wave's column n = ntile*32 + col: k = 16 s + 8 h .. +7, sign-adjusted, split
     const int n = ntile * 32 + col;
@@ -803,7 +814,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
         for (int e = 0; e < 4; ++e) { b_hi[s][e] = h0[e]; b_hi[s][4 + e] = h1[e]; b_lo[s][e] = l0[e]; b_lo[s][4 + e] = l1[e]; }
     }
 
-    for (int f = tid; f < EM_PTS * g.k; f += EM_THREADS) {
+    for (int f = tid; f < PTS * g.k; f += EM_THREADS) {
         int p = f / g.k, t = f - p * g.k;
         int m = m0 + p;
         m = m < g.M ? m : g.M - 1;
@@ -832,6 +843,9 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
     }
     __syncthreads();  // idxs visible
 
+    float4 xm[X1 ? PASSES : 1];
+#pragma unroll
+    for (int e = 0; e < (X1 ? PASSES : 1); ++e) xm[e] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     float4 pg[PASSES];
     auto gather = [&](int t) {
 #pragma unroll
@@ -851,6 +865,10 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
             // (packed pairs: v_pk_fma_f32 / v_pk_mul_f32 round each element exactly as the scalar forms do)
             const em_f32x2 ya = __builtin_elementwise_fma(s1a, (em_f32x2){pg[e].x, pg[e].y}, (em_f32x2){qc[e].x, qc[e].y});
             const em_f32x2 yb = __builtin_elementwise_fma(s1b, (em_f32x2){pg[e].z, pg[e].w}, (em_f32x2){qc[e].z, qc[e].w});
+            if constexpr (X1) {      // running maximum of the pre-activation values (the activation is applied once, at the end)
+                xm[e].x = em_vmax(xm[e].x, ya[0], pinf); xm[e].y = em_vmax(xm[e].y, ya[1], pinf);
+                xm[e].z = em_vmax(xm[e].z, yb[0], pinf); xm[e].w = em_vmax(xm[e].w, yb[1], pinf);
+            }
             const em_f32x2 na = ns2 * ya, nb = ns2 * yb;
             uint2 hh, ll;
             em_split4_packed(em_vmax(ya[0], na[0], pinf), em_vmax(ya[1], na[1], pinf), em_vmax(yb[0], nb[0], pinf),
@@ -900,6 +918,20 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
         __syncthreads();
     }
 
+    if constexpr (X1) {      // x1 rows of this thread: 4 channels of PASSES points, activated, split, 8 bytes into each plane
+        const size_t bc = (size_t)(m0 / g.N);
+#pragma unroll
+        for (int e = 0; e < PASSES; ++e) {
+            const int m = m0 + prow + Cfg::ROWS_PER_PASS * e;
+            if (m >= g.M) continue;
+            uint2 hh, ll;
+            em_split4_packed(em_vmax(xm[e].x, ns * xm[e].x, pinf), em_vmax(xm[e].y, ns * xm[e].y, pinf), em_vmax(xm[e].z, ns * xm[e].z, pinf),
+                             em_vmax(xm[e].w, ns * xm[e].w, pinf), hh, ll);
+            __bf16* dst = reinterpret_cast<__bf16*>(g.x1_hi) + bc * g.out_cloud + ((size_t)(c4 >> 1) * g.panel_ld + ((size_t)m - bc * g.N)) * 8 + (c4 & 1) * 4;
+            *reinterpret_cast<uint2*>(dst) = hh;
+            *reinterpret_cast<uint2*>(dst + g.out_lo) = ll;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1422,6 +1454,18 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
 template <int CM, int CO>
 int edge_mlp_x3_launch(const EdgeMlpArgs& g, hipStream_t stream)
 {
+    if constexpr (CM == 128 && CO == 128) {
+        if (g.x1_hi) {      // with the x1 planes: 32 points per block (see edge_mlp_x3_kernel)
+            constexpr int PTS = 32;
+            using Cfg = EdgeMlpX3Cfg<CM, CO, PTS>;
+            const size_t lds = (size_t)4 * Cfg::IMG * sizeof(__bf16) + (size_t)PTS * g.k * sizeof(int);
+            auto kern = edge_mlp_x3_kernel<CM, CO, PTS, true>;
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3((g.M + PTS - 1) / PTS), dim3(EM_THREADS), lds, stream, g);
+            LPD_CHECK_LAUNCH("lpd_edge_mlp(bf16x3 + x1)");
+            return LPD_OK;
+        }
+    }
     using Cfg = EdgeMlpX3Cfg<CM, CO>;
     size_t lds = (size_t)4 * Cfg::IMG * sizeof(__bf16) + (size_t)EM_PTS * g.k * sizeof(int);
     auto kern = edge_mlp_x3_kernel<CM, CO>;
@@ -1462,7 +1506,7 @@ extern "C" int lpd_edge_gather_max(const float* P, int ldp, const float* Q, int 
 static int edge_mlp_entry(bool x3, const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
                           const float* b1, const float* W2, const float* s2, const float* b2, float* out, int ldo,
                           int M, int N, int CM, int CO, int k, int act, float slope, long long out_cloud, int panel_ld, void* stream_,
-                          long long out_lo = 0)
+                          long long out_lo = 0, void* x1_hi = nullptr)
 {
     hipStream_t stream = (hipStream_t)stream_;
     LPD_CHECK_ARG(P && idx && s1 && b1 && W2 && s2 && b2 && out, "lpd_edge_mlp: null pointer");
@@ -1475,7 +1519,9 @@ static int edge_mlp_entry(bool x3, const float* P, int ldp, const float* Q, int 
     LPD_CHECK_ARG((((uintptr_t)P | (uintptr_t)Q | (uintptr_t)s1 | (uintptr_t)b1 | (uintptr_t)W2) & 15) == 0,
                   "lpd_edge_mlp: pointers must be 16-byte aligned");
     LPD_CHECK_ARG(!out_cloud || (N % EM_PTS == 0 && panel_ld >= N), "lpd_edge_mlp: cloud-panel out needs N %% 64 == 0 and panel_ld >= N");
-    EdgeMlpArgs g{P, Q, idx, s1, b1, W2, s2, b2, out, M, N, k, ldp, ldq, ldo, act, slope, out_cloud, panel_ld, out_lo};
+    LPD_CHECK_ARG(!x1_hi || (out_lo && CM == 128 && CO == 128 && M % 32 == 0 && ((uintptr_t)x1_hi & 7) == 0),
+                  "lpd_edge_mlp: the x1 planes ride with the split 128 -> 128 stage (M %% 32 == 0)");
+    EdgeMlpArgs g{P, Q, idx, s1, b1, W2, s2, b2, out, M, N, k, ldp, ldq, ldo, act, slope, out_cloud, panel_ld, out_lo, x1_hi};
     if (CM == 128 && CO == 128) return x3 ? edge_mlp_x3_launch<128, 128>(g, stream) : edge_mlp_launch<128, 128>(g, stream);
     if (CM == 64 && CO == 64) return x3 ? edge_mlp_x3_launch<64, 64>(g, stream) : edge_mlp_launch<64, 64>(g, stream);
     lpd_set_error("lpd_edge_mlp: (CM=%d, CO=%d) unsupported; built for (128,128) and (64,64)", CM, CO);
@@ -1590,6 +1636,19 @@ extern "C" int lpd_edge_mlp_bf16x3s(const float* P, int ldp, const float* Q, int
     LPD_CHECK_ARG(out_lo != 0 && out_cloud != 0, "lpd_edge_mlp_bf16x3s: split output needs cloud panels and a lo-plane offset");
     return edge_mlp_entry(true, P, ldp, Q, ldq, idx, s1, b1, W2, s2, b2, reinterpret_cast<float*>(out_hi), 8, M, N, CM, CO, k, act, slope,
                           out_cloud, panel_ld, stream, out_lo);
+}
+
+// ... and with x1 = max over k of the stage-1 activation (the DG1-stage K-agg, util/lpdnet_model.py:249-250) written on the way, as a
+// second pair of planes x1_hi (+ out_lo) with the layout of out_hi: replaces lpd_pack_idx16 + lpd_edge_gather_max16s on the same graph.
+// 128 -> 128 channels, M % 32 == 0.
+extern "C" int lpd_edge_mlp_x1_bf16x3s(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, const float* s1,
+                                       const float* b1, const float* W2, const float* s2, const float* b2, void* out_hi, void* x1_hi,
+                                       long long out_lo, int M, int N, int k, int act, float slope, long long out_cloud, int panel_ld,
+                                       void* stream)
+{
+    LPD_CHECK_ARG(out_lo != 0 && out_cloud != 0 && x1_hi, "lpd_edge_mlp_x1_bf16x3s: split outputs need cloud panels, a lo-plane offset and the x1 planes");
+    return edge_mlp_entry(true, P, ldp, Q, ldq, idx, s1, b1, W2, s2, b2, reinterpret_cast<float*>(out_hi), 8, M, N, 128, 128, k, act, slope,
+                          out_cloud, panel_ld, stream, out_lo, x1_hi);
 }
 
 // Train-mode DG1 -> DG2 stage in one launch (edge_mlp_train_kernel): Y1e, Z (raw), the statistics of Z, the selected raw values and

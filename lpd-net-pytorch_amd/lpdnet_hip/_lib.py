@@ -67,6 +67,8 @@ SIGNATURES = {
                               _c_int, _c_int, _c_f, _c_ll, _c_ll, _c_ll, _c_int, _c_p],
     "lpd_edge_gather_max16s": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_ll, _c_p, _c_p, _c_int, _c_int, _c_int,
                                _c_int, _c_int, _c_f, _c_ll, _c_ll, _c_ll, _c_int, _c_p],
+    "lpd_edge_mlp_x1_bf16x3s": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int,
+                                _c_f, _c_ll, _c_int, _c_p],
     "lpd_edge_mlp_bf16x3s": [_c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int,
                              _c_int, _c_int, _c_int, _c_int, _c_f, _c_ll, _c_int, _c_p],
     "lpd_gemm_x3ts": [_c_p, _c_ll, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_int, _c_f, _c_ll, _c_ll, _c_int, _c_int, _c_p],

@@ -334,7 +334,7 @@ def _switch_sig():
     g = globals()
     return (_morton_order(), SIDE_STREAM, getattr(_SIDE_FORCE, "mode", None), PANEL_LAYOUT, g["FUSED_FRONT"], g["FUSE_ASSIGN"], g["CONV3_P8"],
             g["KAGG_WINDOW"], EVAL_CHUNK, ops.GEMM_BF16X3, ops._EXACT.depth, ops._FAST.depth, ops.KNN_IMPL, ops.BF16_SINGLE_PRODUCT,
-            ops.X3W_FORWARD, ops.X3W_IMPL, ops.X3W_BATCHED, ops.X3T_PANELS, ops.X3T_ROWS, ops.P8_IMPL, ops.KAGGW_PERMUTE)
+            ops.X3W_FORWARD, ops.X3W_IMPL, ops.X3W_BATCHED, ops.X3T_PANELS, ops.X3T_ROWS, ops.P8_IMPL, ops.KAGGW_PERMUTE, ops.EDGE_MLP_X1)
 
 
 def replay_eval(model, x, eager):
@@ -553,7 +553,15 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side, assign=None):
         else:
             cat = ops.panels_empty(B, N, 512, x.device)
             x1v, x2v, x3v = cat[:, 0:16], cat[:, 16:32], cat[:, 32:64]
-        if side_job is not None:
+        # x1 = max over k of the DG1 activation is the maximum over the slots of the tile the fused edge MLP builds: with split planes it
+        # is written by that launch (no DG1 K-agg launch, no uint16 packing of the feature-space graph)
+        x1_fused = split and resident and ops.edge_mlp_x1_applies(M, N, 128, net.convDG2[0].weight.shape[0])
+        if x1_fused:
+            if side_job is not None:                     # pq comes from the second stream
+                main, side = torch.cuda.current_stream(), side_job[0]
+                _join(main, side)
+                pq.record_stream(main)
+        elif side_job is not None:
             # the DG1-stage K-agg (HBM-bound) runs on the second stream next to the fused edge MLP (MFMA / VALU-bound); both
             # read pq and the feature-space graph and write different panels of `cat`
             main, side = torch.cuda.current_stream(), side_job[0]
@@ -566,7 +574,8 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side, assign=None):
                 kagg_p(pq[:, :128], pq[:, 128:], pack(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=x1v)
         else:
             kagg_p(pq[:, :128], pq[:, 128:], pack(idx_f), N, scale=s1, shift=b1, act=act, slope=slope, out=x1v)
-        ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope, out=x2v)
+        ops.edge_mlp(pq[:, :128], pq[:, 128:], idx_f, N, s1, b1, _w2d(net.convDG2[0]), s2, b2, act=act, slope=slope, out=x2v,
+                     x1_out=x1v if x1_fused else None)
         if split:
             pq3 = ops.gemm_x3t_split(x2v, split_edge_weight(net.convSN1, "cat_nc"))
         else:

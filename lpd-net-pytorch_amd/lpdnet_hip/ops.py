@@ -867,12 +867,21 @@ def edge_gather_maxw(P, Q, idx16, N, *, scale=None, shift=None, act=ACT_NONE, sl
     return out
 
 
-def edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, *, act=ACT_LEAKY, slope=0.01, out=None, exact=False):
-    """(docstring below)  `out` may be a cloud-panel view [B, CO/8, N, 8]."""
-    return _edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, act, slope, out, exact)
+def edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, *, act=ACT_LEAKY, slope=0.01, out=None, exact=False, x1_out=None):
+    """(docstring below)  `out` may be a cloud-panel view [B, CO/8, N, 8].  x1_out (split planes like `out`, 128 -> 128 only): also
+    x1 = max over k of the stage-1 activation -- the DG1-stage K-agg -- from the same launch (edge_mlp_x1_applies)."""
+    return _edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, act, slope, out, exact, x1_out)
 
 
-def _edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, act, slope, out, exact):
+EDGE_MLP_X1 = _debug.on("edge-mlp-x1")      # eval: the DG1-stage K-agg rides in the fused edge MLP (off: its own launch, lpd_edge_gather_max16)
+
+
+def edge_mlp_x1_applies(M, N, CM, CO, exact=False):
+    """can edge_mlp(..., x1_out=...) run?  (split planes, split-bf16 products, 128 -> 128 channels, 32-point blocks inside one cloud)"""
+    return bool(EDGE_MLP_X1 and GEMM_BF16X3 and not exact and _EXACT.depth == 0 and CM == 128 and CO == 128 and M % 32 == 0 and N % 64 == 0)
+
+
+def _edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, act, slope, out, exact, x1_out=None):
     """Fused DG1-activation -> DG2 conv -> BN -> act -> max over k (include/lpd_hip.h lpd_edge_mlp)."""
     ldp = _rows(P, "P")
     ldq = _rows(Q, "Q") if Q is not None else 0
@@ -896,9 +905,19 @@ def _edge_mlp(P, Q, idx, N, s1, b1, W2, s2, b2, act, slope, out, exact):
         s1, b1 = _vec(s1, "s1", CM), _vec(b1, "b1", CM)
         s2, b2 = _vec(s2, "s2", CO), _vec(b2, "b2", CO)
         lib = _lib.load()
+        if x1_out is not None:
+            if (not _is_split(x1_out) or tuple(x1_out.shape) != tuple(out.shape) or tuple(x1_out.stride()) != tuple(out.stride())
+                    or not edge_mlp_x1_applies(M, N, CM, CO, exact)):
+                raise ValueError("edge_mlp: x1_out must be split planes with the shape and strides of `out` (128 -> 128, M % 32 == 0, N % 64 == 0)")
+            _call(f"edge_mlpx3+x1[{CM}->{CO}]", lib.lpd_edge_mlp_x1_bf16x3s, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(s1), _ptr(b1), _ptr(W2),
+                  _ptr(s2), _ptr(b2), _ptr(out[0]), _ptr(x1_out[0]), out.stride(0), M, N, k, act, float(slope), out.stride(1), out.stride(2) // 8,
+                  _stream())
+            return out
         _call(f"edge_mlpx3[{CM}->{CO}]", lib.lpd_edge_mlp_bf16x3s, _ptr(P), ldp, _ptr(Q), ldq, _ptr(idx), _ptr(s1), _ptr(b1), _ptr(W2), _ptr(s2),
               _ptr(b2), _ptr(out[0]), out.stride(0), M, N, CM, CO, k, act, float(slope), out.stride(1), out.stride(2) // 8, _stream())
         return out
+    if x1_out is not None:
+        raise ValueError("edge_mlp: x1_out is written by the split-plane form only")
     if out.dim() == 4:
         if not _is_panels(out) or out.shape[1] * 8 != CO or out.shape[0] * out.shape[2] != M or out.shape[2] != N:
             raise ValueError("edge_mlp: cloud-panel out must be a [B, CO/8, N, 8] view")

@@ -1128,6 +1128,49 @@ def test_edge_mlp_split_output_and_x3t_on_split_planes(cuda, CM, N, B):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("N,k,B,act", [(512, 20, 2, "leaky"), (4096, 20, 2, "leaky"), (256, 7, 3, "relu"), (64, 20, 5, "leaky")])
+def test_edge_mlp_with_the_dg1_kagg_riding_along(cuda, N, k, B, act):
+    """lpd_edge_mlp_x1_bf16x3s: the fused DG1 -> DG2 stage on 32-point blocks that also writes x1 = max over k of the stage-1
+    activation (the DG1-stage K-agg, util/lpdnet_model.py:249-250).  x2 is bit-identical to the 64-point kernel's planes (the same
+    products in the same order); x1 equals the split of the fp64 evaluation act(s1 (sel P + Q) + b1) to one ulp of the 16-bit split
+    (the standalone K-agg kernel rounds the same expression in a different order) and lpd_edge_gather_max16s to a unit of the lo plane;
+    BatchNorm scales of both signs (max and min selection); the planes around the written ranges stay untouched."""
+    ops = _ops()
+    CM = 128
+    P, Q, idx, s1, b1 = _edge_inputs(B, N, CM, k, 31 * N + k)
+    g = torch.Generator().manual_seed(N + k)
+    W2 = (torch.randn(CM, CM, generator=g) / CM ** 0.5).to(cuda)
+    s2, b2 = torch.randn(CM, generator=g).to(cuda), torch.randn(CM, generator=g).to(cuda)
+    code, slope = (ops.ACT_LEAKY, 0.01) if act == "leaky" else (ops.ACT_RELU, 0.0)
+    args = (P.to(cuda), Q.to(cuda), idx.to(cuda), N, s1.to(cuda), b1.to(cuda), W2, s2, b2)
+    assert ops.edge_mlp_x1_applies(B * N, N, CM, CM)
+    wide = ops.split_panels_empty(B, N, 512, cuda)
+    wide.fill_(3.0)
+    x1v, x2v = wide[:, :, 0:16], wide[:, :, 16:32]
+    ops.edge_mlp(*args, act=code, slope=slope, out=x2v, x1_out=x1v)
+    want2 = ops.edge_mlp(*args, act=code, slope=slope, out=ops.split_panels_empty(B, N, CM, cuda))
+    assert torch.equal(x2v, want2)
+    assert bool((wide[:, :, 32:] == 3.0).all())
+    # x1 against fp64
+    Pd, Qd = P.double(), Q.double()
+    nb = (idx.long() + (torch.arange(B).view(B, 1, 1) * N)).view(B * N, k)
+    y = s1.double() * (Pd[nb] + Qd.unsqueeze(1)) + b1.double()                      # [M, k, C]
+    ref = y.max(dim=1).values
+    ref = torch.where(ref > 0, ref, ref * slope)
+    got = ops.split_to_rows(x1v).double().cpu()
+    assert _rel(got, ref) < 2e-5
+    hi, lo = _split_ref(ref.float().to(cuda))
+    to_rows = lambda Pn: Pn.permute(0, 2, 1, 3).reshape(B * N, CM)
+    assert (to_rows(x1v[0]).float() - hi.float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()      # hi planes within an ulp
+    # ... and against the standalone K-agg kernel on the same graph
+    if k == 20:
+        sep = ops.split_panels_empty(B, N, CM, cuda)
+        ops.edge_gather_max16(args[0], args[1], ops.pack_idx16(args[2]), N, scale=args[4], shift=args[5], act=code, slope=slope, out=sep)
+        assert _rel(ops.split_to_rows(sep), ops.split_to_rows(x1v)) < 2e-5      # (one unit of the lo plane: 2^-17 of the value)
+    with pytest.raises(Exception):      # the x1 planes need the shape and strides of the x2 planes
+        ops.edge_mlp(*args, act=code, slope=slope, out=x2v, x1_out=wide[:, :, 0:8])
+
+
 @pytest.mark.parametrize("Bc,Np,K,N,panels", [(2, 256, 512, 1024, False), (5, 512, 128, 256, True), (32, 256, 512, 1024, False)])
 def test_gemm_p8_fused_assignment_product(cuda, Bc, Np, K, N, panels):
     """lpd_gemm_p8_fused: conv3 and the NetVLAD assignment product of its output in one launch.  C is bit-identical to the plain
