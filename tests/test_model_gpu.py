@@ -521,7 +521,7 @@ def test_second_backward_raises_a_clear_error(cuda):
 
 @pytest.mark.parametrize("env", [{"LPD_GEMM_FP32": "1"}, {"LPD_SIDE_STREAM": "0"}, {"LPD_SIDE_STREAM": "1"}, {"LPD_DEBUG": "no-p8"}, {"LPD_REPLAY": "0"}, {"LPD_DEBUG": "no-knn-split"},
                                  {"LPD_DEBUG": "no-panels"}, {"LPD_DEBUG": "no-fused-front"}, {"LPD_DEBUG": "no-knn-pre"}, {"LPD_DEBUG": "no-x3t-rows"},
-                                 {"LPD_DEBUG": "no-fuse-assign"}, {"LPD_DEBUG": "no-kagg-persist"}],
+                                 {"LPD_DEBUG": "no-fuse-assign"}, {"LPD_DEBUG": "no-kagg-persist"}, {"LPD_DEBUG": "no-edge-mlp-x1"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_documented_switches_are_live(cuda, env):
     """The environment switches README.md documents are read at import, so each one is exercised in a fresh interpreter: the
