@@ -568,10 +568,15 @@ def secondary_eval(dev, points, k, batch, steps, warmup=2, featnet="lpdnet", exa
             kern = kernel_table(ops.PROFILE or {})
             kern_all = None
             if kernels:
+                from lpdnet_hip import engine as _eng
                 ops.PROFILE, ops.PROFILE_ONLY = {}, None
-                for i in range(3):
-                    model(clouds[i % 2])
-                torch.cuda.synchronize()
+                _eng._SIDE_FORCE.mode = False          # one stream: clean per-op durations
+                try:
+                    for i in range(3):
+                        model(clouds[i % 2])
+                    torch.cuda.synchronize()
+                finally:
+                    _eng._SIDE_FORCE.mode = None
                 kern_all = kernel_table(ops.PROFILE)
                 kern_all.update(kern)
             ops.PROFILE, ops.PROFILE_ONLY = None, None
@@ -722,12 +727,16 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = ops.PROFILE
-    # the per-op table of the JSON line comes from a separate, untimed pass with every launch bracketed (HIP events on the launch stream);
-    # a 32-cloud step runs on ONE stream (engine._side_mode), so the entries are clean per-op durations
+    # the per-op table of the detail record comes from a separate, untimed pass with every launch bracketed (HIP events on the launch
+    # stream) and the second stream switched off, so the entries are clean per-op durations
     ops.PROFILE, ops.PROFILE_ONLY = {}, None
-    for i in range(min(args.steps, 5) + 1):
-        step(i)
-    torch.cuda.synchronize()
+    engine._SIDE_FORCE.mode = False          # this pass on ONE stream: clean per-op durations (the timed region runs the product's two)
+    try:
+        for i in range(min(args.steps, 5) + 1):
+            step(i)
+        torch.cuda.synchronize()
+    finally:
+        engine._SIDE_FORCE.mode = None
     prof_all = ops.PROFILE
     prof_all.update({k_: v for k_, v in prof.items()})      # K-agg entries: the timed region's own measurements
     ops.PROFILE = None

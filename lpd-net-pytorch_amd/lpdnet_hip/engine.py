@@ -232,8 +232,9 @@ def _dev_key(device):
 _SIDE_FORCE = __import__("threading").local()      # per-thread override for A/B timing (tools/side_small.py, bench.py's one-stream kernel table)
 
 
-def _side_mode(device, points=None):
-    """use the second stream for this forward?  An explicit setting passes through; auto = batches of at most SIDE_SMALL_POINTS points."""
+def _side_mode(device, points=None, light_side=False):
+    """use the second stream for this forward?  An explicit setting passes through; auto = batches of at most SIDE_SMALL_POINTS points,
+    and every batch whose second stream carries the xyz kNN and the DG1 projection only (light_side: x1 rides in the fused edge MLP)."""
     forced = getattr(_SIDE_FORCE, "mode", None)
     if forced is not None:
         return forced
@@ -241,14 +242,15 @@ def _side_mode(device, points=None):
         return bool(SIDE_STREAM)
     if torch.cuda.is_current_stream_capturing():      # (a capture that forks onto the second stream replays at HALF the eager rate:
         return False                                  #  1.1 vs 0.50 ms at one cloud, 2.04 vs 1.45 at 24 -- measured in round 5)
-    return points is not None and points <= SIDE_SMALL_POINTS
+    return light_side or (points is not None and points <= SIDE_SMALL_POINTS)
 
 
 def side_stream_report(device=None):
     """what the eval forward does: the rule above as one line (bench.py prints it into its JSON line)"""
     if SIDE_STREAM != "auto":
         return "two streams (LPD_SIDE_STREAM=1)" if SIDE_STREAM else "one stream (LPD_SIDE_STREAM=0)"
-    return "one stream; batches of at most %d points (24 clouds x 4096) put the xyz kNN and the DG1 stage on a second stream" % SIDE_SMALL_POINTS
+    return ("two streams: the xyz kNN and the DG1 projection run on a second (high-priority) stream next to the per-point layers and the "
+            "feature-space kNN; paths that still launch the DG1 K-agg by itself use it only up to %d points" % SIDE_SMALL_POINTS)
 
 
 def _join(waiter, signaller):
@@ -474,8 +476,21 @@ def lpdnet_features_eval(net, x, reorder=True, assign=None):
     B, N = x.shape[0], x.shape[2]
     act = ops.ACT_RELU if net.use_relu else ops.ACT_LEAKY
     side_ok = PANEL_LAYOUT and N % 128 == 0 and _resident_shape(net.k, N, B * N, act)
-    out = _lpdnet_features_eval_body(net, x, mfea, side_ok and _side_mode(x.device, B * N), assign)
+    # (round 6) with x1 written by the fused edge MLP the second stream holds the xyz kNN and the DG1 projection only -- no HBM-bound
+    # K-agg beside the edge MLP any more -- and pays at every batch size: 32 clouds 1.91 -> 1.84 ms on three boxes
+    light = side_ok and _x1_rides(net, B * N, N)
+    out = _lpdnet_features_eval_body(net, x, mfea, side_ok and _side_mode(x.device, B * N, light), assign)
     return out if assign is not None else out[:3]
+
+
+def _split_planes(net, N):
+    """[x1 | x2 | x3] as split bf16 planes (conv3 on lpd_gemm_p8)?"""
+    return bool(CONV3_P8 and ops.GEMM_BF16X3 and ops._EXACT.depth == 0 and N % 256 == 0 and net.conv3_lpd.weight.shape[0] % 256 == 0)
+
+
+def _x1_rides(net, M, N):
+    """is x1 written by the fused edge MLP (no DG1 K-agg launch)?  Needs the cloud-resident K-agg class and split planes."""
+    return bool(net.k == 20 and N <= 4096 and _split_planes(net, N) and ops.edge_mlp_x1_applies(M, N, 128, net.convDG2[0].weight.shape[0]))
 
 
 def _lpdnet_features_eval_body(net, x, mfea, use_side, assign=None):
@@ -545,8 +560,7 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side, assign=None):
         # cloud's contiguous block; the GEMMs read / write the panels directly.
         # conv3 on the LDS-DMA ring kernel (lpd_gemm_p8) reads its operand as two bf16 planes (hi + lo), so the producers of
         # x1 / x2 / x3 write those planes instead of fp32 panels (same bytes) and the SN1 projection reads the x2 planes
-        split = (CONV3_P8 and resident and ops.GEMM_BF16X3 and ops._EXACT.depth == 0 and N % 256 == 0
-                 and net.conv3_lpd.weight.shape[0] % 256 == 0)
+        split = resident and _split_planes(net, N)
         if split:
             cat = ops.split_panels_empty(B, N, 512, x.device)
             x1v, x2v, x3v = cat[:, :, 0:16], cat[:, :, 16:32], cat[:, :, 32:64]
@@ -555,7 +569,7 @@ def _lpdnet_features_eval_body(net, x, mfea, use_side, assign=None):
             x1v, x2v, x3v = cat[:, 0:16], cat[:, 16:32], cat[:, 32:64]
         # x1 = max over k of the DG1 activation is the maximum over the slots of the tile the fused edge MLP builds: with split planes it
         # is written by that launch (no DG1 K-agg launch, no uint16 packing of the feature-space graph)
-        x1_fused = split and resident and ops.edge_mlp_x1_applies(M, N, 128, net.convDG2[0].weight.shape[0])
+        x1_fused = split and _x1_rides(net, M, N)
         if x1_fused:
             if side_job is not None:                     # pq comes from the second stream
                 main, side = torch.cuda.current_stream(), side_job[0]
