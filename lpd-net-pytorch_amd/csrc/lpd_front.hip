@@ -134,9 +134,19 @@ __global__ __launch_bounds__(256) void lpdnet_front_kernel(FrontArgs g)
             // the F0 row: four lanes x 64 bytes (round 5; from the accumulators it was 32 four-byte stores per lane: store-issue-bound)
             *reinterpret_cast<float4*>(g.F0 + m * 64 + 16 * j + 4 * q) = t;
         }
+        // (Round 6: kept scalar.  The compiler packed this chain into v_pk_mul_f32 / v_pk_add_f32 with op_sel half-selects, one s_nop
+        //  between dependent instructions; with an MFMA-heavy kernel of ANOTHER stream co-resident on the SIMD the chain returned wrong
+        //  sums for whole 4-point groups -- squared norms and tile maxima off, F0 and the operand image right -- in 37 of 40 launches
+        //  (profiles/r06_concurrency_packed_f32.txt).  The empty asm keeps every step a plain v_mul_f32 / v_add_f32.)
         float sq = __fmul_rn(v[0], v[0]);
+        asm volatile("" : "+v"(sq));
 #pragma unroll
-        for (int c = 1; c < 16; ++c) sq = __fadd_rn(sq, __fmul_rn(v[c], v[c]));
+        for (int c = 1; c < 16; ++c) {
+            float m = __fmul_rn(v[c], v[c]);
+            asm volatile("" : "+v"(m));
+            sq = __fadd_rn(sq, m);
+            asm volatile("" : "+v"(sq));
+        }
         const int lane0 = lane & ~3;
         float total = __shfl(sq, lane0, 64);
         total = __fadd_rn(total, __shfl(sq, lane0 + 1, 64));

@@ -20,7 +20,11 @@ ABI_SMOKE_BIN = os.path.join(REPO, "tests", "abi_smoke")
 # -ffp-contract=off: the kNN arithmetic contract distinguishes fused from non-fused operations
 # (HIP's __fmul_rn/__fadd_rn are plain operators and DO get contracted otherwise); explicit fmaf /
 # MFMA are unaffected.
-FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wno-unused-value"]
+# -fno-slp-vectorize (round 6): the SLP vectoriser packs adjacent scalar fp32 adds / multiplies into v_pk_add_f32 / v_pk_mul_f32 with
+# op_sel half-selects.  One such chain (the squared norms in lpd_front.hip) returned WRONG sums whenever an MFMA-heavy kernel of another
+# HIP stream was co-resident on the SIMD (profiles/r06_concurrency_packed_f32.txt); packed fp32 beside MFMAs is an anti-lever for speed
+# as well (MI355X_MICROARCH.md).  Packed operations that are written as such (float2 __builtin_elementwise_fma) are unaffected.
+FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-unused-value"]
 # measurement builds only (e.g. LPD_EXTRA_FLAGS=-DLPD_P8_BENCH for tools/p8_bench.py's timing-only conv3 variants); part of the
 # content hash, so switching it rebuilds
 FLAGS += os.environ.get("LPD_EXTRA_FLAGS", "").split()

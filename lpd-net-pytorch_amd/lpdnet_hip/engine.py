@@ -25,6 +25,8 @@ class _PerThread(__import__("threading").local):
     # gathers cache-local).  Tests switch it off to compare intermediate index tensors in the caller's order.
     # None = this thread has not set it: the process-wide value below applies
     MORTON_ORDER = None
+    # set by harness.BatchPipeline around a submit with several batches in flight: consecutive batches already overlap on the chip
+    PIPELINED = False
 
 
 _TLS = _PerThread()
@@ -242,7 +244,9 @@ def _side_mode(device, points=None, light_side=False):
         return bool(SIDE_STREAM)
     if torch.cuda.is_current_stream_capturing():      # (a capture that forks onto the second stream replays at HALF the eager rate:
         return False                                  #  1.1 vs 0.50 ms at one cloud, 2.04 vs 1.45 at 24 -- measured in round 5)
-    return light_side or (points is not None and points <= SIDE_SMALL_POINTS)
+    # (with several batches in flight -- harness.BatchPipeline -- the large batches' second stream costs more than it hides: 32 clouds,
+    #  two in flight: 1.66 ms per batch without it, 1.75 with; one in flight: 1.84 without, 1.80 with)
+    return (light_side and not _TLS.PIPELINED) or (points is not None and points <= SIDE_SMALL_POINTS)
 
 
 def side_stream_report(device=None):
@@ -334,7 +338,7 @@ def _model_sig(model):
 def _switch_sig():
     """the module-level switches that steer the eval dispatch (tools and tests flip them at run time)"""
     g = globals()
-    return (_morton_order(), SIDE_STREAM, getattr(_SIDE_FORCE, "mode", None), PANEL_LAYOUT, g["FUSED_FRONT"], g["FUSE_ASSIGN"], g["CONV3_P8"],
+    return (_morton_order(), SIDE_STREAM, getattr(_SIDE_FORCE, "mode", None), _TLS.PIPELINED, PANEL_LAYOUT, g["FUSED_FRONT"], g["FUSE_ASSIGN"], g["CONV3_P8"],
             g["KAGG_WINDOW"], EVAL_CHUNK, ops.GEMM_BF16X3, ops._EXACT.depth, ops._FAST.depth, ops.KNN_IMPL, ops.BF16_SINGLE_PRODUCT,
             ops.X3W_FORWARD, ops.X3W_IMPL, ops.X3W_BATCHED, ops.X3T_PANELS, ops.X3T_ROWS, ops.P8_IMPL, ops.KAGGW_PERMUTE, ops.EDGE_MLP_X1)
 
@@ -417,10 +421,14 @@ _SIDE_LOCK = __import__("threading").Lock()      # nn.DataParallel calls forward
 
 
 def _side_stream(device):
-    key = _dev_key(device)
+    # one second stream per (device, caller's stream): batches in flight on different streams (harness.BatchPipeline, host threads)
+    # must not queue their xyz searches behind each other on ONE shared stream
+    key = _dev_key(device) + (torch.cuda.current_stream(device).cuda_stream,)
     with _SIDE_LOCK:
         st = _SIDE.get(key)
         if st is None:
+            if len(_SIDE) >= 32:                 # callers that create streams by the dozen: forget the oldest pairing
+                _SIDE.pop(next(iter(_SIDE)))
             # high priority: its kernels are the short ones that fill in next to the long kernels of the main stream (measured:
             # 2.39 -> 2.33 ms per step; at default priority the overlap even turned into a loss once RCCL's own streams existed)
             st = _SIDE[key] = torch.cuda.Stream(device=device, priority=_debug.value("side-prio", -1))

@@ -53,11 +53,70 @@ def train_step(model, optimizer, queries, positives, negatives, other_neg, *, ma
     return loss
 
 
+class BatchPipeline:
+    """Embeds a SEQUENCE of independent eval batches with `in_flight` of them on the GPU at once (round 6).
+
+    The stages of one forward are bound by different units -- the two kNN searches by latency (a third of their wave time issuing),
+    conv3 and the fused edge MLP by the matrix cores, the K-agg and the pooling product by HBM -- so the stages of TWO consecutive
+    batches fill each other's gaps: batch i runs on HIP stream i % in_flight (each with its own second stream for the xyz search,
+    engine._side_stream), nothing else changes -- the same launches with the same arguments, bit-identical descriptors.  Measured at
+    32 clouds x 4096 points per batch: 1.76-1.80 -> 1.64 ms per batch with two in flight (three: the same).  Latency of one batch
+    grows (it shares the chip); throughput is what the callers of this class are after (evaluate.py:96-159 embeds whole runs).
+
+        pipe = BatchPipeline(model)              # the model in eval mode
+        outs = [pipe.submit(x) for x in batches] # enqueues; an output is valid once its stream gets there
+        pipe.join()                              # ... or for the caller's stream after this
+    """
+
+    def __init__(self, model, in_flight=2, device=None):
+        if in_flight < 1:
+            raise ValueError("BatchPipeline: in_flight >= 1")
+        self.model = model
+        self.device = device if device is not None else next(model.parameters()).device
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(in_flight)] if in_flight > 1 else []
+        self.count = 0
+        self._used = set()
+
+    def submit(self, x):
+        """model(x) under no_grad on the next stream of the ring; x may still be in production on the caller's current stream"""
+        if not self.streams:
+            with torch.no_grad():
+                return self.model(x)
+        cur = torch.cuda.current_stream(self.device)
+        s = self.streams[self.count % len(self.streams)]
+        self.count += 1
+        s.wait_stream(cur)                       # x (and the weights) as the caller's stream leaves them
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            x.record_stream(s)
+        from . import engine
+        was = engine._TLS.PIPELINED
+        engine._TLS.PIPELINED = True             # (the forward then keeps its own second stream for small batches only)
+        try:
+            with torch.cuda.stream(s), torch.no_grad():
+                out = self.model(x)
+        finally:
+            engine._TLS.PIPELINED = was
+        out.record_stream(cur)                   # the caller will read it on ITS stream after join()
+        self._used.add(s)
+        return out
+
+    def join(self):
+        """the caller's current stream waits for every batch submitted so far"""
+        cur = torch.cuda.current_stream(self.device)
+        for s in self._used:
+            cur.wait_stream(s)
+        self._used.clear()
+
+
+PIPELINE_IN_FLIGHT = 2      # batches in flight inside get_latent_vectors / update_vectors / large eval batches (1: one after the other)
+
+
 def get_latent_vectors(model, clouds, batch_size):
     """clouds: [n, N, 3] array-like (float64 like the benchmark's .bin submaps, or float32) -> [n, D] float32 numpy.
 
     Mirrors evaluate.get_latent_vectors: full batches of `batch_size` clouds, then the ragged remainder in one
-    call, eval mode inside, train mode restored afterwards (evaluate.py:97,156)."""
+    call, eval mode inside, train mode restored afterwards (evaluate.py:97,156).  The batches are independent: two of them are in
+    flight at a time (BatchPipeline)."""
     was_training = model.training
     model.eval()
     dev = next(model.parameters()).device
@@ -65,10 +124,12 @@ def get_latent_vectors(model, clouds, batch_size):
     n = clouds.shape[0]
     outs = []
     try:
-        with torch.no_grad():
-            for s in range(0, n, batch_size):
-                chunk = torch.from_numpy(np.ascontiguousarray(clouds[s:s + batch_size])).float().unsqueeze(1).to(dev)
-                outs.append(model(chunk).detach().cpu().numpy())
+        pipe = BatchPipeline(model, PIPELINE_IN_FLIGHT if dev.type == "cuda" else 1, dev)
+        for s in range(0, n, batch_size):
+            chunk = torch.from_numpy(np.ascontiguousarray(clouds[s:s + batch_size])).float().unsqueeze(1).to(dev)
+            outs.append(pipe.submit(chunk))
+        pipe.join()
+        outs = [o.detach().cpu().numpy() for o in outs]
     finally:
         model.train(was_training)
     if not outs:
@@ -187,10 +248,11 @@ def update_vectors(model, clouds, batch_num, device=None):
     clouds = np.asarray(clouds)
     outs = []
     try:
-        with torch.no_grad():
-            for s in range(0, clouds.shape[0], batch_num):
-                chunk = torch.from_numpy(np.ascontiguousarray(clouds[s:s + batch_num])).to(dev)
-                outs.append(model(chunk.float().unsqueeze(1)))
+        pipe = BatchPipeline(model, PIPELINE_IN_FLIGHT if torch.device(dev).type == "cuda" else 1, torch.device(dev))
+        for s in range(0, clouds.shape[0], batch_num):
+            chunk = torch.from_numpy(np.ascontiguousarray(clouds[s:s + batch_num])).to(dev)
+            outs.append(pipe.submit(chunk.float().unsqueeze(1)))
+        pipe.join()
     finally:
         model.train()          # the reference leaves the model in train mode (:345)
     if not was_training:

@@ -224,6 +224,13 @@ class PointNetVlad(nn.Module):
             # as slices whose [B*N, 1024] feature map stays inside the 256 MiB Infinity Cache + L2 working set the kernels are
             # tuned for (measured: 128 clouds in one piece 12.2 ms = 10.5 k descriptors/s, as 4 x 32 the 32-cloud rate)
             per = max(1, engine.EVAL_CHUNK * 4096 // x.shape[2])
+            if x.is_cuda and not torch.is_grad_enabled() and engine.DEBUG_AUX is None:
+                # ... two slices in flight (harness.BatchPipeline: the stages of consecutive slices are bound by different units)
+                from lpdnet_hip import harness
+                pipe = harness.BatchPipeline(self, harness.PIPELINE_IN_FLIGHT, x.device)
+                outs = [pipe.submit(x[i:i + per]) for i in range(0, x.shape[0], per)]
+                pipe.join()
+                return torch.cat(outs, dim=0)
             return torch.cat([self.forward(x[i:i + per]) for i in range(0, x.shape[0], per)], dim=0)
         if all_eval and isinstance(trunk, LPDNet):
             # eval: conv3 and the NetVLAD assignment product share a launch where that is built (engine.lpdnet_features_eval); small

@@ -715,6 +715,70 @@ def test_small_batch_eval_replays_its_launch_tape(cuda, B):
         engine.invalidate()
 
 
+@pytest.mark.parametrize("featnet", ["lpdnet", "lpdnetorigin"])
+def test_forwards_in_flight_on_several_streams(cuda, featnet):
+    """Results must not depend on what else runs on the chip.  Round 6 found a kernel where they did: a compiler-packed fp32 chain
+    (v_pk_add_f32 with op_sel half-selects, the squared norms in lpd_lpdnet_front) returned wrong sums whenever an MFMA-heavy kernel of
+    another HIP stream was co-resident -- every single-stream test green, 3-35 of 40 concurrent forwards off by up to 4e-3
+    (profiles/r06_concurrency_packed_f32.txt).  Four batches of 32 / 32 / 6 / 1 clouds in flight on three streams, 25 rounds: every
+    descriptor equals the single-stream forward's (2e-6: float atomics in the NetVLAD column sums)."""
+    N = 4096
+    m, _ = _model(featnet, N, cuda)
+    xb = torch.from_numpy(synth.cloud(77, 70, N)).unsqueeze(1).to(cuda)
+    batches = [xb[:32], xb[32:64], xb[64:70], xb[3:4]]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    with torch.no_grad():
+        refs = [m(x).clone() for x in batches]
+        torch.cuda.synchronize()
+        for it in range(25):
+            outs = []
+            for j, x in enumerate(batches):
+                with torch.cuda.stream(streams[(it + j) % 3]):
+                    outs.append(m(x))
+            torch.cuda.synchronize()
+            for o, r in zip(outs, refs):
+                assert _norm_rel(o, r) < 2e-6, it
+
+
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+def test_batch_pipeline_equals_one_batch_after_the_other(cuda, in_flight):
+    """harness.BatchPipeline keeps consecutive eval batches on `in_flight` HIP streams (what get_latent_vectors / update_vectors and
+    the slices of a large eval batch use): the same launches with the same arguments, so every batch's descriptors equal the plain
+    forward's (2e-6: the NetVLAD column sums are float atomics) -- batches of different sizes, a ragged tail, inputs produced on the
+    caller's stream right before the submit, outputs consumed on the caller's stream right after join()."""
+    from lpdnet_hip import harness
+    N = 1024
+    m, _ = _model("lpdnet", N, cuda)
+    sizes = [9, 9, 4, 9, 1, 12, 9]
+    base = [torch.from_numpy(synth.cloud(800 + i, b, N)).unsqueeze(1).to(cuda) for i, b in enumerate(sizes)]
+    with torch.no_grad():
+        want = [m(x).clone() for x in base]
+    torch.cuda.synchronize()
+    pipe = harness.BatchPipeline(m, in_flight)
+    outs = []
+    for x in base:
+        y = x * 1.0                              # produced on the caller's stream: the pipeline's stream has to wait for it
+        outs.append(pipe.submit(y))
+        del y
+    pipe.join()
+    total = torch.cat(outs).sum()                # consumed on the caller's stream
+    for o, w in zip(outs, want):
+        assert o.shape == w.shape and _norm_rel(o, w) < 2e-6
+    assert abs(total.item() - torch.cat(want).sum().item()) < 1e-3
+    # the callers: whole-run embedding (ragged tail) and a batch larger than one eval slice
+    data = np.concatenate([x.squeeze(1).cpu().numpy() for x in base])
+    got = harness.get_latent_vectors(m, data.astype(np.float64), 9)
+    assert _norm_rel(torch.from_numpy(got), torch.cat(want).cpu()) < 2e-6
+    tab = harness.update_vectors(m, data, 16)
+    assert _norm_rel(tab, torch.cat(want)) < 2e-6 and not m.training
+    m2, _ = _model("lpdnet", 4096, cuda)
+    xb = torch.from_numpy(synth.cloud(77, 70, 4096)).unsqueeze(1).to(cuda)
+    with torch.no_grad():
+        whole = m2(xb)                           # 32 + 32 + 6 clouds: sliced, two slices in flight
+        parts = torch.cat([m2(xb[i:i + 32]) for i in range(0, 70, 32)])
+    assert _norm_rel(whole, parts) < 2e-6
+
+
 def test_two_host_threads_on_one_stream_share_a_launch_tape(cuda):
     """util/data.py:117-133 runs the model from DataLoader workers: two host threads call ONE model on the SAME stream (the default
     one) with different inputs while a launch tape exists for that (shape, stream).  A plan has one input and one output buffer:

@@ -19,7 +19,6 @@ pmc() {  # tag, output name, counters ... -- program args
   rocprofv3 --kernel-trace --output-format csv --pmc "${cnt[@]}" -d $O/pmc_$tag -o p -- python3 "$@" > /dev/null 2> $O/pmc_$tag.err
   python3 $R/tools/pmc_kernels.py $O/pmc_$tag > $O/pmc_$tag.summary.txt
 }
-# (per-program tables afterwards: python3 tools/pmc_table.py $O c5 ; python3 tools/pmc_table.py $O tb)
 C5="$R/bench.py --batch 64 --points 16384 --k 64 --steps 2 --warmup 1 --no-train --no-cpu-baseline --no-secondary"
 pmc c5_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- $C5
 pmc c5_sq2 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -- $C5
@@ -31,6 +30,9 @@ pmc tb_sq2 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFL
 pmc tb_fetch FETCH_SIZE -- $TB
 pmc tb_write WRITE_SIZE -- $TB
 cd $R
+# the per-program tables need the per-dispatch counter files, which are too large to travel back: build them here, then drop the big files
+python3 tools/pmc_table.py $O c5 > $O/${TAG}_pmc_cfg5.txt 2>&1
+python3 tools/pmc_table.py $O tb > $O/${TAG}_pmc_train_bf16.txt 2>&1
 find $O -type f -size +3M -delete
 python3 tools/train_profile.py lpdnet bf16 > $O/train_profile_bf16.txt 2>&1
 python3 tools/train_profile.py lpdnet f32 > $O/train_profile_f32.txt 2>&1
