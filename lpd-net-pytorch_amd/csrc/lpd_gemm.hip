@@ -846,12 +846,44 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
     }
 
     const float ns = g.act == 0 ? 1.0f : (g.act == 1 ? 0.0f : g.slope);
+    // Round 6: the RAW result of a whole row tile (no scale / activation / accumulate: the train-mode products whose BatchNorm follows)
+    // leaves without the generic epilogue's per-element affine, activation, row guard and 64-bit address arithmetic -- that epilogue
+    // cost conv3 of the bf16 training step 130 of its 640 us (the same product without statistics and with fp32 stores: 505 us)
+    const bool raw = !(PANELS & 2) && !g.scale && g.act == 0 && !g.accumulate && m0 + 128 <= g.M;      // uniform
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int n = (nt0 + j) * 32 + col;
         if (n >= g.N) continue;
         float bi = 0.f, sc = 1.f, sh = 0.f;
         if (g.bias) bi = g.bias[n];
+        if (raw) {
+            float su = 0.f, sq = 0.f;
+            const long long row0 = (long long)(m0 + rt0 * 32 + 4 * h) * g.ldc + n;
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = i * 32 + (r & 3) + 8 * (r >> 2);      // row inside this lane's share (wave-uniform)
+                    const float v = acc[i][j][r] + bi;
+                    su += v;
+                    sq += v * v;
+                    if constexpr (C16) {      // the lane pair (n, n + 1) leaves as one 4-byte word, written by the even lane
+                        const unsigned mine = __builtin_bit_cast(unsigned short, (__bf16)v);
+                        const unsigned other = lpd_lane_xor1(mine);
+                        if (!(col & 1)) *reinterpret_cast<unsigned*>(reinterpret_cast<uint16_t*>(C) + row0 + (long long)ro * g.ldc) = mine | (other << 16);
+                    } else C[row0 + (long long)ro * g.ldc] = v;
+                }
+            if (g.stat_sum) {        // uniform
+                su += __shfl_xor(su, 32, 64);
+                sq += __shfl_xor(sq, 32, 64);
+                if (h == 0) {
+                    const size_t rofs = (size_t)((m0 >> 7) % LPD_STAT_REPLICAS) * 2 * LPD_STAT_CMAX;
+                    atomicAdd(g.stat_sum + rofs + n, (double)su);
+                    atomicAdd(g.stat_sumsq + rofs + n, (double)sq);
+                }
+            }
+            continue;
+        }
         if (g.scale) { sc = g.scale[n]; sh = g.shift[n]; }
 #pragma unroll
         for (int i = 0; i < RT; ++i)
