@@ -85,6 +85,16 @@ inline LpdStatWs lpd_stat_arg(double* stat_ws) { return LpdStatWs{stat_ws}; }   
     LPD_CHECK_ARG((ncols) > 0 && (ncols) <= LPD_STAT_CMAX, "%s: %d columns exceed the %d of the statistics workspace", name, (int)(ncols), LPD_STAT_CMAX)
 // o0[c] = sum over the replicas of column c (c < ncols <= LPD_STAT_CMAX), o1 likewise; clears the replicas
 int lpd_stat_finish(LpdStatWs ws, double* o0, double* o1, int ncols, hipStream_t stream);
+// Grid of a kernel that ENDS with such a block-level reduction + atomics: every block sends 2 x C fp64 atomics to the replicas, so the
+// block count is the atomic count.  At the 4096 blocks these kernels used to launch (16 per CU) the bn3 backward's reduction pass spent a
+// quarter of its time there: 4096 / 768 / 384 blocks = 502 / 446 / 440 us for the two passes over the [180224, 1024] bf16 map
+// (round 6).  Three blocks per CU keep enough loads in flight for a streaming read (each thread has 4-8 sixteen-byte loads open).
+inline int lpd_reduce_grid(long long blocks_wanted)
+{
+    static const int cap = lpd_debug("reduce-grid", 768);
+    if (blocks_wanted > cap) blocks_wanted = cap;
+    return blocks_wanted < 1 ? 1 : (int)blocks_wanted;
+}
 // offset of this block's replica, to be added to the column index of both pointers
 __device__ __forceinline__ size_t lpd_stat_rofs() { return (size_t)(blockIdx.x % LPD_STAT_REPLICAS) * 2 * LPD_STAT_CMAX; }
 

@@ -78,17 +78,22 @@ __device__ __forceinline__ void xt_split4(const float4& a, uint2& hi, uint2& lo)
     lo = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
 }
 
-template <int KS, bool ROWS>
+// RB (ROWS form only): rows per workgroup.  At K = 128 the two 128-row images (68 KiB) and the staging tiles (18 KiB) left ONE
+// workgroup = one wave per SIMD on a CU: the NetVLAD backward's gradient of the conv3 map ([4096 x 1024 x 128] x 44, bf16 result)
+// took 184 us for 461 MB.  64-row workgroups (53 KiB, 208 registers) run two per CU: 164 us.
+template <int KS, bool ROWS, int RB = 128>
 __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
 {
-    constexpr int K = KS * 16, LDK = K + 8, IMG = 128 * LDK;
+    static_assert(RB == 128 || (ROWS && RB == 64), "panel operands: 128 rows per workgroup");
+    constexpr int RT = RB / 32;                  // 32-row tiles per workgroup (each wave multiplies all of them by its column tiles)
+    constexpr int K = KS * 16, LDK = K + 8, IMG = RB * LDK;
     extern __shared__ __attribute__((aligned(16))) __bf16 img[];     // [hi | lo][128 rows][LDK] (+ ROWS: a [32][36] fp32 staging tile per wave)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const int col = lane & 31;
-    const int m0 = lpd_xcd_remap(blockIdx.x, gridDim.x) * 128;
+    const int m0 = lpd_xcd_remap(blockIdx.x, gridDim.x) * RB;
     const int cloud = ROWS ? 0 : m0 / g.panel_n;
     const int mc0 = ROWS ? m0 : m0 - cloud * g.panel_n;  // first row of the workgroup inside its cloud (ROWS: in the matrix)
     const float* A = ROWS ? g.A + (long long)blockIdx.y * g.sA : g.A + (long long)cloud * g.a_cloud;
@@ -114,11 +119,11 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
         constexpr int Q4 = K / 4, RPP = XT_THREADS / Q4;
         const int c4 = tid % Q4, r0 = tid / Q4;
         const float* src = A + (long long)(mc0 + r0) * g.lda + c4 * 4;
-        float4 v[128 / RPP];
+        float4 v[RB / RPP];
 #pragma unroll
-        for (int p = 0; p < 128 / RPP; ++p) v[p] = *reinterpret_cast<const float4*>(src + (long long)p * RPP * g.lda);
+        for (int p = 0; p < RB / RPP; ++p) v[p] = *reinterpret_cast<const float4*>(src + (long long)p * RPP * g.lda);
 #pragma unroll
-        for (int p = 0; p < 128 / RPP; ++p) {
+        for (int p = 0; p < RB / RPP; ++p) {
             uint2 hh, ll;
             xt_split4(v[p], hh, ll);
             *reinterpret_cast<uint2*>(img + (p * RPP + r0) * LDK + c4 * 4) = hh;
@@ -190,32 +195,32 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
         asm volatile("" : "+v"(opq));            // (an opaque OFFSET: an opaque pointer loses the LDS address space -> flat loads)
         const __bf16* dhi = dh + opq;
         const __bf16* dlo = dhi + IMG;
-        f32x16 acc[4];
+        f32x16 acc[RT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            xt_bf16x8 d_hi[4], d_lo[4];
+            xt_bf16x8 d_hi[RT], d_lo[RT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RT; ++i) {
                 d_hi[i] = *reinterpret_cast<const xt_bf16x8*>(dhi + i * 32 * LDK + s * 16);
                 d_lo[i] = *reinterpret_cast<const xt_bf16x8*>(dlo + i * 32 * LDK + s * 16);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo[s], d_hi[i], acc[i], 0, 0, 0);
+            for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo[s], d_hi[i], acc[i], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[s], d_lo[i], acc[i], 0, 0, 0);
+            for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[s], d_lo[i], acc[i], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[s], d_hi[i], acc[i], 0, 0, 0);
+            for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[s], d_hi[i], acc[i], 0, 0, 0);
             load_w(nt + 4, s);
         }
         // ---- epilogue: registers 4 q .. 4 q + 3 of row tile i are columns 32 nt + 8 q + 4 h + {0..3} of row 32 i + col ----
         if (plain) {                              // uniform: the bare product (the edge projections)
             if constexpr (ROWS) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < RT; ++i) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         *reinterpret_cast<float4*>(stw + q * 8) = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
             for (int q = 0; q < 4; ++q) {
                 float* dst = C + (long long)(nt * 4 + q) * g.panel_ld * 8;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < RT; ++i)
                     *reinterpret_cast<float4*>(dst + i * 32 * 8) = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
             }
             continue;
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
             if (g.scale) { sc = *reinterpret_cast<const float4*>(g.scale + n); sh = *reinterpret_cast<const float4*>(g.shift + n); }
             float* dst = C + (long long)(nt * 4 + q) * g.panel_ld * 8;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RT; ++i) {
                 float4 v = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
                 v.x = (v.x + bi.x) * sc.x + sh.x; v.y = (v.y + bi.y) * sc.y + sh.y;
                 v.z = (v.z + bi.z) * sc.z + sh.z; v.w = (v.w + bi.w) * sc.w + sh.w;
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
         }
         if constexpr (ROWS) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RT; ++i) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     *reinterpret_cast<float4*>(stw + q * 8) = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
@@ -261,13 +266,13 @@ __global__ __launch_bounds__(XT_THREADS, 2) void gemm_x3t_kernel(X3tArgs g)
     }
 }
 
-template <int KS, bool ROWS = false>
+template <int KS, bool ROWS = false, int RB = 128>
 void x3t_launch(const X3tArgs& g, hipStream_t stream, int batch = 1)
 {
-    const size_t lds = (size_t)2 * 128 * (KS * 16 + 8) * sizeof(__bf16) + (ROWS ? 4 * 32 * 36 * sizeof(float) : 0);
-    auto kern = gemm_x3t_kernel<KS, ROWS>;
+    const size_t lds = (size_t)2 * RB * (KS * 16 + 8) * sizeof(__bf16) + (ROWS ? 4 * 32 * 36 * sizeof(float) : 0);
+    auto kern = gemm_x3t_kernel<KS, ROWS, RB>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(g.M / 128, batch), dim3(XT_THREADS), lds, stream, g);
+    hipLaunchKernelGGL(kern, dim3(g.M / RB, batch), dim3(XT_THREADS), lds, stream, g);
 }
 
 }  // namespace
@@ -351,7 +356,9 @@ extern "C" int lpd_gemm_x3t_rows(const float* A, long long lda, const void* frag
     X3tArgs g{A, fhi, fhi + (long long)NT * KS * 512, C, M, N, bias, scale, shift, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), 0, 0, 0, 0, 0,
               lda, ldc, sA, sC, frag_bytes / 2, c_bf16 ? 1 : 0};
     hipStream_t stream = (hipStream_t)stream_;
-    if (KS == 8) x3t_launch<8, true>(g, stream, batch);
+    static const int rb = lpd_debug("x3t-rb", 64);
+    if (KS == 8 && rb == 64 && c_bf16) x3t_launch<8, true, 64>(g, stream, batch);      // 64-row workgroups: two per CU instead of one (see the kernel; fp32 results: 116 us either way)
+    else if (KS == 8) x3t_launch<8, true>(g, stream, batch);
     else x3t_launch<4, true>(g, stream, batch);
     LPD_CHECK_LAUNCH("lpd_gemm_x3t_rows");
     return LPD_OK;

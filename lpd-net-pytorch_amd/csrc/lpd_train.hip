@@ -1172,7 +1172,7 @@ extern "C" int lpd_colstats(const float* X, long long ld, long long R, int C, do
         int w = 1024;
         while (w > C - c0) w >>= 1;
         const int RG = 256 / (w / 4);
-        hipLaunchKernelGGL(colstats_kernel, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream), X + c0, ld, R, w, ws.sum(), ws.sumsq());
+        hipLaunchKernelGGL(colstats_kernel, dim3(lpd_reduce_grid(grid_for(R, RG * 8))), dim3(256), 0, ST(stream), X + c0, ld, R, w, ws.sum(), ws.sumsq());
         LPD_CHECK_LAUNCH("lpd_colstats");
         if (int rc = lpd_stat_finish(ws, sum + c0, sumsq + c0, w, ST(stream))) return rc;
         c0 += w;
@@ -1230,7 +1230,7 @@ extern "C" int lpd_bn_act_bwd(const float* dY, long long lddy, const float* X, l
     LPD_CHECK_ARG(ws.rep, "lpd_bn_act_bwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     LPD_CHECK_STAT_COLS("lpd_bn_act_bwd", C);
     const int RG = 256 / (C / 4);
-    hipLaunchKernelGGL(act == 3 ? bn_act_bwd_reduce_kernel<true> : bn_act_bwd_reduce_kernel<false>, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream),
+    hipLaunchKernelGGL(act == 3 ? bn_act_bwd_reduce_kernel<true> : bn_act_bwd_reduce_kernel<false>, dim3(lpd_reduce_grid(grid_for(R, RG * 8))), dim3(256), 0, ST(stream),
                        dY, lddy, X, ldx, R, C, scale, shift, has_bn ? mean : nullptr, has_bn ? invstd : nullptr, act, slope, ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_bn_act_bwd(reduce)");
     if (int rc = lpd_stat_finish(ws, dbeta, dgamma, C, ST(stream))) return rc;
@@ -1257,7 +1257,8 @@ extern "C" int lpd_bn_act_bwd_bf16(const void* dY, long long lddy, const void* X
         const int w = C - c0 < LPD_STAT_CMAX ? C - c0 : LPD_STAT_CMAX;      // a power of two >= 8
         LPD_CHECK_STAT_COLS("lpd_bn_act_bwd_bf16", w);
         const int RG = 256 / (w / 8);
-        hipLaunchKernelGGL(act == 3 ? bn_act_bwd_reduce16_kernel<true> : bn_act_bwd_reduce16_kernel<false>, dim3(grid_for(R, RG * 8)), dim3(256), 0, ST(stream),
+        const int grid = lpd_reduce_grid(grid_for(R, RG * 8));
+        hipLaunchKernelGGL(act == 3 ? bn_act_bwd_reduce16_kernel<true> : bn_act_bwd_reduce16_kernel<false>, dim3(grid), dim3(256), 0, ST(stream),
                            reinterpret_cast<const uint16_t*>(dY) + c0, lddy, reinterpret_cast<const uint16_t*>(X) + c0, ldx, R, w, scale ? scale + c0 : nullptr,
                            shift ? shift + c0 : nullptr, has_bn ? mean + c0 : nullptr, has_bn ? invstd + c0 : nullptr, act, slope, ws.sum(), ws.sumsq());
         LPD_CHECK_LAUNCH("lpd_bn_act_bwd_bf16(reduce)");

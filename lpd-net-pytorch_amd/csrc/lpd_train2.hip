@@ -1280,9 +1280,9 @@ extern "C" int lpd_edge_split_bwd(const float* dOut, long long ldo, const float*
     LPD_CHECK_ARG(ws.rep, "lpd_edge_split_bwd: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     LPD_CHECK_STAT_COLS("lpd_edge_split_bwd", C);
     const int rg = 256 / (C / 4);
-    if (half) hipLaunchKernelGGL(edge_split_bwd_reduce_kernel<true>, dim3(grid_for(M, rg * 8, 2048)), dim3(256), 0, stream, dOut, ldo, usel, G, Q, ldq, M, C,
+    if (half) hipLaunchKernelGGL(edge_split_bwd_reduce_kernel<true>, dim3(lpd_reduce_grid(grid_for(M, rg * 8, 2048))), dim3(256), 0, stream, dOut, ldo, usel, G, Q, ldq, M, C,
                                  scale, shift, mean, invstd, act, slope, ws.sum(), ws.sumsq());
-    else hipLaunchKernelGGL(edge_split_bwd_reduce_kernel<false>, dim3(grid_for(M, rg * 8, 2048)), dim3(256), 0, stream, dOut, ldo, usel, G, Q, ldq, M, C,
+    else hipLaunchKernelGGL(edge_split_bwd_reduce_kernel<false>, dim3(lpd_reduce_grid(grid_for(M, rg * 8, 2048))), dim3(256), 0, stream, dOut, ldo, usel, G, Q, ldq, M, C,
                             scale, shift, mean, invstd, act, slope, ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_edge_split_bwd(reduce)");
     if (int rc = lpd_stat_finish(ws, dbeta, dgamma, C, stream)) return rc;

@@ -899,7 +899,7 @@ static int bn_sel_bwd_reduce_impl(const float* dOut, long long ldo, const float*
     LPD_CHECK_ARG(ws.rep, "lpd_bn_sel_bwd_reduce: stat_ws is null (lpd_stat_ws_bytes() bytes, zero-filled once by the caller)");
     LPD_CHECK_STAT_COLS("lpd_bn_sel_bwd_reduce", C);
     const int rg = 256 / (C / 4);
-    hipLaunchKernelGGL(bn_sel_bwd_reduce_kernel, dim3(grid_for(M, rg * 4, 4096)), dim3(256), 0, stream, dOut, ldo, Xsel, ldsel, M, C, scale,
+    hipLaunchKernelGGL(bn_sel_bwd_reduce_kernel, dim3(lpd_reduce_grid(grid_for(M, rg * 4, 4096))), dim3(256), 0, stream, dOut, ldo, Xsel, ldsel, M, C, scale,
                        shift, mean, invstd, act == 0 ? 1.0f : (act == 1 ? 0.0f : slope), dpre16, dpre32, ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_bn_sel_bwd_reduce");
     return lpd_stat_finish(ws, dbeta, dgamma, C, stream);
