@@ -183,49 +183,6 @@ def set_train_storage(kind):
     return prev
 
 
-# A second HIP stream inside the lpdnet trunk's training step (round 6; LPD_DEBUG=no-train-side: one stream).  The step's kernels are
-# bound by different units: the kNN searches and the two gather passes over the transposed graph by latency (64-80 % of their wave time
-# parked), the weight-gradient products by the matrix cores.  Work that nothing on the critical path waits for --
-# the xyz search and its transposed graph in the forward; dW3, the SN1 and DG2 weight gradients in the backward -- is enqueued on the
-# second stream AT THE POINT where the main stream reaches a latency-bound kernel (the fork is an event wait, so where it is placed
-# decides what runs beside what), and joined before its results are needed.  Same launches, same arguments: bit-identical gradients.
-# (Round 4 put the weight gradients next to the dX chain, MFMA-bound beside MFMA-bound: 9.32 against 9.28 ms.)
-TRAIN_SIDE = _debug.on("train-side")
-
-
-class _Side:
-    def __init__(self, device):
-        from . import engine
-        on = (TRAIN_SIDE and device.type == "cuda" and ops._TLS.PROFILE is None and engine._TLS.DEBUG_AUX is None
-              and not torch.cuda.is_current_stream_capturing())
-        self.main = torch.cuda.current_stream(device) if on else None
-        self.side = engine._side_stream(device) if on else None
-        self.pending = False
-
-    def run(self, fn, *inputs):
-        """fn() on the second stream, after everything the main stream has been given so far; `inputs`: tensors fn reads that the main
-        stream may free before the join (the allocator must not hand their memory out while the second stream still reads it)"""
-        if self.side is None:
-            return fn()
-        self.side.wait_stream(self.main)
-        for t in inputs:
-            if t is not None:
-                t.record_stream(self.side)
-        with torch.cuda.stream(self.side):
-            out = fn()
-        for o in (out if isinstance(out, (tuple, list)) else (out,)):
-            for t in ((o.rowptr, o.edges) if isinstance(o, ops.GraphT) else (o,)):
-                if isinstance(t, torch.Tensor):
-                    t.record_stream(self.main)
-        self.pending = True
-        return out
-
-    def join(self):
-        if self.pending:
-            self.main.wait_stream(self.side)
-            self.pending = False
-
-
 def _saved(ctx):
     """The forward's saved tensors live in a plain dict on ctx (freed at the end of backward: several GB of edge tensors)."""
     if ctx.saved is None:
@@ -492,15 +449,6 @@ class _LPDNetTrainFn(torch.autograd.Function):
             x = xyz.view(B, 1, N, 3)
         else:
             xyz = x.view(M, 3)
-        # the xyz graph (SN1's, util/lpdnet_model.py:255) depends on the input alone: searched and transposed on the second stream while
-        # the main stream runs the per-point layers, the feature-space search and the DG1 -> DG2 stage
-        sd = _Side(x.device)
-        xyz_rows = x.view(B * N, 3)
-
-        def xyz_graph():
-            i = engine._knn_rows(xyz_rows, B, N, 3, k)
-            return i, ops.GraphT(i, N)
-        side_x = sd.run(xyz_graph, xyz_rows) if sd.side is not None else None
         f0, front = _Front.fwd(net, xyz, w2d(net.conv1_lpd), net.bn1_lpd, w2d(net.conv2_lpd), net.bn2_lpd, B, N, act, slope, p_all)
         idx_f = engine._knn_rows(f0, B, N, 64, k)
         cat = torch.empty((M, 512), dtype=torch.float32, device=x.device)
@@ -551,13 +499,9 @@ class _LPDNetTrainFn(torch.autograd.Function):
             z, stg2 = ops.linear_bn_stats(y1e, w2d(net.convDG2[0]), net.convDG2[1])   # [E,128] raw + its statistics (GEMM epilogue)
             arg2, zsel = ops.group_max(z, k, stg2.scale, stg2.shift, act, slope, cat[:, 128:256], keep_sel=True)   # x2
         # SN1 on the xyz graph, split form: statistics, max and arg-max from one gather pass, no [E,256] tensor
+        idx_x = engine._knn_rows(x.view(B * N, 3), B, N, 3, k)
         wcat3 = engine.split_edge_weight(net.convSN1, "cat_nc")
         pq3 = ops.linear(cat[:, 128:256], wcat3)                                # [M,512] = [P | Q]
-        if side_x is not None:
-            sd.join()
-            idx_x, gt_x = side_x
-        else:
-            idx_x, gt_x = engine._knn_rows(xyz_rows, B, N, 3, k), None
         s3, usel3, arg3, stg3 = ops.edge_split_fwd(pq3[:, :256], pq3[:, 256:], idx_x, N, bn=net.convSN1[1])
         ops.affine_act(usel3, stg3.scale, stg3.shift, act, slope, out=cat[:, 256:512], out16=c16(256, 512))                # x3
         if defer:
@@ -570,7 +514,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
             y3, st3, feat = _PointLayer.fwd(cat, w2d(net.conv3_lpd), net.bn3_lpd, act, slope)
             _LAST.pending = None
         ctx.net, ctx.dims, ctx.actslope, ctx.bf16 = net, (B, N, M, k), (act, slope), bf16
-        ctx.saved = dict(front=front, f0=f0, idx_f=idx_f, idx_x=idx_x, gt_x=gt_x, wcat1=wcat1, post1=post1, post1c=post1c, pq1=pq1 if post1 else None, s1sum=s1sum,
+        ctx.saved = dict(front=front, f0=f0, idx_f=idx_f, idx_x=idx_x, wcat1=wcat1, post1=post1, post1c=post1c, pq1=pq1 if post1 else None, s1sum=s1sum,
                          u1=u1, stg1=stg1, arg1=arg1, y1e=y1e, z=z, zsel=zsel, stg2=stg2, arg2=arg2, wcat3=wcat3, pq3=pq3, s3=s3, usel3=usel3,
                          stg3=stg3, arg3=arg3, cat=cat, cat16=cat16, y3=y3, st3=st3)
         if engine.DEBUG_AUX is not None:
@@ -593,14 +537,11 @@ class _LPDNetTrainFn(torch.autograd.Function):
         act, slope = ctx.actslope
         w2d = engine._w2d
         dfeat = dfeat.contiguous()
-        sd = _Side(dfeat.device)
         # conv3 + bn3 (the incoming gradient buffer belongs to autograd: not modified in place)
         if S["y3"].dtype == torch.bfloat16:      # bf16 map (forward: map16): bf16 gradient in, bf16 dY3, two-product GEMMs on it
             dy3, dg3, db3 = ops.bn_act_bwd_bf16(dfeat, S["y3"], S["st3"], act, slope)
+            dw3 = ops.gemm_tn(dy3, S["cat"] if S["cat16"] is None else S["cat16"])
             dcat = ops.gemm_bf16a(dy3, w2d(net.conv3_lpd), b_kmajor=True)
-            # dW3 (matrix cores) next to SN1's gather pass over the transposed graph (latency-bound): forked HERE, behind the dX product
-            xcat = S["cat"] if S["cat16"] is None else S["cat16"]
-            dw3 = sd.run(lambda: ops.gemm_tn(dy3, xcat), dy3, xcat)
             del dy3
         else:
             dcat, dw3, dg3, db3 = _PointLayer.bwd(dfeat, S["cat"], w2d(net.conv3_lpd), S["y3"], S["st3"], act, slope,
@@ -612,15 +553,15 @@ class _LPDNetTrainFn(torch.autograd.Function):
         dpq3 = torch.empty((M, 512), dtype=torch.bfloat16 if pq16 else torch.float32, device=dfeat.device)    # both halves are fully written below
         pq3 = S["pq3"]
         dgs3, dbs3 = ops.edge_split_bwd(dcat[:, 256:512], S["usel3"], S["arg3"], S["s3"], pq3[:, :256], pq3[:, 256:],
-                                        S.get("gt_x") or ops.GraphT(S["idx_x"], N), S["stg3"], act, slope, k, dP=dpq3[:, :256],
-                                        dQ=dpq3[:, 256:], half=ctx.bf16)
+                                        ops.GraphT(S["idx_x"], N), S["stg3"], act, slope, k, dP=dpq3[:, :256], dQ=dpq3[:, 256:],
+                                        half=ctx.bf16)
         x2 = S["cat"][:, 128:256]
         if pq16:
+            dwcat3 = ops.gemm_tn(dpq3, x2)
             ops.gemm_bf16a(dpq3, S["wcat3"], b_kmajor=True, out=dcat[:, 128:256], accumulate=True)
         else:
+            dwcat3 = _dweight(dpq3, x2)
             ops.gemm(dpq3, S["wcat3"], b_kmajor=True, out=dcat[:, 128:256], accumulate=True)   # dx2 += dPQ3 Wcat3
-        later = []       # weight gradients that wait for the next latency-bound kernel of the main stream (closed-form path below)
-        later.append(lambda: ops.gemm_tn(dpq3, x2) if pq16 else _dweight(dpq3, x2))
         dpq1 = torch.empty((M, 256), dtype=torch.float32, device=dfeat.device)
         w2 = w2d(net.convDG2[0])
         closed = (S["post1"] and ops.EDGE_MLP_TRAIN_BWD and ops.dg2_bwd_fused_applies(M, k, w2.shape[0]) and w2.shape[1] == 128
@@ -635,17 +576,13 @@ class _LPDNetTrainFn(torch.autograd.Function):
             # reductions (lpd_edge_mlp_train_bwd); then ONE gather pass over the transposed graph gives dP / dQ in closed form
             dt = torch.bfloat16 if ctx.bf16 else torch.float32
             dpre2, red2 = ops.bn_sel_bwd_reduce(dcat[:, 128:256], S["zsel"], S["stg2"], act, slope, dtype=dt)
+            dw2 = (ops.edge_dw_sel_bf16 if ctx.bf16 else ops.edge_dw_sel_f32)(S["y1e"], S["arg2"], dpre2, k, w2, S["stg2"], red2)
             redf = red2.float()
             dgs2, dbs2 = redf[1], redf[0]
-            gt_f = ops.GraphT(S["idx_f"], N)
             G1, gsum1, red1 = ops.edge_mlp_train_bwd(S["z"], S["arg2"], dpre2, w2, S["stg2"], red2, S["y1e"], S["arg1"], dcat[:, 0:128],
                                                      S["post1c"], k, act, slope)
-            # the DG2 and SN1 weight gradients next to DG1's gather pass (forked behind the dense DG2 / DG1 backward)
-            y1e_, arg2_, stg2_ = S["y1e"], S["arg2"], S["stg2"]
-            dw2, dwcat3 = sd.run(lambda: ((ops.edge_dw_sel_bf16 if ctx.bf16 else ops.edge_dw_sel_f32)(y1e_, arg2_, dpre2, k, w2, stg2_, red2),
-                                          later.pop()()), y1e_, arg2_, dpre2, red2, dpq3, x2)
             pq1 = S["pq1"]
-            ops.edge_dense_bwd_apply(G1, gsum1, S["s1sum"], pq1[:, :128], pq1[:, 128:], gt_f, S["stg1"], red1, k,
+            ops.edge_dense_bwd_apply(G1, gsum1, S["s1sum"], pq1[:, :128], pq1[:, 128:], ops.GraphT(S["idx_f"], N), S["stg1"], red1, k,
                                      dP=dpq1[:, :128], dQ=dpq1[:, 128:])
             red1f = red1.float()
             dgs1, dbs1 = red1f[1], red1f[0]
@@ -653,7 +590,6 @@ class _LPDNetTrainFn(torch.autograd.Function):
             del G1, gsum1
         elif ctx.bf16:
             # DG2: x2 = groupmax(act(BN(Z))), Z = Y1e W2^T  (bf16 edge tensors, bf16 MFMA products)
-            dwcat3 = later.pop()()
             w2 = w2d(net.convDG2[0])
             if ops.dg2_bwd_fused_applies(M, k, w2.shape[0]) and w2.shape[1] == 128:
                 # no dZ tensor: dW2 from one pass over Y1e (arg-max product + Gram matrix), dY1e = dZ W2 with dZ built in the loader
@@ -673,7 +609,6 @@ class _LPDNetTrainFn(torch.autograd.Function):
             ops.gather_sum_rows_bf16(du1, ops.GraphT(S["idx_f"], N), dpq1[:, :128])
         else:
             # DG2: x2 = groupmax(act(BN(Z))), Z = Y1e W2^T
-            dwcat3 = later.pop()()
             w2 = w2d(net.convDG2[0])
             if (ops.dg2_bwd_fused_applies(M, k, w2.shape[0]) and w2.shape[1] == 128 and ops.GEMM_BF16X3 and ops._EXACT.depth == 0
                     and S["z"].is_contiguous() and S["y1e"].is_contiguous()):
@@ -699,7 +634,6 @@ class _LPDNetTrainFn(torch.autograd.Function):
             engine.DEBUG_AUX.update(dcat=dcat.clone(), dpq3=dpq3.clone(), dpq1=dpq1.clone(), df0=df0.clone())
         (dwc1, dg1, db1, dwc2, dg2, db2), extra = _Front.bwd(net, df0, S["front"], w2d(net.conv1_lpd), w2d(net.conv2_lpd), B, N,
                                                              act, slope)
-        sd.join()
         grads = (dwc1.reshape(net.conv1_lpd.weight.shape), dg1, db1, dwc2.reshape(net.conv2_lpd.weight.shape), dg2, db2,
                  _unsplit_cat_nc(dwcat1, net.convDG1[0].weight), dgs1, dbs1, dw2.reshape(net.convDG2[0].weight.shape), dgs2,
                  dbs2, _unsplit_cat_nc(dwcat3, net.convSN1[0].weight), dgs3, dbs3, dw3.reshape(net.conv3_lpd.weight.shape),
