@@ -401,7 +401,8 @@ int lpd_bn_finalize(const double* sum, const double* sumsq, double count, int C,
 /* Y = act(scale * X + shift) elementwise per column (scale/shift NULL = identity affine).  In-place allowed. */
 int lpd_affine_act(const float* X, long long ldx, float* Y, long long ldy, long long R, int C, const float* scale,
                    const float* shift, int act, float slope, void* stream);
-/* the same with a bf16 copy of the result rows beside the fp32 ones (Y16 [R][ld16] in bf16 elements, ld16 % 4 == 0) */
+/* the same with a bf16 copy of the result rows beside the fp32 ones (Y16 [R][ld16] in bf16 elements, ld16 % 4 == 0); Y may be NULL: only
+   the bf16 rows are written */
 int lpd_affine_act2(const float* X, long long ldx, float* Y, long long ldy, void* Y16, long long ld16, long long R, int C, const float* scale,
                     const float* shift, int act, float slope, void* stream);
 

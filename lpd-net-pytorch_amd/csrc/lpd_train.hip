@@ -140,7 +140,7 @@ __global__ void affine_act_kernel(const float* __restrict__ X, long long ldx, fl
             const float ns = lpd_neg_slope(act, slope);
             y.x = lpd_act_pl(y.x, ns); y.y = lpd_act_pl(y.y, ns); y.z = lpd_act_pl(y.z, ns); y.w = lpd_act_pl(y.w, ns);
         }
-        *reinterpret_cast<float4*>(Y + r * ldy + q * 4) = y;
+        if (Y) *reinterpret_cast<float4*>(Y + r * ldy + q * 4) = y;      // uniform (null: the bf16 copy is the only consumer's form)
         if (Y16) {       // uniform
             const unsigned w0 = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)y.x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)y.y) << 16);
             const unsigned w1 = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)y.z) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)y.w) << 16);
@@ -1205,11 +1205,12 @@ extern "C" int lpd_affine_act(const float* X, long long ldx, float* Y, long long
 }
 
 // lpd_affine_act with a bf16 copy of the result rows beside the fp32 ones (Y16 [R][ld16] bf16 elements, ld16 % 4 == 0): the bf16 storage
-// mode's second form of the point features [x1 | x2 | x3] (the conv3 operand and the B operand of its weight gradient)
+// mode's second form of the point features [x1 | x2 | x3] (the conv3 operand and the B operand of its weight gradient).  Y may be null:
+// only the bf16 rows are written (x1 and x3, whose fp32 form nothing reads in that mode: 277 MB of stores per step at 44 clouds)
 extern "C" int lpd_affine_act2(const float* X, long long ldx, float* Y, long long ldy, void* Y16, long long ld16, long long R, int C,
                                const float* scale, const float* shift, int act, float slope, void* stream)
 {
-    LPD_CHECK_ARG(X && Y && Y16 && R > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ld16 % 4 == 0 && ((uintptr_t)Y16 & 7) == 0,
+    LPD_CHECK_ARG(X && Y16 && R > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && (!Y || ldy % 4 == 0) && ld16 % 4 == 0 && ((uintptr_t)Y16 & 7) == 0,
                   "lpd_affine_act2: bad arguments");
     LPD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "lpd_affine_act2: scale and shift come in pairs");
     hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(R * (C / 4), 256 * 4)), dim3(256), 0, ST(stream), X, ldx, Y, ldy, R,

@@ -468,6 +468,9 @@ class _LPDNetTrainFn(torch.autograd.Function):
         cat16 = (torch.empty((M, 512), dtype=torch.bfloat16, device=x.device)
                  if (map16 and post1 and CAT_BF16 and Co3 % 256 == 0 and M % 32 == 0) else None)
         c16 = (lambda a, b: cat16[:, a:b]) if cat16 is not None else (lambda a, b: None)
+        # with the bf16 copy in place nothing reads the fp32 form of x1 and x3 (conv3 and dW3 take the copy; the SN1 projection and its
+        # weight gradient read x2): their fp32 columns of `cat` stay unwritten -- 277 MB of stores per step at 44 clouds
+        o16 = cat16 is not None and engine.DEBUG_AUX is None
         post1c = None
         if post1:
             # ONE launch for the stage (lpd_edge_mlp_train): the raw edge tensor U1 is never written.  Its BatchNorm statistics, and
@@ -475,7 +478,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
             # so the maximum is act(BN(.)) of the selected raw value); the fused kernel builds Y1e from the gathered rows, multiplies it
             # by W2 and leaves Y1e, Z, the statistics of Z and its per-point selection (by the sign of gamma2) behind
             s1sum, usel1, arg1, stg1 = ops.edge_split_fwd(pq1[:, :128], pq1[:, 128:], idx_f, N, bn=net.convDG1[1])
-            ops.affine_act(usel1, stg1.scale, stg1.shift, act, slope, out=cat[:, 0:128], out16=c16(0, 128))                # x1
+            ops.affine_act(usel1, stg1.scale, stg1.shift, act, slope, out=cat[:, 0:128], out16=c16(0, 128), only16=o16)    # x1
             # (fp32 storage: Z as bf16 when the backward is the one that only takes xhat2 from it, lpd_edge_mlp_train_bwd)
             z16 = bf16 or (ops.Z_BF16 and ops.EDGE_MLP_TRAIN_BWD and ops.dg2_bwd_fused_applies(M, k, 128) and M % 32 == 0)
             # ... and (bf16 storage) no Z at all when that backward will run: it forms the xhat2 term as Y1e K (ops.EDGE_NOZ)
@@ -503,7 +506,7 @@ class _LPDNetTrainFn(torch.autograd.Function):
         wcat3 = engine.split_edge_weight(net.convSN1, "cat_nc")
         pq3 = ops.linear(cat[:, 128:256], wcat3)                                # [M,512] = [P | Q]
         s3, usel3, arg3, stg3 = ops.edge_split_fwd(pq3[:, :256], pq3[:, 256:], idx_x, N, bn=net.convSN1[1])
-        ops.affine_act(usel3, stg3.scale, stg3.shift, act, slope, out=cat[:, 256:512], out16=c16(256, 512))                # x3
+        ops.affine_act(usel3, stg3.scale, stg3.shift, act, slope, out=cat[:, 256:512], out16=c16(256, 512), only16=o16)    # x3
         if defer:
             # PointNetVlad's train path: bn3 + act are applied by the NetVLAD assignment product's operand loader (ops.gemm_act), which
             # also writes the activated map; this Function hands the RAW conv3 output on, with the affine in _LAST.pending

@@ -1258,23 +1258,25 @@ def colsum(X, rows=None):
     return sums[0].float()
 
 
-def affine_act(X, scale, shift, act=ACT_NONE, slope=0.01, out=None, rows=None, out16=None):
+def affine_act(X, scale, shift, act=ACT_NONE, slope=0.01, out=None, rows=None, out16=None, only16=False):
     """out = act(scale * X + shift) over the (first `rows`) rows; out16: a bfloat16 tensor (column slices allowed) that receives a copy
-    of the result rows rounded to bf16 (lpd_affine_act2)."""
+    of the result rows rounded to bf16 (lpd_affine_act2); only16: nothing but that copy is written (returns out16)."""
     ldx = _rows(X, "X")
     R = X.shape[0] if rows is None else rows
     C = X.shape[1]
-    if out is None:
+    if only16 and out16 is None:
+        raise ValueError("affine_act: only16 needs out16")
+    if out is None and not only16:
         out = torch.empty((X.shape[0], C), dtype=torch.float32, device=X.device)
-    ldy = _rows(out, "out")
+    ldy = 0 if only16 else _rows(out, "out")
     lib = _lib.load()
     if out16 is not None:
         _req(out16, "out16", torch.bfloat16)
         if out16.dim() != 2 or out16.stride(1) != 1 or out16.shape[1] != C or out16.shape[0] < R or out16.stride(0) % 4 != 0:
             raise ValueError("affine_act: out16 must be bf16 rows of the result's shape")
-        _call("affine_act", lib.lpd_affine_act2, _ptr(X), ldx, _ptr(out), ldy, _ptr(out16), out16.stride(0), R, C, _ptr(scale), _ptr(shift), act,
-              float(slope), _stream())
-        return out
+        _call("affine_act", lib.lpd_affine_act2, _ptr(X), ldx, None if only16 else _ptr(out), ldy, _ptr(out16), out16.stride(0), R, C, _ptr(scale),
+              _ptr(shift), act, float(slope), _stream())
+        return out16 if only16 else out
     _call("affine_act", lib.lpd_affine_act, _ptr(X), ldx, _ptr(out), ldy, R, C, _ptr(scale), _ptr(shift), act, float(slope),
           _stream())
     return out
