@@ -150,11 +150,32 @@ __global__ __launch_bounds__(256) void edge_gather_max_kernel(GatherArgs g)
 // ------------------------------------------------------------------------------------------
 constexpr unsigned KAGG_IMG1 = 65536 + 128;   // byte offset of the second LDS image (channels 4-7 of the slice)
 
+// Packed indices (lpd_pack_idx16), round 6: per block of 32 points [chunk 0: indices 0-7 of the 32 points, 16 B each | chunk 1: indices
+// 8-15 | chunk 2: indices 16-19, 8 B each] = 1280 bytes.  The two lanes of a point (cl = 0 / 1) load ONE 16-byte piece each (chunk cl) plus
+// the shared 8-byte tail and hand their piece to the partner by DPP where the gathers consume it: two load instructions per point and
+// pass instead of five 8-byte ones, the same ten cache lines per wave.  (The kernel is bound by memory requests per CU -- its Q and out
+// traffic, 2 of 8 instructions per pass, cost 26 % of its time -- and the index loads were 5 of those 8.)
 struct CloudOps {
-    uint2 ix[5];    // 20 16-bit neighbour indices
+    uint4 own;      // indices 8 cl .. 8 cl + 7 (16-bit byte offsets of the row pieces)
+    uint2 tail;     // indices 16-19
     float4 q;
     unsigned m;     // global row of the point (32-bit element offsets: the host checks M * ld * 4 < 2^32)
 };
+__device__ __forceinline__ void kagg_load_idx(CloudOps& o, const unsigned char* idxb, unsigned cl)
+{
+    const unsigned char* blk = idxb + (size_t)(o.m >> 5) * 1280u + (o.m & 31u) * 8u;
+    o.own = *reinterpret_cast<const uint4*>(blk + cl * 512u + (o.m & 31u) * 8u);
+    o.tail = *reinterpret_cast<const uint2*>(blk + 1024u);
+}
+// the five index quads of a point in SLOT order (ix[i].x: slots 4 i, 4 i + 1; .y: 4 i + 2, 4 i + 3)
+__device__ __forceinline__ void kagg_quads(const CloudOps& o, unsigned cl, uint2 (&ix)[5])
+{
+    const uint4 pt = make_uint4(lpd_lane_xor1(o.own.x), lpd_lane_xor1(o.own.y), lpd_lane_xor1(o.own.z), lpd_lane_xor1(o.own.w));
+    const uint4 lo = cl ? pt : o.own, hi = cl ? o.own : pt;
+    ix[0] = make_uint2(lo.x, lo.y); ix[1] = make_uint2(lo.z, lo.w);
+    ix[2] = make_uint2(hi.x, hi.y); ix[3] = make_uint2(hi.z, hi.w);
+    ix[4] = o.tail;
+}
 
 template <bool HAS_Q, bool SPLIT = false>
 __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArgs g, const uint16_t* __restrict__ idx16,
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArg
     const unsigned row0 = (unsigned)b * g.N;
     const int N = g.N;
     const int passes = (N + GROUPS - 1) / GROUPS;
-    const uint2* idx2 = reinterpret_cast<const uint2*>(idx16);
+    const unsigned char* idxb = reinterpret_cast<const unsigned char*>(idx16);
     const float* Qc = g.Q + b * g.q_cloud + sl * g.q_slice + cl * 4;      // row n of the cloud at + n * ld
     float* outc = SPLIT ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(g.out) + b * g.o_cloud + sl * g.o_slice)
                         : g.out + b * g.o_cloud + sl * g.o_slice + cl * 4;
@@ -188,10 +209,7 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArg
     // no divergent tail, so the row reads below are consumed as they arrive instead of being sunk into a branch.
     auto load = [&](CloudOps& o, int ps) {
         o.m = row0 + min(ps * GROUPS + grp, N - 1);
-        // blocked index layout [M/32][5][32] uint2 (lpd_pack_idx16): a wave's load touches 4 lines instead of 20
-        const uint2* ip = idx2 + ((o.m >> 5) * (KQ * 32) + (o.m & 31));   // one address, five immediate offsets
-#pragma unroll
-        for (int i = 0; i < KQ; ++i) o.ix[i] = ip[i * 32];
+        kagg_load_idx(o, idxb, cl);
         if (HAS_Q) o.q = *reinterpret_cast<const float4*>(Qc + (o.m - row0) * ldq);
     };
 
@@ -222,12 +240,14 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16_kernel(GatherArg
 
     auto process = [&](const CloudOps& o) {
         float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        const uint2 ix[5] = {make_uint2(o.own.x, o.own.y), make_uint2(o.own.z, o.own.w),
+                             make_uint2(lpd_lane_xor1(o.own.x), lpd_lane_xor1(o.own.y)), make_uint2(lpd_lane_xor1(o.own.z), lpd_lane_xor1(o.own.w)), o.tail};
 #pragma unroll
         for (int i = 0; i < KQ; ++i) {
-            const float4 a = *reinterpret_cast<const float4*>(winb + ((o.ix[i].x & 0xffffu) + lbase));
-            const float4 bq = *reinterpret_cast<const float4*>(winb + ((o.ix[i].x >> 16) + lbase));
-            const float4 c = *reinterpret_cast<const float4*>(winb + ((o.ix[i].y & 0xffffu) + lbase));
-            const float4 d = *reinterpret_cast<const float4*>(winb + ((o.ix[i].y >> 16) + lbase));
+            const float4 a = *reinterpret_cast<const float4*>(winb + ((ix[i].x & 0xffffu) + lbase));
+            const float4 bq = *reinterpret_cast<const float4*>(winb + ((ix[i].x >> 16) + lbase));
+            const float4 c = *reinterpret_cast<const float4*>(winb + ((ix[i].y & 0xffffu) + lbase));
+            const float4 d = *reinterpret_cast<const float4*>(winb + ((ix[i].y >> 16) + lbase));
             v.x = fmaxf(fmaxf(v.x, a.x), bq.x); v.y = fmaxf(fmaxf(v.y, a.y), bq.y);
             v.z = fmaxf(fmaxf(v.z, a.z), bq.z); v.w = fmaxf(fmaxf(v.w, a.w), bq.w);
             v.x = fmaxf(fmaxf(v.x, c.x), d.x); v.y = fmaxf(fmaxf(v.y, c.y), d.y);
@@ -288,14 +308,12 @@ __global__ __launch_bounds__(THREADS) void edge_split_fwd_cloud16_kernel(SplitFw
     const unsigned row0 = (unsigned)b * g.N;
     const int N = g.N, C = g.C;
     const int passes = (N + GROUPS - 1) / GROUPS;
-    const uint2* idx2 = reinterpret_cast<const uint2*>(idx16);
+    const unsigned char* idxb = reinterpret_cast<const unsigned char*>(idx16);
     const float* Qc = g.Q + (size_t)row0 * g.ldq + col;
     const unsigned ldq = g.ldq;
     auto load = [&](CloudOps& o, int ps) {
         o.m = row0 + min(ps * GROUPS + grp, N - 1);
-        const uint2* ip = idx2 + ((o.m >> 5) * (KQ * 32) + (o.m & 31));
-#pragma unroll
-        for (int i = 0; i < KQ; ++i) o.ix[i] = ip[i * 32];
+        kagg_load_idx(o, idxb, cl);
         o.q = *reinterpret_cast<const float4*>(Qc + (o.m - row0) * ldq);
     };
     const float4 gm = *reinterpret_cast<const float4*>(g.gamma + col);
@@ -336,12 +354,14 @@ __global__ __launch_bounds__(THREADS) void edge_split_fwd_cloud16_kernel(SplitFw
                 ab[c] = take ? t : ab[c];
             }
         };
+        uint2 ix[5];
+        kagg_quads(o, cl, ix);       // slot order: the first extremum decides the arg-max
 #pragma unroll
         for (int i = 0; i < KQ; ++i) {
-            edge(o.ix[i].x & 0xffffu, 4 * i);
-            edge(o.ix[i].x >> 16, 4 * i + 1);
-            edge(o.ix[i].y & 0xffffu, 4 * i + 2);
-            edge(o.ix[i].y >> 16, 4 * i + 3);
+            edge(ix[i].x & 0xffffu, 4 * i);
+            edge(ix[i].x >> 16, 4 * i + 1);
+            edge(ix[i].y & 0xffffu, 4 * i + 2);
+            edge(ix[i].y >> 16, 4 * i + 3);
             __builtin_amdgcn_sched_barrier(0);
         }
         const float sgn[4] = {sg.x, sg.y, sg.z, sg.w}, q[4] = {o.q.x, o.q.y, o.q.z, o.q.w};
@@ -413,7 +433,7 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16p_kernel(GatherAr
     const int w_end = min(w_begin + per, nwork);
     if (w_begin >= w_end) return;
     const int N = g.N;
-    const uint2* idx2 = reinterpret_cast<const uint2*>(idx16);
+    const unsigned char* idxb = reinterpret_cast<const unsigned char*>(idx16);
     const unsigned ldq = g.ldq, ldo = g.ldo;
     auto p_slice_ptr = [&](int w) { return g.P + (long long)(w / nslices) * g.p_cloud + (long long)(w % nslices) * g.p_slice + cl * 4; };
 
@@ -442,9 +462,7 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16p_kernel(GatherAr
                                       sc.w >= 0.f ? 1.f : -1.f);
         auto load = [&](CloudOps& o, int ps) {
             o.m = row0 + min(ps * GROUPS + grpw, N - 1);
-            const uint2* ip = idx2 + ((o.m >> 5) * (KQ * 32) + (o.m & 31));
-#pragma unroll
-            for (int i = 0; i < KQ; ++i) o.ix[i] = ip[i * 32];
+            kagg_load_idx(o, idxb, cl);
             if (HAS_Q) o.q = *reinterpret_cast<const float4*>(Qc + (o.m - row0) * ldq);
         };
         CloudOps ops3[3];
@@ -461,12 +479,15 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16p_kernel(GatherAr
         __syncthreads();
         auto process = [&](const CloudOps& o) {
             float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            // (the maximum is order-free: own piece, partner's piece, tail -- no selects)
+            const uint2 ix[5] = {make_uint2(o.own.x, o.own.y), make_uint2(o.own.z, o.own.w),
+                                 make_uint2(lpd_lane_xor1(o.own.x), lpd_lane_xor1(o.own.y)), make_uint2(lpd_lane_xor1(o.own.z), lpd_lane_xor1(o.own.w)), o.tail};
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
-                const float4 a = *reinterpret_cast<const float4*>(winb + ((o.ix[i].x & 0xffffu) + lbase));
-                const float4 bq = *reinterpret_cast<const float4*>(winb + ((o.ix[i].x >> 16) + lbase));
-                const float4 c = *reinterpret_cast<const float4*>(winb + ((o.ix[i].y & 0xffffu) + lbase));
-                const float4 d = *reinterpret_cast<const float4*>(winb + ((o.ix[i].y >> 16) + lbase));
+                const float4 a = *reinterpret_cast<const float4*>(winb + ((ix[i].x & 0xffffu) + lbase));
+                const float4 bq = *reinterpret_cast<const float4*>(winb + ((ix[i].x >> 16) + lbase));
+                const float4 c = *reinterpret_cast<const float4*>(winb + ((ix[i].y & 0xffffu) + lbase));
+                const float4 d = *reinterpret_cast<const float4*>(winb + ((ix[i].y >> 16) + lbase));
                 v.x = fmaxf(fmaxf(v.x, a.x), bq.x); v.y = fmaxf(fmaxf(v.y, a.y), bq.y);
                 v.z = fmaxf(fmaxf(v.z, a.z), bq.z); v.w = fmaxf(fmaxf(v.w, a.w), bq.w);
                 v.x = fmaxf(fmaxf(v.x, c.x), d.x); v.y = fmaxf(fmaxf(v.y, c.y), d.y);
@@ -496,8 +517,8 @@ __global__ __launch_bounds__(1024) void edge_gather_max_cloud16p_kernel(GatherAr
     }
 }
 
-// int32 [M][20] -> uint16 (16 * index; indices < 4096), blocked for the kernel above: point m, index quad i (4 x u16 = uint2) at
-// ((m / 32) * 5 + i) * 32 + m % 32.  One thread per (point, quad).
+// int32 [M][20] -> uint16 (16 * index; indices < 4096), blocked for the kernels above (CloudOps): per 32 points 1280 bytes =
+// [32 x 16 B: index quads 0, 1 | 32 x 16 B: quads 2, 3 | 32 x 8 B: quad 4].  One thread per (point, quad).
 __global__ void pack_idx16_kernel(const int32_t* __restrict__ in, uint2* __restrict__ out, long long M)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -508,7 +529,9 @@ __global__ void pack_idx16_kernel(const int32_t* __restrict__ in, uint2* __restr
     uint2 o;
     o.x = (uint32_t)((v.x << 4) & 0xffff) | ((uint32_t)v.y << 20);     // 16 * index: the byte offset of the row piece in LDS
     o.y = (uint32_t)((v.z << 4) & 0xffff) | ((uint32_t)v.w << 20);
-    out[((m >> 5) * 5 + i) * 32 + (m & 31)] = o;
+    const long long blk = (m >> 5) * 160;                               // uint2 units: 1280 bytes per block
+    const int p = (int)(m & 31);
+    out[blk + (i < 4 ? (i >> 1) * 64 + p * 2 + (i & 1) : 128 + p)] = o;
 }
 
 // ------------------------------------------------------------------------------------------
