@@ -53,6 +53,22 @@ def train_step(model, optimizer, queries, positives, negatives, other_neg, *, ma
     return loss
 
 
+_RINGS = {}
+
+
+def _stream_ring(device, n):
+    """The n HIP streams of a pipeline, ONE ring per (device, n, host thread), kept for the life of the process.  A pipeline is created
+    per call (PointNetVlad.forward makes one for every eval batch above 32 clouds): with fresh torch.cuda.Stream objects each time the
+    caching allocator -- whose free blocks belong to the stream that allocated them -- met every forward with empty pools and went to
+    hipMalloc inside it (128 clouds per step: 8.4 ms against 7.2 ms for the four slices one after the other)."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n, __import__("threading").get_ident())
+    ring = _RINGS.get(key)
+    if ring is None:
+        ring = _RINGS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return ring
+
+
 class BatchPipeline:
     """Embeds a SEQUENCE of independent eval batches with `in_flight` of them on the GPU at once (round 6).
 
@@ -73,7 +89,7 @@ class BatchPipeline:
             raise ValueError("BatchPipeline: in_flight >= 1")
         self.model = model
         self.device = device if device is not None else next(model.parameters()).device
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(in_flight)] if in_flight > 1 else []
+        self.streams = _stream_ring(self.device, in_flight) if in_flight > 1 else []
         self.count = 0
         self._used = set()
 
