@@ -156,7 +156,7 @@ def compact_line(full, detail_name="bench_detail.json"):
     roof = full.get("roofline")
     if roof:
         r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "frac_direct_form", "algorithmic_bytes_per_launch", "avg_launch_us"))
-        r["kernel"] = str(roof.get("kernel", ""))[:120]
+        r["kernel"] = str(roof.get("kernel", ""))[:160]
         r["traffic"] = roof.get("traffic")
         if isinstance(roof.get("stage"), dict):
             r["stage_frac_direct_form"] = roof["stage"].get("frac_direct_form")
@@ -725,6 +725,10 @@ def main():
     torch.cuda.synchronize()
 
     # ---- the timed region of the contract: EXACTLY K steps between barrier + synchronize ----
+    # (no event hooks here: with several batches in flight an event pair around a launch also spans the time the launch waits for CUs
+    #  behind the other batch's kernels -- 150 us where rocprofv3 sees a 105-us kernel -- so the roofline kernel is timed in the second
+    #  region below, one batch in flight, where a launch has the chip to itself: 93 us by events, 91 us by rocprofv3,
+    #  profiles/r06_eval10_one_in_flight_kernel_stats.csv)
     pipe.join()
     if dist is not None:
         dist.barrier()
@@ -814,7 +818,8 @@ def main():
                         break
             except Exception:
                 traffic = None
-        roof = {"kernel": f"{kname}, SN1 stage, C=256, k={args.k}", "bound": "hbm", "achieved": round(ach, 1),
+        roof = {"kernel": f"{kname}, SN1 stage, C=256, k={args.k}; launch duration with one batch in flight (the kernel alone on the chip)",
+                "bound": "hbm", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_us": kern[key]["avg_us"],
                 "numerator": "split form: P row + Q row + out row + uint16 indices (2 k bytes) per point (the bytes this kernel reads and "
@@ -822,6 +827,9 @@ def main():
                              "1616 B/pt (x2 row, int32 indices, x3 row)",
                 "frac_direct_form": round(alg_direct / t_s / 1e9 / HBM_PEAK_GBS, 4),
                 "direct_form_bytes_per_launch": alg_direct}
+        if args.in_flight > 1:
+            roof["beside_another_batch"] = ("inside the headline's timed region (two batches in flight) the same launch shares the chip: "
+                                            "rocprofv3 of this command averages 105 us = 0.49 (profiles/r06_eval10_train10_kernel_stats.csv)")
         # the SN1 stage as a whole: projection GEMM + K-agg for the stage's own inputs/outputs (x2 in, indices, x3 out)
         pk = next((k_ for k_ in kern if k_.startswith("gemm") and k_.endswith(f"[{pts}x512x128]")), None)
         if pk is not None:

@@ -1,6 +1,7 @@
 # a round's profile set (on the GPU box): bash tools/prof_round.sh <tag, e.g. r06>   -> gpurun_out/<tag>prof (summaries are copied to profiles/<tag>_* by hand)
 #  * K-agg HBM traffic by PMC for configs[1] and configs[4] (tools/kagg_pmc.py -> profiles/kagg_pmc.json)
-#  * rocprofv3 --kernel-trace --stats of the default bench (eval + both train legs), of the configs[4] stress step and of the bf16 train step
+#  * rocprofv3 --kernel-trace --stats of the default bench (eval with two batches in flight + both train legs), of the same eval loop with one
+#    batch in flight, of the configs[4] stress step and of the bf16 train step
 #  * PMC passes (separate runs, --kernel-trace only) over the configs[4] eval step and over one bf16 train step:
 #    SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / SQ_WAVE_CYCLES / SQ_WAIT_*, SQ_LDS_*, FETCH_SIZE, WRITE_SIZE
 TAG=${1:-r06}
@@ -10,6 +11,9 @@ cp profiles/kagg_pmc.json $O/kagg_pmc.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench_under_rocprof.json 2> $O/stats.err
 find $O/stats -name "*kernel_stats*" -exec cp {} $O/${TAG}_eval10_train10_kernel_stats.csv \;
+# the same eval loop with ONE batch in flight (no train legs): every kernel alone on the chip -- the durations the roofline fractions are quoted on
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o one -- python3 $R/bench.py --steps 10 --warmup 3 --in-flight 1 --no-train --no-cpu-baseline --no-secondary > $O/bench_one_in_flight_under_rocprof.json 2> $O/stats1.err
+find $O/stats1 -name "*kernel_stats*" -exec cp {} $O/${TAG}_eval10_one_in_flight_kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats5 -o c5 -- python3 $R/bench.py --batch 64 --points 16384 --k 64 --steps 5 --warmup 2 --no-train --no-cpu-baseline --no-secondary > $O/cfg5_under_rocprof.json 2> $O/stats5.err
 find $O/stats5 -name "*kernel_stats*" -exec cp {} $O/${TAG}_cfg5_kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/statst -o tb -- python3 $R/tools/train_kernels.py bf16 8 > /dev/null 2> $O/statst.err
