@@ -1754,7 +1754,8 @@ static long long gemm_tn_splits(long long M, int KA, int KB, int batch, bool a_b
     }
     long long tiles = (long long)(KA / 128) * ((KB + 127) / 128) * batch;
     long long splits = 1;
-    while (tiles * splits * 2 <= 1024 && M / (splits * 2) >= 1024) splits *= 2;
+    static const int cap = lpd_debug("tn-blocks", 512);      // one resident round of blocks (2 per CU): half the slab traffic of 1024 (eval pooling 147 -> 138 us)
+    while (tiles * splits * 2 <= cap && M / (splits * 2) >= 1024) splits *= 2;
     return splits;
 }
 
