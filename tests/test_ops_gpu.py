@@ -1682,3 +1682,40 @@ def test_bf16_point_feature_copy_operators(cuda):
     assert _rel(dW, y16.double().t() @ cat16.double()) < 2e-6
     with pytest.raises(Exception):
         ops.gemm_tn(y16[:, :128].contiguous(), cat16[:, :128].contiguous())      # KA = 128: not built
+
+
+@pytest.mark.gpu
+def test_affine_act_bf16_only_output(cuda):
+    """lpd_affine_act2 with a NULL fp32 destination (round 6: x1 and x3 of the bf16 training mode leave as bf16 rows only): the bf16 rows
+    are the ones the two-output form writes, bit for bit, and nothing else is touched."""
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(4096, 128, generator=g).to(cuda)
+    sc, sh = (torch.rand(128, generator=g) + 0.5).to(cuda), torch.randn(128, generator=g).to(cuda)
+    both32 = torch.empty_like(X)
+    wide = torch.zeros(4096, 512, dtype=torch.bfloat16, device=cuda)          # a column slice of a wider bf16 tensor, as in the trunk
+    ops.affine_act(X, sc, sh, ops.ACT_LEAKY, 0.01, out=both32, out16=wide[:, 128:256])
+    only = torch.full((4096, 512), 7.0, dtype=torch.bfloat16, device=cuda)
+    r = ops.affine_act(X, sc, sh, ops.ACT_LEAKY, 0.01, out16=only[:, 128:256], only16=True)
+    torch.cuda.synchronize()
+    assert r.data_ptr() == only[:, 128:256].data_ptr()
+    assert torch.equal(only[:, 128:256], wide[:, 128:256])
+    assert (only[:, :128] == 7.0).all() and (only[:, 256:] == 7.0).all()
+    assert torch.equal(wide[:, 128:256], both32.bfloat16())
+    with pytest.raises(ValueError):
+        ops.affine_act(X, sc, sh, ops.ACT_LEAKY, 0.01, only16=True)
+
+
+@pytest.mark.gpu
+def test_batch_pipelines_of_a_thread_share_their_streams(cuda):
+    """harness.BatchPipeline takes its streams from one ring per (device, depth, host thread): a pipeline per call (PointNetVlad.forward
+    makes one for every eval batch above 32 clouds) must not meet the caching allocator with fresh, empty per-stream pools each time."""
+    import threading
+    from lpdnet_hip import harness
+    lin = torch.nn.Linear(4, 4).to(cuda)
+    a, b = harness.BatchPipeline(lin, 2, cuda), harness.BatchPipeline(lin, 2, cuda)
+    assert [s.cuda_stream for s in a.streams] == [s.cuda_stream for s in b.streams] and len(a.streams) == 2
+    assert harness.BatchPipeline(lin, 1, cuda).streams == []
+    other = []
+    t = threading.Thread(target=lambda: other.append([s.cuda_stream for s in harness.BatchPipeline(lin, 2, cuda).streams]))
+    t.start(); t.join()
+    assert other and other[0] != [s.cuda_stream for s in a.streams]          # another host thread: its own ring

@@ -733,7 +733,8 @@ def test_standalone_train_mode_forwards_of_the_submodules(cuda):
                                  {"LPD_DEBUG": "no-edge-mlp-train-bwd,no-assign-act"},       # ... its backward on the round-3 chain, bn3 as its own pass
                                  {"LPD_DEBUG": "no-z-bf16"},
                                  {"LPD_DEBUG": "no-map-bf16,no-tn-tr,no-dw-sel-tr"},  # fp32 conv3 map in the bf16 mode, register-transposing dW
-                                 {"LPD_DEBUG": "no-split-bwd-bf16,no-feat-in-loader,no-x3w-batched,no-edge-noz,no-cat-bf16,no-pq3-bf16"}],
+                                 {"LPD_DEBUG": "no-split-bwd-bf16,no-feat-in-loader,no-x3w-batched,no-edge-noz,no-cat-bf16,no-pq3-bf16"},
+                                 {"LPD_DEBUG": "reduce-grid=4096,x3t-rb=128,tn-blocks=1024"}],     # round 5's launch shapes of the reductions / map gradient / A^T B
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_training_switches_are_live(env):
     """The training-path switches README.md documents are read at import (or at the first launch): the bf16-storage oracle
