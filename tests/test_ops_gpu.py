@@ -1688,6 +1688,7 @@ def test_bf16_point_feature_copy_operators(cuda):
 def test_affine_act_bf16_only_output(cuda):
     """lpd_affine_act2 with a NULL fp32 destination (round 6: x1 and x3 of the bf16 training mode leave as bf16 rows only): the bf16 rows
     are the ones the two-output form writes, bit for bit, and nothing else is touched."""
+    from lpdnet_hip import ops
     g = torch.Generator().manual_seed(5)
     X = torch.randn(4096, 128, generator=g).to(cuda)
     sc, sh = (torch.rand(128, generator=g) + 0.5).to(cuda), torch.randn(128, generator=g).to(cuda)
