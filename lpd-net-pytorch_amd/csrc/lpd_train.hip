@@ -1265,7 +1265,9 @@ extern "C" int lpd_bn_act_bwd_bf16(const void* dY, long long lddy, const void* X
         LPD_CHECK_LAUNCH("lpd_bn_act_bwd_bf16(reduce)");
         if (int rc = lpd_stat_finish(ws, dbeta + c0, dgamma + c0, w, ST(stream))) return rc;
     }
-    hipLaunchKernelGGL(act == 3 ? bn_act_bwd_apply16_kernel<true> : bn_act_bwd_apply16_kernel<false>, dim3(grid_for(R * (C / 8), 256 * 4)), dim3(256), 0, ST(stream), reinterpret_cast<const uint16_t*>(dY),
+    // (the apply pass keeps eight 16-byte loads open per thread: three blocks per CU stream better than sixteen -- 4096 / 768 / 512 blocks:
+    //  the two passes 448 / 393 / 391 us; the one-load-per-trip kernels of this file, lpd_affine_act among them, want the large grids)
+    hipLaunchKernelGGL(act == 3 ? bn_act_bwd_apply16_kernel<true> : bn_act_bwd_apply16_kernel<false>, dim3(lpd_reduce_grid(grid_for(R * (C / 8), 256 * 4))), dim3(256), 0, ST(stream), reinterpret_cast<const uint16_t*>(dY),
                        lddy, reinterpret_cast<const uint16_t*>(X), ldx, reinterpret_cast<uint16_t*>(dX), lddx, R, C, scale, shift, mean, invstd, dbeta,
                        dgamma, (double)R, act, slope, has_bn);
     LPD_CHECK_LAUNCH("lpd_bn_act_bwd_bf16(apply)");
