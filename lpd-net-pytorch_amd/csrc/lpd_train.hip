@@ -232,11 +232,7 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dY, long long 
         }
     };
     load_consts();
-    for (; e < total; e += stride) {
-        const long long r = e / Q;
-        if (!fixed_q) { q = (int)(e - r * Q); load_consts(); }
-        const float4 xv = *reinterpret_cast<const float4*>(X + r * ldx + q * 4);
-        const float4 gv = *reinterpret_cast<const float4*>(dY + r * lddy + q * 4);
+    auto one = [&](const float4& xv, const float4& gv, long long r) {
         const float x[4] = {xv.x, xv.y, xv.z, xv.w};
         const float g[4] = {gv.x, gv.y, gv.z, gv.w};
         float o[4];
@@ -246,6 +242,27 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dY, long long 
             o[c] = has_bn ? sc[c] * (dpre - mb[c] - (x[c] - mu[c]) * is[c] * mg[c]) : dpre;
         }
         *reinterpret_cast<float4*>(dX + r * lddx + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    };
+    if (fixed_q) {      // four rows per trip (eight 16-byte loads open per thread), launched at <= 768 blocks: see lpd_bn_act_bwd_bf16
+        for (; e < total; e += 4 * stride) {
+            float4 xv[4], gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long r = (e + u * stride < total ? e + u * stride : e) / Q;
+                xv[u] = *reinterpret_cast<const float4*>(X + r * ldx + q * 4);
+                gv[u] = *reinterpret_cast<const float4*>(dY + r * lddy + q * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e + u * stride < total) one(xv[u], gv[u], (e + u * stride) / Q);
+        }
+        return;
+    }
+    for (; e < total; e += stride) {
+        const long long r = e / Q;
+        q = (int)(e - r * Q);
+        load_consts();
+        one(*reinterpret_cast<const float4*>(X + r * ldx + q * 4), *reinterpret_cast<const float4*>(dY + r * lddy + q * 4), r);
     }
 }
 
@@ -1235,7 +1252,7 @@ extern "C" int lpd_bn_act_bwd(const float* dY, long long lddy, const float* X, l
                        dY, lddy, X, ldx, R, C, scale, shift, has_bn ? mean : nullptr, has_bn ? invstd : nullptr, act, slope, ws.sum(), ws.sumsq());
     LPD_CHECK_LAUNCH("lpd_bn_act_bwd(reduce)");
     if (int rc = lpd_stat_finish(ws, dbeta, dgamma, C, ST(stream))) return rc;
-    hipLaunchKernelGGL(act == 3 ? bn_act_bwd_apply_kernel<true> : bn_act_bwd_apply_kernel<false>, dim3(grid_for(R * (C / 4), 256 * 4)), dim3(256), 0, ST(stream), dY, lddy, X,
+    hipLaunchKernelGGL(act == 3 ? bn_act_bwd_apply_kernel<true> : bn_act_bwd_apply_kernel<false>, dim3(lpd_reduce_grid(grid_for(R * (C / 4), 256 * 4))), dim3(256), 0, ST(stream), dY, lddy, X,
                        ldx, dX, lddx, R, C, scale, shift, mean, invstd, dbeta, dgamma, (double)R, act, slope, has_bn);
     LPD_CHECK_LAUNCH("lpd_bn_act_bwd(apply)");
     return LPD_OK;
