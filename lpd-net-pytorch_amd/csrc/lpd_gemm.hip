@@ -660,6 +660,8 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
     //              x 32 B = 4 KiB contiguous per instruction)
     float4 ra[2][NF4];
     float4 rsc[2], rsh[2];      // a_scale / a_shift quad of the chunk in flight (row-major staging: a thread's k quad is f % QR for every e)
+    float4 rsc8[2], rsh8[2];    // ... the second quad of a bf16 piece (eight channels per thread)
+    constexpr int QR8 = KC / 8, NF8 = NF4 / 2;      // bf16 rows: 16-byte pieces per row of the chunk, pieces per thread
     int rk0[2] = {0, 0};
     const float* a_base;        // loop-invariant part of this thread's A addresses
     {
@@ -673,9 +675,29 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
         if constexpr (!(PANELS & 1)) {
             if (A16T || (!A16P && g.a_scale)) {      // uniform
                 rk0[set] = k0;
-                rsc[set] = ld4_guard(g.a_scale, k0 + (tid % QR) * 4, g.K);
-                rsh[set] = ld4_guard(g.a_shift, k0 + (tid % QR) * 4, g.K);
+                if constexpr (A16) {      // (bf16 rows: a thread's piece is EIGHT channels, k0 + (tid % QR8) * 8 .. + 7; K % 32 == 0)
+                    rsc[set] = *reinterpret_cast<const float4*>(g.a_scale + k0 + (tid % QR8) * 8);
+                    rsh[set] = *reinterpret_cast<const float4*>(g.a_shift + k0 + (tid % QR8) * 8);
+                    rsc8[set] = *reinterpret_cast<const float4*>(g.a_scale + k0 + (tid % QR8) * 8 + 4);
+                    rsh8[set] = *reinterpret_cast<const float4*>(g.a_shift + k0 + (tid % QR8) * 8 + 4);
+                } else {
+                    rsc[set] = ld4_guard(g.a_scale, k0 + (tid % QR) * 4, g.K);
+                    rsh[set] = ld4_guard(g.a_shift, k0 + (tid % QR) * 4, g.K);
+                }
             }
+        }
+        if constexpr (A16) {
+            // bf16 rows (round 6): one 16-byte piece = eight channels per load (8-byte pieces before: twice the load instructions for the
+            // same bytes); register e holds row (e * 256 + tid) / QR8, piece (e * 256 + tid) % QR8 as raw bits
+#pragma unroll
+            for (int e = 0; e < NF8; ++e) {
+                const int f = e * GEMM_THREADS + tid;
+                int row = m0 + f / QR8;
+                row = row < g.M ? row : g.M - 1;
+                const uint4 w = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a_base) + (long long)row * g.lda + k0 + (f % QR8) * 8);
+                r[e] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+            }
+            return;
         }
 #pragma unroll
         for (int e = 0; e < NF4; ++e) {
@@ -687,10 +709,7 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
                 const int f = e * GEMM_THREADS + tid;
                 int row = m0 + f / QR;
                 row = row < g.M ? row : g.M - 1;
-                if constexpr (A16) {      // four bf16 values as raw bits in .x / .y
-                    const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a_base) + (long long)row * g.lda + k0 + (f % QR) * 4);
-                    r[e] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), 0.0f, 0.0f);
-                } else if constexpr (KTAIL) r[e] = ld4_guard(a_base + (long long)row * g.lda, k0 + (f % QR) * 4, g.K);
+                if constexpr (KTAIL) r[e] = ld4_guard(a_base + (long long)row * g.lda, k0 + (f % QR) * 4, g.K);
                 else r[e] = *reinterpret_cast<const float4*>(a_base + (long long)row * g.lda + k0 + (f % QR) * 4);
             }
         }
@@ -698,6 +717,53 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 4 : 2) void gemm_x3w_wide_kern
     auto store_a = [&](int buf, const float4 (&r)[NF4], int set) {
         __bf16* hi_img = smem16 + buf * 2 * X3V_IMG;
         __bf16* lo_img = hi_img + X3V_IMG;
+        if constexpr (A16) {
+#pragma unroll
+            for (int e = 0; e < NF8; ++e) {
+                const int f = e * GEMM_THREADS + tid;
+                const int rr = f / QR8, k8 = f % QR8;
+                const unsigned w[4] = {__float_as_uint(r[e].x), __float_as_uint(r[e].y), __float_as_uint(r[e].z), __float_as_uint(r[e].w)};
+                if constexpr (A16P) {      // the rows ARE the hi image
+                    *reinterpret_cast<uint4*>(hi_img + rr * X3V_LDK + k8 * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+                    continue;
+                }
+                // behind an operand transform: widened, transformed (multiply, then add -- not fused: the bits of lpd_affine_act), stored
+                const float scv[8] = {rsc[set].x, rsc[set].y, rsc[set].z, rsc[set].w, rsc8[set].x, rsc8[set].y, rsc8[set].z, rsc8[set].w};
+                const float shv[8] = {rsh[set].x, rsh[set].y, rsh[set].z, rsh[set].w, rsh8[set].x, rsh8[set].y, rsh8[set].z, rsh8[set].w};
+                float v[8];
+#pragma unroll
+                for (int p2 = 0; p2 < 4; ++p2) { v[2 * p2] = __uint_as_float(w[p2] << 16); v[2 * p2 + 1] = __uint_as_float(w[p2] & 0xffff0000u); }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    v[c] = scv[c] * v[c] + shv[c];
+                    v[c] = fmaxf(v[c], 0.0f) + g.a_ns * fminf(v[c], 0.0f);
+                }
+                const int m = m0 + rr, kk = rk0[set] + k8 * 8;
+                const bool put = g.a_out && m < g.M;
+                if (g.a_out_bf16) {
+                    // the transformed map IS a bf16 tensor (stored here, or re-formed by every consumer's loader): the product takes the
+                    // rounded values, so that all of them see the same map; they ARE the hi image, the lo image is never read (prods = 2)
+                    bf16x8 ob;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) ob[c] = (__bf16)v[c];
+                    if (put) *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(g.a_out) + (long long)m * g.a_ld + kk) = ob;
+                    *reinterpret_cast<bf16x8*>(hi_img + rr * X3V_LDK + k8 * 8) = ob;
+                    continue;
+                }
+                if (put) {
+                    *reinterpret_cast<float4*>(g.a_out + (long long)m * g.a_ld + kk) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(g.a_out + (long long)m * g.a_ld + kk + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                bf16x4 hh, ll;
+                split4(v[0], v[1], v[2], v[3], hh, ll);
+                *reinterpret_cast<bf16x4*>(hi_img + rr * X3V_LDK + k8 * 8) = hh;
+                *reinterpret_cast<bf16x4*>(lo_img + rr * X3V_LDK + k8 * 8) = ll;
+                split4(v[4], v[5], v[6], v[7], hh, ll);
+                *reinterpret_cast<bf16x4*>(hi_img + rr * X3V_LDK + k8 * 8 + 4) = hh;
+                *reinterpret_cast<bf16x4*>(lo_img + rr * X3V_LDK + k8 * 8 + 4) = ll;
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < NF4; ++e) {
             int rr, k4;
