@@ -557,6 +557,7 @@ struct EdgeMlpArgs {
                           // out_lo elements behind it; out_cloud counts bf16 elements
     void* x1_hi;          // != null (split planes only): ALSO x1 = max over k of the stage-1 activation (util/lpdnet_model.py:249-250), as
                           // a second pair of planes with the layout of `out` (same cloud stride, panel rows and lo offset)
+    int tiles_per_block = 1;   // edge_mlp_x3_kernel: consecutive point tiles a block walks with its weight fragments in registers
 };
 
 // m = m0 + (row inside the block); a block's 64 points lie in one cloud when the output is in cloud-panel form
@@ -819,7 +820,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
     const int col = lane & 31;
     const int ntile = CO == 128 ? wave : (wave >> 1);       // output-column tile of this wave
     const int ptile = CO == 128 ? 0 : (wave & 1);           // first point tile of this wave
-    const int m0 = lpd_xcd_remap(blockIdx.x, gridDim.x) * PTS;
+    const int tile0 = lpd_xcd_remap(blockIdx.x, gridDim.x) * g.tiles_per_block;      // consecutive tiles: one cloud, one XCD
 
     // W2 fragments of this wave's column n = ntile*32 + col: k = 16 s + 8 h .. +7, sign-adjusted, split
     const int n = ntile * 32 + col;
@@ -837,6 +838,11 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
         for (int e = 0; e < 4; ++e) { b_hi[s][e] = h0[e]; b_hi[s][4 + e] = h1[e]; b_lo[s][e] = l0[e]; b_lo[s][4 + e] = l1[e]; }
     }
 
+    // Round 6: a block walks `tiles_per_block` consecutive tiles with its W2 fragments in registers (one tile per block re-read and
+    // re-split the 64-KiB weight in front of every 32-point tile: 4096 times per launch at 32 clouds)
+    for (int rep = 0; rep < g.tiles_per_block; ++rep) {
+    const int m0 = (tile0 + rep) * PTS;
+    if (m0 >= g.M) break;      // uniform
     for (int f = tid; f < PTS * g.k; f += EM_THREADS) {
         int p = f / g.k, t = f - p * g.k;
         int m = m0 + p;
@@ -976,6 +982,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_x3_kernel(EdgeMlpArgs 
                           ((size_t)(n >> 3) * g.panel_ld + ((size_t)m - b * g.N)) * 8 + ((n & 7) & ~1);
             *reinterpret_cast<unsigned*>(dst) = word;
         }
+    }      // tiles of this block
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1210,6 +1217,7 @@ struct EdgeMlpBwdArgs {
     int M, k, act;
     float slope, inv_ns;
     const uint16_t* Kb; const float* cvec;                      // NOZ: K as bf16 [n][m], constants [128] (edge_mlp_bwd_prep_kernel)
+    int tiles_per_block = 1;
 };
 
 constexpr int EB_PTS = 32;
@@ -1256,7 +1264,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
     constexpr int RPP = EM_THREADS / (CM / 4), PASSES = EB_PTS / RPP;      // 8 rows per pass, 4 passes
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];       // [2 buffers][hi (| lo) (| Y1e hi)][32][LDK]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
-    const int m0 = lpd_xcd_remap(blockIdx.x, gridDim.x) * EB_PTS;         // M % 32 == 0 (host check)
+    const int tile0 = lpd_xcd_remap(blockIdx.x, gridDim.x) * g.tiles_per_block;      // consecutive 32-point tiles; M % 32 == 0 (host check)
     const int n = wave * 32 + col;                                        // this lane's column of dY1e / G
     const double count = (double)g.M * (double)g.k;
     // NOZ: K into LDS ([n][m] bf16, 16-byte pieces), this column's constant
@@ -1296,6 +1304,14 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
         a1[c] = NOZ ? 0.0f : -g.invstd2[ch] * m2;
         a0[c] = NOZ ? 0.0f : g.mean2[ch] * g.invstd2[ch] * m2 - m1;
     }
+    const float beta1 = g.beta1[n], rg1 = g.rgamma1[n];
+    const float ns = lpd_neg_slope(g.act, g.slope);
+    float sg = 0.0f, sgx = 0.0f;
+    // Round 6: a block walks `tiles_per_block` consecutive tiles with its weight fragments in registers, the K image in LDS and its two
+    // reduction sums in registers: the 34-KiB K image, the 64-KiB weight and the atomics once per block instead of once per 32 points
+    for (int rep = 0; rep < g.tiles_per_block; ++rep) {
+    const int m0 = (tile0 + rep) * EB_PTS;
+    if (m0 >= g.M) break;      // uniform
     float dp2[PASSES][4];
     uint32_t ar2[PASSES];
 #pragma unroll
@@ -1335,8 +1351,6 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
         dx1v[r] = g.dx1[m * g.lddx1 + n];
         ar1[r >> 2] |= (uint32_t)g.arg1[m * CM + n] << (8 * (r & 3));
     }
-    const float beta1 = g.beta1[n], rg1 = g.rgamma1[n];
-    const float ns = lpd_neg_slope(g.act, g.slope);
 
     typedef unsigned zraw_t __attribute__((ext_vector_type((NOZ ? BF16 : ZBF16) ? 2 : 4)));
     zraw_t zr[PASSES];          // the builder's rows of Z -- NOZ: of Y1e
@@ -1407,7 +1421,6 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
     float gsum[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) gsum[r] = 0.0f;
-    float sg = 0.0f, sgx = 0.0f;
 
     load_z(0);
     build(0, 0);
@@ -1465,6 +1478,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) g.gsum[(size_t)(m0 + (r & 3) + 8 * (r >> 2) + 4 * h) * CM + n] = gsum[r];
+    }      // tiles of this block
     sg += __shfl_xor(sg, 32);
     sgx += __shfl_xor(sgx, 32);
     sgx = (sgx - beta1 * sg) * rg1;      // sum G xhat1 = (sum G pre1 - beta1 sum G) / gamma1
@@ -1472,6 +1486,15 @@ __global__ __launch_bounds__(EM_THREADS, 2) void edge_mlp_train_bwd_kernel(EdgeM
         atomicAdd(&g.sum[lpd_stat_rofs() + n], (double)sg);
         atomicAdd(&g.sumx[lpd_stat_rofs() + n], (double)sgx);
     }
+}
+
+// tiles a block of the fused edge-MLP kernels walks: the smallest count that lets ONE resident round of blocks (two per CU = 512) cover
+// the launch (a second, part-filled round costs a whole block time), at most 16; small launches keep one tile per block
+inline int em_tiles_per_block(int tiles)
+{
+    static const int tmax = lpd_debug("edge-mlp-tiles", 16);
+    const int t = (tiles + 511) / 512;
+    return t < 1 ? 1 : (t > tmax ? tmax : t);
 }
 
 template <int CM, int CO>
@@ -1484,7 +1507,12 @@ int edge_mlp_x3_launch(const EdgeMlpArgs& g, hipStream_t stream)
             const size_t lds = (size_t)4 * Cfg::IMG * sizeof(__bf16) + (size_t)PTS * g.k * sizeof(int);
             auto kern = edge_mlp_x3_kernel<CM, CO, PTS, true>;
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3((g.M + PTS - 1) / PTS), dim3(EM_THREADS), lds, stream, g);
+            // one resident round of blocks (two per CU) where the launch is large enough: 32 clouds = 4096 tiles = 512 blocks of 8 tiles
+            // (1 / 2 / 4 / 8 tiles per block: 304 / 292 / 285 / 281 us); small launches keep one tile per block
+            const int tiles = (g.M + PTS - 1) / PTS;
+            EdgeMlpArgs g2 = g;
+            g2.tiles_per_block = em_tiles_per_block(tiles);
+            hipLaunchKernelGGL(kern, dim3((tiles + g2.tiles_per_block - 1) / g2.tiles_per_block), dim3(EM_THREADS), lds, stream, g2);
             LPD_CHECK_LAUNCH("lpd_edge_mlp(bf16x3 + x1)");
             return LPD_OK;
         }
@@ -1697,6 +1725,8 @@ extern "C" int lpd_edge_mlp_train(const float* P, int ldp, const float* Q, int l
     using Cfg = EdgeMlpX3Cfg<128, 128>;
     const size_t lds = (size_t)(bf16 ? 2 : 4) * Cfg::IMG * sizeof(__bf16) + (size_t)EM_PTS * k * sizeof(int);
     LPD_CHECK_ARG(!bf16 || z_bf16, "lpd_edge_mlp_train: bf16 Y1e goes with bf16 Z");
+    // (one 64-point tile per block: the tile loop that pays in the eval kernel and in the backward costs this kernel 25 more spilled
+    //  registers -- 444 -> 496 us)
     auto launch = [&](auto kern) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(M / EM_PTS), dim3(EM_THREADS), lds, stream, g);
@@ -1731,6 +1761,9 @@ extern "C" int lpd_edge_mlp_train_bwd(const void* Z, const uint8_t* arg2, const 
     LPD_CHECK_STAT_COLS("lpd_edge_mlp_train_bwd", 128);
     EdgeMlpBwdArgs g{Z, arg2, dpre2, W2, scale2, mean2, invstd2, dbeta2, dgamma2, Y1e, arg1, dx1, lddx1, beta1, rgamma1, G, gsum,
                      ws.sum(), ws.sumsq(), M, k, act, slope, inv_ns, reinterpret_cast<const uint16_t*>(kws), kws ? kws + 128 * 128 : nullptr};
+    const int tiles = M / EB_PTS;
+    g.tiles_per_block = em_tiles_per_block(tiles);
+    const dim3 grid((tiles + g.tiles_per_block - 1) / g.tiles_per_block);
     if (!Z) {
         LPD_CHECK_ARG(bf16, "lpd_edge_mlp_train_bwd: the form without Z is built for bf16 storage");
         LPD_CHECK_ARG(((uintptr_t)kws & 15) == 0, "lpd_edge_mlp_train_bwd: kws must be 16-byte aligned");
@@ -1739,15 +1772,15 @@ extern "C" int lpd_edge_mlp_train_bwd(const void* Z, const uint8_t* arg2, const 
         LPD_CHECK_LAUNCH("lpd_edge_mlp_train_bwd(prep)");
         const size_t lds_n = ((size_t)2 * 2 * EB_PTS + 128) * (128 + 8) * sizeof(__bf16);      // two buffers of (dZ hi | Y1e hi) + the K image
         (void)hipFuncSetAttribute((const void*)edge_mlp_train_bwd_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n);
-        hipLaunchKernelGGL((edge_mlp_train_bwd_kernel<true, true, true>), dim3(M / EB_PTS), dim3(EM_THREADS), lds_n, stream, g);
+        hipLaunchKernelGGL((edge_mlp_train_bwd_kernel<true, true, true>), grid, dim3(EM_THREADS), lds_n, stream, g);
         LPD_CHECK_LAUNCH("lpd_edge_mlp_train_bwd(noz)");
         return lpd_stat_finish(ws, dbeta1, dgamma1, 128, stream);
     }
     const size_t lds = (size_t)(bf16 ? 2 : 4) * EB_PTS * (128 + 8) * sizeof(__bf16);
     LPD_CHECK_ARG(!bf16 || z_bf16, "lpd_edge_mlp_train_bwd: bf16 Y1e goes with bf16 Z");
-    if (bf16) hipLaunchKernelGGL((edge_mlp_train_bwd_kernel<true, true>), dim3(M / EB_PTS), dim3(EM_THREADS), lds, stream, g);
-    else if (z_bf16) hipLaunchKernelGGL((edge_mlp_train_bwd_kernel<false, true>), dim3(M / EB_PTS), dim3(EM_THREADS), lds, stream, g);
-    else hipLaunchKernelGGL((edge_mlp_train_bwd_kernel<false, false>), dim3(M / EB_PTS), dim3(EM_THREADS), lds, stream, g);
+    if (bf16) hipLaunchKernelGGL((edge_mlp_train_bwd_kernel<true, true>), grid, dim3(EM_THREADS), lds, stream, g);
+    else if (z_bf16) hipLaunchKernelGGL((edge_mlp_train_bwd_kernel<false, true>), grid, dim3(EM_THREADS), lds, stream, g);
+    else hipLaunchKernelGGL((edge_mlp_train_bwd_kernel<false, false>), grid, dim3(EM_THREADS), lds, stream, g);
     LPD_CHECK_LAUNCH("lpd_edge_mlp_train_bwd");
     return lpd_stat_finish(ws, dbeta1, dgamma1, 128, stream);
 }
