@@ -1521,8 +1521,11 @@ int edge_mlp_x3_launch(const EdgeMlpArgs& g, hipStream_t stream)
     size_t lds = (size_t)4 * Cfg::IMG * sizeof(__bf16) + (size_t)EM_PTS * g.k * sizeof(int);
     auto kern = edge_mlp_x3_kernel<CM, CO>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid((g.M + EM_PTS - 1) / EM_PTS);
-    hipLaunchKernelGGL(kern, grid, dim3(EM_THREADS), lds, stream, g);
+    const int tiles = (g.M + EM_PTS - 1) / EM_PTS;
+    EdgeMlpArgs g2 = g;
+    g2.tiles_per_block = em_tiles_per_block(tiles);
+    dim3 grid((tiles + g2.tiles_per_block - 1) / g2.tiles_per_block);
+    hipLaunchKernelGGL(kern, grid, dim3(EM_THREADS), lds, stream, g2);
     LPD_CHECK_LAUNCH("lpd_edge_mlp(bf16x3)");
     return LPD_OK;
 }
